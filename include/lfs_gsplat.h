@@ -1,0 +1,194 @@
+/* lfs_gsplat.h — C ABI of the MI355X-native (gfx950) 3DGS training rasterizer.
+ *
+ * Drop-in boundary for the reference's native operator backend
+ * (MrNeRF/LichtFeld-Studio): every entry point below replaces one function of
+ * /root/reference/gsplat/Ops.h (namespace gsplat::) or of
+ * /root/reference/fastgs/optimizer/include/adam.h, with the at::Tensor
+ * arguments flattened to raw DEVICE pointers + sizes + a hipStream_t.
+ * The libtorch wrappers that restore the exact Ops.h signatures live in
+ * include/gsplat/Ops.h + lichtfeld-studio_amd/csrc/torch_ops.cpp.
+ *
+ * Conventions (same as the reference):
+ *   - all pointers are device pointers, contiguous, fp32 unless noted;
+ *   - quaternions are (w,x,y,z) and need not be normalised;
+ *   - viewmats are row-major world->camera [C,4,4]; Ks row-major [C,3,3];
+ *   - scales / opacities are the ACTIVATED values (exp / sigmoid applied);
+ *   - every function enqueues on `stream` and returns without synchronising;
+ *   - return value: 0 on success, a hipError_t (>0) from the runtime, or a
+ *     negative LFS_E_* code for argument errors. Nothing is launched on error.
+ *   - "workspace" buffers are caller-owned scratch (size from the matching
+ *     *_workspace_bytes function, 256-byte aligned); contents are undefined
+ *     afterwards unless stated.
+ */
+#ifndef LFS_GSPLAT_H
+#define LFS_GSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFS_API __attribute__((visibility("default")))
+
+typedef void* lfs_stream_t; /* hipStream_t */
+
+enum { LFS_OK = 0, LFS_E_INVALID = -1, LFS_E_UNSUPPORTED = -2, LFS_E_WORKSPACE = -3 };
+
+/* gsplat/Common.h:46-50 */
+enum { LFS_CAMERA_PINHOLE = 0, LFS_CAMERA_ORTHO = 1, LFS_CAMERA_FISHEYE = 2 };
+/* gsplat/Cameras.h:16-22 */
+enum {
+    LFS_SHUTTER_ROLLING_TOP_TO_BOTTOM = 0,
+    LFS_SHUTTER_ROLLING_LEFT_TO_RIGHT = 1,
+    LFS_SHUTTER_ROLLING_BOTTOM_TO_TOP = 2,
+    LFS_SHUTTER_ROLLING_RIGHT_TO_LEFT = 3,
+    LFS_SHUTTER_GLOBAL = 4
+};
+
+/* gsplat/Cameras.h:27-61 UnscentedTransformParameters */
+typedef struct lfs_ut_params {
+    float alpha;                       /* 0.1 */
+    float beta;                        /* 2   */
+    float kappa;                       /* 0   */
+    float in_image_margin_factor;      /* 0.1 */
+    int32_t require_all_sigma_points_valid; /* 1 */
+} lfs_ut_params;
+
+/* The camera block every projection / rasterization entry point of Ops.h
+ * takes (viewmats0, viewmats1, Ks, camera_model, rs_type, radial/tangential/
+ * thin-prism coefficients, image size). n_radial / n_thin_prism say how many
+ * coefficients per camera the tensors really hold (missing ones are 0; the
+ * reference reads 6 / 4 unconditionally). */
+typedef struct lfs_cameras {
+    uint32_t C;
+    uint32_t image_width, image_height;
+    int32_t camera_model;              /* LFS_CAMERA_* */
+    int32_t rs_type;                   /* LFS_SHUTTER_* */
+    const float* viewmats0;            /* [C,4,4] */
+    const float* viewmats1;            /* [C,4,4] or NULL */
+    const float* Ks;                   /* [C,3,3] */
+    const float* radial_coeffs;        /* [C,n_radial] or NULL */
+    int32_t n_radial;
+    const float* tangential_coeffs;    /* [C,2] or NULL */
+    const float* thin_prism_coeffs;    /* [C,n_thin_prism] or NULL */
+    int32_t n_thin_prism;
+} lfs_cameras;
+
+/* ---- gsplat::projection_ut_3dgs_fused  (gsplat/Ops.h:66-90, Projection.cpp:22-110,
+ *      ProjectionUT3DGSFused.cu:17-203). radii int32 [C,N,2]; means2d [C,N,2];
+ *      depths [C,N]; conics [C,N,3]; compensations [C,N] or NULL. Entries of culled
+ *      Gaussians: radii = 0, the other outputs are written as 0 (the reference leaves
+ *      them uninitialised). opacities [N] may be NULL. */
+LFS_API int lfs_projection_ut_3dgs_fused(
+    uint32_t N, const float* means, const float* quats, const float* scales, const float* opacities,
+    const lfs_cameras* cams, float eps2d, float near_plane, float far_plane, float radius_clip,
+    const lfs_ut_params* ut_params,
+    int32_t* radii, float* means2d, float* depths, float* conics, float* compensations,
+    lfs_stream_t stream);
+
+/* ---- gsplat::spherical_harmonics_fwd / _bwd (gsplat/Ops.h:12-25, SphericalHarmonics.cpp:15-76,
+ *      SphericalHarmonicsCUDA.cu). n = number of directions, coeffs [n,K,3], masks bool[n] or NULL.
+ *      fwd: colors [n,3]; masked-out rows are written as 0.
+ *      bwd: v_coeffs [n,K,3] is FULLY written (zeros where masked / unused bases: no pre-zeroing
+ *      needed); v_dirs [n,3] or NULL, fully written. */
+LFS_API int lfs_spherical_harmonics_fwd(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* dirs, const float* coeffs, const uint8_t* masks,
+    float* colors, lfs_stream_t stream);
+LFS_API int lfs_spherical_harmonics_bwd(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* dirs, const float* coeffs, const uint8_t* masks,
+    const float* v_colors, float* v_coeffs, float* v_dirs, lfs_stream_t stream);
+
+/* ---- gsplat::intersect_tile (gsplat/Ops.h:27-38, Intersect.cpp:15-122, IntersectTile.cu).
+ *      Two calls with one host read of *n_isects in between (the reference syncs at the same
+ *      place, Intersect.cpp:76). Non-packed layout only: means2d [C,N,2], radii int32 [C,N,2],
+ *      depths [C,N].
+ *   1) lfs_intersect_tile_count: tiles_per_gauss int32 [C,N]; *n_isects (device int64).
+ *   2) lfs_intersect_tile_emit : isect_ids int64 [n_isects], flatten_ids int32 [n_isects];
+ *      sort != 0 -> ordered exactly as a stable ascending sort of isect_ids
+ *      (key = cam << (32+tile_n_bits) | tile << 32 | depth bits). tile_offsets (optional,
+ *      int32 [C*tile_h*tile_w], may be NULL) receives what lfs_intersect_offset would compute,
+ *      for free, when sort != 0. The SAME workspace must be passed to both calls. */
+LFS_API size_t lfs_intersect_tile_workspace_bytes(uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height);
+LFS_API int lfs_intersect_tile_count(
+    uint32_t C, uint32_t N, const float* means2d, const int32_t* radii,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    int32_t* tiles_per_gauss, int64_t* n_isects, void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+LFS_API int lfs_intersect_tile_emit(
+    uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int sort, int64_t n_isects,
+    const int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* tile_offsets,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+
+/* ---- gsplat::intersect_offset (gsplat/Ops.h:39-43, IntersectTile.cu:206-286).
+ *      offsets int32 [C,tile_h,tile_w] from SORTED isect_ids. */
+LFS_API int lfs_intersect_offset(
+    int64_t n_isects, const int64_t* isect_ids, uint32_t C, uint32_t tile_width, uint32_t tile_height,
+    int32_t* offsets, lfs_stream_t stream);
+
+/* ---- gsplat::rasterize_to_pixels_from_world_3dgs_fwd / _bwd (gsplat/Ops.h:92-166,
+ *      Rasterization.cpp, RasterizeToPixelsFromWorld3DGS{Fwd,Bwd}.cu). channels in 1..4.
+ *      colors [C,N,channels], opacities [C,N], backgrounds [C,channels] or NULL,
+ *      masks bool [C,tile_h,tile_w] or NULL, tile_offsets int32 [C,tile_h,tile_w],
+ *      flatten_ids int32 [n_isects] (values in [0, C*N)).
+ *      fwd: render_colors [C,H,W,channels], render_alphas [C,H,W,1], last_ids int32 [C,H,W].
+ *      bwd: v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,channels],
+ *           v_opacities [C,N] — all FULLY written (no pre-zeroing needed). */
+LFS_API size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t channels);
+LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
+    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
+    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
+    const lfs_cameras* cams, uint32_t tile_size, const lfs_ut_params* ut_params,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    float* render_colors, float* render_alphas, int32_t* last_ids,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
+    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
+    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
+    const lfs_cameras* cams, uint32_t tile_size, const lfs_ut_params* ut_params,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    const float* render_alphas, const int32_t* last_ids,
+    const float* v_render_colors, const float* v_render_alphas,
+    float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+
+/* ---- gsplat::quats_to_rotmats (gsplat/Ops.h:45-48, QuatToRotmatCUDA.cu:14-39): rotmats [N,3,3] row-major */
+LFS_API int lfs_quats_to_rotmats(uint32_t N, const float* quats, float* rotmats, lfs_stream_t stream);
+
+/* ---- gsplat::relocation (gsplat/Ops.h:50-57, RelocationCUDA.cu:12-43): ratios int32 [N], binoms [n_max,n_max] */
+LFS_API int lfs_relocation(
+    uint32_t N, const float* opacities, const float* scales, const int32_t* ratios, const float* binoms, int32_t n_max,
+    float* new_opacities, float* new_scales, lfs_stream_t stream);
+
+/* ---- gsplat::add_noise (gsplat/Ops.h:59-65, RelocationCUDA.cu:88-144): means updated in place */
+LFS_API int lfs_add_noise(
+    uint32_t N, const float* raw_opacities, const float* raw_scales, const float* raw_quats, const float* noise,
+    float* means, float current_lr, lfs_stream_t stream);
+
+/* ---- fast_gs::optimizer::adam_step (fastgs/optimizer/include/adam.h:9-20, adam_kernels.cuh:13-36).
+ *      bias_correction1_rcp = 1/(1-beta1^t), bias_correction2_sqrt_rcp = 1/sqrt(1-beta2^t)
+ *      (fused_adam.cpp:78-79). In place on param / exp_avg / exp_avg_sq. Unlike the reference
+ *      (legacy default stream, adam.cu:22) the launch goes to `stream`. */
+LFS_API int lfs_adam_step(
+    float* param, float* exp_avg, float* exp_avg_sq, const float* param_grad, int64_t n_elements,
+    float lr, float beta1, float beta2, float eps, float bias_correction1_rcp, float bias_correction2_sqrt_rcp,
+    lfs_stream_t stream);
+
+/* One launch for several parameter tensors (the 6 Gaussian parameter groups of
+ * FusedAdam::step, fused_adam.cpp:22-95): same arithmetic as lfs_adam_step per tensor. */
+typedef struct lfs_adam_tensor {
+    float* param; float* exp_avg; float* exp_avg_sq; const float* grad;
+    int64_t n_elements;
+    float lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp;
+} lfs_adam_tensor;
+#define LFS_ADAM_MAX_TENSORS 8
+LFS_API int lfs_adam_step_multi(const lfs_adam_tensor* tensors /* host array */, int32_t n_tensors, lfs_stream_t stream);
+
+/* Library identification: returns "lfs_gsplat gfx950 <abi-version>" */
+LFS_API const char* lfs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFS_GSPLAT_H */

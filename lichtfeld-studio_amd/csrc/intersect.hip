@@ -1,0 +1,485 @@
+// K3-K6 — tile intersection, depth ordering and per-tile offsets (replace
+// gsplat::intersect_tile / intersect_offset; reference: gsplat/IntersectTile.cu
+// :24-113 count/emit, :206-252 offsets, :290-342 CUB radix sort of the 64-bit
+// keys; host gsplat/Intersect.cpp:15-137).
+//
+// Integer stage — outputs are BIT-EXACT with the reference given the same
+// (means2d, radii, depths). The reference emits (key,value) pairs Gaussian-major
+// and runs a 6-pass global LSD radix sort over 46 key bits. Here the tile id is
+// never sorted at all:
+//   count   : per-tile intersection counts (LDS histogram per workgroup, one
+//             global atomic per touched (workgroup, tile))          -> totals[T]
+//   scan    : exclusive scan of totals                              -> tile_offsets[T+1]
+//   scatter : every intersection goes straight into its tile's bucket
+//             (LDS ranks + one reserving atomic per (workgroup, tile))
+//   sort    : one workgroup per tile sorts its bucket in LDS on the composite
+//             (depth bits << 32 | flatten id).
+// A flatten id occurs at most once per tile and the reference's emission order
+// inside a tile is ascending flatten id, so "stable sort by (tile, depth)" and
+// "sort by (tile, depth, flatten id)" are the same total order: the result does
+// not depend on the (atomic, unordered) bucket fill. tile_offsets falls out of
+// the scan, so intersect_offset is free on this path.
+#include "lfs_math.cuh"
+#include "../../include/lfs_gsplat.h"
+
+namespace lfs {
+
+struct TileRect { uint32_t x0, y0, x1, y1; };
+
+// float -> uint32 with CUDA's saturating semantics (negative / NaN -> 0)
+LFS_DI uint32_t sat_u32(float v) {
+    if (!(v > 0.f)) return 0u;
+    if (v >= 4294967296.f) return 0xFFFFFFFFu;
+    return uint32_t(v);
+}
+
+LFS_DI bool tile_rect(const float* __restrict__ means2d, const int32_t* __restrict__ radii, size_t idx,
+                      float tile_size_f, uint32_t tw, uint32_t th, TileRect& r) {
+    const int2 rr = reinterpret_cast<const int2*>(radii)[idx];
+    const float rx = float(rr.x), ry = float(rr.y);
+    if (rx <= 0.f || ry <= 0.f) return false;
+    const float2 m = reinterpret_cast<const float2*>(means2d)[idx];
+    const float trx = rx / tile_size_f, try_ = ry / tile_size_f;
+    const float tx = m.x / tile_size_f, ty = m.y / tile_size_f;
+    r.x0 = min(sat_u32(floorf(tx - trx)), tw);
+    r.y0 = min(sat_u32(floorf(ty - try_)), th);
+    r.x1 = min(sat_u32(ceilf(tx + trx)), tw);
+    r.y1 = min(sat_u32(ceilf(ty + try_)), th);
+    return true;
+}
+
+// number of bits of v: floor(log2 v) + 1 (the reference evaluates this with double log2 on the host)
+static inline uint32_t bit_width_u32(uint32_t v) { uint32_t b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+// ---------------------------------------------------------------------------
+// count: tiles_per_gauss + per-tile totals
+// ---------------------------------------------------------------------------
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(1024) isect_count_kernel(
+    const uint32_t C, const uint32_t N, const uint32_t per_block,
+    const float* __restrict__ means2d, const int32_t* __restrict__ radii,
+    const float tile_size_f, const uint32_t tw, const uint32_t th,
+    int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ totals) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    const uint32_t T = C * tw * th, n_tiles = tw * th;
+    if (LDS_HIST) {
+        for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) hist[t] = 0u;
+        __syncthreads();
+    }
+    const size_t total = size_t(C) * N;
+    const size_t begin = size_t(blockIdx.x) * per_block;
+    const size_t end = min(begin + per_block, total);
+    for (size_t idx = begin + threadIdx.x; idx < end; idx += blockDim.x) {
+        TileRect r;
+        int32_t n = 0;
+        if (tile_rect(means2d, radii, idx, tile_size_f, tw, th, r)) {
+            n = int32_t((r.y1 - r.y0) * (r.x1 - r.x0));
+            const uint32_t base = uint32_t(idx / N) * n_tiles;
+            for (uint32_t i = r.y0; i < r.y1; ++i)
+                for (uint32_t j = r.x0; j < r.x1; ++j) {
+                    if (LDS_HIST) atomicAdd(&hist[base + i * tw + j], 1u);
+                    else atomicAdd(&totals[base + i * tw + j], 1u);
+                }
+        }
+        tiles_per_gauss[idx] = n;
+    }
+    if (LDS_HIST) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+            const uint32_t c = hist[t];
+            if (c) atomicAdd(&totals[t], c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// single-workgroup exclusive scan of totals[T] -> offsets[T+1] (int32), n_isects (int64)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) tile_scan_kernel(
+    const uint32_t T, const uint32_t* __restrict__ totals, int32_t* __restrict__ offsets, int64_t* __restrict__ n_isects) {
+    __shared__ uint64_t wave_sums[16];
+    __shared__ uint64_t carry_s;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < T; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        const uint64_t v = t < T ? totals[t] : 0u;
+        uint64_t s = v; // inclusive wave scan
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t o = __shfl_up(s, d, 64);
+            if (int(lane) >= d) s += o;
+        }
+        if (lane == 63) wave_sums[wave] = s;
+        __syncthreads();
+        uint64_t wave_off = 0;
+        for (uint32_t w = 0; w < wave; ++w) wave_off += wave_sums[w];
+        const uint64_t carry = carry_s;
+        if (t < T) offsets[t] = int32_t(carry + wave_off + s - v);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + s;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { offsets[T] = int32_t(carry_s); *n_isects = int64_t(carry_s); }
+}
+
+// ---------------------------------------------------------------------------
+// scatter: write (key, flatten id) of every intersection into its tile bucket
+// ---------------------------------------------------------------------------
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(1024) isect_scatter_kernel(
+    const uint32_t C, const uint32_t N, const uint32_t per_block,
+    const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+    const float tile_size_f, const uint32_t tw, const uint32_t th, const uint32_t tile_n_bits,
+    const int32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t T = C * tw * th, n_tiles = tw * th;
+    uint32_t* cnt = lds;        // [T] local count, then local rank counter
+    uint32_t* base_s = lds + T; // [T] start of this workgroup's slice inside the tile bucket
+    const size_t total = size_t(C) * N;
+    const size_t begin = size_t(blockIdx.x) * per_block;
+    const size_t end = min(begin + per_block, total);
+    if (LDS_HIST) {
+        for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) cnt[t] = 0u;
+        __syncthreads();
+        for (size_t idx = begin + threadIdx.x; idx < end; idx += blockDim.x) {
+            TileRect r;
+            if (!tile_rect(means2d, radii, idx, tile_size_f, tw, th, r)) continue;
+            const uint32_t cb = uint32_t(idx / N) * n_tiles;
+            for (uint32_t i = r.y0; i < r.y1; ++i)
+                for (uint32_t j = r.x0; j < r.x1; ++j) atomicAdd(&cnt[cb + i * tw + j], 1u);
+        }
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+            const uint32_t c = cnt[t];
+            base_s[t] = c ? atomicAdd(&cursor[t], c) : 0u;
+            cnt[t] = 0u;
+        }
+        __syncthreads();
+    }
+    for (size_t idx = begin + threadIdx.x; idx < end; idx += blockDim.x) {
+        TileRect r;
+        if (!tile_rect(means2d, radii, idx, tile_size_f, tw, th, r)) continue;
+        const uint32_t cid = uint32_t(idx / N);
+        const uint32_t cb = cid * n_tiles;
+        const uint64_t cid_enc = uint64_t(cid) << (32 + tile_n_bits);
+        const uint64_t dbits = uint64_t(__float_as_uint(depths[idx]));
+        for (uint32_t i = r.y0; i < r.y1; ++i)
+            for (uint32_t j = r.x0; j < r.x1; ++j) {
+                const uint32_t tile = i * tw + j, t = cb + tile;
+                uint32_t slot;
+                if (LDS_HIST) slot = base_s[t] + atomicAdd(&cnt[t], 1u);
+                else slot = atomicAdd(&cursor[t], 1u);
+                const size_t pos = size_t(offsets[t]) + slot;
+                isect_ids[pos] = int64_t(cid_enc | (uint64_t(tile) << 32) | dbits);
+                flatten_ids[pos] = int32_t(idx);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-tile sort. Ascending-comparator bitonic network ("flip" formulation: the
+// first step of each merge mirrors inside the block, the rest are half-cleaners),
+// so +inf padding above n never moves below n.
+// ---------------------------------------------------------------------------
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) tile_sort_lds_kernel(
+    const uint32_t n_min, const uint32_t n_max, const int32_t* __restrict__ offsets,
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    const uint32_t t = blockIdx.x;
+    const uint32_t start = uint32_t(offsets[t]);
+    const uint32_t n = uint32_t(offsets[t + 1]) - start;
+    if (n < n_min || n > n_max || n < 2) return;
+    uint32_t n_pad = 2; while (n_pad < n) n_pad <<= 1;
+    const uint64_t hi_bits = uint64_t(isect_ids[start]) & 0xFFFFFFFF00000000ull; // camera | tile: same for the whole bucket
+    for (uint32_t i = threadIdx.x; i < n_pad; i += THREADS) {
+        uint64_t k = ~0ull;
+        if (i < n) k = (uint64_t(uint32_t(isect_ids[start + i])) << 32) | uint32_t(flatten_ids[start + i]);
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+        for (uint32_t i = threadIdx.x; i < n_pad / 2; i += THREADS) { // flip step
+            const uint32_t blk = i / (k >> 1), off = i % (k >> 1);
+            const uint32_t a = blk * k + off, b = blk * k + (k - 1 - off);
+            const uint64_t ka = keys[a], kb = keys[b];
+            if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+        }
+        __syncthreads();
+        for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n_pad / 2; i += THREADS) {
+                const uint32_t a = ((i / j) * (j << 1)) + (i % j), b = a + j;
+                const uint64_t ka = keys[a], kb = keys[b];
+                if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+        const uint64_t k = keys[i];
+        isect_ids[start + i] = int64_t(hi_bits | (k >> 32));
+        flatten_ids[start + i] = int32_t(uint32_t(k));
+    }
+}
+
+// buckets too large for LDS: same network directly on the global arrays
+__global__ void __launch_bounds__(1024) tile_sort_global_kernel(
+    const uint32_t n_min, const int32_t* __restrict__ offsets, int64_t* isect_ids, int32_t* flatten_ids) {
+    const uint32_t t = blockIdx.x;
+    const uint32_t start = uint32_t(offsets[t]);
+    const uint32_t n = uint32_t(offsets[t + 1]) - start;
+    if (n < n_min) return;
+    uint32_t n_pad = 2; while (n_pad < n) n_pad <<= 1;
+    int64_t* K = isect_ids + start; int32_t* V = flatten_ids + start;
+    auto cas = [&](uint32_t a, uint32_t b) {
+        if (b >= n) return; // virtual +inf padding
+        const uint64_t ka = uint64_t(K[a]), kb = uint64_t(K[b]); // same camera|tile prefix: compares depth bits
+        const uint32_t va = uint32_t(V[a]), vb = uint32_t(V[b]);
+        if (ka > kb || (ka == kb && va > vb)) { K[a] = int64_t(kb); K[b] = int64_t(ka); V[a] = int32_t(vb); V[b] = int32_t(va); }
+    };
+    for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+        for (uint32_t i = threadIdx.x; i < n_pad / 2; i += blockDim.x) {
+            const uint32_t blk = i / (k >> 1), off = i % (k >> 1);
+            cas(blk * k + off, blk * k + (k - 1 - off));
+        }
+        __syncthreads();
+        for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n_pad / 2; i += blockDim.x) {
+                const uint32_t a = ((i / j) * (j << 1)) + (i % j);
+                cas(a, a + j);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sort == false path: reference emission order (Gaussian-major), needs the
+// inclusive scan of tiles_per_gauss.
+// ---------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 2048; // per workgroup of 256 threads (8 per thread)
+
+__global__ void __launch_bounds__(256) scan_block_sums_kernel(const size_t n, const int32_t* __restrict__ in, int64_t* __restrict__ block_sums) {
+    __shared__ int64_t ws[4];
+    const size_t base = size_t(blockIdx.x) * SCAN_ITEMS;
+    int64_t s = 0;
+    for (int i = threadIdx.x; i < SCAN_ITEMS; i += 256) { const size_t p = base + i; if (p < n) s += in[p]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ void __launch_bounds__(1024) scan_sums_kernel(const uint32_t nb, int64_t* __restrict__ block_sums) {
+    // exclusive scan of block_sums in place, single workgroup
+    __shared__ int64_t wave_sums[16];
+    __shared__ int64_t carry_s;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        const int64_t v = t < nb ? block_sums[t] : 0;
+        int64_t s = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int64_t o = __shfl_up(s, d, 64); if (int(lane) >= d) s += o; }
+        if (lane == 63) wave_sums[wave] = s;
+        __syncthreads();
+        int64_t wave_off = 0;
+        for (uint32_t w = 0; w < wave; ++w) wave_off += wave_sums[w];
+        const int64_t carry = carry_s;
+        if (t < nb) block_sums[t] = carry + wave_off + s - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + s;
+        __syncthreads();
+    }
+}
+// each thread owns 8 consecutive Gaussians: exclusive start offsets -> emit
+__global__ void __launch_bounds__(256) isect_emit_unsorted_kernel(
+    const uint32_t C, const uint32_t N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
+    const float* __restrict__ depths, const int32_t* __restrict__ tiles_per_gauss, const int64_t* __restrict__ block_offs,
+    const float tile_size_f, const uint32_t tw, const uint32_t th, const uint32_t tile_n_bits,
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
+    __shared__ int64_t ws[4];
+    const size_t total = size_t(C) * N;
+    const size_t base = size_t(blockIdx.x) * SCAN_ITEMS + size_t(threadIdx.x) * 8;
+    int32_t cnt[8]; int64_t local = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { cnt[i] = (base + i < total) ? tiles_per_gauss[base + i] : 0; local += cnt[i]; }
+    int64_t s = local;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int64_t o = __shfl_up(s, d, 64); if (int(lane) >= d) s += o; }
+    if (lane == 63) ws[wave] = s;
+    __syncthreads();
+    int64_t off = block_offs[blockIdx.x] + s - local;
+    for (uint32_t w = 0; w < wave; ++w) off += ws[w];
+    const uint32_t n_tiles = tw * th;
+    (void)n_tiles;
+#pragma unroll 1
+    for (int i = 0; i < 8; ++i) {
+        const size_t idx = base + i;
+        if (idx >= total || cnt[i] == 0) continue;
+        TileRect r;
+        if (!tile_rect(means2d, radii, idx, tile_size_f, tw, th, r)) continue;
+        const uint64_t cid_enc = uint64_t(idx / N) << (32 + tile_n_bits);
+        const uint64_t dbits = uint64_t(__float_as_uint(depths[idx]));
+        int64_t cur = off;
+        for (uint32_t y = r.y0; y < r.y1; ++y)
+            for (uint32_t x = r.x0; x < r.x1; ++x) {
+                isect_ids[cur] = int64_t(cid_enc | (uint64_t(y * tw + x) << 32) | dbits);
+                flatten_ids[cur] = int32_t(idx);
+                ++cur;
+            }
+        off += cnt[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6 standalone: lower-bound offsets from sorted keys
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) isect_offset_kernel(
+    const int64_t n_isects, const int64_t* __restrict__ isect_ids, const uint32_t n_tiles, const uint32_t tile_n_bits,
+    const int64_t T, int32_t* __restrict__ offsets) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_isects) return;
+    auto flat = [&](int64_t key) { const int64_t hi = key >> 32; return (hi >> tile_n_bits) * n_tiles + (hi & ((int64_t(1) << tile_n_bits) - 1)); };
+    const int64_t cur = flat(isect_ids[i]);
+    const int64_t prev = i > 0 ? flat(isect_ids[i - 1]) : -1;
+    for (int64_t t = prev + 1; t <= cur; ++t) offsets[t] = int32_t(i);
+    if (i == n_isects - 1) for (int64_t t = cur + 1; t < T; ++t) offsets[t] = int32_t(n_isects);
+}
+
+// ---- workspace layout ------------------------------------------------------
+struct IsectWs {
+    uint32_t* totals;   // [T]
+    uint32_t* cursor;   // [T]
+    int32_t* offsets;   // [T+1]
+    int64_t* block_sums; // [ceil(CN / SCAN_ITEMS) + 1]
+    size_t bytes;
+};
+static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+static IsectWs isect_ws(void* base, uint32_t C, uint32_t N, uint32_t tw, uint32_t th) {
+    const size_t T = size_t(C) * tw * th;
+    const size_t nb = (size_t(C) * N + SCAN_ITEMS - 1) / SCAN_ITEMS + 1;
+    IsectWs w; char* p = (char*)base; size_t o = 0;
+    w.totals = (uint32_t*)(p + o); o += align256(T * 4);
+    w.cursor = (uint32_t*)(p + o); o += align256(T * 4);
+    w.offsets = (int32_t*)(p + o); o += align256((T + 1) * 4);
+    w.block_sums = (int64_t*)(p + o); o += align256(nb * 8);
+    w.bytes = o;
+    return w;
+}
+static inline uint32_t isect_per_block(size_t total) {
+    // ~512 workgroups of 1024 threads on a big problem, never fewer than 1024 Gaussians each
+    size_t pb = (total + 511) / 512;
+    if (pb < 1024) pb = 1024;
+    return uint32_t((pb + 1023) / 1024 * 1024);
+}
+constexpr size_t LDS_HIST_LIMIT = 64 * 1024; // bytes for the scatter kernel's two [T] arrays
+
+} // namespace lfs
+
+using namespace lfs;
+
+extern "C" size_t lfs_intersect_tile_workspace_bytes(uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height) {
+    return isect_ws(nullptr, C, N, tile_width, tile_height).bytes;
+}
+
+extern "C" int lfs_intersect_tile_count(
+    uint32_t C, uint32_t N, const float* means2d, const int32_t* radii,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    int32_t* tiles_per_gauss, int64_t* n_isects, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    if (!n_isects || !workspace || tile_size == 0 || tile_width == 0 || tile_height == 0 || C == 0) return LFS_E_INVALID;
+    if (bit_width_u32(tile_width * tile_height) + bit_width_u32(C) > 32) return LFS_E_UNSUPPORTED; // IntersectTile.cu:154
+    IsectWs w = isect_ws(workspace, C, N, tile_width, tile_height);
+    if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t T = C * tile_width * tile_height;
+    hipError_t e = hipMemsetAsync(w.totals, 0, (char*)w.offsets - (char*)w.totals, s); // totals + cursor
+    if (e != hipSuccess) return (int)e;
+    const size_t total = size_t(C) * N;
+    if (total > 0) {
+        if (!means2d || !radii || !tiles_per_gauss) return LFS_E_INVALID;
+        const uint32_t pb = isect_per_block(total);
+        const uint32_t blocks = uint32_t((total + pb - 1) / pb);
+        if (size_t(T) * 8 <= LDS_HIST_LIMIT)
+            hipLaunchKernelGGL(isect_count_kernel<true>, dim3(blocks), dim3(1024), T * 4, s, C, N, pb, means2d, radii,
+                               float(tile_size), tile_width, tile_height, tiles_per_gauss, w.totals);
+        else
+            hipLaunchKernelGGL(isect_count_kernel<false>, dim3(blocks), dim3(1024), 0, s, C, N, pb, means2d, radii,
+                               float(tile_size), tile_width, tile_height, tiles_per_gauss, w.totals);
+    }
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lfs_intersect_tile_emit(
+    uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int sort, int64_t n_isects,
+    const int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* tile_offsets,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    if (!workspace || C == 0 || tile_size == 0) return LFS_E_INVALID;
+    IsectWs w = isect_ws(workspace, C, N, tile_width, tile_height);
+    if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t T = C * tile_width * tile_height;
+    if (tile_offsets) {
+        hipError_t e = hipMemcpyAsync(tile_offsets, w.offsets, size_t(T) * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (n_isects <= 0) return LFS_OK;
+    if (n_isects > 0x7FFFFFFFll) return LFS_E_UNSUPPORTED; // offsets / last_ids are int32 in the reference API
+    if (!means2d || !radii || !depths || !isect_ids || !flatten_ids) return LFS_E_INVALID;
+    const uint32_t tile_n_bits = bit_width_u32(tile_width * tile_height);
+    const size_t total = size_t(C) * N;
+    if (sort) {
+        static bool big_lds_enabled = false; // > 64 KiB of dynamic LDS has to be opted into once per process
+        if (!big_lds_enabled) {
+            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_lds_kernel<1024>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            if (ae != hipSuccess) return (int)ae;
+            big_lds_enabled = true;
+        }
+        const uint32_t pb = isect_per_block(total);
+        const uint32_t blocks = uint32_t((total + pb - 1) / pb);
+        if (size_t(T) * 8 <= LDS_HIST_LIMIT)
+            hipLaunchKernelGGL(isect_scatter_kernel<true>, dim3(blocks), dim3(1024), size_t(T) * 8, s, C, N, pb, means2d, radii, depths,
+                               float(tile_size), tile_width, tile_height, tile_n_bits, w.offsets, w.cursor, isect_ids, flatten_ids);
+        else
+            hipLaunchKernelGGL(isect_scatter_kernel<false>, dim3(blocks), dim3(1024), 0, s, C, N, pb, means2d, radii, depths,
+                               float(tile_size), tile_width, tile_height, tile_n_bits, w.offsets, w.cursor, isect_ids, flatten_ids);
+        // size classes: <= 4096 entries (32 KiB LDS), <= 16384 (128 KiB LDS), larger -> global
+        hipLaunchKernelGGL(tile_sort_lds_kernel<256>, dim3(T), dim3(256), 4096 * 8, s, 2u, 4096u, w.offsets, isect_ids, flatten_ids);
+        hipLaunchKernelGGL(tile_sort_lds_kernel<1024>, dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, w.offsets, isect_ids, flatten_ids);
+        hipLaunchKernelGGL(tile_sort_global_kernel, dim3(T), dim3(1024), 0, s, 16385u, w.offsets, isect_ids, flatten_ids);
+    } else {
+        if (!tiles_per_gauss) return LFS_E_INVALID;
+        const uint32_t nb = uint32_t((total + SCAN_ITEMS - 1) / SCAN_ITEMS);
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, s, total, tiles_per_gauss, w.block_sums);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, nb, w.block_sums);
+        hipLaunchKernelGGL(isect_emit_unsorted_kernel, dim3(nb), dim3(256), 0, s, C, N, means2d, radii, depths, tiles_per_gauss,
+                           w.block_sums, float(tile_size), tile_width, tile_height, tile_n_bits, isect_ids, flatten_ids);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int lfs_intersect_offset(
+    int64_t n_isects, const int64_t* isect_ids, uint32_t C, uint32_t tile_width, uint32_t tile_height,
+    int32_t* offsets, lfs_stream_t stream) {
+    if (!offsets) return LFS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t T = int64_t(C) * tile_width * tile_height;
+    if (n_isects <= 0) { // IntersectTile.cu:268-271
+        hipError_t e = hipMemsetAsync(offsets, 0, size_t(T) * 4, s);
+        return (int)e;
+    }
+    if (!isect_ids) return LFS_E_INVALID;
+    const uint32_t n_tiles = tile_width * tile_height;
+    hipLaunchKernelGGL(isect_offset_kernel, dim3(uint32_t((n_isects + 255) / 256)), dim3(256), 0, s,
+                       n_isects, isect_ids, n_tiles, bit_width_u32(n_tiles), T, offsets);
+    return (int)hipGetLastError();
+}

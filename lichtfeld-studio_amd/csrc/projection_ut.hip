@@ -1,0 +1,139 @@
+// K1 — 3DGUT projection (replaces gsplat::projection_ut_3dgs_fused;
+// reference: gsplat/ProjectionUT3DGSFused.cu:17-203, Projection.cpp:22-110).
+//
+// HBM-bound streaming kernel: 44 B read + 8 B radii write per Gaussian, + 24 B
+// for survivors. One lane per (camera, Gaussian); blockIdx.y is
+// the camera so every camera-derived quantity is wave-uniform. The file is
+// compiled with -ffp-contract=off: it has VALU headroom to spare and un-fused
+// arithmetic keeps the sigma-point cancellation (weights -99 / +16.67) on the
+// same rounding path as the oracle.
+#include "lfs_camera.cuh"
+
+namespace lfs {
+
+__global__ void __launch_bounds__(256) projection_ut_kernel(
+    const uint32_t N,
+    const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
+    const float* __restrict__ opacities, const lfs_cameras cams,
+    const float eps2d, const float near_plane, const float far_plane, const float radius_clip,
+    const lfs_ut_params ut,
+    int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
+    float* __restrict__ conics, float* __restrict__ compensations) {
+    const uint32_t cid = blockIdx.y;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= N) return;
+    const size_t idx = size_t(cid) * N + gid;
+
+    CamDev cam;
+    cam_init(cam, cams, cid);
+
+    int32_t out_rx = 0, out_ry = 0;
+    float o_m2x = 0.f, o_m2y = 0.f, o_depth = 0.f, o_c0 = 0.f, o_c1 = 0.f, o_c2 = 0.f, o_comp = 0.f;
+
+    do {
+        const f3 mean{means[3 * gid], means[3 * gid + 1], means[3 * gid + 2]};
+        const f3 scale{scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
+        const quat rot = qnormalize(quat{quats[4 * gid], quats[4 * gid + 1], quats[4 * gid + 2], quats[4 * gid + 3]});
+
+        // depth test at the centre-of-exposure pose
+        quat qc; f3 tc;
+        cam_pose_at(cam, 0.5f, qc, tc);
+        const f3 mean_c = qrotate(qc, mean) + tc;
+        if (mean_c.z < near_plane || mean_c.z > far_plane) break;
+
+        // sigma points (D = 3)
+        const float D = 3.f;
+        const float lambda = ut.alpha * ut.alpha * (D + ut.kappa) - D;
+        const m3 R = qmat3(rot);
+        const float sc[3] = {scale.x, scale.y, scale.z};
+        const float w0m = lambda / (D + lambda);
+        const float w0c = lambda / (D + lambda) + (1.f - ut.alpha * ut.alpha + ut.beta);
+        const float wi = 1.f / (2.f * (D + lambda));
+        const float spread = sqrtf(D + lambda);
+        const bool require_all = ut.require_all_sigma_points_valid != 0;
+
+        f2 ip[7];
+        f2 m{0.f, 0.f};
+        bool valid = require_all, bail = false;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            f3 pt = mean;
+            if (i > 0) {
+                const int a = (i - 1) % 3;
+                const float f = spread * sc[a];
+                const f3 delta{f * R.m[0][a], f * R.m[1][a], f * R.m[2][a]};
+                pt = (i <= 3) ? mean + delta : mean - delta;
+            }
+            f2 p;
+            const bool pv = cam_world_to_image(cam, pt, ut.in_image_margin_factor, p);
+            if (require_all) { valid &= pv; if (!pv) { bail = true; } }
+            else valid |= pv;
+            ip[i] = p;
+            const float w = (i == 0) ? w0m : wi;
+            if (!bail) { m.x = m.x + w * p.x; m.y = m.y + w * p.y; }
+        }
+        if (bail || !valid) break;
+
+        float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const float w = (i == 0) ? w0c : wi;
+            const float dx = ip[i].x - m.x, dy = ip[i].y - m.y;
+            c00 += w * (dx * dx); c01 += w * (dx * dy); c10 += w * (dy * dx); c11 += w * (dy * dy);
+        }
+
+        // 2D blur + compensation
+        const float det_orig = c00 * c11 - c01 * c10;
+        c00 += eps2d; c11 += eps2d;
+        const float det = c00 * c11 - c01 * c10;
+        const float compensation = sqrtf(fmaxf(0.f, det_orig / det));
+        if (det <= 0.f) break;
+        const float ood = 1.f / det;
+
+        float extend = 3.33f;
+        if (opacities != nullptr) {
+            const float op = opacities[gid] * compensation;
+            if (op < (1.f / 255.f)) break;
+            extend = fminf(extend, sqrtf(2.f * logf(op / (1.f / 255.f))));
+        }
+        const float b = 0.5f * (c00 + c11);
+        const float tmp = sqrtf(fmaxf(0.01f, b * b - det));
+        const float r1 = extend * sqrtf(b + tmp);
+        const float rx = ceilf(fminf(extend * sqrtf(c00), r1));
+        const float ry = ceilf(fminf(extend * sqrtf(c11), r1));
+        if (rx <= radius_clip && ry <= radius_clip) break;
+        if (m.x + rx <= 0.f || m.x - rx >= float(cam.width) || m.y + ry <= 0.f || m.y - ry >= float(cam.height)) break;
+
+        out_rx = int32_t(rx); out_ry = int32_t(ry);
+        o_m2x = m.x; o_m2y = m.y; o_depth = mean_c.z;
+        o_c0 = c11 * ood; o_c1 = -c01 * ood; o_c2 = c00 * ood;
+        o_comp = compensation;
+    } while (false);
+
+    reinterpret_cast<int2*>(radii)[idx] = make_int2(out_rx, out_ry);
+    reinterpret_cast<float2*>(means2d)[idx] = make_float2(o_m2x, o_m2y);
+    depths[idx] = o_depth;
+    conics[3 * idx] = o_c0; conics[3 * idx + 1] = o_c1; conics[3 * idx + 2] = o_c2;
+    if (compensations != nullptr) compensations[idx] = o_comp;
+}
+
+} // namespace lfs
+
+extern "C" int lfs_projection_ut_3dgs_fused(
+    uint32_t N, const float* means, const float* quats, const float* scales, const float* opacities,
+    const lfs_cameras* cams, float eps2d, float near_plane, float far_plane, float radius_clip,
+    const lfs_ut_params* ut_params,
+    int32_t* radii, float* means2d, float* depths, float* conics, float* compensations,
+    lfs_stream_t stream) {
+    if (!cams || !cams->viewmats0 || !cams->Ks) return LFS_E_INVALID;
+    if (cams->camera_model != LFS_CAMERA_PINHOLE && cams->camera_model != LFS_CAMERA_FISHEYE) return LFS_E_UNSUPPORTED;
+    if (N == 0 || cams->C == 0) return LFS_OK; // ProjectionUT3DGSFused.cu:242-245
+    if (!means || !quats || !scales || !radii || !means2d || !depths || !conics) return LFS_E_INVALID;
+    lfs_ut_params ut = {0.1f, 2.f, 0.f, 0.1f, 1};
+    if (ut_params) ut = *ut_params;
+    dim3 grid((N + 255) / 256, cams->C);
+    hipLaunchKernelGGL(lfs::projection_ut_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                       N, means, quats, scales, opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
+                       radii, means2d, depths, conics, compensations);
+    return (int)hipGetLastError();
+}

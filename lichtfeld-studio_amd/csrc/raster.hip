@@ -1,0 +1,624 @@
+// K7 / K8 — world-space (3DGUT) alpha compositing and its backward (replace
+// gsplat::rasterize_to_pixels_from_world_3dgs_fwd / _bwd; reference:
+// gsplat/RasterizeToPixelsFromWorld3DGSFwd.cu:19-279, ...Bwd.cu:16-373,
+// host gsplat/Rasterization.cpp:20-261, helpers gsplat/Utils.cuh:80-194).
+//
+// CDNA4 design (not the reference's block-cooperative shared-memory batches):
+//  * pack   : one pass turns every Gaussian into a 64-byte record
+//             { M = S^-1 R^T (9), M(o-mu) or mu (3), opacity, rgb } — all the
+//             per-Gaussian work the reference redoes per tile batch (rotmat,
+//             1/scale, matrix product) happens once per Gaussian, coalesced.
+//  * raster : a wavefront owns an 8x8 pixel cell of a tile and walks the tile's
+//             depth-sorted list ALONE: the list position is wave-uniform, so the
+//             record arrives through the scalar unit (s_load_dwordx16 into
+//             SGPRs, served by the scalar cache / L2) and feeds v_pk_fma_f32
+//             directly. No LDS staging, no __syncthreads, no 64-lane broadcast
+//             reads; early-out, the alpha < 1/255 skip and the backward's
+//             "behind the last contributor" skip are per 8x8 cell (ballot),
+//             4x finer than the reference's 16x16 block.
+//  * bwd    : the chain rule through M is linear, so a lane only accumulates
+//             dL/dM (9), dL/d(gro) (3), dL/dopacity, dL/drgb = 16 floats; a
+//             permlane32/16-swap "transpose" reduction leaves the 16 wave sums
+//             in 16 lanes and ONE 64-byte-contiguous global_atomic_add_f32
+//             instruction per (wave, Gaussian) adds them to a [C*N][16]
+//             accumulator (the reference: 14 shuffle reductions x 5 steps + 14
+//             scalar atomics per (warp, Gaussian)).
+//  * finish : one pass maps the accumulator through the quaternion / scale /
+//             mean vjp (done per (pixel, Gaussian) in the reference).
+#include "lfs_camera.cuh"
+
+namespace lfs {
+
+struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2, r3; };
+
+constexpr int ACC_STRIDE = 16; // A(9) | G(3) | opacity | rgb(3)
+
+static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; size_t bytes; };
+static RasterWs raster_ws(void* base, uint32_t C, uint32_t N) {
+    RasterWs w; char* p = (char*)base; size_t o = 0;
+    w.cams = (CamDev*)(p + o); o += align256(sizeof(CamDev) * C);
+    w.recs = (GaussRec*)(p + o); o += align256(sizeof(GaussRec) * size_t(C) * N);
+    w.acc = (float*)(p + o); o += align256(sizeof(float) * ACC_STRIDE * size_t(C) * N);
+    w.bytes = o;
+    return w;
+}
+
+__global__ void cam_prep_kernel(const lfs_cameras cams, CamDev* __restrict__ out) {
+    for (uint32_t c = threadIdx.x; c < cams.C; c += blockDim.x) {
+        CamDev cd;
+        cam_init(cd, cams, c);
+        out[c] = cd;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pack
+// ---------------------------------------------------------------------------
+template <bool UNIFORM_ORIGIN>
+__global__ void __launch_bounds__(256) raster_pack_kernel(
+    const uint32_t C, const uint32_t N, const uint32_t channels,
+    const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
+    const float* __restrict__ colors, const float* __restrict__ opacities,
+    const CamDev* __restrict__ cams, GaussRec* __restrict__ recs) {
+    const size_t idx = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= size_t(C) * N) return;
+    const uint32_t cid = uint32_t(idx / N), gid = uint32_t(idx % N);
+    const f3 mu{means[3 * gid], means[3 * gid + 1], means[3 * gid + 2]};
+    const float4 q = reinterpret_cast<const float4*>(quats)[gid];
+    const m3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
+    const float is[3] = {1.f / scales[3 * gid], 1.f / scales[3 * gid + 1], 1.f / scales[3 * gid + 2]};
+    m3 M;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
+    f3 g = mu;
+    if (UNIFORM_ORIGIN) g = mul(M, cams[cid].origin - mu);
+    GaussRec rec;
+    rec.r0 = make_float4(M.m[0][0], M.m[0][1], M.m[0][2], g.x);
+    rec.r1 = make_float4(M.m[1][0], M.m[1][1], M.m[1][2], g.y);
+    rec.r2 = make_float4(M.m[2][0], M.m[2][1], M.m[2][2], g.z);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    const float* cp = colors + idx * channels;
+    c0 = cp[0];
+    if (channels > 1) c1 = cp[1];
+    if (channels > 2) c2 = cp[2];
+    rec.r3 = make_float4(opacities[idx], c0, c1, c2);
+    recs[idx] = rec;
+}
+
+// ---------------------------------------------------------------------------
+// tile / cell bookkeeping shared by fwd and bwd
+// ---------------------------------------------------------------------------
+struct CellCtx {
+    uint32_t cid, tile_global, i, j;
+    bool in_grid;
+};
+// Workgroup -> (tile, cell). Consecutive workgroup ids go round-robin over the
+// 8 XCDs; remap so that each XCD works on one contiguous band of tiles and the
+// records of neighbouring tiles meet in the same L2.
+LFS_DI CellCtx cell_ctx(uint32_t n_tiles, uint32_t total_tiles, uint32_t tw, uint32_t tile_size, uint32_t blocks_per_tile, uint32_t waves_per_block) {
+    CellCtx c;
+    const uint32_t nb = total_tiles * blocks_per_tile;
+    const uint32_t per_xcd = (nb + 7) / 8;
+    const uint32_t b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    c.in_grid = b < nb && (blockIdx.x >> 3) < per_xcd;
+    const uint32_t tg = b / blocks_per_tile, bt = b % blocks_per_tile;
+    c.tile_global = tg;
+    c.cid = tg / n_tiles;
+    const uint32_t tile = tg % n_tiles;
+    const uint32_t ty = tile / tw, tx = tile % tw;
+    const uint32_t wps = tile_size >> 3; // 8x8 cells per tile side
+    const uint32_t wl = bt * waves_per_block + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    c.i = ty * tile_size + (wl / wps) * 8 + (lane >> 3);
+    c.j = tx * tile_size + (wl % wps) * 8 + (lane & 7);
+    return c;
+}
+
+LFS_DI float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+LFS_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <int CDIM, bool UNIFORM_ORIGIN>
+__global__ void __launch_bounds__(256) raster_fwd_kernel(
+    const uint32_t C, const uint32_t N, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
+    const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block,
+    const CamDev* __restrict__ cams, const GaussRec* __restrict__ recs, const float* __restrict__ colors,
+    const float* __restrict__ backgrounds, const uint8_t* __restrict__ masks,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ ids, const int32_t n_isects,
+    float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
+    const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
+    const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
+    if (!cc.in_grid) return;
+    const uint32_t cid = cc.cid;
+    const bool inside = cc.i < H && cc.j < W;
+    const size_t pix_id = (size_t(cid) * H + cc.i) * W + cc.j;
+    const float* bg = backgrounds ? backgrounds + cid * CDIM : nullptr;
+
+    if (masks != nullptr && !masks[cc.tile_global]) { // Fwd.cu:141-150 (alpha / last id written as 0 instead of left undefined)
+        if (inside) {
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) render_colors[pix_id * CDIM + k] = bg ? bg[k] : 0.f;
+            render_alphas[pix_id] = 0.f;
+            last_ids[pix_id] = 0;
+        }
+        return;
+    }
+
+    const CamDev& cam = cams[cid];
+    f3 ro, rd;
+    const bool ray_ok = cam_pixel_ray(cam, f2{float(cc.j) + 0.5f, float(cc.i) + 0.5f}, ro, rd);
+    bool done = !(inside && ray_ok);
+
+    const int32_t start = offsets[cc.tile_global];
+    const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
+
+    float T = 1.f;
+    float pix[CDIM];
+#pragma unroll
+    for (int k = 0; k < CDIM; ++k) pix[k] = 0.f;
+    int32_t cur_idx = 0;
+
+    // two-deep scalar prefetch: id two entries ahead, record one entry ahead
+    int32_t g_next = start < end ? ids[start] : 0;
+    int32_t g_next2 = start + 1 < end ? ids[start + 1] : 0;
+    GaussRec rec_next = recs[g_next];
+    for (int32_t idx = start; idx < end; ++idx) {
+        if (__ballot(!done) == 0ull) break;
+        const GaussRec rec = rec_next;
+        const int32_t g = g_next;
+        g_next = g_next2;
+        if (idx + 1 < end) rec_next = recs[g_next];
+        g_next2 = idx + 2 < end ? ids[idx + 2] : 0;
+
+        f3 gro;
+        if (UNIFORM_ORIGIN) gro = {rec.r0.w, rec.r1.w, rec.r2.w};
+        else {
+            const f3 om{ro.x - rec.r0.w, ro.y - rec.r1.w, ro.z - rec.r2.w};
+            gro = {rec.r0.x * om.x + rec.r0.y * om.y + rec.r0.z * om.z,
+                   rec.r1.x * om.x + rec.r1.y * om.y + rec.r1.z * om.z,
+                   rec.r2.x * om.x + rec.r2.y * om.y + rec.r2.z * om.z};
+        }
+        f3 grd{rec.r0.x * rd.x + rec.r0.y * rd.y + rec.r0.z * rd.z,
+               rec.r1.x * rd.x + rec.r1.y * rd.y + rec.r1.z * rd.z,
+               rec.r2.x * rd.x + rec.r2.y * rd.y + rec.r2.z * rd.z};
+        const float l = grd.x * grd.x + grd.y * grd.y + grd.z * grd.z;
+        const float il = l > 0.f ? fast_rsq(l) : 1.f;
+        grd = grd * il;
+        const f3 gc = cross(grd, gro);
+        const float power = -0.5f * (gc.x * gc.x + gc.y * gc.y + gc.z * gc.z);
+        const float alpha = fminf(0.999f, rec.r3.x * __expf(power));
+        const bool pass = !done && !(alpha < (1.f / 255.f));
+        if (__ballot(pass) == 0ull) continue;
+
+        const float next_T = T * (1.f - alpha);
+        const bool fin = pass && next_T <= 1e-4f; // the terminating Gaussian is not composited
+        const bool contrib = pass && !fin;
+        const float vis = alpha * T;
+        if (contrib) {
+            if (CDIM <= 3) {
+                pix[0] += rec.r3.y * vis;
+                if (CDIM > 1) pix[1] += rec.r3.z * vis;
+                if (CDIM > 2) pix[2] += rec.r3.w * vis;
+            } else {
+                const float* cp = colors + size_t(g) * CDIM;
+#pragma unroll
+                for (int k = 0; k < CDIM; ++k) pix[k] += cp[k] * vis;
+            }
+            cur_idx = idx;
+            T = next_T;
+        }
+        done |= fin;
+    }
+
+    if (inside) {
+        render_alphas[pix_id] = 1.f - T;
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) render_colors[pix_id * CDIM + k] = bg ? pix[k] + T * bg[k] : pix[k];
+        last_ids[pix_id] = cur_idx;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+LFS_DI float dpp_ror(float v, int n) {
+    // rotate inside each row of 16 lanes
+    switch (n) {
+    case 8: return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));
+    case 4: return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124, 0xf, 0xf, false));
+    case 2: return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x122, 0xf, 0xf, false));
+    default: return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x121, 0xf, 0xf, false));
+    }
+}
+
+// Sum 16 per-lane values over the 64 lanes and add the 16 totals to dst[0..15]
+// with one 16-lane atomic instruction. Steps 1-2 halve the value count while
+// folding lane halves / row pairs (v_permlane32_swap, v_permlane16_swap), the
+// last four steps are row rotations (DPP).
+LFS_DI void wave_sum16_atomic(const float (&v)[16], float* __restrict__ dst, const uint32_t lane) {
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 8]), false, false);
+        w[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    float u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[j]), __float_as_uint(w[j + 4]), false, false);
+        u[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u[j] += dpp_ror(u[j], 8);
+        u[j] += dpp_ror(u[j], 4);
+        u[j] += dpp_ror(u[j], 2);
+        u[j] += dpp_ror(u[j], 1);
+    }
+    // row r (16 lanes) now holds totals of v[4r .. 4r+3] in u[0..3]
+    const uint32_t j = lane & 3;
+    const float out = (j & 2) ? ((j & 1) ? u[3] : u[2]) : ((j & 1) ? u[1] : u[0]);
+    if ((lane & 15) < 4) unsafeAtomicAdd(dst + 4 * (lane >> 4) + j, out);
+}
+
+template <int CDIM, bool UNIFORM_ORIGIN>
+__global__ void __launch_bounds__(256) raster_bwd_kernel(
+    const uint32_t C, const uint32_t N, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
+    const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block,
+    const CamDev* __restrict__ cams, const GaussRec* __restrict__ recs, const float* __restrict__ colors,
+    const float* __restrict__ backgrounds, const uint8_t* __restrict__ masks,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ ids, const int32_t n_isects,
+    const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
+    float* __restrict__ acc, float* __restrict__ v_colors_extra) {
+    const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
+    const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
+    if (!cc.in_grid) return;
+    const uint32_t cid = cc.cid;
+    if (masks != nullptr && !masks[cc.tile_global]) return; // masked tiles composited nothing
+    const uint32_t lane = threadIdx.x & 63;
+    const bool inside = cc.i < H && cc.j < W;
+    const size_t pix_id = (size_t(cid) * H + cc.i) * W + cc.j;
+    const float* bg = backgrounds ? backgrounds + cid * CDIM : nullptr;
+
+    const CamDev& cam = cams[cid];
+    f3 ro, rd;
+    const bool ray_ok = cam_pixel_ray(cam, f2{float(cc.j) + 0.5f, float(cc.i) + 0.5f}, ro, rd);
+    const bool active = inside && ray_ok;
+
+    const int32_t start = offsets[cc.tile_global];
+    const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
+
+    float T_final = 1.f, v_ra = 0.f;
+    int32_t bin_final = -1; // Bwd.cu:183 uses 0 for inactive pixels; -1 keeps them out of entry 0 as well
+    float vc[CDIM], buffer[CDIM];
+#pragma unroll
+    for (int k = 0; k < CDIM; ++k) { vc[k] = 0.f; buffer[k] = 0.f; }
+    if (active) {
+        T_final = 1.f - render_alphas[pix_id];
+        bin_final = last_ids[pix_id];
+        v_ra = v_render_alphas[pix_id];
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) vc[k] = v_render_colors[pix_id * CDIM + k];
+    }
+    float T = T_final;
+    // T_final * (v_alpha_out - bg . v_color_out): the transmittance-tail term of d/d(alpha)
+    float tail = v_ra;
+    if (bg) {
+        float bd = 0.f;
+#pragma unroll
+        for (int k = 0; k < CDIM; ++k) bd += bg[k] * vc[k];
+        tail -= bd;
+    }
+    tail *= T_final;
+
+    // wave max of bin_final (uniform): nothing behind it can matter for this cell
+    int32_t wmax = bin_final;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, __shfl_xor(wmax, m, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    const int32_t first = min(end - 1, wmax);
+    if (first < start) return;
+
+    int32_t g_next = ids[first];
+    int32_t g_next2 = first - 1 >= start ? ids[first - 1] : 0;
+    GaussRec rec_next = recs[g_next];
+    for (int32_t idx = first; idx >= start; --idx) {
+        const GaussRec rec = rec_next;
+        const int32_t g = g_next;
+        g_next = g_next2;
+        if (idx - 1 >= start) rec_next = recs[g_next];
+        g_next2 = idx - 2 >= start ? ids[idx - 2] : 0;
+
+        f3 om{0.f, 0.f, 0.f}, gro;
+        if (UNIFORM_ORIGIN) gro = {rec.r0.w, rec.r1.w, rec.r2.w};
+        else {
+            om = {ro.x - rec.r0.w, ro.y - rec.r1.w, ro.z - rec.r2.w};
+            gro = {rec.r0.x * om.x + rec.r0.y * om.y + rec.r0.z * om.z,
+                   rec.r1.x * om.x + rec.r1.y * om.y + rec.r1.z * om.z,
+                   rec.r2.x * om.x + rec.r2.y * om.y + rec.r2.z * om.z};
+        }
+        const f3 grd{rec.r0.x * rd.x + rec.r0.y * rd.y + rec.r0.z * rd.z,
+                     rec.r1.x * rd.x + rec.r1.y * rd.y + rec.r1.z * rd.z,
+                     rec.r2.x * rd.x + rec.r2.y * rd.y + rec.r2.z * rd.z};
+        const float l = grd.x * grd.x + grd.y * grd.y + grd.z * grd.z;
+        const float il = l > 0.f ? fast_rsq(l) : 1.f;
+        const f3 grd_n = grd * il;
+        const f3 gc = cross(grd_n, gro);
+        const float power = -0.5f * (gc.x * gc.x + gc.y * gc.y + gc.z * gc.z);
+        const float vis = __expf(power);
+        const float opac = rec.r3.x;
+        const float alpha = fminf(0.999f, opac * vis);
+        const bool valid = active && idx <= bin_final && !(power > 0.f) && !(alpha < (1.f / 255.f));
+        if (__ballot(valid) == 0ull) continue;
+
+        float col[CDIM];
+        if (CDIM <= 3) {
+            col[0] = rec.r3.y;
+            if (CDIM > 1) col[1] = rec.r3.z;
+            if (CDIM > 2) col[2] = rec.r3.w;
+        } else {
+            const float* cp = colors + size_t(g) * CDIM;
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) col[k] = cp[k];
+        }
+
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0.f;
+        float v_extra = 0.f; // 4th colour channel
+        if (valid) {
+            const float ra = fast_rcp(1.f - alpha);
+            T *= ra;
+            const float fac = alpha * T;
+            float v_alpha = tail * ra;
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) {
+                const float vrgb = fac * vc[k];
+                if (k < 3) v[13 + k] = vrgb; else v_extra = vrgb;
+                v_alpha += (col[k] * T - buffer[k] * ra) * vc[k];
+            }
+            if (opac * vis <= 0.999f) {
+                const float v_vis = opac * v_alpha;
+                const float v_gd = -0.5f * vis * v_vis;
+                const f3 v_gc = (2.f * v_gd) * gc;
+                const f3 v_grd_n = -cross(v_gc, gro);
+                const f3 v_gro = cross(v_gc, grd_n);
+                // safe_normalize_bw(grd, v_grd_n)
+                f3 v_grd = v_grd_n;
+                if (l > 0.f) {
+                    const float il3 = il * il * il;
+                    v_grd = il * v_grd_n - (il3 * dot(v_grd_n, grd)) * grd;
+                }
+                // dL/dM = v_grd (x) d  [+ v_gro (x) (o - mu) added per pixel only when the origin varies]
+                v[0] = v_grd.x * rd.x; v[1] = v_grd.x * rd.y; v[2] = v_grd.x * rd.z;
+                v[3] = v_grd.y * rd.x; v[4] = v_grd.y * rd.y; v[5] = v_grd.y * rd.z;
+                v[6] = v_grd.z * rd.x; v[7] = v_grd.z * rd.y; v[8] = v_grd.z * rd.z;
+                if (!UNIFORM_ORIGIN) {
+                    v[0] += v_gro.x * om.x; v[1] += v_gro.x * om.y; v[2] += v_gro.x * om.z;
+                    v[3] += v_gro.y * om.x; v[4] += v_gro.y * om.y; v[5] += v_gro.y * om.z;
+                    v[6] += v_gro.z * om.x; v[7] += v_gro.z * om.y; v[8] += v_gro.z * om.z;
+                }
+                v[9] = v_gro.x; v[10] = v_gro.y; v[11] = v_gro.z;
+                v[12] = vis * v_alpha;
+            }
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) buffer[k] += col[k] * fac;
+        }
+        wave_sum16_atomic(v, acc + size_t(g) * ACC_STRIDE, lane);
+        if (CDIM > 3) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v_extra += __shfl_xor(v_extra, m, 64);
+            if (lane == 0) unsafeAtomicAdd(v_colors_extra + size_t(g) * CDIM + 3, v_extra);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// finish: accumulator -> dL/d(means, quats, scales, colors, opacities)
+// ---------------------------------------------------------------------------
+template <bool UNIFORM_ORIGIN>
+__global__ void __launch_bounds__(256) raster_finish_kernel(
+    const uint32_t C, const uint32_t N, const uint32_t channels,
+    const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
+    const CamDev* __restrict__ cams, const float* __restrict__ acc,
+    float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
+    float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= N) return;
+    float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+    bool geom_loaded = false;
+    f3 mu{0.f, 0.f, 0.f}; float4 q = make_float4(1.f, 0.f, 0.f, 0.f); float is[3] = {0.f, 0.f, 0.f}; m3 R, M;
+    for (uint32_t cid = 0; cid < C; ++cid) {
+        const size_t idx = size_t(cid) * N + gid;
+        const float4* a4 = reinterpret_cast<const float4*>(acc + idx * ACC_STRIDE);
+        const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
+        v_opacities[idx] = a3.x;
+        float* vcol = v_colors + idx * channels;
+        vcol[0] = a3.y;
+        if (channels > 1) vcol[1] = a3.z;
+        if (channels > 2) vcol[2] = a3.w;
+        // (channel 3, when present, was accumulated straight into v_colors by the bwd kernel)
+        const float A[9] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x};
+        const f3 G{a2.y, a2.z, a2.w};
+        bool any = G.x != 0.f || G.y != 0.f || G.z != 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) any |= A[k] != 0.f;
+        if (!any) continue;
+        if (!geom_loaded) {
+            mu = {means[3 * gid], means[3 * gid + 1], means[3 * gid + 2]};
+            q = reinterpret_cast<const float4*>(quats)[gid];
+            R = quat_to_rotmat(q.x, q.y, q.z, q.w);
+            is[0] = 1.f / scales[3 * gid]; is[1] = 1.f / scales[3 * gid + 1]; is[2] = 1.f / scales[3 * gid + 2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
+            geom_loaded = true;
+        }
+        // dL/dM (math rows r, cols c)
+        m3 vM;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vM.m[r][c] = A[3 * r + c];
+        if (UNIFORM_ORIGIN) {
+            const f3 om = cams[cid].origin - mu;
+            const float gv[3] = {G.x, G.y, G.z}, ov[3] = {om.x, om.y, om.z};
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) vM.m[r][c] += gv[r] * ov[c];
+        }
+        // mean: gro = M (o - mu)  ->  dL/dmu = -M^T G
+        const f3 vom = mul_t(M, G);
+        vm[0] -= vom.x; vm[1] -= vom.y; vm[2] -= vom.z;
+        // M = S^-1 R^T, i.e. P = M^T = R S^-1 with dL/dP = (dL/dM)^T:
+        //   dL/dR[r][c] = dL/dP[r][c] / s_c ;  dL/ds_c = -(1/s_c^2) sum_r R[r][c] dL/dP[r][c]
+        m3 GR;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) GR.m[r][c] = vM.m[c][r] * is[c];
+        quat_to_rotmat_vjp(q.x, q.y, q.z, q.w, GR, vq);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            vs[c] += -is[c] * is[c] * (R.m[0][c] * vM.m[c][0] + R.m[1][c] * vM.m[c][1] + R.m[2][c] * vM.m[c][2]);
+    }
+    v_means[3 * gid] = vm[0]; v_means[3 * gid + 1] = vm[1]; v_means[3 * gid + 2] = vm[2];
+    reinterpret_cast<float4*>(v_quats)[gid] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+    v_scales[3 * gid] = vs[0]; v_scales[3 * gid + 1] = vs[1]; v_scales[3 * gid + 2] = vs[2];
+}
+
+struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid; };
+static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom& g) {
+    if (tile_size < 8 || tile_size > 64 || (tile_size & 7)) return false;
+    g.tw = (cams->image_width + tile_size - 1) / tile_size;
+    g.th = (cams->image_height + tile_size - 1) / tile_size;
+    const uint32_t wpt = (tile_size / 8) * (tile_size / 8);
+    g.waves_per_block = wpt < 4 ? wpt : 4;
+    g.blocks_per_tile = wpt / g.waves_per_block;
+    g.threads = g.waves_per_block * 64;
+    const uint64_t nb = uint64_t(cams->C) * g.tw * g.th * g.blocks_per_tile;
+    g.grid = uint32_t(((nb + 7) / 8) * 8);
+    return true;
+}
+
+} // namespace lfs
+
+using namespace lfs;
+
+extern "C" size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t channels) {
+    (void)channels;
+    return raster_ws(nullptr, C, N).bytes;
+}
+
+static int raster_check(uint32_t N, uint32_t channels, const lfs_cameras* cams, uint32_t tile_size, RasterGeom& g) {
+    if (!cams || !cams->viewmats0 || !cams->Ks || cams->C == 0) return LFS_E_INVALID;
+    if (cams->camera_model != LFS_CAMERA_PINHOLE && cams->camera_model != LFS_CAMERA_FISHEYE) return LFS_E_UNSUPPORTED;
+    if (channels < 1 || channels > 4) return LFS_E_UNSUPPORTED; // Rasterization.cpp:65 asserts 3; depth modes need 1 and 4
+    if (!raster_geom(cams, tile_size, g)) return LFS_E_UNSUPPORTED;
+    (void)N;
+    return LFS_OK;
+}
+
+extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
+    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
+    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
+    const lfs_cameras* cams, uint32_t tile_size, const lfs_ut_params* ut_params,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    float* render_colors, float* render_alphas, int32_t* last_ids,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    (void)ut_params; // carried by the reference signature, unused by its rasterizer as well
+    RasterGeom g;
+    int rc = raster_check(N, channels, cams, tile_size, g);
+    if (rc) return rc;
+    if (!render_colors || !render_alphas || !last_ids || !tile_offsets || !workspace) return LFS_E_INVALID;
+    if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
+    const uint32_t C = cams->C;
+    RasterWs w = raster_ws(workspace, C, N);
+    if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
+    if (N > 0 && (!means || !quats || !scales || !colors || !opacities)) return LFS_E_INVALID;
+    if (n_isects > 0 && !flatten_ids) return LFS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
+    hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
+    const size_t CN = size_t(C) * N;
+    if (CN > 0) {
+        const dim3 pg(uint32_t((CN + 255) / 256));
+        if (uniform) hipLaunchKernelGGL(raster_pack_kernel<true>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
+        else hipLaunchKernelGGL(raster_pack_kernel<false>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
+    }
+#define LFS_FWD(CD, UNI)                                                                                         \
+    hipLaunchKernelGGL((raster_fwd_kernel<CD, UNI>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,        \
+                       cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
+                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, flatten_ids, int32_t(n_isects), \
+                       render_colors, render_alphas, last_ids)
+    switch (channels * 2 + (uniform ? 1 : 0)) {
+    case 2: LFS_FWD(1, false); break; case 3: LFS_FWD(1, true); break;
+    case 4: LFS_FWD(2, false); break; case 5: LFS_FWD(2, true); break;
+    case 6: LFS_FWD(3, false); break; case 7: LFS_FWD(3, true); break;
+    case 8: LFS_FWD(4, false); break; default: LFS_FWD(4, true); break;
+    }
+#undef LFS_FWD
+    return (int)hipGetLastError();
+}
+
+extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
+    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
+    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
+    const lfs_cameras* cams, uint32_t tile_size, const lfs_ut_params* ut_params,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    const float* render_alphas, const int32_t* last_ids,
+    const float* v_render_colors, const float* v_render_alphas,
+    float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    (void)ut_params;
+    RasterGeom g;
+    int rc = raster_check(N, channels, cams, tile_size, g);
+    if (rc) return rc;
+    if (!workspace || !tile_offsets) return LFS_E_INVALID;
+    if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
+    const uint32_t C = cams->C;
+    RasterWs w = raster_ws(workspace, C, N);
+    if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
+    if (N == 0) return LFS_OK;
+    if (!means || !quats || !scales || !colors || !opacities || !v_means || !v_quats || !v_scales || !v_colors || !v_opacities) return LFS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
+    const size_t CN = size_t(C) * N;
+    hipError_t e = hipMemsetAsync(w.acc, 0, sizeof(float) * ACC_STRIDE * CN, s);
+    if (e != hipSuccess) return (int)e;
+    if (channels > 3) { e = hipMemsetAsync(v_colors, 0, sizeof(float) * channels * CN, s); if (e != hipSuccess) return (int)e; }
+    // the workspace is self-contained per call: camera state and records are rebuilt here
+    hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
+    {
+        const dim3 pg(uint32_t((CN + 255) / 256));
+        if (uniform) hipLaunchKernelGGL(raster_pack_kernel<true>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
+        else hipLaunchKernelGGL(raster_pack_kernel<false>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
+    }
+    if (n_isects > 0) {
+        if (!flatten_ids || !render_alphas || !last_ids || !v_render_colors || !v_render_alphas) return LFS_E_INVALID;
+#define LFS_BWD(CD, UNI)                                                                                         \
+    hipLaunchKernelGGL((raster_bwd_kernel<CD, UNI>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,        \
+                       cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
+                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, flatten_ids, int32_t(n_isects), \
+                       render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors)
+        switch (channels * 2 + (uniform ? 1 : 0)) {
+        case 2: LFS_BWD(1, false); break; case 3: LFS_BWD(1, true); break;
+        case 4: LFS_BWD(2, false); break; case 5: LFS_BWD(2, true); break;
+        case 6: LFS_BWD(3, false); break; case 7: LFS_BWD(3, true); break;
+        case 8: LFS_BWD(4, false); break; default: LFS_BWD(4, true); break;
+        }
+#undef LFS_BWD
+    }
+    const dim3 fg((N + 255) / 256);
+    if (uniform) hipLaunchKernelGGL(raster_finish_kernel<true>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities);
+    else hipLaunchKernelGGL(raster_finish_kernel<false>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,297 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+numpy/ctypes front-end of oracle/liboracle.so (our CPU restatement of the
+reference's gsplat ops + fastgs Adam, see oracle_ops.hpp) and, when present, of
+oracle/_ref/libtorch_impl_ref.so (the reference's own tests/torch_impl.cpp
+compiled in place).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this package; the product (lichtfeld-studio_amd/)
+never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+PINHOLE, ORTHO, FISHEYE = 0, 1, 2
+ROLLING_TOP_TO_BOTTOM, ROLLING_LEFT_TO_RIGHT, ROLLING_BOTTOM_TO_TOP, ROLLING_RIGHT_TO_LEFT, GLOBAL = range(5)
+
+
+def build(ref: bool = True) -> None:
+    """Compile liboracle.so (always) and _ref (only when /root/reference exists)."""
+    subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True, capture_output=True)
+    if ref and os.path.exists("/root/reference/tests/torch_impl.cpp"):
+        subprocess.run(["make", "-C", _HERE, "ref"], check=True, capture_output=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        _LIB = C.CDLL(path)
+        _LIB.orc_intersect_tile_count.restype = C.c_int64
+    return _LIB
+
+
+def ref_lib():
+    """The reference's own CPU implementation, or None when it was not built."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "libtorch_impl_ref.so")
+        if not os.path.exists(path):
+            return None
+        import torch  # noqa: F401  (libtorch must be loaded first)
+        _REF = C.CDLL(path)
+        _REF.ref_isect_tiles.restype = C.c_int64
+        _REF.ref_cpu_stage_pipeline.restype = C.c_int64
+    return _REF
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dt(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "f32", C.c_float
+    if dtype == np.float64:
+        return "f64", C.c_double
+    raise TypeError(dtype)
+
+
+def _c(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ut(ut, dtype):
+    if ut is None:
+        ut = (0.1, 2.0, 0.0, 0.1, 1.0)
+    return np.asarray(ut, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------
+def quats_to_rotmats(quats, dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    q = _c(quats, dtype)
+    out = np.empty((q.shape[0], 3, 3), dtype)
+    getattr(lib(), f"orc_quats_to_rotmats_{sfx}")(C.c_int64(q.shape[0]), _p(q), _p(out))
+    return out
+
+
+def projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmats1, Ks, width, height,
+                             eps2d=0.3, near_plane=0.01, far_plane=1e4, radius_clip=0.0, calc_compensations=False,
+                             camera_model=PINHOLE, ut_params=None, rs_type=GLOBAL,
+                             radial_coeffs=None, tangential_coeffs=None, thin_prism_coeffs=None, dtype=np.float32):
+    """Returns radii[C,N,2] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], compensations|None.
+    Culled entries hold 0 (the reference leaves them uninitialised)."""
+    sfx, ct = _dt(dtype)
+    means, quats, scales = _c(means, dtype), _c(quats, dtype), _c(scales, dtype)
+    opacities = _c(opacities, dtype)
+    v0, v1, Ks = _c(viewmats0, dtype), _c(viewmats1, dtype), _c(Ks, dtype)
+    rad, tan, thin = _c(radial_coeffs, dtype), _c(tangential_coeffs, dtype), _c(thin_prism_coeffs, dtype)
+    Cn, N = Ks.shape[0], means.shape[0]
+    radii = np.zeros((Cn, N, 2), np.int32)
+    means2d = np.zeros((Cn, N, 2), dtype)
+    depths = np.zeros((Cn, N), dtype)
+    conics = np.zeros((Cn, N, 3), dtype)
+    comp = np.zeros((Cn, N), dtype) if calc_compensations else None
+    ut = _ut(ut_params, dtype)
+    getattr(lib(), f"orc_projection_ut_{sfx}")(
+        C.c_uint32(Cn), C.c_uint32(N), _p(means), _p(quats), _p(scales), _p(opacities), _p(v0), _p(v1), _p(Ks),
+        C.c_uint32(width), C.c_uint32(height), ct(eps2d), ct(near_plane), ct(far_plane), ct(radius_clip),
+        C.c_int(camera_model), _p(ut), C.c_int(rs_type),
+        _p(rad), C.c_int(0 if rad is None else rad.shape[-1]), _p(tan), _p(thin), C.c_int(0 if thin is None else thin.shape[-1]),
+        _p(radii), _p(means2d), _p(depths), _p(conics), _p(comp))
+    return radii, means2d, depths, conics, comp
+
+
+def spherical_harmonics_fwd(degree, dirs, coeffs, masks=None, dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    dirs, coeffs = _c(dirs, dtype), _c(coeffs, dtype)
+    m = None if masks is None else np.ascontiguousarray(masks, np.uint8)
+    N, K = dirs.size // 3, coeffs.shape[-2]
+    colors = np.zeros(dirs.shape, dtype)
+    getattr(lib(), f"orc_sh_fwd_{sfx}")(C.c_int64(N), C.c_int(K), C.c_int(degree), _p(dirs), _p(coeffs), _p(m), _p(colors))
+    return colors
+
+
+def spherical_harmonics_bwd(degree, dirs, coeffs, masks, v_colors, compute_v_dirs=True, dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    dirs, coeffs, v_colors = _c(dirs, dtype), _c(coeffs, dtype), _c(v_colors, dtype)
+    m = None if masks is None else np.ascontiguousarray(masks, np.uint8)
+    N, K = dirs.size // 3, coeffs.shape[-2]
+    v_coeffs = np.zeros(coeffs.shape, dtype)
+    v_dirs = np.zeros(dirs.shape, dtype) if compute_v_dirs else None
+    getattr(lib(), f"orc_sh_bwd_{sfx}")(C.c_int64(N), C.c_int(K), C.c_int(degree), _p(dirs), _p(coeffs), _p(m),
+                                        _p(v_colors), _p(v_coeffs), _p(v_dirs))
+    return v_coeffs, v_dirs
+
+
+def intersect_tile(means2d, radii, depths, C_, tile_size, tile_width, tile_height, sort=True):
+    """means2d [C,N,2] f32, radii [C,N,2] i32, depths [C,N] f32 ->
+    tiles_per_gauss [C,N] i32, isect_ids [I] i64, flatten_ids [I] i32."""
+    means2d, depths = _c(means2d, np.float32), _c(depths, np.float32)
+    radii = _c(radii, np.int32)
+    N = means2d.shape[1]
+    tpg = np.zeros((C_, N), np.int32)
+    n = lib().orc_intersect_tile_count(C.c_uint32(C_), C.c_uint32(N), _p(means2d), _p(radii),
+                                       C.c_uint32(tile_size), C.c_uint32(tile_width), C.c_uint32(tile_height), _p(tpg))
+    ids = np.zeros(n, np.int64)
+    flat = np.zeros(n, np.int32)
+    if n:
+        lib().orc_intersect_tile_emit(C.c_uint32(C_), C.c_uint32(N), _p(means2d), _p(radii), _p(depths),
+                                      C.c_uint32(tile_size), C.c_uint32(tile_width), C.c_uint32(tile_height),
+                                      C.c_int(int(sort)), C.c_int64(n), _p(ids), _p(flat))
+    return tpg, ids, flat
+
+
+def intersect_offset(isect_ids, C_, tile_width, tile_height):
+    ids = _c(isect_ids, np.int64)
+    out = np.zeros((C_, tile_height, tile_width), np.int32)
+    lib().orc_intersect_offset(C.c_int64(ids.shape[0]), _p(ids), C.c_uint32(C_), C.c_uint32(tile_width), C.c_uint32(tile_height), _p(out))
+    return out
+
+
+def _raster_common(means, quats, scales, colors, opacities, backgrounds, masks, viewmats0, viewmats1, Ks,
+                   radial, tangential, thin, tile_offsets, flatten_ids, dtype):
+    means, quats, scales = _c(means, dtype), _c(quats, dtype), _c(scales, dtype)
+    colors, opacities = _c(colors, dtype), _c(opacities, dtype)
+    bg = None if backgrounds is None or np.size(backgrounds) == 0 else _c(backgrounds, dtype)
+    m = None if masks is None else np.ascontiguousarray(masks, np.uint8)
+    v0, v1, Ks = _c(viewmats0, dtype), _c(viewmats1, dtype), _c(Ks, dtype)
+    rad, tan, th = _c(radial, dtype), _c(tangential, dtype), _c(thin, dtype)
+    offs, flat = _c(tile_offsets, np.int32), _c(flatten_ids, np.int32)
+    return means, quats, scales, colors, opacities, bg, m, v0, v1, Ks, rad, tan, th, offs, flat
+
+
+def rasterize_fwd(means, quats, scales, colors, opacities, backgrounds, masks, width, height, tile_size,
+                  viewmats0, viewmats1, Ks, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs,
+                  tile_offsets, flatten_ids, dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    (means, quats, scales, colors, opacities, bg, m, v0, v1, Ks, rad, tan, th, offs, flat) = _raster_common(
+        means, quats, scales, colors, opacities, backgrounds, masks, viewmats0, viewmats1, Ks,
+        radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids, dtype)
+    Cn, N, CD = offs.shape[0], means.shape[0], colors.shape[-1]
+    rc = np.zeros((Cn, height, width, CD), dtype)
+    ra = np.zeros((Cn, height, width, 1), dtype)
+    li = np.zeros((Cn, height, width), np.int32)
+    getattr(lib(), f"orc_rasterize_fwd_{sfx}")(
+        C.c_uint32(Cn), C.c_uint32(N), C.c_int64(flat.shape[0]), C.c_uint32(CD), _p(means), _p(quats), _p(scales),
+        _p(colors), _p(opacities), _p(bg), _p(m), C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile_size),
+        _p(v0), _p(v1), _p(Ks), C.c_int(camera_model), C.c_int(rs_type),
+        _p(rad), C.c_int(0 if rad is None else rad.shape[-1]), _p(tan), _p(th), C.c_int(0 if th is None else th.shape[-1]),
+        _p(offs), _p(flat), _p(rc), _p(ra), _p(li))
+    return rc, ra, li
+
+
+def rasterize_bwd(means, quats, scales, colors, opacities, backgrounds, masks, width, height, tile_size,
+                  viewmats0, viewmats1, Ks, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs,
+                  tile_offsets, flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    (means, quats, scales, colors, opacities, bg, m, v0, v1, Ks, rad, tan, th, offs, flat) = _raster_common(
+        means, quats, scales, colors, opacities, backgrounds, masks, viewmats0, viewmats1, Ks,
+        radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids, dtype)
+    ra, li = _c(render_alphas, dtype), _c(last_ids, np.int32)
+    vrc, vra = _c(v_render_colors, dtype), _c(v_render_alphas, dtype)
+    Cn, N, CD = offs.shape[0], means.shape[0], colors.shape[-1]
+    v_means, v_quats, v_scales = np.zeros_like(means), np.zeros_like(quats), np.zeros_like(scales)
+    v_colors, v_opac = np.zeros_like(colors), np.zeros_like(opacities)
+    getattr(lib(), f"orc_rasterize_bwd_{sfx}")(
+        C.c_uint32(Cn), C.c_uint32(N), C.c_int64(flat.shape[0]), C.c_uint32(CD), _p(means), _p(quats), _p(scales),
+        _p(colors), _p(opacities), _p(bg), _p(m), C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile_size),
+        _p(v0), _p(v1), _p(Ks), C.c_int(camera_model), C.c_int(rs_type),
+        _p(rad), C.c_int(0 if rad is None else rad.shape[-1]), _p(tan), _p(th), C.c_int(0 if th is None else th.shape[-1]),
+        _p(offs), _p(flat), _p(ra), _p(li), _p(vrc), _p(vra),
+        _p(v_means), _p(v_quats), _p(v_scales), _p(v_colors), _p(v_opac))
+    return v_means, v_quats, v_scales, v_colors, v_opac
+
+
+def relocation(opacities, scales, ratios, binoms, n_max, dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    o, s, b = _c(opacities, dtype), _c(scales, dtype), _c(binoms, dtype)
+    r = _c(ratios, np.int32)
+    no, ns = np.zeros_like(o), np.zeros_like(s)
+    getattr(lib(), f"orc_relocation_{sfx}")(C.c_int64(o.shape[0]), _p(o), _p(s), _p(r), _p(b), C.c_int(n_max), _p(no), _p(ns))
+    return no, ns
+
+
+def add_noise(raw_opacities, raw_scales, raw_quats, noise, means, current_lr, dtype=np.float32):
+    """Returns the updated means (the op itself works in place)."""
+    sfx, ct = _dt(dtype)
+    o, s, q, n = _c(raw_opacities, dtype), _c(raw_scales, dtype), _c(raw_quats, dtype), _c(noise, dtype)
+    m = np.array(means, dtype=dtype, copy=True, order="C")
+    getattr(lib(), f"orc_add_noise_{sfx}")(C.c_int64(o.shape[0]), _p(o), _p(s), _p(q), _p(n), _p(m), ct(current_lr))
+    return m
+
+
+def adam_step(param, exp_avg, exp_avg_sq, grad, lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp, dtype=np.float32):
+    """Returns (param, exp_avg, exp_avg_sq) after one step (copies)."""
+    sfx, ct = _dt(dtype)
+    p = np.array(param, dtype=dtype, copy=True, order="C")
+    m = np.array(exp_avg, dtype=dtype, copy=True, order="C")
+    v = np.array(exp_avg_sq, dtype=dtype, copy=True, order="C")
+    g = _c(grad, dtype)
+    getattr(lib(), f"orc_adam_step_{sfx}")(C.c_int64(p.size), _p(p), _p(m), _p(v), _p(g),
+                                           ct(lr), ct(beta1), ct(beta2), ct(eps), ct(bc1_rcp), ct(bc2_sqrt_rcp))
+    return p, m, v
+
+
+def pixel_rays(width, height, viewmat0, viewmat1, K, camera_model=PINHOLE, rs_type=GLOBAL,
+               radial=None, tangential=None, thin_prism=None, dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    v0, v1, K = _c(viewmat0, dtype), _c(viewmat1, dtype), _c(K, dtype)
+    rad, tan, th = _c(radial, dtype), _c(tangential, dtype), _c(thin_prism, dtype)
+    o = np.zeros((height, width, 3), dtype)
+    d = np.zeros((height, width, 3), dtype)
+    valid = np.zeros((height, width), np.uint8)
+    getattr(lib(), f"orc_pixel_rays_{sfx}")(
+        C.c_uint32(width), C.c_uint32(height), _p(v0), _p(v1), _p(K), C.c_int(camera_model), C.c_int(rs_type),
+        _p(rad), C.c_int(0 if rad is None else rad.shape[-1]), _p(tan), _p(th), C.c_int(0 if th is None else th.shape[-1]),
+        _p(o), _p(d), _p(valid))
+    return o, d, valid.astype(bool)
+
+
+# ---- the reference's own CPU code (oracle/_ref) -------------------------------
+def ref_quat_to_rotmat(quats):
+    q = _c(quats, np.float32)
+    out = np.empty((q.shape[0], 3, 3), np.float32)
+    ref_lib().ref_quat_to_rotmat(C.c_int64(q.shape[0]), _p(q), _p(out))
+    return out
+
+
+def ref_spherical_harmonics(degree, dirs, coeffs):
+    d, c = _c(dirs, np.float32), _c(coeffs, np.float32)
+    out = np.empty((d.shape[0], 3), np.float32)
+    ref_lib().ref_spherical_harmonics(C.c_int64(d.shape[0]), C.c_int(c.shape[1]), C.c_int(degree), _p(d), _p(c), _p(out))
+    return out
+
+
+def ref_isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height, sort=True):
+    m, d, r = _c(means2d, np.float32), _c(depths, np.float32), _c(radii, np.int32)
+    Cn, N = m.shape[0], m.shape[1]
+    tpg = np.zeros((Cn, N), np.int32)
+    args = (C.c_int64(Cn), C.c_int64(N), _p(m), _p(r), _p(d), C.c_int(tile_size), C.c_int(tile_width), C.c_int(tile_height), C.c_int(int(sort)))
+    n = ref_lib().ref_isect_tiles(*args, _p(tpg), None, None, C.c_int64(-1))
+    ids, flat = np.zeros(n, np.int64), np.zeros(n, np.int32)
+    ref_lib().ref_isect_tiles(*args, _p(tpg), _p(ids), _p(flat), C.c_int64(n))
+    return tpg, ids, flat
+
+
+def ref_fully_fused_projection(means, quats, scales, viewmat, K, width, height, eps2d=0.3, near_plane=0.01, far_plane=1e10):
+    m, q, s = _c(means, np.float32), _c(quats, np.float32), _c(scales, np.float32)
+    v, K = _c(viewmat, np.float32), _c(K, np.float32)
+    N = m.shape[0]
+    radii, m2 = np.zeros((N, 2), np.int32), np.zeros((N, 2), np.float32)
+    d, c = np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    ref_lib().ref_fully_fused_projection(C.c_int64(N), _p(m), _p(q), _p(s), _p(v), _p(K), C.c_int(width), C.c_int(height),
+                                         C.c_float(eps2d), C.c_float(near_plane), C.c_float(far_plane), _p(radii), _p(m2), _p(d), _p(c))
+    return radii, m2, d, c
