@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train-images/sec (fwd + bwd + Adam) on the 3DGUT hot path.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] (SYN-B of SURVEY.md §8d): 1 000 000 synthetic Gaussians,
+1920x1080, SH degree 3, 16x16 tiles, 64 orbit cameras, lrs of default_optimization_params.json,
+MSE loss against a fixed random target (rasterizer-only metric). One "step" = every rank renders
+one view, backpropagates, the parameter gradients are summed over ranks (one RCCL all-reduce of
+the flat 59*N-float bucket) and every rank applies the fused Adam step: weak scaling, value =
+world * K / max-over-ranks(time).  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0, with
+  roofline     : the dominant kernel (by HIP-event time inside the timed region) against the
+                 8 TB/s HBM peak, algorithmic bytes from SURVEY.md §8d with the measured V and I;
+  cpu_baseline : the CPU oracle (oracle/, "port") timed on this box's host cores for ONE training
+                 image of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
+
+
+def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems: int) -> dict:
+    """Compulsory HBM bytes per launch, keyed by the event names of csrc/."""
+    return {
+        "projection_ut": 52 * N + 24 * V,
+        "sh_fwd": 13 * N + (12 * K + 12) * V,
+        "isect_count_scan": 32 * N + 4 * T,
+        "isect_scatter": 28 * N + 12 * I,
+        "isect_tile_sort": 24 * I,
+        "raster_pack": 60 * N + 64 * N,
+        "raster_fwd": 60 * I + 20 * P,
+        "raster_bwd": 60 * I + 24 * P + 56 * N + 112 * V,
+        "raster_finish": 64 * N + 44 * N + 56 * N,
+        "sh_bwd": 24 * V + 12 * K * V + 12 * K * N + 12 * K * V + 12 * V,
+        "adam_multi": 28 * adam_elems,
+        "adam": 28 * adam_elems,
+    }
+
+
+def cpu_baseline(scene, view: int, target, threads: int) -> dict:
+    """Oracle ("port" of the reference CUDA kernels) on the host cores: ONE training image of the
+    same workload — activations, UT projection, SH, tile intersection + stable sort, compositing fwd,
+    MSE gradient, compositing bwd, SH bwd, activation bwd, Adam on all 59*N parameters."""
+    import numpy as np
+
+    import oracle
+    oracle.lib()
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    sc = scene
+    W, H, deg = sc.width, sc.height, sc.sh_degree
+    means = sc.means.numpy()
+    raw_q, raw_s, raw_o = sc.raw_quats.numpy(), sc.raw_scales.numpy(), sc.raw_opacities.numpy()
+    sh0, shN = sc.sh0.numpy(), sc.shN.numpy()
+    vm, Kmat = sc.viewmats[view:view + 1].numpy(), sc.Ks[view:view + 1].numpy()
+    tgt = target.numpy()
+    t0 = time.perf_counter()
+    quats = raw_q / np.linalg.norm(raw_q, axis=-1, keepdims=True)
+    scales, opac = np.exp(raw_s), 1.0 / (1.0 + np.exp(-raw_o))
+    sh = np.concatenate([sh0, shN], 1)
+    radii, m2, d, con, _ = oracle.projection_ut_3dgs_fused(means, quats, scales, opac, vm, None, Kmat, W, H)
+    dirs = means - np.linalg.inv(vm[0])[:3, 3].astype(np.float32)
+    mask = (radii[0] > 0).all(-1)
+    col = oracle.spherical_harmonics_fwd(deg, dirs, sh, mask)
+    colors = np.maximum(col + 0.5, 0.0)[None]
+    ts = 16
+    tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
+    tpg, ids, flat = oracle.intersect_tile(m2, radii, d, 1, ts, tw, th, True)
+    offs = oracle.intersect_offset(ids, 1, tw, th)
+    bg = np.zeros((1, 3), np.float32)
+    rc, ra, li = oracle.rasterize_fwd(means, quats, scales, colors, opac[None], bg, None, W, H, ts, vm, None, Kmat, 0, 4, None, None, None, offs, flat)
+    img = np.clip(rc[0].transpose(2, 0, 1), 0, 1)
+    v_img = 2.0 * (img - tgt) / img.size
+    v_img = np.where((rc[0].transpose(2, 0, 1) > 0) & (rc[0].transpose(2, 0, 1) < 1), v_img, 0.0)
+    v_rc = np.ascontiguousarray(v_img.transpose(1, 2, 0))[None].astype(np.float32)
+    v_ra = np.zeros_like(ra)
+    g_means, g_quats, g_scales, g_colors, g_opac = oracle.rasterize_bwd(
+        means, quats, scales, colors, opac[None], bg, None, W, H, ts, vm, None, Kmat, 0, 4, None, None, None, offs, flat, ra, li, v_rc, v_ra)
+    g_col = np.where(col + 0.5 > 0, g_colors[0], 0.0).astype(np.float32)
+    g_sh, g_dirs = oracle.spherical_harmonics_bwd(deg, dirs, sh, mask, g_col, True)
+    g_means = g_means + g_dirs
+    g_raw_o = g_opac[0] * opac * (1 - opac)
+    g_raw_s = g_scales * scales
+    dotq = (g_quats * quats).sum(-1, keepdims=True)
+    g_raw_q = (g_quats - dotq * quats) / np.linalg.norm(raw_q, axis=-1, keepdims=True)
+    params = [means, sh0, shN, raw_s, raw_q, raw_o]
+    grads = [g_means, g_sh[:, :1], g_sh[:, 1:], g_raw_s, g_raw_q, g_raw_o]
+    for p, g in zip(params, grads):
+        z = np.zeros_like(p)
+        oracle.adam_step(p, z, z, np.ascontiguousarray(g, dtype=np.float32), 1e-3, 0.9, 0.999, 1e-15, 10.0, 31.6)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "train-images/sec", "cores": threads, "kind": "port",
+            "sample": f"1 training image of the same workload (N={means.shape[0]}, {W}x{H}, SH deg {deg}; "
+                      f"V={int(mask.sum())}, I={int(len(ids))}): oracle fwd+bwd+Adam, {dt:.1f} s wall, OpenMP x{threads}"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="syn-b", choices=["syn-a", "syn-b", "syn-c", "syn-d"])
+    ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
+    ap.add_argument("--views-per-rank", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import lichtfeld_studio_amd as lfs
+    from lichtfeld_studio_amd import capi, scenes
+    from lichtfeld_studio_amd import dist as lfs_dist
+    from lichtfeld_studio_amd.trainer import GutTrainer
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    capi.load_library()
+    rank, world, local_rank = lfs_dist.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    maker = {"syn-a": scenes.syn_a, "syn-b": scenes.syn_b, "syn-c": scenes.syn_c, "syn-d": scenes.syn_d}[args.workload]
+    kw = {"n": args.n} if args.n else {}
+    if args.workload == "syn-a":
+        kw["sh_degree"] = 0
+    scene = maker(**kw)
+    n_views = scene.viewmats.shape[0]
+    trainer = GutTrainer(scene, device, iterations=7000, world=world, rank=rank, views_per_rank=args.views_per_rank)
+    targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
+
+    for _ in range(args.warmup):
+        trainer.train_step(targets)
+    lfs_dist.barrier()
+    torch.cuda.synchronize()
+    profile = not args.no_profile
+    if profile:
+        capi.profile_collect()
+        capi.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(targets)
+    lfs_dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernels = {}
+    if profile:
+        capi.profile_enable(False)
+        kernels = capi.profile_collect()
+    elapsed = lfs_dist.max_over_ranks(elapsed, device)
+
+    if rank != 0:
+        return
+    images = world * args.views_per_rank * args.steps
+    N = scene.N
+    K = (scene.sh_degree + 1) ** 2
+    V = int(trainer.last_visible.sum().item())
+    I = int(trainer.last_n_isects)
+    P = scene.width * scene.height
+    T = ((scene.width + 15) // 16) * ((scene.height + 15) // 16)
+    adam_elems = sum(p.numel() for p in trainer.model.parameters())
+    if trainer.iteration <= 1000:
+        adam_elems -= trainer.model.shN.numel()  # the shN group is skipped while iteration <= 1000 (fused_adam.cpp:68-70)
+    bytes_per = algorithmic_bytes(N, V, I, P, T, K, adam_elems)
+
+    roofline = None
+    per_kernel = {}
+    if kernels:
+        for name, (ms, cnt) in sorted(kernels.items(), key=lambda kv: -kv[1][0]):
+            avg_ms = ms / max(cnt, 1)
+            b = bytes_per.get(name)
+            per_kernel[name] = {"avg_ms": round(avg_ms, 4), "launches": cnt,
+                                "alg_GBps": round(b / (avg_ms * 1e-3) / 1e9, 1) if b else None}
+        dom = max(kernels.items(), key=lambda kv: kv[1][0])[0]
+        avg_s = kernels[dom][0] / max(kernels[dom][1], 1) * 1e-3
+        achieved = bytes_per.get(dom, 0) / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "alg_bytes_per_launch": int(bytes_per.get(dom, 0)), "avg_launch_ms": round(avg_s * 1e3, 4),
+                    "evals_per_s": round(256.0 * I / avg_s, 1) if dom.startswith("raster") else None}
+        # PMC-measured HBM traffic (separate rocprofv3 --pmc passes, see profiles/): filled when a
+        # measurement for this exact workload has been committed.
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                ent = tj.get(f"{args.workload}:{N}", {}).get(dom)
+                if ent is not None:
+                    roofline["traffic"] = ent
+            except Exception:
+                pass
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        threads = args.cpu_threads or (os.cpu_count() or 1)
+        try:
+            cpu = cpu_baseline(scene, 0, scenes.target_image(scene.height, scene.width, seed=43), threads)
+        except Exception as e:  # the oracle is optional at bench time; say so instead of failing the run
+            cpu = {"value": None, "unit": "train-images/sec", "cores": threads, "kind": "port", "sample": f"failed: {e}"}
+
+    out = {
+        "metric": "train-images/sec (fwd+bwd+Adam), 1M Gaussians @1080p",
+        "value": round(images / elapsed, 3), "unit": "train-images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{scene.name}: {N} Gaussians, {scene.width}x{scene.height}, SH degree {scene.sh_degree}, "
+                               f"16x16 tiles, {n_views} orbit cameras, MSE loss, default_optimization_params lrs",
+                   "global_batch": world * args.views_per_rank, "views_per_rank": args.views_per_rank,
+                   "parallelism": f"dp{world}", "visible_gaussians": V, "n_isects": I},
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
+    }
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

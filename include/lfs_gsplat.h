@@ -185,6 +185,13 @@ typedef struct lfs_adam_tensor {
 #define LFS_ADAM_MAX_TENSORS 8
 LFS_API int lfs_adam_step_multi(const lfs_adam_tensor* tensors /* host array */, int32_t n_tensors, lfs_stream_t stream);
 
+/* ---- instrumentation (not in the reference): per-kernel HIP-event timing on the launch stream.
+ *      lfs_profile_enable(1) makes every entry point bracket its principal kernel(s) with events;
+ *      lfs_profile_collect waits for them, sums by kernel name (names: max_entries x 64 chars)
+ *      and clears the log. Returns the number of distinct names written. */
+LFS_API int lfs_profile_enable(int on);
+LFS_API int lfs_profile_collect(int max_entries, char* names, float* total_ms, int* counts);
+
 /* Library identification: returns "lfs_gsplat gfx950 <abi-version>" */
 LFS_API const char* lfs_version(void);
 

@@ -28,11 +28,12 @@ SOURCES = {
     "intersect.hip": ["-ffp-contract=off"],
     "mcmc.hip": ["-ffp-contract=off"],
     "adam.hip": ["-ffp-contract=off"],
+    "prof.hip": [],
     # no SLP packing: v_pk_* operand pairing forces SGPR shuffles right after the scalar record
     # load and defeats the software prefetch (measured on the ISA); plain v_fma with SGPR operands
     "raster.hip": ["-fno-slp-vectorize"],
 }
-HEADERS = ["lfs_math.cuh", "lfs_camera.cuh", os.path.join("..", "..", "include", "lfs_gsplat.h")]
+HEADERS = ["lfs_math.cuh", "lfs_camera.cuh", "lfs_prof.h", os.path.join("..", "..", "include", "lfs_gsplat.h")]
 
 
 def _stale(obj: str, src: str) -> bool:

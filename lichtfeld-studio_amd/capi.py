@@ -78,7 +78,7 @@ EXPORTS = [
     "lfs_projection_ut_3dgs_fused", "lfs_spherical_harmonics_fwd", "lfs_spherical_harmonics_bwd",
     "lfs_intersect_tile_workspace_bytes", "lfs_intersect_tile_count", "lfs_intersect_tile_emit", "lfs_intersect_offset",
     "lfs_rasterize_workspace_bytes", "lfs_rasterize_to_pixels_from_world_3dgs_fwd", "lfs_rasterize_to_pixels_from_world_3dgs_bwd",
-    "lfs_quats_to_rotmats", "lfs_relocation", "lfs_add_noise", "lfs_adam_step", "lfs_adam_step_multi", "lfs_version",
+    "lfs_quats_to_rotmats", "lfs_relocation", "lfs_add_noise", "lfs_adam_step", "lfs_adam_step_multi", "lfs_version", "lfs_profile_enable", "lfs_profile_collect",
 ]
 
 
@@ -171,3 +171,19 @@ def workspace(nbytes: int, device: torch.device, tag: str) -> torch.Tensor:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
+
+
+def profile_enable(on: bool) -> None:
+    load_library().lfs_profile_enable(C.c_int(int(on)))
+
+
+def profile_collect(max_entries: int = 64) -> dict:
+    """{kernel name: (total_ms, launches)} since the last collect; waits for the recorded events."""
+    names = C.create_string_buffer(64 * max_entries)
+    ms = (C.c_float * max_entries)()
+    counts = (C.c_int * max_entries)()
+    n = load_library().lfs_profile_collect(C.c_int(max_entries), names, ms, counts)
+    out = {}
+    for i in range(n):
+        out[names.raw[64 * i:64 * (i + 1)].split(b"\0", 1)[0].decode()] = (float(ms[i]), int(counts[i]))
+    return out

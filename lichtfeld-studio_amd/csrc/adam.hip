@@ -11,6 +11,7 @@
 // Compiled with -ffp-contract=off: identical rounding to the reference formula.
 #include <hip/hip_runtime.h>
 #include "../../include/lfs_gsplat.h"
+#include "lfs_prof.h"
 
 namespace lfs {
 
@@ -89,6 +90,7 @@ extern "C" int lfs_adam_step(
     if (n_elements == 0) return LFS_OK;
     if (n_elements < 0 || !param || !exp_avg || !exp_avg_sq || !param_grad) return LFS_E_INVALID;
     const lfs::AdamScalars s{lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp};
+    lfs::ProfScope prof("adam", (hipStream_t)stream);
     hipLaunchKernelGGL(lfs::adam_kernel, dim3(lfs::adam_blocks(n_elements)), dim3(256), 0, (hipStream_t)stream,
                        param, exp_avg, exp_avg_sq, param_grad, n_elements, s);
     return (int)hipGetLastError();
@@ -115,6 +117,7 @@ extern "C" int lfs_adam_step_multi(const lfs_adam_tensor* tensors, int32_t n_ten
         a.block_begin[a.n + 1] = a.block_begin[a.n] + int32_t(b);
         ++a.n;
     }
+    lfs::ProfScope prof("adam_multi", (hipStream_t)stream);
     hipLaunchKernelGGL(lfs::adam_multi_kernel, dim3(a.block_begin[a.n]), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

@@ -20,6 +20,7 @@
 // not depend on the (atomic, unordered) bucket fill. tile_offsets falls out of
 // the scan, so intersect_offset is free on this path.
 #include "lfs_math.cuh"
+#include "lfs_prof.h"
 #include "../../include/lfs_gsplat.h"
 
 namespace lfs {
@@ -402,6 +403,7 @@ extern "C" int lfs_intersect_tile_count(
     hipError_t e = hipMemsetAsync(w.totals, 0, (char*)w.offsets - (char*)w.totals, s); // totals + cursor
     if (e != hipSuccess) return (int)e;
     const size_t total = size_t(C) * N;
+    lfs::ProfScope prof("isect_count_scan", s);
     if (total > 0) {
         if (!means2d || !radii || !tiles_per_gauss) return LFS_E_INVALID;
         const uint32_t pb = isect_per_block(total);
@@ -446,12 +448,15 @@ extern "C" int lfs_intersect_tile_emit(
         }
         const uint32_t pb = isect_per_block(total);
         const uint32_t blocks = uint32_t((total + pb - 1) / pb);
+        int tok = lfs::prof_begin("isect_scatter", s);
         if (size_t(T) * 8 <= LDS_HIST_LIMIT)
             hipLaunchKernelGGL(isect_scatter_kernel<true>, dim3(blocks), dim3(1024), size_t(T) * 8, s, C, N, pb, means2d, radii, depths,
                                float(tile_size), tile_width, tile_height, tile_n_bits, w.offsets, w.cursor, isect_ids, flatten_ids);
         else
             hipLaunchKernelGGL(isect_scatter_kernel<false>, dim3(blocks), dim3(1024), 0, s, C, N, pb, means2d, radii, depths,
                                float(tile_size), tile_width, tile_height, tile_n_bits, w.offsets, w.cursor, isect_ids, flatten_ids);
+        lfs::prof_end(tok, s);
+        lfs::ProfScope prof_sort("isect_tile_sort", s);
         // size classes: <= 4096 entries (32 KiB LDS), <= 16384 (128 KiB LDS), larger -> global
         hipLaunchKernelGGL(tile_sort_lds_kernel<256>, dim3(T), dim3(256), 4096 * 8, s, 2u, 4096u, w.offsets, isect_ids, flatten_ids);
         hipLaunchKernelGGL(tile_sort_lds_kernel<1024>, dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, w.offsets, isect_ids, flatten_ids);

@@ -8,6 +8,7 @@
 // arithmetic keeps the sigma-point cancellation (weights -99 / +16.67) on the
 // same rounding path as the oracle.
 #include "lfs_camera.cuh"
+#include "lfs_prof.h"
 
 namespace lfs {
 
@@ -132,6 +133,7 @@ extern "C" int lfs_projection_ut_3dgs_fused(
     lfs_ut_params ut = {0.1f, 2.f, 0.f, 0.1f, 1};
     if (ut_params) ut = *ut_params;
     dim3 grid((N + 255) / 256, cams->C);
+    lfs::ProfScope prof("projection_ut", (hipStream_t)stream);
     hipLaunchKernelGGL(lfs::projection_ut_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                        N, means, quats, scales, opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
                        radii, means2d, depths, conics, compensations);

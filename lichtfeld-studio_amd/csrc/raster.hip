@@ -26,6 +26,7 @@
 //  * finish : one pass maps the accumulator through the quaternion / scale /
 //             mean vjp (done per (pixel, Gaussian) in the reference).
 #include "lfs_camera.cuh"
+#include "lfs_prof.h"
 
 namespace lfs {
 
@@ -550,10 +551,12 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
     const size_t CN = size_t(C) * N;
     if (CN > 0) {
+        lfs::ProfScope prof_pack("raster_pack", s);
         const dim3 pg(uint32_t((CN + 255) / 256));
         if (uniform) hipLaunchKernelGGL(raster_pack_kernel<true>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
         else hipLaunchKernelGGL(raster_pack_kernel<false>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
     }
+    lfs::ProfScope prof("raster_fwd", s);
 #define LFS_FWD(CD, UNI)                                                                                         \
     hipLaunchKernelGGL((raster_fwd_kernel<CD, UNI>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,        \
                        cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
@@ -603,6 +606,7 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
         else hipLaunchKernelGGL(raster_pack_kernel<false>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
     }
     if (n_isects > 0) {
+        lfs::ProfScope prof("raster_bwd", s);
         if (!flatten_ids || !render_alphas || !last_ids || !v_render_colors || !v_render_alphas) return LFS_E_INVALID;
 #define LFS_BWD(CD, UNI)                                                                                         \
     hipLaunchKernelGGL((raster_bwd_kernel<CD, UNI>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,        \
@@ -618,6 +622,7 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
 #undef LFS_BWD
     }
     const dim3 fg((N + 255) / 256);
+    lfs::ProfScope prof_fin("raster_finish", s);
     if (uniform) hipLaunchKernelGGL(raster_finish_kernel<true>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities);
     else hipLaunchKernelGGL(raster_finish_kernel<false>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities);
     return (int)hipGetLastError();

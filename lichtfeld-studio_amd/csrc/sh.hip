@@ -11,6 +11,7 @@
 // evaluates the whole (cheap) basis polynomial and picks its own entry with a
 // select tree — VALU is ~1/3 of the memory time.
 #include "lfs_math.cuh"
+#include "lfs_prof.h"
 #include "../../include/lfs_gsplat.h"
 
 namespace lfs {
@@ -201,6 +202,7 @@ extern "C" int lfs_spherical_harmonics_fwd(
     dim3 grid((threads + 255) / 256), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int deg = int(degrees_to_use);
+    lfs::ProfScope prof("sh_fwd", s);
     switch (lpg) {
     case 1: hipLaunchKernelGGL(lfs::sh_fwd_kernel<1>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, colors); break;
     case 4: hipLaunchKernelGGL(lfs::sh_fwd_kernel<4>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, colors); break;
@@ -222,6 +224,7 @@ extern "C" int lfs_spherical_harmonics_bwd(
     dim3 grid((threads + 255) / 256), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int deg = int(degrees_to_use);
+    lfs::ProfScope prof("sh_bwd", s);
     switch (lpg) {
     case 1: hipLaunchKernelGGL(lfs::sh_bwd_kernel<1>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
     case 4: hipLaunchKernelGGL(lfs::sh_bwd_kernel<4>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;

@@ -1,0 +1,74 @@
+"""Data-parallel sharding of training views (new capability: the reference is single-process,
+single-GPU). One process per GPU; Gaussians are replicated; rank r renders the
+views  step*world + r ; ONE all-reduce (RCCL over xGMI, backend "nccl" on ROCm) sums the flat
+59*N-float gradient bucket before the identical Adam step on every rank, so parameters stay
+bit-identical across ranks.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; world == 1 -> no process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def views_for_step(step: int, rank: int, world: int, n_views: int, views_per_rank: int = 1) -> List[int]:
+    """Round-robin assignment: global batch of world*views_per_rank views per step, disjoint across ranks."""
+    base = step * world * views_per_rank
+    return [(base + rank * views_per_rank + k) % n_views for k in range(views_per_rank)]
+
+
+class GradBucket:
+    """Flat fp32 bucket [sum(numel)] with per-parameter views, all-reduced in one collective."""
+
+    def __init__(self, params: List[torch.Tensor]):
+        self.sizes = [p.numel() for p in params]
+        self.shapes = [p.shape for p in params]
+        total = sum(self.sizes)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        self.views = []
+        o = 0
+        for n, s in zip(self.sizes, self.shapes):
+            self.views.append(self.flat[o:o + n].view(s))
+            o += n
+
+    def gather(self, grads: List[Optional[torch.Tensor]]) -> None:
+        for v, g in zip(self.views, grads):
+            if g is None:
+                v.zero_()
+            else:
+                v.copy_(g)
+
+    def all_reduce(self, average: bool = False) -> None:
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if average:
+                self.flat.div_(dist.get_world_size())
+
+
+def barrier() -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return value

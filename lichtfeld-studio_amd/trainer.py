@@ -1,0 +1,60 @@
+"""Minimal stand-in for Trainer::train_step (/root/reference/src/training/trainer.cpp:579-760) on
+the --gut path: render -> loss -> backward -> (all-reduce) -> FusedAdam::step -> zero_grad ->
+scheduler.step. The reference's app shell (dataset IO, strategies, viewer, checkpoints) is out of
+scope; the loss here is the rasterizer-only MSE of SURVEY.md §8d.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import dist as lfs_dist
+from .fused_adam import ExponentialLR, FusedAdam, default_param_groups
+from .rasterizer import Camera, RenderMode, SplatModel, rasterize
+from .scenes import Scene
+
+
+class GutTrainer:
+    def __init__(self, scene: Scene, device, iterations: int = 7000, world: int = 1, rank: int = 0,
+                 views_per_rank: int = 1, fused_adam: bool = True):
+        self.device, self.world, self.rank, self.views_per_rank = device, world, rank, views_per_rank
+        sc = scene.to(device)
+        self.scene = sc
+        mk = lambda t: t.clone().contiguous().requires_grad_(True)
+        self.model = SplatModel(mk(sc.means), mk(sc.sh0), mk(sc.shN), mk(sc.raw_scales), mk(sc.raw_quats), mk(sc.raw_opacities), sc.sh_degree)
+        self.optimizer = FusedAdam(default_param_groups(self.model), fused=fused_adam)
+        self.scheduler = ExponentialLR(self.optimizer, gamma=0.01 ** (1.0 / iterations), param_group_index=0)
+        self.bg = torch.zeros(3, device=device)
+        self.bucket = lfs_dist.GradBucket(self.model.parameters()) if world > 1 else None
+        self.iteration = 0
+        self.last_n_isects = 0
+        self.last_visible = 0
+
+    def camera(self, view: int) -> Camera:
+        sc = self.scene
+        return Camera(sc.viewmats[view:view + 1].contiguous(), sc.Ks[view:view + 1].contiguous(), sc.width, sc.height)
+
+    def train_step(self, targets: List[torch.Tensor], views: Optional[List[int]] = None) -> float:
+        """One optimisation step on this rank's share of the global view batch."""
+        self.iteration += 1
+        if views is None:
+            views = lfs_dist.views_for_step(self.iteration - 1, self.rank, self.world, self.scene.viewmats.shape[0], self.views_per_rank)
+        total_views = self.world * len(views)
+        loss_value = None
+        for k, v in enumerate(views):
+            out = rasterize(self.camera(v), self.model, self.bg, 1.0, False, False, RenderMode.RGB)
+            loss = torch.nn.functional.mse_loss(out.image, targets[k % len(targets)]) / total_views
+            loss.backward()
+            loss_value = loss.detach()
+            self.last_n_isects, self.last_visible = out.n_isects, out.visibility
+        if self.bucket is not None:
+            params = self.model.parameters()
+            self.bucket.gather([p.grad for p in params])
+            self.bucket.all_reduce()
+            for p, gv in zip(params, self.bucket.views):
+                p.grad = gv
+        self.optimizer.step(self.iteration)
+        self.optimizer.zero_grad(set_to_none=True)
+        self.scheduler.step()
+        return loss_value
