@@ -1,0 +1,94 @@
+"""CPU, world_size 2 over gloo: the N>1 path — disjoint view shards, ONE all-reduce of the flat
+gradient bucket, identical Adam step on every rank => parameters stay bit-identical across ranks and
+equal the single-process result on the concatenated view batch (up to fp32 summation order).
+The HIP kernels cannot run here; the per-view gradient is a deterministic stand-in and the Adam
+arithmetic comes from the oracle (the checker), which is exactly what is being verified: the
+data-parallel plumbing of lichtfeld-studio_amd/dist.py."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fake_grads(params, view):
+    g = torch.Generator().manual_seed(1000 + view)
+    return [torch.randn(p.shape, generator=g) * (1 + 0.1 * i) for i, p in enumerate(params)]
+
+
+def _adam_all(oracle, params, states, grads, t):
+    import math
+    out = []
+    for p, (m, v), g in zip(params, states, grads):
+        pn, mn, vn = oracle.adam_step(p.numpy(), m, v, g.numpy().astype(np.float32), 1e-2, 0.9, 0.999, 1e-15,
+                                      1 / (1 - 0.9 ** t), 1 / math.sqrt(1 - 0.999 ** t))
+        out.append((torch.from_numpy(pn), (mn, vn)))
+    return out
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import oracle
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import dist as ld
+    r, w, _ = ld.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(0)
+    params = [torch.randn(50, 3, generator=g), torch.randn(50, 15, 3, generator=g), torch.randn(50, generator=g)]
+    states = [(np.zeros(p.shape, np.float32), np.zeros(p.shape, np.float32)) for p in params]
+    bucket = ld.GradBucket(params)
+    for step in range(3):
+        views = ld.views_for_step(step, rank, world, 8, views_per_rank=2)
+        grads = [torch.zeros_like(p) for p in params]
+        for v in views:
+            for a, b in zip(grads, _fake_grads(params, v)):
+                a += b
+        bucket.gather(grads)
+        bucket.all_reduce()
+        res = _adam_all(oracle, params, states, [x.clone() for x in bucket.views], step + 1)
+        params = [x[0] for x in res]
+        states = [x[1] for x in res]
+    t = ld.max_over_ranks(float(rank), torch.device("cpu"))
+    ld.barrier()
+    q.put((rank, [p.numpy() for p in params], t))
+    dist.destroy_process_group()
+
+
+def test_dp2_matches_single_process_and_ranks_stay_identical():
+    import oracle
+    oracle.lib()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, t0), (_, p1, t1) = results
+    assert t0 == 1.0 and t1 == 1.0  # max over ranks
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b), "replicas diverged"
+    # single process on the concatenated batch
+    sys.path.insert(0, ROOT)
+    from lichtfeld_studio_amd import dist as ld
+    g = torch.Generator().manual_seed(0)
+    params = [torch.randn(50, 3, generator=g), torch.randn(50, 15, 3, generator=g), torch.randn(50, generator=g)]
+    states = [(np.zeros(p.shape, np.float32), np.zeros(p.shape, np.float32)) for p in params]
+    for step in range(3):
+        views = [v for r in range(2) for v in ld.views_for_step(step, r, 2, 8, 2)]
+        grads = [torch.zeros_like(p) for p in params]
+        for v in views:
+            for a, b in zip(grads, _fake_grads(params, v)):
+                a += b
+        res = _adam_all(oracle, params, states, grads, step + 1)
+        params, states = [x[0] for x in res], [x[1] for x in res]
+    for a, b in zip(p0, params):
+        np.testing.assert_allclose(a, b.numpy(), rtol=1e-5, atol=1e-6)

@@ -1,0 +1,150 @@
+"""GPU parity (through the C ABI): K1 projection_ut_3dgs_fused and K2/K9 spherical harmonics vs
+the oracle.  K1 is compiled with -ffp-contract=off so the pinhole/global-shutter path agrees with
+the fp32 oracle to the last bit except for libm (logf only feeds ceil()); tolerances below are the
+reference's own (tests/test_garden_data.cpp:250-274: radii +-1, 1e-4 rel/abs) or tighter."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import make_gaussians, n, pinhole_K, small_rotation_viewmat, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _proj_both(oracle, lfs, ops, means, quats, scales, opac, vm0, vm1, K, W, H, model, shutter, rad=None, tan=None, thin=None,
+               calc_comp=False, ut=None, **kw):
+    o = oracle.projection_ut_3dgs_fused(means, quats, scales, opac, vm0, vm1, K, W, H, calc_compensations=calc_comp,
+                                        camera_model=int(model), rs_type=int(shutter), radial_coeffs=rad, tangential_coeffs=tan,
+                                        thin_prism_coeffs=thin, ut_params=None if ut is None else (ut.alpha, ut.beta, ut.kappa, ut.in_image_margin_factor, float(ut.require_all_sigma_points_valid)), **kw)
+    g = ops.projection_ut_3dgs_fused(t(means), t(quats), t(scales), t(opac), t(vm0), t(vm1), t(K), W, H,
+                                     kw.get("eps2d", 0.3), kw.get("near_plane", 0.01), kw.get("far_plane", 1e4), kw.get("radius_clip", 0.0),
+                                     calc_comp, model, ut, shutter, t(rad), t(tan), t(thin))
+    return o, [n(x) for x in g]
+
+
+def _assert_proj(o, g, exact=False, min_visible=100):
+    o_r, g_r = o[0], g[0]
+    vis = (o_r > 0).all(-1) & (g_r > 0).all(-1)
+    assert vis.sum() >= min_visible
+    assert (o_r != g_r).mean() < (1e-9 if exact else 2e-3)     # cull decisions / ceil() flips
+    assert np.abs(o_r - g_r).max() <= (0 if exact else 1) or ((o_r > 0).all(-1) != (g_r > 0).all(-1)).mean() < 2e-3
+    for k in (1, 2, 3):
+        a, b = g[k][vis], o[k][vis]
+        if exact:
+            assert np.array_equal(a, b)
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-3 if k == 1 else 1e-4)
+    # culled entries are zero-filled
+    dead = ~(g_r > 0).all(-1)
+    assert np.all(g[1][dead] == 0) and np.all(g[2][dead] == 0) and np.all(g[3][dead] == 0)
+
+
+def test_projection_pinhole_global_bit_exact(lfs, oracle_mod):
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng(1)
+    means, quats, scales, opac = make_gaussians(rng, 20000)
+    vm = np.stack([small_rotation_viewmat(rng), small_rotation_viewmat(rng, 0.3, 0.5)])
+    K = pinhole_K(300, 320, 200, C=2)
+    o, g = _proj_both(oracle_mod, lfs, ops, means, quats, scales, opac, vm, None, K, 320, 200, lfs.CameraModelType.PINHOLE, lfs.ShutterType.GLOBAL)
+    _assert_proj(o, g, exact=True, min_visible=5000)
+
+
+def test_projection_without_opacities_and_with_compensations(lfs, oracle_mod):
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng(2)
+    means, quats, scales, _ = make_gaussians(rng, 5000)
+    vm = small_rotation_viewmat(rng)[None]; K = pinhole_K(200, 256, 256)
+    o, g = _proj_both(oracle_mod, lfs, ops, means, quats, scales, None, vm, None, K, 256, 256, lfs.CameraModelType.PINHOLE, lfs.ShutterType.GLOBAL,
+                      calc_comp=True, eps2d=0.5, near_plane=3.2, far_plane=5.0, radius_clip=1.5)
+    _assert_proj(o, g, exact=True)
+    vis = (o[0] > 0).all(-1)
+    np.testing.assert_allclose(g[4][vis], o[4][vis], rtol=1e-6)
+    assert (~vis).sum() > 500  # near/far/radius_clip culls exercised
+
+
+def test_projection_ut_params_any_valid(lfs, oracle_mod):
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng(3)
+    means, quats, scales, opac = make_gaussians(rng, 5000, spread=2.5, smin=0.05, smax=0.4)
+    vm = small_rotation_viewmat(rng)[None]; K = pinhole_K(150, 128, 96)
+    ut = lfs.UnscentedTransformParameters(0.3, 1.0, 0.5, 0.05, False)
+    o, g = _proj_both(oracle_mod, lfs, ops, means, quats, scales, opac, vm, None, K, 128, 96, lfs.CameraModelType.PINHOLE, lfs.ShutterType.GLOBAL, ut=ut)
+    _assert_proj(o, g, exact=False)
+
+
+def test_projection_opencv_distortion(lfs, oracle_mod):
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng(4)
+    means, quats, scales, opac = make_gaussians(rng, 8000)
+    vm = small_rotation_viewmat(rng)[None]; K = pinhole_K(220, 256, 192)
+    rad = np.array([[-0.12, 0.03, 0.0, 0.0]], np.float32)     # the L2 pads radial to 4 (rasterizer.cpp:187-192)
+    tan = np.array([[0.002, -0.001]], np.float32)
+    o, g = _proj_both(oracle_mod, lfs, ops, means, quats, scales, opac, vm, None, K, 256, 192, lfs.CameraModelType.PINHOLE, lfs.ShutterType.GLOBAL, rad=rad, tan=tan)
+    _assert_proj(o, g)
+    rad6 = np.array([[-0.1, 0.02, 0.001, 0.01, 0.0, 0.0]], np.float32)
+    thin = np.array([[0.001, 0.0, -0.002, 0.0]], np.float32)
+    o, g = _proj_both(oracle_mod, lfs, ops, means, quats, scales, opac, vm, None, K, 256, 192, lfs.CameraModelType.PINHOLE, lfs.ShutterType.GLOBAL, rad=rad6, tan=tan, thin=thin)
+    _assert_proj(o, g)
+
+
+def test_projection_fisheye(lfs, oracle_mod):
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng(5)
+    means, quats, scales, opac = make_gaussians(rng, 8000, spread=2.0, zmin=1.5)
+    vm = small_rotation_viewmat(rng)[None]; K = pinhole_K(120, 256, 256)
+    for rad in (np.array([[0.01, -0.002, 0.0, 0.0]], np.float32), np.array([[-0.02, 0.004, -0.001, 0.0002]], np.float32)):
+        o, g = _proj_both(oracle_mod, lfs, ops, means, quats, scales, opac, vm, None, K, 256, 256, lfs.CameraModelType.FISHEYE, lfs.ShutterType.GLOBAL, rad=rad)
+        _assert_proj(o, g)
+
+
+@pytest.mark.parametrize("shutter", [0, 1, 2, 3])
+def test_projection_rolling_shutter(lfs, oracle_mod, shutter):
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng(6 + shutter)
+    means, quats, scales, opac = make_gaussians(rng, 4000)
+    vm0 = small_rotation_viewmat(rng)[None]; vm1 = small_rotation_viewmat(rng, 0.08, 0.15)[None]
+    K = pinhole_K(200, 192, 128)
+    o, g = _proj_both(oracle_mod, lfs, ops, means, quats, scales, opac, vm0, vm1, K, 192, 128, lfs.CameraModelType.PINHOLE, lfs.ShutterType(shutter))
+    _assert_proj(o, g)
+
+
+def test_projection_empty(lfs):
+    from lichtfeld_studio_amd import ops
+    z = lambda *s: torch.zeros(*s, device="cuda:0")
+    out = ops.projection_ut_3dgs_fused(z(0, 3), z(0, 4), z(0, 3), z(0), torch.eye(4, device="cuda:0")[None].contiguous(), None,
+                                       torch.eye(3, device="cuda:0")[None].contiguous(), 64, 64, 0.3, 0.01, 1e4, 0.0, False, lfs.CameraModelType.PINHOLE)
+    assert out[0].shape == (1, 0, 2) and out[3].shape == (1, 0, 3)
+
+
+@pytest.mark.parametrize("degree,K", [(0, 1), (0, 16), (1, 4), (2, 9), (3, 16), (4, 25), (1, 16), (2, 25)])
+def test_spherical_harmonics_fwd_bwd(lfs, oracle_mod, degree, K):
+    """reference tolerance 1e-4 (tests/test_garden_data.cpp:430,495,511); measured ~1e-6."""
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng(20 + degree + K)
+    N = 7001
+    dirs = (rng.standard_normal((N, 3)) * rng.uniform(0.2, 6, (N, 1))).astype(np.float32)
+    coeffs = rng.standard_normal((N, K, 3)).astype(np.float32)
+    masks = rng.random(N) > 0.3
+    vcol = rng.standard_normal((N, 3)).astype(np.float32)
+    for m in (None, masks):
+        o = oracle_mod.spherical_harmonics_fwd(degree, dirs, coeffs, m)
+        g = n(ops.spherical_harmonics_fwd(degree, t(dirs), t(coeffs), t(m, torch.bool)))
+        np.testing.assert_allclose(g, o, rtol=1e-5, atol=1e-5)
+        if m is not None:
+            assert np.all(g[~m] == 0)
+        ovc, ovd = oracle_mod.spherical_harmonics_bwd(degree, dirs, coeffs, m, vcol, True)
+        gvc, gvd = ops.spherical_harmonics_bwd(K, degree, t(dirs), t(coeffs), t(m, torch.bool), t(vcol), True)
+        np.testing.assert_allclose(n(gvc), ovc, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(n(gvd), ovd, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ovd).max()))
+        gvc2, gvd2 = ops.spherical_harmonics_bwd(K, degree, t(dirs), t(coeffs), t(m, torch.bool), t(vcol), False)
+        assert gvd2 is None and torch.equal(gvc2, gvc)
+
+
+def test_sh_matches_reference_golden_on_gpu(lfs):
+    """straight against the vectors produced by the reference's tests/torch_impl.cpp"""
+    import os
+    from lichtfeld_studio_amd import ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sh_fwd.npz"))
+    for deg in range(5):
+        got = n(ops.spherical_harmonics_fwd(deg, t(g["dirs"]), t(g[f"coeffs{deg}"]), None))
+        np.testing.assert_allclose(got, g[f"colors{deg}"], rtol=1e-4, atol=1e-4)

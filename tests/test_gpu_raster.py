@@ -1,0 +1,192 @@
+"""GPU parity: K7 / K8 world-space rasterization forward and backward vs the oracle.
+
+Tolerance model (the reference itself uses __expf / rsqrt / fast division and a
+warp-order-dependent float accumulation, so fp32 bit equality does not exist even between two of
+its own runs):
+  forward : mean |rgb diff| <= 2e-6; <= 0.1 % of pixels deviate by more than 1/255 + 1e-4 (one
+            alpha-threshold / early-termination flip moves a pixel by at most one contribution);
+            alpha likewise; last_ids equal on >= 99.9 % of the pixels.
+  backward: per-tensor relative L2 error <= 1e-3 against the fp32 oracle AND against the fp64
+            oracle (measured: 1e-5 .. 2e-4), with the oracle's forward outputs fed to both sides.
+"""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import make_gaussians, n, pinhole_K, rel_l2, small_rotation_viewmat, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _lists(oracle, means, quats, scales, opac, vm0, vm1, K, W, H, ts, model, shutter, rad, tan, thin):
+    C = K.shape[0]
+    radii, m2, d, _, _ = oracle.projection_ut_3dgs_fused(means, quats, scales, opac, vm0, vm1, K, W, H, camera_model=int(model),
+                                                         rs_type=int(shutter), radial_coeffs=rad, tangential_coeffs=tan, thin_prism_coeffs=thin)
+    tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
+    _, ids, flat = oracle.intersect_tile(m2, radii, d, C, ts, tw, th, True)
+    return oracle.intersect_offset(ids, C, tw, th), flat
+
+
+def _run(oracle, lfs, ops, rng, N, W, H, ts=16, C=1, cdim=3, bg=True, masks=None, model=None, shutter=None, rad=None, tan=None, thin=None,
+         vm1=None, spread=1.0, smin=0.01, smax=0.06, check_bwd=True):
+    model = lfs.CameraModelType.PINHOLE if model is None else model
+    shutter = lfs.ShutterType.GLOBAL if shutter is None else shutter
+    means, quats, scales, opac = make_gaussians(rng, N, spread=spread, smin=smin, smax=smax)
+    vm0 = np.stack([small_rotation_viewmat(rng, 0.05 + 0.1 * c, 0.1) for c in range(C)])
+    K = pinhole_K(0.8 * W, W, H, C)
+    colors = rng.random((C, N, cdim)).astype(np.float32)
+    opacs = np.tile(opac[None], (C, 1)) * rng.uniform(0.8, 1.0, (C, 1)).astype(np.float32)
+    bgc = rng.random((C, cdim)).astype(np.float32) if bg else None
+    offs, flat = _lists(oracle, means, quats, scales, opac, vm0, vm1, K, W, H, ts, model, shutter, rad, tan, thin)
+    assert len(flat) > 0
+    args_o = (means, quats, scales, colors, opacs, bgc, masks, W, H, ts, vm0, vm1, K, int(model), int(shutter), rad, tan, thin, offs, flat)
+    o_rc, o_ra, o_li = oracle.rasterize_fwd(*args_o)
+    args_g = (t(means), t(quats), t(scales), t(colors), t(opacs), t(bgc), t(masks, torch.bool), W, H, ts, t(vm0), t(vm1), t(K), model, None, shutter,
+              t(rad), t(tan), t(thin), t(offs, torch.int32), t(flat, torch.int32))
+    g_rc, g_ra, g_li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args_g)
+    assert g_rc.shape == (C, H, W, cdim) and g_ra.shape == (C, H, W, 1) and g_li.shape == (C, H, W) and g_li.dtype == torch.int32
+    d = np.abs(n(g_rc) - o_rc)
+    assert d.mean() < 2e-6, d.mean()
+    assert (d > 1 / 255 + 1e-4).mean() < 1e-3
+    da = np.abs(n(g_ra) - o_ra)
+    assert da.mean() < 2e-6 and (da > 1 / 255 + 1e-4).mean() < 1e-3
+    assert (n(g_li) == o_li).mean() > 0.999
+    assert (o_ra > 0.05).mean() > 0.05, "degenerate test scene"
+    if not check_bwd:
+        return
+    v_rc = rng.standard_normal(o_rc.shape).astype(np.float32)
+    v_ra = rng.standard_normal(o_ra.shape).astype(np.float32)
+    og = oracle.rasterize_bwd(*args_o, o_ra, o_li, v_rc, v_ra)
+    og64 = oracle.rasterize_bwd(*args_o, o_ra, o_li, v_rc, v_ra, dtype=np.float64)
+    gg = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args_g, t(o_ra), t(o_li, torch.int32), t(v_rc), t(v_ra))
+    for name, a, b, c in zip(["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"], gg, og, og64):
+        assert a.shape == tuple(b.shape), name
+        assert np.isfinite(n(a)).all(), name
+        assert rel_l2(n(a), b) < 1e-3, (name, rel_l2(n(a), b))
+        assert rel_l2(n(a), c) < 1e-3, (name, rel_l2(n(a), c))
+    return gg
+
+
+def test_raster_pinhole_rgb(lfs, oracle_mod):
+    from lichtfeld_studio_amd import ops
+    _run(oracle_mod, lfs, ops, np.random.default_rng(0), 10000, 256, 256)
+
+
+def test_raster_ragged_image_no_background(lfs, oracle_mod):
+    from lichtfeld_studio_amd import ops
+    _run(oracle_mod, lfs, ops, np.random.default_rng(1), 4000, 203, 117, bg=False)
+
+
+@pytest.mark.parametrize("cdim", [1, 2, 4])
+def test_raster_channel_counts(lfs, oracle_mod, cdim):
+    """depth (1) and RGB+depth (4) render modes of rasterizer.cpp:278-297"""
+    from lichtfeld_studio_amd import ops
+    _run(oracle_mod, lfs, ops, np.random.default_rng(2 + cdim), 3000, 128, 96, cdim=cdim)
+
+
+@pytest.mark.parametrize("ts", [8, 32])
+def test_raster_other_tile_sizes(lfs, oracle_mod, ts):
+    from lichtfeld_studio_amd import ops
+    _run(oracle_mod, lfs, ops, np.random.default_rng(10 + ts), 3000, 160, 100, ts=ts)
+
+
+def test_raster_two_cameras(lfs, oracle_mod):
+    """C > 1: geometry indexed with g % N, colours / opacities with the flattened id."""
+    from lichtfeld_studio_amd import ops
+    _run(oracle_mod, lfs, ops, np.random.default_rng(20), 3000, 128, 96, C=2)
+
+
+def test_raster_tile_masks(lfs, oracle_mod):
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng(21)
+    masks = rng.random((1, 6, 8)) > 0.3
+    _run(oracle_mod, lfs, ops, rng, 3000, 128, 96, masks=masks)
+
+
+def test_raster_dense_scene_early_termination(lfs, oracle_mod):
+    """big opaque Gaussians: pixels saturate (T <= 1e-4) long before the tile list ends"""
+    from lichtfeld_studio_amd import ops
+    _run(oracle_mod, lfs, ops, np.random.default_rng(22), 6000, 128, 128, spread=0.4, smin=0.05, smax=0.3)
+
+
+def test_raster_opencv_distortion(lfs, oracle_mod):
+    from lichtfeld_studio_amd import ops
+    _run(oracle_mod, lfs, ops, np.random.default_rng(23), 3000, 128, 96,
+         rad=np.array([[-0.1, 0.02, 0.0, 0.0]], np.float32), tan=np.array([[0.001, -0.002]], np.float32))
+
+
+def test_raster_fisheye(lfs, oracle_mod):
+    from lichtfeld_studio_amd import ops
+    _run(oracle_mod, lfs, ops, np.random.default_rng(24), 3000, 128, 128, model=lfs.CameraModelType.FISHEYE,
+         rad=np.array([[0.01, -0.002, 0.0, 0.0]], np.float32))
+
+
+@pytest.mark.parametrize("shutter", [0, 3])
+def test_raster_rolling_shutter(lfs, oracle_mod, shutter):
+    """per-pixel ray origin: the kernels' non-uniform-origin path"""
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng(25 + shutter)
+    _run(oracle_mod, lfs, ops, rng, 3000, 128, 96, shutter=lfs.ShutterType(shutter), vm1=small_rotation_viewmat(rng, 0.12, 0.2)[None])
+
+
+def test_raster_empty_intersections(lfs):
+    from lichtfeld_studio_amd import ops
+    dev = "cuda:0"
+    N, W, H = 10, 64, 48
+    means = torch.randn(N, 3, device=dev); quats = torch.randn(N, 4, device=dev); scales = torch.rand(N, 3, device=dev) + 0.1
+    colors = torch.rand(1, N, 3, device=dev); opac = torch.rand(1, N, device=dev); bg = torch.tensor([[0.3, 0.2, 0.1]], device=dev)
+    offs = torch.zeros((1, 3, 4), dtype=torch.int32, device=dev); flat = torch.zeros(0, dtype=torch.int32, device=dev)
+    vm = torch.eye(4, device=dev)[None].contiguous(); K = torch.tensor([[[50., 0, 32], [0, 50., 24], [0, 0, 1]]], device=dev)
+    rc, ra, li = ops.rasterize_to_pixels_from_world_3dgs_fwd(means, quats, scales, colors, opac, bg, None, W, H, 16, vm, None, K,
+                                                             lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, offs, flat)
+    assert torch.allclose(rc, bg.view(1, 1, 1, 3).expand_as(rc)) and float(ra.abs().max()) == 0 and int(li.abs().max()) == 0
+    g = ops.rasterize_to_pixels_from_world_3dgs_bwd(means, quats, scales, colors, opac, bg, None, W, H, 16, vm, None, K,
+                                                    lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, offs, flat,
+                                                    ra, li, torch.ones_like(rc), torch.ones_like(ra))
+    assert all(float(x.abs().max()) == 0 for x in g)
+
+
+def test_raster_unsupported_channels_raises(lfs):
+    from lichtfeld_studio_amd import ops
+    dev = "cuda:0"
+    z = lambda *s: torch.zeros(*s, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.rasterize_to_pixels_from_world_3dgs_fwd(z(4, 3), z(4, 4), z(4, 3), z(1, 4, 7), z(1, 4), None, None, 32, 32, 16,
+                                                    torch.eye(4, device=dev)[None].contiguous(), None, torch.eye(3, device=dev)[None].contiguous(),
+                                                    lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None,
+                                                    torch.zeros((1, 2, 2), dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev))
+
+
+def test_raster_bwd_is_linear_in_output_gradients_full_size(lfs):
+    """BASELINE config-2 sized property test (no oracle needed): the backward is linear in
+    (v_render_colors, v_render_alphas), fwd is deterministic, alpha in [0, 1], gradients finite."""
+    from lichtfeld_studio_amd import ops, scenes
+    from lichtfeld_studio_amd.rasterizer import Camera, SplatModel, rasterize
+    dev = torch.device("cuda:0")
+    sc = scenes.syn_b(n=1_000_000, n_views=4).to(dev)
+    model = SplatModel(sc.means, sc.sh0, sc.shN, sc.raw_scales, sc.raw_quats, sc.raw_opacities, 3)
+    cam = Camera(sc.viewmats[:1].contiguous(), sc.Ks[:1].contiguous(), sc.width, sc.height)
+    with torch.no_grad():
+        a = rasterize(cam, model, torch.zeros(3, device=dev))
+        b = rasterize(cam, model, torch.zeros(3, device=dev))
+    assert torch.equal(a.image, b.image) and torch.equal(a.alpha, b.alpha)
+    assert float(a.alpha.min()) >= 0 and float(a.alpha.max()) <= 1 and a.n_isects > 3_000_000
+    # linearity through the raw op
+    quats = torch.nn.functional.normalize(sc.raw_quats, dim=-1); scales = sc.raw_scales.exp(); opac = torch.sigmoid(sc.raw_opacities)[None]
+    radii, m2, d, _, _ = ops.projection_ut_3dgs_fused(sc.means, quats, scales, opac[0], cam.world_view_transform, None, cam.K, sc.width, sc.height,
+                                                      0.3, 0.01, 1e4, 0.0, False, lfs.CameraModelType.PINHOLE)
+    _, ids, flat, offs = ops.intersect_tile(m2, radii, d, None, None, 1, 16, 120, 68, True, return_offsets=True)
+    colors = torch.rand(1, sc.N, 3, device=dev)
+    fa = (sc.means, quats, scales, colors, opac, None, None, sc.width, sc.height, 16, cam.world_view_transform, None, cam.K,
+          lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, offs, flat)
+    rc, ra, li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*fa)
+    g = torch.Generator(device=dev).manual_seed(0)
+    v1, v2 = torch.randn(rc.shape, device=dev, generator=g), torch.randn(rc.shape, device=dev, generator=g)
+    w1, w2 = torch.randn(ra.shape, device=dev, generator=g), torch.randn(ra.shape, device=dev, generator=g)
+    g1 = ops.rasterize_to_pixels_from_world_3dgs_bwd(*fa, ra, li, v1, w1)
+    g2 = ops.rasterize_to_pixels_from_world_3dgs_bwd(*fa, ra, li, v2, w2)
+    g12 = ops.rasterize_to_pixels_from_world_3dgs_bwd(*fa, ra, li, (2 * v1 - 3 * v2).contiguous(), (2 * w1 - 3 * w2).contiguous())
+    for x1, x2, x12 in zip(g1, g2, g12):
+        assert torch.isfinite(x12).all()
+        lin = 2 * x1 - 3 * x2
+        assert float((x12 - lin).norm() / (lin.norm() + 1e-20)) < 1e-4

@@ -1,0 +1,92 @@
+"""CPU: host-side logic that needs no GPU — UT parameter round trip, scene determinism, view
+sharding, the flat gradient bucket, FusedAdam's bookkeeping (bias-correction reciprocals, the
+shN skip, per-parameter step counts) with the kernel call intercepted, ExponentialLR."""
+import math
+
+import numpy as np
+import torch
+
+
+def test_ut_params_roundtrip(lfs):
+    ut = lfs.UnscentedTransformParameters(0.2, 1.5, 0.1, 0.3, False)
+    back = lfs.UnscentedTransformParameters.from_tensor(ut.to_tensor())
+    assert abs(back.alpha - 0.2) < 1e-7 and abs(back.beta - 1.5) < 1e-7 and back.require_all_sigma_points_valid is False
+    d = lfs.UnscentedTransformParameters()
+    assert (d.alpha, d.beta, d.kappa, d.in_image_margin_factor, d.require_all_sigma_points_valid) == (0.1, 2.0, 0.0, 0.1, True)
+
+
+def test_enums_match_reference_values(lfs):
+    assert int(lfs.CameraModelType.PINHOLE) == 0 and int(lfs.CameraModelType.ORTHO) == 1 and int(lfs.CameraModelType.FISHEYE) == 2
+    assert int(lfs.ShutterType.ROLLING_TOP_TO_BOTTOM) == 0 and int(lfs.ShutterType.GLOBAL) == 4
+
+
+def test_scenes_are_deterministic_and_shaped(lfs):
+    from lichtfeld_studio_amd import scenes
+    a, b = scenes.syn_a(), scenes.syn_a()
+    assert torch.equal(a.means, b.means) and a.N == 10000 and a.width == 256
+    s = scenes.syn_b(n=2000, n_views=6)
+    assert s.sh0.shape == (2000, 1, 3) and s.shN.shape == (2000, 15, 3) and s.viewmats.shape == (6, 4, 4)
+    R = s.viewmats[:, :3, :3]
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(6, 3, 3), atol=1e-5)
+    # every camera sits on the radius-10 orbit (heights -1/0/1) and looks at the origin
+    cam_pos = -(R.transpose(1, 2) @ s.viewmats[:, :3, 3:]).squeeze(-1)
+    assert torch.allclose(cam_pos.norm(dim=-1), torch.sqrt(100 + cam_pos[:, 1] ** 2), atol=1e-4)
+
+
+def test_view_sharding_is_disjoint_and_covering(lfs):
+    from lichtfeld_studio_amd.dist import views_for_step
+    world, vpr, n_views = 4, 2, 64
+    seen = []
+    for step in range(8):
+        batch = [v for r in range(world) for v in views_for_step(step, r, world, n_views, vpr)]
+        assert len(set(batch)) == world * vpr
+        seen += batch
+    assert sorted(seen) == list(range(64))
+
+
+def test_grad_bucket_views_and_gather(lfs):
+    from lichtfeld_studio_amd.dist import GradBucket
+    ps = [torch.zeros(5, 3), torch.zeros(5, 1, 3), torch.zeros(5)]
+    b = GradBucket(ps)
+    assert b.flat.numel() == 15 + 15 + 5
+    gs = [torch.arange(15.).view(5, 3), None, torch.ones(5)]
+    b.gather(gs)
+    assert torch.equal(b.views[0], gs[0]) and torch.count_nonzero(b.views[1]) == 0 and torch.equal(b.flat[-5:], torch.ones(5))
+    b.all_reduce()  # no process group: a no-op
+
+
+def test_fused_adam_bookkeeping(lfs, monkeypatch):
+    """fused_adam.cpp:22-95: per-group options, lazy state, step_count++ even when the shN group is
+    skipped (iteration <= 1000), reciprocals in double then float."""
+    from lichtfeld_studio_amd import fused_adam, ops
+    calls = []
+    monkeypatch.setattr(ops, "adam_step_multi", lambda entries: calls.append(list(entries)))
+    ps = [torch.nn.Parameter(torch.zeros(4, 3)) for _ in range(6)]
+    groups = [{"params": [p], "lr": 0.1 * (i + 1)} for i, p in enumerate(ps)]
+    opt = fused_adam.FusedAdam(groups, fused=True)
+    for p in ps:
+        p.grad = torch.ones_like(p)
+    opt.step(iteration=1)
+    assert len(calls[-1]) == 5 and all(e[0] is not ps[2] for e in calls[-1])  # group 3 (shN) skipped
+    assert opt.state[id(ps[2])]["step_count"] == 1
+    e = calls[-1][0]
+    assert abs(e[4] - 0.1) < 1e-12 and abs(e[8] - 1 / (1 - 0.9)) < 1e-6 and abs(e[9] - 1 / math.sqrt(1 - 0.999)) < 1e-3
+    opt.step(iteration=1001)
+    assert len(calls[-1]) == 6
+    shn = [x for x in calls[-1] if x[0] is ps[2]][0]
+    assert abs(shn[8] - 1 / (1 - 0.9 ** 2)) < 1e-6  # its step_count advanced while skipped
+    ps[0].grad = None
+    opt.step(iteration=1002)
+    assert len(calls[-1]) == 5  # parameters without grad are skipped
+    opt.zero_grad()
+    assert all(p.grad is None for p in ps)
+
+
+def test_exponential_lr_only_touches_means_group(lfs):
+    from lichtfeld_studio_amd import fused_adam
+    ps = [torch.nn.Parameter(torch.zeros(2)) for _ in range(2)]
+    opt = fused_adam.FusedAdam([{"params": [ps[0]], "lr": 1.0}, {"params": [ps[1]], "lr": 1.0}])
+    sch = fused_adam.ExponentialLR(opt, gamma=0.01 ** (1 / 100))
+    for _ in range(100):
+        sch.step()
+    assert abs(opt.param_groups[0]["lr"] - 0.01) < 1e-9 and opt.param_groups[1]["lr"] == 1.0
