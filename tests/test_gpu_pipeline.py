@@ -57,7 +57,7 @@ def test_train_step_gradients_match_oracle(lfs, oracle_mod):
     loss.backward()
     o_loss, o_img, o_g, o_I = _oracle_step(oracle_mod, sc, 0, target.numpy(), 2)
     assert out.n_isects == o_I
-    assert abs(float(loss) - o_loss) < 1e-6
+    assert abs(float(loss.detach()) - o_loss) < 1e-6
     assert np.abs(n(out.image) - o_img).mean() < 2e-6
     m = tr.model
     for name, p in [("means", m.means), ("sh0", m.sh0), ("shN", m.shN), ("raw_scales", m.raw_scales), ("raw_quats", m.raw_quats), ("raw_opacities", m.raw_opacities)]:
@@ -97,7 +97,7 @@ def test_render_modes_and_background_gradient(lfs):
     assert torch.allclose(rgb.image, rgbd.image, atol=1e-6)
     covered = rgb.alpha[0] > 0.5
     d_exp = rgbd.depth[0][covered]
-    assert float(d_exp.min()) > 2.5 and float(d_exp.max()) < 9.0        # scene depth range of SYN-A
+    assert float(d_exp.detach().min()) > 2.5 and float(d_exp.detach().max()) < 9.0        # scene depth range of SYN-A
     rgb.image.sum().backward()
     # d(sum image)/d(bg_c) = sum over un-clamped pixels of (1 - alpha)
     expect = float(((1 - rgb.alpha[0]) * ((rgb.image[0] > 0) & (rgb.image[0] < 1))).sum())
