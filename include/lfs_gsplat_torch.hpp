@@ -1,0 +1,74 @@
+// libtorch-facing declarations of the drop-in backend: the SAME symbols (namespaces, names,
+// parameter types and order, return types) that /root/reference/gsplat/Ops.h:12-166 and
+// /root/reference/fastgs/optimizer/include/{adam_api.h:11-21, adam.h:9-20} declare, implemented
+// in lichtfeld-studio_amd/csrc/torch_ops.cpp on top of the C ABI (lfs_gsplat.h).
+// A reference build that links this library instead of gsplat_backend / fastgs_backend keeps
+// including its own Ops.h — the declarations are link-compatible; this header exists so the
+// wrappers can be compiled and tested without the reference tree.
+#pragma once
+#include <ATen/core/Tensor.h>
+#include <c10/util/Optional.h>
+#include <torch/torch.h>
+#include <tuple>
+
+// ---- vocabulary types (gsplat/Common.h:46-50, gsplat/Cameras.h:16-61) -------------------------
+namespace gsplat {
+enum CameraModelType { PINHOLE = 0, ORTHO = 1, FISHEYE = 2 };
+}
+enum class ShutterType { ROLLING_TOP_TO_BOTTOM, ROLLING_LEFT_TO_RIGHT, ROLLING_BOTTOM_TO_TOP, ROLLING_RIGHT_TO_LEFT, GLOBAL };
+
+struct UnscentedTransformParameters {
+    float alpha = 0.1f, beta = 2.f, kappa = 0.f;
+    float in_image_margin_factor = 0.1f;
+    bool require_all_sigma_points_valid = true;
+    torch::Tensor to_tensor() const;
+    static UnscentedTransformParameters from_tensor(const torch::Tensor& t);
+};
+
+namespace gsplat {
+using OptT = at::optional<at::Tensor>;
+
+at::Tensor spherical_harmonics_fwd(const uint32_t degrees_to_use, const at::Tensor dirs, const at::Tensor coeffs, const OptT masks);
+std::tuple<at::Tensor, at::Tensor> spherical_harmonics_bwd(const uint32_t K, const uint32_t degrees_to_use, const at::Tensor dirs,
+                                                           const at::Tensor coeffs, const OptT masks, const at::Tensor v_colors, bool compute_v_dirs);
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor means2d, const at::Tensor radii, const at::Tensor depths,
+                                                              const OptT camera_ids, const OptT gaussian_ids, const uint32_t C,
+                                                              const uint32_t tile_size, const uint32_t tile_width, const uint32_t tile_height,
+                                                              const bool sort);
+at::Tensor intersect_offset(const at::Tensor isect_ids, const uint32_t C, const uint32_t tile_width, const uint32_t tile_height);
+
+at::Tensor quats_to_rotmats(const at::Tensor quats);
+std::tuple<at::Tensor, at::Tensor> relocation(at::Tensor opacities, at::Tensor scales, at::Tensor ratios, at::Tensor binoms, const int n_max);
+void add_noise(at::Tensor raw_opacities, at::Tensor raw_scales, at::Tensor raw_quats, at::Tensor noise, at::Tensor means, const float current_lr);
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> projection_ut_3dgs_fused(
+    const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const OptT opacities, const at::Tensor viewmats0,
+    const OptT viewmats1, const at::Tensor Ks, const uint32_t image_width, const uint32_t image_height, const float eps2d,
+    const float near_plane, const float far_plane, const float radius_clip, const bool calc_compensations,
+    const CameraModelType camera_model, const UnscentedTransformParameters ut_params, ShutterType rs_type,
+    const OptT radial_coeffs, const OptT tangential_coeffs, const OptT thin_prism_coeffs);
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3dgs_fwd(
+    const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
+    const OptT backgrounds, const OptT masks, const uint32_t image_width, const uint32_t image_height, const uint32_t tile_size,
+    const at::Tensor viewmats0, const OptT viewmats1, const at::Tensor Ks, const CameraModelType camera_model,
+    const UnscentedTransformParameters ut_params, ShutterType rs_type, const OptT radial_coeffs, const OptT tangential_coeffs,
+    const OptT thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids);
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3dgs_bwd(
+    const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
+    const OptT backgrounds, const OptT masks, const uint32_t image_width, const uint32_t image_height, const uint32_t tile_size,
+    const at::Tensor viewmats0, const OptT viewmats1, const at::Tensor Ks, const CameraModelType camera_model,
+    const UnscentedTransformParameters ut_params, ShutterType rs_type, const OptT radial_coeffs, const OptT tangential_coeffs,
+    const OptT thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids, const at::Tensor render_alphas,
+    const at::Tensor last_ids, const at::Tensor v_render_colors, const at::Tensor v_render_alphas);
+} // namespace gsplat
+
+namespace fast_gs::optimizer {
+void adam_step(float* param, float* exp_avg, float* exp_avg_sq, const float* param_grad, const int n_elements, const float lr,
+               const float beta1, const float beta2, const float eps, const float bias_correction1_rcp, const float bias_correction2_sqrt_rcp);
+void adam_step_wrapper(torch::Tensor& param, torch::Tensor& exp_avg, torch::Tensor& exp_avg_sq, const torch::Tensor& param_grad,
+                       const float lr, const float beta1, const float beta2, const float eps, const float bias_correction1_rcp,
+                       const float bias_correction2_sqrt_rcp);
+} // namespace fast_gs::optimizer

@@ -72,5 +72,36 @@ def build(force: bool = False) -> str:
     return OUT
 
 
+TORCH_OPS_OUT = os.path.join(HERE, "_lfs_torch_ops.so")
+
+
+def build_torch_ops(force: bool = False) -> str:
+    """libtorch wrappers (csrc/torch_ops.cpp = the reference's gsplat::/fast_gs:: C++ signatures) + a pybind
+    module for the tests -> lichtfeld-studio_amd/_lfs_torch_ops.so, linked against liblfs_gsplat.so."""
+    import sysconfig
+
+    import torch
+    build()
+    srcs = [os.path.join(CSRC, "torch_ops.cpp"), os.path.join(CSRC, "torch_ops_pybind.cpp")]
+    deps = srcs + [os.path.join(HERE, "..", "include", "lfs_gsplat_torch.hpp"), os.path.join(HERE, "..", "include", "lfs_gsplat.h"), OUT]
+    if not force and os.path.exists(TORCH_OPS_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(TORCH_OPS_OUT) for d in deps):
+        return TORCH_OPS_OUT
+    tdir = os.path.dirname(torch.__file__)
+    import pybind11
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-D_GLIBCXX_USE_CXX11_ABI=1",
+           "-DTORCH_EXTENSION_NAME=_lfs_torch_ops", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include", "-I/opt/rocm/include", f"-I{pybind11.get_include()}",
+           f"-I{sysconfig.get_paths()['include']}", *srcs,
+           f"-L{tdir}/lib", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python",
+           f"-L{HERE}", "-llfs_gsplat", "-L/opt/rocm/lib", "-lamdhip64",
+           f"-Wl,-rpath,{tdir}/lib", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-o", TORCH_OPS_OUT]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"torch ops build failed:\n{' '.join(cmd)}\n{r.stdout[-3000:]}\n{r.stderr[-6000:]}")
+    return TORCH_OPS_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--torch-ops" in sys.argv:
+        print(build_torch_ops(force="--force" in sys.argv))

@@ -1,0 +1,256 @@
+// libtorch wrappers restoring the reference's C++ operator signatures (gsplat/Ops.h,
+// fastgs/optimizer adam_api.h / adam.h) over the C ABI of liblfs_gsplat.so. This is the layer a
+// LichtFeld-Studio build links instead of `gsplat_backend` + `fastgs_backend`
+// (gsplat/CMakeLists.txt:42, fastgs/CMakeLists.txt:26): same checks (CHECK_INPUT = device tensor +
+// contiguous), same output allocation (dtype / shape / device from the inputs), current-stream
+// launches, c10::Error on failure. PyTorch-ROCm tensors report is_cuda() == true.
+#include "../../include/lfs_gsplat_torch.hpp"
+#include "../../include/lfs_gsplat.h"
+
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPCachingAllocator.h>
+
+#define LFS_CHECK_INPUT(x)                                        \
+    TORCH_CHECK((x).is_cuda(), #x " must be a CUDA tensor");      \
+    TORCH_CHECK((x).is_contiguous(), #x " must be contiguous")
+#define LFS_DEVICE_GUARD(t)                                       \
+    TORCH_CHECK((t).is_cuda(), #t " must be a CUDA tensor");      \
+    const at::hip::OptionalHIPGuardMasqueradingAsCUDA device_guard(device_of(t))
+
+namespace {
+lfs_stream_t cur_stream() { return (lfs_stream_t)c10::hip::getCurrentHIPStream().stream(); }
+void check_rc(int rc, const char* what) {
+    TORCH_CHECK(rc == 0, what, " failed (", rc == LFS_E_INVALID ? "invalid argument" : rc == LFS_E_UNSUPPORTED ? "unsupported configuration"
+                                             : rc == LFS_E_WORKSPACE ? "workspace too small" : "HIP error", ", code ", rc, ")");
+}
+// optional tensor -> pointer; an empty {0} tensor counts as absent (rasterizer.cpp:300-303 passes one for "no background")
+template <class T> const T* opt_ptr(const gsplat::OptT& t) { return (t.has_value() && t->defined() && t->numel() > 0) ? t->data_ptr<T>() : nullptr; }
+bool present(const gsplat::OptT& t) { return t.has_value() && t->defined() && t->numel() > 0; }
+
+lfs_cameras make_cams(const at::Tensor& viewmats0, const gsplat::OptT& viewmats1, const at::Tensor& Ks, uint32_t W, uint32_t H,
+                      gsplat::CameraModelType model, ShutterType rs, const gsplat::OptT& radial, const gsplat::OptT& tangential, const gsplat::OptT& thin) {
+    lfs_cameras c{};
+    c.C = (uint32_t)Ks.size(0); c.image_width = W; c.image_height = H;
+    c.camera_model = (int32_t)model; c.rs_type = (int32_t)rs;
+    c.viewmats0 = viewmats0.data_ptr<float>(); c.viewmats1 = opt_ptr<float>(viewmats1); c.Ks = Ks.data_ptr<float>();
+    c.radial_coeffs = opt_ptr<float>(radial); c.n_radial = present(radial) ? (int32_t)radial->size(-1) : 0;
+    c.tangential_coeffs = opt_ptr<float>(tangential);
+    c.thin_prism_coeffs = opt_ptr<float>(thin); c.n_thin_prism = present(thin) ? (int32_t)thin->size(-1) : 0;
+    return c;
+}
+lfs_ut_params make_ut(const UnscentedTransformParameters& u) {
+    return lfs_ut_params{u.alpha, u.beta, u.kappa, u.in_image_margin_factor, u.require_all_sigma_points_valid ? 1 : 0};
+}
+at::Tensor scratch(size_t bytes, const at::Tensor& like) {
+    return at::empty({(int64_t)std::max<size_t>(bytes, 256)}, like.options().dtype(at::kByte)); // caching allocator, like CUB_WRAPPER (Common.h:23-30)
+}
+} // namespace
+
+torch::Tensor UnscentedTransformParameters::to_tensor() const {
+    return torch::tensor({alpha, beta, kappa, in_image_margin_factor, static_cast<float>(require_all_sigma_points_valid)},
+                         torch::TensorOptions().dtype(torch::kFloat32));
+}
+UnscentedTransformParameters UnscentedTransformParameters::from_tensor(const torch::Tensor& t) {
+    TORCH_CHECK(t.dim() == 1 && t.size(0) == 5, "UnscentedTransformParameters must be a 1D tensor of size 5");
+    UnscentedTransformParameters u;
+    u.alpha = t[0].item<float>(); u.beta = t[1].item<float>(); u.kappa = t[2].item<float>();
+    u.in_image_margin_factor = t[3].item<float>(); u.require_all_sigma_points_valid = t[4].item<bool>();
+    return u;
+}
+
+namespace gsplat {
+
+at::Tensor spherical_harmonics_fwd(const uint32_t degrees_to_use, const at::Tensor dirs, const at::Tensor coeffs, const OptT masks) {
+    LFS_DEVICE_GUARD(dirs);
+    LFS_CHECK_INPUT(dirs); LFS_CHECK_INPUT(coeffs);
+    if (present(masks)) { LFS_CHECK_INPUT(masks.value()); }
+    TORCH_CHECK(coeffs.size(-1) == 3, "coeffs must have last dimension 3");
+    TORCH_CHECK(dirs.size(-1) == 3, "dirs must have last dimension 3");
+    at::Tensor colors = at::empty_like(dirs);
+    check_rc(lfs_spherical_harmonics_fwd((uint32_t)(dirs.numel() / 3), (uint32_t)coeffs.size(-2), degrees_to_use, dirs.data_ptr<float>(),
+                                         coeffs.data_ptr<float>(), (const uint8_t*)opt_ptr<bool>(masks), colors.data_ptr<float>(), cur_stream()),
+             "spherical_harmonics_fwd");
+    return colors;
+}
+
+std::tuple<at::Tensor, at::Tensor> spherical_harmonics_bwd(const uint32_t K, const uint32_t degrees_to_use, const at::Tensor dirs,
+                                                           const at::Tensor coeffs, const OptT masks, const at::Tensor v_colors, bool compute_v_dirs) {
+    LFS_DEVICE_GUARD(dirs);
+    LFS_CHECK_INPUT(dirs); LFS_CHECK_INPUT(coeffs); LFS_CHECK_INPUT(v_colors);
+    if (present(masks)) { LFS_CHECK_INPUT(masks.value()); }
+    TORCH_CHECK(v_colors.size(-1) == 3, "v_colors must have last dimension 3");
+    TORCH_CHECK(coeffs.size(-1) == 3, "coeffs must have last dimension 3");
+    TORCH_CHECK(dirs.size(-1) == 3, "dirs must have last dimension 3");
+    TORCH_CHECK(coeffs.size(-2) == (int64_t)K, "K does not match coeffs");
+    at::Tensor v_coeffs = at::empty_like(coeffs); // fully written by the kernel
+    at::Tensor v_dirs;
+    if (compute_v_dirs) v_dirs = at::empty_like(dirs);
+    check_rc(lfs_spherical_harmonics_bwd((uint32_t)(dirs.numel() / 3), K, degrees_to_use, dirs.data_ptr<float>(), coeffs.data_ptr<float>(),
+                                         (const uint8_t*)opt_ptr<bool>(masks), v_colors.data_ptr<float>(), v_coeffs.data_ptr<float>(),
+                                         compute_v_dirs ? v_dirs.data_ptr<float>() : nullptr, cur_stream()),
+             "spherical_harmonics_bwd");
+    return std::make_tuple(v_coeffs, v_dirs);
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor means2d, const at::Tensor radii, const at::Tensor depths,
+                                                              const OptT camera_ids, const OptT gaussian_ids, const uint32_t C,
+                                                              const uint32_t tile_size, const uint32_t tile_width, const uint32_t tile_height,
+                                                              const bool sort) {
+    LFS_DEVICE_GUARD(means2d);
+    LFS_CHECK_INPUT(means2d); LFS_CHECK_INPUT(radii); LFS_CHECK_INPUT(depths);
+    TORCH_CHECK(means2d.dim() == 3, "packed mode is not supported (the reference trainer never uses it, rasterizer.cpp:56)");
+    (void)camera_ids; (void)gaussian_ids;
+    const uint32_t N = (uint32_t)means2d.size(1);
+    at::Tensor tiles_per_gauss = at::empty_like(depths, depths.options().dtype(at::kInt));
+    at::Tensor n_dev = at::empty({1}, depths.options().dtype(at::kLong));
+    const size_t ws_bytes = lfs_intersect_tile_workspace_bytes(C, N, tile_width, tile_height);
+    at::Tensor ws = scratch(ws_bytes, depths);
+    check_rc(lfs_intersect_tile_count(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), tile_size, tile_width, tile_height,
+                                      tiles_per_gauss.data_ptr<int32_t>(), n_dev.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+             "intersect_tile(count)");
+    const int64_t n_isects = n_dev.item<int64_t>(); // the one host sync, as Intersect.cpp:76
+    at::Tensor isect_ids = at::empty({n_isects}, depths.options().dtype(at::kLong));
+    at::Tensor flatten_ids = at::empty({n_isects}, depths.options().dtype(at::kInt));
+    check_rc(lfs_intersect_tile_emit(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size, tile_width,
+                                     tile_height, sort ? 1 : 0, n_isects, tiles_per_gauss.data_ptr<int32_t>(),
+                                     n_isects ? isect_ids.data_ptr<int64_t>() : nullptr, n_isects ? flatten_ids.data_ptr<int32_t>() : nullptr, nullptr,
+                                     ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+             "intersect_tile(emit)");
+    return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids);
+}
+
+at::Tensor intersect_offset(const at::Tensor isect_ids, const uint32_t C, const uint32_t tile_width, const uint32_t tile_height) {
+    LFS_DEVICE_GUARD(isect_ids);
+    LFS_CHECK_INPUT(isect_ids);
+    at::Tensor offsets = at::empty({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width}, isect_ids.options().dtype(at::kInt));
+    check_rc(lfs_intersect_offset(isect_ids.size(0), isect_ids.numel() ? isect_ids.data_ptr<int64_t>() : nullptr, C, tile_width, tile_height,
+                                  offsets.data_ptr<int32_t>(), cur_stream()), "intersect_offset");
+    return offsets;
+}
+
+at::Tensor quats_to_rotmats(const at::Tensor quats) {
+    LFS_DEVICE_GUARD(quats);
+    LFS_CHECK_INPUT(quats);
+    at::Tensor rotmats = at::empty({quats.size(0), 3, 3}, quats.options());
+    check_rc(lfs_quats_to_rotmats((uint32_t)quats.size(0), quats.data_ptr<float>(), rotmats.data_ptr<float>(), cur_stream()), "quats_to_rotmats");
+    return rotmats;
+}
+
+std::tuple<at::Tensor, at::Tensor> relocation(at::Tensor opacities, at::Tensor scales, at::Tensor ratios, at::Tensor binoms, const int n_max) {
+    LFS_DEVICE_GUARD(opacities);
+    LFS_CHECK_INPUT(opacities); LFS_CHECK_INPUT(scales); LFS_CHECK_INPUT(ratios); LFS_CHECK_INPUT(binoms);
+    at::Tensor new_opacities = at::empty_like(opacities), new_scales = at::empty_like(scales);
+    check_rc(lfs_relocation((uint32_t)opacities.size(0), opacities.data_ptr<float>(), scales.data_ptr<float>(), ratios.data_ptr<int32_t>(),
+                            binoms.data_ptr<float>(), n_max, new_opacities.data_ptr<float>(), new_scales.data_ptr<float>(), cur_stream()), "relocation");
+    return std::make_tuple(new_opacities, new_scales);
+}
+
+void add_noise(at::Tensor raw_opacities, at::Tensor raw_scales, at::Tensor raw_quats, at::Tensor noise, at::Tensor means, const float current_lr) {
+    LFS_DEVICE_GUARD(raw_opacities);
+    LFS_CHECK_INPUT(raw_opacities); LFS_CHECK_INPUT(raw_scales); LFS_CHECK_INPUT(raw_quats); LFS_CHECK_INPUT(noise); LFS_CHECK_INPUT(means);
+    check_rc(lfs_add_noise((uint32_t)raw_opacities.size(0), raw_opacities.data_ptr<float>(), raw_scales.data_ptr<float>(), raw_quats.data_ptr<float>(),
+                           noise.data_ptr<float>(), means.data_ptr<float>(), current_lr, cur_stream()), "add_noise");
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> projection_ut_3dgs_fused(
+    const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const OptT opacities, const at::Tensor viewmats0,
+    const OptT viewmats1, const at::Tensor Ks, const uint32_t image_width, const uint32_t image_height, const float eps2d,
+    const float near_plane, const float far_plane, const float radius_clip, const bool calc_compensations,
+    const CameraModelType camera_model, const UnscentedTransformParameters ut_params, ShutterType rs_type,
+    const OptT radial_coeffs, const OptT tangential_coeffs, const OptT thin_prism_coeffs) {
+    LFS_DEVICE_GUARD(means);
+    LFS_CHECK_INPUT(means); LFS_CHECK_INPUT(quats); LFS_CHECK_INPUT(scales); LFS_CHECK_INPUT(viewmats0); LFS_CHECK_INPUT(Ks);
+    for (const OptT* o : {&opacities, &viewmats1, &radial_coeffs, &tangential_coeffs, &thin_prism_coeffs})
+        if (present(*o)) { LFS_CHECK_INPUT(o->value()); }
+    const int64_t N = means.size(0), C = Ks.size(0);
+    at::Tensor radii = at::empty({C, N, 2}, means.options().dtype(at::kInt));
+    at::Tensor means2d = at::empty({C, N, 2}, means.options());
+    at::Tensor depths = at::empty({C, N}, means.options());
+    at::Tensor conics = at::empty({C, N, 3}, means.options());
+    at::Tensor compensations;
+    if (calc_compensations) compensations = at::zeros({C, N}, means.options());
+    const lfs_cameras cams = make_cams(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs);
+    const lfs_ut_params ut = make_ut(ut_params);
+    check_rc(lfs_projection_ut_3dgs_fused((uint32_t)N, means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(), opt_ptr<float>(opacities),
+                                          &cams, eps2d, near_plane, far_plane, radius_clip, &ut, radii.data_ptr<int32_t>(), means2d.data_ptr<float>(),
+                                          depths.data_ptr<float>(), conics.data_ptr<float>(), calc_compensations ? compensations.data_ptr<float>() : nullptr,
+                                          cur_stream()), "projection_ut_3dgs_fused");
+    return std::make_tuple(radii, means2d, depths, conics, compensations);
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3dgs_fwd(
+    const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
+    const OptT backgrounds, const OptT masks, const uint32_t image_width, const uint32_t image_height, const uint32_t tile_size,
+    const at::Tensor viewmats0, const OptT viewmats1, const at::Tensor Ks, const CameraModelType camera_model,
+    const UnscentedTransformParameters ut_params, ShutterType rs_type, const OptT radial_coeffs, const OptT tangential_coeffs,
+    const OptT thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids) {
+    LFS_DEVICE_GUARD(means);
+    LFS_CHECK_INPUT(means); LFS_CHECK_INPUT(quats); LFS_CHECK_INPUT(scales); LFS_CHECK_INPUT(colors); LFS_CHECK_INPUT(opacities);
+    LFS_CHECK_INPUT(tile_offsets); LFS_CHECK_INPUT(flatten_ids);
+    if (present(backgrounds)) { LFS_CHECK_INPUT(backgrounds.value()); }
+    if (present(masks)) { LFS_CHECK_INPUT(masks.value()); }
+    TORCH_CHECK(opacities.dim() == 2, "packed mode is not supported");
+    const int64_t C = tile_offsets.size(0), N = means.size(0), channels = colors.size(-1);
+    at::Tensor renders = at::empty({C, (int64_t)image_height, (int64_t)image_width, channels}, means.options());
+    at::Tensor alphas = at::empty({C, (int64_t)image_height, (int64_t)image_width, 1}, means.options());
+    at::Tensor last_ids = at::empty({C, (int64_t)image_height, (int64_t)image_width}, means.options().dtype(at::kInt));
+    const lfs_cameras cams = make_cams(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs);
+    const lfs_ut_params ut = make_ut(ut_params);
+    at::Tensor ws = scratch(lfs_rasterize_workspace_bytes((uint32_t)C, (uint32_t)N, (uint32_t)channels), means);
+    const int rc = lfs_rasterize_to_pixels_from_world_3dgs_fwd(
+        (uint32_t)N, (uint32_t)channels, means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(), colors.data_ptr<float>(),
+        opacities.data_ptr<float>(), opt_ptr<float>(backgrounds), (const uint8_t*)opt_ptr<bool>(masks), &cams, tile_size, &ut,
+        tile_offsets.data_ptr<int32_t>(), flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, flatten_ids.size(0),
+        renders.data_ptr<float>(), alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), ws.data_ptr(), (size_t)ws.numel(), cur_stream());
+    TORCH_CHECK(rc != LFS_E_UNSUPPORTED, "Unsupported number of channels: ", channels); // Rasterization.cpp:127
+    check_rc(rc, "rasterize_to_pixels_from_world_3dgs_fwd");
+    return std::make_tuple(renders, alphas, last_ids);
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3dgs_bwd(
+    const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
+    const OptT backgrounds, const OptT masks, const uint32_t image_width, const uint32_t image_height, const uint32_t tile_size,
+    const at::Tensor viewmats0, const OptT viewmats1, const at::Tensor Ks, const CameraModelType camera_model,
+    const UnscentedTransformParameters ut_params, ShutterType rs_type, const OptT radial_coeffs, const OptT tangential_coeffs,
+    const OptT thin_prism_coeffs, const at::Tensor tile_offsets, const at::Tensor flatten_ids, const at::Tensor render_alphas,
+    const at::Tensor last_ids, const at::Tensor v_render_colors, const at::Tensor v_render_alphas) {
+    LFS_DEVICE_GUARD(means);
+    LFS_CHECK_INPUT(means); LFS_CHECK_INPUT(quats); LFS_CHECK_INPUT(scales); LFS_CHECK_INPUT(colors); LFS_CHECK_INPUT(opacities);
+    LFS_CHECK_INPUT(tile_offsets); LFS_CHECK_INPUT(flatten_ids); LFS_CHECK_INPUT(render_alphas); LFS_CHECK_INPUT(last_ids);
+    LFS_CHECK_INPUT(v_render_colors); LFS_CHECK_INPUT(v_render_alphas);
+    if (present(backgrounds)) { LFS_CHECK_INPUT(backgrounds.value()); }
+    if (present(masks)) { LFS_CHECK_INPUT(masks.value()); }
+    const int64_t C = tile_offsets.size(0), N = means.size(0), channels = colors.size(-1);
+    at::Tensor v_means = at::empty_like(means), v_quats = at::empty_like(quats), v_scales = at::empty_like(scales);
+    at::Tensor v_colors = at::empty_like(colors), v_opacities = at::empty_like(opacities);
+    const lfs_cameras cams = make_cams(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs);
+    const lfs_ut_params ut = make_ut(ut_params);
+    at::Tensor ws = scratch(lfs_rasterize_workspace_bytes((uint32_t)C, (uint32_t)N, (uint32_t)channels), means);
+    const int rc = lfs_rasterize_to_pixels_from_world_3dgs_bwd(
+        (uint32_t)N, (uint32_t)channels, means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(), colors.data_ptr<float>(),
+        opacities.data_ptr<float>(), opt_ptr<float>(backgrounds), (const uint8_t*)opt_ptr<bool>(masks), &cams, tile_size, &ut,
+        tile_offsets.data_ptr<int32_t>(), flatten_ids.numel() ? flatten_ids.data_ptr<int32_t>() : nullptr, flatten_ids.size(0),
+        render_alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), v_render_colors.data_ptr<float>(), v_render_alphas.data_ptr<float>(),
+        v_means.data_ptr<float>(), v_quats.data_ptr<float>(), v_scales.data_ptr<float>(), v_colors.data_ptr<float>(), v_opacities.data_ptr<float>(),
+        ws.data_ptr(), (size_t)ws.numel(), cur_stream());
+    TORCH_CHECK(rc != LFS_E_UNSUPPORTED, "Unsupported number of channels: ", channels);
+    check_rc(rc, "rasterize_to_pixels_from_world_3dgs_bwd");
+    return std::make_tuple(v_means, v_quats, v_scales, v_colors, v_opacities);
+}
+
+} // namespace gsplat
+
+namespace fast_gs::optimizer {
+void adam_step(float* param, float* exp_avg, float* exp_avg_sq, const float* param_grad, const int n_elements, const float lr,
+               const float beta1, const float beta2, const float eps, const float bias_correction1_rcp, const float bias_correction2_sqrt_rcp) {
+    check_rc(lfs_adam_step(param, exp_avg, exp_avg_sq, param_grad, n_elements, lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp,
+                           cur_stream()), "adam_step");
+}
+void adam_step_wrapper(torch::Tensor& param, torch::Tensor& exp_avg, torch::Tensor& exp_avg_sq, const torch::Tensor& param_grad,
+                       const float lr, const float beta1, const float beta2, const float eps, const float bias_correction1_rcp,
+                       const float bias_correction2_sqrt_rcp) {
+    adam_step(param.data_ptr<float>(), exp_avg.data_ptr<float>(), exp_avg_sq.data_ptr<float>(), param_grad.data_ptr<float>(), (int)param.numel(),
+              lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp);
+}
+} // namespace fast_gs::optimizer

@@ -1,0 +1,50 @@
+// Python module `_lfs_torch_ops`: exposes the libtorch wrappers of torch_ops.cpp 1:1 so that the
+// C++ drop-in layer is exercised by the test-suite (tests/test_gpu_torch_ops.py).  Enums travel as
+// ints, UnscentedTransformParameters as its 5-float tensor form (Cameras.h:42-61).
+#include "../../include/lfs_gsplat_torch.hpp"
+#include <torch/extension.h>
+
+namespace py = pybind11;
+using gsplat::OptT;
+
+static UnscentedTransformParameters ut_of(const c10::optional<at::Tensor>& t) {
+    return (t.has_value() && t->defined()) ? UnscentedTransformParameters::from_tensor(t->cpu()) : UnscentedTransformParameters{};
+}
+
+PYBIND11_MODULE(_lfs_torch_ops, m) {
+    m.def("spherical_harmonics_fwd", &gsplat::spherical_harmonics_fwd);
+    m.def("spherical_harmonics_bwd", &gsplat::spherical_harmonics_bwd);
+    m.def("intersect_tile", &gsplat::intersect_tile);
+    m.def("intersect_offset", &gsplat::intersect_offset);
+    m.def("quats_to_rotmats", &gsplat::quats_to_rotmats);
+    m.def("relocation", &gsplat::relocation);
+    m.def("add_noise", &gsplat::add_noise);
+    m.def("projection_ut_3dgs_fused",
+          [](at::Tensor means, at::Tensor quats, at::Tensor scales, OptT opacities, at::Tensor viewmats0, OptT viewmats1, at::Tensor Ks,
+             uint32_t W, uint32_t H, float eps2d, float near_plane, float far_plane, float radius_clip, bool calc_compensations, int camera_model,
+             OptT ut, int rs_type, OptT radial, OptT tangential, OptT thin) {
+              return gsplat::projection_ut_3dgs_fused(means, quats, scales, opacities, viewmats0, viewmats1, Ks, W, H, eps2d, near_plane, far_plane,
+                                                      radius_clip, calc_compensations, (gsplat::CameraModelType)camera_model, ut_of(ut),
+                                                      (ShutterType)rs_type, radial, tangential, thin);
+          });
+    m.def("rasterize_to_pixels_from_world_3dgs_fwd",
+          [](at::Tensor means, at::Tensor quats, at::Tensor scales, at::Tensor colors, at::Tensor opacities, OptT backgrounds, OptT masks,
+             uint32_t W, uint32_t H, uint32_t tile_size, at::Tensor viewmats0, OptT viewmats1, at::Tensor Ks, int camera_model, OptT ut, int rs_type,
+             OptT radial, OptT tangential, OptT thin, at::Tensor tile_offsets, at::Tensor flatten_ids) {
+              return gsplat::rasterize_to_pixels_from_world_3dgs_fwd(means, quats, scales, colors, opacities, backgrounds, masks, W, H, tile_size,
+                                                                     viewmats0, viewmats1, Ks, (gsplat::CameraModelType)camera_model, ut_of(ut),
+                                                                     (ShutterType)rs_type, radial, tangential, thin, tile_offsets, flatten_ids);
+          });
+    m.def("rasterize_to_pixels_from_world_3dgs_bwd",
+          [](at::Tensor means, at::Tensor quats, at::Tensor scales, at::Tensor colors, at::Tensor opacities, OptT backgrounds, OptT masks,
+             uint32_t W, uint32_t H, uint32_t tile_size, at::Tensor viewmats0, OptT viewmats1, at::Tensor Ks, int camera_model, OptT ut, int rs_type,
+             OptT radial, OptT tangential, OptT thin, at::Tensor tile_offsets, at::Tensor flatten_ids, at::Tensor render_alphas, at::Tensor last_ids,
+             at::Tensor v_render_colors, at::Tensor v_render_alphas) {
+              return gsplat::rasterize_to_pixels_from_world_3dgs_bwd(means, quats, scales, colors, opacities, backgrounds, masks, W, H, tile_size,
+                                                                     viewmats0, viewmats1, Ks, (gsplat::CameraModelType)camera_model, ut_of(ut),
+                                                                     (ShutterType)rs_type, radial, tangential, thin, tile_offsets, flatten_ids,
+                                                                     render_alphas, last_ids, v_render_colors, v_render_alphas);
+          });
+    m.def("adam_step_wrapper", [](at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, at::Tensor grad, float lr, float b1, float b2,
+                                  float eps, float bc1, float bc2) { fast_gs::optimizer::adam_step_wrapper(param, exp_avg, exp_avg_sq, grad, lr, b1, b2, eps, bc1, bc2); });
+}
