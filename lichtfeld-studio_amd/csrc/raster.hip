@@ -164,18 +164,8 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     for (int k = 0; k < CDIM; ++k) pix[k] = 0.f;
     int32_t cur_idx = 0;
 
-    // two-deep scalar prefetch: id two entries ahead, record one entry ahead
-    int32_t g_next = start < end ? ids[start] : 0;
-    int32_t g_next2 = start + 1 < end ? ids[start + 1] : 0;
-    GaussRec rec_next = recs[g_next];
-    for (int32_t idx = start; idx < end; ++idx) {
-        if (__ballot(!done) == 0ull) break;
-        const GaussRec rec = rec_next;
-        const int32_t g = g_next;
-        g_next = g_next2;
-        if (idx + 1 < end) rec_next = recs[g_next];
-        g_next2 = idx + 2 < end ? ids[idx + 2] : 0;
-
+    // One evaluation of a record against this lane's ray (wave-uniform record in SGPRs).
+    auto eval = [&](const GaussRec& rec, const int32_t g, const int32_t idx) {
         f3 gro;
         if (UNIFORM_ORIGIN) gro = {rec.r0.w, rec.r1.w, rec.r2.w};
         else {
@@ -194,8 +184,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
         const float power = -0.5f * (gc.x * gc.x + gc.y * gc.y + gc.z * gc.z);
         const float alpha = fminf(0.999f, rec.r3.x * __expf(power));
         const bool pass = !done && !(alpha < (1.f / 255.f));
-        if (__ballot(pass) == 0ull) continue;
-
+        if (__ballot(pass) == 0ull) return;
         const float next_T = T * (1.f - alpha);
         const bool fin = pass && next_T <= 1e-4f; // the terminating Gaussian is not composited
         const bool contrib = pass && !fin;
@@ -214,6 +203,33 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
             T = next_T;
         }
         done |= fin;
+    };
+
+    // Two groups of two record buffers in SGPRs. Scalar loads return out of order, so every wait is
+    // s_waitcnt lgkmcnt(0): the loop waits for group B right BEFORE refilling group A (and vice versa), which
+    // gives each record load two full evaluations (~300 cycles) in flight and never copies a buffer.
+    if (start < end) {
+        const int32_t last = end - 1;
+        auto id_at = [&](int32_t k) { return ids[min(k, last)]; };
+        int32_t gA0 = id_at(start), gA1 = id_at(start + 1), gB0 = id_at(start + 2), gB1 = id_at(start + 3);
+        int32_t nA0 = id_at(start + 4), nA1 = id_at(start + 5), nB0 = 0, nB1 = 0;
+        GaussRec A0 = recs[gA0], A1 = recs[gA1], B0 = recs[gB0], B1 = recs[gB1];
+        for (int32_t i = start; i < end; i += 4) {
+            if (__ballot(!done) == 0ull) break;
+            eval(A0, gA0, i);
+            if (i + 1 < end) eval(A1, gA1, i + 1);
+            asm volatile("; group B must have landed before group A is refilled" ::"s"(B0.r0.x), "s"(B1.r0.x));
+            gA0 = nA0; gA1 = nA1;
+            A0 = recs[gA0]; A1 = recs[gA1];
+            nB0 = id_at(i + 6); nB1 = id_at(i + 7);
+            if (i + 2 >= end || __ballot(!done) == 0ull) break;
+            eval(B0, gB0, i + 2);
+            if (i + 3 < end) eval(B1, gB1, i + 3);
+            asm volatile("; group A must have landed before group B is refilled" ::"s"(A0.r0.x), "s"(A1.r0.x));
+            gB0 = nB0; gB1 = nB1;
+            B0 = recs[gB0]; B1 = recs[gB1];
+            nA0 = id_at(i + 8); nA1 = id_at(i + 9);
+        }
     }
 
     if (inside) {
