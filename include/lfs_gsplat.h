@@ -135,7 +135,14 @@ LFS_API int lfs_intersect_offset(
  *      fwd: render_colors [C,H,W,channels], render_alphas [C,H,W,1], last_ids int32 [C,H,W].
  *      bwd: v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,channels],
  *           v_opacities [C,N] — all FULLY written (no pre-zeroing needed). */
-LFS_API size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t channels);
+/*      workspace: camera state + one 64-B record, one 64-B gradient accumulator row and one 32-B culling
+ *      record per (camera, Gaussian) + the compacted per-8x8-cell lists ((tile_size/8)^2 * n_isects * 8 B,
+ *      worst case). Returns 0 for an unsupported tile_size. */
+LFS_API size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t channels, uint32_t image_width,
+                                             uint32_t image_height, uint32_t tile_size, int64_t n_isects);
+/*      developer switch, not part of the reference API: bit 0 = build the per-cell lists without culling
+ *      (fwd output must be bit-identical either way; tests/test_gpu_raster.py). */
+LFS_API void lfs_set_debug_flags(uint32_t flags);
 LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
     const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,

@@ -35,12 +35,19 @@ struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2, r3; };
 constexpr int ACC_STRIDE = 16; // A(9) | G(3) | opacity | rgb(3)
 
 static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
-struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; size_t bytes; };
-static RasterWs raster_ws(void* base, uint32_t C, uint32_t N) {
+// Per-Gaussian culling record (camera space, divided by depth, r^2 folded in): see raster_pack_kernel.
+struct __attribute__((aligned(16))) CullRec { float4 a, b; };
+
+struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; CullRec* cull; int32_t* cell_count; int2* cell_list; size_t bytes; };
+// cells = C * tiles * (tile_size/8)^2 ; the compacted per-cell lists hold at most (tile_size/8)^2 * n_isects entries
+static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, uint64_t cell_entries) {
     RasterWs w; char* p = (char*)base; size_t o = 0;
     w.cams = (CamDev*)(p + o); o += align256(sizeof(CamDev) * C);
     w.recs = (GaussRec*)(p + o); o += align256(sizeof(GaussRec) * size_t(C) * N);
     w.acc = (float*)(p + o); o += align256(sizeof(float) * ACC_STRIDE * size_t(C) * N);
+    w.cull = (CullRec*)(p + o); o += align256(sizeof(CullRec) * size_t(C) * N);
+    w.cell_count = (int32_t*)(p + o); o += align256(sizeof(int32_t) * cells);
+    w.cell_list = (int2*)(p + o); o += align256(sizeof(int2) * cell_entries);
     w.bytes = o;
     return w;
 }
@@ -61,7 +68,7 @@ __global__ void __launch_bounds__(256) raster_pack_kernel(
     const uint32_t C, const uint32_t N, const uint32_t channels,
     const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
     const float* __restrict__ colors, const float* __restrict__ opacities,
-    const CamDev* __restrict__ cams, GaussRec* __restrict__ recs) {
+    const CamDev* __restrict__ cams, GaussRec* __restrict__ recs, CullRec* __restrict__ cull) {
     const size_t idx = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= size_t(C) * N) return;
     const uint32_t cid = uint32_t(idx / N), gid = uint32_t(idx % N);
@@ -85,15 +92,54 @@ __global__ void __launch_bounds__(256) raster_pack_kernel(
     c0 = cp[0];
     if (channels > 1) c1 = cp[1];
     if (channels > 2) c2 = cp[2];
-    rec.r3 = make_float4(opacities[idx], c0, c1, c2);
+    const float opac = opacities[idx];
+    rec.r3 = make_float4(opac, c0, c1, c2);
     recs[idx] = rec;
+
+    // Culling record for raster_cull_kernel. A pixel can only composite this Gaussian when
+    // opac * exp(-d^2/2) >= 1/255, d = Mahalanobis distance from the centre to the pixel's ray LINE, i.e.
+    // d^2 <= r^2 = 2 ln(255 opac). For a plane x = t z through the camera centre (camera space) that has all
+    // rays of a cell on one side and the centre p on the other, d >= |p.x - t p.z| / sqrt(w^T Sigma w),
+    // w = (1,0,-t). Stored divided by p.z^2 with r^2 (plus a safety margin) folded into Sigma:
+    //   a = {p.x/p.z, p.y/p.z, Sxx, Syy}, b = {Sxz, Syz, Szz, -}   with S = r^2 Sigma_cam / p.z^2.
+    // NaN in a.x/a.y = "never cull" (centre too close to the camera plane for the backward half of the ray
+    // lines to be excluded, rolling shutter, non-finite input); +inf in a.x = "always culled" (opac < 1/255).
+    CullRec cr;
+    const float qnan = __builtin_nanf("");
+    cr.a = make_float4(qnan, qnan, 0.f, 0.f);
+    cr.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (UNIFORM_ORIGIN) {
+        const m3& Ri = cams[cid].Rinv;                // camera -> world, so world -> camera is its transpose
+        const f3 pc = mul_t(Ri, mu - cams[cid].origin);
+        m3 A;                                         // A = Rc R S  (Sigma_cam = A A^T)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                A.m[r][c] = (Ri.m[0][r] * R.m[0][c] + Ri.m[1][r] * R.m[1][c] + Ri.m[2][r] * R.m[2][c]) * scales[3 * gid + c];
+        const float Sxx = A.m[0][0] * A.m[0][0] + A.m[0][1] * A.m[0][1] + A.m[0][2] * A.m[0][2];
+        const float Syy = A.m[1][0] * A.m[1][0] + A.m[1][1] * A.m[1][1] + A.m[1][2] * A.m[1][2];
+        const float Szz = A.m[2][0] * A.m[2][0] + A.m[2][1] * A.m[2][1] + A.m[2][2] * A.m[2][2];
+        const float Sxz = A.m[0][0] * A.m[2][0] + A.m[0][1] * A.m[2][1] + A.m[0][2] * A.m[2][2];
+        const float Syz = A.m[1][0] * A.m[2][0] + A.m[1][1] * A.m[2][1] + A.m[1][2] * A.m[2][2];
+        const float r2 = fmaxf(0.f, 2.f * logf(255.f * opac)) * 1.02f + 0.02f;
+        if (opac < (1.f / 255.f)) {
+            cr.a.x = __builtin_inff();
+        } else if (pc.z > 0.f && pc.z * pc.z > 1.5f * r2 * Szz) {
+            const float inv = 1.f / pc.z;
+            const float k = r2 * inv * inv;
+            cr.a = make_float4(pc.x * inv, pc.y * inv, k * Sxx, k * Syy);
+            cr.b = make_float4(k * Sxz, k * Syz, k * Szz, 0.f);
+        }
+    }
+    cull[idx] = cr;
 }
 
 // ---------------------------------------------------------------------------
-// tile / cell bookkeeping shared by fwd and bwd
+// tile / cell bookkeeping shared by cull, fwd and bwd
 // ---------------------------------------------------------------------------
 struct CellCtx {
-    uint32_t cid, tile_global, i, j;
+    uint32_t cid, tile_global, wl, i, j; // wl = 8x8 cell index inside the tile (wave-uniform)
     bool in_grid;
 };
 // Workgroup -> (tile, cell). Consecutive workgroup ids go round-robin over the
@@ -111,15 +157,178 @@ LFS_DI CellCtx cell_ctx(uint32_t n_tiles, uint32_t total_tiles, uint32_t tw, uin
     const uint32_t tile = tg % n_tiles;
     const uint32_t ty = tile / tw, tx = tile % tw;
     const uint32_t wps = tile_size >> 3; // 8x8 cells per tile side
-    const uint32_t wl = bt * waves_per_block + (threadIdx.x >> 6);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.wl = bt * waves_per_block + wave;
     const uint32_t lane = threadIdx.x & 63;
-    c.i = ty * tile_size + (wl / wps) * 8 + (lane >> 3);
-    c.j = tx * tile_size + (wl % wps) * 8 + (lane & 7);
+    c.i = ty * tile_size + (c.wl / wps) * 8 + (lane >> 3);
+    c.j = tx * tile_size + (c.wl % wps) * 8 + (lane & 7);
     return c;
 }
 
 LFS_DI float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 LFS_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+LFS_DI float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+LFS_DI float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+LFS_DI float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// cull: per 8x8 cell, compact the tile's depth-sorted list down to the entries that CAN reach the
+// 1/255 alpha threshold on at least one of the cell's rays (conservative: never drops a contributor, so
+// fwd/bwd results are exactly those of walking the full tile list). Lane = list entry; the four side
+// planes of the cell's ray pyramid are wave-uniform. Output per cell: count + (gaussian, list index)
+// pairs in list order, stored in the cell's slice of a [cells_per_tile * n_isects] array.
+// ---------------------------------------------------------------------------
+template <bool UNIFORM_ORIGIN>
+__global__ void __launch_bounds__(256) raster_cull_kernel(
+    const uint32_t C, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
+    const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block, const uint32_t cull_enabled,
+    const CamDev* __restrict__ cams, const CullRec* __restrict__ cull, const uint8_t* __restrict__ masks,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ ids, const int32_t n_isects,
+    int32_t* __restrict__ cell_count, int2* __restrict__ cell_list) {
+    const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
+    const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
+    if (!cc.in_grid) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wpt = (tile_size >> 3) * (tile_size >> 3);
+    const size_t cell = size_t(cc.tile_global) * wpt + cc.wl;
+    const bool inside = cc.i < H && cc.j < W;
+    const int32_t start = offsets[cc.tile_global];
+    const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
+    const bool tile_masked = masks != nullptr && !masks[cc.tile_global];
+
+    // cell bounds in normalised camera coordinates (x/z, y/z) over the rays that can composite at all
+    const CamDev& cam = cams[cc.cid];
+    f3 ro, rd;
+    const bool ray_ok = cam_pixel_ray(cam, f2{float(cc.j) + 0.5f, float(cc.i) + 0.5f}, ro, rd);
+    const bool active = inside && ray_ok;
+    if (__ballot(active) == 0ull || tile_masked || end <= start) {
+        if (lane == 0) cell_count[cell] = 0;
+        return;
+    }
+    bool can_cull = UNIFORM_ORIGIN && cull_enabled != 0;
+    float tu_lo = 0.f, tu_hi = 0.f, tv_lo = 0.f, tv_hi = 0.f;
+    if (UNIFORM_ORIGIN) {
+        const f3 cd = mul_t(cam.Rinv, rd); // back to camera space
+        const bool front = cd.z > 0.f;
+        can_cull = can_cull && (__ballot(active && !front) == 0ull);
+        const float iz = front ? 1.f / cd.z : 0.f;
+        const float tu = cd.x * iz, tv = cd.y * iz;
+        const float big = 3.0e38f;
+        const float mu_ = 0.25f / cam.fx, mv_ = 0.25f / cam.fy; // numerical safety margin: a quarter pixel
+        tu_lo = wave_min(active ? tu : big) - mu_;
+        tu_hi = wave_max(active ? tu : -big) + mu_;
+        tv_lo = wave_min(active ? tv : big) - mv_;
+        tv_hi = wave_max(active ? tv : -big) + mv_;
+        can_cull = can_cull && (tu_hi - tu_lo < 1e30f) && (tv_hi - tv_lo < 1e30f);
+    }
+    tu_lo = uniform_f(tu_lo); tu_hi = uniform_f(tu_hi); tv_lo = uniform_f(tv_lo); tv_hi = uniform_f(tv_hi);
+
+    int2* __restrict__ out = cell_list + (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
+    int32_t count = 0;
+    // one plane: centre coordinate c (x/z or y/z), slope t, S = (Scc, Scz, Szz); sgn = +1 for the upper side
+    auto outside = [](float c, float t, float sgn, float Scc, float Scz, float Szz) {
+        const float s = sgn * (c - t);
+        const float tt = t * t;
+        const float q = Scc - 2.f * t * Scz + tt * Szz;
+        const float Q = Scc + 2.f * fabsf(t * Scz) + tt * Szz;
+        return s > 0.f && s * s > q + 4e-6f * Q;
+    };
+    int32_t idx = start + int32_t(lane);
+    int32_t g = idx < end ? ids[idx] : 0;
+    for (int32_t base = start; base < end; base += 64) {
+        const int32_t my_idx = idx, my_g = g;
+        const bool valid = my_idx < end;
+        idx += 64;
+        g = idx < end ? ids[idx] : 0; // next batch's ids in flight during this batch's test
+        bool hit = valid;
+        if (can_cull) {
+            const CullRec cr = cull[my_g];
+            const bool culled = outside(cr.a.x, tu_hi, 1.f, cr.a.z, cr.b.x, cr.b.z) || outside(cr.a.x, tu_lo, -1.f, cr.a.z, cr.b.x, cr.b.z) ||
+                                outside(cr.a.y, tv_hi, 1.f, cr.a.w, cr.b.y, cr.b.z) || outside(cr.a.y, tv_lo, -1.f, cr.a.w, cr.b.y, cr.b.z);
+            hit = valid && !culled;
+        }
+        const uint64_t m = __ballot(hit);
+        if (hit) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+            out[count + int32_t(rank)] = make_int2(my_g, my_idx);
+        }
+        count += __popcll(m);
+    }
+    if (lane == 0) cell_count[cell] = count;
+}
+
+// One Gaussian against one ray, shared by fwd and bwd so that both see bit-identical alphas. Every sum of
+// products is an explicit fma chain: with -ffp-contract=fast alone the compiler is free to pick WHICH product
+// of a*b + c*d it fuses, and it picks differently in different inlined copies - results would depend on the
+// position of a Gaussian in the list (measured: 1 ulp), and the culling on/off bit-identity test would fail.
+LFS_DI float fma3(float ax, float bx, float ay, float by, float az, float bz) {
+    return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
+}
+LFS_DI f3 cross_fma(const f3& a, const f3& b) {
+    return {__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)), __builtin_fmaf(a.x, b.y, -(b.x * a.y))};
+}
+struct RayEval { f3 om, gro, grd, grd_n, gc; float l, il, vis; };
+template <bool UNIFORM_ORIGIN>
+LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& rd, RayEval& e) {
+    e.om = {0.f, 0.f, 0.f};
+    if (UNIFORM_ORIGIN) e.gro = {rec.r0.w, rec.r1.w, rec.r2.w};
+    else {
+        e.om = {ro.x - rec.r0.w, ro.y - rec.r1.w, ro.z - rec.r2.w};
+        e.gro = {fma3(rec.r0.x, e.om.x, rec.r0.y, e.om.y, rec.r0.z, e.om.z),
+                 fma3(rec.r1.x, e.om.x, rec.r1.y, e.om.y, rec.r1.z, e.om.z),
+                 fma3(rec.r2.x, e.om.x, rec.r2.y, e.om.y, rec.r2.z, e.om.z)};
+    }
+    e.grd = {fma3(rec.r0.x, rd.x, rec.r0.y, rd.y, rec.r0.z, rd.z),
+             fma3(rec.r1.x, rd.x, rec.r1.y, rd.y, rec.r1.z, rd.z),
+             fma3(rec.r2.x, rd.x, rec.r2.y, rd.y, rec.r2.z, rd.z)};
+    e.l = fma3(e.grd.x, e.grd.x, e.grd.y, e.grd.y, e.grd.z, e.grd.z);
+    e.il = e.l > 0.f ? fast_rsq(e.l) : 1.f;
+    e.grd_n = e.grd * e.il;
+    e.gc = cross_fma(e.grd_n, e.gro);
+    const float power = -0.5f * fma3(e.gc.x, e.gc.x, e.gc.y, e.gc.y, e.gc.z, e.gc.z);
+    e.vis = __expf(power); // power <= 0 by construction (NaN propagates)
+}
+
+// Walk a cell list with the records arriving through the SCALAR unit: two groups of two record
+// buffers in SGPRs. Scalar loads return out of order, so every wait is s_waitcnt lgkmcnt(0): the loop
+// waits for group B right BEFORE refilling group A (and vice versa), which gives each record load two full
+// evaluations (~300 cycles) in flight and never copies a buffer. Entries are visited at positions
+// first, first+step, ... (n of them); eval(rec, entry) per entry; alive() is polled every two entries.
+template <int STEP, class Eval, class Alive>
+LFS_DI void walk_cell_list(const int2* __restrict__ cl, const GaussRec* __restrict__ recs, const int32_t first, const int32_t n,
+                           Eval&& eval, Alive&& alive) {
+    if (n <= 0) return;
+    const int32_t last = n - 1;
+    auto ent = [&](int32_t k) { return cl[first + STEP * min(k, last)]; };
+    int2 eA0 = ent(0), eA1 = ent(1), eB0 = ent(2), eB1 = ent(3);
+    int2 nA0 = ent(4), nA1 = ent(5), nB0 = make_int2(0, 0), nB1 = make_int2(0, 0);
+    GaussRec A0 = recs[eA0.x], A1 = recs[eA1.x], B0 = recs[eB0.x], B1 = recs[eB1.x];
+    for (int32_t k = 0; k < n; k += 4) {
+        if (!alive()) break;
+        eval(A0, eA0);
+        if (k + 1 < n) eval(A1, eA1);
+        asm volatile("; group B must have landed before group A is refilled" ::"s"(B0.r0.x), "s"(B1.r0.x));
+        eA0 = nA0; eA1 = nA1;
+        A0 = recs[eA0.x]; A1 = recs[eA1.x];
+        nB0 = ent(k + 6); nB1 = ent(k + 7);
+        if (k + 2 >= n || !alive()) break;
+        eval(B0, eB0);
+        if (k + 3 < n) eval(B1, eB1);
+        asm volatile("; group A must have landed before group B is refilled" ::"s"(A0.r0.x), "s"(A1.r0.x));
+        eB0 = nB0; eB1 = nB1;
+        B0 = recs[eB0.x]; B1 = recs[eB1.x];
+        nA0 = ent(k + 8); nA1 = ent(k + 9);
+    }
+}
 
 // ---------------------------------------------------------------------------
 // forward
@@ -130,7 +339,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block,
     const CamDev* __restrict__ cams, const GaussRec* __restrict__ recs, const float* __restrict__ colors,
     const float* __restrict__ backgrounds, const uint8_t* __restrict__ masks,
-    const int32_t* __restrict__ offsets, const int32_t* __restrict__ ids, const int32_t n_isects,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ cell_count, const int2* __restrict__ cell_list, const int32_t n_isects,
     float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
     const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
@@ -155,8 +364,11 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     const bool ray_ok = cam_pixel_ray(cam, f2{float(cc.j) + 0.5f, float(cc.i) + 0.5f}, ro, rd);
     bool done = !(inside && ray_ok);
 
+    const uint32_t wpt = (tile_size >> 3) * (tile_size >> 3);
     const int32_t start = offsets[cc.tile_global];
     const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
+    const int2* __restrict__ cl = cell_list + (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
+    const int32_t cnt = cell_count[size_t(cc.tile_global) * wpt + cc.wl];
 
     float T = 1.f;
     float pix[CDIM];
@@ -165,24 +377,10 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     int32_t cur_idx = 0;
 
     // One evaluation of a record against this lane's ray (wave-uniform record in SGPRs).
-    auto eval = [&](const GaussRec& rec, const int32_t g, const int32_t idx) {
-        f3 gro;
-        if (UNIFORM_ORIGIN) gro = {rec.r0.w, rec.r1.w, rec.r2.w};
-        else {
-            const f3 om{ro.x - rec.r0.w, ro.y - rec.r1.w, ro.z - rec.r2.w};
-            gro = {rec.r0.x * om.x + rec.r0.y * om.y + rec.r0.z * om.z,
-                   rec.r1.x * om.x + rec.r1.y * om.y + rec.r1.z * om.z,
-                   rec.r2.x * om.x + rec.r2.y * om.y + rec.r2.z * om.z};
-        }
-        f3 grd{rec.r0.x * rd.x + rec.r0.y * rd.y + rec.r0.z * rd.z,
-               rec.r1.x * rd.x + rec.r1.y * rd.y + rec.r1.z * rd.z,
-               rec.r2.x * rd.x + rec.r2.y * rd.y + rec.r2.z * rd.z};
-        const float l = grd.x * grd.x + grd.y * grd.y + grd.z * grd.z;
-        const float il = l > 0.f ? fast_rsq(l) : 1.f;
-        grd = grd * il;
-        const f3 gc = cross(grd, gro);
-        const float power = -0.5f * (gc.x * gc.x + gc.y * gc.y + gc.z * gc.z);
-        const float alpha = fminf(0.999f, rec.r3.x * __expf(power));
+    auto eval = [&](const GaussRec& rec, const int2 e) {
+        RayEval re;
+        ray_eval<UNIFORM_ORIGIN>(rec, ro, rd, re);
+        const float alpha = fminf(0.999f, rec.r3.x * re.vis);
         const bool pass = !done && !(alpha < (1.f / 255.f));
         if (__ballot(pass) == 0ull) return;
         const float next_T = T * (1.f - alpha);
@@ -191,46 +389,20 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
         const float vis = alpha * T;
         if (contrib) {
             if (CDIM <= 3) {
-                pix[0] += rec.r3.y * vis;
-                if (CDIM > 1) pix[1] += rec.r3.z * vis;
-                if (CDIM > 2) pix[2] += rec.r3.w * vis;
+                pix[0] = __builtin_fmaf(rec.r3.y, vis, pix[0]);
+                if (CDIM > 1) pix[1] = __builtin_fmaf(rec.r3.z, vis, pix[1]);
+                if (CDIM > 2) pix[2] = __builtin_fmaf(rec.r3.w, vis, pix[2]);
             } else {
-                const float* cp = colors + size_t(g) * CDIM;
+                const float* cp = colors + size_t(e.x) * CDIM;
 #pragma unroll
-                for (int k = 0; k < CDIM; ++k) pix[k] += cp[k] * vis;
+                for (int k = 0; k < CDIM; ++k) pix[k] = __builtin_fmaf(cp[k], vis, pix[k]);
             }
-            cur_idx = idx;
+            cur_idx = e.y;
             T = next_T;
         }
         done |= fin;
     };
-
-    // Two groups of two record buffers in SGPRs. Scalar loads return out of order, so every wait is
-    // s_waitcnt lgkmcnt(0): the loop waits for group B right BEFORE refilling group A (and vice versa), which
-    // gives each record load two full evaluations (~300 cycles) in flight and never copies a buffer.
-    if (start < end) {
-        const int32_t last = end - 1;
-        auto id_at = [&](int32_t k) { return ids[min(k, last)]; };
-        int32_t gA0 = id_at(start), gA1 = id_at(start + 1), gB0 = id_at(start + 2), gB1 = id_at(start + 3);
-        int32_t nA0 = id_at(start + 4), nA1 = id_at(start + 5), nB0 = 0, nB1 = 0;
-        GaussRec A0 = recs[gA0], A1 = recs[gA1], B0 = recs[gB0], B1 = recs[gB1];
-        for (int32_t i = start; i < end; i += 4) {
-            if (__ballot(!done) == 0ull) break;
-            eval(A0, gA0, i);
-            if (i + 1 < end) eval(A1, gA1, i + 1);
-            asm volatile("; group B must have landed before group A is refilled" ::"s"(B0.r0.x), "s"(B1.r0.x));
-            gA0 = nA0; gA1 = nA1;
-            A0 = recs[gA0]; A1 = recs[gA1];
-            nB0 = id_at(i + 6); nB1 = id_at(i + 7);
-            if (i + 2 >= end || __ballot(!done) == 0ull) break;
-            eval(B0, gB0, i + 2);
-            if (i + 3 < end) eval(B1, gB1, i + 3);
-            asm volatile("; group A must have landed before group B is refilled" ::"s"(A0.r0.x), "s"(A1.r0.x));
-            gB0 = nB0; gB1 = nB1;
-            B0 = recs[gB0]; B1 = recs[gB1];
-            nA0 = id_at(i + 8); nA1 = id_at(i + 9);
-        }
-    }
+    walk_cell_list<1>(cl, recs, 0, cnt, eval, [&]() { return __ballot(!done) != 0ull; });
 
     if (inside) {
         render_alphas[pix_id] = 1.f - T;
@@ -289,7 +461,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block,
     const CamDev* __restrict__ cams, const GaussRec* __restrict__ recs, const float* __restrict__ colors,
     const float* __restrict__ backgrounds, const uint8_t* __restrict__ masks,
-    const int32_t* __restrict__ offsets, const int32_t* __restrict__ ids, const int32_t n_isects,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ cell_count, const int2* __restrict__ cell_list, const int32_t n_isects,
     const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ acc, float* __restrict__ v_colors_extra) {
@@ -308,8 +480,11 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     const bool ray_ok = cam_pixel_ray(cam, f2{float(cc.j) + 0.5f, float(cc.i) + 0.5f}, ro, rd);
     const bool active = inside && ray_ok;
 
+    const uint32_t wpt = (tile_size >> 3) * (tile_size >> 3);
     const int32_t start = offsets[cc.tile_global];
     const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
+    const int2* __restrict__ cl = cell_list + (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
+    const int32_t cnt = cell_count[size_t(cc.tile_global) * wpt + cc.wl];
 
     float T_final = 1.f, v_ra = 0.f;
     int32_t bin_final = -1; // Bwd.cu:183 uses 0 for inactive pixels; -1 keeps them out of entry 0 as well
@@ -339,40 +514,24 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, __shfl_xor(wmax, m, 64));
     wmax = __builtin_amdgcn_readfirstlane(wmax);
-    const int32_t first = min(end - 1, wmax);
-    if (first < start) return;
+    // number of cell-list entries whose list index is <= wmax (entries are in ascending list order)
+    int32_t lo = 0, hi = cnt;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (cl[mid].y <= wmax) lo = mid + 1; else hi = mid;
+    }
+    const int32_t n_walk = lo;
+    if (n_walk <= 0) return;
 
-    int32_t g_next = ids[first];
-    int32_t g_next2 = first - 1 >= start ? ids[first - 1] : 0;
-    GaussRec rec_next = recs[g_next];
-    for (int32_t idx = first; idx >= start; --idx) {
-        const GaussRec rec = rec_next;
-        const int32_t g = g_next;
-        g_next = g_next2;
-        if (idx - 1 >= start) rec_next = recs[g_next];
-        g_next2 = idx - 2 >= start ? ids[idx - 2] : 0;
-
-        f3 om{0.f, 0.f, 0.f}, gro;
-        if (UNIFORM_ORIGIN) gro = {rec.r0.w, rec.r1.w, rec.r2.w};
-        else {
-            om = {ro.x - rec.r0.w, ro.y - rec.r1.w, ro.z - rec.r2.w};
-            gro = {rec.r0.x * om.x + rec.r0.y * om.y + rec.r0.z * om.z,
-                   rec.r1.x * om.x + rec.r1.y * om.y + rec.r1.z * om.z,
-                   rec.r2.x * om.x + rec.r2.y * om.y + rec.r2.z * om.z};
-        }
-        const f3 grd{rec.r0.x * rd.x + rec.r0.y * rd.y + rec.r0.z * rd.z,
-                     rec.r1.x * rd.x + rec.r1.y * rd.y + rec.r1.z * rd.z,
-                     rec.r2.x * rd.x + rec.r2.y * rd.y + rec.r2.z * rd.z};
-        const float l = grd.x * grd.x + grd.y * grd.y + grd.z * grd.z;
-        const float il = l > 0.f ? fast_rsq(l) : 1.f;
-        const f3 grd_n = grd * il;
-        const f3 gc = cross(grd_n, gro);
-        const float power = -0.5f * (gc.x * gc.x + gc.y * gc.y + gc.z * gc.z);
-        const float vis = __expf(power);
+    auto eval = [&](const GaussRec& rec, const int2 e) {
+        RayEval re;
+        ray_eval<UNIFORM_ORIGIN>(rec, ro, rd, re);
+        const f3 &om = re.om, &gro = re.gro, &grd = re.grd, &grd_n = re.grd_n, &gc = re.gc;
+        const float l = re.l, il = re.il, vis = re.vis;
         const float opac = rec.r3.x;
         const float alpha = fminf(0.999f, opac * vis);
-        const bool valid = active && idx <= bin_final && !(power > 0.f) && !(alpha < (1.f / 255.f));
-        if (__ballot(valid) == 0ull) continue;
+        const bool valid = active && e.y <= bin_final && !(alpha < (1.f / 255.f)); // (power > 0 cannot happen: -0.5 * sum of squares)
+        if (__ballot(valid) == 0ull) return;
 
         float col[CDIM];
         if (CDIM <= 3) {
@@ -380,7 +539,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
             if (CDIM > 1) col[1] = rec.r3.z;
             if (CDIM > 2) col[2] = rec.r3.w;
         } else {
-            const float* cp = colors + size_t(g) * CDIM;
+            const float* cp = colors + size_t(e.x) * CDIM;
 #pragma unroll
             for (int k = 0; k < CDIM; ++k) col[k] = cp[k];
         }
@@ -427,13 +586,14 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 #pragma unroll
             for (int k = 0; k < CDIM; ++k) buffer[k] += col[k] * fac;
         }
-        wave_sum16_atomic(v, acc + size_t(g) * ACC_STRIDE, lane);
+        wave_sum16_atomic(v, acc + size_t(e.x) * ACC_STRIDE, lane);
         if (CDIM > 3) {
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) v_extra += __shfl_xor(v_extra, m, 64);
-            if (lane == 0) unsafeAtomicAdd(v_colors_extra + size_t(g) * CDIM + 3, v_extra);
+            if (lane == 0) unsafeAtomicAdd(v_colors_extra + size_t(e.x) * CDIM + 3, v_extra);
         }
-    }
+    };
+    walk_cell_list<-1>(cl, recs, n_walk - 1, n_walk, eval, []() { return true; });
 }
 
 // ---------------------------------------------------------------------------
@@ -512,27 +672,37 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
     v_scales[3 * gid] = vs[0]; v_scales[3 * gid + 1] = vs[1]; v_scales[3 * gid + 2] = vs[2];
 }
 
-struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid; };
+struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid, wpt; uint64_t cells; };
 static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom& g) {
     if (tile_size < 8 || tile_size > 64 || (tile_size & 7)) return false;
     g.tw = (cams->image_width + tile_size - 1) / tile_size;
     g.th = (cams->image_height + tile_size - 1) / tile_size;
-    const uint32_t wpt = (tile_size / 8) * (tile_size / 8);
-    g.waves_per_block = wpt < 4 ? wpt : 4;
-    g.blocks_per_tile = wpt / g.waves_per_block;
+    g.wpt = (tile_size / 8) * (tile_size / 8);
+    g.waves_per_block = g.wpt < 4 ? g.wpt : 4;
+    g.blocks_per_tile = g.wpt / g.waves_per_block;
     g.threads = g.waves_per_block * 64;
     const uint64_t nb = uint64_t(cams->C) * g.tw * g.th * g.blocks_per_tile;
     g.grid = uint32_t(((nb + 7) / 8) * 8);
+    g.cells = uint64_t(cams->C) * g.tw * g.th * g.wpt;
     return true;
 }
+
+static uint32_t g_debug_flags = 0; // bit 0: keep every tile-list entry in the cell lists (no culling)
 
 } // namespace lfs
 
 using namespace lfs;
 
-extern "C" size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t channels) {
+extern "C" void lfs_set_debug_flags(uint32_t flags) { g_debug_flags = flags; }
+
+extern "C" size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t channels, uint32_t image_width, uint32_t image_height,
+                                                uint32_t tile_size, int64_t n_isects) {
     (void)channels;
-    return raster_ws(nullptr, C, N).bytes;
+    lfs_cameras cams{};
+    cams.C = C; cams.image_width = image_width; cams.image_height = image_height;
+    RasterGeom g;
+    if (!raster_geom(&cams, tile_size, g) || n_isects < 0) return 0;
+    return raster_ws(nullptr, C, N, g.cells, uint64_t(g.wpt) * uint64_t(n_isects)).bytes;
 }
 
 static int raster_check(uint32_t N, uint32_t channels, const lfs_cameras* cams, uint32_t tile_size, RasterGeom& g) {
@@ -542,6 +712,31 @@ static int raster_check(uint32_t N, uint32_t channels, const lfs_cameras* cams, 
     if (!raster_geom(cams, tile_size, g)) return LFS_E_UNSUPPORTED;
     (void)N;
     return LFS_OK;
+}
+
+// camera state, 64-byte records + culling records, compacted per-cell lists: everything fwd and bwd walk
+static void raster_prepare(const RasterWs& w, const RasterGeom& g, uint32_t N, uint32_t channels, const float* means, const float* quats,
+                           const float* scales, const float* colors, const float* opacities, const uint8_t* masks,
+                           const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+                           int64_t n_isects, hipStream_t s) {
+    const uint32_t C = cams->C;
+    const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
+    hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
+    const size_t CN = size_t(C) * N;
+    if (CN > 0) {
+        lfs::ProfScope prof_pack("raster_pack", s);
+        const dim3 pg(uint32_t((CN + 255) / 256));
+        if (uniform) hipLaunchKernelGGL(raster_pack_kernel<true>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs, w.cull);
+        else hipLaunchKernelGGL(raster_pack_kernel<false>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs, w.cull);
+    }
+    lfs::ProfScope prof_cull("raster_cull", s);
+    const uint32_t cull_on = (g_debug_flags & 1u) ? 0u : 1u;
+    if (uniform) hipLaunchKernelGGL(raster_cull_kernel<true>, dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height,
+                                    tile_size, g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, flatten_ids,
+                                    int32_t(n_isects), w.cell_count, w.cell_list);
+    else hipLaunchKernelGGL(raster_cull_kernel<false>, dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height,
+                            tile_size, g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, flatten_ids,
+                            int32_t(n_isects), w.cell_count, w.cell_list);
 }
 
 extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
@@ -558,25 +753,18 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     if (!render_colors || !render_alphas || !last_ids || !tile_offsets || !workspace) return LFS_E_INVALID;
     if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
     const uint32_t C = cams->C;
-    RasterWs w = raster_ws(workspace, C, N);
+    RasterWs w = raster_ws(workspace, C, N, g.cells, uint64_t(g.wpt) * uint64_t(n_isects));
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N > 0 && (!means || !quats || !scales || !colors || !opacities)) return LFS_E_INVALID;
     if (n_isects > 0 && !flatten_ids) return LFS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
-    hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
-    const size_t CN = size_t(C) * N;
-    if (CN > 0) {
-        lfs::ProfScope prof_pack("raster_pack", s);
-        const dim3 pg(uint32_t((CN + 255) / 256));
-        if (uniform) hipLaunchKernelGGL(raster_pack_kernel<true>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
-        else hipLaunchKernelGGL(raster_pack_kernel<false>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
-    }
+    raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects, s);
     lfs::ProfScope prof("raster_fwd", s);
 #define LFS_FWD(CD, UNI)                                                                                         \
     hipLaunchKernelGGL((raster_fwd_kernel<CD, UNI>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,        \
                        cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
-                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, flatten_ids, int32_t(n_isects), \
+                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, int32_t(n_isects), \
                        render_colors, render_alphas, last_ids)
     switch (channels * 2 + (uniform ? 1 : 0)) {
     case 2: LFS_FWD(1, false); break; case 3: LFS_FWD(1, true); break;
@@ -604,30 +792,25 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
     if (!workspace || !tile_offsets) return LFS_E_INVALID;
     if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
     const uint32_t C = cams->C;
-    RasterWs w = raster_ws(workspace, C, N);
+    RasterWs w = raster_ws(workspace, C, N, g.cells, uint64_t(g.wpt) * uint64_t(n_isects));
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N == 0) return LFS_OK;
     if (!means || !quats || !scales || !colors || !opacities || !v_means || !v_quats || !v_scales || !v_colors || !v_opacities) return LFS_E_INVALID;
+    if (n_isects > 0 && (!flatten_ids || !render_alphas || !last_ids || !v_render_colors || !v_render_alphas)) return LFS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
     const size_t CN = size_t(C) * N;
     hipError_t e = hipMemsetAsync(w.acc, 0, sizeof(float) * ACC_STRIDE * CN, s);
     if (e != hipSuccess) return (int)e;
     if (channels > 3) { e = hipMemsetAsync(v_colors, 0, sizeof(float) * channels * CN, s); if (e != hipSuccess) return (int)e; }
-    // the workspace is self-contained per call: camera state and records are rebuilt here
-    hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
-    {
-        const dim3 pg(uint32_t((CN + 255) / 256));
-        if (uniform) hipLaunchKernelGGL(raster_pack_kernel<true>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
-        else hipLaunchKernelGGL(raster_pack_kernel<false>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs);
-    }
+    // the workspace is self-contained per call: camera state, records and cell lists are rebuilt here
+    raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects, s);
     if (n_isects > 0) {
         lfs::ProfScope prof("raster_bwd", s);
-        if (!flatten_ids || !render_alphas || !last_ids || !v_render_colors || !v_render_alphas) return LFS_E_INVALID;
 #define LFS_BWD(CD, UNI)                                                                                         \
     hipLaunchKernelGGL((raster_bwd_kernel<CD, UNI>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,        \
                        cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
-                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, flatten_ids, int32_t(n_isects), \
+                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, int32_t(n_isects), \
                        render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors)
         switch (channels * 2 + (uniform ? 1 : 0)) {
         case 2: LFS_BWD(1, false); break; case 3: LFS_BWD(1, true); break;

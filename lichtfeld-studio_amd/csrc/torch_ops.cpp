@@ -197,7 +197,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
     at::Tensor last_ids = at::empty({C, (int64_t)image_height, (int64_t)image_width}, means.options().dtype(at::kInt));
     const lfs_cameras cams = make_cams(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs);
     const lfs_ut_params ut = make_ut(ut_params);
-    at::Tensor ws = scratch(lfs_rasterize_workspace_bytes((uint32_t)C, (uint32_t)N, (uint32_t)channels), means);
+    at::Tensor ws = scratch(lfs_rasterize_workspace_bytes((uint32_t)C, (uint32_t)N, (uint32_t)channels, (uint32_t)image_width, (uint32_t)image_height, (uint32_t)tile_size, flatten_ids.numel()), means);
     const int rc = lfs_rasterize_to_pixels_from_world_3dgs_fwd(
         (uint32_t)N, (uint32_t)channels, means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(), colors.data_ptr<float>(),
         opacities.data_ptr<float>(), opt_ptr<float>(backgrounds), (const uint8_t*)opt_ptr<bool>(masks), &cams, tile_size, &ut,
@@ -226,7 +226,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     at::Tensor v_colors = at::empty_like(colors), v_opacities = at::empty_like(opacities);
     const lfs_cameras cams = make_cams(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs);
     const lfs_ut_params ut = make_ut(ut_params);
-    at::Tensor ws = scratch(lfs_rasterize_workspace_bytes((uint32_t)C, (uint32_t)N, (uint32_t)channels), means);
+    at::Tensor ws = scratch(lfs_rasterize_workspace_bytes((uint32_t)C, (uint32_t)N, (uint32_t)channels, (uint32_t)image_width, (uint32_t)image_height, (uint32_t)tile_size, flatten_ids.numel()), means);
     const int rc = lfs_rasterize_to_pixels_from_world_3dgs_bwd(
         (uint32_t)N, (uint32_t)channels, means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(), colors.data_ptr<float>(),
         opacities.data_ptr<float>(), opt_ptr<float>(backgrounds), (const uint8_t*)opt_ptr<bool>(masks), &cams, tile_size, &ut,

@@ -178,8 +178,11 @@ def projection_ut_3dgs_fused(means: Tensor, quats: Tensor, scales: Tensor, opaci
 # -----------------------------------------------------------------------------------------
 # World-space rasterization (Ops.h:92-166, Rasterization.cpp:20-261)
 # -----------------------------------------------------------------------------------------
-def _raster_ws(C_: int, N: int, channels: int, dev) -> Tensor:
-    nbytes = load_library().lfs_rasterize_workspace_bytes(C.c_uint32(C_), C.c_uint32(N), C.c_uint32(channels))
+def _raster_ws(C_: int, N: int, channels: int, image_width: int, image_height: int, tile_size: int, n_isects: int, dev) -> Tensor:
+    nbytes = load_library().lfs_rasterize_workspace_bytes(C.c_uint32(C_), C.c_uint32(N), C.c_uint32(channels), C.c_uint32(image_width),
+                                                          C.c_uint32(image_height), C.c_uint32(tile_size), C.c_int64(n_isects))
+    if nbytes == 0:
+        raise LfsError(f"rasterize: unsupported tile_size {tile_size}")
     return workspace(nbytes, dev, "raster")
 
 
@@ -207,7 +210,7 @@ def rasterize_to_pixels_from_world_3dgs_fwd(
     cams = cameras_struct(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type,
                           radial_coeffs, tangential_coeffs, thin_prism_coeffs)
     ut = ut_struct(ut_params)
-    ws = _raster_ws(Cn, N, channels, dev)
+    ws = _raster_ws(Cn, N, channels, image_width, image_height, tile_size, flatten_ids.shape[0], dev)
     rc = load_library().lfs_rasterize_to_pixels_from_world_3dgs_fwd(
         C.c_uint32(N), C.c_uint32(channels), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities),
         ptr(backgrounds), ptr(masks), C.byref(cams), C.c_uint32(tile_size), C.byref(ut),
@@ -241,7 +244,7 @@ def rasterize_to_pixels_from_world_3dgs_bwd(
     cams = cameras_struct(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type,
                           radial_coeffs, tangential_coeffs, thin_prism_coeffs)
     ut = ut_struct(ut_params)
-    ws = _raster_ws(Cn, N, channels, dev)
+    ws = _raster_ws(Cn, N, channels, image_width, image_height, tile_size, flatten_ids.shape[0], dev)
     rc = load_library().lfs_rasterize_to_pixels_from_world_3dgs_bwd(
         C.c_uint32(N), C.c_uint32(channels), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities),
         ptr(backgrounds), ptr(masks), C.byref(cams), C.c_uint32(tile_size), C.byref(ut),

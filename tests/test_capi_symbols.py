@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lfs):
 def test_workspace_size_queries_are_pure_host_functions(lfs):
     lib = lfs.load_library()
     a = lib.lfs_intersect_tile_workspace_bytes(ctypes.c_uint32(1), ctypes.c_uint32(1000000), ctypes.c_uint32(120), ctypes.c_uint32(68))
-    b = lib.lfs_rasterize_workspace_bytes(ctypes.c_uint32(1), ctypes.c_uint32(1000000), ctypes.c_uint32(3))
+    b = lib.lfs_rasterize_workspace_bytes(ctypes.c_uint32(1), ctypes.c_uint32(1000000), ctypes.c_uint32(3), ctypes.c_uint32(1920), ctypes.c_uint32(1080), ctypes.c_uint32(16), ctypes.c_int64(5000000))
     assert a > 3 * 8160 * 4 and a % 256 == 0
     assert b >= 1000000 * 128 and b % 256 == 0
 

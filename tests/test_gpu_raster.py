@@ -195,3 +195,71 @@ def test_raster_bwd_is_linear_in_output_gradients_full_size(lfs):
         assert torch.isfinite(x12).all()
         lin = 2 * x1 - 3 * x2
         assert float((x12 - lin).norm() / (lin.norm() + 1e-20)) < 1e-4
+
+
+def _cull_on_off(lfs, fn):
+    lib = lfs.load_library()
+    try:
+        lib.lfs_set_debug_flags(1)   # per-cell lists = full tile lists
+        ref = fn()
+    finally:
+        lib.lfs_set_debug_flags(0)
+    return ref, fn()
+
+
+@pytest.mark.parametrize("kind", ["small", "needles", "huge_and_near", "low_opacity"])
+def test_cell_culling_is_conservative(lfs, oracle_mod, kind):
+    """The per-8x8-cell culling (raster_cull_kernel) may only drop entries that cannot reach alpha >= 1/255 on any
+    ray of the cell: forward outputs must be BIT-identical with culling on and off, the backward equal up to the
+    float-atomic summation order."""
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng({"small": 40, "needles": 41, "huge_and_near": 42, "low_opacity": 43}[kind])
+    N, W, H, ts = 6000, 200, 136, 16
+    means, quats, scales, opac = make_gaussians(rng, N, spread=1.5, smin=0.01, smax=0.05)
+    if kind == "needles":
+        scales = (np.exp(rng.uniform(np.log(1e-4), np.log(0.5), (N, 3)))).astype(np.float32)
+    elif kind == "huge_and_near":
+        scales[: N // 4] *= 40.0                                   # screen-filling
+        means[N // 4: N // 2, 2] = rng.uniform(0.02, 0.3, N // 4)  # right in front of the camera plane
+        means[N // 2: N // 2 + 200, 2] = rng.uniform(-0.5, 0.0, 200)  # behind the camera (never listed by the projection, listed here on purpose)
+    elif kind == "low_opacity":
+        opac = rng.uniform(0.0, 0.02, N).astype(np.float32)
+        opac[::7] = 0.9
+    vm0 = small_rotation_viewmat(rng, 0.2, 0.3)[None]
+    K = pinhole_K(0.8 * W, W, H, 1)
+    colors = rng.random((1, N, 3)).astype(np.float32)
+    tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
+    # adversarial lists: EVERY Gaussian is listed in EVERY tile (depth-sorted) - culling has to sort it out
+    depth = (means @ vm0[0, :3, :3].T + vm0[0, :3, 3])[:, 2]
+    order = np.argsort(depth, kind="stable").astype(np.int32)
+    n_t = tw * th
+    per_tile = 400
+    flat = np.concatenate([np.sort(rng.choice(N, per_tile, replace=False)) for _ in range(n_t)]).astype(np.int32)
+    flat = order[flat.reshape(n_t, per_tile)].reshape(-1)  # ascending depth inside each tile
+    offs = (np.arange(n_t, dtype=np.int32) * per_tile).reshape(1, th, tw)
+    args = (t(means), t(quats), t(scales), t(colors), t(opac[None]), None, None, W, H, ts, t(vm0), None, t(K), lfs.CameraModelType.PINHOLE, None,
+            lfs.ShutterType.GLOBAL, None, None, None, t(offs, torch.int32), t(flat, torch.int32))
+    (r0, a0, l0), (r1, a1, l1) = _cull_on_off(lfs, lambda: ops.rasterize_to_pixels_from_world_3dgs_fwd(*args))
+    assert torch.equal(r0, r1) and torch.equal(a0, a1) and torch.equal(l0, l1)
+    assert float(a1.max()) > 0.05, "degenerate scene"
+    v_rc, v_ra = t(rng.standard_normal(tuple(r1.shape)).astype(np.float32)), t(rng.standard_normal(tuple(a1.shape)).astype(np.float32))
+    bwd = lambda: ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, a1, l1, v_rc, v_ra)
+    g0, g1 = _cull_on_off(lfs, bwd)
+    g2 = bwd()  # run-to-run noise of the float atomics (large for ill-conditioned needles)
+    for x0, x1, x2 in zip(g0, g1, g2):
+        assert torch.isfinite(x1).all()
+        noise = float((x2 - x1).norm() / (x1.norm() + 1e-30))
+        assert float((x0 - x1).norm() / (x0.norm() + 1e-30)) < max(1e-5, 5 * noise)
+
+
+def test_cell_culling_full_size_bit_identical(lfs):
+    """SYN-B (1M Gaussians, 1080p) through the real projection / intersection lists."""
+    from lichtfeld_studio_amd import scenes
+    from lichtfeld_studio_amd.rasterizer import Camera, SplatModel, rasterize
+    dev = torch.device("cuda:0")
+    sc = scenes.syn_b(n=1_000_000, n_views=4).to(dev)
+    model = SplatModel(sc.means, sc.sh0, sc.shN, sc.raw_scales, sc.raw_quats, sc.raw_opacities, 3)
+    cam = Camera(sc.viewmats[1:2].contiguous(), sc.Ks[1:2].contiguous(), sc.width, sc.height)
+    with torch.no_grad():
+        a, b = _cull_on_off(lfs, lambda: rasterize(cam, model, torch.zeros(3, device=dev)))
+    assert torch.equal(a.image, b.image) and torch.equal(a.alpha, b.alpha)
