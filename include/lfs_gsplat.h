@@ -134,7 +134,7 @@ LFS_API int lfs_intersect_offset(
  *      flatten_ids int32 [n_isects] (values in [0, C*N)).
  *      fwd: render_colors [C,H,W,channels], render_alphas [C,H,W,1], last_ids int32 [C,H,W].
  *      bwd: v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,channels],
- *           v_opacities [C,N] — all FULLY written (no pre-zeroing needed). */
+ *           v_opacities [C,N] — all FULLY written (no pre-zeroing needed). v_render_alphas may be NULL (= zeros). */
 /*      workspace: camera state + one 64-B record, one 64-B gradient accumulator row and one 32-B culling
  *      record per (camera, Gaussian) + the compacted per-8x8-cell lists ((tile_size/8)^2 * n_isects * 8 B,
  *      worst case). Returns 0 for an unsupported tile_size. */
@@ -159,6 +159,44 @@ LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
     const float* v_render_colors, const float* v_render_alphas,
     float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+
+/*      extension (not in Ops.h): the same backward, for a caller that still owns the workspace the matching
+ *      forward call filled (same inputs, nothing else ran on that workspace in between): skips rebuilding
+ *      the records and the per-cell lists. Used by the autograd Function of rasterizer.py. */
+LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared(
+    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
+    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
+    const lfs_cameras* cams, uint32_t tile_size, const lfs_ut_params* ut_params,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    const float* render_alphas, const int32_t* last_ids,
+    const float* v_render_colors, const float* v_render_alphas,
+    float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+
+/* ---- Fused L2 extensions (not in Ops.h; lichtfeld-studio_amd/fused.py, trainer.py): the libtorch element-wise
+ *      work rasterizer.cpp:200-263 / splat_data.cpp:267-286 / the trainer's loss wrap around the operators,
+ *      as single passes. Same arithmetic as the op-by-op path (tests/test_gpu_fused.py).
+ *   lfs_sh_model_fwd : colors [N,3] = clamp_min(SH(normalize(means - campos(viewmat)), cat(sh0, shN)) + 0.5, 0)
+ *                      with mask = all(radii > 0); viewmat = ONE rigid row-major [4,4] on the device.
+ *   lfs_sh_model_bwd : v_colors = dL/dcolors (the clamp is applied inside from `colors`); v_sh0 [N,1,3], v_shN [N,K-1,3]
+ *                      written (accumulate = 0) or added to (accumulate != 0); v_means [N,3] += dL/d(dirs).
+ *   lfs_activations_fwd / _bwd : quats = normalize(raw), scales = exp(raw), opacities = sigmoid(raw) and the vjp.
+ *   lfs_mse_loss_fwd_bwd : *loss += weight * mean((clamp(render,0,1) - target)^2), v_render = d/d(render);
+ *                      render / v_render HWC [H,W,3], target CHW [3,H,W]. */
+LFS_API int lfs_sh_model_fwd(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+    const int32_t* radii, float* colors, lfs_stream_t stream);
+LFS_API int lfs_sh_model_bwd(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+    const int32_t* radii, const float* colors, const float* v_colors, int accumulate,
+    float* v_sh0, float* v_shN, float* v_means, lfs_stream_t stream);
+LFS_API int lfs_activations_fwd(uint32_t N, const float* raw_quats, const float* raw_scales, const float* raw_opacities,
+                                float* quats, float* scales, float* opacities, lfs_stream_t stream);
+LFS_API int lfs_activations_bwd(uint32_t N, const float* raw_quats, const float* scales, const float* opacities,
+                                const float* v_quats, const float* v_scales, const float* v_opacities, int accumulate,
+                                float* g_raw_quats, float* g_raw_scales, float* g_raw_opacities, lfs_stream_t stream);
+LFS_API int lfs_mse_loss_fwd_bwd(uint32_t H, uint32_t W, const float* render_hwc, const float* target_chw, float weight,
+                                 float* v_render_hwc, float* loss, lfs_stream_t stream);
 
 /* ---- gsplat::quats_to_rotmats (gsplat/Ops.h:45-48, QuatToRotmatCUDA.cu:14-39): rotmats [N,3,3] row-major */
 LFS_API int lfs_quats_to_rotmats(uint32_t N, const float* quats, float* rotmats, lfs_stream_t stream);

@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     if (active) {
         T_final = 1.f - render_alphas[pix_id];
         bin_final = last_ids[pix_id];
-        v_ra = v_render_alphas[pix_id];
+        v_ra = v_render_alphas ? v_render_alphas[pix_id] : 0.f;
 #pragma unroll
         for (int k = 0; k < CDIM; ++k) vc[k] = v_render_colors[pix_id * CDIM + k];
     }
@@ -776,16 +776,15 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     return (int)hipGetLastError();
 }
 
-extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
+static int raster_bwd_impl(
     uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
     const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
-    const lfs_cameras* cams, uint32_t tile_size, const lfs_ut_params* ut_params,
+    const lfs_cameras* cams, uint32_t tile_size,
     const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
     const float* render_alphas, const int32_t* last_ids,
     const float* v_render_colors, const float* v_render_alphas,
     float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
-    (void)ut_params;
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream, bool prepared) {
     RasterGeom g;
     int rc = raster_check(N, channels, cams, tile_size, g);
     if (rc) return rc;
@@ -796,15 +795,16 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N == 0) return LFS_OK;
     if (!means || !quats || !scales || !colors || !opacities || !v_means || !v_quats || !v_scales || !v_colors || !v_opacities) return LFS_E_INVALID;
-    if (n_isects > 0 && (!flatten_ids || !render_alphas || !last_ids || !v_render_colors || !v_render_alphas)) return LFS_E_INVALID;
+    if (n_isects > 0 && (!flatten_ids || !render_alphas || !last_ids || !v_render_colors)) return LFS_E_INVALID; // v_render_alphas == NULL: zeros
     hipStream_t s = (hipStream_t)stream;
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
     const size_t CN = size_t(C) * N;
     hipError_t e = hipMemsetAsync(w.acc, 0, sizeof(float) * ACC_STRIDE * CN, s);
     if (e != hipSuccess) return (int)e;
     if (channels > 3) { e = hipMemsetAsync(v_colors, 0, sizeof(float) * channels * CN, s); if (e != hipSuccess) return (int)e; }
-    // the workspace is self-contained per call: camera state, records and cell lists are rebuilt here
-    raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects, s);
+    // self-contained call: camera state, records and cell lists are rebuilt; "prepared" = the caller guarantees
+    // the workspace still holds what the forward call with the same inputs left there
+    if (!prepared) raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects, s);
     if (n_isects > 0) {
         lfs::ProfScope prof("raster_bwd", s);
 #define LFS_BWD(CD, UNI)                                                                                         \
@@ -825,4 +825,34 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
     if (uniform) hipLaunchKernelGGL(raster_finish_kernel<true>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities);
     else hipLaunchKernelGGL(raster_finish_kernel<false>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities);
     return (int)hipGetLastError();
+}
+
+extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
+    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
+    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
+    const lfs_cameras* cams, uint32_t tile_size, const lfs_ut_params* ut_params,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    const float* render_alphas, const int32_t* last_ids,
+    const float* v_render_colors, const float* v_render_alphas,
+    float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    (void)ut_params;
+    return raster_bwd_impl(N, channels, means, quats, scales, colors, opacities, backgrounds, masks, cams, tile_size, tile_offsets, flatten_ids,
+                           n_isects, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
+                           v_opacities, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared(
+    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
+    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
+    const lfs_cameras* cams, uint32_t tile_size, const lfs_ut_params* ut_params,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    const float* render_alphas, const int32_t* last_ids,
+    const float* v_render_colors, const float* v_render_alphas,
+    float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    (void)ut_params;
+    return raster_bwd_impl(N, channels, means, quats, scales, colors, opacities, backgrounds, masks, cams, tile_size, tile_offsets, flatten_ids,
+                           n_isects, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
+                           v_opacities, workspace, workspace_bytes, stream, true);
 }

@@ -186,6 +186,93 @@ __global__ void __launch_bounds__(256) sh_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fused L2 variants (extensions, not in Ops.h): what rasterizer.cpp:256-263 builds around the op with
+// libtorch - dirs = means - campos, masks = all(radii > 0), coeffs = cat(sh0, shN),
+// colors = clamp_min(sh + 0.5, 0) - folded into the kernel, so none of those tensors is materialised
+// (the cat alone is a 192 MB copy per step at 1M Gaussians, and again in the backward).
+// ---------------------------------------------------------------------------
+LFS_DI f3 campos_of(const float* __restrict__ vm) { // -R^T t of a rigid row-major [4,4] world->camera matrix
+    return {-(vm[0] * vm[3] + vm[4] * vm[7] + vm[8] * vm[11]),
+            -(vm[1] * vm[3] + vm[5] * vm[7] + vm[9] * vm[11]),
+            -(vm[2] * vm[3] + vm[6] * vm[7] + vm[10] * vm[11])};
+}
+
+template <int LPG>
+__global__ void __launch_bounds__(256) sh_model_fwd_kernel(
+    const uint32_t n, const uint32_t K, const int degree,
+    const float* __restrict__ means, const float* __restrict__ viewmat, const float* __restrict__ sh0, const float* __restrict__ shN,
+    const int32_t* __restrict__ radii, float* __restrict__ colors) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = tid / LPG;
+    const int k = tid % LPG;
+    if (g >= n) return;
+    const int Kd = (degree + 1) * (degree + 1);
+    const bool on = radii[2 * g] > 0 && radii[2 * g + 1] > 0;
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    if (on) {
+        const f3 cp = campos_of(viewmat);
+        float x = means[3 * g] - cp.x, y = means[3 * g + 1] - cp.y, z = means[3 * g + 2] - cp.z;
+        if (degree >= 1) { const float inorm = 1.f / sqrtf(x * x + y * y + z * z); x *= inorm; y *= inorm; z *= inorm; }
+        float b[25];
+        sh_basis<false>(degree, x, y, z, b, nullptr, nullptr, nullptr);
+        const float bk = pick<LPG>(b, k);
+        if (k < Kd) {
+            const float* cf = (k == 0) ? sh0 + size_t(g) * 3 : shN + (size_t(g) * (K - 1) + (k - 1)) * 3;
+            r0 = bk * cf[0]; r1 = bk * cf[1]; r2 = bk * cf[2];
+        }
+    }
+    r0 = group_sum<LPG>(r0); r1 = group_sum<LPG>(r1); r2 = group_sum<LPG>(r2);
+    if (k == 0) { colors[3 * g] = fmaxf(r0 + 0.5f, 0.f); colors[3 * g + 1] = fmaxf(r1 + 0.5f, 0.f); colors[3 * g + 2] = fmaxf(r2 + 0.5f, 0.f); }
+}
+
+// v_colors = dL/d(clamped colors); the clamp passes where the stored colour is > 0. v_sh0 / v_shN are written
+// (ACCUM = false) or added to (ACCUM = true: second and later views of a step); v_means += dL/d(dirs).
+template <int LPG, bool ACCUM>
+__global__ void __launch_bounds__(256) sh_model_bwd_kernel(
+    const uint32_t n, const uint32_t K, const int degree,
+    const float* __restrict__ means, const float* __restrict__ viewmat, const float* __restrict__ sh0, const float* __restrict__ shN,
+    const int32_t* __restrict__ radii, const float* __restrict__ colors, const float* __restrict__ v_colors,
+    float* __restrict__ v_sh0, float* __restrict__ v_shN, float* __restrict__ v_means) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = tid / LPG;
+    const int k = tid % LPG;
+    if (g >= n) return;
+    const int Kd = (degree + 1) * (degree + 1);
+    const bool on = radii[2 * g] > 0 && radii[2 * g + 1] > 0;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    float x = 0.f, y = 0.f, z = 0.f, inorm = 1.f;
+    if (on) {
+        const f3 cp = campos_of(viewmat);
+        x = means[3 * g] - cp.x; y = means[3 * g + 1] - cp.y; z = means[3 * g + 2] - cp.z;
+        if (degree >= 1) { inorm = 1.f / sqrtf(x * x + y * y + z * z); x *= inorm; y *= inorm; z *= inorm; }
+        const float v0 = colors[3 * g] > 0.f ? v_colors[3 * g] : 0.f;
+        const float v1 = colors[3 * g + 1] > 0.f ? v_colors[3 * g + 1] : 0.f;
+        const float v2 = colors[3 * g + 2] > 0.f ? v_colors[3 * g + 2] : 0.f;
+        float b[25], bx[25], by[25], bz[25];
+        sh_basis<true>(degree, x, y, z, b, bx, by, bz);
+        const float bk = pick<LPG>(b, k);
+        if (k < Kd) {
+            o0 = bk * v0; o1 = bk * v1; o2 = bk * v2;
+            if (degree >= 1) {
+                const float* cf = (k == 0) ? sh0 + size_t(g) * 3 : shN + (size_t(g) * (K - 1) + (k - 1)) * 3;
+                const float s = cf[0] * v0 + cf[1] * v1 + cf[2] * v2;
+                gx = pick<LPG>(bx, k) * s; gy = pick<LPG>(by, k) * s; gz = pick<LPG>(bz, k) * s;
+            }
+        }
+    }
+    if (uint32_t(k) < K) {
+        float* vc = (k == 0) ? v_sh0 + size_t(g) * 3 : v_shN + (size_t(g) * (K - 1) + (k - 1)) * 3;
+        if (ACCUM) { if (on) { vc[0] += o0; vc[1] += o1; vc[2] += o2; } }
+        else { vc[0] = o0; vc[1] = o1; vc[2] = o2; }
+    }
+    gx = group_sum<LPG>(gx); gy = group_sum<LPG>(gy); gz = group_sum<LPG>(gz);
+    if (k == 0 && on && degree >= 1) {
+        const float d = gx * x + gy * y + gz * z;
+        v_means[3 * g] += (gx - d * x) * inorm; v_means[3 * g + 1] += (gy - d * y) * inorm; v_means[3 * g + 2] += (gz - d * z) * inorm;
+    }
+}
+
 static inline int lanes_for(uint32_t k) { return k <= 1 ? 1 : k <= 4 ? 4 : k <= 16 ? 16 : 32; }
 
 } // namespace lfs
@@ -231,5 +318,54 @@ extern "C" int lfs_spherical_harmonics_bwd(
     case 16: hipLaunchKernelGGL(lfs::sh_bwd_kernel<16>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
     default: hipLaunchKernelGGL(lfs::sh_bwd_kernel<32>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int lfs_sh_model_fwd(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+    const int32_t* radii, float* colors, lfs_stream_t stream) {
+    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
+    if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
+    if (n == 0) return LFS_OK;
+    if (!means || !viewmat || !sh0 || (K > 1 && !shN) || !radii || !colors) return LFS_E_INVALID;
+    const int lpg = lfs::lanes_for(Kd);
+    dim3 grid((uint64_t(n) * lpg + 255) / 256), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int deg = int(degrees_to_use);
+    lfs::ProfScope prof("sh_fwd", s);
+    switch (lpg) {
+    case 1: hipLaunchKernelGGL(lfs::sh_model_fwd_kernel<1>, grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, colors); break;
+    case 4: hipLaunchKernelGGL(lfs::sh_model_fwd_kernel<4>, grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, colors); break;
+    case 16: hipLaunchKernelGGL(lfs::sh_model_fwd_kernel<16>, grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, colors); break;
+    default: hipLaunchKernelGGL(lfs::sh_model_fwd_kernel<32>, grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, colors); break;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int lfs_sh_model_bwd(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+    const int32_t* radii, const float* colors, const float* v_colors, int accumulate,
+    float* v_sh0, float* v_shN, float* v_means, lfs_stream_t stream) {
+    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
+    if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
+    if (n == 0) return LFS_OK;
+    if (!means || !viewmat || !sh0 || (K > 1 && (!shN || !v_shN)) || !radii || !colors || !v_colors || !v_sh0 || !v_means) return LFS_E_INVALID;
+    const int lpg = lfs::lanes_for(K);
+    dim3 grid((uint64_t(n) * lpg + 255) / 256), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int deg = int(degrees_to_use);
+    lfs::ProfScope prof("sh_bwd", s);
+#define LFS_SHB(L)                                                                                                                       \
+    if (accumulate) hipLaunchKernelGGL((lfs::sh_model_bwd_kernel<L, true>), grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, \
+                                       colors, v_colors, v_sh0, v_shN, v_means);                                                          \
+    else hipLaunchKernelGGL((lfs::sh_model_bwd_kernel<L, false>), grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, colors,    \
+                            v_colors, v_sh0, v_shN, v_means)
+    switch (lpg) {
+    case 1: LFS_SHB(1); break;
+    case 4: LFS_SHB(4); break;
+    case 16: LFS_SHB(16); break;
+    default: LFS_SHB(32); break;
+    }
+#undef LFS_SHB
     return (int)hipGetLastError();
 }

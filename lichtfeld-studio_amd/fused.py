@@ -1,0 +1,115 @@
+"""Fused L2 path for the --gut training step (extension; same arithmetic as rasterizer.py + torch autograd).
+
+rasterizer.py mirrors the reference's L2 one libtorch op at a time (activations, `cat(sh0, shN)`, `dirs`, masks,
+`clamp_min`, permute / clamp of the image, the loss and the autograd graph of all of it): ~100 small launches
+and ~0.8 ms of HBM passes per step at 1M Gaussians. Here the same step is a fixed sequence of C-ABI calls
+with NO autograd graph: forward and backward are issued explicitly, the element-wise glue lives in the fused
+kernels of csrc/l2_fused.hip and csrc/sh.hip (`lfs_sh_model_*`), the rasterizer backward reuses the
+forward's workspace, and the raw-parameter gradients are written straight into the caller's buffers (for
+data parallel runs: views of the flat all-reduce bucket, so there is no gather copy).
+
+Restricted to what the trainer uses: one camera per call, RGB render mode, global shutter, MSE loss.
+tests/test_gpu_fused.py checks every stage and the end-to-end gradients against the autograd path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .capi import (CameraModelType, ShutterType, UnscentedTransformParameters, cameras_struct, check, load_library, ptr,
+                   require_gpu, stream, ut_struct)
+from .rasterizer import Camera, SplatModel
+
+
+def activations_fwd(raw_quats, raw_scales, raw_opacities):
+    require_gpu(raw_quats, raw_scales, raw_opacities)
+    N = raw_quats.shape[0]
+    quats, scales, opac = torch.empty_like(raw_quats), torch.empty_like(raw_scales), torch.empty_like(raw_opacities)
+    check(load_library().lfs_activations_fwd(C.c_uint32(N), ptr(raw_quats), ptr(raw_scales), ptr(raw_opacities),
+                                             ptr(quats), ptr(scales), ptr(opac), stream()), "activations_fwd")
+    return quats, scales, opac
+
+
+def activations_bwd(raw_quats, scales, opacities, v_quats, v_scales, v_opacities, g_raw_quats, g_raw_scales, g_raw_opacities, accumulate: bool):
+    require_gpu(raw_quats, scales, opacities, v_quats, v_scales, v_opacities, g_raw_quats, g_raw_scales, g_raw_opacities)
+    check(load_library().lfs_activations_bwd(C.c_uint32(raw_quats.shape[0]), ptr(raw_quats), ptr(scales), ptr(opacities),
+                                             ptr(v_quats), ptr(v_scales), ptr(v_opacities), C.c_int(int(accumulate)),
+                                             ptr(g_raw_quats), ptr(g_raw_scales), ptr(g_raw_opacities), stream()), "activations_bwd")
+
+
+def sh_model_fwd(sh_degree: int, means, viewmat, sh0, shN, radii):
+    require_gpu(means, viewmat, sh0, shN, radii)
+    N, K = means.shape[0], 1 + shN.shape[1]
+    colors = torch.empty((N, 3), dtype=means.dtype, device=means.device)
+    check(load_library().lfs_sh_model_fwd(C.c_uint32(N), C.c_uint32(K), C.c_uint32(sh_degree), ptr(means), ptr(viewmat), ptr(sh0), ptr(shN),
+                                          ptr(radii), ptr(colors), stream()), "sh_model_fwd")
+    return colors
+
+
+def sh_model_bwd(sh_degree: int, means, viewmat, sh0, shN, radii, colors, v_colors, v_sh0, v_shN, v_means, accumulate: bool):
+    require_gpu(means, viewmat, sh0, shN, radii, colors, v_colors, v_sh0, v_shN, v_means)
+    N, K = means.shape[0], 1 + shN.shape[1]
+    check(load_library().lfs_sh_model_bwd(C.c_uint32(N), C.c_uint32(K), C.c_uint32(sh_degree), ptr(means), ptr(viewmat), ptr(sh0), ptr(shN),
+                                          ptr(radii), ptr(colors), ptr(v_colors), C.c_int(int(accumulate)),
+                                          ptr(v_sh0), ptr(v_shN), ptr(v_means), stream()), "sh_model_bwd")
+
+
+def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
+    """loss_acc (1-element tensor) += weight * mse(clamp(render, 0, 1), target); returns dL/d(render) [H,W,3]."""
+    require_gpu(render_hwc, target_chw, loss_acc)
+    H, W = render_hwc.shape[-3], render_hwc.shape[-2]
+    assert render_hwc.shape[-1] == 3 and tuple(target_chw.shape) == (3, H, W), (render_hwc.shape, target_chw.shape)
+    v = torch.empty_like(render_hwc)
+    check(load_library().lfs_mse_loss_fwd_bwd(C.c_uint32(H), C.c_uint32(W), ptr(render_hwc), ptr(target_chw), C.c_float(weight),
+                                              ptr(v), ptr(loss_acc), stream()), "mse_loss_fwd_bwd")
+    return v
+
+
+@dataclass
+class FusedStepOutput:
+    image_hwc: torch.Tensor      # [1,H,W,3] un-clamped render (rasterizer output)
+    alpha: torch.Tensor          # [1,H,W,1]
+    radii: torch.Tensor          # [1,N,2]
+    n_isects: int
+
+
+def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
+                        grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool) -> FusedStepOutput:
+    """One view: forward, MSE against `target_chw`, backward. `grads` = six tensors shaped like model.parameters()
+    (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
+    Constants as in rasterizer.cpp:176-181."""
+    assert camera.camera_model_type == CameraModelType.PINHOLE and camera.radial_distortion is None and camera.tangential_distortion is None, \
+        "the fused path covers the trainer's undistorted pinhole cameras; use rasterizer.rasterize for the rest"
+    W, H = int(camera.image_width), int(camera.image_height)
+    viewmat, Kmat = camera.world_view_transform.contiguous(), camera.K.contiguous()
+    means, sh0, shN, raw_scales, raw_quats, raw_opac = [p.detach() for p in model.parameters()]
+    g_means, g_sh0, g_shN, g_scales, g_quats, g_opac = grads
+    deg = model.get_active_sh_degree()
+    ut = UnscentedTransformParameters()
+    tile = 16
+    tw, th = (W + tile - 1) // tile, (H + tile - 1) // tile
+    with torch.no_grad():
+        quats, scales, opac = activations_fwd(raw_quats, raw_scales, raw_opac)
+        radii, means2d, depths, _, _ = ops.projection_ut_3dgs_fused(means, quats, scales, opac, viewmat, None, Kmat, W, H, 0.3, 0.01, 10000.0, 0.0,
+                                                                    False, CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None)
+        colors = sh_model_fwd(deg, means, viewmat, sh0, shN, radii)
+        _, _, flatten_ids, offsets = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True)
+        bg = None if bg_color is None else bg_color.view(1, -1).contiguous()
+        fwd_args = (means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, None, W, H, tile, viewmat, None, Kmat,
+                    CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None, offsets, flatten_ids)
+        render, alpha, last_ids, ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(*fwd_args, own_workspace=True)
+        v_render = mse_loss_fwd_bwd(render, target_chw, weight, loss_acc)
+        v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
+            *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws)
+        # SH backward adds dL/d(dirs) onto the rasterizer's dL/d(means) in place, then the means gradient lands in the caller's buffer
+        sh_model_bwd(deg, means, viewmat, sh0, shN, radii, colors, v_colors.squeeze(0), g_sh0, g_shN, v_means, accumulate)
+        if accumulate:
+            g_means.add_(v_means)
+        else:
+            g_means.copy_(v_means)
+        activations_bwd(raw_quats, scales, opac, v_quats, v_scales, v_opac.squeeze(0), g_quats, g_scales, g_opac, accumulate)
+    return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]))

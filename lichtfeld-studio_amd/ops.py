@@ -193,9 +193,11 @@ def rasterize_to_pixels_from_world_3dgs_fwd(
         viewmats0: Tensor, viewmats1: Optional[Tensor], Ks: Tensor, camera_model: CameraModelType,
         ut_params: Optional[UnscentedTransformParameters], rs_type: ShutterType,
         radial_coeffs: Optional[Tensor], tangential_coeffs: Optional[Tensor], thin_prism_coeffs: Optional[Tensor],
-        tile_offsets: Tensor, flatten_ids: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        tile_offsets: Tensor, flatten_ids: Tensor, own_workspace: bool = False):
     """-> (renders [C,H,W,channels], alphas [C,H,W,1], last_ids int32 [C,H,W]). channels in 1..4
-    (the reference asserts 3, Rasterization.cpp:65, although its L2 builds 1- and 4-channel inputs)."""
+    (the reference asserts 3, Rasterization.cpp:65, although its L2 builds 1- and 4-channel inputs).
+    own_workspace=True (extension): the call gets a fresh workspace tensor, returned as a 4th value, that the
+    matching backward can reuse (prepared_workspace=) instead of rebuilding records and per-cell lists."""
     backgrounds, masks, viewmats1 = _opt(backgrounds), _opt(masks), _opt(viewmats1)
     radial_coeffs, tangential_coeffs, thin_prism_coeffs = _opt(radial_coeffs), _opt(tangential_coeffs), _opt(thin_prism_coeffs)
     require_gpu(means, quats, scales, colors, opacities, backgrounds, masks, viewmats0, viewmats1, Ks,
@@ -210,7 +212,14 @@ def rasterize_to_pixels_from_world_3dgs_fwd(
     cams = cameras_struct(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type,
                           radial_coeffs, tangential_coeffs, thin_prism_coeffs)
     ut = ut_struct(ut_params)
-    ws = _raster_ws(Cn, N, channels, image_width, image_height, tile_size, flatten_ids.shape[0], dev)
+    if own_workspace:
+        nbytes = load_library().lfs_rasterize_workspace_bytes(C.c_uint32(Cn), C.c_uint32(N), C.c_uint32(channels), C.c_uint32(image_width),
+                                                              C.c_uint32(image_height), C.c_uint32(tile_size), C.c_int64(flatten_ids.shape[0]))
+        if nbytes == 0:
+            raise LfsError(f"rasterize: unsupported tile_size {tile_size}")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    else:
+        ws = _raster_ws(Cn, N, channels, image_width, image_height, tile_size, flatten_ids.shape[0], dev)
     rc = load_library().lfs_rasterize_to_pixels_from_world_3dgs_fwd(
         C.c_uint32(N), C.c_uint32(channels), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities),
         ptr(backgrounds), ptr(masks), C.byref(cams), C.c_uint32(tile_size), C.byref(ut),
@@ -219,6 +228,8 @@ def rasterize_to_pixels_from_world_3dgs_fwd(
     if rc == -2:
         raise LfsError(f"Unsupported number of channels / tile size / camera model: channels={channels}, tile_size={tile_size}")
     check(rc, "rasterize_to_pixels_from_world_3dgs_fwd")
+    if own_workspace:
+        return renders, alphas, last_ids, ws
     return renders, alphas, last_ids
 
 
@@ -230,7 +241,7 @@ def rasterize_to_pixels_from_world_3dgs_bwd(
         ut_params: Optional[UnscentedTransformParameters], rs_type: ShutterType,
         radial_coeffs: Optional[Tensor], tangential_coeffs: Optional[Tensor], thin_prism_coeffs: Optional[Tensor],
         tile_offsets: Tensor, flatten_ids: Tensor, render_alphas: Tensor, last_ids: Tensor,
-        v_render_colors: Tensor, v_render_alphas: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+        v_render_colors: Tensor, v_render_alphas: Tensor, prepared_workspace: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     """-> (v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,ch], v_opacities [C,N])."""
     backgrounds, masks, viewmats1 = _opt(backgrounds), _opt(masks), _opt(viewmats1)
     radial_coeffs, tangential_coeffs, thin_prism_coeffs = _opt(radial_coeffs), _opt(tangential_coeffs), _opt(thin_prism_coeffs)
@@ -244,8 +255,12 @@ def rasterize_to_pixels_from_world_3dgs_bwd(
     cams = cameras_struct(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type,
                           radial_coeffs, tangential_coeffs, thin_prism_coeffs)
     ut = ut_struct(ut_params)
-    ws = _raster_ws(Cn, N, channels, image_width, image_height, tile_size, flatten_ids.shape[0], dev)
-    rc = load_library().lfs_rasterize_to_pixels_from_world_3dgs_bwd(
+    lib = load_library()
+    if prepared_workspace is not None:
+        ws, entry = prepared_workspace, lib.lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared
+    else:
+        ws, entry = _raster_ws(Cn, N, channels, image_width, image_height, tile_size, flatten_ids.shape[0], dev), lib.lfs_rasterize_to_pixels_from_world_3dgs_bwd
+    rc = entry(
         C.c_uint32(N), C.c_uint32(channels), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities),
         ptr(backgrounds), ptr(masks), C.byref(cams), C.c_uint32(tile_size), C.byref(ut),
         ptr(tile_offsets), ptr(flatten_ids), C.c_int64(flatten_ids.shape[0]),

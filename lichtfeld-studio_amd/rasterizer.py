@@ -130,7 +130,8 @@ class GUTRasterizationFunction(torch.autograd.Function):
                 None if bg_color is None else bg_color.contiguous(), None if masks is None else masks.contiguous(),
                 width, height, tile_size, viewmat.contiguous(), None, K.contiguous(), camera_model, ut_params, ShutterType.GLOBAL,
                 radial_coeffs, tangential_coeffs, thin_prism_coeffs, isect_offsets.contiguous(), flatten_ids.contiguous())
-        render_colors, render_alpha, last_ids = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
+        # the forward's workspace (records + per-cell lists) is kept for the backward (own tensor, not the shared scratch)
+        render_colors, render_alpha, last_ids, ctx.raster_ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args, own_workspace=True)
         ctx.fwd_args = args
         ctx.save_for_backward(render_alpha, last_ids)
         ctx.bg_needs_grad = bg_color is not None and bg_color.requires_grad
@@ -142,7 +143,8 @@ class GUTRasterizationFunction(torch.autograd.Function):
         v_render_colors = v_render_colors.contiguous()
         v_render_alpha = v_render_alpha.contiguous()
         v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
-            *ctx.fwd_args, render_alpha, last_ids, v_render_colors, v_render_alpha)
+            *ctx.fwd_args, render_alpha, last_ids, v_render_colors, v_render_alpha, prepared_workspace=ctx.raster_ws)
+        ctx.raster_ws = None
         v_bg = None
         if ctx.bg_needs_grad:
             v_bg = (v_render_colors * (1.0 - render_alpha)).float().sum(dim=(-3, -2))

@@ -17,7 +17,7 @@ from .scenes import Scene
 
 class GutTrainer:
     def __init__(self, scene: Scene, device, iterations: int = 7000, world: int = 1, rank: int = 0,
-                 views_per_rank: int = 1, fused_adam: bool = True):
+                 views_per_rank: int = 1, fused_adam: bool = True, fused_l2: bool = True):
         self.device, self.world, self.rank, self.views_per_rank = device, world, rank, views_per_rank
         sc = scene.to(device)
         self.scene = sc
@@ -26,10 +26,22 @@ class GutTrainer:
         self.optimizer = FusedAdam(default_param_groups(self.model), fused=fused_adam)
         self.scheduler = ExponentialLR(self.optimizer, gamma=0.01 ** (1.0 / iterations), param_group_index=0)
         self.bg = torch.zeros(3, device=device)
-        self.bucket = lfs_dist.GradBucket(self.model.parameters()) if world > 1 else None
+        # fused_l2: explicit forward/backward through the fused kernels (fused.py) instead of torch autograd over
+        # the op-by-op mirror (rasterizer.py); gradients land directly in the flat bucket the all-reduce works on.
+        self.fused_l2 = fused_l2
+        self.bucket = lfs_dist.GradBucket(self.model.parameters()) if (world > 1 or fused_l2) else None
+        self.loss_acc = torch.zeros(1, device=device)
         self.iteration = 0
         self.last_n_isects = 0
-        self.last_visible = 0
+        self._last_radii = None
+        self._last_visible = None
+
+    @property
+    def last_visible(self):
+        """bool [N]: Gaussians with radii > 0 in the last rendered view"""
+        if self._last_radii is not None:
+            return (self._last_radii[0] > 0).all(-1)
+        return self._last_visible
 
     def camera(self, view: int) -> Camera:
         sc = self.scene
@@ -42,12 +54,26 @@ class GutTrainer:
             views = lfs_dist.views_for_step(self.iteration - 1, self.rank, self.world, self.scene.viewmats.shape[0], self.views_per_rank)
         total_views = self.world * len(views)
         loss_value = None
+        if self.fused_l2:
+            from .fused import render_and_backward
+            params = self.model.parameters()
+            self.loss_acc.zero_()
+            for k, v in enumerate(views):
+                out = render_and_backward(self.camera(v), self.model, self.bg, targets[k % len(targets)], 1.0 / total_views,
+                                          self.bucket.views, self.loss_acc, accumulate=k > 0)
+                self.last_n_isects, self._last_radii = out.n_isects, out.radii
+            self.bucket.all_reduce()
+            for p, gv in zip(params, self.bucket.views):
+                p.grad = gv
+            self.optimizer.step(self.iteration)
+            self.scheduler.step()
+            return self.loss_acc  # this rank's share of the loss (a 1-element tensor, read it after a sync)
         for k, v in enumerate(views):
             out = rasterize(self.camera(v), self.model, self.bg, 1.0, False, False, RenderMode.RGB)
             loss = torch.nn.functional.mse_loss(out.image, targets[k % len(targets)]) / total_views
             loss.backward()
             loss_value = loss.detach()
-            self.last_n_isects, self.last_visible = out.n_isects, out.visibility
+            self.last_n_isects, self._last_visible = out.n_isects, out.visibility
         if self.bucket is not None:
             params = self.model.parameters()
             self.bucket.gather([p.grad for p in params])

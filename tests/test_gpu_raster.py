@@ -263,3 +263,25 @@ def test_cell_culling_full_size_bit_identical(lfs):
     with torch.no_grad():
         a, b = _cull_on_off(lfs, lambda: rasterize(cam, model, torch.zeros(3, device=dev)))
     assert torch.equal(a.image, b.image) and torch.equal(a.alpha, b.alpha)
+
+
+def test_prepared_backward_equals_self_contained_backward(lfs, oracle_mod):
+    """lfs_rasterize_..._bwd_prepared (reuses the forward's records and per-cell lists) vs the self-contained entry."""
+    from lichtfeld_studio_amd import ops
+    rng = np.random.default_rng(77)
+    N, W, H, ts = 5000, 176, 144, 16
+    means, quats, scales, opac = make_gaussians(rng, N)
+    vm0 = small_rotation_viewmat(rng, 0.1, 0.1)[None]
+    K = pinhole_K(0.8 * W, W, H, 1)
+    colors = rng.random((1, N, 3)).astype(np.float32)
+    offs, flat = _lists(oracle_mod, means, quats, scales, opac, vm0, None, K, W, H, ts, lfs.CameraModelType.PINHOLE, lfs.ShutterType.GLOBAL, None, None, None)
+    args = (t(means), t(quats), t(scales), t(colors), t(opac[None]), t(rng.random((1, 3)).astype(np.float32)), None, W, H, ts, t(vm0), None, t(K),
+            lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, t(offs, torch.int32), t(flat, torch.int32))
+    rc, ra, li, ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args, own_workspace=True)
+    rc2, ra2, li2 = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
+    assert torch.equal(rc, rc2) and torch.equal(ra, ra2) and torch.equal(li, li2)
+    v_rc, v_ra = torch.randn_like(rc), torch.randn_like(ra)
+    ga = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra, prepared_workspace=ws)
+    gb = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra)
+    for a, b in zip(ga, gb):
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 1e-5
