@@ -276,7 +276,10 @@ LFS_DI float fma3(float ax, float bx, float ay, float by, float az, float bz) {
 LFS_DI f3 cross_fma(const f3& a, const f3& b) {
     return {__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)), __builtin_fmaf(a.x, b.y, -(b.x * a.y))};
 }
-struct RayEval { f3 om, gro, grd, grd_n, gc; float l, il, vis; };
+// Distance of the Gaussian centre to the ray line in the Gaussian's normalised frame, written through the foot
+// vector w = gro - (gro . n) n (n = normalised M d) instead of the reference's |n x gro|: |w| = |n x gro|, same
+// operation count, and the backward collapses to dL/dgro = -s w, dL/d(M d) = il (gro . n) s w (s = vis * dL/dvis).
+struct RayEval { f3 om, gro, grd_n, w; float il, g, vis; };
 template <bool UNIFORM_ORIGIN>
 LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& rd, RayEval& e) {
     e.om = {0.f, 0.f, 0.f};
@@ -287,15 +290,16 @@ LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& rd, RayEval& e
                  fma3(rec.r1.x, e.om.x, rec.r1.y, e.om.y, rec.r1.z, e.om.z),
                  fma3(rec.r2.x, e.om.x, rec.r2.y, e.om.y, rec.r2.z, e.om.z)};
     }
-    e.grd = {fma3(rec.r0.x, rd.x, rec.r0.y, rd.y, rec.r0.z, rd.z),
-             fma3(rec.r1.x, rd.x, rec.r1.y, rd.y, rec.r1.z, rd.z),
-             fma3(rec.r2.x, rd.x, rec.r2.y, rd.y, rec.r2.z, rd.z)};
-    e.l = fma3(e.grd.x, e.grd.x, e.grd.y, e.grd.y, e.grd.z, e.grd.z);
-    e.il = e.l > 0.f ? fast_rsq(e.l) : 1.f;
-    e.grd_n = e.grd * e.il;
-    e.gc = cross_fma(e.grd_n, e.gro);
-    const float power = -0.5f * fma3(e.gc.x, e.gc.x, e.gc.y, e.gc.y, e.gc.z, e.gc.z);
-    e.vis = __expf(power); // power <= 0 by construction (NaN propagates)
+    const f3 grd{fma3(rec.r0.x, rd.x, rec.r0.y, rd.y, rec.r0.z, rd.z),
+                 fma3(rec.r1.x, rd.x, rec.r1.y, rd.y, rec.r1.z, rd.z),
+                 fma3(rec.r2.x, rd.x, rec.r2.y, rd.y, rec.r2.z, rd.z)};
+    const float l = fma3(grd.x, grd.x, grd.y, grd.y, grd.z, grd.z);
+    e.il = l > 0.f ? fast_rsq(l) : 1.f;
+    e.grd_n = grd * e.il;
+    e.g = fma3(e.gro.x, e.grd_n.x, e.gro.y, e.grd_n.y, e.gro.z, e.grd_n.z);
+    e.w = {__builtin_fmaf(-e.g, e.grd_n.x, e.gro.x), __builtin_fmaf(-e.g, e.grd_n.y, e.gro.y), __builtin_fmaf(-e.g, e.grd_n.z, e.gro.z)};
+    // exp(-0.5 |w|^2) as one exp2: -0.5 * log2(e) = -0.72134752
+    e.vis = __builtin_amdgcn_exp2f(-0.72134752044448170f * fma3(e.w.x, e.w.x, e.w.y, e.w.y, e.w.z, e.w.z));
 }
 
 // Walk a cell list with the records arriving through the SCALAR unit: two groups of two record
@@ -488,9 +492,9 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 
     float T_final = 1.f, v_ra = 0.f;
     int32_t bin_final = -1; // Bwd.cu:183 uses 0 for inactive pixels; -1 keeps them out of entry 0 as well
-    float vc[CDIM], buffer[CDIM];
+    float vc[CDIM], Bsum = 0.f;
 #pragma unroll
-    for (int k = 0; k < CDIM; ++k) { vc[k] = 0.f; buffer[k] = 0.f; }
+    for (int k = 0; k < CDIM; ++k) vc[k] = 0.f;
     if (active) {
         T_final = 1.f - render_alphas[pix_id];
         bin_final = last_ids[pix_id];
@@ -526,66 +530,56 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     auto eval = [&](const GaussRec& rec, const int2 e) {
         RayEval re;
         ray_eval<UNIFORM_ORIGIN>(rec, ro, rd, re);
-        const f3 &om = re.om, &gro = re.gro, &grd = re.grd, &grd_n = re.grd_n, &gc = re.gc;
-        const float l = re.l, il = re.il, vis = re.vis;
-        const float opac = rec.r3.x;
-        const float alpha = fminf(0.999f, opac * vis);
-        const bool valid = active && e.y <= bin_final && !(alpha < (1.f / 255.f)); // (power > 0 cannot happen: -0.5 * sum of squares)
+        const float vis = re.vis, opac = rec.r3.x;
+        const float araw = opac * vis;
+        const float alpha = fminf(0.999f, araw);
+        const bool valid = active && e.y <= bin_final && !(alpha < (1.f / 255.f)); // (vis > 1 cannot happen: exp2 of -c |w|^2)
         if (__ballot(valid) == 0ull) return;
 
-        float col[CDIM];
+        // Invalid lanes are masked by zeroing three scalars (fac, v_op, and through it s): every reduced value below is
+        // a product with one of them. (All factors are finite for an inactive lane: its ray is 0, so w = gro.)
+        const float ra = fast_rcp(1.f - alpha);
+        const float Tn = T * ra;
+        T = valid ? Tn : T;
+        const float fac = valid ? alpha * Tn : 0.f;
+        float v[16], v_extra = 0.f, cv;
         if (CDIM <= 3) {
-            col[0] = rec.r3.y;
-            if (CDIM > 1) col[1] = rec.r3.z;
-            if (CDIM > 2) col[2] = rec.r3.w;
+            cv = rec.r3.y * vc[0];
+            if (CDIM > 1) cv = __builtin_fmaf(rec.r3.z, vc[1], cv);
+            if (CDIM > 2) cv = __builtin_fmaf(rec.r3.w, vc[2], cv);
         } else {
             const float* cp = colors + size_t(e.x) * CDIM;
+            cv = cp[0] * vc[0];
 #pragma unroll
-            for (int k = 0; k < CDIM; ++k) col[k] = cp[k];
+            for (int k = 1; k < CDIM; ++k) cv = __builtin_fmaf(cp[k], vc[k], cv);
         }
-
-        float v[16];
+        // dL/dalpha = (tail - B) / (1 - alpha) + T (c . v_c), B = sum over the entries behind of fac_j (c_j . v_c)
+        const float v_alpha = __builtin_fmaf(ra, tail - Bsum, Tn * cv);
+        Bsum = __builtin_fmaf(fac, cv, Bsum);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = 0.f;
-        float v_extra = 0.f; // 4th colour channel
-        if (valid) {
-            const float ra = fast_rcp(1.f - alpha);
-            T *= ra;
-            const float fac = alpha * T;
-            float v_alpha = tail * ra;
-#pragma unroll
-            for (int k = 0; k < CDIM; ++k) {
-                const float vrgb = fac * vc[k];
-                if (k < 3) v[13 + k] = vrgb; else v_extra = vrgb;
-                v_alpha += (col[k] * T - buffer[k] * ra) * vc[k];
-            }
-            if (opac * vis <= 0.999f) {
-                const float v_vis = opac * v_alpha;
-                const float v_gd = -0.5f * vis * v_vis;
-                const f3 v_gc = (2.f * v_gd) * gc;
-                const f3 v_grd_n = -cross(v_gc, gro);
-                const f3 v_gro = cross(v_gc, grd_n);
-                // safe_normalize_bw(grd, v_grd_n)
-                f3 v_grd = v_grd_n;
-                if (l > 0.f) {
-                    const float il3 = il * il * il;
-                    v_grd = il * v_grd_n - (il3 * dot(v_grd_n, grd)) * grd;
-                }
-                // dL/dM = v_grd (x) d  [+ v_gro (x) (o - mu) added per pixel only when the origin varies]
-                v[0] = v_grd.x * rd.x; v[1] = v_grd.x * rd.y; v[2] = v_grd.x * rd.z;
-                v[3] = v_grd.y * rd.x; v[4] = v_grd.y * rd.y; v[5] = v_grd.y * rd.z;
-                v[6] = v_grd.z * rd.x; v[7] = v_grd.z * rd.y; v[8] = v_grd.z * rd.z;
-                if (!UNIFORM_ORIGIN) {
-                    v[0] += v_gro.x * om.x; v[1] += v_gro.x * om.y; v[2] += v_gro.x * om.z;
-                    v[3] += v_gro.y * om.x; v[4] += v_gro.y * om.y; v[5] += v_gro.y * om.z;
-                    v[6] += v_gro.z * om.x; v[7] += v_gro.z * om.y; v[8] += v_gro.z * om.z;
-                }
-                v[9] = v_gro.x; v[10] = v_gro.y; v[11] = v_gro.z;
-                v[12] = vis * v_alpha;
-            }
-#pragma unroll
-            for (int k = 0; k < CDIM; ++k) buffer[k] += col[k] * fac;
+        for (int k = 0; k < CDIM; ++k) {
+            const float vrgb = fac * vc[k];
+            if (k < 3) v[13 + k] = vrgb; else v_extra = vrgb;
         }
+#pragma unroll
+        for (int k = CDIM; k < 3; ++k) v[13 + k] = 0.f;
+        // through alpha = min(0.999, opac * vis): no gradient on the clamped side
+        const float v_op = (valid && araw <= 0.999f) ? vis * v_alpha : 0.f; // dL/dopacity
+        v[12] = v_op;
+        const float sgeo = opac * v_op;                                     // s = vis * dL/dvis
+        const f3 a = re.w * sgeo;                                           // = -dL/dgro (the sign is undone in raster_finish_kernel)
+        const f3 vg = a * (re.il * re.g);                                   // dL/d(M d)
+        // dL/dM = vg (x) d  [+ dL/dgro (x) (o - mu) per pixel only when the origin varies]
+        v[0] = vg.x * rd.x; v[1] = vg.x * rd.y; v[2] = vg.x * rd.z;
+        v[3] = vg.y * rd.x; v[4] = vg.y * rd.y; v[5] = vg.y * rd.z;
+        v[6] = vg.z * rd.x; v[7] = vg.z * rd.y; v[8] = vg.z * rd.z;
+        if (!UNIFORM_ORIGIN) {
+            const f3& om = re.om;
+            v[0] -= a.x * om.x; v[1] -= a.x * om.y; v[2] -= a.x * om.z;
+            v[3] -= a.y * om.x; v[4] -= a.y * om.y; v[5] -= a.y * om.z;
+            v[6] -= a.z * om.x; v[7] -= a.z * om.y; v[8] -= a.z * om.z;
+        }
+        v[9] = a.x; v[10] = a.y; v[11] = a.z;
         wave_sum16_atomic(v, acc + size_t(e.x) * ACC_STRIDE, lane);
         if (CDIM > 3) {
 #pragma unroll
@@ -622,7 +616,7 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
         if (channels > 2) vcol[2] = a3.w;
         // (channel 3, when present, was accumulated straight into v_colors by the bwd kernel)
         const float A[9] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x};
-        const f3 G{a2.y, a2.z, a2.w};
+        const f3 G{-a2.y, -a2.z, -a2.w}; // the bwd kernel accumulates -dL/dgro
         bool any = G.x != 0.f || G.y != 0.f || G.z != 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) any |= A[k] != 0.f;
