@@ -5,11 +5,10 @@
 //
 // HBM-bound: 12*K B of coefficients per Gaussian dominate. The reference maps one
 // thread to one (Gaussian, channel) so coefficient loads are 12-B strided across
-// lanes; here LPG lanes share one Gaussian and lane k owns basis k, so a wave's
-// coefficient load is one fully coalesced 64 x 12 B block, the K-sum is a DPP
-// butterfly, and v_coeffs is stored with the same coalesced shape. Every lane
-// evaluates the whole (cheap) basis polynomial and picks its own entry with a
-// select tree — VALU is ~1/3 of the memory time.
+// lanes; here lane k of a group of LPG lanes owns basis k of a Gaussian, so a wave's
+// coefficient access is one fully coalesced 64 x 12 B block (a 4-lanes x 48-B layout was
+// measured 2.5x slower: partial-line stores), and the basis polynomial is evaluated once
+// per Gaussian in a lane-per-Gaussian phase and handed over through LDS (see the kernels).
 #include "lfs_math.cuh"
 #include "lfs_prof.h"
 #include "../../include/lfs_gsplat.h"
@@ -91,22 +90,6 @@ LFS_DI void sh_basis(const int degree, const float x, const float y, const float
     }
 }
 
-// pick a[k] for a per-lane k without dynamic register indexing (select tree)
-template <int LPG>
-LFS_DI float pick(const float* a, const int k) {
-    if (LPG == 1) return a[0];
-    float t[32];
-#pragma unroll
-    for (int i = 0; i < LPG; ++i) t[i] = (i < 25) ? a[i] : 0.f;
-#pragma unroll
-    for (int w = LPG / 2, bit = 0; w >= 1; w >>= 1, ++bit) {
-        const bool hi = (k >> bit) & 1;
-#pragma unroll
-        for (int i = 0; i < w; ++i) t[i] = hi ? t[2 * i + 1] : t[2 * i];
-    }
-    return t[0];
-}
-
 template <int LPG>
 LFS_DI float group_sum(float v) {
 #pragma unroll
@@ -114,166 +97,199 @@ LFS_DI float group_sum(float v) {
     return v;
 }
 
-template <int LPG>
-__global__ void __launch_bounds__(256) sh_fwd_kernel(
-    const uint32_t n, const uint32_t K, const int degree,
-    const float* __restrict__ dirs, const float* __restrict__ coeffs, const uint8_t* __restrict__ masks,
-    float* __restrict__ colors) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t g = tid / LPG;
-    const int k = tid % LPG;
-    if (g >= n) return;
-    const int Kd = (degree + 1) * (degree + 1);
-    const bool on = masks == nullptr || masks[g] != 0;
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    if (on) { // uniform per LPG group
-        float x = dirs[3 * g], y = dirs[3 * g + 1], z = dirs[3 * g + 2];
-        if (degree >= 1) { const float inorm = 1.f / sqrtf(x * x + y * y + z * z); x *= inorm; y *= inorm; z *= inorm; }
-        float b[25];
-        sh_basis<false>(degree, x, y, z, b, nullptr, nullptr, nullptr);
-        const float bk = pick<LPG>(b, k);
-        if (k < Kd) {
-            const float* cf = coeffs + (size_t(g) * K + k) * 3;
-            r0 = bk * cf[0]; r1 = bk * cf[1]; r2 = bk * cf[2];
-        }
-    }
-    r0 = group_sum<LPG>(r0); r1 = group_sum<LPG>(r1); r2 = group_sum<LPG>(r2);
-    if (k == 0) { colors[3 * g] = r0; colors[3 * g + 1] = r1; colors[3 * g + 2] = r2; }
-}
-
-template <int LPG>
-__global__ void __launch_bounds__(256) sh_bwd_kernel(
-    const uint32_t n, const uint32_t K, const int degree,
-    const float* __restrict__ dirs, const float* __restrict__ coeffs, const uint8_t* __restrict__ masks,
-    const float* __restrict__ v_colors, float* __restrict__ v_coeffs, float* __restrict__ v_dirs) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t g = tid / LPG;
-    const int k = tid % LPG;
-    if (g >= n) return;
-    const int Kd = (degree + 1) * (degree + 1);
-    const bool on = masks == nullptr || masks[g] != 0;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f;   // v_coeffs[g][k][:]
-    float gx = 0.f, gy = 0.f, gz = 0.f;   // lane-k share of dL/d(unit dir)
-    float x = 0.f, y = 0.f, z = 0.f, inorm = 1.f;
-    if (on) {
-        x = dirs[3 * g]; y = dirs[3 * g + 1]; z = dirs[3 * g + 2];
-        if (degree >= 1) { inorm = 1.f / sqrtf(x * x + y * y + z * z); x *= inorm; y *= inorm; z *= inorm; }
-        const float v0 = v_colors[3 * g], v1 = v_colors[3 * g + 1], v2 = v_colors[3 * g + 2];
-        float b[25], bx[25], by[25], bz[25];
-        if (v_dirs != nullptr) sh_basis<true>(degree, x, y, z, b, bx, by, bz);
-        else sh_basis<false>(degree, x, y, z, b, nullptr, nullptr, nullptr);
-        const float bk = pick<LPG>(b, k);
-        if (k < Kd) {
-            o0 = bk * v0; o1 = bk * v1; o2 = bk * v2;
-            if (v_dirs != nullptr && degree >= 1) {
-                const float* cf = coeffs + (size_t(g) * K + k) * 3;
-                const float s = cf[0] * v0 + cf[1] * v1 + cf[2] * v2;
-                gx = pick<LPG>(bx, k) * s; gy = pick<LPG>(by, k) * s; gz = pick<LPG>(bz, k) * s;
-            }
-        }
-    }
-    if (uint32_t(k) < K) {
-        float* vc = v_coeffs + (size_t(g) * K + k) * 3;
-        vc[0] = o0; vc[1] = o1; vc[2] = o2;
-    }
-    if (v_dirs != nullptr) {
-        gx = group_sum<LPG>(gx); gy = group_sum<LPG>(gy); gz = group_sum<LPG>(gz);
-        if (k == 0) {
-            // tangent-plane projection + chain through the normalisation
-            const float d = gx * x + gy * y + gz * z;
-            v_dirs[3 * g] = (gx - d * x) * inorm; v_dirs[3 * g + 1] = (gy - d * y) * inorm; v_dirs[3 * g + 2] = (gz - d * z) * inorm;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Fused L2 variants (extensions, not in Ops.h): what rasterizer.cpp:256-263 builds around the op with
-// libtorch - dirs = means - campos, masks = all(radii > 0), coeffs = cat(sh0, shN),
-// colors = clamp_min(sh + 0.5, 0) - folded into the kernel, so none of those tensors is materialised
-// (the cat alone is a 192 MB copy per step at 1M Gaussians, and again in the backward).
-// ---------------------------------------------------------------------------
 LFS_DI f3 campos_of(const float* __restrict__ vm) { // -R^T t of a rigid row-major [4,4] world->camera matrix
     return {-(vm[0] * vm[3] + vm[4] * vm[7] + vm[8] * vm[11]),
             -(vm[1] * vm[3] + vm[5] * vm[7] + vm[9] * vm[11]),
             -(vm[2] * vm[3] + vm[6] * vm[7] + vm[10] * vm[11])};
 }
 
-template <int LPG>
-__global__ void __launch_bounds__(256) sh_model_fwd_kernel(
-    const uint32_t n, const uint32_t K, const int degree,
-    const float* __restrict__ means, const float* __restrict__ viewmat, const float* __restrict__ sh0, const float* __restrict__ shN,
-    const int32_t* __restrict__ radii, float* __restrict__ colors) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t g = tid / LPG;
-    const int k = tid % LPG;
-    if (g >= n) return;
-    const int Kd = (degree + 1) * (degree + 1);
-    const bool on = radii[2 * g] > 0 && radii[2 * g + 1] > 0;
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    if (on) {
-        const f3 cp = campos_of(viewmat);
-        float x = means[3 * g] - cp.x, y = means[3 * g + 1] - cp.y, z = means[3 * g + 2] - cp.z;
-        if (degree >= 1) { const float inorm = 1.f / sqrtf(x * x + y * y + z * z); x *= inorm; y *= inorm; z *= inorm; }
-        float b[25];
-        sh_basis<false>(degree, x, y, z, b, nullptr, nullptr, nullptr);
-        const float bk = pick<LPG>(b, k);
-        if (k < Kd) {
-            const float* cf = (k == 0) ? sh0 + size_t(g) * 3 : shN + (size_t(g) * (K - 1) + (k - 1)) * 3;
-            r0 = bk * cf[0]; r1 = bk * cf[1]; r2 = bk * cf[2];
-        }
-    }
-    r0 = group_sum<LPG>(r0); r1 = group_sum<LPG>(r1); r2 = group_sum<LPG>(r2);
-    if (k == 0) { colors[3 * g] = fmaxf(r0 + 0.5f, 0.f); colors[3 * g + 1] = fmaxf(r1 + 0.5f, 0.f); colors[3 * g + 2] = fmaxf(r2 + 0.5f, 0.f); }
+// Where the operands of one call live. MODEL = false: the op of Ops.h (dirs, coeffs [n,K,3], bool masks).
+// MODEL = true (fused L2 extension, not in Ops.h): what rasterizer.cpp:256-263 builds around the op with libtorch -
+// dirs = means - campos, masks = all(radii > 0), coeffs = cat(sh0, shN), colors = clamp_min(sh + 0.5, 0) - folded
+// in, so none of those tensors is materialised (the cat alone is a 192 MB copy per step at 1M Gaussians, and
+// again in the backward).
+struct ShArgs {
+    uint32_t n, K; int degree;
+    const float* dirs; const float* coeffs; const uint8_t* masks;                      // op
+    const float* means; const float* viewmat; const float* sh0; const float* shN; const int32_t* radii; // model
+    const float* colors;                                                                // model bwd: clamped forward output
+};
+template <bool MODEL> LFS_DI bool sh_on(const ShArgs& a, uint32_t g) {
+    if (MODEL) return a.radii[2 * g] > 0 && a.radii[2 * g + 1] > 0;
+    return a.masks == nullptr || a.masks[g] != 0;
+}
+template <bool MODEL> LFS_DI f3 sh_dir(const ShArgs& a, uint32_t g) {
+    if (MODEL) { const f3 cp = campos_of(a.viewmat); return {a.means[3 * g] - cp.x, a.means[3 * g + 1] - cp.y, a.means[3 * g + 2] - cp.z}; }
+    return {a.dirs[3 * g], a.dirs[3 * g + 1], a.dirs[3 * g + 2]};
+}
+template <bool MODEL, class T> LFS_DI T* sh_coef(T* coeffs, T* sh0, T* shN, uint32_t K, uint32_t g, int k) {
+    if (MODEL) return k == 0 ? sh0 + size_t(g) * 3 : shN + (size_t(g) * (K - 1) + (k - 1)) * 3;
+    return coeffs + (size_t(g) * K + k) * 3;
 }
 
-// v_colors = dL/d(clamped colors); the clamp passes where the stored colour is > 0. v_sh0 / v_shN are written
-// (ACCUM = false) or added to (ACCUM = true: second and later views of a step); v_means += dL/d(dirs).
-template <int LPG, bool ACCUM>
-__global__ void __launch_bounds__(256) sh_model_bwd_kernel(
-    const uint32_t n, const uint32_t K, const int degree,
-    const float* __restrict__ means, const float* __restrict__ viewmat, const float* __restrict__ sh0, const float* __restrict__ shN,
-    const int32_t* __restrict__ radii, const float* __restrict__ colors, const float* __restrict__ v_colors,
-    float* __restrict__ v_sh0, float* __restrict__ v_shN, float* __restrict__ v_means) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t g = tid / LPG;
-    const int k = tid % LPG;
-    if (g >= n) return;
+// One wavefront per workgroup handles 64 Gaussians in three phases (no cross-wave sync needed):
+//   1. lane = Gaussian : evaluate the basis polynomial ONCE per Gaussian, park b[0..LPG) in LDS (row stride LPG+1:
+//                        conflict-free for both access directions);
+//   2. lane = (Gaussian, basis) for 64/LPG Gaussians per iteration: coefficient rows are read / written as fully
+//                        coalesced 64 x 12 B blocks; fwd: 16-lane butterfly sum; bwd: v_coeffs = b_k v, and
+//                        s_k = coeff_k . v overwrites b_k in LDS;
+//   3. (bwd) lane = Gaussian : dL/d(dir) = sum_k s_k grad b_k, evaluated once per Gaussian.
+// The previous layout evaluated the polynomial in every one of the LPG lanes of a Gaussian and was VALU-bound
+// (rocprof: 8.1e7 VALU instructions = 0.13 ms of the 0.20 ms backward at 1M Gaussians, K = 16).
+template <int LPG, bool MODEL>
+__global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors) {
+    __shared__ float lds[64 * (LPG + 1)];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g0 = blockIdx.x * 64u;
+    const int degree = a.degree;
     const int Kd = (degree + 1) * (degree + 1);
-    const bool on = radii[2 * g] > 0 && radii[2 * g + 1] > 0;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-    float x = 0.f, y = 0.f, z = 0.f, inorm = 1.f;
-    if (on) {
-        const f3 cp = campos_of(viewmat);
-        x = means[3 * g] - cp.x; y = means[3 * g + 1] - cp.y; z = means[3 * g + 2] - cp.z;
-        if (degree >= 1) { inorm = 1.f / sqrtf(x * x + y * y + z * z); x *= inorm; y *= inorm; z *= inorm; }
-        const float v0 = colors[3 * g] > 0.f ? v_colors[3 * g] : 0.f;
-        const float v1 = colors[3 * g + 1] > 0.f ? v_colors[3 * g + 1] : 0.f;
-        const float v2 = colors[3 * g + 2] > 0.f ? v_colors[3 * g + 2] : 0.f;
-        float b[25], bx[25], by[25], bz[25];
-        sh_basis<true>(degree, x, y, z, b, bx, by, bz);
-        const float bk = pick<LPG>(b, k);
-        if (k < Kd) {
-            o0 = bk * v0; o1 = bk * v1; o2 = bk * v2;
-            if (degree >= 1) {
-                const float* cf = (k == 0) ? sh0 + size_t(g) * 3 : shN + (size_t(g) * (K - 1) + (k - 1)) * 3;
-                const float s = cf[0] * v0 + cf[1] * v1 + cf[2] * v2;
-                gx = pick<LPG>(bx, k) * s; gy = pick<LPG>(by, k) * s; gz = pick<LPG>(bz, k) * s;
+    {   // phase 1
+        const uint32_t g = g0 + lane;
+        float b[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) b[k] = 0.f;
+        if (g < a.n && sh_on<MODEL>(a, g)) {
+            f3 d = sh_dir<MODEL>(a, g);
+            if (degree >= 1) { const float inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
+            sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
+        } // masked-out rows: b = 0 -> colour 0
+#pragma unroll
+        for (int k = 0; k < LPG; ++k) lds[lane * (LPG + 1) + k] = (k < 25) ? b[k] : 0.f;
+    }
+    __syncthreads();
+    constexpr int GPI = 64 / LPG; // Gaussians per iteration
+    const int k = lane % LPG;
+    for (int it = 0; it < LPG; ++it) {
+        const uint32_t gl = it * GPI + lane / LPG;
+        const uint32_t g = g0 + gl;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        if (g < a.n && k < Kd) {
+            const float bk = lds[gl * (LPG + 1) + k];
+            if (bk != 0.f) { // (also skips the coefficient rows of masked-out Gaussians)
+                const float* cf = sh_coef<MODEL>(a.coeffs, a.sh0, a.shN, a.K, g, k);
+                r0 = bk * cf[0]; r1 = bk * cf[1]; r2 = bk * cf[2];
             }
         }
+        r0 = group_sum<LPG>(r0); r1 = group_sum<LPG>(r1); r2 = group_sum<LPG>(r2);
+        if (k == 0 && g < a.n) {
+            if (MODEL) { r0 = fmaxf(r0 + 0.5f, 0.f); r1 = fmaxf(r1 + 0.5f, 0.f); r2 = fmaxf(r2 + 0.5f, 0.f); }
+            colors[3 * g] = r0; colors[3 * g + 1] = r1; colors[3 * g + 2] = r2;
+        }
     }
-    if (uint32_t(k) < K) {
-        float* vc = (k == 0) ? v_sh0 + size_t(g) * 3 : v_shN + (size_t(g) * (K - 1) + (k - 1)) * 3;
-        if (ACCUM) { if (on) { vc[0] += o0; vc[1] += o1; vc[2] += o2; } }
+}
+
+// op   : v_coeffs [n,K,3] fully written, v_dirs [n,3] (or NULL) fully written.
+// model: v_colors = dL/d(clamped colors), the clamp passes where the stored colour is > 0; v_sh0 / v_shN written
+//        (ACCUM = false) or added to (ACCUM = true: second and later views of a step); v_means += dL/d(dirs).
+template <int LPG, bool MODEL, bool ACCUM>
+__global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float* __restrict__ v_colors,
+                                                    float* __restrict__ v_coeffs, float* __restrict__ v_sh0, float* __restrict__ v_shN,
+                                                    float* __restrict__ v_dirs) {
+    __shared__ float lds[64 * (LPG + 1)];
+    __shared__ float ldv[64 * 3];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g0 = blockIdx.x * 64u;
+    const int degree = a.degree;
+    const int Kd = (degree + 1) * (degree + 1);
+    const bool want_dirs = (v_dirs != nullptr) && degree >= 1;
+    // phase 1 (lane = Gaussian)
+    const uint32_t gmine = g0 + lane;
+    const bool on = gmine < a.n && sh_on<MODEL>(a, gmine);
+    f3 d{0.f, 0.f, 0.f};
+    float inorm = 1.f;
+    {
+        float b[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) b[k] = 0.f;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (on) {
+            d = sh_dir<MODEL>(a, gmine);
+            if (degree >= 1) { inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
+            sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
+            v0 = v_colors[3 * gmine]; v1 = v_colors[3 * gmine + 1]; v2 = v_colors[3 * gmine + 2];
+            if (MODEL) {
+                if (!(a.colors[3 * gmine] > 0.f)) v0 = 0.f;
+                if (!(a.colors[3 * gmine + 1] > 0.f)) v1 = 0.f;
+                if (!(a.colors[3 * gmine + 2] > 0.f)) v2 = 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LPG; ++k) lds[lane * (LPG + 1) + k] = (k < 25) ? b[k] : 0.f;
+        ldv[lane * 3] = v0; ldv[lane * 3 + 1] = v1; ldv[lane * 3 + 2] = v2;
+    }
+    __syncthreads();
+    // phase 2 (lane = (Gaussian, basis))
+    constexpr int GPI = 64 / LPG;
+    const int k = lane % LPG;
+    for (int it = 0; it < LPG; ++it) {
+        const uint32_t gl = it * GPI + lane / LPG;
+        const uint32_t g = g0 + gl;
+        if (g >= a.n || uint32_t(k) >= a.K) continue;
+        const float bk = lds[gl * (LPG + 1) + k]; // 0 for masked-out Gaussians and for k >= Kd
+        const float v0 = ldv[gl * 3], v1 = ldv[gl * 3 + 1], v2 = ldv[gl * 3 + 2];
+        float* vc = sh_coef<MODEL>(v_coeffs, v_sh0, v_shN, a.K, g, k);
+        const float o0 = bk * v0, o1 = bk * v1, o2 = bk * v2;
+        if (ACCUM) { if (bk != 0.f) { vc[0] += o0; vc[1] += o1; vc[2] += o2; } }
         else { vc[0] = o0; vc[1] = o1; vc[2] = o2; }
+        if (want_dirs) {
+            float sk = 0.f;
+            if (k < Kd && (v0 != 0.f || v1 != 0.f || v2 != 0.f)) {
+                const float* cf = sh_coef<MODEL>(a.coeffs, a.sh0, a.shN, a.K, g, k);
+                sk = cf[0] * v0 + cf[1] * v1 + cf[2] * v2;
+            }
+            lds[gl * (LPG + 1) + k] = sk;
+        }
     }
-    gx = group_sum<LPG>(gx); gy = group_sum<LPG>(gy); gz = group_sum<LPG>(gz);
-    if (k == 0 && on && degree >= 1) {
-        const float d = gx * x + gy * y + gz * z;
-        v_means[3 * g] += (gx - d * x) * inorm; v_means[3 * g + 1] += (gy - d * y) * inorm; v_means[3 * g + 2] += (gz - d * z) * inorm;
+    if (v_dirs == nullptr) return;
+    __syncthreads();
+    // phase 3 (lane = Gaussian)
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    if (on && want_dirs) {
+        float b[25], bx[25], by[25], bz[25];
+        sh_basis<true>(degree, d.x, d.y, d.z, b, bx, by, bz);
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int kk = 1; kk < LPG && kk < 25; ++kk) {
+            const float sk = lds[lane * (LPG + 1) + kk];
+            gx += bx[kk] * sk; gy += by[kk] * sk; gz += bz[kk] * sk;
+        }
+        // tangent-plane projection + chain through the normalisation
+        const float dd = gx * d.x + gy * d.y + gz * d.z;
+        ox = (gx - dd * d.x) * inorm; oy = (gy - dd * d.y) * inorm; oz = (gz - dd * d.z) * inorm;
+    }
+    if (gmine < a.n) {
+        if (MODEL) { if (on && want_dirs) { v_dirs[3 * gmine] += ox; v_dirs[3 * gmine + 1] += oy; v_dirs[3 * gmine + 2] += oz; } }
+        else { v_dirs[3 * gmine] = ox; v_dirs[3 * gmine + 1] = oy; v_dirs[3 * gmine + 2] = oz; }
     }
 }
 
 static inline int lanes_for(uint32_t k) { return k <= 1 ? 1 : k <= 4 ? 4 : k <= 16 ? 16 : 32; }
+
+template <bool MODEL>
+static int sh_launch_fwd(const ShArgs& a, uint32_t Kcover, float* colors, hipStream_t s) {
+    const dim3 grid((a.n + 63) / 64), block(64);
+    lfs::ProfScope prof("sh_fwd", s);
+    switch (lanes_for(Kcover)) {
+    case 1: hipLaunchKernelGGL((sh_fwd_kernel<1, MODEL>), grid, block, 0, s, a, colors); break;
+    case 4: hipLaunchKernelGGL((sh_fwd_kernel<4, MODEL>), grid, block, 0, s, a, colors); break;
+    case 16: hipLaunchKernelGGL((sh_fwd_kernel<16, MODEL>), grid, block, 0, s, a, colors); break;
+    default: hipLaunchKernelGGL((sh_fwd_kernel<32, MODEL>), grid, block, 0, s, a, colors); break;
+    }
+    return (int)hipGetLastError();
+}
+
+template <bool MODEL, bool ACCUM>
+static int sh_launch_bwd(const ShArgs& a, const float* v_colors, float* v_coeffs, float* v_sh0, float* v_shN, float* v_dirs, hipStream_t s) {
+    const dim3 grid((a.n + 63) / 64), block(64);
+    lfs::ProfScope prof("sh_bwd", s);
+    switch (lanes_for(a.K)) { // every one of the K rows of v_coeffs is written
+    case 1: hipLaunchKernelGGL((sh_bwd_kernel<1, MODEL, ACCUM>), grid, block, 0, s, a, v_colors, v_coeffs, v_sh0, v_shN, v_dirs); break;
+    case 4: hipLaunchKernelGGL((sh_bwd_kernel<4, MODEL, ACCUM>), grid, block, 0, s, a, v_colors, v_coeffs, v_sh0, v_shN, v_dirs); break;
+    case 16: hipLaunchKernelGGL((sh_bwd_kernel<16, MODEL, ACCUM>), grid, block, 0, s, a, v_colors, v_coeffs, v_sh0, v_shN, v_dirs); break;
+    default: hipLaunchKernelGGL((sh_bwd_kernel<32, MODEL, ACCUM>), grid, block, 0, s, a, v_colors, v_coeffs, v_sh0, v_shN, v_dirs); break;
+    }
+    return (int)hipGetLastError();
+}
 
 } // namespace lfs
 
@@ -284,19 +300,9 @@ extern "C" int lfs_spherical_harmonics_fwd(
     if (degrees_to_use > 4 || Kd > K) return LFS_E_INVALID;
     if (n == 0) return LFS_OK;
     if (!dirs || !coeffs || !colors) return LFS_E_INVALID;
-    const int lpg = lfs::lanes_for(Kd);
-    const uint64_t threads = uint64_t(n) * lpg;
-    dim3 grid((threads + 255) / 256), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    const int deg = int(degrees_to_use);
-    lfs::ProfScope prof("sh_fwd", s);
-    switch (lpg) {
-    case 1: hipLaunchKernelGGL(lfs::sh_fwd_kernel<1>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, colors); break;
-    case 4: hipLaunchKernelGGL(lfs::sh_fwd_kernel<4>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, colors); break;
-    case 16: hipLaunchKernelGGL(lfs::sh_fwd_kernel<16>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, colors); break;
-    default: hipLaunchKernelGGL(lfs::sh_fwd_kernel<32>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, colors); break;
-    }
-    return (int)hipGetLastError();
+    lfs::ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.dirs = dirs; a.coeffs = coeffs; a.masks = masks;
+    return lfs::sh_launch_fwd<false>(a, Kd, colors, (hipStream_t)stream);
 }
 
 extern "C" int lfs_spherical_harmonics_bwd(
@@ -306,19 +312,9 @@ extern "C" int lfs_spherical_harmonics_bwd(
     if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
     if (n == 0) return LFS_OK;
     if (!dirs || !coeffs || !v_colors || !v_coeffs) return LFS_E_INVALID;
-    const int lpg = lfs::lanes_for(K); // every one of the K rows of v_coeffs is written
-    const uint64_t threads = uint64_t(n) * lpg;
-    dim3 grid((threads + 255) / 256), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    const int deg = int(degrees_to_use);
-    lfs::ProfScope prof("sh_bwd", s);
-    switch (lpg) {
-    case 1: hipLaunchKernelGGL(lfs::sh_bwd_kernel<1>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
-    case 4: hipLaunchKernelGGL(lfs::sh_bwd_kernel<4>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
-    case 16: hipLaunchKernelGGL(lfs::sh_bwd_kernel<16>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
-    default: hipLaunchKernelGGL(lfs::sh_bwd_kernel<32>, grid, block, 0, s, n, K, deg, dirs, coeffs, masks, v_colors, v_coeffs, v_dirs); break;
-    }
-    return (int)hipGetLastError();
+    lfs::ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.dirs = dirs; a.coeffs = coeffs; a.masks = masks;
+    return lfs::sh_launch_bwd<false, false>(a, v_colors, v_coeffs, nullptr, nullptr, v_dirs, (hipStream_t)stream);
 }
 
 extern "C" int lfs_sh_model_fwd(
@@ -328,18 +324,9 @@ extern "C" int lfs_sh_model_fwd(
     if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
     if (n == 0) return LFS_OK;
     if (!means || !viewmat || !sh0 || (K > 1 && !shN) || !radii || !colors) return LFS_E_INVALID;
-    const int lpg = lfs::lanes_for(Kd);
-    dim3 grid((uint64_t(n) * lpg + 255) / 256), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    const int deg = int(degrees_to_use);
-    lfs::ProfScope prof("sh_fwd", s);
-    switch (lpg) {
-    case 1: hipLaunchKernelGGL(lfs::sh_model_fwd_kernel<1>, grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, colors); break;
-    case 4: hipLaunchKernelGGL(lfs::sh_model_fwd_kernel<4>, grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, colors); break;
-    case 16: hipLaunchKernelGGL(lfs::sh_model_fwd_kernel<16>, grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, colors); break;
-    default: hipLaunchKernelGGL(lfs::sh_model_fwd_kernel<32>, grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, colors); break;
-    }
-    return (int)hipGetLastError();
+    lfs::ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii;
+    return lfs::sh_launch_fwd<true>(a, Kd, colors, (hipStream_t)stream);
 }
 
 extern "C" int lfs_sh_model_bwd(
@@ -350,22 +337,8 @@ extern "C" int lfs_sh_model_bwd(
     if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
     if (n == 0) return LFS_OK;
     if (!means || !viewmat || !sh0 || (K > 1 && (!shN || !v_shN)) || !radii || !colors || !v_colors || !v_sh0 || !v_means) return LFS_E_INVALID;
-    const int lpg = lfs::lanes_for(K);
-    dim3 grid((uint64_t(n) * lpg + 255) / 256), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    const int deg = int(degrees_to_use);
-    lfs::ProfScope prof("sh_bwd", s);
-#define LFS_SHB(L)                                                                                                                       \
-    if (accumulate) hipLaunchKernelGGL((lfs::sh_model_bwd_kernel<L, true>), grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, \
-                                       colors, v_colors, v_sh0, v_shN, v_means);                                                          \
-    else hipLaunchKernelGGL((lfs::sh_model_bwd_kernel<L, false>), grid, block, 0, s, n, K, deg, means, viewmat, sh0, shN, radii, colors,    \
-                            v_colors, v_sh0, v_shN, v_means)
-    switch (lpg) {
-    case 1: LFS_SHB(1); break;
-    case 4: LFS_SHB(4); break;
-    case 16: LFS_SHB(16); break;
-    default: LFS_SHB(32); break;
-    }
-#undef LFS_SHB
-    return (int)hipGetLastError();
+    lfs::ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
+    if (accumulate) return lfs::sh_launch_bwd<true, true>(a, v_colors, nullptr, v_sh0, v_shN, v_means, (hipStream_t)stream);
+    return lfs::sh_launch_bwd<true, false>(a, v_colors, nullptr, v_sh0, v_shN, v_means, (hipStream_t)stream);
 }
