@@ -235,6 +235,7 @@ LFS_API int lfs_adam_step_multi(const lfs_adam_tensor* tensors /* host array */,
  *      lfs_profile_collect waits for them, sums by kernel name (names: max_entries x 64 chars)
  *      and clears the log. Returns the number of distinct names written. */
 LFS_API int lfs_profile_enable(int on);
+LFS_API int lfs_profile_filter(const char* name); /* only time the scopes called `name` (NULL / "" = all) */
 LFS_API int lfs_profile_collect(int max_entries, char* names, float* total_ms, int* counts);
 
 /* Library identification: returns "lfs_gsplat gfx950 <abi-version>" */

@@ -79,7 +79,7 @@ EXPORTS = [
     "lfs_intersect_tile_workspace_bytes", "lfs_intersect_tile_count", "lfs_intersect_tile_emit", "lfs_intersect_offset",
     "lfs_rasterize_workspace_bytes", "lfs_set_debug_flags", "lfs_rasterize_to_pixels_from_world_3dgs_fwd", "lfs_rasterize_to_pixels_from_world_3dgs_bwd", "lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared",
     "lfs_sh_model_fwd", "lfs_sh_model_bwd", "lfs_activations_fwd", "lfs_activations_bwd", "lfs_mse_loss_fwd_bwd",
-    "lfs_quats_to_rotmats", "lfs_relocation", "lfs_add_noise", "lfs_adam_step", "lfs_adam_step_multi", "lfs_version", "lfs_profile_enable", "lfs_profile_collect",
+    "lfs_quats_to_rotmats", "lfs_relocation", "lfs_add_noise", "lfs_adam_step", "lfs_adam_step_multi", "lfs_version", "lfs_profile_enable", "lfs_profile_filter", "lfs_profile_collect",
 ]
 
 
@@ -176,6 +176,11 @@ def workspace(nbytes: int, device: torch.device, tag: str) -> torch.Tensor:
 
 def profile_enable(on: bool) -> None:
     load_library().lfs_profile_enable(C.c_int(int(on)))
+
+
+def profile_filter(name: str | None) -> None:
+    """Time only the scopes called `name` (None = all)."""
+    load_library().lfs_profile_filter(C.c_char_p(name.encode()) if name else None)
 
 
 def profile_collect(max_entries: int = 64) -> dict:

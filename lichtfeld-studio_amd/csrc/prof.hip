@@ -11,14 +11,23 @@ namespace {
 struct Pending { std::string name; hipEvent_t e0, e1; bool closed; };
 std::mutex g_mu;
 bool g_on = false;
+std::string g_filter; // empty: every scope; otherwise only scopes with exactly this name
 std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_pool; // recycled events: creating two per scope costs more than recording them
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
 } // namespace
 
 int prof_begin(const char* name, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_on) return -1;
-    Pending p{name, nullptr, nullptr, false};
-    if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return -1;
+    if (!g_filter.empty() && g_filter != name) return -1;
+    Pending p{name, get_event(), get_event(), false};
+    if (!p.e0 || !p.e1) return -1;
     (void)hipEventRecord(p.e0, s);
     g_pending.push_back(p);
     return int(g_pending.size()) - 1;
@@ -37,6 +46,14 @@ extern "C" int lfs_profile_enable(int on) {
     return LFS_OK;
 }
 
+// Restrict timing to the scopes called `name` (NULL or "" = all): keeps the event overhead out of a timed region
+// that only needs its dominant kernel.
+extern "C" int lfs_profile_filter(const char* name) {
+    std::lock_guard<std::mutex> lk(lfs::g_mu);
+    lfs::g_filter = name ? name : "";
+    return LFS_OK;
+}
+
 // Waits for all recorded events, aggregates by kernel name, clears the log.
 // names: max_entries x 64 chars; total_ms / counts: max_entries. Returns the number of names.
 extern "C" int lfs_profile_collect(int max_entries, char* names, float* total_ms, int* counts) {
@@ -52,7 +69,7 @@ extern "C" int lfs_profile_collect(int max_entries, char* names, float* total_ms
                 if (k < n) { total_ms[k] += ms; counts[k] += 1; }
             }
         }
-        (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
+        lfs::g_pool.push_back(p.e0); lfs::g_pool.push_back(p.e1);
     }
     lfs::g_pending.clear();
     return n;

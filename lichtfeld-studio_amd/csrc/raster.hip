@@ -194,9 +194,15 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
     const CamDev* __restrict__ cams, const CullRec* __restrict__ cull, const uint8_t* __restrict__ masks,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ ids, const int32_t n_isects,
     int32_t* __restrict__ cell_count, int2* __restrict__ cell_list) {
+    // The (up to 4) cells of a workgroup belong to the same tile and walk the same list: the workgroup gathers each
+    // batch of 64 * waves entries ONCE (one entry per thread: id + 32-B culling record, a dependent random gather that
+    // would otherwise be repeated by every cell and keep the texture-address unit busy) and hands it over through LDS;
+    // every wave then tests the whole batch against its own cell. Double-buffered: one barrier per batch.
+    __shared__ float4 s_a[2][256], s_b[2][256];
+    __shared__ int32_t s_g[2][256];
     const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
-    if (!cc.in_grid) return;
+    if (!cc.in_grid) return; // (uniform per workgroup)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wpt = (tile_size >> 3) * (tile_size >> 3);
     const size_t cell = size_t(cc.tile_global) * wpt + cc.wl;
@@ -204,16 +210,17 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
     const int32_t start = offsets[cc.tile_global];
     const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
     const bool tile_masked = masks != nullptr && !masks[cc.tile_global];
+    if (tile_masked || end <= start) { // uniform per workgroup
+        if (lane == 0) cell_count[cell] = 0;
+        return;
+    }
 
     // cell bounds in normalised camera coordinates (x/z, y/z) over the rays that can composite at all
     const CamDev& cam = cams[cc.cid];
     f3 ro, rd;
     const bool ray_ok = cam_pixel_ray(cam, f2{float(cc.j) + 0.5f, float(cc.i) + 0.5f}, ro, rd);
     const bool active = inside && ray_ok;
-    if (__ballot(active) == 0ull || tile_masked || end <= start) {
-        if (lane == 0) cell_count[cell] = 0;
-        return;
-    }
+    const bool cell_live = __ballot(active) != 0ull; // a dead cell still helps with the loads and the barriers
     bool can_cull = UNIFORM_ORIGIN && cull_enabled != 0;
     float tu_lo = 0.f, tu_hi = 0.f, tv_lo = 0.f, tv_hi = 0.f;
     if (UNIFORM_ORIGIN) {
@@ -231,6 +238,7 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
         can_cull = can_cull && (tu_hi - tu_lo < 1e30f) && (tv_hi - tv_lo < 1e30f);
     }
     tu_lo = uniform_f(tu_lo); tu_hi = uniform_f(tu_hi); tv_lo = uniform_f(tv_lo); tv_hi = uniform_f(tv_hi);
+    const bool need_recs = UNIFORM_ORIGIN && cull_enabled != 0; // workgroup-uniform (can_cull is per cell)
 
     int2* __restrict__ out = cell_list + (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
     int32_t count = 0;
@@ -242,26 +250,43 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
         const float Q = Scc + 2.f * fabsf(t * Scz) + tt * Szz;
         return s > 0.f && s * s > q + 4e-6f * Q;
     };
-    int32_t idx = start + int32_t(lane);
-    int32_t g = idx < end ? ids[idx] : 0;
-    for (int32_t base = start; base < end; base += 64) {
-        const int32_t my_idx = idx, my_g = g;
-        const bool valid = my_idx < end;
-        idx += 64;
-        g = idx < end ? ids[idx] : 0; // next batch's ids in flight during this batch's test
-        bool hit = valid;
-        if (can_cull) {
-            const CullRec cr = cull[my_g];
-            const bool culled = outside(cr.a.x, tu_hi, 1.f, cr.a.z, cr.b.x, cr.b.z) || outside(cr.a.x, tu_lo, -1.f, cr.a.z, cr.b.x, cr.b.z) ||
-                                outside(cr.a.y, tv_hi, 1.f, cr.a.w, cr.b.y, cr.b.z) || outside(cr.a.y, tv_lo, -1.f, cr.a.w, cr.b.y, cr.b.z);
-            hit = valid && !culled;
+    const int32_t E = int32_t(blockDim.x);          // entries per batch
+    const int32_t nsub = E >> 6;                    // = waves in the workgroup
+    auto fetch = [&](int32_t base, int32_t& g, CullRec& cr) {
+        const int32_t i = base + int32_t(threadIdx.x);
+        g = i < end ? ids[i] : 0;
+        if (need_recs) cr = cull[g];
+    };
+    int32_t g_reg; CullRec cr_reg;
+    cr_reg.a = make_float4(0.f, 0.f, 0.f, 0.f); cr_reg.b = cr_reg.a;
+    fetch(start, g_reg, cr_reg);
+    int buf = 0;
+    for (int32_t base = start; base < end; base += E, buf ^= 1) {
+        s_g[buf][threadIdx.x] = g_reg;
+        if (need_recs) { s_a[buf][threadIdx.x] = cr_reg.a; s_b[buf][threadIdx.x] = cr_reg.b; }
+        __syncthreads();
+        if (base + E < end) fetch(base + E, g_reg, cr_reg); // in flight during the tests below
+        if (!cell_live) continue;
+        for (int32_t sub = 0; sub < nsub; ++sub) {
+            const int32_t slot = (sub << 6) + int32_t(lane);
+            const int32_t my_idx = base + slot;
+            if (base + (sub << 6) >= end) break; // uniform
+            const bool valid = my_idx < end;
+            const int32_t my_g = s_g[buf][slot];
+            bool hit = valid;
+            if (can_cull) {
+                const float4 a = s_a[buf][slot], b = s_b[buf][slot];
+                const bool culled = outside(a.x, tu_hi, 1.f, a.z, b.x, b.z) || outside(a.x, tu_lo, -1.f, a.z, b.x, b.z) ||
+                                    outside(a.y, tv_hi, 1.f, a.w, b.y, b.z) || outside(a.y, tv_lo, -1.f, a.w, b.y, b.z);
+                hit = valid && !culled;
+            }
+            const uint64_t m = __ballot(hit);
+            if (hit) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+                out[count + int32_t(rank)] = make_int2(my_g, my_idx);
+            }
+            count += __popcll(m);
         }
-        const uint64_t m = __ballot(hit);
-        if (hit) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            out[count + int32_t(rank)] = make_int2(my_g, my_idx);
-        }
-        count += __popcll(m);
     }
     if (lane == 0) cell_count[cell] = count;
 }

@@ -29,7 +29,7 @@ class GutTrainer:
         # fused_l2: explicit forward/backward through the fused kernels (fused.py) instead of torch autograd over
         # the op-by-op mirror (rasterizer.py); gradients land directly in the flat bucket the all-reduce works on.
         self.fused_l2 = fused_l2
-        self.bucket = lfs_dist.GradBucket(self.model.parameters()) if (world > 1 or fused_l2) else None
+        self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2]) if (world > 1 or fused_l2) else None  # 2 = shN
         self.loss_acc = torch.zeros(1, device=device)
         self.iteration = 0
         self.last_n_isects = 0
@@ -62,7 +62,7 @@ class GutTrainer:
                 out = render_and_backward(self.camera(v), self.model, self.bg, targets[k % len(targets)], 1.0 / total_views,
                                           self.bucket.views, self.loss_acc, accumulate=k > 0)
                 self.last_n_isects, self._last_radii = out.n_isects, out.radii
-            self.bucket.all_reduce()
+            self.bucket.all_reduce(skip_deferred=self.iteration <= 1000)  # shN's gradient is not read by Adam until then
             for p, gv in zip(params, self.bucket.views):
                 p.grad = gv
             self.optimizer.step(self.iteration)
@@ -77,7 +77,7 @@ class GutTrainer:
         if self.bucket is not None:
             params = self.model.parameters()
             self.bucket.gather([p.grad for p in params])
-            self.bucket.all_reduce()
+            self.bucket.all_reduce(skip_deferred=self.iteration <= 1000)
             for p, gv in zip(params, self.bucket.views):
                 p.grad = gv
         self.optimizer.step(self.iteration)

@@ -92,3 +92,45 @@ def test_dp2_matches_single_process_and_ranks_stay_identical():
         params, states = [x[0] for x in res], [x[1] for x in res]
     for a, b in zip(p0, params):
         np.testing.assert_allclose(a, b.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _worker_deferred(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import dist as ld
+    ld.init_distributed(backend="gloo")
+    params = [torch.zeros(7, 3), torch.zeros(7, 15, 3), torch.zeros(7), torch.zeros(7, 4)]
+    bucket = ld.GradBucket(params, deferred=[1])
+    assert bucket.active_numel == 7 * 3 + 7 + 7 * 4 and bucket.flat.numel() == sum(p.numel() for p in params)
+    assert all(v.shape == p.shape for v, p in zip(bucket.views, params))
+    grads = [torch.full_like(p, float(rank + 1) * (i + 1)) for i, p in enumerate(params)]
+    bucket.gather(grads)
+    bucket.all_reduce(skip_deferred=True)
+    part = [v.clone() for v in bucket.views]
+    bucket.gather(grads)
+    bucket.all_reduce(skip_deferred=False)
+    full = [v.clone() for v in bucket.views]
+    q.put((rank, [x.numpy() for x in part], [x.numpy() for x in full]))
+    dist.destroy_process_group()
+
+
+def test_deferred_bucket_segment_is_left_out_of_the_collective():
+    """The higher-degree SH gradient (not read by Adam while iteration <= 1000) sits at the end of the flat bucket and is
+    skipped by all_reduce(skip_deferred=True); everything else is summed over the ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_deferred, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, part, full in results:
+        for i in range(4):
+            total = 3.0 * (i + 1)               # (1 + 2) * (i + 1)
+            local = float(rank + 1) * (i + 1)
+            assert np.all(full[i] == total)
+            assert np.all(part[i] == (local if i == 1 else total))
