@@ -202,23 +202,33 @@ __global__ void __launch_bounds__(THREADS) tile_sort_lds_kernel(
         keys[i] = k;
     }
     __syncthreads();
+    // Barrier elision: pair index i = it * THREADS + wave * 64 + lane. For a flip with k <= 128 and for half-cleaners
+    // with j <= 64 the 64 pairs of a wave live inside ONE aligned block of 128 keys, the same block in every such stage,
+    // so consecutive wave-local stages only need the in-order LDS pipeline of that wave. A workgroup barrier is needed
+    // only around the stages that cross 128-key blocks (9 of the 55 stages at n_pad = 1024).
+    bool prev_cross = false;
     for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+        const bool flip_cross = k > 128;
+        if (flip_cross || prev_cross) __syncthreads();
+        prev_cross = flip_cross;
         for (uint32_t i = threadIdx.x; i < n_pad / 2; i += THREADS) { // flip step
             const uint32_t blk = i / (k >> 1), off = i % (k >> 1);
             const uint32_t a = blk * k + off, b = blk * k + (k - 1 - off);
             const uint64_t ka = keys[a], kb = keys[b];
             if (ka > kb) { keys[a] = kb; keys[b] = ka; }
         }
-        __syncthreads();
         for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
+            const bool cross = j >= 128;
+            if (cross || prev_cross) __syncthreads();
+            prev_cross = cross;
             for (uint32_t i = threadIdx.x; i < n_pad / 2; i += THREADS) {
                 const uint32_t a = ((i / j) * (j << 1)) + (i % j), b = a + j;
                 const uint64_t ka = keys[a], kb = keys[b];
                 if (ka > kb) { keys[a] = kb; keys[b] = ka; }
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
         const uint64_t k = keys[i];
         isect_ids[start + i] = int64_t(hi_bits | (k >> 32));
@@ -457,8 +467,12 @@ extern "C" int lfs_intersect_tile_emit(
                                float(tile_size), tile_width, tile_height, tile_n_bits, w.offsets, w.cursor, isect_ids, flatten_ids);
         lfs::prof_end(tok, s);
         lfs::ProfScope prof_sort("isect_tile_sort", s);
-        // size classes: <= 4096 entries (32 KiB LDS), <= 16384 (128 KiB LDS), larger -> global
-        hipLaunchKernelGGL(tile_sort_lds_kernel<256>, dim3(T), dim3(256), 4096 * 8, s, 2u, 4096u, w.offsets, isect_ids, flatten_ids);
+        // size classes (LDS sized to the class so that small tiles do not cap the occupancy): <= 512 / 1024 / 2048 / 4096
+        // entries with 256 threads, <= 16384 (128 KiB LDS) with 1024 threads, larger -> global
+        hipLaunchKernelGGL(tile_sort_lds_kernel<256>, dim3(T), dim3(256), 512 * 8, s, 2u, 512u, w.offsets, isect_ids, flatten_ids);
+        hipLaunchKernelGGL(tile_sort_lds_kernel<256>, dim3(T), dim3(256), 1024 * 8, s, 513u, 1024u, w.offsets, isect_ids, flatten_ids);
+        hipLaunchKernelGGL(tile_sort_lds_kernel<256>, dim3(T), dim3(256), 2048 * 8, s, 1025u, 2048u, w.offsets, isect_ids, flatten_ids);
+        hipLaunchKernelGGL(tile_sort_lds_kernel<256>, dim3(T), dim3(256), 4096 * 8, s, 2049u, 4096u, w.offsets, isect_ids, flatten_ids);
         hipLaunchKernelGGL(tile_sort_lds_kernel<1024>, dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, w.offsets, isect_ids, flatten_ids);
         hipLaunchKernelGGL(tile_sort_global_kernel, dim3(T), dim3(1024), 0, s, 16385u, w.offsets, isect_ids, flatten_ids);
     } else {
