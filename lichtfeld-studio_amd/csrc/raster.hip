@@ -82,11 +82,19 @@ __global__ void __launch_bounds__(256) raster_pack_kernel(
 #pragma unroll
         for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
     f3 g = mu;
-    if (UNIFORM_ORIGIN) g = mul(M, cams[cid].origin - mu);
+    m3 Mr = M; // what the record carries: M for rolling shutters (world-space rays), M * Rinv for a global shutter
+    if (UNIFORM_ORIGIN) {
+        g = mul(M, cams[cid].origin - mu);
+        const m3& Ri = cams[cid].Rinv; // camera -> world: the kernels then work on CAMERA-space ray directions
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Mr.m[r][c] = M.m[r][0] * Ri.m[0][c] + M.m[r][1] * Ri.m[1][c] + M.m[r][2] * Ri.m[2][c];
+    }
     GaussRec rec;
-    rec.r0 = make_float4(M.m[0][0], M.m[0][1], M.m[0][2], g.x);
-    rec.r1 = make_float4(M.m[1][0], M.m[1][1], M.m[1][2], g.y);
-    rec.r2 = make_float4(M.m[2][0], M.m[2][1], M.m[2][2], g.z);
+    rec.r0 = make_float4(Mr.m[0][0], Mr.m[0][1], Mr.m[0][2], g.x);
+    rec.r1 = make_float4(Mr.m[1][0], Mr.m[1][1], Mr.m[1][2], g.y);
+    rec.r2 = make_float4(Mr.m[2][0], Mr.m[2][1], Mr.m[2][2], g.z);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     const float* cp = colors + idx * channels;
     c0 = cp[0];
@@ -301,28 +309,35 @@ LFS_DI float fma3(float ax, float bx, float ay, float by, float az, float bz) {
 LFS_DI f3 cross_fma(const f3& a, const f3& b) {
     return {__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)), __builtin_fmaf(a.x, b.y, -(b.x * a.y))};
 }
-// Distance of the Gaussian centre to the ray line in the Gaussian's normalised frame, written through the foot
-// vector w = gro - (gro . n) n (n = normalised M d) instead of the reference's |n x gro|: |w| = |n x gro|, same
-// operation count, and the backward collapses to dL/dgro = -s w, dL/d(M d) = il (gro . n) s w (s = vis * dL/dvis).
-struct RayEval { f3 om, gro, grd_n, w; float il, g, vis; };
-template <bool UNIFORM_ORIGIN>
-LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& rd, RayEval& e) {
+// Ray modes (template parameter of fwd / bwd):
+//   0 rolling shutter : world-space ray (ro, rd) per pixel, record = {M, mu}
+//   1 global shutter  : camera-space direction d (any camera model), record = {M Rinv, M (o - mu)}
+// (A third mode with d = (u, v, 1) for pinholes was tried: the three multiplications it saves come back as v_mov,
+//  because a VOP3 instruction on gfx9 can read only one SGPR and fma(M01, v, M02) needs two.)
+constexpr int RAY_ROLLING = 0, RAY_GLOBAL = 1;
+
+// Distance of the Gaussian centre to the ray line in the Gaussian's normalised frame. With q = M d (un-normalised),
+// t = (gro . q) / |q|^2 and the foot vector w = gro - t q:  |w| equals the reference's |normalize(q) x gro|, and the
+// backward collapses to dL/dgro = -s w, dL/dq = t s w (s = vis * dL/dvis): no normalisation, no cross products.
+struct RayEval { f3 om, w; float t, vis; };
+template <int MODE>
+LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& d, RayEval& e) {
     e.om = {0.f, 0.f, 0.f};
-    if (UNIFORM_ORIGIN) e.gro = {rec.r0.w, rec.r1.w, rec.r2.w};
+    f3 gro;
+    if (MODE != RAY_ROLLING) gro = {rec.r0.w, rec.r1.w, rec.r2.w};
     else {
         e.om = {ro.x - rec.r0.w, ro.y - rec.r1.w, ro.z - rec.r2.w};
-        e.gro = {fma3(rec.r0.x, e.om.x, rec.r0.y, e.om.y, rec.r0.z, e.om.z),
-                 fma3(rec.r1.x, e.om.x, rec.r1.y, e.om.y, rec.r1.z, e.om.z),
-                 fma3(rec.r2.x, e.om.x, rec.r2.y, e.om.y, rec.r2.z, e.om.z)};
+        gro = {fma3(rec.r0.x, e.om.x, rec.r0.y, e.om.y, rec.r0.z, e.om.z),
+               fma3(rec.r1.x, e.om.x, rec.r1.y, e.om.y, rec.r1.z, e.om.z),
+               fma3(rec.r2.x, e.om.x, rec.r2.y, e.om.y, rec.r2.z, e.om.z)};
     }
-    const f3 grd{fma3(rec.r0.x, rd.x, rec.r0.y, rd.y, rec.r0.z, rd.z),
-                 fma3(rec.r1.x, rd.x, rec.r1.y, rd.y, rec.r1.z, rd.z),
-                 fma3(rec.r2.x, rd.x, rec.r2.y, rd.y, rec.r2.z, rd.z)};
-    const float l = fma3(grd.x, grd.x, grd.y, grd.y, grd.z, grd.z);
-    e.il = l > 0.f ? fast_rsq(l) : 1.f;
-    e.grd_n = grd * e.il;
-    e.g = fma3(e.gro.x, e.grd_n.x, e.gro.y, e.grd_n.y, e.gro.z, e.grd_n.z);
-    e.w = {__builtin_fmaf(-e.g, e.grd_n.x, e.gro.x), __builtin_fmaf(-e.g, e.grd_n.y, e.gro.y), __builtin_fmaf(-e.g, e.grd_n.z, e.gro.z)};
+    const f3 q{fma3(rec.r0.x, d.x, rec.r0.y, d.y, rec.r0.z, d.z),
+               fma3(rec.r1.x, d.x, rec.r1.y, d.y, rec.r1.z, d.z),
+               fma3(rec.r2.x, d.x, rec.r2.y, d.y, rec.r2.z, d.z)};
+    const float l = fma3(q.x, q.x, q.y, q.y, q.z, q.z);
+    const float rl = l > 0.f ? fast_rcp(l) : 0.f; // l == 0: no direction (inactive lane / degenerate record), w = gro
+    e.t = fma3(gro.x, q.x, gro.y, q.y, gro.z, q.z) * rl;
+    e.w = {__builtin_fmaf(-e.t, q.x, gro.x), __builtin_fmaf(-e.t, q.y, gro.y), __builtin_fmaf(-e.t, q.z, gro.z)};
     // exp(-0.5 |w|^2) as one exp2: -0.5 * log2(e) = -0.72134752
     e.vis = __builtin_amdgcn_exp2f(-0.72134752044448170f * fma3(e.w.x, e.w.x, e.w.y, e.w.y, e.w.z, e.w.z));
 }
@@ -362,7 +377,19 @@ LFS_DI void walk_cell_list(const int2* __restrict__ cl, const GaussRec* __restri
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <int CDIM, bool UNIFORM_ORIGIN>
+// this lane's ray in the form the mode wants; false when the pixel has no ray
+template <int MODE>
+LFS_DI bool lane_ray(const CamDev& cam, const uint32_t j, const uint32_t i, f3& ro, f3& d) {
+    const f2 ip{float(j) + 0.5f, float(i) + 0.5f};
+    if (MODE == RAY_ROLLING) return cam_pixel_ray(cam, ip, ro, d);
+    ro = cam.origin;
+    f3 cd;
+    const bool ok = cam_unproject(cam, ip, cd);
+    d = ok ? cd : f3{0.f, 0.f, 0.f};
+    return ok;
+}
+
+template <int CDIM, int MODE>
 __global__ void __launch_bounds__(256) raster_fwd_kernel(
     const uint32_t C, const uint32_t N, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
     const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block,
@@ -390,8 +417,12 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 
     const CamDev& cam = cams[cid];
     f3 ro, rd;
-    const bool ray_ok = cam_pixel_ray(cam, f2{float(cc.j) + 0.5f, float(cc.i) + 0.5f}, ro, rd);
-    bool done = !(inside && ray_ok);
+    const bool ray_ok = lane_ray<MODE>(cam, cc.j, cc.i, ro, rd);
+    // "done" is carried as the lane's alpha threshold: 1/255 while the pixel is live, +inf once it has terminated (or never
+    // had a ray). One compare then answers both "not done" and "alpha >= 1/255", and the per-lane state stays out of the
+    // boolean VGPR juggling the compiler otherwise emits for a loop-carried bool (6 VALU per evaluation, measured in the ISA).
+    const float INF = __builtin_inff();
+    float thr = (inside && ray_ok) ? (1.f / 255.f) : INF;
 
     const uint32_t wpt = (tile_size >> 3) * (tile_size >> 3);
     const int32_t start = offsets[cc.tile_global];
@@ -408,9 +439,9 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     // One evaluation of a record against this lane's ray (wave-uniform record in SGPRs).
     auto eval = [&](const GaussRec& rec, const int2 e) {
         RayEval re;
-        ray_eval<UNIFORM_ORIGIN>(rec, ro, rd, re);
+        ray_eval<MODE>(rec, ro, rd, re);
         const float alpha = fminf(0.999f, rec.r3.x * re.vis);
-        const bool pass = !done && !(alpha < (1.f / 255.f));
+        const bool pass = !(alpha < thr); // live pixel and alpha >= 1/255 (a NaN alpha passes, as in the reference's `if (alpha < 1/255) continue`)
         if (__ballot(pass) == 0ull) return;
         const float next_T = T * (1.f - alpha);
         const bool fin = pass && next_T <= 1e-4f; // the terminating Gaussian is not composited
@@ -429,9 +460,9 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
             cur_idx = e.y;
             T = next_T;
         }
-        done |= fin;
+        thr = fin ? INF : thr;
     };
-    walk_cell_list<1>(cl, recs, 0, cnt, eval, [&]() { return __ballot(!done) != 0ull; });
+    walk_cell_list<1>(cl, recs, 0, cnt, eval, [&]() { return __ballot(thr < INF) != 0ull; });
 
     if (inside) {
         render_alphas[pix_id] = 1.f - T;
@@ -444,20 +475,15 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-LFS_DI float dpp_ror(float v, int n) {
-    // rotate inside each row of 16 lanes
-    switch (n) {
-    case 8: return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));
-    case 4: return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124, 0xf, 0xf, false));
-    case 2: return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x122, 0xf, 0xf, false));
-    default: return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x121, 0xf, 0xf, false));
-    }
+template <int CTRL>
+LFS_DI float dpp_mov(float v) { // row-local lane permutation (DPP): 0xB1 = lane^1, 0x4E = lane^2, 0x124 / 0x128 = rotate by 4 / 8
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
 }
 
-// Sum 16 per-lane values over the 64 lanes and add the 16 totals to dst[0..15]
-// with one 16-lane atomic instruction. Steps 1-2 halve the value count while
-// folding lane halves / row pairs (v_permlane32_swap, v_permlane16_swap), the
-// last four steps are row rotations (DPP).
+// Sum 16 per-lane values over the 64 lanes and add the 16 totals to dst[0..15] with one 16-lane atomic instruction.
+// Every step but the last two HALVES the number of live values while folding lanes: v_permlane32_swap (lane halves),
+// v_permlane16_swap (row pairs), then lane^1 and lane^2 inside the quads (select + DPP add); two row rotations finish.
+// 35 VALU for 16 sums (a butterfly per value would be 16 x 6).
 LFS_DI void wave_sum16_atomic(const float (&v)[16], float* __restrict__ dst, const uint32_t lane) {
     float w[8];
 #pragma unroll
@@ -471,20 +497,20 @@ LFS_DI void wave_sum16_atomic(const float (&v)[16], float* __restrict__ dst, con
         auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[j]), __float_as_uint(w[j + 4]), false, false);
         u[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        u[j] += dpp_ror(u[j], 8);
-        u[j] += dpp_ror(u[j], 4);
-        u[j] += dpp_ror(u[j], 2);
-        u[j] += dpp_ror(u[j], 1);
-    }
-    // row r (16 lanes) now holds totals of v[4r .. 4r+3] in u[0..3]
-    const uint32_t j = lane & 3;
-    const float out = (j & 2) ? ((j & 1) ? u[3] : u[2]) : ((j & 1) ? u[1] : u[0]);
-    if ((lane & 15) < 4) unsafeAtomicAdd(dst + 4 * (lane >> 4) + j, out);
+    // row r (16 lanes) now holds partial sums of v[4r .. 4r+3] in u[0..3]
+    const bool b0 = lane & 1, b1 = lane & 2;
+    // lane^1: even lanes keep (u0, u1), odd lanes keep (u2, u3)
+    const float s0 = (b0 ? u[2] : u[0]) + dpp_mov<0xB1>(b0 ? u[0] : u[2]);
+    const float s1 = (b0 ? u[3] : u[1]) + dpp_mov<0xB1>(b0 ? u[1] : u[3]);
+    // lane^2: bit1 == 0 keeps the first of the pair, bit1 == 1 the second
+    float t = (b1 ? s1 : s0) + dpp_mov<0x4E>(b1 ? s0 : s1);
+    t += dpp_mov<0x124>(t);
+    t += dpp_mov<0x128>(t);
+    // lane L holds the total of v[4 * (L >> 4) + 2 * (L & 1) + ((L >> 1) & 1)]
+    if ((lane & 12) == 0) unsafeAtomicAdd(dst + 4 * (lane >> 4) + 2 * (lane & 1) + ((lane >> 1) & 1), t);
 }
 
-template <int CDIM, bool UNIFORM_ORIGIN>
+template <int CDIM, int MODE>
 __global__ void __launch_bounds__(256) raster_bwd_kernel(
     const uint32_t C, const uint32_t N, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
     const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block,
@@ -506,7 +532,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 
     const CamDev& cam = cams[cid];
     f3 ro, rd;
-    const bool ray_ok = cam_pixel_ray(cam, f2{float(cc.j) + 0.5f, float(cc.i) + 0.5f}, ro, rd);
+    const bool ray_ok = lane_ray<MODE>(cam, cc.j, cc.i, ro, rd);
     const bool active = inside && ray_ok;
 
     const uint32_t wpt = (tile_size >> 3) * (tile_size >> 3);
@@ -554,15 +580,15 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 
     auto eval = [&](const GaussRec& rec, const int2 e) {
         RayEval re;
-        ray_eval<UNIFORM_ORIGIN>(rec, ro, rd, re);
+        ray_eval<MODE>(rec, ro, rd, re);
         const float vis = re.vis, opac = rec.r3.x;
         const float araw = opac * vis;
         const float alpha = fminf(0.999f, araw);
-        const bool valid = active && e.y <= bin_final && !(alpha < (1.f / 255.f)); // (vis > 1 cannot happen: exp2 of -c |w|^2)
+        const bool valid = e.y <= bin_final && !(alpha < (1.f / 255.f)); // (inactive lanes carry bin_final = -1; vis > 1 cannot happen)
         if (__ballot(valid) == 0ull) return;
 
         // Invalid lanes are masked by zeroing three scalars (fac, v_op, and through it s): every reduced value below is
-        // a product with one of them. (All factors are finite for an inactive lane: its ray is 0, so w = gro.)
+        // a product with one of them. (All factors are finite for an inactive lane: its direction is 0, so w = gro, t = 0.)
         const float ra = fast_rcp(1.f - alpha);
         const float Tn = T * ra;
         T = valid ? Tn : T;
@@ -593,12 +619,12 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         v[12] = v_op;
         const float sgeo = opac * v_op;                                     // s = vis * dL/dvis
         const f3 a = re.w * sgeo;                                           // = -dL/dgro (the sign is undone in raster_finish_kernel)
-        const f3 vg = a * (re.il * re.g);                                   // dL/d(M d)
-        // dL/dM = vg (x) d  [+ dL/dgro (x) (o - mu) per pixel only when the origin varies]
+        const f3 vg = a * re.t;                                             // dL/dq, q = (record matrix) d
+        // dL/d(record matrix) = vg (x) d  [- a (x) (o - mu) per pixel only when the origin varies]
         v[0] = vg.x * rd.x; v[1] = vg.x * rd.y; v[2] = vg.x * rd.z;
         v[3] = vg.y * rd.x; v[4] = vg.y * rd.y; v[5] = vg.y * rd.z;
         v[6] = vg.z * rd.x; v[7] = vg.z * rd.y; v[8] = vg.z * rd.z;
-        if (!UNIFORM_ORIGIN) {
+        if (MODE == RAY_ROLLING) {
             const f3& om = re.om;
             v[0] -= a.x * om.x; v[1] -= a.x * om.y; v[2] -= a.x * om.z;
             v[3] -= a.y * om.x; v[4] -= a.y * om.y; v[5] -= a.y * om.z;
@@ -657,12 +683,17 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
                 for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
             geom_loaded = true;
         }
-        // dL/dM (math rows r, cols c)
+        // dL/dM (math rows r, cols c). Global shutter: the record matrix was M Rinv, so dL/dM = dL/d(M Rinv) Rinv^T
         m3 vM;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) vM.m[r][c] = A[3 * r + c];
+            for (int c = 0; c < 3; ++c) {
+                if (UNIFORM_ORIGIN) {
+                    const m3& Ri = cams[cid].Rinv;
+                    vM.m[r][c] = A[3 * r] * Ri.m[c][0] + A[3 * r + 1] * Ri.m[c][1] + A[3 * r + 2] * Ri.m[c][2];
+                } else vM.m[r][c] = A[3 * r + c];
+            }
         if (UNIFORM_ORIGIN) {
             const f3 om = cams[cid].origin - mu;
             const float gv[3] = {G.x, G.y, G.z}, ov[3] = {om.x, om.y, om.z};
@@ -724,6 +755,11 @@ extern "C" size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t
     return raster_ws(nullptr, C, N, g.cells, uint64_t(g.wpt) * uint64_t(n_isects)).bytes;
 }
 
+static int raster_mode(const lfs_cameras* cams) {
+    if (cams->rs_type != LFS_SHUTTER_GLOBAL) return lfs::RAY_ROLLING;
+    return lfs::RAY_GLOBAL;
+}
+
 static int raster_check(uint32_t N, uint32_t channels, const lfs_cameras* cams, uint32_t tile_size, RasterGeom& g) {
     if (!cams || !cams->viewmats0 || !cams->Ks || cams->C == 0) return LFS_E_INVALID;
     if (cams->camera_model != LFS_CAMERA_PINHOLE && cams->camera_model != LFS_CAMERA_FISHEYE) return LFS_E_UNSUPPORTED;
@@ -777,19 +813,18 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     if (N > 0 && (!means || !quats || !scales || !colors || !opacities)) return LFS_E_INVALID;
     if (n_isects > 0 && !flatten_ids) return LFS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
     raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects, s);
     lfs::ProfScope prof("raster_fwd", s);
-#define LFS_FWD(CD, UNI)                                                                                         \
-    hipLaunchKernelGGL((raster_fwd_kernel<CD, UNI>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,        \
+#define LFS_FWD(CD, MODE)                                                                                        \
+    hipLaunchKernelGGL((raster_fwd_kernel<CD, MODE>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,        \
                        cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, int32_t(n_isects), \
                        render_colors, render_alphas, last_ids)
-    switch (channels * 2 + (uniform ? 1 : 0)) {
-    case 2: LFS_FWD(1, false); break; case 3: LFS_FWD(1, true); break;
-    case 4: LFS_FWD(2, false); break; case 5: LFS_FWD(2, true); break;
-    case 6: LFS_FWD(3, false); break; case 7: LFS_FWD(3, true); break;
-    case 8: LFS_FWD(4, false); break; default: LFS_FWD(4, true); break;
+    switch (channels * 2 + raster_mode(cams)) {
+    case 2: LFS_FWD(1, 0); break; case 3: LFS_FWD(1, 1); break;
+    case 4: LFS_FWD(2, 0); break; case 5: LFS_FWD(2, 1); break;
+    case 6: LFS_FWD(3, 0); break; case 7: LFS_FWD(3, 1); break;
+    case 8: LFS_FWD(4, 0); break; default: LFS_FWD(4, 1); break;
     }
 #undef LFS_FWD
     return (int)hipGetLastError();
@@ -826,16 +861,16 @@ static int raster_bwd_impl(
     if (!prepared) raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects, s);
     if (n_isects > 0) {
         lfs::ProfScope prof("raster_bwd", s);
-#define LFS_BWD(CD, UNI)                                                                                         \
-    hipLaunchKernelGGL((raster_bwd_kernel<CD, UNI>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,        \
+#define LFS_BWD(CD, MODE)                                                                                        \
+    hipLaunchKernelGGL((raster_bwd_kernel<CD, MODE>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,        \
                        cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, int32_t(n_isects), \
                        render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors)
-        switch (channels * 2 + (uniform ? 1 : 0)) {
-        case 2: LFS_BWD(1, false); break; case 3: LFS_BWD(1, true); break;
-        case 4: LFS_BWD(2, false); break; case 5: LFS_BWD(2, true); break;
-        case 6: LFS_BWD(3, false); break; case 7: LFS_BWD(3, true); break;
-        case 8: LFS_BWD(4, false); break; default: LFS_BWD(4, true); break;
+        switch (channels * 2 + raster_mode(cams)) {
+        case 2: LFS_BWD(1, 0); break; case 3: LFS_BWD(1, 1); break;
+        case 4: LFS_BWD(2, 0); break; case 5: LFS_BWD(2, 1); break;
+        case 6: LFS_BWD(3, 0); break; case 7: LFS_BWD(3, 1); break;
+        case 8: LFS_BWD(4, 0); break; default: LFS_BWD(4, 1); break;
         }
 #undef LFS_BWD
     }
