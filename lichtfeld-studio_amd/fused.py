@@ -60,6 +60,7 @@ def sh_model_bwd(sh_degree: int, means, viewmat, sh0, shN, radii, colors, v_colo
 
 def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
     """loss_acc (1-element tensor) += weight * mse(clamp(render, 0, 1), target); returns dL/d(render) [H,W,3]."""
+    target_chw = target_chw.contiguous()  # (a CHW view of an HWC render is a common caller mistake; no-op otherwise)
     require_gpu(render_hwc, target_chw, loss_acc)
     H, W = render_hwc.shape[-3], render_hwc.shape[-2]
     assert render_hwc.shape[-1] == 3 and tuple(target_chw.shape) == (3, H, W), (render_hwc.shape, target_chw.shape)

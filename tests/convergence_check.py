@@ -1,0 +1,160 @@
+"""PSNR-after-training check (BASELINE.json north star: "PSNR within 0.05 dB of reference after 7k iters").
+
+The reference's CUDA trainer cannot run here, so the comparison is HIP path vs the CPU oracle (the line-by-line restatement of
+the reference kernels, tests only) driven through the SAME training recipe: identical initial parameters, view order, MSE loss,
+Adam hyper-parameters (eval/default_optimization_params.json learning rates, eps 1e-15, the shN group skipped while
+iteration <= 1000, exponential decay of the means lr), same number of iterations. Task: recover a ground-truth set of Gaussians
+from its own renders, starting from a perturbed copy.
+
+    python tests/convergence_check.py --iters 7000 --oracle-iters 1500      # prints one JSON line
+
+`tests/test_gpu_convergence.py` runs a short version under pytest -m gpu.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_task(n=6000, size=192, n_views=8, sh_degree=1, seed=7):
+    from lichtfeld_studio_amd import scenes
+    g = torch.Generator().manual_seed(seed)
+    K_ = (sh_degree + 1) ** 2
+    means = (torch.rand(n, 3, generator=g) * 2 - 1) * 2.0
+    quats = torch.randn(n, 4, generator=g)
+    raw_scales = math.log(0.07) + 0.3 * torch.randn(n, 3, generator=g)
+    raw_opac = 1.0 + 1.5 * torch.randn(n, generator=g)
+    sh0 = 0.6 * torch.randn(n, 1, 3, generator=g)
+    shN = 0.15 * torch.randn(n, K_ - 1, 3, generator=g)
+    viewmats = scenes.orbit_cameras(n_views, radius=7.0)
+    Ks = torch.tensor([[size * 1.1, 0, size / 2], [0, size * 1.1, size / 2], [0, 0, 1]], dtype=torch.float32).repeat(n_views, 1, 1)
+    gt = scenes.Scene("GT", size, size, sh_degree, means, quats, raw_scales, raw_opac, sh0, shN, viewmats, Ks)
+    # perturbed start
+    init = scenes.Scene("INIT", size, size, sh_degree,
+                        means + 0.04 * torch.randn(n, 3, generator=g), quats + 0.3 * torch.randn(n, 4, generator=g),
+                        raw_scales + 0.3 * torch.randn(n, 3, generator=g), raw_opac + 1.0 * torch.randn(n, generator=g),
+                        sh0 + 0.4 * torch.randn(n, 1, 3, generator=g), torch.zeros_like(shN), viewmats, Ks)
+    return gt, init
+
+
+def psnr(a: np.ndarray, b: np.ndarray) -> float:
+    mse = float(((a - b) ** 2).mean())
+    return 10.0 * math.log10(1.0 / max(mse, 1e-20))
+
+
+def render_views_hip(scene, dev):
+    from lichtfeld_studio_amd.rasterizer import Camera, SplatModel, rasterize
+    sc = scene.to(dev)
+    model = SplatModel(sc.means, sc.sh0, sc.shN, sc.raw_scales, sc.raw_quats, sc.raw_opacities, sc.sh_degree)
+    out = []
+    with torch.no_grad():
+        for v in range(sc.viewmats.shape[0]):
+            cam = Camera(sc.viewmats[v:v + 1].contiguous(), sc.Ks[v:v + 1].contiguous(), sc.width, sc.height)
+            out.append(rasterize(cam, model, torch.zeros(3, device=dev)).image.contiguous().clone())
+    return out
+
+
+def train_hip(init, targets, iters, total_iters, dev, report_every, fused=True):
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    tr = GutTrainer(init, dev, iterations=total_iters, fused_l2=fused)
+    V = init.viewmats.shape[0]
+    hist = {}
+    for it in range(iters):
+        v = it % V
+        tr.train_step([targets[v]], views=[v])
+        if (it + 1) % report_every == 0 or it + 1 == iters:
+            m = tr.model
+            from lichtfeld_studio_amd import scenes
+            cur = scenes.Scene("cur", init.width, init.height, init.sh_degree, m.means.detach(), m.raw_quats.detach(), m.raw_scales.detach(),
+                               m.raw_opacities.detach(), m.sh0.detach(), m.shN.detach(), tr.scene.viewmats, tr.scene.Ks)
+            imgs = render_views_hip(cur, dev)
+            hist[it + 1] = float(np.mean([psnr(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(imgs, targets)]))
+    return hist, tr
+
+
+def train_oracle(init, targets_np, iters, total_iters, report_every):
+    """The same recipe on the CPU oracle (restatement of the reference kernels) + the oracle's Adam."""
+    import oracle
+    from lichtfeld_studio_amd import scenes
+    from test_gpu_pipeline import _oracle_step
+    oracle.lib()
+    names = ["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"]
+    P = {"means": init.means.numpy().copy(), "sh0": init.sh0.numpy().copy(), "shN": init.shN.numpy().copy(),
+         "raw_scales": init.raw_scales.numpy().copy(), "raw_quats": init.raw_quats.numpy().copy(), "raw_opacities": init.raw_opacities.numpy().copy()}
+    M = {k: np.zeros_like(v) for k, v in P.items()}
+    Vv = {k: np.zeros_like(v) for k, v in P.items()}
+    lrs = {"means": 1.6e-4, "sh0": 2.5e-3, "shN": 2.5e-3 / 20, "raw_scales": 5e-3, "raw_quats": 1e-3, "raw_opacities": 5e-2}
+    gamma = 0.01 ** (1.0 / total_iters)
+    nV = init.viewmats.shape[0]
+    hist = {}
+
+    def as_scene():
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        return scenes.Scene("o", init.width, init.height, init.sh_degree, t(P["means"]), t(P["raw_quats"]), t(P["raw_scales"]), t(P["raw_opacities"]),
+                            t(P["sh0"]), t(P["shN"]), init.viewmats, init.Ks)
+
+    for it in range(iters):
+        v = it % nV
+        _, _, g, _ = _oracle_step(oracle, as_scene(), v, targets_np[v], init.sh_degree)
+        step = it + 1
+        for k in names:
+            if k == "shN" and step <= 1000:
+                continue
+            gk = np.ascontiguousarray(g[k], dtype=np.float32).reshape(P[k].shape)
+            p, m, vv = oracle.adam_step(P[k].reshape(-1), M[k].reshape(-1), Vv[k].reshape(-1), gk.reshape(-1), lrs[k], 0.9, 0.999, 1e-15,
+                                        1.0 / (1.0 - 0.9 ** step), 1.0 / math.sqrt(1.0 - 0.999 ** step))
+            P[k], M[k], Vv[k] = p.reshape(P[k].shape), m.reshape(P[k].shape), vv.reshape(P[k].shape)
+        lrs["means"] *= gamma
+        if step % report_every == 0 or step == iters:
+            sc = as_scene()
+            ps = []
+            for w in range(nV):
+                _, img, _, _ = _oracle_step(oracle, sc, w, targets_np[w], init.sh_degree)
+                ps.append(psnr(img, targets_np[w]))
+            hist[step] = float(np.mean(ps))
+    return hist
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=7000)
+    ap.add_argument("--oracle-iters", type=int, default=0, help="also train the CPU oracle for this many iterations (0 = skip)")
+    ap.add_argument("--n", type=int, default=6000)
+    ap.add_argument("--size", type=int, default=192)
+    ap.add_argument("--report-every", type=int, default=1000)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    gt, init = make_task(n=args.n, size=args.size)
+    targets = render_views_hip(gt, dev)
+    t0 = time.time()
+    hip_hist, _ = train_hip(init, targets, args.iters, args.iters, dev, args.report_every)
+    t_hip = time.time() - t0
+    start = float(np.mean([psnr(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(render_views_hip(init, dev), targets)]))
+    out = {"task": f"recover {args.n} Gaussians from {gt.viewmats.shape[0]} views {args.size}x{args.size}, SH degree {gt.sh_degree}, MSE loss",
+           "psnr_start": round(start, 3), "hip_psnr": {k: round(v, 3) for k, v in hip_hist.items()}, "hip_seconds": round(t_hip, 1)}
+    if args.oracle_iters:
+        t0 = time.time()
+        # the same schedule (lr decay defined over --iters), stopped early
+        hip_short, _ = train_hip(init, targets, args.oracle_iters, args.iters, dev, args.oracle_iters)
+        o_hist = train_oracle(init, [t.cpu().numpy() for t in targets], args.oracle_iters, args.iters, args.oracle_iters)
+        out["oracle_iters"] = args.oracle_iters
+        out["oracle_psnr"] = {k: round(v, 3) for k, v in o_hist.items()}
+        out["hip_psnr_same_iters"] = {k: round(v, 3) for k, v in hip_short.items()}
+        out["psnr_gap_db"] = round(abs(list(o_hist.values())[-1] - list(hip_short.values())[-1]), 4)
+        out["oracle_seconds"] = round(time.time() - t0, 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
