@@ -49,7 +49,7 @@ def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems
         "raster_finish": 64 * N + 44 * N + 56 * N,
         "sh_bwd": 24 * V + 12 * K * V + 12 * K * N + 12 * K * V + 12 * V,
         "activations_fwd": 2 * 32 * N, "activations_bwd": 32 * N + 32 * N + 32 * N + 32 * N,
-        "mse_loss": 36 * P,
+        "mse_loss": 36 * P, "photometric_loss": 36 * P + 2 * 36 * P,
         "adam_multi": 28 * adam_elems,
         "adam": 28 * adam_elems,
     }
@@ -119,6 +119,7 @@ def main() -> None:
     ap.add_argument("--workload", default="syn-b", choices=["syn-a", "syn-b", "syn-c", "syn-d"])
     ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
     ap.add_argument("--views-per-rank", type=int, default=1)
+    ap.add_argument("--loss", default="mse", choices=["mse", "l1_ssim"], help="mse = rasterizer-only metric of SURVEY.md §8d (default); l1_ssim = the reference's photometric loss")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -144,7 +145,7 @@ def main() -> None:
         kw["sh_degree"] = 0
     scene = maker(**kw)
     n_views = scene.viewmats.shape[0]
-    trainer = GutTrainer(scene, device, iterations=7000, world=world, rank=rank, views_per_rank=args.views_per_rank)
+    trainer = GutTrainer(scene, device, iterations=7000, world=world, rank=rank, views_per_rank=args.views_per_rank, loss=args.loss)
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
 
     # Warm-up. Its last (up to 3) steps run with every kernel scope timed (HIP events on the launch stream): that gives the
@@ -241,7 +242,7 @@ def main() -> None:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{scene.name}: {N} Gaussians, {scene.width}x{scene.height}, SH degree {scene.sh_degree}, "
-                               f"16x16 tiles, {n_views} orbit cameras, MSE loss, default_optimization_params lrs",
+                               f"16x16 tiles, {n_views} orbit cameras, {'MSE' if args.loss == 'mse' else 'L1 + 0.2 D-SSIM'} loss, default_optimization_params lrs",
                    "global_batch": world * args.views_per_rank, "views_per_rank": args.views_per_rank,
                    "parallelism": f"dp{world}", "visible_gaussians": V, "n_isects": I},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,

@@ -198,6 +198,21 @@ LFS_API int lfs_activations_bwd(uint32_t N, const float* raw_quats, const float*
 LFS_API int lfs_mse_loss_fwd_bwd(uint32_t H, uint32_t W, const float* render_hwc, const float* target_chw, float weight,
                                  float* v_render_hwc, float* loss, lfs_stream_t stream);
 
+/* ---- "next" row 2 of SURVEY.md §8f: fused SSIM (fusedssim / fusedssim_backward, include/kernels/ssim.cuh:11-30,
+ *      src/training/kernels/ssim.cu:64-510) and the trainer's photometric loss (trainer.cpp:122-125).
+ *      img1 / img2 / maps [B,CH,H,W]; 11-tap Gaussian window, zero padding. dm_* may all be NULL (train == false).
+ *      lfs_photometric_loss_fwd_bwd (extension): *loss += weight * ((1 - lambda) * L1 + lambda * (1 - mean SSIM over the
+ *      "valid" crop)) of clamp(render, 0, 1) against target; render / v_render HWC [H,W,3], target CHW [3,H,W]. */
+LFS_API int lfs_fused_ssim_fwd(uint32_t B, uint32_t CH, uint32_t H, uint32_t W, float C1, float C2, const float* img1, const float* img2,
+                               float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, lfs_stream_t stream);
+LFS_API int lfs_fused_ssim_bwd(uint32_t B, uint32_t CH, uint32_t H, uint32_t W, float C1, float C2, const float* img1, const float* img2,
+                               const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                               float* dL_dimg1, lfs_stream_t stream);
+LFS_API size_t lfs_photometric_loss_workspace_bytes(uint32_t H, uint32_t W);
+LFS_API int lfs_photometric_loss_fwd_bwd(uint32_t H, uint32_t W, const float* render_hwc, const float* target_chw, float lambda_dssim,
+                                         float weight, float* v_render_hwc, float* loss, void* workspace, size_t workspace_bytes,
+                                         lfs_stream_t stream);
+
 /* ---- gsplat::quats_to_rotmats (gsplat/Ops.h:45-48, QuatToRotmatCUDA.cu:14-39): rotmats [N,3,3] row-major */
 LFS_API int lfs_quats_to_rotmats(uint32_t N, const float* quats, float* rotmats, lfs_stream_t stream);
 

@@ -29,6 +29,7 @@ SOURCES = {
     "mcmc.hip": ["-ffp-contract=off"],
     "adam.hip": ["-ffp-contract=off"],
     "l2_fused.hip": ["-ffp-contract=off"],
+    "ssim.hip": ["-ffp-contract=off"],
     "prof.hip": [],
     # no SLP packing: v_pk_* operand pairing forces SGPR shuffles right after the scalar record
     # load and defeats the software prefetch (measured on the ISA); plain v_fma with SGPR operands

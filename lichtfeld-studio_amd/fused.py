@@ -79,8 +79,10 @@ class FusedStepOutput:
 
 
 def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
-                        grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool) -> FusedStepOutput:
-    """One view: forward, MSE against `target_chw`, backward. `grads` = six tensors shaped like model.parameters()
+                        grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool, loss: str = "mse",
+                        lambda_dssim: float = 0.2) -> FusedStepOutput:
+    """One view: forward, loss against `target_chw` ("mse": the rasterizer-only metric of SURVEY.md §8d; "l1_ssim": the reference's
+    photometric loss, trainer.cpp:115-128), backward. `grads` = six tensors shaped like model.parameters()
     (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
     Constants as in rasterizer.cpp:176-181."""
     assert camera.camera_model_type == CameraModelType.PINHOLE and camera.radial_distortion is None and camera.tangential_distortion is None, \
@@ -103,7 +105,13 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         fwd_args = (means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, None, W, H, tile, viewmat, None, Kmat,
                     CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None, offsets, flatten_ids)
         render, alpha, last_ids, ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(*fwd_args, own_workspace=True)
-        v_render = mse_loss_fwd_bwd(render, target_chw, weight, loss_acc)
+        if loss == "mse":
+            v_render = mse_loss_fwd_bwd(render, target_chw, weight, loss_acc)
+        elif loss == "l1_ssim":
+            from .losses import photometric_loss_fwd_bwd
+            v_render = photometric_loss_fwd_bwd(render, target_chw, lambda_dssim, weight, loss_acc)
+        else:
+            raise ValueError(f"unknown loss {loss!r}")
         v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
             *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws)
         # SH backward adds dL/d(dirs) onto the rasterizer's dL/d(means) in place, then the means gradient lands in the caller's buffer

@@ -17,7 +17,7 @@ from .scenes import Scene
 
 class GutTrainer:
     def __init__(self, scene: Scene, device, iterations: int = 7000, world: int = 1, rank: int = 0,
-                 views_per_rank: int = 1, fused_adam: bool = True, fused_l2: bool = True):
+                 views_per_rank: int = 1, fused_adam: bool = True, fused_l2: bool = True, loss: str = "mse", lambda_dssim: float = 0.2):
         self.device, self.world, self.rank, self.views_per_rank = device, world, rank, views_per_rank
         sc = scene.to(device)
         self.scene = sc
@@ -29,6 +29,7 @@ class GutTrainer:
         # fused_l2: explicit forward/backward through the fused kernels (fused.py) instead of torch autograd over
         # the op-by-op mirror (rasterizer.py); gradients land directly in the flat bucket the all-reduce works on.
         self.fused_l2 = fused_l2
+        self.loss_kind, self.lambda_dssim = loss, lambda_dssim  # "mse" | "l1_ssim" (trainer.cpp:115-128)
         self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2]) if (world > 1 or fused_l2) else None  # 2 = shN
         self.loss_acc = torch.zeros(1, device=device)
         self.iteration = 0
@@ -60,7 +61,7 @@ class GutTrainer:
             self.loss_acc.zero_()
             for k, v in enumerate(views):
                 out = render_and_backward(self.camera(v), self.model, self.bg, targets[k % len(targets)], 1.0 / total_views,
-                                          self.bucket.views, self.loss_acc, accumulate=k > 0)
+                                          self.bucket.views, self.loss_acc, accumulate=k > 0, loss=self.loss_kind, lambda_dssim=self.lambda_dssim)
                 self.last_n_isects, self._last_radii = out.n_isects, out.radii
             self.bucket.all_reduce(skip_deferred=self.iteration <= 1000)  # shN's gradient is not read by Adam until then
             for p, gv in zip(params, self.bucket.views):
@@ -70,7 +71,11 @@ class GutTrainer:
             return self.loss_acc  # this rank's share of the loss (a 1-element tensor, read it after a sync)
         for k, v in enumerate(views):
             out = rasterize(self.camera(v), self.model, self.bg, 1.0, False, False, RenderMode.RGB)
-            loss = torch.nn.functional.mse_loss(out.image, targets[k % len(targets)]) / total_views
+            if self.loss_kind == "l1_ssim":
+                from .losses import photometric_loss
+                loss = photometric_loss(out.image, targets[k % len(targets)], self.lambda_dssim) / total_views
+            else:
+                loss = torch.nn.functional.mse_loss(out.image, targets[k % len(targets)]) / total_views
             loss.backward()
             loss_value = loss.detach()
             self.last_n_isects, self._last_visible = out.n_isects, out.visibility

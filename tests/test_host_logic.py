@@ -90,3 +90,18 @@ def test_exponential_lr_only_touches_means_group(lfs):
     for _ in range(100):
         sch.step()
     assert abs(opt.param_groups[0]["lr"] - 0.01) < 1e-9 and opt.param_groups[1]["lr"] == 1.0
+
+
+def test_ssim_reference_is_self_consistent():
+    """tests/ssim_reference.py (the checker of the GPU SSIM tests): identical images -> 1, symmetric in its arguments, window sums to 1,
+    analytic gradient == finite differences (fp64 gradcheck)."""
+    import torch
+    import ssim_reference as ref
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(1, 2, 20, 23, generator=g, dtype=torch.float64)
+    b = torch.rand(1, 2, 20, 23, generator=g, dtype=torch.float64)
+    assert abs(sum(ref.GAUSS) - 1.0) < 1e-6
+    assert torch.allclose(ref.ssim_map(a, a)[:, :, 5:-5, 5:-5], torch.ones(1, 2, 10, 13, dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(ref.ssim_map(a, b), ref.ssim_map(b, a), atol=1e-12)
+    a.requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda x: ref.photometric_loss(x, b, 0.2), (a,), eps=1e-6, atol=1e-6)
