@@ -193,7 +193,9 @@ LFS_API int lfs_sh_model_bwd(
 LFS_API int lfs_activations_fwd(uint32_t N, const float* raw_quats, const float* raw_scales, const float* raw_opacities,
                                 float* quats, float* scales, float* opacities, lfs_stream_t stream);
 LFS_API int lfs_activations_bwd(uint32_t N, const float* raw_quats, const float* scales, const float* opacities,
-                                const float* v_quats, const float* v_scales, const float* v_opacities, int accumulate,
+                                const float* v_quats, const float* v_scales, const float* v_opacities,
+                                float scale_reg, float opacity_reg, /* + d/d(activated) of scale_reg * mean(scales) + opacity_reg * mean(opacities), trainer.cpp:132-158 */
+                                int accumulate,
                                 float* g_raw_quats, float* g_raw_scales, float* g_raw_opacities, lfs_stream_t stream);
 LFS_API int lfs_mse_loss_fwd_bwd(uint32_t H, uint32_t W, const float* render_hwc, const float* target_chw, float weight,
                                  float* v_render_hwc, float* loss, lfs_stream_t stream);

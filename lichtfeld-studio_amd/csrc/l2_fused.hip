@@ -30,6 +30,7 @@ template <bool ACCUM>
 __global__ void __launch_bounds__(256) activations_bwd_kernel(
     const uint32_t N, const float* __restrict__ raw_quats, const float* __restrict__ scales, const float* __restrict__ opacities,
     const float* __restrict__ v_quats, const float* __restrict__ v_scales, const float* __restrict__ v_opacities,
+    const float v_scale_reg, const float v_opacity_reg,
     float* __restrict__ g_raw_quats, float* __restrict__ g_raw_scales, float* __restrict__ g_raw_opacities) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
@@ -50,11 +51,11 @@ __global__ void __launch_bounds__(256) activations_bwd_kernel(
     *gqo = gq;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float gs = v_scales[3 * g + k] * scales[3 * g + k];
+        const float gs = (v_scales[3 * g + k] + v_scale_reg) * scales[3 * g + k];
         if (ACCUM) g_raw_scales[3 * g + k] += gs; else g_raw_scales[3 * g + k] = gs;
     }
     const float o = opacities[g];
-    const float go = v_opacities[g] * o * (1.f - o);
+    const float go = (v_opacities[g] + v_opacity_reg) * o * (1.f - o);
     if (ACCUM) g_raw_opacities[g] += go; else g_raw_opacities[g] = go;
 }
 
@@ -95,15 +96,17 @@ extern "C" int lfs_activations_fwd(uint32_t N, const float* raw_quats, const flo
 }
 
 extern "C" int lfs_activations_bwd(uint32_t N, const float* raw_quats, const float* scales, const float* opacities,
-                                   const float* v_quats, const float* v_scales, const float* v_opacities, int accumulate,
+                                   const float* v_quats, const float* v_scales, const float* v_opacities, float scale_reg, float opacity_reg, int accumulate,
                                    float* g_raw_quats, float* g_raw_scales, float* g_raw_opacities, lfs_stream_t stream) {
     if (N == 0) return LFS_OK;
     if (!raw_quats || !scales || !opacities || !v_quats || !v_scales || !v_opacities || !g_raw_quats || !g_raw_scales || !g_raw_opacities) return LFS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     lfs::ProfScope prof("activations_bwd", s);
     const dim3 grid((N + 255) / 256), block(256);
-    if (accumulate) hipLaunchKernelGGL(lfs::activations_bwd_kernel<true>, grid, block, 0, s, N, raw_quats, scales, opacities, v_quats, v_scales, v_opacities, g_raw_quats, g_raw_scales, g_raw_opacities);
-    else hipLaunchKernelGGL(lfs::activations_bwd_kernel<false>, grid, block, 0, s, N, raw_quats, scales, opacities, v_quats, v_scales, v_opacities, g_raw_quats, g_raw_scales, g_raw_opacities);
+    // regularisers of trainer.cpp:132-158: scale_reg * mean(scales) (mean over 3N values) and opacity_reg * mean(opacities)
+    const float vs = scale_reg / (3.f * float(N)), vo = opacity_reg / float(N);
+    if (accumulate) hipLaunchKernelGGL(lfs::activations_bwd_kernel<true>, grid, block, 0, s, N, raw_quats, scales, opacities, v_quats, v_scales, v_opacities, vs, vo, g_raw_quats, g_raw_scales, g_raw_opacities);
+    else hipLaunchKernelGGL(lfs::activations_bwd_kernel<false>, grid, block, 0, s, N, raw_quats, scales, opacities, v_quats, v_scales, v_opacities, vs, vo, g_raw_quats, g_raw_scales, g_raw_opacities);
     return (int)hipGetLastError();
 }
 

@@ -34,10 +34,11 @@ def activations_fwd(raw_quats, raw_scales, raw_opacities):
     return quats, scales, opac
 
 
-def activations_bwd(raw_quats, scales, opacities, v_quats, v_scales, v_opacities, g_raw_quats, g_raw_scales, g_raw_opacities, accumulate: bool):
+def activations_bwd(raw_quats, scales, opacities, v_quats, v_scales, v_opacities, g_raw_quats, g_raw_scales, g_raw_opacities, accumulate: bool,
+                    scale_reg: float = 0.0, opacity_reg: float = 0.0):
     require_gpu(raw_quats, scales, opacities, v_quats, v_scales, v_opacities, g_raw_quats, g_raw_scales, g_raw_opacities)
     check(load_library().lfs_activations_bwd(C.c_uint32(raw_quats.shape[0]), ptr(raw_quats), ptr(scales), ptr(opacities),
-                                             ptr(v_quats), ptr(v_scales), ptr(v_opacities), C.c_int(int(accumulate)),
+                                             ptr(v_quats), ptr(v_scales), ptr(v_opacities), C.c_float(scale_reg), C.c_float(opacity_reg), C.c_int(int(accumulate)),
                                              ptr(g_raw_quats), ptr(g_raw_scales), ptr(g_raw_opacities), stream()), "activations_bwd")
 
 
@@ -80,7 +81,7 @@ class FusedStepOutput:
 
 def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
                         grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool, loss: str = "mse",
-                        lambda_dssim: float = 0.2) -> FusedStepOutput:
+                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0) -> FusedStepOutput:
     """One view: forward, loss against `target_chw` ("mse": the rasterizer-only metric of SURVEY.md §8d; "l1_ssim": the reference's
     photometric loss, trainer.cpp:115-128), backward. `grads` = six tensors shaped like model.parameters()
     (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
@@ -120,5 +121,6 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
             g_means.add_(v_means)
         else:
             g_means.copy_(v_means)
-        activations_bwd(raw_quats, scales, opac, v_quats, v_scales, v_opac.squeeze(0), g_quats, g_scales, g_opac, accumulate)
+        # the regularisers of trainer.cpp:132-158 are per step, not per view: the caller passes them with the first view only
+        activations_bwd(raw_quats, scales, opac, v_quats, v_scales, v_opac.squeeze(0), g_quats, g_scales, g_opac, accumulate, scale_reg, opacity_reg)
     return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]))

@@ -58,6 +58,16 @@ class FusedAdam:
             for e in entries:
                 ops.adam_step_wrapper(*e)
 
+    def replace_param(self, group_index: int, old: torch.Tensor, new: torch.Tensor, state_fn) -> None:
+        """Swap a parameter tensor for a new one (densification: cat / index_select), carrying its Adam state over:
+        exp_avg / exp_avg_sq -> state_fn(tensor), step_count kept (strategy_utils.cpp:57-129)."""
+        group = self.param_groups[group_index]
+        group["params"] = [new if p is old else p for p in group["params"]]
+        st = self.state.pop(id(old), None)
+        if st is not None:
+            self.state[id(new)] = {"step_count": st["step_count"], "exp_avg": state_fn(st["exp_avg"]).contiguous(),
+                                   "exp_avg_sq": state_fn(st["exp_avg_sq"]).contiguous()}
+
     def zero_grad(self, set_to_none: bool = True) -> None:
         for g in self.param_groups:
             for p in g["params"]:

@@ -17,14 +17,31 @@ from .scenes import Scene
 
 class GutTrainer:
     def __init__(self, scene: Scene, device, iterations: int = 7000, world: int = 1, rank: int = 0,
-                 views_per_rank: int = 1, fused_adam: bool = True, fused_l2: bool = True, loss: str = "mse", lambda_dssim: float = 0.2):
+                 views_per_rank: int = 1, fused_adam: bool = True, fused_l2: bool = True, loss: str = "mse", lambda_dssim: float = 0.2,
+                 strategy: Optional[str] = None, opt_params=None, scene_scale: float = 1.0, seed: int = 0):
+        """strategy: None (fixed set of Gaussians: the benchmark), "mcmc" (strategies.MCMC: relocation + growth + SGLD noise, with
+        the scale / opacity regularisers of trainer.cpp:132-158) or "default" (ADC; needs densification_info, see strategies.py).
+        `seed` seeds the strategy's generator: the same on every rank, so replicas densify identically."""
         self.device, self.world, self.rank, self.views_per_rank = device, world, rank, views_per_rank
         sc = scene.to(device)
         self.scene = sc
         mk = lambda t: t.clone().contiguous().requires_grad_(True)
         self.model = SplatModel(mk(sc.means), mk(sc.sh0), mk(sc.shN), mk(sc.raw_scales), mk(sc.raw_quats), mk(sc.raw_opacities), sc.sh_degree)
-        self.optimizer = FusedAdam(default_param_groups(self.model), fused=fused_adam)
-        self.scheduler = ExponentialLR(self.optimizer, gamma=0.01 ** (1.0 / iterations), param_group_index=0)
+        self.strategy = None
+        self.scale_reg = self.opacity_reg = 0.0
+        if strategy is not None:
+            from . import strategies
+            op = opt_params or strategies.OptimizationParameters(iterations=iterations)
+            gen = torch.Generator(device=device).manual_seed(seed)
+            cls = {"mcmc": strategies.MCMC, "default": strategies.DefaultStrategy}[strategy]
+            self.strategy = cls(self.model, op, scene_scale=scene_scale, generator=gen, on_resize=self._on_resize)
+            self.optimizer, self.scheduler = self.strategy.optimizer, self.strategy.scheduler
+            if strategy == "mcmc":
+                self.scale_reg, self.opacity_reg = op.scale_reg, op.opacity_reg
+            lambda_dssim = op.lambda_dssim
+        else:
+            self.optimizer = FusedAdam(default_param_groups(self.model), fused=fused_adam)
+            self.scheduler = ExponentialLR(self.optimizer, gamma=0.01 ** (1.0 / iterations), param_group_index=0)
         self.bg = torch.zeros(3, device=device)
         # fused_l2: explicit forward/backward through the fused kernels (fused.py) instead of torch autograd over
         # the op-by-op mirror (rasterizer.py); gradients land directly in the flat bucket the all-reduce works on.
@@ -36,6 +53,11 @@ class GutTrainer:
         self.last_n_isects = 0
         self._last_radii = None
         self._last_visible = None
+
+    def _on_resize(self) -> None:
+        """The strategy replaced parameter tensors (densification): the flat gradient bucket has to follow."""
+        if self.bucket is not None:
+            self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2])
 
     @property
     def last_visible(self):
@@ -61,13 +83,20 @@ class GutTrainer:
             self.loss_acc.zero_()
             for k, v in enumerate(views):
                 out = render_and_backward(self.camera(v), self.model, self.bg, targets[k % len(targets)], 1.0 / total_views,
-                                          self.bucket.views, self.loss_acc, accumulate=k > 0, loss=self.loss_kind, lambda_dssim=self.lambda_dssim)
+                                          self.bucket.views, self.loss_acc, accumulate=k > 0, loss=self.loss_kind, lambda_dssim=self.lambda_dssim,
+                                          # regularisers: once per step, and 1/world of them per rank (the all-reduce sums the ranks)
+                                          scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
+                                          opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0)
                 self.last_n_isects, self._last_radii = out.n_isects, out.radii
             self.bucket.all_reduce(skip_deferred=self.iteration <= 1000)  # shN's gradient is not read by Adam until then
             for p, gv in zip(params, self.bucket.views):
                 p.grad = gv
-            self.optimizer.step(self.iteration)
-            self.scheduler.step()
+            if self.strategy is not None:  # trainer.cpp:741-760: post_backward (may replace the parameter tensors) then step
+                self.strategy.post_backward(self.iteration)
+                self.strategy.step(self.iteration)  # FusedAdam skips tensors without a gradient, as the reference's does after add_new_gs
+            else:
+                self.optimizer.step(self.iteration)
+                self.scheduler.step()
             return self.loss_acc  # this rank's share of the loss (a 1-element tensor, read it after a sync)
         for k, v in enumerate(views):
             out = rasterize(self.camera(v), self.model, self.bg, 1.0, False, False, RenderMode.RGB)
@@ -76,6 +105,10 @@ class GutTrainer:
                 loss = photometric_loss(out.image, targets[k % len(targets)], self.lambda_dssim) / total_views
             else:
                 loss = torch.nn.functional.mse_loss(out.image, targets[k % len(targets)]) / total_views
+            if k == 0 and self.scale_reg > 0:
+                loss = loss + self.scale_reg / self.world * self.model.get_scaling().mean()
+            if k == 0 and self.opacity_reg > 0:
+                loss = loss + self.opacity_reg / self.world * self.model.get_opacity().mean()
             loss.backward()
             loss_value = loss.detach()
             self.last_n_isects, self._last_visible = out.n_isects, out.visibility
@@ -85,6 +118,10 @@ class GutTrainer:
             self.bucket.all_reduce(skip_deferred=self.iteration <= 1000)
             for p, gv in zip(params, self.bucket.views):
                 p.grad = gv
+        if self.strategy is not None:
+            self.strategy.post_backward(self.iteration)
+            self.strategy.step(self.iteration)
+            return loss_value
         self.optimizer.step(self.iteration)
         self.optimizer.zero_grad(set_to_none=True)
         self.scheduler.step()
