@@ -102,9 +102,16 @@ LFS_DI void cam_init(CamDev& cam, const lfs_cameras& in, uint32_t cid) {
     for (int i = 0; i < 4; ++i) cam.thin[i] = 0.f;
     const int nr_max = (in.camera_model == LFS_CAMERA_FISHEYE) ? 4 : 6;
     const int rstride = (in.camera_model == LFS_CAMERA_FISHEYE) ? 4 : in.n_radial;
-    if (in.radial_coeffs) for (int i = 0; i < nr_max && i < in.n_radial; ++i) cam.radial[i] = in.radial_coeffs[rstride * cid + i];
+    // (fully unrolled with predicates: a run-time trip count would force the arrays of CamDev into scratch memory)
+    if (in.radial_coeffs) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (i < nr_max && i < in.n_radial) cam.radial[i] = in.radial_coeffs[rstride * cid + i];
+    }
     if (in.tangential_coeffs) { cam.tangential[0] = in.tangential_coeffs[2 * cid]; cam.tangential[1] = in.tangential_coeffs[2 * cid + 1]; }
-    if (in.thin_prism_coeffs) for (int i = 0; i < 4 && i < in.n_thin_prism; ++i) cam.thin[i] = in.thin_prism_coeffs[in.n_thin_prism * cid + i];
+    if (in.thin_prism_coeffs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < in.n_thin_prism) cam.thin[i] = in.thin_prism_coeffs[in.n_thin_prism * cid + i];
+    }
     cam.distorted = (in.camera_model != LFS_CAMERA_FISHEYE) &&
                     (in.radial_coeffs != nullptr || in.tangential_coeffs != nullptr || in.thin_prism_coeffs != nullptr);
     cam_load_pose(in.viewmats0 + 16 * cid, cam.q_start, cam.t_start);
