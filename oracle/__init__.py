@@ -295,3 +295,48 @@ def ref_fully_fused_projection(means, quats, scales, viewmat, K, width, height, 
     ref_lib().ref_fully_fused_projection(C.c_int64(N), _p(m), _p(q), _p(s), _p(v), _p(K), C.c_int(width), C.c_int(height),
                                          C.c_float(eps2d), C.c_float(near_plane), C.c_float(far_plane), _p(radii), _p(m2), _p(d), _p(c))
     return radii, m2, d, c
+
+
+# ---- fastgs (EWA) rasterizer (oracle_fastgs.hpp) --------------------------------
+def _fg_args(dt, means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c, cam_pos, active_sh_bases, W, H, fx, fy, cx, cy, near, far):
+    cf = C.c_float if dt == np.float32 else C.c_double
+    arrs = [_c(x, dt) for x in (means, scales_raw, rot_raw, np.asarray(opac_raw).reshape(-1), sh0, sh_rest, np.asarray(w2c).reshape(4, 4), np.asarray(cam_pos).reshape(3))]
+    N = arrs[0].shape[0]
+    total_rest = arrs[5].shape[1] if arrs[5].ndim == 3 else 0
+    return arrs, N, total_rest, [C.c_int64(N)] + [_p(a) for a in arrs] + [C.c_int(active_sh_bases), C.c_int(total_rest), C.c_int(W), C.c_int(H),
+                                                                           cf(fx), cf(fy), cf(cx), cf(cy), cf(near), cf(far)]
+
+
+def fastgs_forward(means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c, cam_pos, active_sh_bases, W, H, fx, fy, cx, cy,
+                   near=0.01, far=1e10, dtype=np.float32):
+    """-> dict(image [3,H,W], alpha [H,W], n_contrib [H,W], mean2d, conic_opacity, color, n_touched, bounds, offsets, ids).
+    The forward keeps its state inside the library for fastgs_backward (same dtype, called right after)."""
+    dt = np.dtype(dtype).type
+    sfx = "f32" if dt == np.float32 else "f64"
+    arrs, N, total_rest, args = _fg_args(dt, means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c, cam_pos, active_sh_bases, W, H, fx, fy, cx, cy, near, far)
+    out = dict(image=np.zeros((3, H, W), dt), alpha=np.zeros((H, W), dt), n_contrib=np.zeros((H, W), np.int32), mean2d=np.zeros((N, 2), dt),
+               conic_opacity=np.zeros((N, 4), dt), color=np.zeros((N, 3), dt), n_touched=np.zeros(N, np.int32), bounds=np.zeros((N, 4), np.int32))
+    f = getattr(lib(), f"orc_fastgs_forward_{sfx}")
+    f.restype = C.c_int64
+    n_inst = f(*args, _p(out["image"]), _p(out["alpha"]), _p(out["n_contrib"]), _p(out["mean2d"]), _p(out["conic_opacity"]), _p(out["color"]),
+               _p(out["n_touched"]), _p(out["bounds"]))
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    out["offsets"], out["ids"] = np.zeros(T + 1, np.int32), np.zeros(max(n_inst, 1), np.int32)
+    getattr(lib(), f"orc_fastgs_lists_{sfx}")(_p(out["offsets"]), _p(out["ids"]))
+    out["ids"] = out["ids"][:n_inst]
+    out["_keep"] = arrs
+    return out
+
+
+def fastgs_backward(fwd, means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c, cam_pos, active_sh_bases, W, H, fx, fy, cx, cy,
+                    g_image, g_alpha, near=0.01, far=1e10, dtype=np.float32, densification_info=None):
+    """-> (g_means, g_scales_raw, g_rot_raw, g_opac_raw, g_sh0, g_sh_rest, densification_info [2,N])."""
+    dt = np.dtype(dtype).type
+    sfx = "f32" if dt == np.float32 else "f64"
+    arrs, N, total_rest, args = _fg_args(dt, means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c, cam_pos, active_sh_bases, W, H, fx, fy, cx, cy, near, far)
+    gi, ga = _c(g_image, dt), _c(np.asarray(g_alpha).reshape(H, W), dt)
+    img, al, nc = _c(fwd["image"], dt), _c(fwd["alpha"], dt), _c(fwd["n_contrib"], np.int32)
+    g = [np.zeros((N, 3), dt), np.zeros((N, 3), dt), np.zeros((N, 4), dt), np.zeros(N, dt), np.zeros((N, 1, 3), dt), np.zeros((N, max(total_rest, 0), 3), dt)]
+    dens = np.zeros((2, N), dt) if densification_info is None else _c(densification_info, dt).copy()
+    getattr(lib(), f"orc_fastgs_backward_{sfx}")(*args, _p(img), _p(al), _p(nc), _p(gi), _p(ga), *[_p(x) for x in g], _p(dens))
+    return (*g, dens)

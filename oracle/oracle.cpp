@@ -2,6 +2,7 @@
 // Built by oracle/Makefile into oracle/liboracle.so. Only tests/,
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
 #include "oracle_ops.hpp"
+#include "oracle_fastgs.hpp"
 
 using namespace orc;
 
@@ -101,4 +102,42 @@ ORC_API void orc_intersect_tile_emit(uint32_t C, uint32_t N, const float* means2
 ORC_API void orc_intersect_offset(int64_t n_isects, const int64_t* isect_ids, uint32_t C, uint32_t tile_width, uint32_t tile_height, int32_t* offsets) {
     intersect_offset(n_isects, isect_ids, C, tile_width, tile_height, offsets);
 }
-ORC_API int orc_version() { return 1; }
+// ---- fastgs (EWA) rasterizer: forward keeps its per-primitive state and tile lists for the matching backward call ----
+template <class T> struct FgState { std::vector<fg::Prim<T>> P; fg::Lists L; };
+template <class T> static FgState<T>& fg_state() { static FgState<T> s; return s; }
+#define DEFINE_FASTGS_API(SFX, T)                                                                                      \
+ORC_API int64_t orc_fastgs_forward_##SFX(int64_t N, const T* means, const T* scales_raw, const T* rot_raw, const T* opac_raw,    \
+    const T* sh0, const T* sh_rest, const T* w2c, const T* cam_pos, int active_sh_bases, int total_rest, int W, int H,  \
+    T fx, T fy, T cx, T cy, T near_, T far_, T* image, T* alpha, int32_t* n_contrib,                                   \
+    T* mean2d, T* conic_opacity, T* color, int32_t* n_touched, int32_t* bounds) {                                       \
+    fg::Args<T> a{N, means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c, cam_pos, active_sh_bases, total_rest, W, H, fx, fy, cx, cy, near_, far_}; \
+    FgState<T>& st = fg_state<T>();                                                                                     \
+    fg::preprocess<T>(a, st.P);                                                                                         \
+    fg::build_lists<T>(a, st.P, st.L);                                                                                  \
+    fg::blend<T>(a, st.P, st.L, image, alpha, n_contrib);                                                               \
+    for (int64_t i = 0; i < N; ++i) {                                                                                   \
+        const fg::Prim<T>& p = st.P[i];                                                                                 \
+        mean2d[2 * i] = p.mx; mean2d[2 * i + 1] = p.my;                                                                 \
+        conic_opacity[4 * i] = p.ca; conic_opacity[4 * i + 1] = p.cb; conic_opacity[4 * i + 2] = p.cc; conic_opacity[4 * i + 3] = p.opacity; \
+        color[3 * i] = p.col[0]; color[3 * i + 1] = p.col[1]; color[3 * i + 2] = p.col[2];                              \
+        n_touched[i] = int32_t(p.n_touched);                                                                            \
+        bounds[4 * i] = int32_t(p.x0); bounds[4 * i + 1] = int32_t(p.x1); bounds[4 * i + 2] = int32_t(p.y0); bounds[4 * i + 3] = int32_t(p.y1); \
+    }                                                                                                                   \
+    return int64_t(st.L.ids.size());                                                                                    \
+}                                                                                                                       \
+ORC_API void orc_fastgs_lists_##SFX(int32_t* offsets, int32_t* ids) {                                                   \
+    FgState<T>& st = fg_state<T>();                                                                                     \
+    std::copy(st.L.offsets.begin(), st.L.offsets.end(), offsets); std::copy(st.L.ids.begin(), st.L.ids.end(), ids);     \
+}                                                                                                                       \
+ORC_API void orc_fastgs_backward_##SFX(int64_t N, const T* means, const T* scales_raw, const T* rot_raw, const T* opac_raw,       \
+    const T* sh0, const T* sh_rest, const T* w2c, const T* cam_pos, int active_sh_bases, int total_rest, int W, int H,  \
+    T fx, T fy, T cx, T cy, T near_, T far_, const T* image, const T* alpha, const int32_t* n_contrib,                  \
+    const T* g_image, const T* g_alpha, T* g_means, T* g_scales_raw, T* g_rot_raw, T* g_opac_raw, T* g_sh0, T* g_sh_rest, T* densification_info) { \
+    fg::Args<T> a{N, means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c, cam_pos, active_sh_bases, total_rest, W, H, fx, fy, cx, cy, near_, far_}; \
+    FgState<T>& st = fg_state<T>();                                                                                     \
+    fg::backward<T>(a, st.P, st.L, image, alpha, n_contrib, g_image, g_alpha, g_means, g_scales_raw, g_rot_raw, g_opac_raw, g_sh0, g_sh_rest, densification_info); \
+}
+DEFINE_FASTGS_API(f32, float)
+DEFINE_FASTGS_API(f64, double)
+
+ORC_API int orc_version() { return 2; }
