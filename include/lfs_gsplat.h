@@ -200,6 +200,36 @@ LFS_API int lfs_activations_bwd(uint32_t N, const float* raw_quats, const float*
 LFS_API int lfs_mse_loss_fwd_bwd(uint32_t H, uint32_t W, const float* render_hwc, const float* target_chw, float weight,
                                  float* v_render_hwc, float* loss, lfs_stream_t stream);
 
+/* ---- "next" row 1 of SURVEY.md §8f: the reference's default training rasterizer (fastgs, EWA splatting).
+ *      Replaces fast_gs::rasterization::forward_wrapper / backward_wrapper (fastgs/rasterization/include/rasterization_api.h:27-75,
+ *      src/rasterization_api.cu, forward.cu, backward.cu, kernels_{forward,backward}.cuh). Inputs are the RAW parameters
+ *      (log-scales, un-normalised quaternions wxyz, opacity logits, sh0 [N,1,3], sh_rest [N,total_bases_sh_rest,3]); w2c is a
+ *      row-major [4,4] (rows 0-2 used) and cam_position [3], both on the device. image [3,H,W], alpha [1,H,W] (CHW, no background).
+ *      The reference's four opaque buffer tensors become two caller-owned workspaces that must survive until the backward:
+ *        1) lfs_fastgs_preprocess   : per-primitive stage + per-tile counts; *n_instances (device int64) = list length
+ *        2) (host reads n_instances: the reference syncs at the same place, forward.cu:114-117)
+ *        3) lfs_fastgs_render       : instance lists (scatter + per-tile depth sort), per-cell culling, blending
+ *        4) lfs_fastgs_backward     : blending backward + per-primitive backward; gradients FULLY written; densification_info
+ *                                     [2,N] (or NULL) is accumulated into (visibility count, screen-space gradient norm). */
+LFS_API size_t lfs_fastgs_primitive_workspace_bytes(uint32_t N, uint32_t width, uint32_t height);
+LFS_API size_t lfs_fastgs_instance_workspace_bytes(uint32_t width, uint32_t height, int64_t n_instances);
+LFS_API int lfs_fastgs_preprocess(
+    uint32_t N, const float* means, const float* scales_raw, const float* rotations_raw, const float* opacities_raw,
+    const float* sh_coefficients_0, const float* sh_coefficients_rest, uint32_t total_bases_sh_rest, const float* w2c, const float* cam_position,
+    uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, float near_plane, float far_plane,
+    int64_t* n_instances, void* primitive_workspace, size_t primitive_workspace_bytes, lfs_stream_t stream);
+LFS_API int lfs_fastgs_render(
+    uint32_t N, uint32_t width, uint32_t height, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
+    void* instance_workspace, size_t instance_workspace_bytes, float* image, float* alpha, lfs_stream_t stream);
+LFS_API int lfs_fastgs_backward(
+    uint32_t N, const float* means, const float* scales_raw, const float* rotations_raw, const float* sh_coefficients_rest, uint32_t total_bases_sh_rest,
+    const float* w2c, const float* cam_position, uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy, float cx, float cy,
+    float near_plane, float far_plane, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
+    void* instance_workspace, size_t instance_workspace_bytes, const float* grad_image, const float* grad_alpha, const float* alpha,
+    float* densification_info, float* grad_means, float* grad_scales_raw, float* grad_rotations_raw, float* grad_opacities_raw,
+    float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest, lfs_stream_t stream);
+LFS_API void lfs_fastgs_set_debug_flags(uint32_t flags); /* bit 0: no per-cell culling (bit-identity test) */
+
 /* ---- "next" row 2 of SURVEY.md §8f: fused SSIM (fusedssim / fusedssim_backward, include/kernels/ssim.cuh:11-30,
  *      src/training/kernels/ssim.cu:64-510) and the trainer's photometric loss (trainer.cpp:122-125).
  *      img1 / img2 / maps [B,CH,H,W]; 11-tap Gaussian window, zero padding. dm_* may all be NULL (train == false).

@@ -30,12 +30,14 @@ SOURCES = {
     "adam.hip": ["-ffp-contract=off"],
     "l2_fused.hip": ["-ffp-contract=off"],
     "ssim.hip": ["-ffp-contract=off"],
+    "fastgs_prep.hip": ["-ffp-contract=off"],
+    "fastgs_blend.hip": ["-fno-slp-vectorize"],
     "prof.hip": [],
     # no SLP packing: v_pk_* operand pairing forces SGPR shuffles right after the scalar record
     # load and defeats the software prefetch (measured on the ISA); plain v_fma with SGPR operands
     "raster.hip": ["-fno-slp-vectorize"],
 }
-HEADERS = ["lfs_math.cuh", "lfs_camera.cuh", "lfs_prof.h", os.path.join("..", "..", "include", "lfs_gsplat.h")]
+HEADERS = ["lfs_math.cuh", "lfs_camera.cuh", "lfs_prof.h", "lfs_raster_common.cuh", "lfs_tilelists.cuh", "lfs_fastgs.cuh", os.path.join("..", "..", "include", "lfs_gsplat.h")]
 
 
 def _stale(obj: str, src: str) -> bool:

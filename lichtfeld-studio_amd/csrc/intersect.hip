@@ -21,6 +21,7 @@
 // the scan, so intersect_offset is free on this path.
 #include "lfs_math.cuh"
 #include "lfs_prof.h"
+#include "lfs_tilelists.cuh"
 #include "../../include/lfs_gsplat.h"
 
 namespace lfs {
@@ -94,38 +95,6 @@ __global__ void __launch_bounds__(1024) isect_count_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// single-workgroup exclusive scan of totals[T] -> offsets[T+1] (int32), n_isects (int64)
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) tile_scan_kernel(
-    const uint32_t T, const uint32_t* __restrict__ totals, int32_t* __restrict__ offsets, int64_t* __restrict__ n_isects) {
-    __shared__ uint64_t wave_sums[16];
-    __shared__ uint64_t carry_s;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < T; base += 1024) {
-        const uint32_t t = base + threadIdx.x;
-        const uint64_t v = t < T ? totals[t] : 0u;
-        uint64_t s = v; // inclusive wave scan
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t o = __shfl_up(s, d, 64);
-            if (int(lane) >= d) s += o;
-        }
-        if (lane == 63) wave_sums[wave] = s;
-        __syncthreads();
-        uint64_t wave_off = 0;
-        for (uint32_t w = 0; w < wave; ++w) wave_off += wave_sums[w];
-        const uint64_t carry = carry_s;
-        if (t < T) offsets[t] = int32_t(carry + wave_off + s - v);
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + wave_off + s;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { offsets[T] = int32_t(carry_s); *n_isects = int64_t(carry_s); }
-}
-
-// ---------------------------------------------------------------------------
 // scatter: write (key, flatten id) of every intersection into its tile bucket
 // ---------------------------------------------------------------------------
 template <bool LDS_HIST>
@@ -178,183 +147,6 @@ __global__ void __launch_bounds__(1024) isect_scatter_kernel(
                 // bytes doubled the number of scattered partial-line writes, the cost of this kernel: WRITE_SIZE 297 MB for 53 MB.)
                 isect_ids[pos] = int64_t((dbits << 32) | uint64_t(uint32_t(idx)));
             }
-    }
-}
-
-// Ascending bitonic network over n_pad (power of two) 64-bit keys in LDS; all THREADS threads of the workgroup call it.
-// Barrier elision: pair index i = it * THREADS + wave * 64 + lane. For a flip with k <= 128 and for half-cleaners
-// with j <= 64 the 64 pairs of a wave live inside ONE aligned block of 128 keys, the same block in every such stage,
-// so consecutive wave-local stages only need the in-order LDS pipeline of that wave. A workgroup barrier is needed
-// only around the stages that cross 128-key blocks (9 of the 55 stages at n_pad = 1024).
-template <int THREADS>
-LFS_DI void bitonic_sort_lds(uint64_t* __restrict__ keys, const uint32_t n_pad) {
-    bool prev_cross = false;
-    for (uint32_t k = 2; k <= n_pad; k <<= 1) {
-        const bool flip_cross = k > 128;
-        if (flip_cross || prev_cross) __syncthreads();
-        prev_cross = flip_cross;
-        for (uint32_t i = threadIdx.x; i < n_pad / 2; i += THREADS) { // flip step
-            const uint32_t blk = i / (k >> 1), off = i % (k >> 1);
-            const uint32_t a = blk * k + off, b = blk * k + (k - 1 - off);
-            const uint64_t ka = keys[a], kb = keys[b];
-            if (ka > kb) { keys[a] = kb; keys[b] = ka; }
-        }
-        for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
-            const bool cross = j >= 128;
-            if (cross || prev_cross) __syncthreads();
-            prev_cross = cross;
-            for (uint32_t i = threadIdx.x; i < n_pad / 2; i += THREADS) {
-                const uint32_t a = ((i / j) * (j << 1)) + (i % j), b = a + j;
-                const uint64_t ka = keys[a], kb = keys[b];
-                if (ka > kb) { keys[a] = kb; keys[b] = ka; }
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// Per-tile sort, fast path: the keys of one tile are spread over a depth range, so ONE counting pass on a monotone
-// 8-bit quantisation of the (unsigned) depth bits leaves 256 bins of ~n/256 keys, each finished by a single-thread
-// rank count: ~10 LDS operations per key instead of the ~110 of the bitonic network (which was LDS-pipe bound:
-// 0.17 ms at 4.4 M intersections). Exact: the quantisation is monotone in the key, ties fall into one bin, and a bin
-// with more than BIN_LIMIT keys (degenerate depth distributions) sends the tile through the bitonic network instead.
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
-    const uint32_t n_min, const uint32_t n_max, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets,
-    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    __shared__ uint32_t s_hist[256], s_off[257], s_minmax[2], s_big;
-    constexpr uint32_t BIN_LIMIT = 32;
-    const uint32_t t = blockIdx.x;
-    const uint32_t start = uint32_t(offsets[t]);
-    const uint32_t n = uint32_t(offsets[t + 1]) - start;
-    if (n < n_min || n > n_max) return;
-    uint32_t n_pad = 2; while (n_pad < n) n_pad <<= 1;
-    uint64_t* A = lds64;          // [n_pad] input copy
-    uint64_t* B = lds64 + n_pad;  // [n_pad] binned / sorted
-    const uint64_t hi_bits = ((uint64_t(t / n_tiles) << tile_n_bits) | uint64_t(t % n_tiles)) << 32;
-    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) { s_minmax[0] = 0xFFFFFFFFu; s_minmax[1] = 0u; s_big = 0u; }
-    __syncthreads();
-    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-        const uint64_t k = uint64_t(isect_ids[start + i]);
-        A[i] = k;
-        const uint32_t d = uint32_t(k >> 32);
-        lo = min(lo, d); hi = max(hi, d);
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { lo = min(lo, uint32_t(__shfl_xor(int(lo), m, 64))); hi = max(hi, uint32_t(__shfl_xor(int(hi), m, 64))); }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&s_minmax[0], lo); atomicMax(&s_minmax[1], hi); }
-    __syncthreads();
-    const uint32_t dmin = s_minmax[0];
-    const float scale = 256.f / (float(s_minmax[1] - dmin) + 1.f); // monotone map of the unsigned depth bits onto [0, 256)
-    auto bin_of = [&](uint64_t k) { return min(255u, uint32_t(float(uint32_t(k >> 32) - dmin) * scale)); };
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) atomicAdd(&s_hist[bin_of(A[i])], 1u);
-    __syncthreads();
-    if (threadIdx.x < 64) { // exclusive scan of the 256 counts by one wave (4 per lane)
-        const uint32_t l = threadIdx.x;
-        const uint32_t c0 = s_hist[4 * l], c1 = s_hist[4 * l + 1], c2 = s_hist[4 * l + 2], c3 = s_hist[4 * l + 3];
-        const uint32_t tot = c0 + c1 + c2 + c3;
-        uint32_t inc = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inc), d, 64)); if (int(l) >= d) inc += o; }
-        const uint32_t ex = inc - tot;
-        s_off[4 * l] = ex; s_off[4 * l + 1] = ex + c0; s_off[4 * l + 2] = ex + c0 + c1; s_off[4 * l + 3] = ex + c0 + c1 + c2;
-        if (l == 63) s_off[256] = inc;
-        if (max(max(c0, c1), max(c2, c3)) > BIN_LIMIT) atomicOr(&s_big, 1u);
-        s_hist[4 * l] = 0u; s_hist[4 * l + 1] = 0u; s_hist[4 * l + 2] = 0u; s_hist[4 * l + 3] = 0u; // reused as fill cursors
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-        const uint64_t k = A[i];
-        const uint32_t b = bin_of(k);
-        B[s_off[b] + atomicAdd(&s_hist[b], 1u)] = k;
-    }
-    for (uint32_t i = n + threadIdx.x; i < n_pad; i += THREADS) B[i] = ~0ull;
-    __syncthreads();
-    if (s_big) {
-        bitonic_sort_lds<THREADS>(B, n_pad);
-        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-            const uint64_t k = B[i];
-            isect_ids[start + i] = int64_t(hi_bits | (k >> 32));
-            flatten_ids[start + i] = int32_t(uint32_t(k));
-        }
-        return;
-    }
-    // rank inside the bin = number of smaller keys in it (keys are unique: a flatten id occurs once per tile); every key
-    // goes straight to its final global position - no serial insertion chain, no further barrier
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-        const uint64_t k = B[i];
-        const uint32_t b = bin_of(k);
-        const uint32_t o = s_off[b], m = s_off[b + 1] - o;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < m; ++j) rank += B[o + j] < k ? 1u : 0u;
-        isect_ids[start + o + rank] = int64_t(hi_bits | (k >> 32));
-        flatten_ids[start + o + rank] = int32_t(uint32_t(k));
-    }
-}
-
-// ---------------------------------------------------------------------------
-// per-tile sort. Ascending-comparator bitonic network ("flip" formulation: the
-// first step of each merge mirrors inside the block, the rest are half-cleaners),
-// so +inf padding above n never moves below n.
-// ---------------------------------------------------------------------------
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS) tile_sort_lds_kernel(
-    const uint32_t n_min, const uint32_t n_max, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets,
-    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
-    const uint32_t t = blockIdx.x;
-    const uint32_t start = uint32_t(offsets[t]);
-    const uint32_t n = uint32_t(offsets[t + 1]) - start;
-    if (n < n_min || n > n_max) return;
-    uint32_t n_pad = 2; while (n_pad < n) n_pad <<= 1;
-    // camera | tile: the same for the whole bucket (the scatter kernel left (depth << 32 | flatten id) in isect_ids)
-    const uint64_t hi_bits = ((uint64_t(t / n_tiles) << tile_n_bits) | uint64_t(t % n_tiles)) << 32;
-    for (uint32_t i = threadIdx.x; i < n_pad; i += THREADS) keys[i] = i < n ? uint64_t(isect_ids[start + i]) : ~0ull;
-    __syncthreads();
-    bitonic_sort_lds<THREADS>(keys, n_pad);
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-        const uint64_t k = keys[i];
-        isect_ids[start + i] = int64_t(hi_bits | (k >> 32));
-        flatten_ids[start + i] = int32_t(uint32_t(k));
-    }
-}
-
-// buckets too large for LDS: same network directly on the combined keys in global memory, then the same conversion
-__global__ void __launch_bounds__(1024) tile_sort_global_kernel(
-    const uint32_t n_min, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets, int64_t* isect_ids, int32_t* flatten_ids) {
-    const uint32_t t = blockIdx.x;
-    const uint32_t start = uint32_t(offsets[t]);
-    const uint32_t n = uint32_t(offsets[t + 1]) - start;
-    if (n < n_min) return;
-    uint32_t n_pad = 2; while (n_pad < n) n_pad <<= 1;
-    uint64_t* K = reinterpret_cast<uint64_t*>(isect_ids + start);
-    auto cas = [&](uint32_t a, uint32_t b) {
-        if (b >= n) return; // virtual +inf padding
-        const uint64_t ka = K[a], kb = K[b];
-        if (ka > kb) { K[a] = kb; K[b] = ka; }
-    };
-    for (uint32_t k = 2; k <= n_pad; k <<= 1) {
-        for (uint32_t i = threadIdx.x; i < n_pad / 2; i += blockDim.x) {
-            const uint32_t blk = i / (k >> 1), off = i % (k >> 1);
-            cas(blk * k + off, blk * k + (k - 1 - off));
-        }
-        __syncthreads();
-        for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < n_pad / 2; i += blockDim.x) {
-                const uint32_t a = ((i / j) * (j << 1)) + (i % j);
-                cas(a, a + j);
-            }
-            __syncthreads();
-        }
-    }
-    const uint64_t hi_bits = ((uint64_t(t / n_tiles) << tile_n_bits) | uint64_t(t % n_tiles)) << 32;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint64_t k = K[i];
-        flatten_ids[start + i] = int32_t(uint32_t(k));
-        K[i] = hi_bits | (k >> 32);
     }
 }
 

@@ -27,12 +27,9 @@
 //             mean vjp (done per (pixel, Gaussian) in the reference).
 #include "lfs_camera.cuh"
 #include "lfs_prof.h"
+#include "lfs_raster_common.cuh"
 
 namespace lfs {
-
-struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2, r3; };
-
-constexpr int ACC_STRIDE = 16; // A(9) | G(3) | opacity | rgb(3)
 
 static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 // Per-Gaussian culling record (camera space, divided by depth, r^2 folded in): see raster_pack_kernel.
@@ -141,51 +138,6 @@ __global__ void __launch_bounds__(256) raster_pack_kernel(
         }
     }
     cull[idx] = cr;
-}
-
-// ---------------------------------------------------------------------------
-// tile / cell bookkeeping shared by cull, fwd and bwd
-// ---------------------------------------------------------------------------
-struct CellCtx {
-    uint32_t cid, tile_global, wl, i, j; // wl = 8x8 cell index inside the tile (wave-uniform)
-    bool in_grid;
-};
-// Workgroup -> (tile, cell). Consecutive workgroup ids go round-robin over the
-// 8 XCDs; remap so that each XCD works on one contiguous band of tiles and the
-// records of neighbouring tiles meet in the same L2.
-LFS_DI CellCtx cell_ctx(uint32_t n_tiles, uint32_t total_tiles, uint32_t tw, uint32_t tile_size, uint32_t blocks_per_tile, uint32_t waves_per_block) {
-    CellCtx c;
-    const uint32_t nb = total_tiles * blocks_per_tile;
-    const uint32_t per_xcd = (nb + 7) / 8;
-    const uint32_t b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    c.in_grid = b < nb && (blockIdx.x >> 3) < per_xcd;
-    const uint32_t tg = b / blocks_per_tile, bt = b % blocks_per_tile;
-    c.tile_global = tg;
-    c.cid = tg / n_tiles;
-    const uint32_t tile = tg % n_tiles;
-    const uint32_t ty = tile / tw, tx = tile % tw;
-    const uint32_t wps = tile_size >> 3; // 8x8 cells per tile side
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    c.wl = bt * waves_per_block + wave;
-    const uint32_t lane = threadIdx.x & 63;
-    c.i = ty * tile_size + (c.wl / wps) * 8 + (lane >> 3);
-    c.j = tx * tile_size + (c.wl % wps) * 8 + (lane & 7);
-    return c;
-}
-
-LFS_DI float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-LFS_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-
-LFS_DI float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
-LFS_DI float wave_min(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
-    return v;
-}
-LFS_DI float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
 }
 
 // ---------------------------------------------------------------------------
@@ -299,16 +251,6 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
     if (lane == 0) cell_count[cell] = count;
 }
 
-// One Gaussian against one ray, shared by fwd and bwd so that both see bit-identical alphas. Every sum of
-// products is an explicit fma chain: with -ffp-contract=fast alone the compiler is free to pick WHICH product
-// of a*b + c*d it fuses, and it picks differently in different inlined copies - results would depend on the
-// position of a Gaussian in the list (measured: 1 ulp), and the culling on/off bit-identity test would fail.
-LFS_DI float fma3(float ax, float bx, float ay, float by, float az, float bz) {
-    return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
-}
-LFS_DI f3 cross_fma(const f3& a, const f3& b) {
-    return {__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)), __builtin_fmaf(a.x, b.y, -(b.x * a.y))};
-}
 // Ray modes (template parameter of fwd / bwd):
 //   0 rolling shutter : world-space ray (ro, rd) per pixel, record = {M, mu}
 //   1 global shutter  : camera-space direction d (any camera model), record = {M Rinv, M (o - mu)}
@@ -340,38 +282,6 @@ LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& d, RayEval& e)
     e.w = {__builtin_fmaf(-e.t, q.x, gro.x), __builtin_fmaf(-e.t, q.y, gro.y), __builtin_fmaf(-e.t, q.z, gro.z)};
     // exp(-0.5 |w|^2) as one exp2: -0.5 * log2(e) = -0.72134752
     e.vis = __builtin_amdgcn_exp2f(-0.72134752044448170f * fma3(e.w.x, e.w.x, e.w.y, e.w.y, e.w.z, e.w.z));
-}
-
-// Walk a cell list with the records arriving through the SCALAR unit: two groups of two record
-// buffers in SGPRs. Scalar loads return out of order, so every wait is s_waitcnt lgkmcnt(0): the loop
-// waits for group B right BEFORE refilling group A (and vice versa), which gives each record load two full
-// evaluations (~300 cycles) in flight and never copies a buffer. Entries are visited at positions
-// first, first+step, ... (n of them); eval(rec, entry) per entry; alive() is polled every two entries.
-template <int STEP, class Eval, class Alive>
-LFS_DI void walk_cell_list(const int2* __restrict__ cl, const GaussRec* __restrict__ recs, const int32_t first, const int32_t n,
-                           Eval&& eval, Alive&& alive) {
-    if (n <= 0) return;
-    const int32_t last = n - 1;
-    auto ent = [&](int32_t k) { return cl[first + STEP * min(k, last)]; };
-    int2 eA0 = ent(0), eA1 = ent(1), eB0 = ent(2), eB1 = ent(3);
-    int2 nA0 = ent(4), nA1 = ent(5), nB0 = make_int2(0, 0), nB1 = make_int2(0, 0);
-    GaussRec A0 = recs[eA0.x], A1 = recs[eA1.x], B0 = recs[eB0.x], B1 = recs[eB1.x];
-    for (int32_t k = 0; k < n; k += 4) {
-        if (!alive()) break;
-        eval(A0, eA0);
-        if (k + 1 < n) eval(A1, eA1);
-        asm volatile("; group B must have landed before group A is refilled" ::"s"(B0.r0.x), "s"(B1.r0.x));
-        eA0 = nA0; eA1 = nA1;
-        A0 = recs[eA0.x]; A1 = recs[eA1.x];
-        nB0 = ent(k + 6); nB1 = ent(k + 7);
-        if (k + 2 >= n || !alive()) break;
-        eval(B0, eB0);
-        if (k + 3 < n) eval(B1, eB1);
-        asm volatile("; group A must have landed before group B is refilled" ::"s"(A0.r0.x), "s"(A1.r0.x));
-        eB0 = nB0; eB1 = nB1;
-        B0 = recs[eB0.x]; B1 = recs[eB1.x];
-        nA0 = ent(k + 8); nA1 = ent(k + 9);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -475,41 +385,6 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-template <int CTRL>
-LFS_DI float dpp_mov(float v) { // row-local lane permutation (DPP): 0xB1 = lane^1, 0x4E = lane^2, 0x124 / 0x128 = rotate by 4 / 8
-    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
-}
-
-// Sum 16 per-lane values over the 64 lanes and add the 16 totals to dst[0..15] with one 16-lane atomic instruction.
-// Every step but the last two HALVES the number of live values while folding lanes: v_permlane32_swap (lane halves),
-// v_permlane16_swap (row pairs), then lane^1 and lane^2 inside the quads (select + DPP add); two row rotations finish.
-// 35 VALU for 16 sums (a butterfly per value would be 16 x 6).
-LFS_DI void wave_sum16_atomic(const float (&v)[16], float* __restrict__ dst, const uint32_t lane) {
-    float w[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 8]), false, false);
-        w[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    float u[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[j]), __float_as_uint(w[j + 4]), false, false);
-        u[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    // row r (16 lanes) now holds partial sums of v[4r .. 4r+3] in u[0..3]
-    const bool b0 = lane & 1, b1 = lane & 2;
-    // lane^1: even lanes keep (u0, u1), odd lanes keep (u2, u3)
-    const float s0 = (b0 ? u[2] : u[0]) + dpp_mov<0xB1>(b0 ? u[0] : u[2]);
-    const float s1 = (b0 ? u[3] : u[1]) + dpp_mov<0xB1>(b0 ? u[1] : u[3]);
-    // lane^2: bit1 == 0 keeps the first of the pair, bit1 == 1 the second
-    float t = (b1 ? s1 : s0) + dpp_mov<0x4E>(b1 ? s0 : s1);
-    t += dpp_mov<0x124>(t);
-    t += dpp_mov<0x128>(t);
-    // lane L holds the total of v[4 * (L >> 4) + 2 * (L & 1) + ((L >> 1) & 1)]
-    if ((lane & 12) == 0) unsafeAtomicAdd(dst + 4 * (lane >> 4) + 2 * (lane & 1) + ((lane >> 1) & 1), t);
-}
-
 template <int CDIM, int MODE>
 __global__ void __launch_bounds__(256) raster_bwd_kernel(
     const uint32_t C, const uint32_t N, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,

@@ -1,0 +1,106 @@
+"""GPU parity: the fastgs (EWA) rasterizer — SURVEY.md §8f row 1 — against the CPU oracle (oracle/oracle_fastgs.hpp, pinned to the
+reference's torch_impl where that exists, see tests/test_oracle_fastgs.py).
+Tolerances as for the 3DGUT rasterizer (fast-math exp, alpha-threshold flips): forward mean |diff| <= 2e-6 and <= 0.1 % of the
+pixels beyond 1/255 + 1e-4; instance count identical; gradients: relative L2 vs the fp64 oracle <= 1e-2 in total and <= 5e-4 after
+setting aside the 0.5 % worst rows (threshold flips hit single (pixel, primitive) pairs)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import n, rel_l2, rel_l2_rows, t
+from test_oracle_fastgs import _scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _settings(sc):
+    from lichtfeld_studio_amd.fastgs import FastGSSettings
+    return FastGSSettings(t(sc["cam_pos"]), sc["active_sh_bases"], sc["W"], sc["H"], sc["fx"], sc["fy"], sc["cx"], sc["cy"], 0.01, 1e10)
+
+
+def _dev_args(sc):
+    return [t(sc[k]) for k in ("means", "scales_raw", "rot_raw", "opac_raw", "sh0", "sh_rest", "w2c")]
+
+
+def _oracle_fwd(o, sc, dtype=np.float32):
+    return o.fastgs_forward(sc["means"], sc["scales_raw"], sc["rot_raw"], sc["opac_raw"], sc["sh0"], sc["sh_rest"], sc["w2c"], sc["cam_pos"],
+                            sc["active_sh_bases"], sc["W"], sc["H"], sc["fx"], sc["fy"], sc["cx"], sc["cy"], dtype=dtype)
+
+
+@pytest.mark.parametrize("cfg", [dict(N=3000, W=160, H=112, seed=0, deg=3), dict(N=2000, W=203, H=117, seed=1, deg=0),
+                                 dict(N=1500, W=64, H=64, seed=2, deg=1, spread=0.4), dict(N=4000, W=256, H=256, seed=3, deg=2, spread=2.5)])
+def test_fastgs_forward_backward_match_oracle(lfs, oracle_mod, cfg):
+    from lichtfeld_studio_amd import fastgs
+    sc = _scene(**cfg)
+    s = _settings(sc)
+    image, alpha, pws, iws, n_inst = fastgs.forward_wrapper(*_dev_args(sc), s)
+    f32 = _oracle_fwd(oracle_mod, sc, np.float32)
+    assert n_inst == len(f32["ids"])
+    d = np.abs(n(image) - f32["image"])
+    assert d.mean() < 2e-6 and (d > 1 / 255 + 1e-4).mean() < 1e-3, (d.mean(), d.max())
+    da = np.abs(n(alpha)[0] - f32["alpha"])
+    assert da.mean() < 2e-6 and (da > 1 / 255 + 1e-4).mean() < 1e-3
+    assert f32["alpha"].max() > 0.3, "degenerate scene"
+    # backward: both sides get the oracle's forward state (fp64 oracle = truth)
+    rng = np.random.default_rng(5)
+    gi, ga = rng.standard_normal((3, sc["H"], sc["W"])).astype(np.float32), rng.standard_normal((1, sc["H"], sc["W"])).astype(np.float32)
+    dens = torch.zeros(2, cfg["N"], device=DEV)
+    g = fastgs.backward_wrapper(dens, t(gi), t(ga), image, alpha, *[t(sc[k]) for k in ("means", "scales_raw", "rot_raw", "sh_rest")], pws, iws, t(sc["w2c"]), s, n_inst)
+    f64 = _oracle_fwd(oracle_mod, sc, np.float64)
+    og = oracle_mod.fastgs_backward(f64, sc["means"], sc["scales_raw"], sc["rot_raw"], sc["opac_raw"], sc["sh0"], sc["sh_rest"], sc["w2c"], sc["cam_pos"],
+                                    sc["active_sh_bases"], sc["W"], sc["H"], sc["fx"], sc["fy"], sc["cx"], sc["cy"], gi, ga, dtype=np.float64)
+    for name, a, b in zip(["means", "scales_raw", "rot_raw", "opac_raw", "sh0", "sh_rest"], g, og[:6]):
+        a = n(a).reshape(b.shape)
+        assert np.isfinite(a).all(), name
+        if np.abs(b).max() == 0:
+            assert np.abs(a).max() == 0, name
+            continue
+        assert rel_l2(a, b) < 1e-2, (name, rel_l2(a, b))
+        assert rel_l2_rows(a.reshape(cfg["N"], -1), b.reshape(cfg["N"], -1), drop_frac=0.005) < 5e-4, (name, rel_l2_rows(a.reshape(cfg["N"], -1), b.reshape(cfg["N"], -1), 0.005))
+    dn = n(dens)
+    assert np.array_equal(dn[0], og[6][0].astype(np.float32))                      # visibility counts
+    assert rel_l2_rows(dn[1][:, None], og[6][1][:, None], drop_frac=0.005) < 1e-3  # screen-space gradient norms
+
+
+def test_fastgs_cell_culling_is_bit_identical(lfs):
+    from lichtfeld_studio_amd import fastgs
+    lib = lfs.load_library()
+    sc = _scene(N=5000, W=240, H=176, seed=7, deg=1, spread=1.5)
+    sc["scales_raw"][:300] += 2.0     # some screen-filling primitives
+    s = _settings(sc)
+    try:
+        lib.lfs_fastgs_set_debug_flags(1)
+        a = fastgs.forward_wrapper(*_dev_args(sc), s)
+    finally:
+        lib.lfs_fastgs_set_debug_flags(0)
+    b = fastgs.forward_wrapper(*_dev_args(sc), s)
+    assert a[4] == b[4] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_fast_rasterize_autograd_and_full_size(lfs):
+    """1M primitives at 1080p through fast_rasterize + autograd: finite gradients, determinism of the forward, alpha in [0,1],
+    background blend, densification_info counts == primitives with a gradient."""
+    from lichtfeld_studio_amd import fastgs, scenes
+    from lichtfeld_studio_amd.rasterizer import Camera, SplatModel
+    dev = torch.device(DEV)
+    sc = scenes.syn_b(n=1_000_000, n_views=4).to(dev)
+    mk = lambda x: x.clone().requires_grad_(True)
+    model = SplatModel(mk(sc.means), mk(sc.sh0), mk(sc.shN), mk(sc.raw_scales), mk(sc.raw_quats), mk(sc.raw_opacities), 3)
+    cam = Camera(sc.viewmats[:1].contiguous(), sc.Ks[:1].contiguous(), sc.width, sc.height)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    dens = torch.zeros(2, sc.N, device=dev)
+    out = fastgs.fast_rasterize(cam, model, bg, dens)
+    with torch.no_grad():
+        out2 = fastgs.fast_rasterize(cam, model, bg)
+    assert torch.equal(out.image, out2.image) and out.image.shape == (3, 1080, 1920)
+    assert float(out.alpha.min()) >= 0 and float(out.alpha.max()) <= 1 and float(out.alpha.mean()) > 0.3
+    empty = out.alpha[0] == 0
+    if bool(empty.any()):
+        assert torch.allclose(out.image[:, empty], bg.view(3, 1).expand(3, int(empty.sum())))
+    out.image.square().mean().backward()
+    for p in model.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert float(model.means.grad.abs().max()) > 0
+    seen = dens[0] > 0
+    assert 0.5 < float(seen.float().mean()) <= 1.0 and bool((dens[1][~seen] == 0).all())
