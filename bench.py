@@ -119,6 +119,7 @@ def main() -> None:
     ap.add_argument("--workload", default="syn-b", choices=["syn-a", "syn-b", "syn-c", "syn-d"])
     ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
     ap.add_argument("--views-per-rank", type=int, default=1)
+    ap.add_argument("--rasterizer", default="gut", choices=["gut", "fastgs"], help="gut = the north-star 3DGUT path (default); fastgs = the reference's default EWA rasterizer (SURVEY.md §8f row 1)")
     ap.add_argument("--loss", default="mse", choices=["mse", "l1_ssim"], help="mse = rasterizer-only metric of SURVEY.md §8d (default); l1_ssim = the reference's photometric loss")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -145,7 +146,7 @@ def main() -> None:
         kw["sh_degree"] = 0
     scene = maker(**kw)
     n_views = scene.viewmats.shape[0]
-    trainer = GutTrainer(scene, device, iterations=7000, world=world, rank=rank, views_per_rank=args.views_per_rank, loss=args.loss)
+    trainer = GutTrainer(scene, device, iterations=7000, world=world, rank=rank, views_per_rank=args.views_per_rank, loss=args.loss, rasterizer=args.rasterizer)
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
 
     # Warm-up. Its last (up to 3) steps run with every kernel scope timed (HIP events on the launch stream): that gives the
@@ -189,7 +190,7 @@ def main() -> None:
     images = world * args.views_per_rank * args.steps
     N = scene.N
     K = (scene.sh_degree + 1) ** 2
-    V = int(trainer.last_visible.sum().item())
+    V = int(trainer.last_visible.sum().item()) if trainer.last_visible is not None else 0
     I = int(trainer.last_n_isects)
     P = scene.width * scene.height
     T = ((scene.width + 15) // 16) * ((scene.height + 15) // 16)
@@ -241,7 +242,7 @@ def main() -> None:
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{scene.name}: {N} Gaussians, {scene.width}x{scene.height}, SH degree {scene.sh_degree}, "
+        "config": {"rasterizer": args.rasterizer, "workload": f"{scene.name}: {N} Gaussians, {scene.width}x{scene.height}, SH degree {scene.sh_degree}, "
                                f"16x16 tiles, {n_views} orbit cameras, {'MSE' if args.loss == 'mse' else 'L1 + 0.2 D-SSIM'} loss, default_optimization_params lrs",
                    "global_batch": world * args.views_per_rank, "views_per_rank": args.views_per_rank,
                    "parallelism": f"dp{world}", "visible_gaussians": V, "n_isects": I},

@@ -199,6 +199,9 @@ LFS_API int lfs_activations_bwd(uint32_t N, const float* raw_quats, const float*
                                 float* g_raw_quats, float* g_raw_scales, float* g_raw_opacities, lfs_stream_t stream);
 LFS_API int lfs_mse_loss_fwd_bwd(uint32_t H, uint32_t W, const float* render_hwc, const float* target_chw, float weight,
                                  float* v_render_hwc, float* loss, lfs_stream_t stream);
+/*      the same for a CHW render that is NOT clamped (the fastgs path, fast_rasterizer.cpp:62-66) */
+LFS_API int lfs_mse_loss_chw_fwd_bwd(uint32_t H, uint32_t W, const float* render_chw, const float* target_chw, float weight,
+                                     float* v_render_chw, float* loss, lfs_stream_t stream);
 
 /* ---- "next" row 1 of SURVEY.md §8f: the reference's default training rasterizer (fastgs, EWA splatting).
  *      Replaces fast_gs::rasterization::forward_wrapper / backward_wrapper (fastgs/rasterization/include/rasterization_api.h:27-75,
@@ -222,9 +225,9 @@ LFS_API int lfs_fastgs_render(
     uint32_t N, uint32_t width, uint32_t height, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
     void* instance_workspace, size_t instance_workspace_bytes, float* image, float* alpha, lfs_stream_t stream);
 LFS_API int lfs_fastgs_backward(
-    uint32_t N, const float* means, const float* scales_raw, const float* rotations_raw, const float* sh_coefficients_rest, uint32_t total_bases_sh_rest,
-    const float* w2c, const float* cam_position, uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy, float cx, float cy,
-    float near_plane, float far_plane, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
+    uint32_t N, const float* means, const float* scales_raw, const float* rotations_raw, const float* sh_coefficients_0, const float* sh_coefficients_rest,
+    uint32_t total_bases_sh_rest, const float* w2c, const float* cam_position, uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy,
+    float cx, float cy, float near_plane, float far_plane, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
     void* instance_workspace, size_t instance_workspace_bytes, const float* grad_image, const float* grad_alpha, const float* alpha,
     float* densification_info, float* grad_means, float* grad_scales_raw, float* grad_rotations_raw, float* grad_opacities_raw,
     float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest, lfs_stream_t stream);

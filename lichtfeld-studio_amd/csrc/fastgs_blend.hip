@@ -15,7 +15,7 @@ namespace lfs {
 namespace fgs {
 
 int launch_scatter(uint32_t N, const Frame& f, const PrimWs& w, int64_t* keys, hipStream_t s);
-int launch_preprocess_bwd(uint32_t N, const float* means, const float* scales_raw, const float* rot_raw, const float* sh_rest, const Frame& f, const PrimWs& w,
+int launch_preprocess_bwd(uint32_t N, const float* means, const float* scales_raw, const float* rot_raw, const float* sh0, const float* sh_rest, const Frame& f, const PrimWs& w,
                           float* g_means, float* g_scales_raw, float* g_rot_raw, float* g_opac_raw, float* g_sh0, float* g_sh_rest, float* densification_info, hipStream_t s);
 
 // cell-level version of kernel_utils.cuh:108-148 on the record's conic in bits (A, B, C) = log2(e) (a/2, b, c/2): the ratios that
@@ -259,9 +259,9 @@ extern "C" int lfs_fastgs_render(
 }
 
 extern "C" int lfs_fastgs_backward(
-    uint32_t N, const float* means, const float* scales_raw, const float* rotations_raw, const float* sh_coefficients_rest, uint32_t total_bases_sh_rest,
-    const float* w2c, const float* cam_position, uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy, float cx, float cy,
-    float near_plane, float far_plane, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
+    uint32_t N, const float* means, const float* scales_raw, const float* rotations_raw, const float* sh_coefficients_0, const float* sh_coefficients_rest,
+    uint32_t total_bases_sh_rest, const float* w2c, const float* cam_position, uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy,
+    float cx, float cy, float near_plane, float far_plane, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
     void* instance_workspace, size_t instance_workspace_bytes, const float* grad_image, const float* grad_alpha, const float* alpha,
     float* densification_info, float* grad_means, float* grad_scales_raw, float* grad_rotations_raw, float* grad_opacities_raw,
     float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest, lfs_stream_t stream) {
@@ -271,7 +271,7 @@ extern "C" int lfs_fastgs_backward(
     fgs::InstWs iw = fgs::inst_ws(instance_workspace, width, height, uint64_t(n_instances));
     if (!instance_workspace || instance_workspace_bytes < iw.bytes) return LFS_E_WORKSPACE;
     if (N == 0) return LFS_OK;
-    if (!means || !scales_raw || !rotations_raw || !grad_means || !grad_scales_raw || !grad_rotations_raw || !grad_opacities_raw || !grad_sh_coefficients_0 ||
+    if (!means || !scales_raw || !rotations_raw || !sh_coefficients_0 || !grad_means || !grad_scales_raw || !grad_rotations_raw || !grad_opacities_raw || !grad_sh_coefficients_0 ||
         (total_bases_sh_rest > 0 && (!sh_coefficients_rest || !grad_sh_coefficients_rest))) return LFS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const fgs::Frame f = make_frame(w2c, cam_position, active_sh_bases, total_bases_sh_rest, width, height, fx, fy, cx, cy, near_plane, far_plane);
@@ -283,6 +283,6 @@ extern "C" int lfs_fastgs_backward(
         hipLaunchKernelGGL(fgs::fg_blend_bwd_kernel, dim3(grid), dim3(256), 0, s, f.gw, f.gh, width, height, w.rec, w.offsets, iw.cell_count, iw.cell_list,
                            alpha, w.n_contrib, grad_image, grad_alpha, w.acc);
     }
-    return fgs::launch_preprocess_bwd(N, means, scales_raw, rotations_raw, sh_coefficients_rest, f, w, grad_means, grad_scales_raw, grad_rotations_raw,
+    return fgs::launch_preprocess_bwd(N, means, scales_raw, rotations_raw, sh_coefficients_0, sh_coefficients_rest, f, w, grad_means, grad_scales_raw, grad_rotations_raw,
                                       grad_opacities_raw, grad_sh_coefficients_0, grad_sh_coefficients_rest, densification_info, s);
 }

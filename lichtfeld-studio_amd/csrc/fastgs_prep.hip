@@ -73,32 +73,6 @@ LFS_DI void ewa(const Frame& f, const float* __restrict__ m, const float* __rest
     o.c = o.jc2[0] * o.jw2[0] + o.jc2[1] * o.jw2[1] + o.jc2[2] * o.jw2[2] + DILATION;
 }
 
-// kernel_utils.cuh:15-36
-LFS_DI void sh_color(const Frame& f, const float* __restrict__ sh0, const float* __restrict__ sh_rest, const float* __restrict__ m, uint32_t i, float* r) {
-    const float* c0 = sh0 + 3 * size_t(i);
-    const float* cr = sh_rest + size_t(i) * f.total_rest * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) r[c] = 0.5f + 0.28209479177387814f * c0[c];
-    if (f.active_sh_bases > 1) {
-        float x = m[0] - f.cam_pos[0], y = m[1] - f.cam_pos[1], z = m[2] - f.cam_pos[2];
-        const float inv = 1.f / sqrtf(x * x + y * y + z * z);
-        x *= inv; y *= inv; z *= inv;
-        auto add = [&](float w, int k) { r[0] += w * cr[3 * k]; r[1] += w * cr[3 * k + 1]; r[2] += w * cr[3 * k + 2]; };
-        add(-0.48860251190291987f * y, 0); add(0.48860251190291987f * z, 1); add(-0.48860251190291987f * x, 2);
-        if (f.active_sh_bases > 4) {
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
-            add(1.0925484305920792f * xy, 3); add(-1.0925484305920792f * yz, 4); add(0.94617469575755997f * zz - 0.31539156525251999f, 5);
-            add(-1.0925484305920792f * xz, 6); add(0.54627421529603959f * xx - 0.54627421529603959f * yy, 7);
-            if (f.active_sh_bases > 9) {
-                add(0.59004358992664352f * y * (-3.f * xx + yy), 8); add(2.8906114426405538f * xy * z, 9);
-                add(0.45704579946446572f * y * (1.f - 5.f * zz), 10); add(0.3731763325901154f * z * (5.f * zz - 3.f), 11);
-                add(0.45704579946446572f * x * (1.f - 5.f * zz), 12); add(1.4453057213202769f * z * (xx - yy), 13);
-                add(0.59004358992664352f * x * (-xx + 3.f * yy), 14);
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // forward preprocess: one thread per primitive. Per-tile counts go through an LDS histogram (one coalesced global atomic
 // per touched (workgroup, tile), see intersect.hip) when the tile grid fits.
@@ -106,7 +80,7 @@ LFS_DI void sh_color(const Frame& f, const float* __restrict__ sh0, const float*
 template <bool LDS_HIST>
 __global__ void __launch_bounds__(1024) fg_preprocess_kernel(
     const uint32_t N, const uint32_t per_block, const float* __restrict__ means, const float* __restrict__ scales_raw, const float* __restrict__ rot_raw,
-    const float* __restrict__ opac_raw, const float* __restrict__ sh0, const float* __restrict__ sh_rest, const Frame f,
+    const float* __restrict__ opac_raw, const Frame f,
     GaussRec* __restrict__ rec, float2* __restrict__ mean2d_o, float4* __restrict__ conic_opacity_o, ushort4* __restrict__ bounds_o,
     uint32_t* __restrict__ n_touched_o, uint32_t* __restrict__ depth_bits_o, uint32_t* __restrict__ totals) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
@@ -148,14 +122,10 @@ __global__ void __launch_bounds__(1024) fg_preprocess_kernel(
                         if (LDS_HIST) atomicAdd(&hist[ty * f.gw + tx], 1u); else atomicAdd(&totals[ty * f.gw + tx], 1u);
                     }
             if (n_touched == 0) break;
-            float col[3];
-            sh_color(f, sh0, sh_rest, m, i, col);
-            GaussRec r;
-            r.r0 = make_float4(mx, my, 0.5f * LOG2E * ca, LOG2E * cb);
-            r.r1 = make_float4(0.5f * LOG2E * cc, LOG2E * power_threshold, opacity, 0.f);
-            r.r2 = make_float4(fmaxf(col[0], 0.f), fmaxf(col[1], 0.f), fmaxf(col[2], 0.f), 0.f);
-            r.r3 = make_float4(col[0], col[1], col[2], 0.f);
-            rec[i] = r;
+            // (r2 = max(SH colour + 0.5, 0) is filled in by the SH kernel of sh.hip right after this one)
+            float4* r = reinterpret_cast<float4*>(rec + i);
+            r[0] = make_float4(mx, my, 0.5f * LOG2E * ca, LOG2E * cb);
+            r[1] = make_float4(0.5f * LOG2E * cc, LOG2E * power_threshold, opacity, 0.f);
             mean2d_o[i] = make_float2(mx, my);
             conic_opacity_o[i] = make_float4(ca, cb, cc, opacity);
             bounds_o[i] = make_ushort4(uint16_t(x0), uint16_t(x1), uint16_t(y0), uint16_t(y1));
@@ -219,22 +189,20 @@ __global__ void __launch_bounds__(1024) fg_scatter_kernel(
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) fg_preprocess_bwd_kernel(
     const uint32_t N, const float* __restrict__ means, const float* __restrict__ scales_raw, const float* __restrict__ rot_raw,
-    const float* __restrict__ sh_rest, const Frame f, const GaussRec* __restrict__ rec, const float4* __restrict__ conic_opacity,
+    const Frame f, const GaussRec* __restrict__ rec, const float4* __restrict__ conic_opacity,
     const uint32_t* __restrict__ n_touched, const float* __restrict__ acc, float* __restrict__ g_means, float* __restrict__ g_scales_raw, float* __restrict__ g_rot_raw,
-    float* __restrict__ g_opac_raw, float* __restrict__ g_sh0, float* __restrict__ g_sh_rest, float* __restrict__ densification_info) {
+    float* __restrict__ g_opac_raw, float* __restrict__ densification_info) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    float* gr = g_sh_rest + size_t(i) * f.total_rest * 3;
     if (n_touched[i] == 0) { // the reference leaves these rows at the zeros they were allocated with
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { g_means[3 * size_t(i) + c] = 0.f; g_scales_raw[3 * size_t(i) + c] = 0.f; g_sh0[3 * size_t(i) + c] = 0.f; }
+        for (int c = 0; c < 3; ++c) { g_means[3 * size_t(i) + c] = 0.f; g_scales_raw[3 * size_t(i) + c] = 0.f; }
         reinterpret_cast<float4*>(g_rot_raw)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         g_opac_raw[i] = 0.f;
-        for (uint32_t k = 0; k < 3 * f.total_rest; ++k) gr[k] = 0.f;
         return;
     }
     const float4* a4 = reinterpret_cast<const float4*>(acc + size_t(i) * ACC_STRIDE);
-    const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2];
+    const float4 a0 = a4[0], a1 = a4[1];
     const GaussRec r = rec[i];
     // accumulator row (fastgs_blend.hip): {S1 = sum h dx, S2 = sum h dy, sum h dx dx, sum h dx dy | sum h dy dy, sum alpha dL/dalpha, dc.r, dc.g | dc.b}
     // with h = -alpha dL/dalpha: dL/dmean2d = conic (S1, S2), dL/dconic = 0.5 (sum h dx dx, sum h dx dy, sum h dy dy)
@@ -243,60 +211,8 @@ __global__ void __launch_bounds__(256) fg_preprocess_bwd_kernel(
     const float dcon[3] = {0.5f * a0.z, 0.5f * a0.w, 0.5f * a1.x};
     const float opacity = r.r1.z;
     g_opac_raw[i] = a1.y * (1.0f - opacity);
-    float gcl[3] = {a1.z, a1.w, a2.x};                       // dL/d(clamped colour) -> through max(colour, 0)
-    if (!(r.r3.x >= 0.f)) gcl[0] = 0.f;
-    if (!(r.r3.y >= 0.f)) gcl[1] = 0.f;
-    if (!(r.r3.z >= 0.f)) gcl[2] = 0.f;
     const float* m = means + 3 * size_t(i);
-    // ---- SH backward
-#pragma unroll
-    for (int c = 0; c < 3; ++c) g_sh0[3 * size_t(i) + c] = 0.28209479177387814f * gcl[c];
-    float dpos[3] = {0.f, 0.f, 0.f};
-    for (uint32_t k = 0; k < 3 * f.total_rest; ++k) gr[k] = 0.f; // bases beyond the active degree
-    if (f.active_sh_bases > 1) {
-        const float* cr = sh_rest + size_t(i) * f.total_rest * 3;
-        const float xr = m[0] - f.cam_pos[0], yr = m[1] - f.cam_pos[1], zr = m[2] - f.cam_pos[2];
-        const float inv = 1.f / sqrtf(xr * xr + yr * yr + zr * zr);
-        const float x = xr * inv, y = yr * inv, z = zr * inv;
-        float gdx[3], gdy[3], gdz[3];
-        auto setg = [&](int k, float w) { gr[3 * k] = w * gcl[0]; gr[3 * k + 1] = w * gcl[1]; gr[3 * k + 2] = w * gcl[2]; };
-        setg(0, -0.48860251190291987f * y); setg(1, 0.48860251190291987f * z); setg(2, -0.48860251190291987f * x);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { gdx[c] = -0.48860251190291987f * cr[6 + c]; gdy[c] = -0.48860251190291987f * cr[c]; gdz[c] = 0.48860251190291987f * cr[3 + c]; }
-        if (f.active_sh_bases > 4) {
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
-            setg(3, 1.0925484305920792f * xy); setg(4, -1.0925484305920792f * yz); setg(5, 0.94617469575755997f * zz - 0.31539156525251999f);
-            setg(6, -1.0925484305920792f * xz); setg(7, 0.54627421529603959f * xx - 0.54627421529603959f * yy);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                gdx[c] += 1.0925484305920792f * y * cr[9 + c] + -1.0925484305920792f * z * cr[18 + c] + 1.0925484305920792f * x * cr[21 + c];
-                gdy[c] += 1.0925484305920792f * x * cr[9 + c] + -1.0925484305920792f * z * cr[12 + c] + -1.0925484305920792f * y * cr[21 + c];
-                gdz[c] += -1.0925484305920792f * y * cr[12 + c] + 1.8923493915151202f * z * cr[15 + c] + -1.0925484305920792f * x * cr[18 + c];
-            }
-            if (f.active_sh_bases > 9) {
-                setg(8, 0.59004358992664352f * y * (-3.f * xx + yy)); setg(9, 2.8906114426405538f * xy * z);
-                setg(10, 0.45704579946446572f * y * (1.f - 5.f * zz)); setg(11, 0.3731763325901154f * z * (5.f * zz - 3.f));
-                setg(12, 0.45704579946446572f * x * (1.f - 5.f * zz)); setg(13, 1.4453057213202769f * z * (xx - yy));
-                setg(14, 0.59004358992664352f * x * (-xx + 3.f * yy));
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    gdx[c] += -3.5402615395598609f * xy * cr[24 + c] + 2.8906114426405538f * yz * cr[27 + c] + (0.45704579946446572f - 2.2852289973223288f * zz) * cr[36 + c] +
-                              2.8906114426405538f * xz * cr[39 + c] + (-1.7701307697799304f * xx + 1.7701307697799304f * yy) * cr[42 + c];
-                    gdy[c] += (-1.7701307697799304f * xx + 1.7701307697799304f * yy) * cr[24 + c] + 2.8906114426405538f * xz * cr[27 + c] +
-                              (0.45704579946446572f - 2.2852289973223288f * zz) * cr[30 + c] + -2.8906114426405538f * yz * cr[39 + c] + 3.5402615395598609f * xy * cr[42 + c];
-                    gdz[c] += 2.8906114426405538f * xy * cr[27 + c] + -4.5704579946446566f * yz * cr[30 + c] + (5.597644988851731f * zz - 1.1195289977703462f) * cr[33 + c] +
-                              -4.5704579946446566f * xz * cr[36 + c] + (1.4453057213202769f * xx - 1.4453057213202769f * yy) * cr[39 + c];
-                }
-            }
-        }
-        const float gd[3] = {gdx[0] * gcl[0] + gdx[1] * gcl[1] + gdx[2] * gcl[2], gdy[0] * gcl[0] + gdy[1] * gcl[1] + gdy[2] * gcl[2],
-                             gdz[0] * gcl[0] + gdz[1] * gcl[1] + gdz[2] * gcl[2]};
-        const float xx = xr * xr, yy = yr * yr, zz = zr * zr, xy = xr * yr, xz = xr * zr, yz = yr * zr;
-        const float n2 = xx + yy + zz, rsq3 = 1.f / sqrtf(n2 * n2 * n2);
-        dpos[0] = ((yy + zz) * gd[0] - xy * gd[1] - xz * gd[2]) * rsq3;
-        dpos[1] = (-xy * gd[0] + (xx + zz) * gd[1] - yz * gd[2]) * rsq3;
-        dpos[2] = (-xz * gd[0] - yz * gd[1] + (xx + yy) * gd[2]) * rsq3;
-    }
+    const float dpos[3] = {0.f, 0.f, 0.f}; // (the colour -> position term is added by the SH backward kernel of sh.hip, which runs after this one)
     // ---- EWA backward
     const float4 q = reinterpret_cast<const float4*>(rot_raw)[i];
     Cov cv;
@@ -366,12 +282,18 @@ int launch_scatter(uint32_t N, const Frame& f, const PrimWs& w, int64_t* keys, h
         hipLaunchKernelGGL(fg_scatter_kernel<false>, dim3(blocks), dim3(1024), 0, s, N, pb, f, w.mean2d, w.conic_opacity, w.bounds, w.n_touched, w.depth_bits, w.offsets, w.cursor, keys);
     return (int)hipGetLastError();
 }
-int launch_preprocess_bwd(uint32_t N, const float* means, const float* scales_raw, const float* rot_raw, const float* sh_rest, const Frame& f, const PrimWs& w,
+int launch_preprocess_bwd(uint32_t N, const float* means, const float* scales_raw, const float* rot_raw, const float* sh0, const float* sh_rest, const Frame& f, const PrimWs& w,
                           float* g_means, float* g_scales_raw, float* g_rot_raw, float* g_opac_raw, float* g_sh0, float* g_sh_rest, float* densification_info, hipStream_t s) {
-    lfs::ProfScope prof("fastgs_preprocess_bwd", s);
-    hipLaunchKernelGGL(fg_preprocess_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, means, scales_raw, rot_raw, sh_rest, f, w.rec, w.conic_opacity, w.n_touched, w.acc,
-                       g_means, g_scales_raw, g_rot_raw, g_opac_raw, g_sh0, g_sh_rest, densification_info);
-    return (int)hipGetLastError();
+    {
+        lfs::ProfScope prof("fastgs_preprocess_bwd", s);
+        hipLaunchKernelGGL(fg_preprocess_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, means, scales_raw, rot_raw, f, w.rec, w.conic_opacity, w.n_touched, w.acc,
+                           g_means, g_scales_raw, g_rot_raw, g_opac_raw, densification_info);
+    }
+    // SH backward (convert_sh_to_color_backward, kernel_utils.cuh:38-106) with the coalesced three-phase kernel of sh.hip: reads dL/d(clamped colour) from the
+    // accumulator rows (floats 6..8 of 16), the clamp mask from the record's colour (floats 8..10 of 16), writes g_sh0 / g_sh_rest fully, adds dL/dposition to g_means
+    const uint32_t degree = f.active_sh_bases >= 16 ? 3 : f.active_sh_bases >= 9 ? 2 : f.active_sh_bases >= 4 ? 1 : 0;
+    return sh_records_bwd(N, 1 + f.total_rest, degree, means, f.cam_pos, sh0, sh_rest, w.n_touched, reinterpret_cast<const float*>(w.rec) + 8, 16, w.acc + 6, 16,
+                          g_sh0, g_sh_rest, g_means, s);
 }
 
 } // namespace fgs
@@ -407,12 +329,18 @@ extern "C" int lfs_fastgs_preprocess(
             const uint32_t pb = fgs::per_block_for(N), blocks = (N + pb - 1) / pb;
             if (size_t(T) * 8 <= 64 * 1024)
                 hipLaunchKernelGGL(fgs::fg_preprocess_kernel<true>, dim3(blocks), dim3(1024), size_t(T) * 4, s, N, pb, means, scales_raw, rotations_raw, opacities_raw,
-                                   sh_coefficients_0, sh_coefficients_rest, f, w.rec, w.mean2d, w.conic_opacity, w.bounds, w.n_touched, w.depth_bits, w.totals);
+                                   f, w.rec, w.mean2d, w.conic_opacity, w.bounds, w.n_touched, w.depth_bits, w.totals);
             else
                 hipLaunchKernelGGL(fgs::fg_preprocess_kernel<false>, dim3(blocks), dim3(1024), 0, s, N, pb, means, scales_raw, rotations_raw, opacities_raw,
-                                   sh_coefficients_0, sh_coefficients_rest, f, w.rec, w.mean2d, w.conic_opacity, w.bounds, w.n_touched, w.depth_bits, w.totals);
+                                   f, w.rec, w.mean2d, w.conic_opacity, w.bounds, w.n_touched, w.depth_bits, w.totals);
         }
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_instances);
+    }
+    if (N > 0) { // SH colour (convert_sh_to_color, kernel_utils.cuh:15-36) of the visible primitives, written into the records
+        const uint32_t degree = active_sh_bases >= 16 ? 3 : active_sh_bases >= 9 ? 2 : active_sh_bases >= 4 ? 1 : 0;
+        const int rc = sh_records_fwd(N, 1 + total_bases_sh_rest, degree, means, cam_position, sh_coefficients_0, sh_coefficients_rest, w.n_touched,
+                                      reinterpret_cast<float*>(w.rec) + 8, 16, s);
+        if (rc) return rc;
     }
     return (int)hipGetLastError();
 }

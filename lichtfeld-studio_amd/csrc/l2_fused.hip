@@ -61,6 +61,8 @@ __global__ void __launch_bounds__(256) activations_bwd_kernel(
 
 // loss += sum((clamp(x,0,1) - t)^2) * inv_numel * weight; v_render = 2 (clamp(x) - t) * inv_numel * weight where 0 <= x <= 1
 // (torch::clamp passes the gradient on the closed interval). render HWC, target CHW.
+// CHW = true: render / v_render are [3,H,W] and NOT clamped (the fastgs path: fast_rasterizer.cpp hands the image on as is)
+template <bool CHW>
 __global__ void __launch_bounds__(256) mse_loss_kernel(
     const uint32_t H, const uint32_t W, const float* __restrict__ render, const float* __restrict__ target,
     const float scale, float* __restrict__ v_render, float* __restrict__ loss) {
@@ -69,10 +71,11 @@ __global__ void __launch_bounds__(256) mse_loss_kernel(
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float x = render[3 * size_t(p) + c];
-            const float d = fminf(fmaxf(x, 0.f), 1.f) - target[size_t(c) * P + p];
+            const size_t ri = CHW ? size_t(c) * P + p : 3 * size_t(p) + c;
+            const float x = render[ri];
+            const float d = (CHW ? x : fminf(fmaxf(x, 0.f), 1.f)) - target[size_t(c) * P + p];
             acc += d * d;
-            v_render[3 * size_t(p) + c] = (x >= 0.f && x <= 1.f) ? 2.f * d * scale : 0.f;
+            v_render[ri] = (CHW || (x >= 0.f && x <= 1.f)) ? 2.f * d * scale : 0.f;
         }
     }
 #pragma unroll
@@ -118,6 +121,18 @@ extern "C" int lfs_mse_loss_fwd_bwd(uint32_t H, uint32_t W, const float* render_
     lfs::ProfScope prof("mse_loss", s);
     const uint32_t P = H * W;
     const uint32_t blocks = (P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048;
-    hipLaunchKernelGGL(lfs::mse_loss_kernel, dim3(blocks), dim3(256), 0, s, H, W, render_hwc, target_chw, weight / float(3u * P), v_render_hwc, loss);
+    hipLaunchKernelGGL(lfs::mse_loss_kernel<false>, dim3(blocks), dim3(256), 0, s, H, W, render_hwc, target_chw, weight / float(3u * P), v_render_hwc, loss);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lfs_mse_loss_chw_fwd_bwd(uint32_t H, uint32_t W, const float* render_chw, const float* target_chw, float weight,
+                                        float* v_render_chw, float* loss, lfs_stream_t stream) {
+    if (H == 0 || W == 0) return LFS_OK;
+    if (!render_chw || !target_chw || !v_render_chw || !loss) return LFS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    lfs::ProfScope prof("mse_loss", s);
+    const uint32_t P = H * W;
+    const uint32_t blocks = (P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048;
+    hipLaunchKernelGGL(lfs::mse_loss_kernel<true>, dim3(blocks), dim3(256), 0, s, H, W, render_chw, target_chw, weight / float(3u * P), v_render_chw, loss);
     return (int)hipGetLastError();
 }

@@ -4,6 +4,12 @@
 #include "lfs_raster_common.cuh"
 
 namespace lfs {
+// sh.hip: the SH kernels with strided colour operands (colours live inside the 64-B blend records / accumulator rows)
+int sh_records_fwd(uint32_t n, uint32_t K, uint32_t degree, const float* means, const float* campos, const float* sh0, const float* shN,
+                   const uint32_t* mask_u32, float* colors, uint32_t colors_stride, hipStream_t s);
+int sh_records_bwd(uint32_t n, uint32_t K, uint32_t degree, const float* means, const float* campos, const float* sh0, const float* shN,
+                   const uint32_t* mask_u32, const float* colors, uint32_t colors_stride, const float* v_colors, uint32_t v_stride,
+                   float* v_sh0, float* v_shN, float* v_means, hipStream_t s);
 namespace fgs {
 
 // fastgs/rasterization/include/rasterization_config.h:14-33
@@ -25,7 +31,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
 // Per-primitive + per-tile + per-pixel state: written by the forward, read by the backward.
 //   rec[N]   64-B blend record: r0 = {mean2d.x, mean2d.y, A, B}, r1 = {C, thr', opacity, -}, r2 = {max(colour, 0), -},
-//            r3 = {unclamped colour, -} with (A, B, C) = log2(e) * (conic.x / 2, conic.y, conic.z / 2) and thr' = log2(e) *
+//            r3 unused; with (A, B, C) = log2(e) * (conic.x / 2, conic.y, conic.z / 2) and thr' = log2(e) *
 //            log(255 * opacity): sigma' = A dx^2 + B dx dy + C dy^2 is the Gaussian exponent in bits (one v_exp_f32).
 struct PrimWs {
     GaussRec* rec; float2* mean2d; float4* conic_opacity; ushort4* bounds; uint32_t* n_touched; uint32_t* depth_bits;

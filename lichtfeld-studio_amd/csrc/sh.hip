@@ -113,13 +113,17 @@ struct ShArgs {
     const float* dirs; const float* coeffs; const uint8_t* masks;                      // op
     const float* means; const float* viewmat; const float* sh0; const float* shN; const int32_t* radii; // model
     const float* colors;                                                                // model bwd: clamped forward output
+    // strided / alternative operands of the model variant (the fastgs rasterizer keeps colours inside its 64-B records):
+    const float* campos;      // camera centre [3] instead of a view matrix
+    const uint32_t* mask_u32; // visibility = mask_u32[g] != 0 instead of radii
+    uint32_t cs, vs;          // element stride of colors / v_colors rows (0 = 3)
 };
 template <bool MODEL> LFS_DI bool sh_on(const ShArgs& a, uint32_t g) {
-    if (MODEL) return a.radii[2 * g] > 0 && a.radii[2 * g + 1] > 0;
+    if (MODEL) return a.mask_u32 ? a.mask_u32[g] != 0u : (a.radii[2 * g] > 0 && a.radii[2 * g + 1] > 0);
     return a.masks == nullptr || a.masks[g] != 0;
 }
 template <bool MODEL> LFS_DI f3 sh_dir(const ShArgs& a, uint32_t g) {
-    if (MODEL) { const f3 cp = campos_of(a.viewmat); return {a.means[3 * g] - cp.x, a.means[3 * g + 1] - cp.y, a.means[3 * g + 2] - cp.z}; }
+    if (MODEL) { const f3 cp = a.campos ? f3{a.campos[0], a.campos[1], a.campos[2]} : campos_of(a.viewmat); return {a.means[3 * g] - cp.x, a.means[3 * g + 1] - cp.y, a.means[3 * g + 2] - cp.z}; }
     return {a.dirs[3 * g], a.dirs[3 * g + 1], a.dirs[3 * g + 2]};
 }
 template <bool MODEL, class T> LFS_DI T* sh_coef(T* coeffs, T* sh0, T* shN, uint32_t K, uint32_t g, int k) {
@@ -173,7 +177,8 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
         r0 = group_sum<LPG>(r0); r1 = group_sum<LPG>(r1); r2 = group_sum<LPG>(r2);
         if (k == 0 && g < a.n) {
             if (MODEL) { r0 = fmaxf(r0 + 0.5f, 0.f); r1 = fmaxf(r1 + 0.5f, 0.f); r2 = fmaxf(r2 + 0.5f, 0.f); }
-            colors[3 * g] = r0; colors[3 * g + 1] = r1; colors[3 * g + 2] = r2;
+            const size_t cs = (MODEL && a.cs) ? a.cs : 3;
+            colors[cs * g] = r0; colors[cs * g + 1] = r1; colors[cs * g + 2] = r2;
         }
     }
 }
@@ -206,11 +211,12 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
             d = sh_dir<MODEL>(a, gmine);
             if (degree >= 1) { inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
             sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
-            v0 = v_colors[3 * gmine]; v1 = v_colors[3 * gmine + 1]; v2 = v_colors[3 * gmine + 2];
+            const size_t vs = (MODEL && a.vs) ? a.vs : 3, cs = (MODEL && a.cs) ? a.cs : 3;
+            v0 = v_colors[vs * gmine]; v1 = v_colors[vs * gmine + 1]; v2 = v_colors[vs * gmine + 2];
             if (MODEL) {
-                if (!(a.colors[3 * gmine] > 0.f)) v0 = 0.f;
-                if (!(a.colors[3 * gmine + 1] > 0.f)) v1 = 0.f;
-                if (!(a.colors[3 * gmine + 2] > 0.f)) v2 = 0.f;
+                if (!(a.colors[cs * gmine] > 0.f)) v0 = 0.f;
+                if (!(a.colors[cs * gmine + 1] > 0.f)) v1 = 0.f;
+                if (!(a.colors[cs * gmine + 2] > 0.f)) v2 = 0.f;
             }
         }
 #pragma unroll
@@ -289,6 +295,23 @@ static int sh_launch_bwd(const ShArgs& a, const float* v_colors, float* v_coeffs
     default: hipLaunchKernelGGL((sh_bwd_kernel<32, MODEL, ACCUM>), grid, block, 0, s, a, v_colors, v_coeffs, v_sh0, v_shN, v_dirs); break;
     }
     return (int)hipGetLastError();
+}
+
+// used by fastgs_{prep,blend}.hip: SH colour of visible primitives written straight into the blend records (stride in floats),
+// and its backward reading dL/dcolour from the blend accumulator rows
+int sh_records_fwd(uint32_t n, uint32_t K, uint32_t degree, const float* means, const float* campos, const float* sh0, const float* shN,
+                   const uint32_t* mask_u32, float* colors, uint32_t colors_stride, hipStream_t s) {
+    ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degree); a.means = means; a.campos = campos; a.sh0 = sh0; a.shN = shN; a.mask_u32 = mask_u32; a.cs = colors_stride;
+    return sh_launch_fwd<true>(a, (degree + 1) * (degree + 1), colors, s);
+}
+int sh_records_bwd(uint32_t n, uint32_t K, uint32_t degree, const float* means, const float* campos, const float* sh0, const float* shN,
+                   const uint32_t* mask_u32, const float* colors, uint32_t colors_stride, const float* v_colors, uint32_t v_stride,
+                   float* v_sh0, float* v_shN, float* v_means, hipStream_t s) {
+    ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degree); a.means = means; a.campos = campos; a.sh0 = sh0; a.shN = shN; a.mask_u32 = mask_u32;
+    a.colors = colors; a.cs = colors_stride; a.vs = v_stride;
+    return sh_launch_bwd<true, false>(a, v_colors, nullptr, v_sh0, v_shN, v_means, s);
 }
 
 } // namespace lfs

@@ -65,25 +65,30 @@ def forward_wrapper(means, scales_raw, rotations_raw, opacities_raw, sh_coeffici
 
 
 def backward_wrapper(densification_info: Optional[torch.Tensor], grad_image, grad_alpha, image, alpha, means, scales_raw, rotations_raw,
-                     sh_coefficients_rest, primitive_workspace, instance_workspace, w2c, s: FastGSSettings, n_instances: int):
+                     sh_coefficients_0, sh_coefficients_rest, primitive_workspace, instance_workspace, w2c, s: FastGSSettings, n_instances: int, out=None):
     """-> (grad_means, grad_scales_raw, grad_rotations_raw, grad_opacities_raw [N,1], grad_sh_coefficients_0, grad_sh_coefficients_rest);
     densification_info [2,N] (when given and non-empty) is accumulated into in place (kernels_backward.cuh:229-232)."""
     w2c = w2c.reshape(-1, 4, 4)[0].contiguous()
     cam_position = s.cam_position.reshape(-1)[:3].contiguous()
     grad_image, grad_alpha, alpha = grad_image.contiguous(), grad_alpha.contiguous(), alpha.contiguous()
     means, scales_raw, rotations_raw, shr = means.contiguous(), scales_raw.contiguous(), rotations_raw.contiguous(), sh_coefficients_rest.contiguous()
-    require_gpu(grad_image, grad_alpha, alpha, means, scales_raw, rotations_raw, shr, w2c, cam_position)
+    sh0 = sh_coefficients_0.contiguous()  # (the reference's backward does not need sh0; the SH backward kernel here shares its operand list with the forward)
+    require_gpu(grad_image, grad_alpha, alpha, means, scales_raw, rotations_raw, sh0, shr, w2c, cam_position)
     N = means.shape[0]
     total_rest = shr.shape[1] if shr.dim() == 3 else 0
     dens = densification_info if (densification_info is not None and densification_info.numel() > 0) else None
     if dens is not None and (tuple(dens.shape) != (2, N) or not dens.is_contiguous()):
         raise LfsError("densification_info must be a contiguous [2,N] tensor")
-    g_means, g_scales, g_rot = torch.empty_like(means), torch.empty_like(scales_raw), torch.empty_like(rotations_raw)
-    g_opac = torch.empty((N, 1), dtype=means.dtype, device=means.device)
-    g_sh0 = torch.empty((N, 1, 3), dtype=means.dtype, device=means.device)
-    g_shr = torch.empty_like(shr)
+    if out is not None:  # extension: write into the caller's (contiguous) buffers, e.g. views of the data-parallel gradient bucket
+        g_means, g_scales, g_rot, g_opac, g_sh0, g_shr = out
+        require_gpu(*out)
+    else:
+        g_means, g_scales, g_rot = torch.empty_like(means), torch.empty_like(scales_raw), torch.empty_like(rotations_raw)
+        g_opac = torch.empty((N, 1), dtype=means.dtype, device=means.device)
+        g_sh0 = torch.empty((N, 1, 3), dtype=means.dtype, device=means.device)
+        g_shr = torch.empty_like(shr)
     check(load_library().lfs_fastgs_backward(
-        C.c_uint32(N), ptr(means), ptr(scales_raw), ptr(rotations_raw), ptr(shr), C.c_uint32(total_rest), ptr(w2c), ptr(cam_position), *_frame_args(s),
+        C.c_uint32(N), ptr(means), ptr(scales_raw), ptr(rotations_raw), ptr(sh0), ptr(shr), C.c_uint32(total_rest), ptr(w2c), ptr(cam_position), *_frame_args(s),
         C.c_int64(n_instances), ptr(primitive_workspace), C.c_size_t(primitive_workspace.numel()), ptr(instance_workspace), C.c_size_t(instance_workspace.numel()),
         ptr(grad_image), ptr(grad_alpha), ptr(alpha), ptr(dens), ptr(g_means), ptr(g_scales), ptr(g_rot), ptr(g_opac), ptr(g_sh0), ptr(g_shr), stream()), "fastgs_backward")
     return g_means, g_scales, g_rot, g_opac, g_sh0, g_shr
@@ -95,15 +100,15 @@ class FastGSRasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, scales_raw, rotations_raw, opacities_raw, sh0, sh_rest, w2c, densification_info, settings: FastGSSettings):
         image, alpha, pws, iws, n_instances = forward_wrapper(means, scales_raw, rotations_raw, opacities_raw, sh0, sh_rest, w2c, settings)
-        ctx.save_for_backward(image, alpha, means, scales_raw, rotations_raw, sh_rest, w2c)
+        ctx.save_for_backward(image, alpha, means, scales_raw, rotations_raw, sh0, sh_rest, w2c)
         ctx.state = (pws, iws, n_instances, settings, densification_info, opacities_raw.shape)
         return image, alpha
 
     @staticmethod
     def backward(ctx, grad_image, grad_alpha):
-        image, alpha, means, scales_raw, rotations_raw, sh_rest, w2c = ctx.saved_tensors
+        image, alpha, means, scales_raw, rotations_raw, sh0, sh_rest, w2c = ctx.saved_tensors
         pws, iws, n_instances, settings, dens, opac_shape = ctx.state
-        g = backward_wrapper(dens, grad_image, grad_alpha, image, alpha, means, scales_raw, rotations_raw, sh_rest, pws, iws, w2c, settings, n_instances)
+        g = backward_wrapper(dens, grad_image, grad_alpha, image, alpha, means, scales_raw, rotations_raw, sh0, sh_rest, pws, iws, w2c, settings, n_instances)
         return g[0], g[1], g[2], g[3].reshape(opac_shape), g[4], g[5], None, None, None
 
 
@@ -119,3 +124,30 @@ def fast_rasterize(camera: Camera, model: SplatModel, bg_color: torch.Tensor, de
     image, alpha = FastGSRasterize.apply(model.means, model.raw_scales, model.raw_quats, model.raw_opacities, model.sh0, model.shN, w2c, densification_info, settings)
     image = image + (1.0 - alpha) * bg_color.view(3, 1, 1)
     return RenderOutput(image=image, alpha=alpha, depth=None, means2d=None, depths=None, radii=None, visibility=None, width=W, height=H, n_isects=0)
+
+
+def mse_loss_chw_fwd_bwd(render_chw: torch.Tensor, target_chw: torch.Tensor, weight: float, loss_acc: torch.Tensor) -> torch.Tensor:
+    """loss_acc += weight * mse(render, target) (no clamp: fast_rasterize hands the image on as is); returns dL/d(render) [3,H,W]."""
+    target_chw = target_chw.contiguous()
+    require_gpu(render_chw, target_chw, loss_acc)
+    H, W = render_chw.shape[-2], render_chw.shape[-1]
+    v = torch.empty_like(render_chw)
+    check(load_library().lfs_mse_loss_chw_fwd_bwd(C.c_uint32(H), C.c_uint32(W), ptr(render_chw), ptr(target_chw), C.c_float(weight), ptr(v), ptr(loss_acc), stream()),
+          "mse_loss_chw_fwd_bwd")
+    return v
+
+
+def render_and_backward(settings: FastGSSettings, w2c: torch.Tensor, model: SplatModel, target_chw: torch.Tensor, weight: float, grads, loss_acc: torch.Tensor,
+                        densification_info: Optional[torch.Tensor] = None):
+    """One training view without an autograd graph (black background, MSE loss): forward, loss, backward; the gradients of
+    (means, sh0, shN, raw_scales, raw_quats, raw_opacities) are WRITTEN into `grads` (param-group order)."""
+    means, sh0, shN, raw_scales, raw_quats, raw_opac = [p.detach() for p in model.parameters()]
+    g_means, g_sh0, g_shN, g_scales, g_quats, g_opac = grads
+    with torch.no_grad():
+        image, alpha, pws, iws, n_inst = forward_wrapper(means, raw_scales, raw_quats, raw_opac, sh0, shN, w2c, settings)
+        v_image = mse_loss_chw_fwd_bwd(image, target_chw, weight, loss_acc)
+        if not hasattr(render_and_backward, "_zero") or render_and_backward._zero.shape != alpha.shape or render_and_backward._zero.device != alpha.device:
+            render_and_backward._zero = torch.zeros_like(alpha)
+        backward_wrapper(densification_info, v_image, render_and_backward._zero, image, alpha, means, raw_scales, raw_quats, sh0, shN, pws, iws, w2c, settings, n_inst,
+                         out=(g_means, g_scales, g_quats, g_opac.view(-1, 1), g_sh0, g_shN))
+    return image, alpha, n_inst

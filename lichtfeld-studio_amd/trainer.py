@@ -18,7 +18,7 @@ from .scenes import Scene
 class GutTrainer:
     def __init__(self, scene: Scene, device, iterations: int = 7000, world: int = 1, rank: int = 0,
                  views_per_rank: int = 1, fused_adam: bool = True, fused_l2: bool = True, loss: str = "mse", lambda_dssim: float = 0.2,
-                 strategy: Optional[str] = None, opt_params=None, scene_scale: float = 1.0, seed: int = 0):
+                 strategy: Optional[str] = None, opt_params=None, scene_scale: float = 1.0, seed: int = 0, rasterizer: str = "gut"):
         """strategy: None (fixed set of Gaussians: the benchmark), "mcmc" (strategies.MCMC: relocation + growth + SGLD noise, with
         the scale / opacity regularisers of trainer.cpp:132-158) or "default" (ADC; needs densification_info, see strategies.py).
         `seed` seeds the strategy's generator: the same on every rank, so replicas densify identically."""
@@ -27,6 +27,8 @@ class GutTrainer:
         self.scene = sc
         mk = lambda t: t.clone().contiguous().requires_grad_(True)
         self.model = SplatModel(mk(sc.means), mk(sc.sh0), mk(sc.shN), mk(sc.raw_scales), mk(sc.raw_quats), mk(sc.raw_opacities), sc.sh_degree)
+        self.rasterizer = rasterizer  # "gut" (3DGUT, the north-star path) | "fastgs" (the reference's default EWA rasterizer)
+        self._fg_settings = {}
         self.strategy = None
         self.scale_reg = self.opacity_reg = 0.0
         if strategy is not None:
@@ -66,6 +68,50 @@ class GutTrainer:
             return (self._last_radii[0] > 0).all(-1)
         return self._last_visible
 
+    def _fastgs_settings(self, view: int):
+        from .fastgs import FastGSSettings
+        st = self._fg_settings.get(view)
+        if st is None:  # intrinsics / camera centre read back once per view, not per step
+            sc = self.scene
+            K = sc.Ks[view].cpu()
+            w2c = sc.viewmats[view]
+            cam_pos = (-(w2c[:3, :3].T @ w2c[:3, 3])).contiguous()
+            deg = self.model.get_active_sh_degree()
+            st = FastGSSettings(cam_pos, (deg + 1) ** 2, sc.width, sc.height, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), 0.01, 1e10)
+            self._fg_settings[view] = st
+        st.active_sh_bases = (self.model.get_active_sh_degree() + 1) ** 2
+        return st
+
+    def _train_step_fastgs(self, targets, views, total_views):
+        """The same step through the fastgs (EWA) rasterizer: fused preprocess -> blend -> MSE -> blend backward -> preprocess
+        backward (raw-parameter gradients straight into the flat bucket) -> all-reduce -> fused Adam. Black background, MSE loss."""
+        from .fastgs import render_and_backward as fg_step
+        if self.bucket is None:
+            self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2])
+        params = self.model.parameters()
+        self.loss_acc.zero_()
+        if len(views) == 1:
+            grads = self.bucket.views
+            _, _, self.last_n_isects = fg_step(self._fastgs_settings(views[0]), self.scene.viewmats[views[0]:views[0] + 1].contiguous(), self.model,
+                                               targets[0], 1.0 / total_views, grads, self.loss_acc)
+        else:
+            if not hasattr(self, "_fg_tmp"):
+                self._fg_tmp = [torch.empty_like(v) for v in self.bucket.views]
+            for k, v in enumerate(views):
+                dst = self.bucket.views if k == 0 else self._fg_tmp
+                _, _, self.last_n_isects = fg_step(self._fastgs_settings(v), self.scene.viewmats[v:v + 1].contiguous(), self.model,
+                                                   targets[k % len(targets)], 1.0 / total_views, dst, self.loss_acc)
+                if k > 0:
+                    for a, b in zip(self.bucket.views, self._fg_tmp):
+                        a.add_(b)
+        self._last_radii = None
+        self.bucket.all_reduce(skip_deferred=self.iteration <= 1000)
+        for p, gv in zip(params, self.bucket.views):
+            p.grad = gv
+        self.optimizer.step(self.iteration)
+        self.scheduler.step()
+        return self.loss_acc
+
     def camera(self, view: int) -> Camera:
         sc = self.scene
         return Camera(sc.viewmats[view:view + 1].contiguous(), sc.Ks[view:view + 1].contiguous(), sc.width, sc.height)
@@ -77,6 +123,8 @@ class GutTrainer:
             views = lfs_dist.views_for_step(self.iteration - 1, self.rank, self.world, self.scene.viewmats.shape[0], self.views_per_rank)
         total_views = self.world * len(views)
         loss_value = None
+        if self.rasterizer == "fastgs":
+            return self._train_step_fastgs(targets, views, total_views)
         if self.fused_l2:
             from .fused import render_and_backward
             params = self.model.parameters()
