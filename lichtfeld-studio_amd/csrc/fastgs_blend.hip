@@ -191,14 +191,13 @@ __global__ void __launch_bounds__(256) fg_blend_bwd_kernel(
         Bsum = __builtin_fmaf(w, cv, Bsum);
         const float aD = valid ? f.alpha * dl_dalpha : 0.f;      // (no clamp mask on alpha, as in the reference)
         const float hx = -aD * f.dx, hy = -aD * f.dy;
-        float v[16];
-        v[0] = hx; v[1] = hy;                                     // -> dL/dmean2d = conic . (sum hx, sum hy)
-        v[2] = hx * f.dx; v[3] = hx * f.dy; v[4] = hy * f.dy;     // -> dL/dconic = 0.5 * (...)
-        v[5] = aD;
-        v[6] = w * gc0; v[7] = w * gc1; v[8] = w * gc2;
-#pragma unroll
-        for (int k = 9; k < 16; ++k) v[k] = 0.f;
-        wave_sum16_atomic(v, acc + size_t(e.x) * ACC_STRIDE, lane);
+        // accumulator row: {sum hx, sum hy, sum hx dx, sum hx dy | sum hy dy, dc.r, dc.g, dc.b | sum alpha dL/dalpha}
+        //   dL/dmean2d = conic . (sum hx, sum hy), dL/dconic = 0.5 (sum hx dx, sum hx dy, sum hy dy)   (fastgs_prep.hip)
+        const float v[8] = {hx, hy, hx * f.dx, hx * f.dy, hy * f.dy, w * gc0, w * gc1, w * gc2};
+        float* row = acc + size_t(e.x) * ACC_STRIDE;
+        wave_sum8_atomic(v, row, lane);
+        const float tot = wave_sum1(aD);
+        if (lane == 0) unsafeAtomicAdd(row + 8, tot);
     };
     walk_cell_list<-1>(cl, recs, lo - 1, lo, eval, []() { return true; });
 }
@@ -222,6 +221,7 @@ extern "C" int lfs_fastgs_render(
     uint32_t N, uint32_t width, uint32_t height, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
     void* instance_workspace, size_t instance_workspace_bytes, float* image, float* alpha, lfs_stream_t stream) {
     if (!primitive_workspace || !image || !alpha || width == 0 || height == 0 || n_instances < 0 || n_instances > 0x7FFFFFFFll) return LFS_E_INVALID;
+    if (N >= (1u << 26) || uint64_t(n_instances) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets of the record walker
     fgs::PrimWs w = fgs::prim_ws(primitive_workspace, N, width, height);
     if (primitive_workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     fgs::InstWs iw = fgs::inst_ws(instance_workspace, width, height, uint64_t(n_instances));

@@ -202,15 +202,15 @@ __global__ void __launch_bounds__(256) fg_preprocess_bwd_kernel(
         return;
     }
     const float4* a4 = reinterpret_cast<const float4*>(acc + size_t(i) * ACC_STRIDE);
-    const float4 a0 = a4[0], a1 = a4[1];
+    const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2];
     const GaussRec r = rec[i];
-    // accumulator row (fastgs_blend.hip): {S1 = sum h dx, S2 = sum h dy, sum h dx dx, sum h dx dy | sum h dy dy, sum alpha dL/dalpha, dc.r, dc.g | dc.b}
+    // accumulator row (fastgs_blend.hip): {S1 = sum h dx, S2 = sum h dy, sum h dx dx, sum h dx dy | sum h dy dy, dc.r, dc.g, dc.b | sum alpha dL/dalpha}
     // with h = -alpha dL/dalpha: dL/dmean2d = conic (S1, S2), dL/dconic = 0.5 (sum h dx dx, sum h dx dy, sum h dy dy)
     const float4 co = conic_opacity[i];
     const float dm2[2] = {co.x * a0.x + co.y * a0.y, co.y * a0.x + co.z * a0.y};
     const float dcon[3] = {0.5f * a0.z, 0.5f * a0.w, 0.5f * a1.x};
     const float opacity = r.r1.z;
-    g_opac_raw[i] = a1.y * (1.0f - opacity);
+    g_opac_raw[i] = a2.x * (1.0f - opacity);
     const float* m = means + 3 * size_t(i);
     const float dpos[3] = {0.f, 0.f, 0.f}; // (the colour -> position term is added by the SH backward kernel of sh.hip, which runs after this one)
     // ---- EWA backward
@@ -292,7 +292,7 @@ int launch_preprocess_bwd(uint32_t N, const float* means, const float* scales_ra
     // SH backward (convert_sh_to_color_backward, kernel_utils.cuh:38-106) with the coalesced three-phase kernel of sh.hip: reads dL/d(clamped colour) from the
     // accumulator rows (floats 6..8 of 16), the clamp mask from the record's colour (floats 8..10 of 16), writes g_sh0 / g_sh_rest fully, adds dL/dposition to g_means
     const uint32_t degree = f.active_sh_bases >= 16 ? 3 : f.active_sh_bases >= 9 ? 2 : f.active_sh_bases >= 4 ? 1 : 0;
-    return sh_records_bwd(N, 1 + f.total_rest, degree, means, f.cam_pos, sh0, sh_rest, w.n_touched, reinterpret_cast<const float*>(w.rec) + 8, 16, w.acc + 6, 16,
+    return sh_records_bwd(N, 1 + f.total_rest, degree, means, f.cam_pos, sh0, sh_rest, w.n_touched, reinterpret_cast<const float*>(w.rec) + 8, 16, w.acc + 5, 16,
                           g_sh0, g_sh_rest, g_means, s);
 }
 

@@ -76,24 +76,28 @@ LFS_DI void walk_cell_list(const int2* __restrict__ cl, const GaussRec* __restri
                            Eval&& eval, Alive&& alive) {
     if (n <= 0) return;
     const int32_t last = n - 1;
-    auto ent = [&](int32_t k) { return cl[first + STEP * min(k, last)]; };
+    // unsigned 32-bit BYTE offsets: the scalar load then takes (64-bit base, 32-bit offset register) and the per-entry address
+    // arithmetic is one shift instead of a sign extension + 64-bit shift + 64-bit add (the EWA forward, 22 VALU per entry, was
+    // limited by its ~19 SALU per entry). Limits: C*N < 2^26 records, cell list < 2^29 entries (checked by the callers).
+    auto ent = [&](int32_t k) { return *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(cl) + (uint32_t(first + STEP * min(k, last)) << 3)); };
+    auto rec_at = [&](int32_t g) { return *reinterpret_cast<const GaussRec*>(reinterpret_cast<const char*>(recs) + (uint32_t(g) << 6)); };
     int2 eA0 = ent(0), eA1 = ent(1), eB0 = ent(2), eB1 = ent(3);
     int2 nA0 = ent(4), nA1 = ent(5), nB0 = make_int2(0, 0), nB1 = make_int2(0, 0);
-    GaussRec A0 = recs[eA0.x], A1 = recs[eA1.x], B0 = recs[eB0.x], B1 = recs[eB1.x];
+    GaussRec A0 = rec_at(eA0.x), A1 = rec_at(eA1.x), B0 = rec_at(eB0.x), B1 = rec_at(eB1.x);
     for (int32_t k = 0; k < n; k += 4) {
         if (!alive()) break;
         eval(A0, eA0);
         if (k + 1 < n) eval(A1, eA1);
         asm volatile("; group B must have landed before group A is refilled" ::"s"(B0.r0.x), "s"(B1.r0.x));
         eA0 = nA0; eA1 = nA1;
-        A0 = recs[eA0.x]; A1 = recs[eA1.x];
+        A0 = rec_at(eA0.x); A1 = rec_at(eA1.x);
         nB0 = ent(k + 6); nB1 = ent(k + 7);
         if (k + 2 >= n || !alive()) break;
         eval(B0, eB0);
         if (k + 3 < n) eval(B1, eB1);
         asm volatile("; group A must have landed before group B is refilled" ::"s"(A0.r0.x), "s"(A1.r0.x));
         eB0 = nB0; eB1 = nB1;
-        B0 = recs[eB0.x]; B1 = recs[eB1.x];
+        B0 = rec_at(eB0.x); B1 = rec_at(eB1.x);
         nA0 = ent(k + 8); nA1 = ent(k + 9);
     }
 }
@@ -131,6 +135,41 @@ LFS_DI void wave_sum16_atomic(const float (&v)[16], float* __restrict__ dst, con
     t += dpp_mov<0x128>(t);
     // lane L holds the total of v[4 * (L >> 4) + 2 * (L & 1) + ((L >> 1) & 1)]
     if ((lane & 12) == 0) unsafeAtomicAdd(dst + 4 * (lane >> 4) + 2 * (lane & 1) + ((lane >> 1) & 1), t);
+}
+
+
+// 8 per-lane values -> 8 totals with one 8-lane atomic instruction (same halving scheme as wave_sum16_atomic: 18 VALU), and a
+// single value -> its total by a row butterfly + two cross-row folds (7 VALU). Used by the EWA blend backward (9 sums).
+LFS_DI void wave_sum8_atomic(const float (&v)[8], float* __restrict__ dst, const uint32_t lane) {
+    float w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 4]), false, false);
+        w[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    float u[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[j]), __float_as_uint(w[j + 2]), false, false);
+        u[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    // row r (16 lanes) holds partial sums of v[j + 2r] in u[j]
+    const bool b0 = lane & 1;
+    float t = (b0 ? u[1] : u[0]) + dpp_mov<0xB1>(b0 ? u[0] : u[1]);
+    t += dpp_mov<0x4E>(t);
+    t += dpp_mov<0x124>(t);
+    t += dpp_mov<0x128>(t);
+    if ((lane & 14) == 0) unsafeAtomicAdd(dst + 2 * (lane >> 4) + (lane & 1), t);
+}
+LFS_DI float wave_sum1(float v) { // every lane gets the total
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x128>(v);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
 } // namespace lfs

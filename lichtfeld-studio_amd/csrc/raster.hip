@@ -640,7 +640,7 @@ static int raster_check(uint32_t N, uint32_t channels, const lfs_cameras* cams, 
     if (cams->camera_model != LFS_CAMERA_PINHOLE && cams->camera_model != LFS_CAMERA_FISHEYE) return LFS_E_UNSUPPORTED;
     if (channels < 1 || channels > 4) return LFS_E_UNSUPPORTED; // Rasterization.cpp:65 asserts 3; depth modes need 1 and 4
     if (!raster_geom(cams, tile_size, g)) return LFS_E_UNSUPPORTED;
-    (void)N;
+    if (uint64_t(cams->C) * N >= (1ull << 26)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets of the record walker (4 GB of 64-B records)
     return LFS_OK;
 }
 
@@ -682,6 +682,7 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     if (rc) return rc;
     if (!render_colors || !render_alphas || !last_ids || !tile_offsets || !workspace) return LFS_E_INVALID;
     if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
+    if (uint64_t(n_isects) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
     const uint32_t C = cams->C;
     RasterWs w = raster_ws(workspace, C, N, g.cells, uint64_t(g.wpt) * uint64_t(n_isects));
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
@@ -719,6 +720,7 @@ static int raster_bwd_impl(
     if (rc) return rc;
     if (!workspace || !tile_offsets) return LFS_E_INVALID;
     if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
+    if (uint64_t(n_isects) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
     const uint32_t C = cams->C;
     RasterWs w = raster_ws(workspace, C, N, g.cells, uint64_t(g.wpt) * uint64_t(n_isects));
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
