@@ -212,7 +212,8 @@ LFS_API int lfs_mse_loss_chw_fwd_bwd(uint32_t H, uint32_t W, const float* render
  *        1) lfs_fastgs_preprocess   : per-primitive stage + per-tile counts; *n_instances (device int64) = list length
  *        2) (host reads n_instances: the reference syncs at the same place, forward.cu:114-117)
  *        3) lfs_fastgs_render       : instance lists (scatter + per-tile depth sort), per-cell culling, blending
- *        4) lfs_fastgs_backward     : blending backward + per-primitive backward; gradients FULLY written; densification_info
+ *        4) lfs_fastgs_backward     : blending backward + per-primitive backward; gradients FULLY written; sh_coefficients_0 may be
+ *                                     NULL (the reference's backward does not take it either); densification_info
  *                                     [2,N] (or NULL) is accumulated into (visibility count, screen-space gradient norm). */
 LFS_API size_t lfs_fastgs_primitive_workspace_bytes(uint32_t N, uint32_t width, uint32_t height);
 LFS_API size_t lfs_fastgs_instance_workspace_bytes(uint32_t width, uint32_t height, int64_t n_instances);
@@ -247,6 +248,29 @@ LFS_API size_t lfs_photometric_loss_workspace_bytes(uint32_t H, uint32_t W);
 LFS_API int lfs_photometric_loss_fwd_bwd(uint32_t H, uint32_t W, const float* render_hwc, const float* target_chw, float lambda_dssim,
                                          float weight, float* v_render_hwc, float* loss, void* workspace, size_t workspace_bytes,
                                          lfs_stream_t stream);
+/* ... and for a CHW render [3,H,W] (the fastgs rasterizer's image layout), which is NOT clamped (fast_rasterizer.cpp:63 hands
+ * the image to the loss as is); v_render_chw [3,H,W] */
+LFS_API int lfs_photometric_loss_chw_fwd_bwd(uint32_t H, uint32_t W, const float* render_chw, const float* target_chw, float lambda_dssim,
+                                             float weight, float* v_render_chw, float* loss, void* workspace, size_t workspace_bytes,
+                                             lfs_stream_t stream);
+
+/* ---- bilateral-grid appearance model (row 2 of §8f, BASELINE config 5): gs::bilateral_grid::slice_forward_cuda /
+ *      slice_backward_cuda / tv_loss_forward_cuda / tv_loss_backward_cuda (include/kernels/bilateral_grid.cuh:12-33,
+ *      src/training/kernels/bilateral_grid_{forward,backward,tv}.cu). grid [12,L,H,W]; image h x w (both >= 2), uniform
+ *      x/y coordinates, guidance z = luma. Extensions: chw != 0 reads / writes the image planes as [3,h,w] instead of
+ *      [h,w,3]; clamp_input != 0 folds BilateralGrid::apply's clamp(rgb, 0, 1) (components/bilateral_grid.cpp:115) into
+ *      both passes. grad_grid is ACCUMULATED into (the reference zero-fills, then atomically adds: zero it for the same
+ *      result); grad_rgb is fully written. TV: grids [N,12,L,H,W]; *loss += weight * tv; the backward takes dL/dloss as a
+ *      host float (the reference reads it with .item(), bilateral_grid_tv.cu:181). */
+LFS_API int lfs_bilateral_slice_fwd(uint32_t L, uint32_t H, uint32_t W, uint32_t h, uint32_t w, const float* grid, const float* rgb,
+                                    uint32_t chw, uint32_t clamp_input, float* output, lfs_stream_t stream);
+LFS_API int lfs_bilateral_slice_bwd(uint32_t L, uint32_t H, uint32_t W, uint32_t h, uint32_t w, const float* grid, const float* rgb,
+                                    const float* grad_output, uint32_t chw, uint32_t clamp_input, float* grad_grid, float* grad_rgb,
+                                    lfs_stream_t stream);
+LFS_API int lfs_bilateral_tv_loss_fwd(uint32_t N, uint32_t L, uint32_t H, uint32_t W, const float* grids, float weight, float* loss,
+                                      lfs_stream_t stream);
+LFS_API int lfs_bilateral_tv_loss_bwd(uint32_t N, uint32_t L, uint32_t H, uint32_t W, const float* grids, float grad_output, uint32_t accumulate,
+                                      float* grad_grids, lfs_stream_t stream);
 
 /* ---- gsplat::quats_to_rotmats (gsplat/Ops.h:45-48, QuatToRotmatCUDA.cu:14-39): rotmats [N,3,3] row-major */
 LFS_API int lfs_quats_to_rotmats(uint32_t N, const float* quats, float* rotmats, lfs_stream_t stream);

@@ -72,3 +72,36 @@ void adam_step_wrapper(torch::Tensor& param, torch::Tensor& exp_avg, torch::Tens
                        const float lr, const float beta1, const float beta2, const float eps, const float bias_correction1_rcp,
                        const float bias_correction2_sqrt_rcp);
 } // namespace fast_gs::optimizer
+
+// ---- fastgs/rasterization/include/rasterization_api.h:27-75, include/kernels/ssim.cuh:11-30 ----
+namespace fast_gs::rasterization {
+// (image, alpha, per_primitive_buffers, per_tile_buffers, per_instance_buffers, per_bucket_buffers,
+//  n_visible_primitives, n_instances, n_buckets, primitive_primitive_indices_selector, instance_primitive_indices_selector).
+// The state of this implementation lives in per_primitive_buffers (primitive workspace) and per_instance_buffers (instance
+// workspace); the other two buffers are empty, n_visible_primitives / n_buckets / the selectors are 0.
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, int, int, int, int, int> forward_wrapper(
+    const torch::Tensor& means, const torch::Tensor& scales_raw, const torch::Tensor& rotations_raw, const torch::Tensor& opacities_raw,
+    const torch::Tensor& sh_coefficients_0, const torch::Tensor& sh_coefficients_rest, const torch::Tensor& w2c, const torch::Tensor& cam_position,
+    const int active_sh_bases, const int width, const int height, const float focal_x, const float focal_y, const float center_x,
+    const float center_y, const float near_plane, const float far_plane);
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> backward_wrapper(
+    torch::Tensor& densification_info, const torch::Tensor& grad_image, const torch::Tensor& grad_alpha, const torch::Tensor& image,
+    const torch::Tensor& alpha, const torch::Tensor& means, const torch::Tensor& scales_raw, const torch::Tensor& rotations_raw,
+    const torch::Tensor& sh_coefficients_rest, const torch::Tensor& per_primitive_buffers, const torch::Tensor& per_tile_buffers,
+    const torch::Tensor& per_instance_buffers, const torch::Tensor& per_bucket_buffers, const torch::Tensor& w2c, const torch::Tensor& cam_position,
+    const int active_sh_bases, const int width, const int height, const float focal_x, const float focal_y, const float center_x,
+    const float center_y, const float near_plane, const float far_plane, const int n_visible_primitives, const int n_instances,
+    const int n_buckets, const int primitive_primitive_indices_selector, const int instance_primitive_indices_selector);
+} // namespace fast_gs::rasterization
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> fusedssim(float C1, float C2, torch::Tensor& img1, torch::Tensor& img2, bool train);
+torch::Tensor fusedssim_backward(float C1, float C2, torch::Tensor& img1, torch::Tensor& img2, torch::Tensor& dL_dmap, torch::Tensor& dm_dmu1,
+                                 torch::Tensor& dm_dsigma1_sq, torch::Tensor& dm_dsigma12);
+
+// ---- include/kernels/bilateral_grid.cuh:12-33 ----
+namespace gs::bilateral_grid {
+void slice_forward_cuda(const torch::Tensor& grid, const torch::Tensor& rgb, torch::Tensor& output, bool use_uniform_coords = true);
+std::tuple<torch::Tensor, torch::Tensor> slice_backward_cuda(const torch::Tensor& grid, const torch::Tensor& rgb, const torch::Tensor& grad_output);
+torch::Tensor tv_loss_forward_cuda(const torch::Tensor& grids);
+torch::Tensor tv_loss_backward_cuda(const torch::Tensor& grids, const torch::Tensor& grad_output);
+} // namespace gs::bilateral_grid

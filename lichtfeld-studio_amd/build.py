@@ -30,6 +30,7 @@ SOURCES = {
     "adam.hip": ["-ffp-contract=off"],
     "l2_fused.hip": ["-ffp-contract=off"],
     "ssim.hip": ["-ffp-contract=off"],
+    "bilateral_grid.hip": ["-ffp-contract=off"],
     "fastgs_prep.hip": ["-ffp-contract=off"],
     "fastgs_blend.hip": ["-fno-slp-vectorize"],
     "prof.hip": [],

@@ -271,7 +271,7 @@ extern "C" int lfs_fastgs_backward(
     fgs::InstWs iw = fgs::inst_ws(instance_workspace, width, height, uint64_t(n_instances));
     if (!instance_workspace || instance_workspace_bytes < iw.bytes) return LFS_E_WORKSPACE;
     if (N == 0) return LFS_OK;
-    if (!means || !scales_raw || !rotations_raw || !sh_coefficients_0 || !grad_means || !grad_scales_raw || !grad_rotations_raw || !grad_opacities_raw || !grad_sh_coefficients_0 ||
+    if (!means || !scales_raw || !rotations_raw || !grad_means || !grad_scales_raw || !grad_rotations_raw || !grad_opacities_raw || !grad_sh_coefficients_0 ||
         (total_bases_sh_rest > 0 && (!sh_coefficients_rest || !grad_sh_coefficients_rest))) return LFS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const fgs::Frame f = make_frame(w2c, cam_position, active_sh_bases, total_bases_sh_rest, width, height, fx, fy, cx, cy, near_plane, far_plane);

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
         else { vc[0] = o0; vc[1] = o1; vc[2] = o2; }
         if (want_dirs) {
             float sk = 0.f;
-            if (k < Kd && (v0 != 0.f || v1 != 0.f || v2 != 0.f)) {
+            if (k >= 1 && k < Kd && (v0 != 0.f || v1 != 0.f || v2 != 0.f)) { // (basis 0 is constant: no direction gradient, sh0 is not read)
                 const float* cf = sh_coef<MODEL>(a.coeffs, a.sh0, a.shN, a.K, g, k);
                 sk = cf[0] * v0 + cf[1] * v1 + cf[2] * v2;
             }

@@ -254,3 +254,134 @@ void adam_step_wrapper(torch::Tensor& param, torch::Tensor& exp_avg, torch::Tens
               lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp);
 }
 } // namespace fast_gs::optimizer
+
+// ---------------------------------------------------------------------------------------------------------
+// fast_gs::rasterization (rasterization_api.h:27-75, src/rasterization_api.cu) and fusedssim (ssim.cuh:11-30)
+// ---------------------------------------------------------------------------------------------------------
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, int, int, int, int, int>
+fast_gs::rasterization::forward_wrapper(
+    const torch::Tensor& means, const torch::Tensor& scales_raw, const torch::Tensor& rotations_raw, const torch::Tensor& opacities_raw,
+    const torch::Tensor& sh_coefficients_0, const torch::Tensor& sh_coefficients_rest, const torch::Tensor& w2c, const torch::Tensor& cam_position,
+    const int active_sh_bases, const int width, const int height, const float focal_x, const float focal_y, const float center_x,
+    const float center_y, const float near_plane, const float far_plane) {
+    LFS_DEVICE_GUARD(means);
+    LFS_CHECK_INPUT(means); LFS_CHECK_INPUT(scales_raw); LFS_CHECK_INPUT(rotations_raw); LFS_CHECK_INPUT(opacities_raw);
+    LFS_CHECK_INPUT(sh_coefficients_0); LFS_CHECK_INPUT(sh_coefficients_rest);
+    const uint32_t N = (uint32_t)means.size(0), total_rest = (uint32_t)sh_coefficients_rest.size(1);
+    const at::Tensor w2c_c = w2c.contiguous(), cam_c = cam_position.contiguous();
+    const auto fopt = means.options().dtype(at::kFloat), bopt = means.options().dtype(at::kByte);
+    at::Tensor image = at::empty({3, height, width}, fopt), alpha = at::empty({1, height, width}, fopt);
+    at::Tensor prim = at::empty({(int64_t)lfs_fastgs_primitive_workspace_bytes(N, (uint32_t)width, (uint32_t)height)}, bopt);
+    at::Tensor n_inst_dev = at::zeros({1}, means.options().dtype(at::kLong));
+    check_rc(lfs_fastgs_preprocess(N, means.data_ptr<float>(), scales_raw.data_ptr<float>(), rotations_raw.data_ptr<float>(), opacities_raw.data_ptr<float>(),
+                                   sh_coefficients_0.data_ptr<float>(), total_rest ? sh_coefficients_rest.data_ptr<float>() : nullptr, total_rest,
+                                   w2c_c.data_ptr<float>(), cam_c.data_ptr<float>(), (uint32_t)active_sh_bases, (uint32_t)width, (uint32_t)height,
+                                   focal_x, focal_y, center_x, center_y, near_plane, far_plane, n_inst_dev.data_ptr<int64_t>(), prim.data_ptr(),
+                                   (size_t)prim.numel(), cur_stream()), "fast_gs::rasterization::forward (preprocess)");
+    const int64_t n_instances = n_inst_dev.item<int64_t>(); // the host sync of forward.cu:114-117
+    at::Tensor inst = at::empty({(int64_t)std::max<size_t>(256, lfs_fastgs_instance_workspace_bytes((uint32_t)width, (uint32_t)height, n_instances))}, bopt);
+    check_rc(lfs_fastgs_render(N, (uint32_t)width, (uint32_t)height, n_instances, prim.data_ptr(), (size_t)prim.numel(), inst.data_ptr(), (size_t)inst.numel(),
+                               image.data_ptr<float>(), alpha.data_ptr<float>(), cur_stream()), "fast_gs::rasterization::forward (render)");
+    at::Tensor none = at::empty({0}, bopt);
+    return {image, alpha, prim, none, inst, none.clone(), 0, (int)n_instances, 0, 0, 0};
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+fast_gs::rasterization::backward_wrapper(
+    torch::Tensor& densification_info, const torch::Tensor& grad_image, const torch::Tensor& grad_alpha, const torch::Tensor& image,
+    const torch::Tensor& alpha, const torch::Tensor& means, const torch::Tensor& scales_raw, const torch::Tensor& rotations_raw,
+    const torch::Tensor& sh_coefficients_rest, const torch::Tensor& per_primitive_buffers, const torch::Tensor& per_tile_buffers,
+    const torch::Tensor& per_instance_buffers, const torch::Tensor& per_bucket_buffers, const torch::Tensor& w2c, const torch::Tensor& cam_position,
+    const int active_sh_bases, const int width, const int height, const float focal_x, const float focal_y, const float center_x,
+    const float center_y, const float near_plane, const float far_plane, const int n_visible_primitives, const int n_instances,
+    const int n_buckets, const int primitive_primitive_indices_selector, const int instance_primitive_indices_selector) {
+    (void)image; (void)per_tile_buffers; (void)per_bucket_buffers; (void)n_visible_primitives; (void)n_buckets;
+    (void)primitive_primitive_indices_selector; (void)instance_primitive_indices_selector;
+    LFS_DEVICE_GUARD(means);
+    TORCH_CHECK(!w2c.requires_grad(), "pose optimisation (grad_w2c) is not implemented by this backend");
+    const uint32_t N = (uint32_t)means.size(0), total_rest = (uint32_t)sh_coefficients_rest.size(1);
+    const auto fopt = means.options().dtype(at::kFloat);
+    at::Tensor g_means = at::empty({N, 3}, fopt), g_scales = at::empty({N, 3}, fopt), g_rot = at::empty({N, 4}, fopt), g_opac = at::empty({N, 1}, fopt);
+    at::Tensor g_sh0 = at::empty({N, 1, 3}, fopt), g_shr = at::empty({N, (int64_t)total_rest, 3}, fopt);
+    const at::Tensor gi = grad_image.contiguous(), ga = grad_alpha.contiguous(), al = alpha.contiguous(), w2c_c = w2c.contiguous(), cam_c = cam_position.contiguous();
+    const bool dens = densification_info.defined() && densification_info.dim() > 0 && densification_info.size(0) > 0;
+    check_rc(lfs_fastgs_backward(N, means.data_ptr<float>(), scales_raw.data_ptr<float>(), rotations_raw.data_ptr<float>(), nullptr,
+                                 total_rest ? sh_coefficients_rest.data_ptr<float>() : nullptr, total_rest, w2c_c.data_ptr<float>(), cam_c.data_ptr<float>(),
+                                 (uint32_t)active_sh_bases, (uint32_t)width, (uint32_t)height, focal_x, focal_y, center_x, center_y, near_plane, far_plane,
+                                 (int64_t)n_instances, per_primitive_buffers.data_ptr(), (size_t)per_primitive_buffers.numel(), per_instance_buffers.data_ptr(),
+                                 (size_t)per_instance_buffers.numel(), gi.data_ptr<float>(), ga.data_ptr<float>(), al.data_ptr<float>(),
+                                 dens ? densification_info.data_ptr<float>() : nullptr, g_means.data_ptr<float>(), g_scales.data_ptr<float>(),
+                                 g_rot.data_ptr<float>(), g_opac.data_ptr<float>(), g_sh0.data_ptr<float>(), total_rest ? g_shr.data_ptr<float>() : nullptr,
+                                 cur_stream()), "fast_gs::rasterization::backward");
+    return {g_means, g_scales, g_rot, g_opac, g_sh0, g_shr, torch::Tensor()};
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> fusedssim(float C1, float C2, torch::Tensor& img1, torch::Tensor& img2, bool train) {
+    LFS_DEVICE_GUARD(img1);
+    const at::Tensor a = img1.contiguous(), b = img2.contiguous();
+    TORCH_CHECK(a.dim() == 4 && a.sizes() == b.sizes(), "fusedssim expects two [B,CH,H,W] tensors of the same shape");
+    at::Tensor map = at::empty_like(a);
+    at::Tensor d1 = train ? at::empty_like(a) : at::empty({0}, a.options()), d2 = train ? at::empty_like(a) : at::empty({0}, a.options()),
+               d3 = train ? at::empty_like(a) : at::empty({0}, a.options());
+    check_rc(lfs_fused_ssim_fwd((uint32_t)a.size(0), (uint32_t)a.size(1), (uint32_t)a.size(2), (uint32_t)a.size(3), C1, C2, a.data_ptr<float>(), b.data_ptr<float>(),
+                                map.data_ptr<float>(), train ? d1.data_ptr<float>() : nullptr, train ? d2.data_ptr<float>() : nullptr,
+                                train ? d3.data_ptr<float>() : nullptr, cur_stream()), "fusedssim");
+    return {map, d1, d2, d3};
+}
+
+torch::Tensor fusedssim_backward(float C1, float C2, torch::Tensor& img1, torch::Tensor& img2, torch::Tensor& dL_dmap, torch::Tensor& dm_dmu1,
+                                 torch::Tensor& dm_dsigma1_sq, torch::Tensor& dm_dsigma12) {
+    LFS_DEVICE_GUARD(img1);
+    const at::Tensor a = img1.contiguous(), b = img2.contiguous(), g = dL_dmap.contiguous(), d1 = dm_dmu1.contiguous(), d2 = dm_dsigma1_sq.contiguous(),
+                     d3 = dm_dsigma12.contiguous();
+    at::Tensor out = at::empty_like(a);
+    check_rc(lfs_fused_ssim_bwd((uint32_t)a.size(0), (uint32_t)a.size(1), (uint32_t)a.size(2), (uint32_t)a.size(3), C1, C2, a.data_ptr<float>(), b.data_ptr<float>(),
+                                g.data_ptr<float>(), d1.data_ptr<float>(), d2.data_ptr<float>(), d3.data_ptr<float>(), out.data_ptr<float>(), cur_stream()),
+             "fusedssim_backward");
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gs::bilateral_grid (include/kernels/bilateral_grid.cuh:12-33)
+// ---------------------------------------------------------------------------------------------------------
+void gs::bilateral_grid::slice_forward_cuda(const torch::Tensor& grid, const torch::Tensor& rgb, torch::Tensor& output, bool use_uniform_coords) {
+    (void)use_uniform_coords; // the reference ignores it as well: only uniform coordinates exist (bilateral_grid_forward.cu:96-115)
+    LFS_DEVICE_GUARD(grid);
+    LFS_CHECK_INPUT(grid); LFS_CHECK_INPUT(rgb); LFS_CHECK_INPUT(output);
+    TORCH_CHECK(grid.dim() == 4 && grid.size(0) == 12, "Grid must be [12, L, H, W]");
+    TORCH_CHECK(rgb.dim() == 3 && rgb.size(2) == 3 && output.sizes() == rgb.sizes(), "RGB / output must be [H, W, 3]");
+    check_rc(lfs_bilateral_slice_fwd((uint32_t)grid.size(1), (uint32_t)grid.size(2), (uint32_t)grid.size(3), (uint32_t)rgb.size(0), (uint32_t)rgb.size(1),
+                                     grid.data_ptr<float>(), rgb.data_ptr<float>(), 0, 0, output.data_ptr<float>(), cur_stream()), "bilateral_grid::slice_forward_cuda");
+}
+
+std::tuple<torch::Tensor, torch::Tensor> gs::bilateral_grid::slice_backward_cuda(const torch::Tensor& grid, const torch::Tensor& rgb, const torch::Tensor& grad_output) {
+    LFS_DEVICE_GUARD(grid);
+    LFS_CHECK_INPUT(grid); LFS_CHECK_INPUT(rgb); LFS_CHECK_INPUT(grad_output);
+    TORCH_CHECK(grid.dim() == 4 && grid.size(0) == 12, "Grid must be [12, L, H, W]");
+    TORCH_CHECK(rgb.dim() == 3 && rgb.size(2) == 3 && grad_output.sizes() == rgb.sizes(), "RGB / grad_output must be [H, W, 3]");
+    at::Tensor grad_grid = at::zeros_like(grid), grad_rgb = at::empty_like(rgb);
+    check_rc(lfs_bilateral_slice_bwd((uint32_t)grid.size(1), (uint32_t)grid.size(2), (uint32_t)grid.size(3), (uint32_t)rgb.size(0), (uint32_t)rgb.size(1),
+                                     grid.data_ptr<float>(), rgb.data_ptr<float>(), grad_output.data_ptr<float>(), 0, 0, grad_grid.data_ptr<float>(),
+                                     grad_rgb.data_ptr<float>(), cur_stream()), "bilateral_grid::slice_backward_cuda");
+    return {grad_grid, grad_rgb};
+}
+
+torch::Tensor gs::bilateral_grid::tv_loss_forward_cuda(const torch::Tensor& grids) {
+    LFS_DEVICE_GUARD(grids);
+    LFS_CHECK_INPUT(grids);
+    TORCH_CHECK(grids.dim() == 5 && grids.size(1) == 12, "Grids must be [N, 12, L, H, W]");
+    at::Tensor tv = at::zeros({}, grids.options());
+    check_rc(lfs_bilateral_tv_loss_fwd((uint32_t)grids.size(0), (uint32_t)grids.size(2), (uint32_t)grids.size(3), (uint32_t)grids.size(4), grids.data_ptr<float>(), 1.f,
+                                       tv.data_ptr<float>(), cur_stream()), "bilateral_grid::tv_loss_forward_cuda");
+    return tv;
+}
+
+torch::Tensor gs::bilateral_grid::tv_loss_backward_cuda(const torch::Tensor& grids, const torch::Tensor& grad_output) {
+    LFS_DEVICE_GUARD(grids);
+    LFS_CHECK_INPUT(grids);
+    TORCH_CHECK(grids.dim() == 5 && grids.size(1) == 12, "Grids must be [N, 12, L, H, W]");
+    at::Tensor grad = at::empty_like(grids);
+    check_rc(lfs_bilateral_tv_loss_bwd((uint32_t)grids.size(0), (uint32_t)grids.size(2), (uint32_t)grids.size(3), (uint32_t)grids.size(4), grids.data_ptr<float>(),
+                                       grad_output.item<float>(), 0, grad.data_ptr<float>(), cur_stream()), "bilateral_grid::tv_loss_backward_cuda");
+    return grad;
+}

@@ -47,4 +47,27 @@ PYBIND11_MODULE(_lfs_torch_ops, m) {
           });
     m.def("adam_step_wrapper", [](at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, at::Tensor grad, float lr, float b1, float b2,
                                   float eps, float bc1, float bc2) { fast_gs::optimizer::adam_step_wrapper(param, exp_avg, exp_avg_sq, grad, lr, b1, b2, eps, bc1, bc2); });
+    m.def("fastgs_forward_wrapper",
+          [](at::Tensor means, at::Tensor scales_raw, at::Tensor rotations_raw, at::Tensor opacities_raw, at::Tensor sh0, at::Tensor sh_rest, at::Tensor w2c,
+             at::Tensor cam_position, int active_sh_bases, int width, int height, float fx, float fy, float cx, float cy, float near_plane, float far_plane) {
+              return fast_gs::rasterization::forward_wrapper(means, scales_raw, rotations_raw, opacities_raw, sh0, sh_rest, w2c, cam_position,
+                                                             active_sh_bases, width, height, fx, fy, cx, cy, near_plane, far_plane);
+          });
+    m.def("fastgs_backward_wrapper",
+          [](at::Tensor densification_info, at::Tensor grad_image, at::Tensor grad_alpha, at::Tensor image, at::Tensor alpha, at::Tensor means,
+             at::Tensor scales_raw, at::Tensor rotations_raw, at::Tensor sh_rest, at::Tensor prim, at::Tensor tile, at::Tensor inst, at::Tensor bucket,
+             at::Tensor w2c, at::Tensor cam_position, int active_sh_bases, int width, int height, float fx, float fy, float cx, float cy,
+             float near_plane, float far_plane, int n_visible, int n_instances, int n_buckets, int sel0, int sel1) {
+              return fast_gs::rasterization::backward_wrapper(densification_info, grad_image, grad_alpha, image, alpha, means, scales_raw, rotations_raw,
+                                                              sh_rest, prim, tile, inst, bucket, w2c, cam_position, active_sh_bases, width, height, fx, fy,
+                                                              cx, cy, near_plane, far_plane, n_visible, n_instances, n_buckets, sel0, sel1);
+          });
+    m.def("fusedssim", [](float C1, float C2, at::Tensor a, at::Tensor b, bool train) { return fusedssim(C1, C2, a, b, train); });
+    m.def("fusedssim_backward", [](float C1, float C2, at::Tensor a, at::Tensor b, at::Tensor g, at::Tensor d1, at::Tensor d2, at::Tensor d3) {
+        return fusedssim_backward(C1, C2, a, b, g, d1, d2, d3);
+    });
+    m.def("bilateral_slice_forward", [](at::Tensor grid, at::Tensor rgb) { at::Tensor out = at::empty_like(rgb); gs::bilateral_grid::slice_forward_cuda(grid, rgb, out, true); return out; });
+    m.def("bilateral_slice_backward", [](at::Tensor grid, at::Tensor rgb, at::Tensor go) { return gs::bilateral_grid::slice_backward_cuda(grid, rgb, go); });
+    m.def("bilateral_tv_loss_forward", [](at::Tensor grids) { return gs::bilateral_grid::tv_loss_forward_cuda(grids); });
+    m.def("bilateral_tv_loss_backward", [](at::Tensor grids, at::Tensor go) { return gs::bilateral_grid::tv_loss_backward_cuda(grids, go); });
 }

@@ -74,6 +74,12 @@ class GradBucket:
                 buf.div_(dist.get_world_size())
 
 
+def all_reduce_sum(t: torch.Tensor) -> None:
+    """In-place sum over ranks of a replicated-side tensor (bilateral-grid gradient, densification_info); no-op at world 1."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -138,14 +138,24 @@ def mse_loss_chw_fwd_bwd(render_chw: torch.Tensor, target_chw: torch.Tensor, wei
 
 
 def render_and_backward(settings: FastGSSettings, w2c: torch.Tensor, model: SplatModel, target_chw: torch.Tensor, weight: float, grads, loss_acc: torch.Tensor,
-                        densification_info: Optional[torch.Tensor] = None):
-    """One training view without an autograd graph (black background, MSE loss): forward, loss, backward; the gradients of
-    (means, sh0, shN, raw_scales, raw_quats, raw_opacities) are WRITTEN into `grads` (param-group order)."""
+                        densification_info: Optional[torch.Tensor] = None, loss: str = "mse", lambda_dssim: float = 0.2, bilateral=None, image_idx: int = 0):
+    """One training view without an autograd graph (black background; loss "mse" or the trainer's "l1_ssim", trainer.cpp:122-125):
+    forward, [bilateral-grid slice, trainer.cpp:662-664,] loss, backward; the gradients of (means, sh0, shN, raw_scales, raw_quats,
+    raw_opacities) are WRITTEN into `grads` (param-group order); the bilateral grid's gradient is accumulated into its .grad."""
     means, sh0, shN, raw_scales, raw_quats, raw_opac = [p.detach() for p in model.parameters()]
     g_means, g_sh0, g_shN, g_scales, g_quats, g_opac = grads
     with torch.no_grad():
         image, alpha, pws, iws, n_inst = forward_wrapper(means, raw_scales, raw_quats, raw_opac, sh0, shN, w2c, settings)
-        v_image = mse_loss_chw_fwd_bwd(image, target_chw, weight, loss_acc)
+        shown = image if bilateral is None else bilateral.apply_fused(image, image_idx, chw=True)
+        if loss == "l1_ssim":
+            from .losses import photometric_loss_chw_fwd_bwd
+            v_image = photometric_loss_chw_fwd_bwd(shown, target_chw, lambda_dssim, weight, loss_acc)
+        elif loss == "mse":
+            v_image = mse_loss_chw_fwd_bwd(shown, target_chw, weight, loss_acc)
+        else:
+            raise ValueError(f"unknown loss {loss!r}")
+        if bilateral is not None:
+            v_image = bilateral.apply_fused_backward(image, image_idx, v_image, chw=True)
         if not hasattr(render_and_backward, "_zero") or render_and_backward._zero.shape != alpha.shape or render_and_backward._zero.device != alpha.device:
             render_and_backward._zero = torch.zeros_like(alpha)
         backward_wrapper(densification_info, v_image, render_and_backward._zero, image, alpha, means, raw_scales, raw_quats, sh0, shN, pws, iws, w2c, settings, n_inst,

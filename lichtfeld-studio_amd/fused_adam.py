@@ -88,6 +88,26 @@ class ExponentialLR:
         self.opt.param_groups[self.idx]["lr"] *= self.gamma
 
 
+class WarmupExponentialLR:
+    """scheduler.hpp / scheduler.cpp:27-63 — linear warm-up from warmup_start_factor to 1 over warmup_steps, exponential decay after;
+    param_group_index -1 = all groups. Works on FusedAdam and torch.optim optimizers (both expose param_groups[i]["lr"])."""
+
+    def __init__(self, optimizer, gamma: float, warmup_steps: int = 0, warmup_start_factor: float = 1.0, param_group_index: int = -1):
+        self.opt, self.gamma, self.warmup_steps, self.start, self.idx = optimizer, gamma, warmup_steps, warmup_start_factor, param_group_index
+        self.current_step = 0
+        self.initial_lrs = [g["lr"] for g in optimizer.param_groups]
+
+    def step(self) -> None:
+        self.current_step += 1
+        groups = range(len(self.opt.param_groups)) if self.idx < 0 else [self.idx]
+        for i in groups:
+            if self.current_step <= self.warmup_steps:
+                factor = self.start + (1.0 - self.start) * (self.current_step / self.warmup_steps)
+            else:
+                factor = self.gamma ** (self.current_step - self.warmup_steps)
+            self.opt.param_groups[i]["lr"] = self.initial_lrs[i] * factor
+
+
 def default_param_groups(model, scene_scale: float = 1.0, means_lr=1.6e-4, shs_lr=2.5e-3, scaling_lr=5e-3, rotation_lr=1e-3, opacity_lr=5e-2):
     """strategy_utils.cpp:20-45 with the learning rates of eval/default_optimization_params.json."""
     means, sh0, shN, scales, quats, opac = model.parameters()

@@ -115,3 +115,17 @@ def photometric_loss_fwd_bwd(render_hwc: torch.Tensor, target_chw: torch.Tensor,
     check(lib.lfs_photometric_loss_fwd_bwd(C.c_uint32(H), C.c_uint32(W), ptr(render_hwc), ptr(target_chw), C.c_float(lambda_dssim), C.c_float(weight),
                                            ptr(v), ptr(loss_acc), ptr(ws), C.c_size_t(ws.numel()), stream()), "photometric_loss_fwd_bwd")
     return v
+
+
+def photometric_loss_chw_fwd_bwd(render_chw: torch.Tensor, target_chw: torch.Tensor, lambda_dssim: float, weight: float, loss_acc: torch.Tensor) -> torch.Tensor:
+    """The same for the fastgs rasterizer's CHW image, which reaches the loss un-clamped (fast_rasterizer.cpp:63): returns dL/d(render) [3,H,W]."""
+    target_chw = target_chw.contiguous()
+    require_gpu(render_chw, target_chw, loss_acc)
+    H, W = render_chw.shape[-2], render_chw.shape[-1]
+    assert render_chw.is_contiguous() and tuple(render_chw.shape[-3:]) == (3, H, W) and tuple(target_chw.shape) == (3, H, W), (render_chw.shape, target_chw.shape)
+    lib = load_library()
+    ws = workspace(lib.lfs_photometric_loss_workspace_bytes(C.c_uint32(H), C.c_uint32(W)), render_chw.device, "photometric")
+    v = torch.empty_like(render_chw)
+    check(lib.lfs_photometric_loss_chw_fwd_bwd(C.c_uint32(H), C.c_uint32(W), ptr(render_chw), ptr(target_chw), C.c_float(lambda_dssim), C.c_float(weight),
+                                               ptr(v), ptr(loss_acc), ptr(ws), C.c_size_t(ws.numel()), stream()), "photometric_loss_chw_fwd_bwd")
+    return v

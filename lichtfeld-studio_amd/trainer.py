@@ -18,7 +18,8 @@ from .scenes import Scene
 class GutTrainer:
     def __init__(self, scene: Scene, device, iterations: int = 7000, world: int = 1, rank: int = 0,
                  views_per_rank: int = 1, fused_adam: bool = True, fused_l2: bool = True, loss: str = "mse", lambda_dssim: float = 0.2,
-                 strategy: Optional[str] = None, opt_params=None, scene_scale: float = 1.0, seed: int = 0, rasterizer: str = "gut"):
+                 strategy: Optional[str] = None, opt_params=None, scene_scale: float = 1.0, seed: int = 0, rasterizer: str = "gut",
+                 use_bilateral_grid: bool = False, bilateral_grid_dims=(16, 16, 8), bilateral_grid_lr: float = 2e-3, tv_loss_weight: float = 10.0):
         """strategy: None (fixed set of Gaussians: the benchmark), "mcmc" (strategies.MCMC: relocation + growth + SGLD noise, with
         the scale / opacity regularisers of trainer.cpp:132-158) or "default" (ADC; needs densification_info, see strategies.py).
         `seed` seeds the strategy's generator: the same on every rank, so replicas densify identically."""
@@ -30,6 +31,8 @@ class GutTrainer:
         self.rasterizer = rasterizer  # "gut" (3DGUT, the north-star path) | "fastgs" (the reference's default EWA rasterizer)
         self._fg_settings = {}
         self.strategy = None
+        self.strategy_kind = strategy
+        self.densification_info = None   # [2,N]: fastgs backward's (visibility count, screen-space gradient norm) for ADC
         self.scale_reg = self.opacity_reg = 0.0
         if strategy is not None:
             from . import strategies
@@ -45,6 +48,18 @@ class GutTrainer:
             self.optimizer = FusedAdam(default_param_groups(self.model), fused=fused_adam)
             self.scheduler = ExponentialLR(self.optimizer, gamma=0.01 ** (1.0 / iterations), param_group_index=0)
         self.bg = torch.zeros(3, device=device)
+        # appearance model of BASELINE config 5 (trainer.cpp:66-99: Adam(lr, eps 1e-15) + warm-up exponential schedule), fastgs path only
+        self.bilateral, self.tv_loss_weight = None, tv_loss_weight
+        if use_bilateral_grid:
+            if rasterizer != "fastgs":
+                raise ValueError("the bilateral grid is wired into the fastgs training step only")
+            from .bilateral_grid import BilateralGrid
+            from .fused_adam import WarmupExponentialLR
+            gx, gy, gl = bilateral_grid_dims
+            self.bilateral = BilateralGrid(sc.viewmats.shape[0], gx, gy, gl, device=device)
+            self.bilateral.grids.grad = torch.zeros_like(self.bilateral.grids)
+            self.bilateral_optimizer = torch.optim.Adam([self.bilateral.grids], lr=bilateral_grid_lr, eps=1e-15)
+            self.bilateral_scheduler = WarmupExponentialLR(self.bilateral_optimizer, gamma=0.01 ** (1.0 / iterations), warmup_steps=1000, warmup_start_factor=0.01)
         # fused_l2: explicit forward/backward through the fused kernels (fused.py) instead of torch autograd over
         # the op-by-op mirror (rasterizer.py); gradients land directly in the flat bucket the all-reduce works on.
         self.fused_l2 = fused_l2
@@ -83,33 +98,64 @@ class GutTrainer:
         return st
 
     def _train_step_fastgs(self, targets, views, total_views):
-        """The same step through the fastgs (EWA) rasterizer: fused preprocess -> blend -> MSE -> blend backward -> preprocess
-        backward (raw-parameter gradients straight into the flat bucket) -> all-reduce -> fused Adam. Black background, MSE loss."""
+        """The same step through the fastgs (EWA) rasterizer - the reference's default training path (trainer.cpp:656-760): fused
+        preprocess -> blend -> [bilateral grid] -> loss ("mse" | "l1_ssim") -> blend backward -> preprocess backward (raw-parameter
+        gradients straight into the flat bucket) -> all-reduce -> strategy.post_backward (ADC fed by the rasterizer's
+        densification_info, or MCMC) -> fused Adam. Black background."""
         from .fastgs import render_and_backward as fg_step
         if self.bucket is None:
             self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2])
         params = self.model.parameters()
+        N = params[0].shape[0]
         self.loss_acc.zero_()
-        if len(views) == 1:
-            grads = self.bucket.views
-            _, _, self.last_n_isects = fg_step(self._fastgs_settings(views[0]), self.scene.viewmats[views[0]:views[0] + 1].contiguous(), self.model,
-                                               targets[0], 1.0 / total_views, grads, self.loss_acc)
-        else:
-            if not hasattr(self, "_fg_tmp"):
-                self._fg_tmp = [torch.empty_like(v) for v in self.bucket.views]
-            for k, v in enumerate(views):
-                dst = self.bucket.views if k == 0 else self._fg_tmp
-                _, _, self.last_n_isects = fg_step(self._fastgs_settings(v), self.scene.viewmats[v:v + 1].contiguous(), self.model,
-                                                   targets[k % len(targets)], 1.0 / total_views, dst, self.loss_acc)
-                if k > 0:
-                    for a, b in zip(self.bucket.views, self._fg_tmp):
-                        a.add_(b)
+        dens = None
+        if self.strategy is not None and self.strategy_kind == "default" and self.iteration < self.strategy.params.stop_refine:
+            if self.densification_info is None or self.densification_info.shape[1] != N:   # default_strategy.cpp:312-314
+                self.densification_info = torch.zeros((2, N), device=self.device)
+            dens = self.densification_info
+        if len(views) > 1 and (not hasattr(self, "_fg_tmp") or self._fg_tmp[0].shape[0] != N):
+            self._fg_tmp = [torch.empty_like(v) for v in self.bucket.views]
+        for k, v in enumerate(views):
+            dst = self.bucket.views if k == 0 else self._fg_tmp
+            _, _, self.last_n_isects = fg_step(self._fastgs_settings(v), self.scene.viewmats[v:v + 1].contiguous(), self.model, targets[k % len(targets)],
+                                               1.0 / total_views, dst, self.loss_acc, densification_info=dens, loss=self.loss_kind,
+                                               lambda_dssim=self.lambda_dssim, bilateral=self.bilateral, image_idx=v)
+            if k > 0:
+                for a, b in zip(self.bucket.views, self._fg_tmp):
+                    a.add_(b)
+        if self.scale_reg > 0 or self.opacity_reg > 0:   # trainer.cpp:132-158, once per step and 1/world of it per rank
+            with torch.no_grad():
+                raw_scales, raw_opac = params[3].detach(), params[5].detach()
+                if self.scale_reg > 0:
+                    self.bucket.views[3].add_(torch.exp(raw_scales), alpha=self.scale_reg / self.world / raw_scales.numel())
+                    self.loss_acc += self.scale_reg / self.world * torch.exp(raw_scales).mean()
+                if self.opacity_reg > 0:
+                    sg = torch.sigmoid(raw_opac)
+                    self.bucket.views[5].add_((sg * (1 - sg)).view_as(self.bucket.views[5]), alpha=self.opacity_reg / self.world / raw_opac.numel())
+                    self.loss_acc += self.opacity_reg / self.world * sg.mean()
+        if self.bilateral is not None and self.tv_loss_weight > 0:   # trainer.cpp:699-705
+            self.bilateral.tv_loss_fused(self.tv_loss_weight / self.world, self.loss_acc)
         self._last_radii = None
         self.bucket.all_reduce(skip_deferred=self.iteration <= 1000)
         for p, gv in zip(params, self.bucket.views):
             p.grad = gv
-        self.optimizer.step(self.iteration)
-        self.scheduler.step()
+        if self.bilateral is not None:
+            if self.world > 1:
+                lfs_dist.all_reduce_sum(self.bilateral.grids.grad)
+            self.bilateral_optimizer.step()
+            self.bilateral_optimizer.zero_grad(set_to_none=False)
+            self.bilateral_scheduler.step()
+        if self.strategy is not None:
+            if self.strategy_kind == "default":
+                if dens is not None and self.world > 1 and self.strategy.is_refining(self.iteration):
+                    lfs_dist.all_reduce_sum(dens)   # replicas must take the same densification decisions
+                self.densification_info = self.strategy.post_backward(self.iteration, dens)
+            else:
+                self.strategy.post_backward(self.iteration)
+            self.strategy.step(self.iteration)
+        else:
+            self.optimizer.step(self.iteration)
+            self.scheduler.step()
         return self.loss_acc
 
     def camera(self, view: int) -> Camera:

@@ -128,3 +128,42 @@ def test_fastgs_trainer_step_matches_autograd(lfs):
     assert any(bool((a != b.detach()).any()) for a, b in zip(before, tr.model.parameters()))
     losses = [float(tr.train_step([target], views=[0])) for _ in range(30)]
     assert losses[-1] < 0.9 * float(loss_ref)
+
+
+def test_fastgs_trainer_reference_default_configuration(lfs):
+    """The reference's default training configuration on the fastgs path (trainer.cpp:656-760): L1 + SSIM loss, ADC strategy fed by
+    the rasterizer's densification_info, and (config 5) the bilateral grid with its TV regulariser. First step against torch
+    autograd over the mirrored modules; then the loop trains, densifies and keeps every tensor consistent."""
+    from lichtfeld_studio_amd import fastgs, losses, scenes, strategies
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    dev = torch.device(DEV)
+    sc = scenes.syn_a(n=4000, sh_degree=1)
+    op = strategies.OptimizationParameters(iterations=300, start_refine=20, refine_every=20, stop_refine=200, reset_every=100000, sh_degree_interval=1000)
+    tr = GutTrainer(sc, dev, iterations=300, rasterizer="fastgs", loss="l1_ssim", strategy="default", opt_params=op, use_bilateral_grid=True,
+                    tv_loss_weight=10.0)
+    with torch.no_grad():
+        tr.bilateral.grids.add_(0.05 * torch.randn(tr.bilateral.grids.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3)))
+    target = (scenes.target_image(sc.height, sc.width) * 0.8 + 0.1).to(dev)
+    # reference composition with autograd
+    out = fastgs.fast_rasterize(tr.camera(0), tr.model, torch.zeros(3, device=dev))
+    shown = tr.bilateral.apply(out.image, 0)
+    loss_ref = losses.photometric_loss(shown, target, op.lambda_dssim) + 10.0 * tr.bilateral.tv_loss()
+    loss_ref.backward()
+    ref_grads = [p.grad.clone() for p in tr.model.parameters()]
+    ref_grid_grad = tr.bilateral.grids.grad.clone()
+    for p in tr.model.parameters():
+        p.grad = None
+    tr.bilateral.grids.grad = torch.zeros_like(tr.bilateral.grids)
+    n0 = tr.model.means.shape[0]
+    grids_before = tr.bilateral.grids.detach().clone()
+    loss = tr.train_step([target], views=[0])
+    assert abs(float(loss) - float(loss_ref)) < 2e-6 * max(1.0, float(loss_ref))
+    for name, g, r in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], tr.bucket.views, ref_grads):
+        assert rel_l2(n(g), n(r).reshape(n(g).shape)) < 2e-4, (name, rel_l2(n(g), n(r).reshape(n(g).shape)))
+    assert bool((tr.bilateral.grids.detach() != grids_before).any()) and float(ref_grid_grad.abs().max()) > 0
+    assert tr.densification_info is not None and float(tr.densification_info[0].sum()) > 0
+    losses_seen = [float(tr.train_step([target], views=[k % sc.viewmats.shape[0]])) for k in range(120)]
+    assert tr.model.means.shape[0] > n0, "ADC never densified"
+    assert all(p.shape[0] == tr.model.means.shape[0] for p in tr.model.parameters())
+    assert tr.densification_info.shape == (2, tr.model.means.shape[0])
+    assert np.isfinite(losses_seen).all() and np.mean(losses_seen[-10:]) < 0.9 * np.mean(losses_seen[:10])

@@ -103,3 +103,23 @@ def test_photometric_loss_full_size_properties(lfs):
     loss.zero_()
     v = losses.photometric_loss_fwd_bwd(img[None].contiguous(), other, 0.2, 1.0, loss)
     assert 0.2 < float(loss) < 0.6 and torch.isfinite(v).all() and float(v.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("H,W,lam", [(64, 64, 0.2), (117, 203, 0.2), (9, 40, 0.2)])
+def test_fused_photometric_loss_chw_matches_torch(lfs, H, W, lam):
+    """fastgs layout: CHW render, NOT clamped (fast_rasterizer.cpp:63 -> compute_photometric_loss), CHW gradient out."""
+    from lichtfeld_studio_amd import losses
+    g = torch.Generator().manual_seed(H * 1000 + W + 1)
+    render = torch.rand(3, H, W, generator=g) * 1.4 - 0.2
+    target = torch.rand(3, H, W, generator=g)
+    loss = torch.zeros(1, device=DEV)
+    v = losses.photometric_loss_chw_fwd_bwd(render.to(DEV), target.to(DEV), lam, 0.5, loss)
+    r = render.double().requires_grad_(True)
+    lr = 0.5 * ref.photometric_loss(r.unsqueeze(0), target.double().unsqueeze(0), lam)
+    if H > 10 and W > 10:
+        lr.backward()
+    else:
+        (0.5 * (1 - lam) * (r - target.double()).abs().mean()).backward()
+    assert abs(float(loss) - float(lr)) < 2e-6
+    assert float((v.cpu().double() - r.grad).abs().max()) < 1e-5 * float(r.grad.abs().max()) + 1e-12
+    assert abs(float(losses.photometric_loss(render.to(DEV), target.to(DEV), lam)) * 0.5 - float(lr)) < 2e-6

@@ -21,7 +21,8 @@ def test_torch_ops_module_surface_and_cpu_rejection():
     m = _mod()
     for name in ["spherical_harmonics_fwd", "spherical_harmonics_bwd", "intersect_tile", "intersect_offset", "quats_to_rotmats", "relocation",
                  "add_noise", "projection_ut_3dgs_fused", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
-                 "adam_step_wrapper"]:
+                 "adam_step_wrapper", "fastgs_forward_wrapper", "fastgs_backward_wrapper", "fusedssim", "fusedssim_backward",
+                 "bilateral_slice_forward", "bilateral_slice_backward", "bilateral_tv_loss_forward", "bilateral_tv_loss_backward"]:
         assert hasattr(m, name)
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         m.quats_to_rotmats(torch.randn(3, 4))
@@ -80,3 +81,61 @@ def test_torch_ops_equal_python_mirror(lfs):
     with pytest.raises(RuntimeError, match="Unsupported number of channels"):
         m.rasterize_to_pixels_from_world_3dgs_fwd(means, quats, scales, torch.rand(1, 5000, 7, device=dev), opac[None].contiguous(), None, None, W, H, 16,
                                                   vm, None, K, 0, None, 4, None, None, None, offs, t1[2])
+
+
+@pytest.mark.gpu
+def test_torch_fastgs_and_ssim_wrappers_equal_python_mirror(lfs):
+    """fast_gs::rasterization::forward_wrapper / backward_wrapper and fusedssim / fusedssim_backward with the reference's
+    argument lists (rasterization_api.h:27-75, ssim.cuh:11-30): same C entry points as fastgs.py / losses.py -> same forward
+    bits; backward up to atomic ordering. The backward takes no sh_coefficients_0, as in the reference."""
+    m = _mod()
+    from lichtfeld_studio_amd import fastgs, losses
+    from test_oracle_fastgs import _scene
+    from gpu_util import t
+    sc = _scene(N=4000, W=208, H=144, seed=11, deg=2)
+    a = [t(sc[k]) for k in ("means", "scales_raw", "rot_raw", "opac_raw", "sh0", "sh_rest", "w2c")]
+    cam = t(sc["cam_pos"])
+    fr = (sc["active_sh_bases"], sc["W"], sc["H"], sc["fx"], sc["fy"], sc["cx"], sc["cy"], 0.01, 1e10)
+    out = m.fastgs_forward_wrapper(*a, cam, *fr)
+    assert len(out) == 11
+    image, alpha, prim, tile, inst, bucket, n_vis, n_inst, n_buckets, s0, s1 = out
+    s = fastgs.FastGSSettings(cam, *fr)
+    image2, alpha2, pws, iws, n_inst2 = fastgs.forward_wrapper(*a, s)
+    assert n_inst == n_inst2 and torch.equal(image, image2) and torch.equal(alpha, alpha2)
+    assert image.shape == (3, sc["H"], sc["W"]) and alpha.shape == (1, sc["H"], sc["W"]) and prim.dtype == torch.uint8
+    gi, ga = torch.randn_like(image), torch.randn_like(alpha)
+    dens1, dens2 = torch.zeros(2, 4000, device="cuda:0"), torch.zeros(2, 4000, device="cuda:0")
+    g1 = m.fastgs_backward_wrapper(dens1, gi, ga, image, alpha, a[0], a[1], a[2], a[5], prim, tile, inst, bucket, a[6], cam, *fr, n_vis, n_inst,
+                                   n_buckets, s0, s1)
+    g2 = fastgs.backward_wrapper(dens2, gi, ga, image2, alpha2, a[0], a[1], a[2], a[4], a[5], pws, iws, a[6], s, n_inst2)
+    assert len(g1) == 7 and g1[6] is None     # grad_w2c undefined: w2c does not require grad (rasterization_api.cu backward)
+    for x, y in zip(g1[:6], g2[:6]):
+        assert x.shape == y.shape or x.numel() == y.numel()
+        assert torch.allclose(x.reshape(-1), y.reshape(-1), rtol=1e-4, atol=1e-6 + 1e-5 * float(y.abs().max()))
+    assert torch.equal(dens1[0], dens2[0]) and torch.allclose(dens1[1], dens2[1], rtol=1e-4, atol=1e-7)
+    # no densification info requested: empty tensor, as the reference's `densification_info.size(0) > 0` test
+    g3 = m.fastgs_backward_wrapper(torch.empty(0, device="cuda:0"), gi, ga, image, alpha, a[0], a[1], a[2], a[5], prim, tile, inst, bucket, a[6], cam,
+                                   *fr, n_vis, n_inst, n_buckets, s0, s1)
+    assert torch.allclose(g3[0], g1[0], rtol=1e-4, atol=1e-6 + 1e-5 * float(g1[0].abs().max()))
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        m.fastgs_forward_wrapper(*[x.cpu() for x in a], cam.cpu(), *fr)
+
+    x1, x2 = torch.rand(2, 3, 67, 90, device="cuda:0"), torch.rand(2, 3, 67, 90, device="cuda:0")
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    r1, r2 = m.fusedssim(C1, C2, x1, x2, True), losses.fusedssim(C1, C2, x1, x2, True)
+    for u, v in zip(r1, r2):
+        assert torch.equal(u, v)
+    assert m.fusedssim(C1, C2, x1, x2, False)[1].numel() == 0
+    dmap = torch.randn_like(x1)
+    assert torch.equal(m.fusedssim_backward(C1, C2, x1, x2, dmap, *r1[1:]), losses.fusedssim_backward(C1, C2, x1, x2, dmap, *r2[1:]))
+    # gs::bilateral_grid::* (include/kernels/bilateral_grid.cuh)
+    from lichtfeld_studio_amd import bilateral_grid as bg
+    grid, rgb, go = torch.randn(12, 8, 16, 16, device="cuda:0"), torch.rand(120, 200, 3, device="cuda:0"), torch.randn(120, 200, 3, device="cuda:0")
+    assert torch.equal(m.bilateral_slice_forward(grid, rgb), bg.slice_forward(grid, rgb))
+    b1, b2 = m.bilateral_slice_backward(grid, rgb, go), bg.slice_backward(grid, rgb, go)
+    assert torch.equal(b1[1], b2[1]) and torch.allclose(b1[0], b2[0], rtol=1e-4, atol=1e-5 * float(b2[0].abs().max()))
+    grids = torch.randn(3, 12, 8, 16, 16, device="cuda:0")
+    assert torch.allclose(m.bilateral_tv_loss_forward(grids), bg.tv_loss_forward(grids), rtol=1e-5)
+    assert torch.equal(m.bilateral_tv_loss_backward(grids, torch.tensor(0.5)), bg.tv_loss_backward(grids, 0.5))
+    with pytest.raises(RuntimeError, match="Grid must be"):
+        m.bilateral_slice_forward(grid[:11].contiguous(), rgb)

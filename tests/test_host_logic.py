@@ -105,3 +105,25 @@ def test_ssim_reference_is_self_consistent():
     assert torch.allclose(ref.ssim_map(a, b), ref.ssim_map(b, a), atol=1e-12)
     a.requires_grad_(True)
     assert torch.autograd.gradcheck(lambda x: ref.photometric_loss(x, b, 0.2), (a,), eps=1e-6, atol=1e-6)
+
+
+def test_warmup_exponential_lr_follows_reference_schedule():
+    """scheduler.cpp:27-63: linear warm-up from start factor to 1 over warmup_steps, then gamma^(step - warmup_steps)."""
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd.fused_adam import WarmupExponentialLR
+
+    class Opt:
+        param_groups = [{"lr": 2e-3}, {"lr": 1.0}]
+    o = Opt()
+    s = WarmupExponentialLR(o, gamma=0.5, warmup_steps=4, warmup_start_factor=0.01)
+    seen = []
+    for _ in range(7):
+        s.step()
+        seen.append(o.param_groups[0]["lr"] / 2e-3)
+    expect = [0.01 + 0.99 * 0.25, 0.01 + 0.99 * 0.5, 0.01 + 0.99 * 0.75, 1.0, 0.5, 0.25, 0.125]
+    assert all(abs(a - b) < 1e-12 for a, b in zip(seen, expect)), seen
+    assert abs(o.param_groups[1]["lr"] - 0.125) < 1e-12
+    o2 = Opt(); o2.param_groups = [{"lr": 1.0}, {"lr": 1.0}]
+    s2 = WarmupExponentialLR(o2, gamma=0.5, param_group_index=1)
+    s2.step()
+    assert o2.param_groups[0]["lr"] == 1.0 and o2.param_groups[1]["lr"] == 0.5
