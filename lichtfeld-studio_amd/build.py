@@ -31,6 +31,7 @@ SOURCES = {
     "l2_fused.hip": ["-ffp-contract=off"],
     "ssim.hip": ["-ffp-contract=off"],
     "bilateral_grid.hip": ["-ffp-contract=off"],
+    "dataprep.hip": ["-ffp-contract=off"],
     "fastgs_prep.hip": ["-ffp-contract=off"],
     "fastgs_blend.hip": ["-fno-slp-vectorize"],
     "prof.hip": [],
@@ -77,6 +78,22 @@ def build(force: bool = False) -> str:
     return OUT
 
 
+IO_OUT = os.path.join(HERE, "liblfs_io.so")
+
+
+def build_io(force: bool = False) -> str:
+    """Host-only data-format library (csrc_host/lfs_io.cpp: COLMAP, splat PLY, PNG/PNM) -> lichtfeld-studio_amd/liblfs_io.so (g++ + zlib)."""
+    src = os.path.join(HERE, "csrc_host", "lfs_io.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "lfs_io.h")]
+    if not force and os.path.exists(IO_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(IO_OUT) for d in deps):
+        return IO_OUT
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-Wall", "-Wextra", src, "-lz", "-o", IO_OUT]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"liblfs_io build failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return IO_OUT
+
+
 TORCH_OPS_OUT = os.path.join(HERE, "_lfs_torch_ops.so")
 
 
@@ -108,5 +125,6 @@ def build_torch_ops(force: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_io(force="--force" in sys.argv))
     if "--torch-ops" in sys.argv:
         print(build_torch_ops(force="--force" in sys.argv))

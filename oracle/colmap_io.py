@@ -1,0 +1,304 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): pure-Python / numpy restatement of the reference's data-format code.
+  COLMAP binary / text readers      src/loader/formats/colmap.cpp:305-640
+  camera assembly, model table      src/loader/formats/colmap.cpp:645-880 (+ scaling :172-283)
+  PLY attribute layout              src/core/splat_data.cpp:113-169, :402-419, :484-505
+  load_image sizes                  src/core/image_io.cpp:112-270
+  OpenImageIO resample              third-party (vcpkg "openimageio", version floating with the vcpkg baseline
+                                    4334d8b4c8916018600212ab4dd4bbdc343065d1; not vendored): ImageBufAlgo::resample(interpolate=true)
+                                    restated from its published algorithm (sample at the destination pixel centre, bilinear, clamp)
+  compute_mean_neighbor_distances   src/core/splat_data.cpp:64-111 (nanoflann kd-tree there; exact search either way)
+PARITY UNPINNED: the reference has no tests or fixtures for any of this, and its loaders need libtorch + OpenImageIO + tinyply to
+build. The writers below produce the byte layouts COLMAP documents; the readers are checked against them and against Pillow.
+"""
+import os
+import struct
+
+import numpy as np
+
+MODELS = {  # id: (name, n_params)
+    0: ("SIMPLE_PINHOLE", 3), 1: ("PINHOLE", 4), 2: ("SIMPLE_RADIAL", 4), 3: ("RADIAL", 5), 4: ("OPENCV", 8), 5: ("OPENCV_FISHEYE", 8),
+    6: ("FULL_OPENCV", 12), 7: ("FOV", 5), 8: ("SIMPLE_RADIAL_FISHEYE", 4), 9: ("RADIAL_FISHEYE", 5), 10: ("THIN_PRISM_FISHEYE", 12)}
+NAME_TO_ID = {v[0]: k for k, v in MODELS.items()}
+F32 = np.float32
+
+
+# ---- writers (the documented COLMAP layouts) ----
+def write_cameras_bin(path, cams):
+    """cams: list of (camera_id, model_id, width, height, params)"""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(cams)))
+        for cid, model, w, h, params in cams:
+            f.write(struct.pack("<IiQQ", cid, model, w, h))
+            f.write(struct.pack(f"<{len(params)}d", *params))
+
+
+def write_images_bin(path, images, n_points2d=3):
+    """images: list of (image_id, qvec[4], tvec[3], camera_id, name)"""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(images)))
+        for k, (iid, q, t, cid, name) in enumerate(images):
+            f.write(struct.pack("<I4d3dI", iid, *q, *t, cid))
+            f.write(name.encode() + b"\0")
+            n = (n_points2d + k) % 5
+            f.write(struct.pack("<Q", n))
+            for j in range(n):
+                f.write(struct.pack("<ddQ", 1.5 * j, 2.5 * j, j))
+
+
+def write_points3d_bin(path, xyz, rgb):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(xyz)))
+        for i, (p, c) in enumerate(zip(xyz, rgb)):
+            f.write(struct.pack("<Q3d3Bd", i + 1, *[float(v) for v in p], *[int(v) for v in c], 0.5))
+            track = i % 4
+            f.write(struct.pack("<Q", track))
+            for j in range(track):
+                f.write(struct.pack("<II", j, j + 1))
+
+
+def write_cameras_txt(path, cams, crlf=False):
+    nl = "\r\n" if crlf else "\n"
+    with open(path, "w", newline="") as f:
+        f.write("# Camera list with one line of data per camera:" + nl + "#   CAMERA_ID, MODEL, WIDTH, HEIGHT, PARAMS[]" + nl)
+        for cid, model, w, h, params in cams:
+            f.write(f"{cid} {MODELS[model][0]} {w} {h} " + " ".join(repr(float(p)) for p in params) + nl)
+
+
+def write_images_txt(path, images, crlf=False):
+    nl = "\r\n" if crlf else "\n"
+    with open(path, "w", newline="") as f:
+        f.write("# Image list with two lines of data per image:" + nl)
+        for iid, q, t, cid, name in images:
+            f.write(f"{iid} " + " ".join(repr(float(v)) for v in (*q, *t)) + f" {cid} {name}" + nl)
+            f.write("10.5 20.25 -1 3.5 4.5 7" + nl)
+
+
+def write_points3d_txt(path, xyz, rgb):
+    with open(path, "w") as f:
+        f.write("# 3D point list\n")
+        for i, (p, c) in enumerate(zip(xyz, rgb)):
+            f.write(f"{i + 1} {float(p[0])!r} {float(p[1])!r} {float(p[2])!r} {int(c[0])} {int(c[1])} {int(c[2])} 0.5 1 2 3 4\n")
+
+
+# ---- readers / assembly (restatement of the reference) ----
+def folder_scale(folder):
+    """colmap.cpp:265-283"""
+    us = folder.rfind("_")
+    if us < 0:
+        return 1.0
+    try:
+        v = float(F32(float(folder[us + 1:])))
+    except ValueError:
+        return 1.0
+    return v if 0 < v <= 16 else 1.0
+
+
+def _scaled(model, w, h, params, factor):
+    params = [float(p) for p in params]
+    if factor != 1.0:
+        w, h = int(F32(w) / F32(factor)), int(F32(h) / F32(factor))
+        n = 3 if MODELS[model][0] in ("SIMPLE_PINHOLE", "SIMPLE_RADIAL", "RADIAL", "SIMPLE_RADIAL_FISHEYE", "RADIAL_FISHEYE") else 4
+        for i in range(n):
+            params[i] = params[i] / float(F32(factor))
+    return w, h, np.array(params, np.float64).astype(F32)
+
+
+def read_cameras_bin(path, factor=1.0):
+    b = open(path, "rb").read()
+    n, = struct.unpack_from("<Q", b, 0)
+    o, out = 8, {}
+    for _ in range(n):
+        cid, model, w, h = struct.unpack_from("<IiQQ", b, o)
+        o += 24
+        if model not in MODELS:
+            raise RuntimeError(f"Unsupported camera-model id {model}")
+        k = MODELS[model][1]
+        params = struct.unpack_from(f"<{k}d", b, o)
+        o += 8 * k
+        out[cid] = (model,) + _scaled(model, w, h, params, factor)
+    if o != len(b):
+        raise RuntimeError("cameras.bin: trailing bytes")
+    return out
+
+
+def read_images_bin(path):
+    b = open(path, "rb").read()
+    n, = struct.unpack_from("<Q", b, 0)
+    o, out = 8, []
+    for _ in range(n):
+        iid, = struct.unpack_from("<I", b, o)
+        q = np.array(struct.unpack_from("<4d", b, o + 4)).astype(F32)
+        t = np.array(struct.unpack_from("<3d", b, o + 36)).astype(F32)
+        cid, = struct.unpack_from("<I", b, o + 60)
+        o += 64
+        e = b.index(b"\0", o)
+        name = b[o:e].decode()
+        o = e + 1
+        npts, = struct.unpack_from("<Q", b, o)
+        o += 8 + 24 * npts
+        out.append((iid, q, t, cid, name))
+    if o != len(b):
+        raise RuntimeError("images.bin: trailing bytes")
+    return out
+
+
+def _lines(path):
+    """colmap.cpp:459-488"""
+    lines = []
+    with open(path, newline="") as f:
+        text = f.read()
+        raw = text.split("\n")
+        if raw and raw[-1] == "":   # std::getline does not produce an extra line after a final newline
+            raw.pop()
+        for line in raw:
+            if line.startswith("#"):
+                continue
+            if line.endswith("\r"):
+                line = line[:-1]
+            lines.append(line)
+    if not lines:
+        raise RuntimeError("empty")
+    if lines[-1] == "":
+        lines.pop()
+    return lines
+
+
+def read_cameras_txt(path, factor=1.0):
+    out = {}
+    for line in _lines(path):
+        tok = line.split(" ")
+        model = NAME_TO_ID[tok[1]]
+        out[int(tok[0])] = (model,) + _scaled(model, int(tok[2]), int(tok[3]), [float(t) for t in tok[4:]], factor)
+    return out
+
+
+def read_images_txt(path):
+    lines = _lines(path)
+    assert len(lines) % 2 == 0
+    out = []
+    for i in range(0, len(lines), 2):
+        tok = lines[i].split(" ")
+        assert len(tok) == 10
+        out.append((int(tok[0]), np.array([F32(float(v)) for v in tok[1:5]], F32), np.array([F32(float(v)) for v in tok[5:8]], F32), int(tok[8]), tok[9]))
+    return out
+
+
+def qvec2rotmat(q):
+    """colmap.cpp:29-50, float32 throughout"""
+    q = q.astype(F32)
+    den = max(F32(np.sqrt(F32(np.sum(q * q, dtype=F32)))), F32(1e-12))
+    w, x, y, z = [F32(v / den) for v in q]
+    one, two = F32(1), F32(2)
+    return np.array([[one - two * (y * y + z * z), two * (x * y - z * w), two * (x * z + y * w)],
+                     [two * (x * y + z * w), one - two * (x * x + z * z), two * (y * z - x * w)],
+                     [two * (x * z - y * w), two * (y * z + x * w), one - two * (x * x + y * y)]], F32)
+
+
+# (focal count, radial indices, tangential indices, projection type) per model; None = rejected (colmap.cpp:682-830)
+LAYOUT = {0: (1, [], [], 0), 1: (2, [], [], 0), 2: (1, [3], [], 0), 3: (1, [3, 4], [], 0), 4: (2, [4, 5], [6, 7], 0), 5: (2, [4, 5, 6, 7], [], 2),
+          6: (2, [4, 5, 8, 9, 10, 11], [6, 7], 0), 7: None, 8: (1, [3], [], 2), 9: (1, [3, 4], [], 2), 10: None}
+
+
+def assemble(cams, images, first_image_size=None):
+    """-> list of dicts + scene centre. first_image_size (w, h): the real size of image 0 if the file exists (colmap.cpp:836-865)."""
+    out, locs = [], []
+    for iid, q, t, cid, name in images:
+        model, w, h, p = cams[cid]
+        R = qvec2rotmat(q)
+        locs.append(-(R.T.astype(F32) @ t.astype(F32)).astype(F32))
+        if LAYOUT[model] is None:
+            raise RuntimeError("not supported")
+        nf, rad, tan, proj = LAYOUT[model]
+        v = dict(camera_id=cid, colmap_model=model, camera_model_type=proj, width=w, height=h, focal_x=p[0], focal_y=p[1] if nf == 2 else p[0],
+                 center_x=p[nf], center_y=p[nf + 1], R=R, T=t.astype(F32), radial=np.array([p[i] for i in rad], F32),
+                 tangential=np.array([p[i] for i in tan], F32), params=p, name=name)
+        if model == 2 and p[3] == 0:
+            v["radial"] = np.zeros(0, F32)
+        out.append(v)
+    if out and first_image_size is not None:
+        sx, sy = F32(first_image_size[0]) / F32(out[0]["width"]), F32(first_image_size[1]) / F32(out[0]["height"])
+        if abs(sx - 1) > 1e-5 or abs(sy - 1) > 1e-5:
+            for v in out:
+                v["width"], v["height"] = first_image_size
+                v["focal_x"] = F32(v["focal_x"] * sx); v["focal_y"] = F32(v["focal_y"] * sy)
+                v["center_x"] = F32(v["center_x"] * sx); v["center_y"] = F32(v["center_y"] * sy)
+    return out, np.mean(np.stack(locs).astype(np.float64), 0).astype(F32) if locs else None
+
+
+# ---- images ----
+def target_size(w, h, res_div, max_width):
+    """image_io.cpp:112-270 (sizes only)"""
+    nw, nh = w, h
+    if res_div in (2, 4, 8):
+        nw, nh = max(1, w // res_div), max(1, h // res_div)
+    if max_width > 0 and (nw > max_width or nh > max_width):
+        if nw > nh:
+            nw, nh = max(1, max_width), max(1, max_width * nh // nw)
+        else:
+            nw, nh = max(1, max_width * nw // nh), max(1, max_width)
+    return nw, nh
+
+
+def resample_u8(src, dw, dh):
+    """OpenImageIO ImageBufAlgo::resample(interpolate=true) on a u8 [h,w,3] image -> u8 [dh,dw,3], float32 arithmetic."""
+    sh, sw = src.shape[:2]
+    x, y = np.arange(dw, dtype=F32), np.arange(dh, dtype=F32)
+    fx = ((x + F32(0.5)) * F32(F32(1) / F32(dw))) * F32(sw) - F32(0.5)
+    fy = ((y + F32(0.5)) * F32(F32(1) / F32(dh))) * F32(sh) - F32(0.5)
+    flx, fly = np.floor(fx), np.floor(fy)
+    ax, ay = (fx - flx).astype(F32)[None, :, None], (fy - fly).astype(F32)[:, None, None]
+    x0, x1 = np.clip(flx.astype(int), 0, sw - 1), np.clip(flx.astype(int) + 1, 0, sw - 1)
+    y0, y1 = np.clip(fly.astype(int), 0, sh - 1), np.clip(fly.astype(int) + 1, 0, sh - 1)
+    f = src.astype(F32) * F32(F32(1) / F32(255))
+    v00, v01, v10, v11 = f[y0][:, x0], f[y0][:, x1], f[y1][:, x0], f[y1][:, x1]
+    one = F32(1)
+    top = (one - ax) * v00 + ax * v01
+    bot = (one - ax) * v10 + ax * v11
+    v = (one - ay) * top + ay * bot
+    return np.clip(v * F32(255) + F32(0.5), 0, 255).astype(np.int32).astype(np.uint8)
+
+
+def image_to_chw(src_u8, dw=None, dh=None):
+    h, w = src_u8.shape[:2]
+    if (dw or w) != w or (dh or h) != h:
+        src_u8 = resample_u8(src_u8, dw, dh)
+    return (src_u8.astype(F32) / F32(255)).transpose(2, 0, 1)
+
+
+# ---- point cloud ----
+def mean_neighbor_distances(points):
+    """splat_data.cpp:64-111 with an exact brute-force search (float32 squared distances accumulated in x, y, z order)."""
+    p = points.astype(F32)
+    n = len(p)
+    if n <= 1:
+        return np.full(n, 0.01, F32)
+    out = np.zeros(n, F32)
+    for i in range(n):
+        d = p[i] - p
+        d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(F32) + d[:, 2] * d[:, 2]).astype(F32)
+        best = np.sort(d2, kind="stable")[:min(4, n)]
+        vals = [F32(np.sqrt(v)) for v in best if v > 1e-8][:3]
+        s = F32(0)
+        for v in vals:
+            s = F32(s + v)
+        out[i] = F32(s / F32(len(vals))) if vals else F32(0.01)
+    return out
+
+
+# ---- PLY ----
+def ply_attribute_names(n_dc, n_rest):
+    """splat_data.cpp:402-419"""
+    return (["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(n_dc)] + [f"f_rest_{i}" for i in range(n_rest)] + ["opacity"]
+            + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)])
+
+
+def ply_bytes(means, sh0, shN, opacity, scaling, rotation):
+    """The file SplatData::save_ply writes (tinyply binary little endian, float properties, vertex-interleaved)."""
+    N = len(means)
+    f_dc = np.transpose(sh0, (0, 2, 1)).reshape(N, -1)
+    f_rest = np.transpose(shN, (0, 2, 1)).reshape(N, -1)
+    rot = rotation / np.maximum(np.linalg.norm(rotation, axis=-1, keepdims=True), 1e-12)
+    rows = np.concatenate([means, np.zeros_like(means), f_dc, f_rest, opacity.reshape(N, 1), scaling, rot], 1).astype("<f4")
+    names = ply_attribute_names(f_dc.shape[1], f_rest.shape[1])
+    hdr = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % N + "".join(f"property float {n}\n" for n in names) + "end_header\n"
+    return hdr.encode() + rows.tobytes()

@@ -1,0 +1,134 @@
+"""GPU parity for the data-side kernels (csrc/dataprep.hip) and the COLMAP -> trainer path against
+oracle/colmap_io.py. u8 -> CHW float: bit-exact without resampling; with resampling the 8-bit values may differ by one level where
+the float32 bilinear result lands within rounding distance of x.5 (stated: <= 0.1 % of the samples, never more than one level).
+Mean 3-NN distances: same float32 squared distances, so bit-exact up to the final division (<= 1 ulp)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import n, t
+from oracle import colmap_io as oc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("shape,out", [((37, 53), None), ((270, 480), (240, 135)), ((1080, 1920), (480, 270)), ((101, 203), (50, 25)), ((64, 64), (200, 90)),
+                                       ((3286, 4946), (1236, 821))])
+def test_image_u8_to_chw_matches_oracle(lfs, shape, out):
+    from lichtfeld_studio_amd import loader
+    rng = np.random.default_rng(shape[0])
+    small = rng.integers(0, 256, (shape[0] // 8 + 2, shape[1] // 8 + 2, 3), dtype=np.uint8)      # some spatial structure + noise
+    img = np.clip(np.kron(small, np.ones((8, 8, 1), np.uint8))[:shape[0], :shape[1]].astype(int) + rng.integers(-9, 10, (*shape, 3)), 0, 255).astype(np.uint8)
+    dev = torch.from_numpy(img).to(DEV)
+    if out is None:
+        got = n(loader.u8_to_chw_f32(dev))
+        assert np.array_equal(got, oc.image_to_chw(img))
+        return
+    got = n(loader.u8_to_chw_f32(dev, out[0], out[1]))
+    ref = oc.image_to_chw(img, out[0], out[1])
+    assert got.shape == ref.shape == (3, out[1], out[0])
+    lv = np.rint(np.abs(got - ref) * 255)
+    assert lv.max() <= 1 and (lv > 0).mean() < 1e-3, (lv.max(), (lv > 0).mean())
+    assert np.array_equal(np.rint(got * 255) / np.float32(255), got)       # values sit on the 8-bit lattice, like the reference's u8 round trip
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 257, 3000])
+def test_mean_neighbor_distances_match_oracle(lfs, N):
+    from lichtfeld_studio_amd import loader
+    rng = np.random.default_rng(N)
+    pts = rng.standard_normal((N, 3)).astype(np.float32)
+    if N >= 257:                     # exact duplicates and a tight cluster: the d^2 <= 1e-8 rule
+        pts[10] = pts[11] = pts[12] = pts[13]
+        pts[20] = pts[21]
+        pts[30:33] = pts[33] + np.float32(1e-5) * rng.standard_normal((3, 3)).astype(np.float32)
+    got = n(loader.mean_neighbor_distances(t(pts)))
+    ref = oc.mean_neighbor_distances(pts)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=2e-7, atol=0)
+    if N >= 257:
+        assert got[10] == ref[10] and got[20] == ref[20]
+
+
+def test_mean_neighbor_distances_large_against_kdtree(lfs):
+    """200k points against scipy's exact kd-tree (float64 distances): the property the initial scales rest on."""
+    from scipy.spatial import cKDTree
+    from lichtfeld_studio_amd import loader
+    pts = np.random.default_rng(0).standard_normal((200_000, 3)).astype(np.float32)
+    got = n(loader.mean_neighbor_distances(t(pts)))
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    np.testing.assert_allclose(got, d[:, 1:4].mean(1), rtol=2e-5)
+
+
+def _synthetic_colmap(tmp, W=160, H=112, n_views=9, n_pts=4000):
+    """A COLMAP directory rendered from a known Gaussian scene: images are written as PNGs by liblfs_io."""
+    from lichtfeld_studio_amd import loader, scenes
+    from lichtfeld_studio_amd.rasterizer import rasterize
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    sc = scenes._syn_box("SYN-T", 7, n_pts, W, H, 120.0, n_views, sh_degree=1)
+    sc.raw_scales += float(np.log(8.0))       # ~2 px footprints at this focal length
+    tr = GutTrainer(sc, torch.device(DEV), iterations=10)
+    base = os.path.join(tmp, "scene")
+    os.makedirs(os.path.join(base, "sparse", "0"), exist_ok=True)
+    os.makedirs(os.path.join(base, "images"), exist_ok=True)
+    V = sc.viewmats.shape[0]
+    cams, images = [(1, 1, W, H, [float(sc.Ks[0, 0, 0]), float(sc.Ks[0, 1, 1]), float(sc.Ks[0, 0, 2]), float(sc.Ks[0, 1, 2])])], []
+    from scipy.spatial.transform import Rotation
+    for v in range(V):
+        with torch.no_grad():
+            img = rasterize(tr.camera(v), tr.model, tr.bg, 1.0, False, False).image
+        loader.write_png(os.path.join(base, "images", f"v{v:02d}.png"), (img.clamp(0, 1).permute(1, 2, 0) * 255 + 0.5).to(torch.uint8).cpu().numpy())
+        m = sc.viewmats[v].double().cpu().numpy()
+        q = Rotation.from_matrix(m[:3, :3]).as_quat()          # x, y, z, w
+        images.append((v + 1, [q[3], q[0], q[1], q[2]], list(m[:3, 3]), 1, f"v{v:02d}.png"))
+    oc.write_cameras_bin(os.path.join(base, "sparse", "0", "cameras.bin"), cams)
+    oc.write_images_bin(os.path.join(base, "sparse", "0", "images.bin"), images)
+    xyz = sc.means.cpu().numpy()[::2]
+    rgb = np.clip((sc.sh0[::2, 0].cpu().numpy() * 0.28209479177387814 + 0.5) * 255, 0, 255).astype(np.uint8)
+    oc.write_points3d_bin(os.path.join(base, "sparse", "0", "points3D.bin"), xyz, rgb)
+    return base, sc, xyz, rgb
+
+
+def test_colmap_directory_to_training_and_ply(lfs, tmp_path):
+    """COLMAP dir -> cameras, point cloud, initial model (3-NN scales, SH0 from colours, logit opacity) -> fastgs training steps on the
+    loaded images -> PLY -> load_ply gives back the trained tensors."""
+    from lichtfeld_studio_amd import loader
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    base, src, xyz, rgb = _synthetic_colmap(str(tmp_path))
+    scene, ds, scene_scale = loader.colmap_scene(base, "images", split="train", test_every=4, sh_degree=1, init_scaling=1.0, init_opacity=0.1, device=DEV)
+    V = src.viewmats.shape[0]
+    assert len(ds) == V - len(range(0, V, 4)) and scene.width == src.width and scene.height == src.height
+    # cameras survive the quaternion round trip; K equals the source intrinsics
+    for k, i in enumerate(ds.indices):
+        assert torch.allclose(scene.viewmats[k].cpu(), src.viewmats[i].cpu(), atol=2e-6)
+        assert torch.allclose(scene.Ks[k].cpu(), src.Ks[i].cpu(), atol=1e-4)
+    # init_model_from_pointcloud against the restatement
+    assert np.array_equal(n(scene.means), xyz.astype(np.float32))
+    nn = np.maximum(oc.mean_neighbor_distances(xyz), 1e-7)
+    np.testing.assert_allclose(n(scene.raw_scales), np.repeat(np.log(np.sqrt(nn) * 1.0)[:, None], 3, 1), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(n(scene.sh0)[:, 0], (rgb.astype(np.float32) / 255 - 0.5) / 0.28209479177387814, rtol=1e-6, atol=1e-6)
+    assert np.allclose(n(scene.raw_opacities), np.log(0.1 / 0.9), atol=1e-6) and np.array_equal(n(scene.raw_quats), np.tile([1, 0, 0, 0], (len(xyz), 1)))
+    center = np.mean([-(src.viewmats[i, :3, :3].cpu().numpy().T @ src.viewmats[i, :3, 3].cpu().numpy()) for i in range(V)], 0)
+    dists = np.sort(np.linalg.norm(xyz - center, axis=1))
+    assert abs(scene_scale - dists[(len(dists) - 1) // 2]) < 1e-5 * scene_scale        # torch's median: the lower middle element
+    # images: the dataset yields the PNG bytes as CHW floats
+    cam, img = ds.get(0, DEV)
+    from PIL import Image
+    assert np.array_equal(n(img), (np.asarray(Image.open(cam.image_path)).astype(np.float32) / np.float32(255)).transpose(2, 0, 1))
+    half = loader.load_image(cam.image_path, 2, 0, DEV)
+    assert half.shape == (3, src.height // 2, src.width // 2)
+    # training on the loaded data
+    tr = GutTrainer(scene, torch.device(DEV), iterations=200, rasterizer="fastgs", loss="l1_ssim")
+    targets = [ds.get(k, DEV)[1] for k in range(len(ds))]
+    losses = [float(tr.train_step([targets[k % len(ds)]], views=[k % len(ds)])) for k in range(100)]
+    assert np.isfinite(losses).all() and np.mean(losses[-8:]) < 0.85 * np.mean(losses[:8]), (losses[:3], losses[-3:])
+    # PLY round trip of the trained model
+    path = str(tmp_path / "out" / "splat_100.ply")
+    loader.save_ply(tr.model, path)
+    back = loader.load_ply(path, DEV)
+    for name, a, b in zip(["means", "sh0", "shN", "scales", "quats", "opac"], back.parameters(), tr.model.parameters()):
+        b = torch.nn.functional.normalize(b, dim=-1) if name == "quats" else b
+        assert torch.equal(a.detach(), b.detach()), name
+    assert os.path.getsize(path) == len(open(path, "rb").read().split(b"end_header\n")[0]) + 11 + 4 * len(xyz) * (6 + 3 + 9 + 1 + 3 + 4)

@@ -1,0 +1,268 @@
+"""CPU: liblfs_io.so (COLMAP bin + txt, splat PLY, PNG / PNM, image sizes) through lichtfeld_studio_amd.loader against the
+restatement in oracle/colmap_io.py on synthetic datasets written in the documented COLMAP layouts; PNG decoding against Pillow.
+Integers / strings / bytes bit-exact; float32 camera quantities to 2e-7 relative (same float32 expressions, libm sqrt)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import colmap_io as oc
+
+
+@pytest.fixture(scope="module")
+def ld():
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import loader
+    loader.io_library()
+    return loader
+
+
+def _dataset(rng, n_images=13):
+    # one camera per supported model (ids deliberately unordered), images cycling through them
+    params = {0: [800.5, 320.25, 240.75], 1: [810.0, 790.5, 321.0, 239.0], 2: [805.0, 320.0, 240.0, 0.0], 3: [600.0, 300.0, 200.0, 0.05, -0.01],
+              4: [700.0, 710.0, 330.0, 250.0, 0.1, -0.05, 0.001, -0.002], 5: [400.0, 401.0, 320.0, 240.0, 0.01, 0.02, -0.03, 0.004],
+              6: [650.0, 655.0, 322.0, 242.0, 0.1, 0.2, 0.003, 0.004, 0.5, 0.6, 0.7, 0.8], 8: [380.0, 320.0, 240.0, 0.07], 9: [390.0, 321.0, 241.0, 0.02, -0.004]}
+    params[20] = [805.0, 320.0, 240.0, 0.125]   # SIMPLE_RADIAL with k1 != 0 (kept as radial distortion)
+    cams = [(cid * 3 + 1, (2 if cid == 20 else cid), 640, 480, p) for cid, p in params.items()]
+    ids = [c[0] for c in cams]
+    images = []
+    for i in range(n_images):
+        q = rng.standard_normal(4) * (0.5 + i)         # un-normalised on purpose
+        t = rng.standard_normal(3) * 3
+        images.append((100 + i, list(q), list(t), ids[i % len(ids)], f"img_{i:03d}.png" if i % 2 else f"sub dir_{i}.JPG".replace(" ", "_")))
+    xyz = rng.standard_normal((57, 3)) * 2
+    rgb = rng.integers(0, 256, (57, 3))
+    return cams, images, xyz, rgb
+
+
+def _write(base, cams, images, xyz, rgb, layout="sparse/0", txt=False, images_folder="images", upper=False):
+    sp = os.path.join(base, layout) if layout else base
+    os.makedirs(sp, exist_ok=True)
+    os.makedirs(os.path.join(base, images_folder), exist_ok=True)
+    name = (lambda s: s.upper()) if upper else (lambda s: s)
+    if txt:
+        oc.write_cameras_txt(os.path.join(sp, name("cameras.txt")), cams, crlf=True)
+        oc.write_images_txt(os.path.join(sp, name("images.txt")), images, crlf=True)
+        oc.write_points3d_txt(os.path.join(sp, name("points3D.txt")), xyz, rgb)
+    else:
+        oc.write_cameras_bin(os.path.join(sp, name("cameras.bin")), cams)
+        oc.write_images_bin(os.path.join(sp, name("images.bin")), images)
+        oc.write_points3d_bin(os.path.join(sp, name("points3D.bin")), xyz, rgb)
+    return sp
+
+
+def _compare(views, center, ref_views, ref_center, base, folder):
+    assert len(views) == len(ref_views)
+    for v, r in zip(views, ref_views):
+        assert (v.camera_id, v.colmap_model, v.camera_model_type, v.width, v.height, v.image_name) == \
+               (r["camera_id"], r["colmap_model"], r["camera_model_type"], r["width"], r["height"], r["name"])
+        assert v.image_path == os.path.join(base, folder, r["name"])
+        for a, b in [(v.focal_x, r["focal_x"]), (v.focal_y, r["focal_y"]), (v.center_x, r["center_x"]), (v.center_y, r["center_y"])]:
+            assert abs(a - b) <= 2e-7 * abs(b), (a, b)
+        np.testing.assert_allclose(v.R, r["R"], rtol=0, atol=2e-7)
+        assert np.array_equal(v.T, r["T"]) and np.array_equal(v.params, r["params"])
+        assert np.array_equal(v.radial_distortion, r["radial"]) and np.array_equal(v.tangential_distortion, r["tangential"])
+    np.testing.assert_allclose(center, ref_center, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("layout,upper", [("sparse/0", False), ("sparse", True), ("", False)])
+def test_colmap_binary_and_text_match_oracle(ld, tmp_path, layout, upper):
+    rng = np.random.default_rng(11)
+    cams, images, xyz, rgb = _dataset(rng)
+    base = str(tmp_path / "scene")
+    sp = _write(base, cams, images, xyz, rgb, layout, txt=False, upper=upper)
+    _write(base, cams, images, xyz, rgb, layout, txt=True, upper=upper)
+    n = (lambda s: s.upper()) if upper else (lambda s: s)
+    ref_cams = oc.read_cameras_bin(os.path.join(sp, n("cameras.bin")))
+    ref_views, ref_center = oc.assemble(ref_cams, oc.read_images_bin(os.path.join(sp, n("images.bin"))))
+    views, center = ld.read_colmap_cameras_and_images(base, "images")
+    _compare(views, center, ref_views, ref_center, base, "images")
+    assert views[0].R.dtype == np.float32 and abs(np.linalg.det(views[0].R.astype(np.float64)) - 1) < 1e-5
+    # the model table: what ends up where
+    by_model = {v.colmap_model: v for v in views}
+    assert by_model[5].camera_model_type == 2 and len(by_model[5].radial_distortion) == 4 and len(by_model[5].tangential_distortion) == 0
+    assert len(by_model[6].radial_distortion) == 6 and list(by_model[6].tangential_distortion) == [np.float32(0.003), np.float32(0.004)]
+    assert by_model[0].focal_x == by_model[0].focal_y == np.float32(800.5)
+    k1_zero = [v for v in views if v.colmap_model == 2 and v.params[3] == 0][0]
+    k1_set = [v for v in views if v.colmap_model == 2 and v.params[3] != 0][0]
+    assert len(k1_zero.radial_distortion) == 0 and list(k1_set.radial_distortion) == [np.float32(0.125)]
+    # text files: float32 parsing of the decimal strings (std::stof), otherwise the same assembly
+    tviews, tcenter = ld.read_colmap_cameras_and_images_text(base, "images")
+    tref_views, tref_center = oc.assemble(oc.read_cameras_txt(os.path.join(sp, n("cameras.txt"))), oc.read_images_txt(os.path.join(sp, n("images.txt"))))
+    _compare(tviews, tcenter, tref_views, tref_center, base, "images")
+    # points
+    pc = ld.read_colmap_point_cloud(base)
+    assert np.array_equal(pc.means, xyz.astype(np.float32)) and np.array_equal(pc.colors, rgb.astype(np.uint8))
+    pct = ld.read_colmap_point_cloud_text(base)
+    assert np.array_equal(pct.means, xyz.astype(np.float32)) and np.array_equal(pct.colors, rgb.astype(np.uint8))
+
+
+def test_colmap_scale_factor_and_image_size_correction(ld, tmp_path):
+    rng = np.random.default_rng(5)
+    cams, images, xyz, rgb = _dataset(rng, n_images=4)
+    base = str(tmp_path / "scene")
+    sp = _write(base, cams, images, xyz, rgb, images_folder="images_4")
+    views, _ = ld.read_colmap_cameras_and_images(base, "images_4")
+    ref_views, _ = oc.assemble(oc.read_cameras_bin(os.path.join(sp, "cameras.bin"), 4.0), oc.read_images_bin(os.path.join(sp, "images.bin")))
+    for v, r in zip(views, ref_views):
+        assert (v.width, v.height) == (160, 120) == (r["width"], r["height"])
+        assert np.array_equal(v.params, r["params"]) and v.focal_x == r["focal_x"] and v.center_y == r["center_y"]
+    assert views[0].focal_x == np.float32(views[0].params[0]) and abs(views[0].params[0] * 4 - cams[[c[0] for c in cams].index(views[0].camera_id)][4][0]) < 1e-3
+    assert [oc.folder_scale(s) for s in ("images", "images_2", "images_x", "images_32", "a_b_8")] == [1.0, 2.0, 1.0, 1.0, 8.0]
+    # the first image exists with a different size: every view is rescaled to it (colmap.cpp:836-865)
+    ld.write_png(os.path.join(base, "images_4", images[0][4]), np.zeros((90, 200, 3), np.uint8))
+    views2, _ = ld.read_colmap_cameras_and_images(base, "images_4")
+    ref2, _ = oc.assemble(oc.read_cameras_bin(os.path.join(sp, "cameras.bin"), 4.0), oc.read_images_bin(os.path.join(sp, "images.bin")), first_image_size=(200, 90))
+    for v, r in zip(views2, ref2):
+        assert (v.width, v.height) == (200, 90)
+        assert v.focal_x == r["focal_x"] and v.focal_y == r["focal_y"] and v.center_x == r["center_x"] and v.center_y == r["center_y"]
+
+
+def test_colmap_error_behaviour(ld, tmp_path):
+    rng = np.random.default_rng(7)
+    cams, images, xyz, rgb = _dataset(rng, n_images=3)
+    base = str(tmp_path / "scene")
+    sp = _write(base, cams, images, xyz, rgb)
+    with pytest.raises(ld.LoaderError, match="Images folder does not exist"):
+        ld.read_colmap_cameras_and_images(base, "images_8")
+    with pytest.raises(ld.LoaderError, match="Cannot find 'cameras.txt'"):
+        ld.read_colmap_cameras_and_images_text(base, "images")
+    for fname, what in (("cameras.bin", "cameras.bin"), ("images.bin", "images.bin"), ("points3D.bin", "points3D.bin")):
+        path = os.path.join(sp, fname)
+        good = open(path, "rb").read()
+        open(path, "wb").write(good + b"\0")
+        with pytest.raises(ld.LoaderError, match=f"{what}: trailing bytes"):
+            ld.read_colmap_point_cloud(base) if fname.startswith("points") else ld.read_colmap_cameras_and_images(base, "images")
+        open(path, "wb").write(good[:-9])           # truncated: an error, not a read past the buffer
+        with pytest.raises(ld.LoaderError, match="unexpected end of file|trailing bytes|unterminated"):
+            ld.read_colmap_point_cloud(base) if fname.startswith("points") else ld.read_colmap_cameras_and_images(base, "images")
+        open(path, "wb").write(good)
+    # rejected models and ids
+    for model, n_params, msg in ((7, 5, "FOV camera model is not supported"), (10, 12, "THIN_PRISM_FISHEYE camera model is not supported")):
+        oc.write_cameras_bin(os.path.join(sp, "cameras.bin"), [(cams[0][0], model, 640, 480, [1.0] * n_params)])
+        oc.write_images_bin(os.path.join(sp, "images.bin"), [(1, [1, 0, 0, 0], [0, 0, 0], cams[0][0], "a.png")])
+        with pytest.raises(ld.LoaderError, match=msg):
+            ld.read_colmap_cameras_and_images(base, "images")
+    with open(os.path.join(sp, "cameras.bin"), "wb") as f:
+        f.write(struct.pack("<QIiQQ", 1, 1, 11, 640, 480))
+    with pytest.raises(ld.LoaderError, match="Unsupported camera-model id 11"):
+        ld.read_colmap_cameras_and_images(base, "images")
+    oc.write_cameras_bin(os.path.join(sp, "cameras.bin"), [(5, 1, 640, 480, [1.0, 1.0, 2.0, 2.0])])
+    oc.write_images_bin(os.path.join(sp, "images.bin"), [(1, [1, 0, 0, 0], [0, 0, 0], 6, "a.png")])
+    with pytest.raises(ld.LoaderError, match="Camera ID 6 not found"):
+        ld.read_colmap_cameras_and_images(base, "images")
+    open(os.path.join(sp, "images.txt"), "w").write("# c\n1 1 0 0 0 0 0 0 5 a.png\n\n2 1 0 0 0 0 0 0 5\n1 2 3\n")
+    open(os.path.join(sp, "cameras.txt"), "w").write("5 PINHOLE 640 480 1 1 2 2\n")
+    with pytest.raises(ld.LoaderError, match="Invalid format in images.txt line 3"):
+        ld.read_colmap_cameras_and_images_text(base, "images")
+    open(os.path.join(sp, "cameras.txt"), "w").write("5 PINHOLEX 640 480 1 1 2 2\n")
+    with pytest.raises(ld.LoaderError, match="Invalid format in cameras.txt"):
+        ld.read_colmap_cameras_and_images_text(base, "images")
+
+
+def test_ply_write_matches_reference_layout_and_reads_back(ld, tmp_path):
+    import torch
+    from lichtfeld_studio_amd.rasterizer import SplatModel
+    rng = np.random.default_rng(3)
+    N, K = 101, 9
+    arr = dict(means=rng.standard_normal((N, 3)), sh0=rng.standard_normal((N, 1, 3)), shN=rng.standard_normal((N, K - 1, 3)),
+               scales=rng.standard_normal((N, 3)), quats=rng.standard_normal((N, 4)) * 3, opac=rng.standard_normal(N))
+    t = {k: torch.tensor(v, dtype=torch.float32) for k, v in arr.items()}
+    model = SplatModel(t["means"], t["sh0"], t["shN"], t["scales"], t["quats"], t["opac"], 2)
+    path = str(tmp_path / "out" / "splat_7000.ply")
+    ld.save_ply(model, path)
+    f32 = {k: v.numpy() for k, v in t.items()}
+    ref = oc.ply_bytes(f32["means"], f32["sh0"], f32["shN"], f32["opac"], f32["scales"], f32["quats"])
+    got = open(path, "rb").read()
+    hdr_len = got.index(b"end_header\n") + 11
+    assert got[:hdr_len] == ref[:hdr_len]
+    a, b = np.frombuffer(got[hdr_len:], "<f4").reshape(N, -1), np.frombuffer(ref[hdr_len:], "<f4").reshape(N, -1)
+    assert a.shape[1] == 6 + 3 + 3 * (K - 1) + 1 + 3 + 4
+    assert np.array_equal(a[:, :-4], b[:, :-4]) and np.allclose(a[:, -4:], b[:, -4:], atol=1e-7)   # rotation normalised by torch vs numpy
+    names, data = ld.read_ply(path)
+    assert names == oc.ply_attribute_names(3, 3 * (K - 1)) and np.array_equal(data, a)
+    back = ld.load_ply(path, device="cpu")
+    for name, x, y in zip(["means", "sh0", "shN", "scales", "quats", "opac"], back.parameters(), [t["means"], t["sh0"], t["shN"], t["scales"],
+                                                                                                 torch.nn.functional.normalize(t["quats"], dim=-1), t["opac"]]):
+        assert x.shape == y.shape and torch.allclose(x.detach(), y, atol=1e-7), name
+    assert back.get_active_sh_degree() == 2
+    # generic reader: ascii, mixed types, an element after the vertices, doubles
+    p2 = str(tmp_path / "mixed.ply")
+    open(p2, "w").write("ply\nformat ascii 1.0\ncomment hi\nelement vertex 2\nproperty double x\nproperty float y\nproperty uchar red\nelement face 1\n"
+                        "property list uchar int vertex_indices\nend_header\n0.5 1.5 255\n-2 3e-1 7\n3 0 1 1\n")
+    names, data = ld.read_ply(p2)
+    assert names == ["x", "y", "red"] and np.array_equal(data, np.array([[0.5, 1.5, 255], [-2, 0.3, 7]], np.float32))
+    p3 = str(tmp_path / "bin.ply")
+    with open(p3, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 2\nproperty double x\nproperty short s\nproperty uchar c\nend_header\n")
+        f.write(struct.pack("<dhBdhB", 1.25, -3, 200, -7.5, 12, 1))
+    names, data = ld.read_ply(p3)
+    assert np.array_equal(data, np.array([[1.25, -3, 200], [-7.5, 12, 1]], np.float32))
+    for bad, msg in ((b"plx\n", "File too small|missing PLY header"), (b"ply\nformat binary_big_endian 1.0\nelement vertex 0\nend_header\n", "not supported"),
+                     (b"ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty float x\nend_header\nabcd", "truncated"),
+                     (b"ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty float x\n", "No end_header")):
+        open(p3, "wb").write(bad + b" " * 8)
+        with pytest.raises(ld.LoaderError, match=msg):
+            ld.read_ply(p3)
+
+
+def test_image_headers_decoders_and_sizes(ld, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    cases = {"rgb.png": Image.fromarray(rgb), "rgba.png": Image.fromarray(np.dstack([rgb, rgb[..., :1]]), "RGBA"), "grey.png": Image.fromarray(rgb[..., 0], "L"),
+             "la.png": Image.fromarray(rgb[..., :2], "LA"), "pal.png": Image.fromarray(rgb).quantize(17), "rgb.jpg": Image.fromarray(rgb),
+             "grey16.png": Image.fromarray((rgb[..., 0].astype(np.uint16) * 257))}
+    for name, im in cases.items():
+        p = str(tmp_path / name)
+        im.save(p, **({"quality": 95} if name.endswith("jpg") else {"optimize": name == "rgb.png"}))
+        w, h, c = ld.get_image_info(p)
+        assert (w, h) == (53, 37), name
+        assert c == {"rgb.png": 3, "rgba.png": 4, "grey.png": 1, "la.png": 2, "pal.png": 3, "rgb.jpg": 3, "grey16.png": 1}[name], name
+        got = ld.decode_rgb8(p)
+        assert got.shape == (37, 53, 3) and got.dtype == np.uint8
+        if name in ("rgb.png", "rgba.png"):
+            assert np.array_equal(got, rgb), name
+        elif name in ("grey.png", "grey16.png"):
+            assert np.array_equal(got, np.repeat(rgb[..., :1], 3, -1)), name
+        elif name == "la.png":      # 2 channels -> (r, g, (r + g) / 2), image_io.cpp:235-247
+            assert np.array_equal(got[..., :2], rgb[..., :2]) and np.array_equal(got[..., 2], ((rgb[..., 0].astype(int) + rgb[..., 1]) // 2).astype(np.uint8))
+        elif name == "pal.png":
+            assert np.array_equal(got, np.asarray(Image.open(p).convert("RGB")))
+        else:                        # JPEG goes through Pillow
+            assert np.array_equal(got, np.asarray(Image.open(p).convert("RGB")))
+    # PNM, and our own PNG writer through Pillow
+    pp = str(tmp_path / "a.ppm")
+    open(pp, "wb").write(b"P6\n# c\n53 37\n255\n" + rgb.tobytes())
+    assert ld.get_image_info(pp) == (53, 37, 3) and np.array_equal(ld.decode_rgb8(pp), rgb)
+    pg = str(tmp_path / "a.pgm")
+    open(pg, "wb").write(b"P5 53 37 255\n" + rgb[..., 1].tobytes())
+    assert ld.get_image_info(pg) == (53, 37, 1) and np.array_equal(ld.decode_rgb8(pg)[..., 2], rgb[..., 1])
+    pw = str(tmp_path / "w.png")
+    ld.write_png(pw, rgb)
+    assert np.array_equal(np.asarray(Image.open(pw)), rgb) and np.array_equal(ld.decode_rgb8(pw), rgb)
+    with pytest.raises(ld.LoaderError, match="Failed to open"):
+        ld.get_image_info(str(tmp_path / "missing.png"))
+    head = open(pw, "rb").read()[:60]
+    open(pw, "wb").write(head)
+    with pytest.raises(ld.LoaderError, match="PNG"):
+        ld.decode_rgb8(pw)
+    # load_image's output sizes (image_io.cpp:112-270)
+    for w, h, div, mw in [(1920, 1080, -1, 0), (1920, 1080, 1, 0), (1920, 1080, 2, 0), (4946, 3286, 4, 0), (4946, 3286, 8, 500), (1000, 3000, -1, 1600),
+                          (3000, 1000, 2, 1000), (5, 3, 8, 0), (1600, 1600, -1, 1600), (1601, 1600, -1, 1600)]:
+        assert ld.image_target_size(w, h, div, mw) == oc.target_size(w, h, div, mw), (w, h, div, mw)
+    with pytest.raises(ld.LoaderError, match="unsupported resize factor 3"):
+        ld.image_target_size(100, 100, 3, 0)
+
+
+def test_dataset_split_and_camera_matrices(ld):
+    cams = [ld.CameraData(i, 1, 0, 640, 480, 500.0, 510.0, 320.0, 240.0, np.eye(3, dtype=np.float32), np.array([1, 2, 3], np.float32), np.zeros(0, np.float32),
+                          np.zeros(0, np.float32), np.zeros(4, np.float32), f"{i}.png", f"/nonexistent/{i}.png") for i in range(20)]
+    tr, va, al = (ld.CameraDataset(cams, s, test_every=8) for s in ("train", "val", "all"))
+    assert va.indices == [0, 8, 16] and len(tr) == 17 and 8 not in tr.indices and len(al) == 20     # dataset.hpp:42
+    assert tr.image_size(0) == (640, 480) and ld.CameraDataset(cams, "all", 8, resize_factor=2).image_size(0) == (320, 240)
+    m = ld.world_to_view(cams[0])
+    assert np.array_equal(m[:3, 3], [1, 2, 3]) and np.array_equal(m[3], [0, 0, 0, 1])               # [R | t], camera.cpp:15-23
+    K = ld.intrinsics(cams[0], 320, 240)
+    assert np.array_equal(K, np.array([[250, 0, 160], [0, 255, 120], [0, 0, 1]], np.float32))          # camera.cpp:77-98
