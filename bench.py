@@ -121,6 +121,10 @@ def main() -> None:
     ap.add_argument("--views-per-rank", type=int, default=1)
     ap.add_argument("--rasterizer", default="gut", choices=["gut", "fastgs"], help="gut = the north-star 3DGUT path (default); fastgs = the reference's default EWA rasterizer (SURVEY.md §8f row 1)")
     ap.add_argument("--loss", default="mse", choices=["mse", "l1_ssim"], help="mse = rasterizer-only metric of SURVEY.md §8d (default); l1_ssim = the reference's photometric loss")
+    ap.add_argument("--start-iteration", type=int, default=3000,
+                    help="iteration counter the timed steps start from. Default 3000 = the steady state of a 7k-iteration run: SH degree 3 active and "
+                         "FusedAdam updating shN (the reference skips shN while iteration <= 1000, fused_adam.cpp:68-70; pass 0 for that cheaper phase)")
+    ap.add_argument("--replicated", action="store_true", help="multi-GPU: keep shN replicated (59 floats / Gaussian all-reduced) instead of SH-sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -146,7 +150,9 @@ def main() -> None:
         kw["sh_degree"] = 0
     scene = maker(**kw)
     n_views = scene.viewmats.shape[0]
-    trainer = GutTrainer(scene, device, iterations=7000, world=world, rank=rank, views_per_rank=args.views_per_rank, loss=args.loss, rasterizer=args.rasterizer)
+    trainer = GutTrainer(scene, device, iterations=7000, world=world, rank=rank, views_per_rank=args.views_per_rank, loss=args.loss, rasterizer=args.rasterizer,
+                         sh_sharded=False if args.replicated else None)
+    trainer.iteration = args.start_iteration
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
 
     # Warm-up. Its last (up to 3) steps run with every kernel scope timed (HIP events on the launch stream): that gives the
@@ -245,7 +251,8 @@ def main() -> None:
         "config": {"rasterizer": args.rasterizer, "workload": f"{scene.name}: {N} Gaussians, {scene.width}x{scene.height}, SH degree {scene.sh_degree}, "
                                f"16x16 tiles, {n_views} orbit cameras, {'MSE' if args.loss == 'mse' else 'L1 + 0.2 D-SSIM'} loss, default_optimization_params lrs",
                    "global_batch": world * args.views_per_rank, "views_per_rank": args.views_per_rank,
-                   "parallelism": f"dp{world}", "visible_gaussians": V, "n_isects": I},
+                   "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ""), "start_iteration": args.start_iteration,
+                   "visible_gaussians": V, "n_isects": I},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
     }
     print(json.dumps(out), flush=True)

@@ -1,8 +1,10 @@
 """Data-parallel sharding of training views (new capability: the reference is single-process,
 single-GPU). One process per GPU; Gaussians are replicated; rank r renders the
 views  step*world + r ; ONE all-reduce (RCCL over xGMI, backend "nccl" on ROCm) sums the flat
-59*N-float gradient bucket before the identical Adam step on every rank, so parameters stay
-bit-identical across ranks.
+gradient bucket before the identical Adam step on every rank, so the replicated parameters stay
+bit-identical across ranks. Two layouts: fully replicated (59 floats / Gaussian in
+the all-reduce at SH degree 3) and, by default for the fused 3DGUT step, SH-sharded (class ShExchange:
+14 floats / Gaussian in the all-reduce, shN and its Adam state owned by one rank each).
 """
 from __future__ import annotations
 
@@ -69,15 +71,116 @@ class GradBucket:
     def all_reduce(self, average: bool = False, skip_deferred: bool = False) -> None:
         if dist.is_initialized() and dist.get_world_size() > 1:
             buf = self.flat[:self.active_numel] if skip_deferred else self.flat
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            if _staged(buf):
+                host = buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                buf.copy_(host)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
             if average:
                 buf.div_(dist.get_world_size())
+
+
+def _staged(t: torch.Tensor) -> bool:
+    """gloo has no device collectives for every op: device tensors are staged through the host (tests on one GPU; RCCL needs no staging)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+class ShExchange:
+    """SH-sharded data parallelism: the higher-degree SH coefficients (shN: 45 of a Gaussian's 59 floats at degree 3) and their
+    Adam state are NOT replicated. Rank r owns the rows [r*S, (r+1)*S) of shN; per training step
+
+        radii  (8 B / Gaussian / view)  --all-to-all-->  owners            (which Gaussians each view sees)
+        owners evaluate SH for their rows for EVERY rank's view;  colours (12 B) --all-to-all--> the rendering ranks
+        ... rasterize forward / backward on the own view ...
+        dL/dcolour (12 B)  --all-to-all-->  owners;  owners run the SH backward for every view into their shard gradient
+        (and add the view-direction term of dL/dmeans into their rows of the replicated means gradient)
+
+    so the shN gradient never crosses xGMI: the step's all-reduce covers 14 floats per Gaussian instead of 59, and Adam touches
+    1/world of shN on each rank. Per Gaussian and step a rank moves 32 B through all-to-all + 56 B through the all-reduce,
+    against 236 B for the replicated layout; the SH arithmetic is the same in total (N Gaussian-views per rank either way).
+    The kernels are passed in (`sh_fwd`, `sh_bwd`: the signatures of fused.sh_model_fwd / sh_model_bwd) so the exchange logic is
+    testable on CPU with the oracle as stand-in (tests/test_dist_gloo.py)."""
+
+    def __init__(self, n_gaussians: int, world: int, rank: int):
+        self.N, self.world, self.rank = n_gaussians, world, rank
+        self.S = (n_gaussians + world - 1) // world
+        self.r0 = min(rank * self.S, n_gaussians)
+        self.r1 = min(self.r0 + self.S, n_gaussians)
+        self.n = self.r1 - self.r0
+
+    def shard(self, t: torch.Tensor) -> torch.Tensor:
+        return t[self.r0:self.r1]
+
+    def _pad(self, t: torch.Tensor) -> torch.Tensor:
+        """[N, ...] -> [world, S, ...] (zero rows after N)"""
+        out = torch.zeros((self.world * self.S,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        out[:self.N] = t
+        return out.view((self.world, self.S) + tuple(t.shape[1:]))
+
+    def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
+        """send[j] goes to rank j; recv[j] came from rank j"""
+        send = send.contiguous()
+        if self.world == 1 or not dist.is_initialized():
+            return send.clone()
+        if _staged(send):
+            host, out = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
+            dist.all_to_all_single(out, host)
+            return out.to(send.device)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send)
+        return recv
+
+    def gather_rows(self, shard_rows: torch.Tensor) -> torch.Tensor:
+        """Owner shards [n_r, ...] -> the full [N, ...] tensor on every rank (export, evaluation, strategies)."""
+        pad = torch.zeros((self.S,) + tuple(shard_rows.shape[1:]), dtype=shard_rows.dtype, device=shard_rows.device)
+        pad[:self.n] = shard_rows
+        if self.world == 1 or not dist.is_initialized():
+            return pad[:self.N]
+        if _staged(pad):
+            parts = [torch.empty(pad.shape, dtype=pad.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, pad.cpu())
+            return torch.cat(parts)[:self.N].to(pad.device)
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad)
+        return torch.cat(parts)[:self.N]
+
+    def forward(self, deg: int, means, sh0, shN_shard, radii, viewmats_all, sh_fwd):
+        """radii [N,2] int32 of THIS rank's view; viewmats_all[j] = the [1,4,4] view matrix rank j renders now.
+        -> (colours [N,3] of this rank's view, ctx for backward)"""
+        radii_recv = self._all_to_all(self._pad(radii))                     # [world, S, 2]: view j's radii for my rows
+        m, s0 = self.shard(means), self.shard(sh0)
+        colors_send = torch.zeros((self.world, self.S, 3), dtype=means.dtype, device=means.device)
+        for j in range(self.world):
+            if self.n:
+                colors_send[j, :self.n] = sh_fwd(deg, m, viewmats_all[j], s0, shN_shard, radii_recv[j, :self.n].unsqueeze(0).contiguous())
+        colors = self._all_to_all(colors_send).view(self.world * self.S, 3)[:self.N]
+        return colors.contiguous(), (radii_recv, colors_send)
+
+    def backward(self, ctx, deg: int, means, sh0, shN_shard, viewmats_all, v_colors, g_sh0, g_shN_shard, g_means, accumulate: bool, sh_bwd) -> None:
+        """v_colors [N,3] = dL/dcolours of this rank's view. Writes (accumulate False) or adds to g_shN_shard and MY rows of g_sh0 (the
+        other rows are zeroed / left alone: the all-reduce brings their owners' values), adds dL/d(dirs) into my rows of g_means."""
+        radii_recv, colors_send = ctx
+        v_recv = self._all_to_all(self._pad(v_colors))                      # [world, S, 3]: view j's dL/dcolour for my rows
+        if not accumulate:
+            g_sh0.zero_()
+        if not self.n:
+            return
+        m, s0 = self.shard(means), self.shard(sh0)
+        for j in range(self.world):
+            sh_bwd(deg, m, viewmats_all[j], s0, shN_shard, radii_recv[j, :self.n].unsqueeze(0).contiguous(), colors_send[j, :self.n].contiguous(),
+                   v_recv[j, :self.n].contiguous(), self.shard(g_sh0), g_shN_shard, self.shard(g_means), accumulate or j > 0)
 
 
 def all_reduce_sum(t: torch.Tensor) -> None:
     """In-place sum over ranks of a replicated-side tensor (bilateral-grid gradient, densification_info); no-op at world 1."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if _staged(t):
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
 def barrier() -> None:
@@ -87,7 +190,7 @@ def barrier() -> None:
 
 def max_over_ranks(value: float, device) -> float:
     if dist.is_initialized() and dist.get_world_size() > 1:
-        t = torch.tensor([value], dtype=torch.float64, device=device)
+        t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return value

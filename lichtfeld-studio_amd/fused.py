@@ -81,11 +81,13 @@ class FusedStepOutput:
 
 def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
                         grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool, loss: str = "mse",
-                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0) -> FusedStepOutput:
+                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None) -> FusedStepOutput:
     """One view: forward, loss against `target_chw` ("mse": the rasterizer-only metric of SURVEY.md §8d; "l1_ssim": the reference's
     photometric loss, trainer.cpp:115-128), backward. `grads` = six tensors shaped like model.parameters()
     (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
-    Constants as in rasterizer.cpp:176-181."""
+    Constants as in rasterizer.cpp:176-181.
+    With `sh_exchange` (dist.ShExchange; multi-GPU) model.shN / grads[2] hold only this rank's rows and the SH stages run on the
+    owners: `viewmats_all[j]` is the view matrix rank j renders in this call (every rank calls this the same number of times)."""
     assert camera.camera_model_type == CameraModelType.PINHOLE and camera.radial_distortion is None and camera.tangential_distortion is None, \
         "the fused path covers the trainer's undistorted pinhole cameras; use rasterizer.rasterize for the rest"
     W, H = int(camera.image_width), int(camera.image_height)
@@ -100,7 +102,10 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         quats, scales, opac = activations_fwd(raw_quats, raw_scales, raw_opac)
         radii, means2d, depths, _, _ = ops.projection_ut_3dgs_fused(means, quats, scales, opac, viewmat, None, Kmat, W, H, 0.3, 0.01, 10000.0, 0.0,
                                                                     False, CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None)
-        colors = sh_model_fwd(deg, means, viewmat, sh0, shN, radii)
+        if sh_exchange is None:
+            colors = sh_model_fwd(deg, means, viewmat, sh0, shN, radii)
+        else:
+            colors, sh_ctx = sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd)
         _, _, flatten_ids, offsets = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True)
         bg = None if bg_color is None else bg_color.view(1, -1).contiguous()
         fwd_args = (means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, None, W, H, tile, viewmat, None, Kmat,
@@ -116,11 +121,14 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
             *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws)
         # SH backward adds dL/d(dirs) onto the rasterizer's dL/d(means) in place, then the means gradient lands in the caller's buffer
-        sh_model_bwd(deg, means, viewmat, sh0, shN, radii, colors, v_colors.squeeze(0), g_sh0, g_shN, v_means, accumulate)
+        if sh_exchange is None:
+            sh_model_bwd(deg, means, viewmat, sh0, shN, radii, colors, v_colors.squeeze(0), g_sh0, g_shN, v_means, accumulate)
         if accumulate:
             g_means.add_(v_means)
         else:
             g_means.copy_(v_means)
+        if sh_exchange is not None:  # owners: SH backward of every rank's view for their rows (dL/d(dirs) straight into g_means)
+            sh_exchange.backward(sh_ctx, deg, means, sh0, shN, viewmats_all, v_colors.squeeze(0), g_sh0, g_shN, g_means, accumulate, sh_model_bwd)
         # the regularisers of trainer.cpp:132-158 are per step, not per view: the caller passes them with the first view only
         activations_bwd(raw_quats, scales, opac, v_quats, v_scales, v_opac.squeeze(0), g_quats, g_scales, g_opac, accumulate, scale_reg, opacity_reg)
     return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]))

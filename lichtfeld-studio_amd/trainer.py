@@ -19,7 +19,8 @@ class GutTrainer:
     def __init__(self, scene: Scene, device, iterations: int = 7000, world: int = 1, rank: int = 0,
                  views_per_rank: int = 1, fused_adam: bool = True, fused_l2: bool = True, loss: str = "mse", lambda_dssim: float = 0.2,
                  strategy: Optional[str] = None, opt_params=None, scene_scale: float = 1.0, seed: int = 0, rasterizer: str = "gut",
-                 use_bilateral_grid: bool = False, bilateral_grid_dims=(16, 16, 8), bilateral_grid_lr: float = 2e-3, tv_loss_weight: float = 10.0):
+                 use_bilateral_grid: bool = False, bilateral_grid_dims=(16, 16, 8), bilateral_grid_lr: float = 2e-3, tv_loss_weight: float = 10.0,
+                 sh_sharded: Optional[bool] = None):
         """strategy: None (fixed set of Gaussians: the benchmark), "mcmc" (strategies.MCMC: relocation + growth + SGLD noise, with
         the scale / opacity regularisers of trainer.cpp:132-158) or "default" (ADC; needs densification_info, see strategies.py).
         `seed` seeds the strategy's generator: the same on every rank, so replicas densify identically."""
@@ -27,7 +28,15 @@ class GutTrainer:
         sc = scene.to(device)
         self.scene = sc
         mk = lambda t: t.clone().contiguous().requires_grad_(True)
-        self.model = SplatModel(mk(sc.means), mk(sc.sh0), mk(sc.shN), mk(sc.raw_scales), mk(sc.raw_quats), mk(sc.raw_opacities), sc.sh_degree)
+        # SH-sharded data parallelism (dist.ShExchange): shN and its Adam state live on one rank each. Default for the fused 3DGUT step
+        # on more than one rank; the strategies index all parameters by Gaussian and keep the replicated layout.
+        if sh_sharded is None:
+            sh_sharded = world > 1 and fused_l2 and rasterizer == "gut" and strategy is None
+        if sh_sharded and not (fused_l2 and rasterizer == "gut" and strategy is None):
+            raise ValueError("sh_sharded needs the fused 3DGUT step without a densification strategy")
+        self.sh_exchange = lfs_dist.ShExchange(sc.means.shape[0], world, rank) if sh_sharded else None
+        shN0 = self.sh_exchange.shard(sc.shN) if sh_sharded else sc.shN
+        self.model = SplatModel(mk(sc.means), mk(sc.sh0), mk(shN0), mk(sc.raw_scales), mk(sc.raw_quats), mk(sc.raw_opacities), sc.sh_degree)
         self.rasterizer = rasterizer  # "gut" (3DGUT, the north-star path) | "fastgs" (the reference's default EWA rasterizer)
         self._fg_settings = {}
         self.strategy = None
@@ -158,15 +167,25 @@ class GutTrainer:
             self.scheduler.step()
         return self.loss_acc
 
+    def full_shN(self) -> torch.Tensor:
+        """[N,K-1,3] on every rank (all-gathers the owners' rows when SH-sharded): export, evaluation."""
+        return self.model.shN.detach() if self.sh_exchange is None else self.sh_exchange.gather_rows(self.model.shN.detach())
+
     def camera(self, view: int) -> Camera:
         sc = self.scene
         return Camera(sc.viewmats[view:view + 1].contiguous(), sc.Ks[view:view + 1].contiguous(), sc.width, sc.height)
 
-    def train_step(self, targets: List[torch.Tensor], views: Optional[List[int]] = None) -> float:
-        """One optimisation step on this rank's share of the global view batch."""
+    def train_step(self, targets: List[torch.Tensor], views: Optional[List[int]] = None, views_all: Optional[List[List[int]]] = None) -> float:
+        """One optimisation step on this rank's share of the global view batch. `views` overrides this rank's views of the round-robin
+        schedule; SH-sharded, the owners must know every rank's views: pass `views_all` (one list per rank) with an explicit schedule."""
         self.iteration += 1
+        if views_all is not None:
+            views = views_all[self.rank]
+        elif views is not None and self.sh_exchange is not None and self.world > 1:
+            raise ValueError("SH-sharded: pass views_all (every rank's views), the SH owners evaluate them")
         if views is None:
             views = lfs_dist.views_for_step(self.iteration - 1, self.rank, self.world, self.scene.viewmats.shape[0], self.views_per_rank)
+        self._views_all = views_all
         total_views = self.world * len(views)
         loss_value = None
         if self.rasterizer == "fastgs":
@@ -175,14 +194,21 @@ class GutTrainer:
             from .fused import render_and_backward
             params = self.model.parameters()
             self.loss_acc.zero_()
+            every = None
+            if self.sh_exchange is not None:  # what every rank renders at sub-step k (the owners evaluate SH for all of them)
+                every = self._views_all or [lfs_dist.views_for_step(self.iteration - 1, j, self.world, self.scene.viewmats.shape[0], len(views))
+                                            for j in range(self.world)]
             for k, v in enumerate(views):
+                vm_all = None if every is None else [self.scene.viewmats[e[k]:e[k] + 1].contiguous() for e in every]
                 out = render_and_backward(self.camera(v), self.model, self.bg, targets[k % len(targets)], 1.0 / total_views,
                                           self.bucket.views, self.loss_acc, accumulate=k > 0, loss=self.loss_kind, lambda_dssim=self.lambda_dssim,
                                           # regularisers: once per step, and 1/world of them per rank (the all-reduce sums the ranks)
                                           scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
-                                          opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0)
+                                          opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0,
+                                          sh_exchange=self.sh_exchange, viewmats_all=vm_all)
                 self.last_n_isects, self._last_radii = out.n_isects, out.radii
-            self.bucket.all_reduce(skip_deferred=self.iteration <= 1000)  # shN's gradient is not read by Adam until then
+            # the deferred segment (shN) stays out of the all-reduce while Adam does not read it (iteration <= 1000) and, SH-sharded, always
+            self.bucket.all_reduce(skip_deferred=self.iteration <= 1000 or self.sh_exchange is not None)
             for p, gv in zip(params, self.bucket.views):
                 p.grad = gv
             if self.strategy is not None:  # trainer.cpp:741-760: post_backward (may replace the parameter tensors) then step

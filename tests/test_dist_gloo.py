@@ -134,3 +134,109 @@ def test_deferred_bucket_segment_is_left_out_of_the_collective():
             local = float(rank + 1) * (i + 1)
             assert np.all(full[i] == total)
             assert np.all(part[i] == (local if i == 1 else total))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SH-sharded data parallelism (dist.ShExchange): the exchange logic with the oracle's SH as the stand-in kernels
+# ---------------------------------------------------------------------------------------------------------------------
+def _sh_standins(oracle):
+    """CPU stand-ins with the signatures of fused.sh_model_fwd / sh_model_bwd (what lfs_sh_model_fwd / _bwd compute)."""
+    def campos(viewmat):
+        m = viewmat.reshape(4, 4).double().numpy()
+        return -(m[:3, :3].T @ m[:3, 3])
+
+    def fwd(deg, means, viewmat, sh0, shN, radii):
+        dirs = means.double().numpy() - campos(viewmat)
+        mask = (radii.reshape(-1, 2).numpy() > 0).all(-1)
+        c = oracle.spherical_harmonics_fwd(deg, dirs, torch.cat([sh0, shN], 1).double().numpy(), mask, dtype=np.float64)
+        return torch.from_numpy(np.maximum(c + 0.5, 0.0)).float()
+
+    def bwd(deg, means, viewmat, sh0, shN, radii, colors, v_colors, v_sh0, v_shN, v_means, accumulate):
+        dirs = means.double().numpy() - campos(viewmat)
+        mask = (radii.reshape(-1, 2).numpy() > 0).all(-1)
+        vc = v_colors.double().numpy() * (colors.numpy() > 0)          # clamp_min backward
+        v_coeffs, v_dirs = oracle.spherical_harmonics_bwd(deg, dirs, torch.cat([sh0, shN], 1).double().numpy(), mask, vc, True, dtype=np.float64)
+        v_coeffs, v_dirs = torch.from_numpy(v_coeffs).float(), torch.from_numpy(v_dirs).float()
+        if accumulate:
+            v_sh0 += v_coeffs[:, :1]; v_shN += v_coeffs[:, 1:]
+        else:
+            v_sh0.copy_(v_coeffs[:, :1]); v_shN.copy_(v_coeffs[:, 1:])
+        v_means += v_dirs
+    return fwd, bwd
+
+
+def _sh_problem(world):
+    g = torch.Generator().manual_seed(5)
+    N, K, deg = 203, 9, 2                                  # N not divisible by the world size: the last shard is short
+    means = torch.randn(N, 3, generator=g)
+    sh0, shN = torch.randn(N, 1, 3, generator=g), torch.randn(N, K - 1, 3, generator=g)
+    viewmats, radii, v_colors = [], [], []
+    for j in range(world):
+        m = torch.eye(4)
+        m[:3, 3] = torch.randn(3, generator=g) * 3
+        viewmats.append(m[None])
+        radii.append((torch.rand(N, 2, generator=g) > 0.3).int() * 5)      # ~half of the Gaussians visible per view
+        v_colors.append(torch.randn(N, 3, generator=g))
+    return N, K, deg, means, sh0, shN, viewmats, radii, v_colors
+
+
+def _sh_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import oracle
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import dist as ld
+    ld.init_distributed(backend="gloo")
+    fwd, bwd = _sh_standins(oracle)
+    N, K, deg, means, sh0, shN, viewmats, radii, v_colors = _sh_problem(world)
+    ex = ld.ShExchange(N, world, rank)
+    shN_shard = ex.shard(shN).clone()
+    # two sub-steps (views_per_rank = 2): the second accumulates
+    g_sh0, g_shN, g_means = torch.zeros(N, 1, 3), torch.zeros(ex.n, K - 1, 3), torch.zeros(N, 3)
+    colors_seen = []
+    for k in range(2):
+        vm = [viewmats[(j + k) % world] for j in range(world)]
+        my = (rank + k) % world
+        colors, ctx = ex.forward(deg, means, sh0, shN_shard, radii[my], vm, fwd)
+        colors_seen.append(colors)
+        g_means += 0.0 if k else 1.0                        # stands for the rasterizer's own dL/dmeans (copy_ / add_ happen before the SH backward)
+        ex.backward(ctx, deg, means, sh0, shN_shard, vm, v_colors[my] * (k + 1), g_sh0, g_shN, g_means, k > 0, bwd)
+    bucket = ld.GradBucket([g_means, g_sh0])
+    bucket.gather([g_means, g_sh0])
+    bucket.all_reduce()
+    full = ex.gather_rows(g_shN)
+    q.put((rank, [c.numpy() for c in colors_seen], bucket.views[0].numpy().copy(), bucket.views[1].numpy().copy(), full.numpy(), (ex.r0, ex.r1)))
+    dist.destroy_process_group()
+
+
+def test_sh_sharded_exchange_matches_replicated_computation():
+    import oracle
+    oracle.lib()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sh_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # replicated reference: every rank evaluates SH for its own views on the full tensors, gradients summed over ranks
+    fwd, bwd = _sh_standins(oracle)
+    N, K, deg, means, sh0, shN, viewmats, radii, v_colors = _sh_problem(world)
+    ref_sh0, ref_shN, ref_means = torch.zeros(N, 1, 3), torch.zeros(N, K - 1, 3), torch.full((N, 3), float(world))
+    for rank in range(world):
+        for k in range(2):
+            my = (rank + k) % world
+            c = fwd(deg, means, viewmats[my], sh0, shN, radii[my])
+            vis = (radii[my] > 0).all(-1)
+            assert np.allclose(results[rank][1][k][vis.numpy()], c.numpy()[vis.numpy()], atol=1e-6)      # colours of the visible Gaussians
+            bwd(deg, means, viewmats[my], sh0, shN, radii[my], c, v_colors[my] * (k + 1), ref_sh0, ref_shN, ref_means, True)
+    assert results[0][5] == (0, 102) and results[1][5] == (102, 203)
+    for rank in range(world):
+        assert np.allclose(results[rank][2], ref_means.numpy(), atol=2e-5), "means gradient (rasterizer part + SH view-direction part)"
+        assert np.allclose(results[rank][3], ref_sh0.numpy(), atol=2e-5)
+        assert np.allclose(results[rank][4], ref_shN.numpy(), atol=2e-5), "all-gathered shard gradients == replicated shN gradient"
+    assert np.array_equal(results[0][4], results[1][4])

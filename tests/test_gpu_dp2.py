@@ -1,0 +1,80 @@
+"""GPU, two processes on ONE device over gloo (device tensors staged through the host in dist.py; RCCL refuses two ranks on
+one GPU, and the driver's multi-GPU run is the only place with more than one): the data-parallel step end to end with the real HIP
+kernels. Both layouts - SH-sharded (default) and fully replicated - must reproduce a single process that renders the same
+global batch (views_per_rank = 2) up to fp32 summation order, and keep the replicated parameters bit-identical across ranks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS = 4
+
+
+def _scene():
+    from lichtfeld_studio_amd import scenes
+    sc = scenes._syn_box("SYN-DP", 3, 6001, 192, 128, 150.0, 8, sh_degree=2)     # odd N: uneven shards
+    sc.raw_scales += float(np.log(6.0))
+    return sc
+
+
+def _worker(rank, world, port, sharded, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import dist as ld, scenes
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    ld.init_distributed(backend="gloo")
+    dev = torch.device("cuda:0")
+    sc = _scene()
+    tr = GutTrainer(sc, dev, iterations=100, world=world, rank=rank, sh_sharded=sharded)
+    tr.iteration = 1000           # past the shN warm-up: Adam updates shN, the replicated layout all-reduces it
+    target = scenes.target_image(sc.height, sc.width).to(dev) * 0.6
+    losses = [float(tr.train_step([target])) for _ in range(STEPS)]
+    params = [p.detach().cpu().numpy() for p in tr.model.parameters()]
+    params[2] = tr.full_shN().cpu().numpy()
+    q.put((rank, params, losses, tuple(tr.model.shN.shape)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded", [True, False])
+def test_two_rank_step_matches_single_process(lfs, sharded):
+    from lichtfeld_studio_amd import scenes
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + int(sharded)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, sharded, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=600) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single process, same global batch
+    dev = torch.device("cuda:0")
+    sc = _scene()
+    tr = GutTrainer(sc, dev, iterations=100, views_per_rank=2)
+    tr.iteration = 1000
+    target = scenes.target_image(sc.height, sc.width).to(dev) * 0.6
+    ref_losses = [float(tr.train_step([target])) for _ in range(STEPS)]
+    ref = [p.detach().cpu().numpy() for p in tr.model.parameters()]
+    (_, p0, l0, s0), (_, p1, l1, s1) = results
+    N = sc.means.shape[0]
+    assert (s0[0], s1[0]) == ((3001, 3000) if sharded else (N, N))
+    for name, a, b, r in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], p0, p1, ref):
+        assert np.array_equal(a, b), f"{name}: ranks diverged"
+        # Adam normalises the step: a gradient that differs in the last bits moves a parameter by the same lr - compare the update
+        # (elements whose gradient is pure rounding noise may step the other way: allow 0.01 % of them)
+        tol = 2e-3 * np.abs(r - _scene_param(sc, name)).max() + 1e-7
+        assert (np.abs(a - r) > tol).mean() < 1e-4, (name, np.abs(a - r).max(), tol)
+    assert np.allclose(np.array(l0) + np.array(l1), ref_losses, rtol=1e-5)      # each rank reports its share of the loss
+    assert float(np.abs(ref[2] - sc.shN.numpy()).max()) > 0                     # shN did train
+
+
+def _scene_param(sc, name):
+    return {"means": sc.means, "sh0": sc.sh0, "shN": sc.shN, "raw_scales": sc.raw_scales, "raw_quats": sc.raw_quats, "raw_opacities": sc.raw_opacities}[name].numpy()
