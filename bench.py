@@ -48,6 +48,9 @@ def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems
         "raster_bwd": 60 * I + 24 * P + 56 * N + 112 * V,
         "raster_finish": 64 * N + 44 * N + 56 * N,
         "sh_bwd": 24 * V + 12 * K * V + 12 * K * N + 12 * K * V + 12 * V,
+        # single-view steps: SH backward with shN's Adam update inside (no shN gradient tensor): read p, m, v + write p, m, v of shN,
+        # dL/dcolour + colour + means + radii of the visible, sh0 gradient out
+        "sh_bwd_adam": 6 * 12 * (K - 1) * N + 48 * V + 12 * N + 12 * V,
         "activations_fwd": 2 * 32 * N, "activations_bwd": 32 * N + 32 * N + 32 * N + 32 * N,
         "mse_loss": 36 * P, "photometric_loss": 36 * P + 2 * 36 * P,
         "adam_multi": 28 * adam_elems,
@@ -201,8 +204,9 @@ def main() -> None:
     P = scene.width * scene.height
     T = ((scene.width + 15) // 16) * ((scene.height + 15) // 16)
     adam_elems = sum(p.numel() for p in trainer.model.parameters())
-    if trainer.iteration <= 1000:
-        adam_elems -= trainer.model.shN.numel()  # the shN group is skipped while iteration <= 1000 (fused_adam.cpp:68-70)
+    if trainer.iteration <= 1000 or (world == 1 and args.views_per_rank == 1 and trainer.inline_shN_adam and args.rasterizer == "gut"):
+        # shN is not in the optimizer launch: skipped while iteration <= 1000 (fused_adam.cpp:68-70), updated inside sh_bwd_adam afterwards
+        adam_elems -= trainer.model.shN.numel()
     bytes_per = algorithmic_bytes(N, V, I, P, T, K, adam_elems)
 
     roofline = None

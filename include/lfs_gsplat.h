@@ -190,6 +190,14 @@ LFS_API int lfs_sh_model_bwd(
     uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
     const int32_t* radii, const float* colors, const float* v_colors, int accumulate,
     float* v_sh0, float* v_shN, float* v_means, lfs_stream_t stream);
+/* lfs_sh_model_bwd for a step with ONE view, fused with the optimizer: the gradient of shN is not stored but consumed by the
+ * Adam update (fast_gs::optimizer::adam_step arithmetic, adam_kernels.cuh:13-36) of shN / its moments in place; v_sh0 written,
+ * v_means += dL/d(dirs) computed from the pre-update shN. Element-wise identical to lfs_sh_model_bwd + lfs_adam_step on shN. */
+LFS_API int lfs_sh_model_bwd_adam(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, float* shN,
+    const int32_t* radii, const float* colors, const float* v_colors, float* v_sh0, float* v_means,
+    float* shN_exp_avg, float* shN_exp_avg_sq, float lr, float beta1, float beta2, float eps, float bias_correction1_rcp,
+    float bias_correction2_sqrt_rcp, lfs_stream_t stream);
 LFS_API int lfs_activations_fwd(uint32_t N, const float* raw_quats, const float* raw_scales, const float* raw_opacities,
                                 float* quats, float* scales, float* opacities, lfs_stream_t stream);
 LFS_API int lfs_activations_bwd(uint32_t N, const float* raw_quats, const float* scales, const float* opacities,

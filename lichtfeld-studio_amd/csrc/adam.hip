@@ -12,19 +12,9 @@
 #include <hip/hip_runtime.h>
 #include "../../include/lfs_gsplat.h"
 #include "lfs_prof.h"
+#include "lfs_adam.cuh"
 
 namespace lfs {
-
-struct AdamScalars { float lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp; };
-
-__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, const float g, const AdamScalars& s) {
-    const float m1 = s.beta1 * m + (1.0f - s.beta1) * g;
-    const float m2 = s.beta2 * v + (1.0f - s.beta2) * g * g;
-    const float denom = sqrtf(m2) * s.bc2_sqrt_rcp + s.eps;
-    const float step = s.lr * s.bc1_rcp;
-    p -= step * m1 / denom;
-    m = m1; v = m2;
-}
 
 __device__ __forceinline__ void adam_range(float* __restrict__ param, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                             const float* __restrict__ grad, const int64_t n, const AdamScalars& s,

@@ -11,6 +11,7 @@
 // per Gaussian in a lane-per-Gaussian phase and handed over through LDS (see the kernels).
 #include "lfs_math.cuh"
 #include "lfs_prof.h"
+#include "lfs_adam.cuh"
 #include "../../include/lfs_gsplat.h"
 
 namespace lfs {
@@ -186,10 +187,15 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
 // op   : v_coeffs [n,K,3] fully written, v_dirs [n,3] (or NULL) fully written.
 // model: v_colors = dL/d(clamped colors), the clamp passes where the stored colour is > 0; v_sh0 / v_shN written
 //        (ACCUM = false) or added to (ACCUM = true: second and later views of a step); v_means += dL/d(dirs).
-template <int LPG, bool MODEL, bool ACCUM>
+// ADAM (model form, single view): the higher-degree gradient rows are not stored at all - basis * dL/dcolour is consumed by the
+//        Adam update of shN on the spot (v_shN unused; adam.m / adam.v = its moments). Saves the 180 B / Gaussian write here and the
+//        180 B / Gaussian read in the optimizer kernel; element-wise identical to sh_bwd followed by adam_step on shN.
+struct ShAdam { float* m; float* v; AdamScalars s; };
+
+template <int LPG, bool MODEL, bool ACCUM, bool ADAM = false>
 __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float* __restrict__ v_colors,
                                                     float* __restrict__ v_coeffs, float* __restrict__ v_sh0, float* __restrict__ v_shN,
-                                                    float* __restrict__ v_dirs) {
+                                                    float* __restrict__ v_dirs, const ShAdam adam = ShAdam{}) {
     __shared__ float lds[64 * (LPG + 1)];
     __shared__ float ldv[64 * 3];
     const uint32_t lane = threadIdx.x;
@@ -233,18 +239,28 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
         if (g >= a.n || uint32_t(k) >= a.K) continue;
         const float bk = lds[gl * (LPG + 1) + k]; // 0 for masked-out Gaussians and for k >= Kd
         const float v0 = ldv[gl * 3], v1 = ldv[gl * 3 + 1], v2 = ldv[gl * 3 + 2];
-        float* vc = sh_coef<MODEL>(v_coeffs, v_sh0, v_shN, a.K, g, k);
         const float o0 = bk * v0, o1 = bk * v1, o2 = bk * v2;
-        if (ACCUM) { if (bk != 0.f) { vc[0] += o0; vc[1] += o1; vc[2] += o2; } }
-        else { vc[0] = o0; vc[1] = o1; vc[2] = o2; }
-        if (want_dirs) {
-            float sk = 0.f;
-            if (k >= 1 && k < Kd && (v0 != 0.f || v1 != 0.f || v2 != 0.f)) { // (basis 0 is constant: no direction gradient, sh0 is not read)
+        float sk = 0.f;
+        if (ADAM && k >= 1) {
+            // shN[g][k-1][:] : read once (the direction gradient needs the pre-update value), update, write back
+            const size_t e = (size_t(g) * (a.K - 1) + (k - 1)) * 3;
+            float* pp = const_cast<float*>(a.shN) + e;
+            float p0 = pp[0], p1 = pp[1], p2 = pp[2];
+            if (want_dirs && k < Kd) sk = p0 * v0 + p1 * v1 + p2 * v2;
+            float m0 = adam.m[e], m1 = adam.m[e + 1], m2 = adam.m[e + 2], q0 = adam.v[e], q1 = adam.v[e + 1], q2 = adam.v[e + 2];
+            adam_elem(p0, m0, q0, o0, adam.s); adam_elem(p1, m1, q1, o1, adam.s); adam_elem(p2, m2, q2, o2, adam.s);
+            pp[0] = p0; pp[1] = p1; pp[2] = p2;
+            adam.m[e] = m0; adam.m[e + 1] = m1; adam.m[e + 2] = m2; adam.v[e] = q0; adam.v[e + 1] = q1; adam.v[e + 2] = q2;
+        } else {
+            float* vc = sh_coef<MODEL>(v_coeffs, v_sh0, v_shN, a.K, g, k);
+            if (ACCUM) { if (bk != 0.f) { vc[0] += o0; vc[1] += o1; vc[2] += o2; } }
+            else { vc[0] = o0; vc[1] = o1; vc[2] = o2; }
+            if (want_dirs && k >= 1 && k < Kd && (v0 != 0.f || v1 != 0.f || v2 != 0.f)) { // (basis 0 is constant: no direction gradient, sh0 is not read)
                 const float* cf = sh_coef<MODEL>(a.coeffs, a.sh0, a.shN, a.K, g, k);
                 sk = cf[0] * v0 + cf[1] * v1 + cf[2] * v2;
             }
-            lds[gl * (LPG + 1) + k] = sk;
         }
+        if (want_dirs) lds[gl * (LPG + 1) + k] = sk;
     }
     if (v_dirs == nullptr) return;
     __syncthreads();
@@ -293,6 +309,18 @@ static int sh_launch_bwd(const ShArgs& a, const float* v_colors, float* v_coeffs
     case 4: hipLaunchKernelGGL((sh_bwd_kernel<4, MODEL, ACCUM>), grid, block, 0, s, a, v_colors, v_coeffs, v_sh0, v_shN, v_dirs); break;
     case 16: hipLaunchKernelGGL((sh_bwd_kernel<16, MODEL, ACCUM>), grid, block, 0, s, a, v_colors, v_coeffs, v_sh0, v_shN, v_dirs); break;
     default: hipLaunchKernelGGL((sh_bwd_kernel<32, MODEL, ACCUM>), grid, block, 0, s, a, v_colors, v_coeffs, v_sh0, v_shN, v_dirs); break;
+    }
+    return (int)hipGetLastError();
+}
+
+static int sh_launch_bwd_adam(const ShArgs& a, const float* v_colors, float* v_sh0, float* v_dirs, const ShAdam& adam, hipStream_t s) {
+    const dim3 grid((a.n + 63) / 64), block(64);
+    lfs::ProfScope prof("sh_bwd_adam", s);
+    switch (lanes_for(a.K)) {
+    case 1: return LFS_E_INVALID; // K == 1: there is no shN
+    case 4: hipLaunchKernelGGL((sh_bwd_kernel<4, true, false, true>), grid, block, 0, s, a, v_colors, nullptr, v_sh0, nullptr, v_dirs, adam); break;
+    case 16: hipLaunchKernelGGL((sh_bwd_kernel<16, true, false, true>), grid, block, 0, s, a, v_colors, nullptr, v_sh0, nullptr, v_dirs, adam); break;
+    default: hipLaunchKernelGGL((sh_bwd_kernel<32, true, false, true>), grid, block, 0, s, a, v_colors, nullptr, v_sh0, nullptr, v_dirs, adam); break;
     }
     return (int)hipGetLastError();
 }
@@ -364,4 +392,19 @@ extern "C" int lfs_sh_model_bwd(
     a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
     if (accumulate) return lfs::sh_launch_bwd<true, true>(a, v_colors, nullptr, v_sh0, v_shN, v_means, (hipStream_t)stream);
     return lfs::sh_launch_bwd<true, false>(a, v_colors, nullptr, v_sh0, v_shN, v_means, (hipStream_t)stream);
+}
+
+extern "C" int lfs_sh_model_bwd_adam(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, float* shN,
+    const int32_t* radii, const float* colors, const float* v_colors, float* v_sh0, float* v_means,
+    float* shN_exp_avg, float* shN_exp_avg_sq, float lr, float beta1, float beta2, float eps, float bias_correction1_rcp,
+    float bias_correction2_sqrt_rcp, lfs_stream_t stream) {
+    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
+    if (degrees_to_use > 4 || Kd > K || K > 32 || K < 2) return LFS_E_INVALID;
+    if (n == 0) return LFS_OK;
+    if (!means || !viewmat || !sh0 || !shN || !radii || !colors || !v_colors || !v_sh0 || !v_means || !shN_exp_avg || !shN_exp_avg_sq) return LFS_E_INVALID;
+    lfs::ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
+    const lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp}};
+    return lfs::sh_launch_bwd_adam(a, v_colors, v_sh0, v_means, adam, (hipStream_t)stream);
 }

@@ -59,6 +59,16 @@ def sh_model_bwd(sh_degree: int, means, viewmat, sh0, shN, radii, colors, v_colo
                                           ptr(v_sh0), ptr(v_shN), ptr(v_means), stream()), "sh_model_bwd")
 
 
+def sh_model_bwd_adam(sh_degree: int, means, viewmat, sh0, shN, radii, colors, v_colors, v_sh0, v_means, adam: dict):
+    """sh_model_bwd of a single-view step with the Adam update of shN applied in the same kernel (`adam`: FusedAdam.prepare_inline)."""
+    require_gpu(means, viewmat, sh0, shN, radii, colors, v_colors, v_sh0, v_means, adam["exp_avg"], adam["exp_avg_sq"])
+    N, K = means.shape[0], 1 + shN.shape[1]
+    check(load_library().lfs_sh_model_bwd_adam(C.c_uint32(N), C.c_uint32(K), C.c_uint32(sh_degree), ptr(means), ptr(viewmat), ptr(sh0), ptr(shN),
+                                               ptr(radii), ptr(colors), ptr(v_colors), ptr(v_sh0), ptr(v_means), ptr(adam["exp_avg"]), ptr(adam["exp_avg_sq"]),
+                                               C.c_float(adam["lr"]), C.c_float(adam["beta1"]), C.c_float(adam["beta2"]), C.c_float(adam["eps"]),
+                                               C.c_float(adam["bc1_rcp"]), C.c_float(adam["bc2_sqrt_rcp"]), stream()), "sh_model_bwd_adam")
+
+
 def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
     """loss_acc (1-element tensor) += weight * mse(clamp(render, 0, 1), target); returns dL/d(render) [H,W,3]."""
     target_chw = target_chw.contiguous()  # (a CHW view of an HWC render is a common caller mistake; no-op otherwise)
@@ -81,13 +91,14 @@ class FusedStepOutput:
 
 def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
                         grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool, loss: str = "mse",
-                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None) -> FusedStepOutput:
+                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None, adam_shN: Optional[dict] = None) -> FusedStepOutput:
     """One view: forward, loss against `target_chw` ("mse": the rasterizer-only metric of SURVEY.md §8d; "l1_ssim": the reference's
     photometric loss, trainer.cpp:115-128), backward. `grads` = six tensors shaped like model.parameters()
     (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
     Constants as in rasterizer.cpp:176-181.
     With `sh_exchange` (dist.ShExchange; multi-GPU) model.shN / grads[2] hold only this rank's rows and the SH stages run on the
-    owners: `viewmats_all[j]` is the view matrix rank j renders in this call (every rank calls this the same number of times)."""
+    owners: `viewmats_all[j]` is the view matrix rank j renders in this call (every rank calls this the same number of times).
+    With `adam_shN` (FusedAdam.prepare_inline; one view per step on one rank) grads[2] is not written: shN is updated in place."""
     assert camera.camera_model_type == CameraModelType.PINHOLE and camera.radial_distortion is None and camera.tangential_distortion is None, \
         "the fused path covers the trainer's undistorted pinhole cameras; use rasterizer.rasterize for the rest"
     W, H = int(camera.image_width), int(camera.image_height)
@@ -121,7 +132,10 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
             *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws)
         # SH backward adds dL/d(dirs) onto the rasterizer's dL/d(means) in place, then the means gradient lands in the caller's buffer
-        if sh_exchange is None:
+        if adam_shN is not None:     # single view, single rank: shN's gradient is consumed by its Adam update inside the SH backward
+            assert sh_exchange is None and not accumulate
+            sh_model_bwd_adam(deg, means, viewmat, sh0, shN, radii, colors, v_colors.squeeze(0), g_sh0, v_means, adam_shN)
+        elif sh_exchange is None:
             sh_model_bwd(deg, means, viewmat, sh0, shN, radii, colors, v_colors.squeeze(0), g_sh0, g_shN, v_means, accumulate)
         if accumulate:
             g_means.add_(v_means)

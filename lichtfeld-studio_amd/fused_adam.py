@@ -27,6 +27,7 @@ class FusedAdam:
             self.param_groups.append(g)
         self.state = {}
         self.fused = fused
+        self._inline_done = set()
 
     def _state(self, p: torch.Tensor) -> dict:
         st = self.state.get(id(p))
@@ -35,6 +36,20 @@ class FusedAdam:
             self.state[id(p)] = st
         return st
 
+    def prepare_inline(self, p: torch.Tensor) -> dict:
+        """The scalars and moment tensors of this step's update of `p`, for a producer kernel that applies Adam itself
+        (lfs_sh_model_bwd_adam). Advances step_count; the next step() skips `p` (once)."""
+        for group in self.param_groups:
+            if any(q is p for q in group["params"]):
+                st = self._state(p)
+                st["step_count"] += 1
+                beta1, beta2 = group["betas"]
+                self._inline_done.add(id(p))
+                return {"exp_avg": st["exp_avg"], "exp_avg_sq": st["exp_avg_sq"], "lr": float(group["lr"]), "beta1": float(beta1), "beta2": float(beta2),
+                        "eps": float(group["eps"]), "bc1_rcp": float(1.0 / (1.0 - math.pow(beta1, st["step_count"]))),
+                        "bc2_sqrt_rcp": float(1.0 / math.sqrt(1.0 - math.pow(beta2, st["step_count"])))}
+        raise ValueError("prepare_inline: not a parameter of this optimizer")
+
     @torch.no_grad()
     def step(self, iteration: int) -> None:
         entries = []
@@ -42,6 +57,9 @@ class FusedAdam:
             lr, eps = group["lr"], group["eps"]
             beta1, beta2 = group["betas"]
             for p in group["params"]:
+                if id(p) in self._inline_done:   # updated by its producer kernel in this step
+                    self._inline_done.discard(id(p))
+                    continue
                 if p.grad is None:
                     continue
                 st = self._state(p)

@@ -75,6 +75,7 @@ class GutTrainer:
         self.loss_kind, self.lambda_dssim = loss, lambda_dssim  # "mse" | "l1_ssim" (trainer.cpp:115-128)
         self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2]) if (world > 1 or fused_l2) else None  # 2 = shN
         self.loss_acc = torch.zeros(1, device=device)
+        self.inline_shN_adam = True   # see train_step; False keeps the SH backward and the optimizer separate (tests compare the two)
         self.iteration = 0
         self.last_n_isects = 0
         self._last_radii = None
@@ -198,6 +199,11 @@ class GutTrainer:
             if self.sh_exchange is not None:  # what every rank renders at sub-step k (the owners evaluate SH for all of them)
                 every = self._views_all or [lfs_dist.views_for_step(self.iteration - 1, j, self.world, self.scene.viewmats.shape[0], len(views))
                                             for j in range(self.world)]
+            # one view, one rank, Adam reading shN (iteration > 1000): the SH backward applies shN's Adam update itself (no shN gradient tensor)
+            inline = None
+            if (self.inline_shN_adam and self.world == 1 and len(views) == 1 and self.strategy is None and self.iteration > 1000
+                    and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False)):
+                inline = self.optimizer.prepare_inline(self.model.shN)
             for k, v in enumerate(views):
                 vm_all = None if every is None else [self.scene.viewmats[e[k]:e[k] + 1].contiguous() for e in every]
                 out = render_and_backward(self.camera(v), self.model, self.bg, targets[k % len(targets)], 1.0 / total_views,
@@ -205,7 +211,7 @@ class GutTrainer:
                                           # regularisers: once per step, and 1/world of them per rank (the all-reduce sums the ranks)
                                           scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
                                           opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0,
-                                          sh_exchange=self.sh_exchange, viewmats_all=vm_all)
+                                          sh_exchange=self.sh_exchange, viewmats_all=vm_all, adam_shN=inline)
                 self.last_n_isects, self._last_radii = out.n_isects, out.radii
             # the deferred segment (shN) stays out of the all-reduce while Adam does not read it (iteration <= 1000) and, SH-sharded, always
             self.bucket.all_reduce(skip_deferred=self.iteration <= 1000 or self.sh_exchange is not None)

@@ -122,3 +122,53 @@ def test_fused_and_autograd_trainers_take_the_same_steps(lfs):
     for pa, pb in zip(a.model.parameters(), b.model.parameters()):
         # Adam normalises every gradient to ~lr-sized steps, so atomics-order noise on tiny gradients is visible: compare loosely
         assert float((pa - pb).abs().max()) < 5e-3 and rel_l2(n(pa), n(pb)) < 1e-4
+
+
+def test_inline_shN_adam_is_bit_identical_to_separate_kernels(lfs):
+    """lfs_sh_model_bwd_adam (SH backward + Adam on shN in one kernel, no shN gradient tensor) against lfs_sh_model_bwd followed by
+    lfs_adam_step on shN, same inputs: shN, both moments, v_sh0 and v_means bit-identical, over several chained updates. (Whole
+    training runs cannot be compared bit for bit: the rasterizer backward sums with float atomics.)"""
+    from lichtfeld_studio_amd import fused, ops, scenes
+    from lichtfeld_studio_amd.fused_adam import FusedAdam
+    dev = torch.device(DEV)
+    sc = scenes.syn_a(n=7001, sh_degree=3).to(dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    N = sc.means.shape[0]
+    radii = (torch.rand(1, N, 2, device=dev, generator=g) > 0.25).int() * 3          # a quarter of the Gaussians invisible
+    vm = sc.viewmats[:1].contiguous()
+    for deg in (3, 1):
+        pa, pb = sc.shN.clone(), sc.shN.clone()
+        oa, ob = FusedAdam([{"params": [pa], "lr": 2.5e-3 / 20}]), FusedAdam([{"params": [pb], "lr": 2.5e-3 / 20}])
+        for it in range(4):
+            colors = fused.sh_model_fwd(deg, sc.means, vm, sc.sh0, pa, radii)
+            v_colors = torch.randn(N, 3, device=dev, generator=g)
+            # separate kernels
+            v_sh0_b, v_shN_b, v_means_b = torch.empty_like(sc.sh0), torch.empty_like(pb), torch.ones(N, 3, device=dev)
+            fused.sh_model_bwd(deg, sc.means, vm, sc.sh0, pb, radii, colors, v_colors, v_sh0_b, v_shN_b, v_means_b, False)
+            pb.grad = v_shN_b
+            ob.step(2000 + it)
+            # one kernel
+            v_sh0_a, v_means_a = torch.empty_like(sc.sh0), torch.ones(N, 3, device=dev)
+            fused.sh_model_bwd_adam(deg, sc.means, vm, sc.sh0, pa, radii, colors, v_colors, v_sh0_a, v_means_a, oa.prepare_inline(pa))
+            pa.grad = torch.full_like(pa, float("nan"))      # must not be read
+            oa.step(2000 + it)
+            assert torch.equal(pa, pb) and torch.equal(v_sh0_a, v_sh0_b) and torch.equal(v_means_a, v_means_b), (deg, it)
+            sa, sb = oa._state(pa), ob._state(pb)
+            assert sa["step_count"] == sb["step_count"] == it + 1
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+        assert float((pa - sc.shN).abs().max()) > 0
+
+
+def test_inline_shN_adam_trainer_path_trains(lfs):
+    from lichtfeld_studio_amd import scenes
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    dev = torch.device(DEV)
+    sc = scenes.syn_a(n=6000, sh_degree=3)
+    target = scenes.target_image(sc.height, sc.width).to(dev)
+    a, b = GutTrainer(sc, dev, iterations=100), GutTrainer(sc, dev, iterations=100)
+    b.inline_shN_adam = False
+    a.iteration = b.iteration = 998
+    la = [float(a.train_step([target], views=[0])) for _ in range(12)]
+    lb = [float(b.train_step([target], views=[0])) for _ in range(12)]
+    assert np.allclose(la, lb, rtol=1e-4) and la[-1] < la[0]
+    assert torch.allclose(a.model.shN, b.model.shN, atol=2e-3) and float((a.model.shN.detach() - sc.shN.to(dev)).abs().max()) > 0
