@@ -164,17 +164,25 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
     __syncthreads();
     constexpr int GPI = 64 / LPG; // Gaussians per iteration
     const int k = lane % LPG;
+    // all coefficient loads of the wavefront are issued before the first use (LPG independent 12-byte loads per lane in flight);
+    // b_0 != 0 marks the rows that are evaluated at all (masked-out Gaussians have b = 0 and their coefficients are not fetched)
+    float c0[LPG], c1[LPG], c2[LPG];
+#pragma unroll
     for (int it = 0; it < LPG; ++it) {
         const uint32_t gl = it * GPI + lane / LPG;
         const uint32_t g = g0 + gl;
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-        if (g < a.n && k < Kd) {
-            const float bk = lds[gl * (LPG + 1) + k];
-            if (bk != 0.f) { // (also skips the coefficient rows of masked-out Gaussians)
-                const float* cf = sh_coef<MODEL>(a.coeffs, a.sh0, a.shN, a.K, g, k);
-                r0 = bk * cf[0]; r1 = bk * cf[1]; r2 = bk * cf[2];
-            }
+        c0[it] = c1[it] = c2[it] = 0.f;
+        if (g < a.n && k < Kd && lds[gl * (LPG + 1)] != 0.f) {
+            const float* cf = sh_coef<MODEL>(a.coeffs, a.sh0, a.shN, a.K, g, k);
+            c0[it] = cf[0]; c1[it] = cf[1]; c2[it] = cf[2];
         }
+    }
+#pragma unroll
+    for (int it = 0; it < LPG; ++it) {
+        const uint32_t gl = it * GPI + lane / LPG;
+        const uint32_t g = g0 + gl;
+        const float bk = lds[gl * (LPG + 1) + k];
+        float r0 = bk * c0[it], r1 = bk * c1[it], r2 = bk * c2[it];
         r0 = group_sum<LPG>(r0); r1 = group_sum<LPG>(r1); r2 = group_sum<LPG>(r2);
         if (k == 0 && g < a.n) {
             if (MODEL) { r0 = fmaxf(r0 + 0.5f, 0.f); r1 = fmaxf(r1 + 0.5f, 0.f); r2 = fmaxf(r2 + 0.5f, 0.f); }
@@ -242,7 +250,8 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
         const float o0 = bk * v0, o1 = bk * v1, o2 = bk * v2;
         float sk = 0.f;
         if (ADAM && k >= 1) {
-            // shN[g][k-1][:] : read once (the direction gradient needs the pre-update value), update, write back
+            // shN[g][k-1][:] : read once (the direction gradient needs the pre-update value), update, write back.
+            // (Loading four rows ahead per lane was measured slower: 0.31 vs 0.23 ms.)
             const size_t e = (size_t(g) * (a.K - 1) + (k - 1)) * 3;
             float* pp = const_cast<float*>(a.shN) + e;
             float p0 = pp[0], p1 = pp[1], p2 = pp[2];
