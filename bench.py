@@ -120,7 +120,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="syn-b", choices=["syn-a", "syn-b", "syn-c", "syn-d"])
-    ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
+    ap.add_argument("--n", "--gaussians", dest="n", type=int, default=0, help="override the number of Gaussians (use --gaussians under torch.distributed.run, whose parser claims --n*)")
     ap.add_argument("--views-per-rank", type=int, default=1)
     ap.add_argument("--rasterizer", default="gut", choices=["gut", "fastgs"], help="gut = the north-star 3DGUT path (default); fastgs = the reference's default EWA rasterizer (SURVEY.md §8f row 1)")
     ap.add_argument("--loss", default="mse", choices=["mse", "l1_ssim"], help="mse = rasterizer-only metric of SURVEY.md §8d (default); l1_ssim = the reference's photometric loss")
@@ -144,6 +144,8 @@ def main() -> None:
     rank, world, local_rank = lfs_dist.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("LFS_DIST_BACKEND") == "gloo":   # smoke mode: all ranks share the visible device(s)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 

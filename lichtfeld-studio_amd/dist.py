@@ -23,8 +23,8 @@ def init_distributed(backend: Optional[str] = None) -> tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # LFS_DIST_BACKEND=gloo: several ranks on one GPU (tests / smoke runs; collectives staged through the host)
+            backend = os.environ.get("LFS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
