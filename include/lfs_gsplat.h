@@ -198,6 +198,18 @@ LFS_API int lfs_sh_model_bwd_adam(
     const int32_t* radii, const float* colors, const float* v_colors, float* v_sh0, float* v_means,
     float* shN_exp_avg, float* shN_exp_avg_sq, float lr, float beta1, float beta2, float eps, float bias_correction1_rcp,
     float bias_correction2_sqrt_rcp, lfs_stream_t stream);
+/* Multi-view forms for SH-sharded data parallelism (the owner of n Gaussians evaluates the views of all ranks in ONE launch; coefficient
+ * rows are read once for all views): viewmats [V,4,4]; radii [V,view_stride,2], colors / v_colors [V,view_stride,3] with the first n rows of
+ * every view used. Backward: the coefficient gradient is summed over the views, then written / added (accumulate) to v_sh0, v_shN, or -
+ * shN_exp_avg != NULL, accumulate == 0 - consumed by shN's Adam update as in lfs_sh_model_bwd_adam; v_means += sum over views of dL/d(dirs). */
+LFS_API int lfs_sh_model_fwd_views(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, uint32_t n_views, uint32_t view_stride, const float* means, const float* viewmats,
+    const float* sh0, const float* shN, const int32_t* radii, float* colors, lfs_stream_t stream);
+LFS_API int lfs_sh_model_bwd_views(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, uint32_t n_views, uint32_t view_stride, const float* means, const float* viewmats,
+    const float* sh0, float* shN, const int32_t* radii, const float* colors, const float* v_colors, int accumulate,
+    float* v_sh0, float* v_shN, float* v_means, float* shN_exp_avg, float* shN_exp_avg_sq, float lr, float beta1, float beta2, float eps,
+    float bias_correction1_rcp, float bias_correction2_sqrt_rcp, lfs_stream_t stream);
 LFS_API int lfs_activations_fwd(uint32_t N, const float* raw_quats, const float* raw_scales, const float* raw_opacities,
                                 float* quats, float* scales, float* opacities, lfs_stream_t stream);
 LFS_API int lfs_activations_bwd(uint32_t N, const float* raw_quats, const float* scales, const float* opacities,

@@ -334,6 +334,164 @@ static int sh_launch_bwd_adam(const ShArgs& a, const float* v_colors, float* v_s
     return (int)hipGetLastError();
 }
 
+// ---- multi-view forms (SH-sharded data parallelism, dist.ShExchange): the owner of a block of Gaussians evaluates SH for the views of
+// ALL ranks in one launch. Coefficient rows are fetched once and kept in registers across the views (the per-view launches
+// re-read 192 B per Gaussian and view); the backward accumulates the coefficient gradient over the views in registers and either
+// stores it once or, ADAM, hands it straight to the Adam update of shN (as sh_bwd_kernel<.., ADAM>). Per-view operands
+// (radii, colors, v_colors) are [V, view_stride, ...] with the first n rows of each view used.
+struct ShViews {
+    uint32_t n, K; int degree; uint32_t V, view_stride;
+    const float* means; const float* viewmats; const float* sh0; const float* shN; const int32_t* radii; const float* colors;
+};
+
+template <int LPG>
+__global__ void __launch_bounds__(64) sh_views_fwd_kernel(const ShViews a, float* __restrict__ colors) {
+    __shared__ float lds[64 * (LPG + 1)];
+    const uint32_t lane = threadIdx.x, g0 = blockIdx.x * 64u, gmine = g0 + lane;
+    const int degree = a.degree, Kd = (degree + 1) * (degree + 1);
+    constexpr int GPI = 64 / LPG;
+    const int k = lane % LPG;
+    float c0[LPG], c1[LPG], c2[LPG];
+#pragma unroll
+    for (int it = 0; it < LPG; ++it) {
+        const uint32_t g = g0 + it * GPI + lane / LPG;
+        c0[it] = c1[it] = c2[it] = 0.f;
+        if (g < a.n && k < Kd) {
+            const float* cf = sh_coef<true>((const float*)nullptr, a.sh0, a.shN, a.K, g, k);
+            c0[it] = cf[0]; c1[it] = cf[1]; c2[it] = cf[2];
+        }
+    }
+    f3 m{0.f, 0.f, 0.f};
+    if (gmine < a.n) m = {a.means[3 * gmine], a.means[3 * gmine + 1], a.means[3 * gmine + 2]};
+    for (uint32_t v = 0; v < a.V; ++v) {
+        {   // phase 1 (lane = Gaussian)
+            float b[25];
+#pragma unroll
+            for (int kk = 0; kk < 25; ++kk) b[kk] = 0.f;
+            const int32_t* rr = a.radii + (size_t(v) * a.view_stride + gmine) * 2;
+            if (gmine < a.n && rr[0] > 0 && rr[1] > 0) {
+                const f3 cp = campos_of(a.viewmats + 16 * v);
+                f3 d{m.x - cp.x, m.y - cp.y, m.z - cp.z};
+                if (degree >= 1) { const float inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
+                sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
+            }
+#pragma unroll
+            for (int kk = 0; kk < LPG; ++kk) lds[lane * (LPG + 1) + kk] = (kk < 25) ? b[kk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < LPG; ++it) {
+            const uint32_t gl = it * GPI + lane / LPG, g = g0 + gl;
+            const float bk = lds[gl * (LPG + 1) + k];
+            const float r0 = group_sum<LPG>(bk * c0[it]), r1 = group_sum<LPG>(bk * c1[it]), r2 = group_sum<LPG>(bk * c2[it]);
+            if (k == 0 && g < a.n) {
+                float* o = colors + (size_t(v) * a.view_stride + g) * 3;
+                o[0] = fmaxf(r0 + 0.5f, 0.f); o[1] = fmaxf(r1 + 0.5f, 0.f); o[2] = fmaxf(r2 + 0.5f, 0.f);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int LPG, bool ADAM>
+__global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const float* __restrict__ v_colors, const int accumulate,
+                                                          float* __restrict__ v_sh0, float* __restrict__ v_shN, float* __restrict__ v_means,
+                                                          const ShAdam adam) {
+    __shared__ float lds[64 * (LPG + 1)];
+    __shared__ float ldv[64 * 3];
+    const uint32_t lane = threadIdx.x, g0 = blockIdx.x * 64u, gmine = g0 + lane;
+    const int degree = a.degree, Kd = (degree + 1) * (degree + 1);
+    const bool want_dirs = degree >= 1;
+    constexpr int GPI = 64 / LPG;
+    const int k = lane % LPG;
+    // gradient accumulators over the views; the coefficient rows needed for dL/d(dirs) are re-read per view (L2 hits after the
+    // first view) rather than cached: with them the kernel needs > 256 VGPRs next to the 100 of the derivative basis in phase 3
+    float a0[LPG], a1[LPG], a2[LPG];
+#pragma unroll
+    for (int it = 0; it < LPG; ++it) a0[it] = a1[it] = a2[it] = 0.f;
+    f3 m{0.f, 0.f, 0.f};
+    if (gmine < a.n) m = {a.means[3 * gmine], a.means[3 * gmine + 1], a.means[3 * gmine + 2]};
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    for (uint32_t v = 0; v < a.V; ++v) {
+        f3 d{0.f, 0.f, 0.f};
+        float inorm = 1.f;
+        bool on = false;
+        {   // phase 1 (lane = Gaussian)
+            float b[25];
+#pragma unroll
+            for (int kk = 0; kk < 25; ++kk) b[kk] = 0.f;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            const size_t row = size_t(v) * a.view_stride + gmine;
+            if (gmine < a.n) { const int32_t* rr = a.radii + row * 2; on = rr[0] > 0 && rr[1] > 0; }
+            if (on) {
+                const f3 cp = campos_of(a.viewmats + 16 * v);
+                d = {m.x - cp.x, m.y - cp.y, m.z - cp.z};
+                if (degree >= 1) { inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
+                sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
+                v0 = v_colors[row * 3]; v1 = v_colors[row * 3 + 1]; v2 = v_colors[row * 3 + 2];
+                if (!(a.colors[row * 3] > 0.f)) v0 = 0.f;       // clamp_min backward
+                if (!(a.colors[row * 3 + 1] > 0.f)) v1 = 0.f;
+                if (!(a.colors[row * 3 + 2] > 0.f)) v2 = 0.f;
+            }
+#pragma unroll
+            for (int kk = 0; kk < LPG; ++kk) lds[lane * (LPG + 1) + kk] = (kk < 25) ? b[kk] : 0.f;
+            ldv[lane * 3] = v0; ldv[lane * 3 + 1] = v1; ldv[lane * 3 + 2] = v2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < LPG; ++it) { // phase 2 (lane = (Gaussian, basis))
+            const uint32_t gl = it * GPI + lane / LPG;
+            const float bk = lds[gl * (LPG + 1) + k];
+            const float v0 = ldv[gl * 3], v1 = ldv[gl * 3 + 1], v2 = ldv[gl * 3 + 2];
+            a0[it] += bk * v0; a1[it] += bk * v1; a2[it] += bk * v2;
+            if (want_dirs) {
+                float sk = 0.f;
+                if (k >= 1 && k < Kd && g0 + gl < a.n && (v0 != 0.f || v1 != 0.f || v2 != 0.f)) { // (basis 0 is constant: sh0 is not needed)
+                    const float* cf = a.shN + (size_t(g0 + gl) * (a.K - 1) + (k - 1)) * 3;
+                    sk = cf[0] * v0 + cf[1] * v1 + cf[2] * v2;
+                }
+                lds[gl * (LPG + 1) + k] = sk;
+            }
+        }
+        __syncthreads();
+        if (on && want_dirs) { // phase 3 (lane = Gaussian)
+            float b[25], bx[25], by[25], bz[25];
+            sh_basis<true>(degree, d.x, d.y, d.z, b, bx, by, bz);
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+            for (int kk = 1; kk < LPG && kk < 25; ++kk) {
+                const float sk = lds[lane * (LPG + 1) + kk];
+                gx += bx[kk] * sk; gy += by[kk] * sk; gz += bz[kk] * sk;
+            }
+            const float dd = gx * d.x + gy * d.y + gz * d.z;
+            ox += (gx - dd * d.x) * inorm; oy += (gy - dd * d.y) * inorm; oz += (gz - dd * d.z) * inorm;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < LPG; ++it) {
+        const uint32_t g = g0 + it * GPI + lane / LPG;
+        if (g >= a.n || uint32_t(k) >= a.K) continue;
+        if (k == 0) {
+            float* o = v_sh0 + size_t(g) * 3;
+            if (accumulate) { o[0] += a0[it]; o[1] += a1[it]; o[2] += a2[it]; }
+            else { o[0] = a0[it]; o[1] = a1[it]; o[2] = a2[it]; }
+            continue;
+        }
+        const size_t e = (size_t(g) * (a.K - 1) + (k - 1)) * 3;
+        if (ADAM) {
+            float* pp = const_cast<float*>(a.shN) + e;
+            float q0 = pp[0], q1 = pp[1], q2 = pp[2];
+            float m0 = adam.m[e], m1 = adam.m[e + 1], m2 = adam.m[e + 2], s0 = adam.v[e], s1 = adam.v[e + 1], s2 = adam.v[e + 2];
+            adam_elem(q0, m0, s0, a0[it], adam.s); adam_elem(q1, m1, s1, a1[it], adam.s); adam_elem(q2, m2, s2, a2[it], adam.s);
+            pp[0] = q0; pp[1] = q1; pp[2] = q2;
+            adam.m[e] = m0; adam.m[e + 1] = m1; adam.m[e + 2] = m2; adam.v[e] = s0; adam.v[e + 1] = s1; adam.v[e + 2] = s2;
+        } else if (accumulate) { v_shN[e] += a0[it]; v_shN[e + 1] += a1[it]; v_shN[e + 2] += a2[it]; }
+        else { v_shN[e] = a0[it]; v_shN[e + 1] = a1[it]; v_shN[e + 2] = a2[it]; }
+    }
+    if (gmine < a.n && want_dirs) { v_means[3 * gmine] += ox; v_means[3 * gmine + 1] += oy; v_means[3 * gmine + 2] += oz; }
+}
+
 // used by fastgs_{prep,blend}.hip: SH colour of visible primitives written straight into the blend records (stride in floats),
 // and its backward reading dL/dcolour from the blend accumulator rows
 int sh_records_fwd(uint32_t n, uint32_t K, uint32_t degree, const float* means, const float* campos, const float* sh0, const float* shN,
@@ -416,4 +574,56 @@ extern "C" int lfs_sh_model_bwd_adam(
     a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
     const lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp}};
     return lfs::sh_launch_bwd_adam(a, v_colors, v_sh0, v_means, adam, (hipStream_t)stream);
+}
+
+static bool sh_views_ok(uint32_t n, uint32_t K, uint32_t degree, uint32_t V, uint32_t stride) {
+    const uint32_t Kd = (degree + 1) * (degree + 1);
+    return degree <= 4 && Kd <= K && K <= 32 && V >= 1 && stride >= n;
+}
+
+extern "C" int lfs_sh_model_fwd_views(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, uint32_t n_views, uint32_t view_stride, const float* means, const float* viewmats,
+    const float* sh0, const float* shN, const int32_t* radii, float* colors, lfs_stream_t stream) {
+    if (n == 0 || n_views == 0) return LFS_OK;
+    if (!sh_views_ok(n, K, degrees_to_use, n_views, view_stride)) return LFS_E_INVALID;
+    if (!means || !viewmats || !sh0 || (K > 1 && !shN) || !radii || !colors) return LFS_E_INVALID;
+    const lfs::ShViews a{n, K, int(degrees_to_use), n_views, view_stride, means, viewmats, sh0, shN, radii, nullptr};
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((n + 63) / 64), block(64);
+    lfs::ProfScope prof("sh_fwd", s);
+    switch (lfs::lanes_for((degrees_to_use + 1) * (degrees_to_use + 1))) {
+    case 1: hipLaunchKernelGGL((lfs::sh_views_fwd_kernel<1>), grid, block, 0, s, a, colors); break;
+    case 4: hipLaunchKernelGGL((lfs::sh_views_fwd_kernel<4>), grid, block, 0, s, a, colors); break;
+    case 16: hipLaunchKernelGGL((lfs::sh_views_fwd_kernel<16>), grid, block, 0, s, a, colors); break;
+    default: hipLaunchKernelGGL((lfs::sh_views_fwd_kernel<32>), grid, block, 0, s, a, colors); break;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int lfs_sh_model_bwd_views(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, uint32_t n_views, uint32_t view_stride, const float* means, const float* viewmats,
+    const float* sh0, float* shN, const int32_t* radii, const float* colors, const float* v_colors, int accumulate,
+    float* v_sh0, float* v_shN, float* v_means, float* shN_exp_avg, float* shN_exp_avg_sq, float lr, float beta1, float beta2, float eps,
+    float bias_correction1_rcp, float bias_correction2_sqrt_rcp, lfs_stream_t stream) {
+    if (n == 0 || n_views == 0) return LFS_OK;
+    if (!sh_views_ok(n, K, degrees_to_use, n_views, view_stride)) return LFS_E_INVALID;
+    const bool inline_adam = shN_exp_avg != nullptr;
+    if (!means || !viewmats || !sh0 || (K > 1 && !shN) || !radii || !colors || !v_colors || !v_sh0 || !v_means) return LFS_E_INVALID;
+    if (inline_adam ? (accumulate || !shN_exp_avg_sq || K < 2) : (K > 1 && !v_shN)) return LFS_E_INVALID;
+    const lfs::ShViews a{n, K, int(degrees_to_use), n_views, view_stride, means, viewmats, sh0, shN, radii, colors};
+    const lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp}};
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((n + 63) / 64), block(64);
+    lfs::ProfScope prof(inline_adam ? "sh_bwd_adam" : "sh_bwd", s);
+#define LFS_SH_VIEWS_BWD(L)                                                                                                                  \
+    if (inline_adam) hipLaunchKernelGGL((lfs::sh_views_bwd_kernel<L, true>), grid, block, 0, s, a, v_colors, accumulate, v_sh0, v_shN, v_means, adam); \
+    else hipLaunchKernelGGL((lfs::sh_views_bwd_kernel<L, false>), grid, block, 0, s, a, v_colors, accumulate, v_sh0, v_shN, v_means, adam)
+    switch (lfs::lanes_for(K)) {
+    case 1: LFS_SH_VIEWS_BWD(1); break;
+    case 4: LFS_SH_VIEWS_BWD(4); break;
+    case 16: LFS_SH_VIEWS_BWD(16); break;
+    default: LFS_SH_VIEWS_BWD(32); break;
+    }
+#undef LFS_SH_VIEWS_BWD
+    return (int)hipGetLastError();
 }

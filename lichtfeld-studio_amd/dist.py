@@ -99,8 +99,8 @@ class ShExchange:
     so the shN gradient never crosses xGMI: the step's all-reduce covers 14 floats per Gaussian instead of 59, and Adam touches
     1/world of shN on each rank. Per Gaussian and step a rank moves 32 B through all-to-all + 56 B through the all-reduce,
     against 236 B for the replicated layout; the SH arithmetic is the same in total (N Gaussian-views per rank either way).
-    The kernels are passed in (`sh_fwd`, `sh_bwd`: the signatures of fused.sh_model_fwd / sh_model_bwd) so the exchange logic is
-    testable on CPU with the oracle as stand-in (tests/test_dist_gloo.py)."""
+    The kernels are passed in (the signatures of fused.sh_model_fwd_views / sh_model_bwd_views: ONE launch covers the views of all ranks,
+    coefficient rows are read once) so the exchange logic is testable on CPU with the oracle as stand-in (tests/test_dist_gloo.py)."""
 
     def __init__(self, n_gaussians: int, world: int, rank: int):
         self.N, self.world, self.rank = n_gaussians, world, rank
@@ -145,31 +145,30 @@ class ShExchange:
         dist.all_gather(parts, pad)
         return torch.cat(parts)[:self.N]
 
-    def forward(self, deg: int, means, sh0, shN_shard, radii, viewmats_all, sh_fwd):
+    def forward(self, deg: int, means, sh0, shN_shard, radii, viewmats_all, sh_fwd_views):
         """radii [N,2] int32 of THIS rank's view; viewmats_all[j] = the [1,4,4] view matrix rank j renders now.
-        -> (colours [N,3] of this rank's view, ctx for backward)"""
+        -> (colours [N,3] of this rank's view, ctx for backward). `sh_fwd_views`: fused.sh_model_fwd_views (one launch for all views)."""
         radii_recv = self._all_to_all(self._pad(radii))                     # [world, S, 2]: view j's radii for my rows
-        m, s0 = self.shard(means), self.shard(sh0)
-        colors_send = torch.zeros((self.world, self.S, 3), dtype=means.dtype, device=means.device)
-        for j in range(self.world):
-            if self.n:
-                colors_send[j, :self.n] = sh_fwd(deg, m, viewmats_all[j], s0, shN_shard, radii_recv[j, :self.n].unsqueeze(0).contiguous())
+        vms = torch.cat([v.reshape(1, 4, 4) for v in viewmats_all]).contiguous()
+        if self.n:
+            colors_send = sh_fwd_views(deg, self.shard(means), vms, self.shard(sh0), shN_shard, radii_recv)   # [world, S, 3]
+        else:
+            colors_send = torch.zeros((self.world, self.S, 3), dtype=means.dtype, device=means.device)
         colors = self._all_to_all(colors_send).view(self.world * self.S, 3)[:self.N]
-        return colors.contiguous(), (radii_recv, colors_send)
+        return colors.contiguous(), (radii_recv, colors_send, vms)
 
-    def backward(self, ctx, deg: int, means, sh0, shN_shard, viewmats_all, v_colors, g_sh0, g_shN_shard, g_means, accumulate: bool, sh_bwd) -> None:
+    def backward(self, ctx, deg: int, means, sh0, shN_shard, viewmats_all, v_colors, g_sh0, g_shN_shard, g_means, accumulate: bool, sh_bwd_views,
+                 adam=None) -> None:
         """v_colors [N,3] = dL/dcolours of this rank's view. Writes (accumulate False) or adds to g_shN_shard and MY rows of g_sh0 (the
-        other rows are zeroed / left alone: the all-reduce brings their owners' values), adds dL/d(dirs) into my rows of g_means."""
-        radii_recv, colors_send = ctx
+        other rows are zeroed / left alone: the all-reduce brings their owners' values), adds dL/d(dirs) into my rows of g_means.
+        `adam` (FusedAdam.prepare_inline of the shard; needs accumulate False): the shard is updated in place, g_shN_shard is not written."""
+        radii_recv, colors_send, vms = ctx
         v_recv = self._all_to_all(self._pad(v_colors))                      # [world, S, 3]: view j's dL/dcolour for my rows
         if not accumulate:
             g_sh0.zero_()
-        if not self.n:
-            return
-        m, s0 = self.shard(means), self.shard(sh0)
-        for j in range(self.world):
-            sh_bwd(deg, m, viewmats_all[j], s0, shN_shard, radii_recv[j, :self.n].unsqueeze(0).contiguous(), colors_send[j, :self.n].contiguous(),
-                   v_recv[j, :self.n].contiguous(), self.shard(g_sh0), g_shN_shard, self.shard(g_means), accumulate or j > 0)
+        if self.n:
+            sh_bwd_views(deg, self.shard(means), vms, self.shard(sh0), shN_shard, radii_recv, colors_send, v_recv, self.shard(g_sh0), g_shN_shard,
+                         self.shard(g_means), accumulate, adam)
 
 
 def all_reduce_sum(t: torch.Tensor) -> None:

@@ -69,6 +69,31 @@ def sh_model_bwd_adam(sh_degree: int, means, viewmat, sh0, shN, radii, colors, v
                                                C.c_float(adam["bc1_rcp"]), C.c_float(adam["bc2_sqrt_rcp"]), stream()), "sh_model_bwd_adam")
 
 
+def sh_model_fwd_views(sh_degree: int, means, viewmats, sh0, shN, radii_views):
+    """Owner side of dist.ShExchange: means / sh0 / shN = the owner's n rows; viewmats [V,4,4]; radii_views [V,S,2] (first n rows of each view
+    used) -> colours [V,S,3] (rows >= n zero)."""
+    require_gpu(means, viewmats, sh0, shN, radii_views)
+    n, K, V, S = means.shape[0], 1 + shN.shape[1], radii_views.shape[0], radii_views.shape[1]
+    colors = torch.zeros((V, S, 3), dtype=means.dtype, device=means.device)
+    check(load_library().lfs_sh_model_fwd_views(C.c_uint32(n), C.c_uint32(K), C.c_uint32(sh_degree), C.c_uint32(V), C.c_uint32(S), ptr(means), ptr(viewmats),
+                                                ptr(sh0), ptr(shN), ptr(radii_views), ptr(colors), stream()), "sh_model_fwd_views")
+    return colors
+
+
+def sh_model_bwd_views(sh_degree: int, means, viewmats, sh0, shN, radii_views, colors_views, v_colors_views, v_sh0, v_shN, v_means, accumulate: bool,
+                       adam: Optional[dict] = None):
+    """The backward of sh_model_fwd_views summed over the views: v_sh0 / v_shN (the owner's rows) written or added to, v_means += dL/d(dirs);
+    with `adam` (FusedAdam.prepare_inline; accumulate False) v_shN is not touched and shN is updated in place."""
+    require_gpu(means, viewmats, sh0, shN, radii_views, colors_views, v_colors_views, v_sh0, v_means)
+    n, K, V, S = means.shape[0], 1 + shN.shape[1], radii_views.shape[0], radii_views.shape[1]
+    z = C.c_float(0.0)
+    sc = [C.c_float(adam[k]) for k in ("lr", "beta1", "beta2", "eps", "bc1_rcp", "bc2_sqrt_rcp")] if adam else [z] * 6
+    check(load_library().lfs_sh_model_bwd_views(C.c_uint32(n), C.c_uint32(K), C.c_uint32(sh_degree), C.c_uint32(V), C.c_uint32(S), ptr(means), ptr(viewmats),
+                                                ptr(sh0), ptr(shN), ptr(radii_views), ptr(colors_views), ptr(v_colors_views), C.c_int(int(accumulate)),
+                                                ptr(v_sh0), None if adam else ptr(v_shN), ptr(v_means), ptr(adam["exp_avg"]) if adam else None,
+                                                ptr(adam["exp_avg_sq"]) if adam else None, *sc, stream()), "sh_model_bwd_views")
+
+
 def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
     """loss_acc (1-element tensor) += weight * mse(clamp(render, 0, 1), target); returns dL/d(render) [H,W,3]."""
     target_chw = target_chw.contiguous()  # (a CHW view of an HWC render is a common caller mistake; no-op otherwise)
@@ -91,14 +116,15 @@ class FusedStepOutput:
 
 def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
                         grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool, loss: str = "mse",
-                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None, adam_shN: Optional[dict] = None) -> FusedStepOutput:
+                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None, adam_shN: Optional[dict] = None, adam_shard: Optional[dict] = None) -> FusedStepOutput:
     """One view: forward, loss against `target_chw` ("mse": the rasterizer-only metric of SURVEY.md §8d; "l1_ssim": the reference's
     photometric loss, trainer.cpp:115-128), backward. `grads` = six tensors shaped like model.parameters()
     (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
     Constants as in rasterizer.cpp:176-181.
     With `sh_exchange` (dist.ShExchange; multi-GPU) model.shN / grads[2] hold only this rank's rows and the SH stages run on the
     owners: `viewmats_all[j]` is the view matrix rank j renders in this call (every rank calls this the same number of times).
-    With `adam_shN` (FusedAdam.prepare_inline; one view per step on one rank) grads[2] is not written: shN is updated in place."""
+    With `adam_shN` (FusedAdam.prepare_inline; one view per step on one rank) grads[2] is not written: shN is updated in place;
+    `adam_shard` is the same for the owner's rows under `sh_exchange` (one view per rank and step)."""
     assert camera.camera_model_type == CameraModelType.PINHOLE and camera.radial_distortion is None and camera.tangential_distortion is None, \
         "the fused path covers the trainer's undistorted pinhole cameras; use rasterizer.rasterize for the rest"
     W, H = int(camera.image_width), int(camera.image_height)
@@ -116,7 +142,7 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         if sh_exchange is None:
             colors = sh_model_fwd(deg, means, viewmat, sh0, shN, radii)
         else:
-            colors, sh_ctx = sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd)
+            colors, sh_ctx = sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd_views)
         _, _, flatten_ids, offsets = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True)
         bg = None if bg_color is None else bg_color.view(1, -1).contiguous()
         fwd_args = (means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, None, W, H, tile, viewmat, None, Kmat,
@@ -142,7 +168,8 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         else:
             g_means.copy_(v_means)
         if sh_exchange is not None:  # owners: SH backward of every rank's view for their rows (dL/d(dirs) straight into g_means)
-            sh_exchange.backward(sh_ctx, deg, means, sh0, shN, viewmats_all, v_colors.squeeze(0), g_sh0, g_shN, g_means, accumulate, sh_model_bwd)
+            sh_exchange.backward(sh_ctx, deg, means, sh0, shN, viewmats_all, v_colors.squeeze(0), g_sh0, g_shN, g_means, accumulate, sh_model_bwd_views,
+                                 adam=adam_shard)
         # the regularisers of trainer.cpp:132-158 are per step, not per view: the caller passes them with the first view only
         activations_bwd(raw_quats, scales, opac, v_quats, v_scales, v_opac.squeeze(0), g_quats, g_scales, g_opac, accumulate, scale_reg, opacity_reg)
     return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]))

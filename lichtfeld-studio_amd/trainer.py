@@ -204,6 +204,10 @@ class GutTrainer:
             if (self.inline_shN_adam and self.world == 1 and len(views) == 1 and self.strategy is None and self.iteration > 1000
                     and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False)):
                 inline = self.optimizer.prepare_inline(self.model.shN)
+            inline_shard = None   # SH-sharded, one view per rank: the owners' multi-view SH backward applies the shard's Adam update
+            if (self.inline_shN_adam and self.sh_exchange is not None and len(views) == 1 and self.iteration > 1000 and self.sh_exchange.n
+                    and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False)):
+                inline_shard = self.optimizer.prepare_inline(self.model.shN)
             for k, v in enumerate(views):
                 vm_all = None if every is None else [self.scene.viewmats[e[k]:e[k] + 1].contiguous() for e in every]
                 out = render_and_backward(self.camera(v), self.model, self.bg, targets[k % len(targets)], 1.0 / total_views,
@@ -211,7 +215,7 @@ class GutTrainer:
                                           # regularisers: once per step, and 1/world of them per rank (the all-reduce sums the ranks)
                                           scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
                                           opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0,
-                                          sh_exchange=self.sh_exchange, viewmats_all=vm_all, adam_shN=inline)
+                                          sh_exchange=self.sh_exchange, viewmats_all=vm_all, adam_shN=inline, adam_shard=inline_shard)
                 self.last_n_isects, self._last_radii = out.n_isects, out.radii
             # the deferred segment (shN) stays out of the all-reduce while Adam does not read it (iteration <= 1000) and, SH-sharded, always
             self.bucket.all_reduce(skip_deferred=self.iteration <= 1000 or self.sh_exchange is not None)

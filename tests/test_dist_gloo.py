@@ -162,7 +162,19 @@ def _sh_standins(oracle):
         else:
             v_sh0.copy_(v_coeffs[:, :1]); v_shN.copy_(v_coeffs[:, 1:])
         v_means += v_dirs
-    return fwd, bwd
+    def fwd_views(deg, means, viewmats, sh0, shN, radii_views):
+        V, S, n = radii_views.shape[0], radii_views.shape[1], means.shape[0]
+        out = torch.zeros(V, S, 3)
+        for v in range(V):
+            out[v, :n] = fwd(deg, means, viewmats[v], sh0, shN, radii_views[v, :n])
+        return out
+
+    def bwd_views(deg, means, viewmats, sh0, shN, radii_views, colors_views, v_colors_views, v_sh0, v_shN, v_means, accumulate, adam=None):
+        assert adam is None
+        n = means.shape[0]
+        for v in range(radii_views.shape[0]):
+            bwd(deg, means, viewmats[v], sh0, shN, radii_views[v, :n], colors_views[v, :n], v_colors_views[v, :n], v_sh0, v_shN, v_means, accumulate or v > 0)
+    return fwd, bwd, fwd_views, bwd_views
 
 
 def _sh_problem(world):
@@ -187,7 +199,7 @@ def _sh_worker(rank, world, port, q):
     import lichtfeld_studio_amd  # noqa: F401
     from lichtfeld_studio_amd import dist as ld
     ld.init_distributed(backend="gloo")
-    fwd, bwd = _sh_standins(oracle)
+    _, _, fwd, bwd = _sh_standins(oracle)
     N, K, deg, means, sh0, shN, viewmats, radii, v_colors = _sh_problem(world)
     ex = ld.ShExchange(N, world, rank)
     shN_shard = ex.shard(shN).clone()
@@ -224,7 +236,7 @@ def test_sh_sharded_exchange_matches_replicated_computation():
         p.join(timeout=60)
         assert p.exitcode == 0
     # replicated reference: every rank evaluates SH for its own views on the full tensors, gradients summed over ranks
-    fwd, bwd = _sh_standins(oracle)
+    fwd, bwd, _, _ = _sh_standins(oracle)
     N, K, deg, means, sh0, shN, viewmats, radii, v_colors = _sh_problem(world)
     ref_sh0, ref_shN, ref_means = torch.zeros(N, 1, 3), torch.zeros(N, K - 1, 3), torch.full((N, 3), float(world))
     for rank in range(world):

@@ -172,3 +172,53 @@ def test_inline_shN_adam_trainer_path_trains(lfs):
     lb = [float(b.train_step([target], views=[0])) for _ in range(12)]
     assert np.allclose(la, lb, rtol=1e-4) and la[-1] < la[0]
     assert torch.allclose(a.model.shN, b.model.shN, atol=2e-3) and float((a.model.shN.detach() - sc.shN.to(dev)).abs().max()) > 0
+
+
+def test_multi_view_sh_kernels_match_per_view_launches(lfs):
+    """lfs_sh_model_fwd_views / _bwd_views (the owner side of SH-sharded data parallelism: all views in one launch, coefficients read once)
+    against one lfs_sh_model_fwd / _bwd launch per view; and the inline-Adam form against the stored gradient + lfs_adam_step."""
+    from lichtfeld_studio_amd import fused, scenes
+    from lichtfeld_studio_amd.fused_adam import FusedAdam
+    dev = torch.device(DEV)
+    sc = scenes.syn_a(n=5003, sh_degree=3).to(dev)
+    g = torch.Generator(device=dev).manual_seed(2)
+    n, V, S = sc.means.shape[0], 5, 5100                     # S > n: padded rows, as for the last shard
+    vms = torch.eye(4, device=dev).repeat(V, 1, 1)
+    vms[:, :3, 3] = torch.randn(V, 3, device=dev, generator=g) * 2
+    radii = torch.zeros(V, S, 2, dtype=torch.int32, device=dev)
+    radii[:, :n] = (torch.rand(V, n, 2, device=dev, generator=g) > 0.3).int() * 4
+    v_colors = torch.randn(V, S, 3, device=dev, generator=g)
+    for deg in (3, 2, 0):
+        colors = fused.sh_model_fwd_views(deg, sc.means, vms, sc.sh0, sc.shN, radii)
+        ref_sh0, ref_shN, ref_means = torch.zeros_like(sc.sh0), torch.zeros_like(sc.shN), torch.ones(n, 3, device=dev)
+        for v in range(V):
+            c = fused.sh_model_fwd(deg, sc.means, vms[v:v + 1].contiguous(), sc.sh0, sc.shN, radii[v:v + 1, :n].contiguous())
+            vis = (radii[v, :n] > 0).all(-1)
+            assert torch.equal(colors[v, :n][vis], c[vis]), (deg, v)
+            fused.sh_model_bwd(deg, sc.means, vms[v:v + 1].contiguous(), sc.sh0, sc.shN, radii[v:v + 1, :n].contiguous(), c, v_colors[v, :n].contiguous(),
+                               ref_sh0, ref_shN, ref_means, v > 0)
+        assert float(colors[:, n:].abs().max()) == 0
+        v_sh0, v_shN, v_means = torch.empty_like(sc.sh0), torch.empty_like(sc.shN), torch.ones(n, 3, device=dev)
+        fused.sh_model_bwd_views(deg, sc.means, vms, sc.sh0, sc.shN, radii, colors, v_colors, v_sh0, v_shN, v_means, False)
+        assert torch.equal(v_sh0, ref_sh0) and torch.equal(v_shN, ref_shN)           # same products, same summation order over the views
+        assert torch.allclose(v_means, ref_means, rtol=1e-5, atol=1e-6)              # dL/d(dirs): summed in registers vs in memory
+        # accumulate: a second call doubles the coefficient gradients
+        fused.sh_model_bwd_views(deg, sc.means, vms, sc.sh0, sc.shN, radii, colors, v_colors, v_sh0, v_shN, v_means, True)
+        assert torch.allclose(v_shN, 2 * ref_shN, rtol=1e-6, atol=1e-7) and torch.allclose(v_sh0, 2 * ref_sh0, rtol=1e-6, atol=1e-7)
+        if deg == 0:
+            continue
+        # inline Adam == stored gradient + optimizer step
+        pa, pb = sc.shN.clone(), sc.shN.clone()
+        oa, ob = FusedAdam([{"params": [pa], "lr": 1.25e-4}]), FusedAdam([{"params": [pb], "lr": 1.25e-4}])
+        for it in range(2):
+            ca = fused.sh_model_fwd_views(deg, sc.means, vms, sc.sh0, pa, radii)
+            s0a, ma = torch.empty_like(sc.sh0), torch.zeros(n, 3, device=dev)
+            fused.sh_model_bwd_views(deg, sc.means, vms, sc.sh0, pa, radii, ca, v_colors, s0a, None, ma, False, adam=oa.prepare_inline(pa))
+            s0b, gb, mb = torch.empty_like(sc.sh0), torch.empty_like(pb), torch.zeros(n, 3, device=dev)
+            fused.sh_model_bwd_views(deg, sc.means, vms, sc.sh0, pb, radii, ca, v_colors, s0b, gb, mb, False)
+            pb.grad = gb
+            ob.step(2000 + it)
+            pa.grad = torch.full_like(pa, float("nan"))
+            oa.step(2000 + it)
+            assert torch.equal(pa, pb) and torch.equal(s0a, s0b) and torch.equal(ma, mb), (deg, it)
+        assert float((pa - sc.shN).abs().max()) > 0
