@@ -172,6 +172,14 @@ LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared(
     const float* v_render_colors, const float* v_render_alphas,
     float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+/* ... with the clamped MSE of lfs_mse_loss_fwd_bwd folded into the kernel's prologue (extension: one camera, 3 channels, no masks):
+ * dL/d(render) is derived from render_colors [H,W,3] and target_chw [3,H,W] in registers and never stored; *loss += weight * mse. */
+LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse(
+    uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
+    const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+    int64_t n_isects, const float* render_colors, const float* render_alphas, const int32_t* last_ids, const float* target_chw, float weight,
+    float* loss, float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
+    lfs_stream_t stream);
 
 /* ---- Fused L2 extensions (not in Ops.h; lichtfeld-studio_amd/fused.py, trainer.py): the libtorch element-wise
  *      work rasterizer.cpp:200-263 / splat_data.cpp:267-286 / the trainer's loss wrap around the operators,

@@ -35,13 +35,14 @@ static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 // Per-Gaussian culling record (camera space, divided by depth, r^2 folded in): see raster_pack_kernel.
 struct __attribute__((aligned(16))) CullRec { float4 a, b; };
 
+constexpr uint32_t LOSS_SLOTS = 256; // fused MSE: the wavefronts' partial sums are spread over this many addresses (one hot address costs ~0.08 ms)
 struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; CullRec* cull; int32_t* cell_count; int2* cell_list; size_t bytes; };
 // cells = C * tiles * (tile_size/8)^2 ; the compacted per-cell lists hold at most (tile_size/8)^2 * n_isects entries
 static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, uint64_t cell_entries) {
     RasterWs w; char* p = (char*)base; size_t o = 0;
     w.cams = (CamDev*)(p + o); o += align256(sizeof(CamDev) * C);
     w.recs = (GaussRec*)(p + o); o += align256(sizeof(GaussRec) * size_t(C) * N);
-    w.acc = (float*)(p + o); o += align256(sizeof(float) * ACC_STRIDE * size_t(C) * N);
+    w.acc = (float*)(p + o); o += align256(sizeof(float) * (ACC_STRIDE * size_t(C) * N + LOSS_SLOTS)); // + the fused-loss partial sums
     w.cull = (CullRec*)(p + o); o += align256(sizeof(CullRec) * size_t(C) * N);
     w.cell_count = (int32_t*)(p + o); o += align256(sizeof(int32_t) * cells);
     w.cell_list = (int2*)(p + o); o += align256(sizeof(int2) * cell_entries);
@@ -385,7 +386,13 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-template <int CDIM, int MODE>
+// Optional fused loss (extension, CDIM = 3, one camera): the kernel derives dL/d(render) = d/d(render) of
+// weight * mean((clamp(render, 0, 1) - target)^2) from the forward image and the CHW target itself and adds the loss to *loss -
+// the arithmetic of l2_fused.hip's mse_loss_kernel per pixel, so v_render_colors is never materialised and the loss kernel's
+// pass over the image disappears.
+struct MseFuse { const float* render; const float* target; float scale; float* loss; };
+
+template <int CDIM, int MODE, bool LOSS = false>
 __global__ void __launch_bounds__(256) raster_bwd_kernel(
     const uint32_t C, const uint32_t N, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
     const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block,
@@ -394,7 +401,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ cell_count, const int2* __restrict__ cell_list, const int32_t n_isects,
     const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
-    float* __restrict__ acc, float* __restrict__ v_colors_extra) {
+    float* __restrict__ acc, float* __restrict__ v_colors_extra, const MseFuse mse = MseFuse{}) {
     const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
     if (!cc.in_grid) return;
@@ -425,8 +432,27 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         T_final = 1.f - render_alphas[pix_id];
         bin_final = last_ids[pix_id];
         v_ra = v_render_alphas ? v_render_alphas[pix_id] : 0.f;
+        if (!LOSS) {
 #pragma unroll
-        for (int k = 0; k < CDIM; ++k) vc[k] = v_render_colors[pix_id * CDIM + k];
+            for (int k = 0; k < CDIM; ++k) vc[k] = v_render_colors[pix_id * CDIM + k];
+        }
+    }
+    if (LOSS) { // every pixel of the image belongs to exactly one lane of one wavefront
+        float lsum = 0.f;
+        if (inside) {
+            const size_t P = size_t(H) * W;
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) {
+                const float x = mse.render[pix_id * CDIM + k];
+                const float d = fminf(fmaxf(x, 0.f), 1.f) - mse.target[size_t(k) * P + pix_id];
+                lsum += d * d;
+                const float g = (x >= 0.f && x <= 1.f) ? 2.f * d * mse.scale : 0.f;
+                if (active) vc[k] = g;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) lsum += __shfl_xor(lsum, m, 64);
+        if (lane == 0 && lsum != 0.f) unsafeAtomicAdd(mse.loss + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (LOSS_SLOTS - 1)), lsum * mse.scale);
     }
     float T = T_final;
     // T_final * (v_alpha_out - bg . v_color_out): the transmittance-tail term of d/d(alpha)
@@ -525,7 +551,13 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
     const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
     const CamDev* __restrict__ cams, const float* __restrict__ acc,
     float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
-    float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    float* __restrict__ v_colors, float* __restrict__ v_opacities, const float* __restrict__ loss_slots, float* __restrict__ loss) {
+    if (loss_slots != nullptr && blockIdx.x == 0) { // fused MSE: fold the backward kernel's partial sums into the caller's accumulator
+        float v = threadIdx.x < LOSS_SLOTS ? loss_slots[threadIdx.x] : 0.f;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0.f) unsafeAtomicAdd(loss, v);
+    }
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= N) return;
     float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
@@ -714,11 +746,12 @@ static int raster_bwd_impl(
     const float* render_alphas, const int32_t* last_ids,
     const float* v_render_colors, const float* v_render_alphas,
     float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream, bool prepared) {
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream, bool prepared, const MseFuse* mse = nullptr) {
     RasterGeom g;
     int rc = raster_check(N, channels, cams, tile_size, g);
     if (rc) return rc;
     if (!workspace || !tile_offsets) return LFS_E_INVALID;
+    if (mse && (channels != 3 || cams->C != 1 || masks || v_render_alphas || !mse->render || !mse->target || !mse->loss)) return LFS_E_INVALID;
     if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
     if (uint64_t(n_isects) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
     const uint32_t C = cams->C;
@@ -726,11 +759,13 @@ static int raster_bwd_impl(
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N == 0) return LFS_OK;
     if (!means || !quats || !scales || !colors || !opacities || !v_means || !v_quats || !v_scales || !v_colors || !v_opacities) return LFS_E_INVALID;
-    if (n_isects > 0 && (!flatten_ids || !render_alphas || !last_ids || !v_render_colors)) return LFS_E_INVALID; // v_render_alphas == NULL: zeros
+    if (n_isects > 0 && (!flatten_ids || !render_alphas || !last_ids || (!v_render_colors && !mse))) return LFS_E_INVALID; // v_render_alphas == NULL: zeros
     hipStream_t s = (hipStream_t)stream;
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
     const size_t CN = size_t(C) * N;
-    hipError_t e = hipMemsetAsync(w.acc, 0, sizeof(float) * ACC_STRIDE * CN, s);
+    hipError_t e = hipMemsetAsync(w.acc, 0, sizeof(float) * (ACC_STRIDE * CN + (mse ? LOSS_SLOTS : 0)), s);
+    MseFuse mse_dev{};
+    if (mse) { mse_dev = *mse; mse_dev.loss = w.acc + ACC_STRIDE * CN; } // the kernel adds into the slots, raster_finish folds them into *loss
     if (e != hipSuccess) return (int)e;
     if (channels > 3) { e = hipMemsetAsync(v_colors, 0, sizeof(float) * channels * CN, s); if (e != hipSuccess) return (int)e; }
     // self-contained call: camera state, records and cell lists are rebuilt; "prepared" = the caller guarantees
@@ -743,6 +778,16 @@ static int raster_bwd_impl(
                        cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, int32_t(n_isects), \
                        render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors)
+        if (mse) {
+            if (raster_mode(cams) == 0)
+                hipLaunchKernelGGL((raster_bwd_kernel<3, 0, true>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th, cams->image_width, cams->image_height,
+                                   tile_size, g.blocks_per_tile, g.waves_per_block, w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count,
+                                   w.cell_list, int32_t(n_isects), render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors, mse_dev);
+            else
+                hipLaunchKernelGGL((raster_bwd_kernel<3, 1, true>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th, cams->image_width, cams->image_height,
+                                   tile_size, g.blocks_per_tile, g.waves_per_block, w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count,
+                                   w.cell_list, int32_t(n_isects), render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors, mse_dev);
+        } else
         switch (channels * 2 + raster_mode(cams)) {
         case 2: LFS_BWD(1, 0); break; case 3: LFS_BWD(1, 1); break;
         case 4: LFS_BWD(2, 0); break; case 5: LFS_BWD(2, 1); break;
@@ -753,8 +798,10 @@ static int raster_bwd_impl(
     }
     const dim3 fg((N + 255) / 256);
     lfs::ProfScope prof_fin("raster_finish", s);
-    if (uniform) hipLaunchKernelGGL(raster_finish_kernel<true>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities);
-    else hipLaunchKernelGGL(raster_finish_kernel<false>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities);
+    const float* slots = mse ? w.acc + ACC_STRIDE * CN : nullptr;
+    float* loss_out = mse ? mse->loss : nullptr;
+    if (uniform) hipLaunchKernelGGL(raster_finish_kernel<true>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities, slots, loss_out);
+    else hipLaunchKernelGGL(raster_finish_kernel<false>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities, slots, loss_out);
     return (int)hipGetLastError();
 }
 
@@ -786,4 +833,20 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared(
     return raster_bwd_impl(N, channels, means, quats, scales, colors, opacities, backgrounds, masks, cams, tile_size, tile_offsets, flatten_ids,
                            n_isects, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
                            v_opacities, workspace, workspace_bytes, stream, true);
+}
+
+// "prepared" backward with the clamped MSE loss of lfs_mse_loss_fwd_bwd folded in (extension): render_colors [H,W,3] = the forward
+// output, target_chw [3,H,W]; *loss += weight * mean((clamp(render, 0, 1) - target)^2). One camera, 3 channels, no masks.
+extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse(
+    uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
+    const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+    int64_t n_isects, const float* render_colors, const float* render_alphas, const int32_t* last_ids, const float* target_chw, float weight,
+    float* loss, float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
+    lfs_stream_t stream) {
+    if (!cams || !render_colors || !target_chw || !loss) return LFS_E_INVALID;
+    const MseFuse mse{render_colors, target_chw, weight / float(3u * cams->image_width * cams->image_height), loss};
+    if (n_isects == 0) return LFS_E_UNSUPPORTED; // nothing rendered: use lfs_mse_loss_fwd_bwd (the loss of the background image)
+    return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, n_isects,
+                           render_alphas, last_ids, nullptr, nullptr, v_means, v_quats, v_scales, v_colors, v_opacities, workspace, workspace_bytes,
+                           stream, true, &mse);
 }

@@ -106,6 +106,9 @@ def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
     return v
 
 
+FUSE_MSE_INTO_BACKWARD = True   # False: separate lfs_mse_loss_fwd_bwd launch (tests compare the two)
+
+
 @dataclass
 class FusedStepOutput:
     image_hwc: torch.Tensor      # [1,H,W,3] un-clamped render (rasterizer output)
@@ -148,15 +151,23 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         fwd_args = (means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, None, W, H, tile, viewmat, None, Kmat,
                     CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None, offsets, flatten_ids)
         render, alpha, last_ids, ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(*fwd_args, own_workspace=True)
-        if loss == "mse":
+        fuse_mse = loss == "mse" and FUSE_MSE_INTO_BACKWARD and flatten_ids.shape[0] > 0
+        if fuse_mse:
+            v_render = None          # derived inside the rasterizer backward from `render` and the target
+        elif loss == "mse":
             v_render = mse_loss_fwd_bwd(render, target_chw, weight, loss_acc)
         elif loss == "l1_ssim":
             from .losses import photometric_loss_fwd_bwd
             v_render = photometric_loss_fwd_bwd(render, target_chw, lambda_dssim, weight, loss_acc)
         else:
             raise ValueError(f"unknown loss {loss!r}")
-        v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
-            *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws)
+        if fuse_mse:
+            v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_bwd_prepared_mse(
+                means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, W, H, tile, viewmat, Kmat, CameraModelType.PINHOLE, ShutterType.GLOBAL,
+                offsets, flatten_ids, render, alpha, last_ids, target_chw, weight, loss_acc, ws)
+        else:
+            v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
+                *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws)
         # SH backward adds dL/d(dirs) onto the rasterizer's dL/d(means) in place, then the means gradient lands in the caller's buffer
         if adam_shN is not None:     # single view, single rank: shN's gradient is consumed by its Adam update inside the SH backward
             assert sh_exchange is None and not accumulate

@@ -271,6 +271,29 @@ def rasterize_to_pixels_from_world_3dgs_bwd(
     return v_means, v_quats, v_scales, v_colors, v_opacities
 
 
+def rasterize_bwd_prepared_mse(means: Tensor, quats: Tensor, scales: Tensor, colors: Tensor, opacities: Tensor, backgrounds: Optional[Tensor],
+                               image_width: int, image_height: int, tile_size: int, viewmats0: Tensor, Ks: Tensor, camera_model: CameraModelType,
+                               rs_type: ShutterType, tile_offsets: Tensor, flatten_ids: Tensor, render_colors: Tensor, render_alphas: Tensor, last_ids: Tensor,
+                               target_chw: Tensor, weight: float, loss_acc: Tensor, prepared_workspace: Tensor):
+    """Extension: the prepared backward with the clamped MSE loss folded in (lfs_..._bwd_prepared_mse): loss_acc += weight * mse(clamp(render), target),
+    dL/d(render) stays in registers. -> (v_means, v_quats, v_scales, v_colors [1,N,3], v_opacities [1,N])."""
+    backgrounds = _opt(backgrounds)
+    target_chw = target_chw.contiguous()
+    require_gpu(means, quats, scales, colors, opacities, backgrounds, viewmats0, Ks, tile_offsets, flatten_ids, render_colors, render_alphas, last_ids, target_chw, loss_acc)
+    N = means.shape[0]
+    assert colors.shape[-1] == 3 and tile_offsets.shape[0] == 1 and tuple(target_chw.shape) == (3, image_height, image_width)
+    v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
+    v_colors, v_opacities = torch.empty_like(colors), torch.empty_like(opacities)
+    cams = cameras_struct(viewmats0, None, Ks, image_width, image_height, camera_model, rs_type, None, None, None)
+    rc = load_library().lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse(
+        C.c_uint32(N), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities), ptr(backgrounds), C.byref(cams), C.c_uint32(tile_size),
+        ptr(tile_offsets), ptr(flatten_ids), C.c_int64(flatten_ids.shape[0]), ptr(render_colors), ptr(render_alphas), ptr(last_ids), ptr(target_chw),
+        C.c_float(weight), ptr(loss_acc), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_colors), ptr(v_opacities),
+        ptr(prepared_workspace), C.c_size_t(prepared_workspace.numel()), stream())
+    check(rc, "rasterize_bwd_prepared_mse")
+    return v_means, v_quats, v_scales, v_colors, v_opacities
+
+
 # -----------------------------------------------------------------------------------------
 # fast_gs::optimizer (adam_api.h:11-21, adam.h:9-20)
 # -----------------------------------------------------------------------------------------

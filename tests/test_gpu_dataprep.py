@@ -132,3 +132,27 @@ def test_colmap_directory_to_training_and_ply(lfs, tmp_path):
         b = torch.nn.functional.normalize(b, dim=-1) if name == "quats" else b
         assert torch.equal(a.detach(), b.detach()), name
     assert os.path.getsize(path) == len(open(path, "rb").read().split(b"end_header\n")[0]) + 11 + 4 * len(xyz) * (6 + 3 + 9 + 1 + 3 + 4)
+
+
+def test_train_colmap_tool_end_to_end(lfs, tmp_path):
+    """tools/train_colmap.py: COLMAP directory -> ADC training on the fastgs path with L1 + SSIM -> PSNR / SSIM on the held-out views
+    (metrics.cpp formulas) -> PLY; and the metric functions against their definitions."""
+    import json
+    import subprocess
+    import sys
+    from lichtfeld_studio_amd import evaluate
+    base, src, xyz, rgb = _synthetic_colmap(str(tmp_path), n_views=12)
+    out = str(tmp_path / "run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "train_colmap.py"), "-d", base, "-i", "250", "--strategy", "default", "--eval", "--test-every", "4",
+                        "--sh-degree", "1", "-o", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["val_images"] == 3 and res["images"] == 9 and os.path.exists(res["ply"])
+    assert res["psnr"] > 16.0 and 0.2 < res["ssim"] <= 1.0, res        # 250 iterations from a point cloud: clearly better than a blank frame (~12 dB)
+    a, b = torch.rand(2, 3, 40, 50, device=DEV), torch.rand(2, 3, 40, 50, device=DEV)
+    mse = ((a - b) ** 2).reshape(2, -1).mean(1)
+    assert abs(evaluate.psnr(a, b) - float((10 * torch.log10(1 / mse)).mean())) < 1e-4
+    assert evaluate.psnr(a, a) == pytest.approx(100.0) and evaluate.ssim(a, a) == pytest.approx(1.0, abs=1e-5)
+    from ssim_reference import ssim_map
+    assert abs(evaluate.ssim(a, b) - float(ssim_map(a.double().cpu(), b.double().cpu()).mean())) < 1e-5

@@ -222,3 +222,34 @@ def test_multi_view_sh_kernels_match_per_view_launches(lfs):
             oa.step(2000 + it)
             assert torch.equal(pa, pb) and torch.equal(s0a, s0b) and torch.equal(ma, mb), (deg, it)
         assert float((pa - sc.shN).abs().max()) > 0
+
+
+def test_mse_folded_into_backward_matches_separate_loss_kernel(lfs):
+    """lfs_..._bwd_prepared_mse (dL/d(render) derived in the rasterizer backward's prologue) against lfs_mse_loss_fwd_bwd + the prepared
+    backward: same per-pixel expressions -> gradients equal up to the backward's atomic summation order; loss equal to fp32 summation order.
+    Includes pixels outside [0,1] (clamp mask), a background, and a ragged image size."""
+    from lichtfeld_studio_amd import fused, scenes
+    from lichtfeld_studio_amd.rasterizer import Camera, SplatModel
+    dev = torch.device(DEV)
+    sc = scenes._syn_box("SYN-M", 5, 5000, 203, 117, 160.0, 2, sh_degree=1).to(dev)
+    sc.raw_scales += 1.8
+    sc.sh0 *= 8.0                                             # over- and under-shooting colours
+    model = SplatModel(sc.means, sc.sh0, sc.shN, sc.raw_scales, sc.raw_quats, sc.raw_opacities, 1)
+    cam = Camera(sc.viewmats[:1].contiguous(), sc.Ks[:1].contiguous(), sc.width, sc.height)
+    target = scenes.target_image(sc.height, sc.width).to(dev)
+    bg = torch.tensor([0.2, 0.5, 0.9], device=dev)
+    res = []
+    for flag in (True, False, False):
+        fused.FUSE_MSE_INTO_BACKWARD = flag
+        grads = [torch.zeros_like(p) for p in model.parameters()]
+        loss = torch.zeros(1, device=dev)
+        out = fused.render_and_backward(cam, model, bg, target, 0.7, grads, loss, accumulate=False, loss="mse")
+        res.append((float(loss), grads, out.image_hwc))
+    fused.FUSE_MSE_INTO_BACKWARD = True
+    (la, ga, ia), (lb, gb, ib), (lc, gc, _) = res
+    assert torch.equal(ia, ib) and float((ia < 0).float().mean() + (ia > 1).float().mean()) > 0.003
+    assert abs(la - lb) < 1e-6 * max(1.0, abs(lb)) and lb > 0
+    for name, a, b, c in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], ga, gb, gc):
+        noise = float((b - c).abs().max())                    # run-to-run noise of the float atomics
+        assert float((a - b).abs().max()) <= max(5 * noise, 1e-4 * float(b.abs().max())), (name, float((a - b).abs().max()), noise)
+        assert float(b.abs().max()) > 0
