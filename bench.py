@@ -58,6 +58,36 @@ def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems
     }
 
 
+def reference_torch_impl_baseline(threads: int):
+    """The reference's OWN CPU code (tests/torch_impl.cpp, compiled in place into oracle/_ref by oracle/Makefile - no reference source is
+    copied) on the host cores, at the size it is written for (config 1 / SYN-A: 10k Gaussians, 256x256, SH degree 0): EWA projection +
+    SH colours + tile intersection, forward only (torch_impl has no compositing and no unscented transform; its isect loop does one
+    `.item()` per Gaussian and is impractical at 1M). Median of 5. Returns None when the prebuilt library is absent."""
+    import numpy as np
+
+    import oracle
+    from lichtfeld_studio_amd import scenes
+    try:
+        oracle.ref_lib()
+    except Exception:
+        return None
+    sc = scenes.syn_a()
+    means, quats = sc.means.numpy(), sc.raw_quats.numpy()
+    scales = np.exp(sc.raw_scales.numpy())
+    vm, Kmat = sc.viewmats[0].numpy(), sc.Ks[0].numpy()
+    sh = sc.sh0.numpy()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        radii, m2, d, _ = oracle.ref_fully_fused_projection(means, quats, scales, vm, Kmat, sc.width, sc.height)
+        oracle.ref_spherical_harmonics(0, means - np.linalg.inv(vm)[:3, 3].astype(np.float32), sh)
+        oracle.ref_isect_tiles(m2[None], radii[None], d[None], 16, sc.width // 16, sc.height // 16, True)
+        ts.append(time.perf_counter() - t0)
+    ms = sorted(ts)[len(ts) // 2] * 1e3
+    return {"value": round(ms, 2), "unit": "ms", "cores": threads, "kind": "reference",
+            "sample": "tests/torch_impl.cpp: fully_fused_projection + spherical_harmonics + isect_tiles, forward, SYN-A (10000 Gaussians, 256x256, SH deg 0), median of 5"}
+
+
 def cpu_baseline(scene, view: int, target, threads: int) -> dict:
     """Oracle ("port" of the reference CUDA kernels) on the host cores: ONE training image of the
     same workload — activations, UT projection, SH, tile intersection + stable sort, compositing fwd,
@@ -246,6 +276,10 @@ def main() -> None:
             cpu = cpu_baseline(scene, 0, scenes.target_image(scene.height, scene.width, seed=43), threads)
         except Exception as e:  # the oracle is optional at bench time; say so instead of failing the run
             cpu = {"value": None, "unit": "train-images/sec", "cores": threads, "kind": "port", "sample": f"failed: {e}"}
+        try:  # and the reference's own CPU code at the size it can run (north star: "the reference's CPU torch_impl path timed on the same box")
+            cpu["reference_torch_impl"] = reference_torch_impl_baseline(threads)
+        except Exception as e:
+            cpu["reference_torch_impl"] = {"value": None, "sample": f"failed: {e}"}
 
     out = {
         "metric": "train-images/sec (fwd+bwd+Adam), 1M Gaussians @1080p",
