@@ -260,6 +260,16 @@ LFS_API int lfs_fastgs_backward(
     void* instance_workspace, size_t instance_workspace_bytes, const float* grad_image, const float* grad_alpha, const float* alpha,
     float* densification_info, float* grad_means, float* grad_scales_raw, float* grad_rotations_raw, float* grad_opacities_raw,
     float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest, lfs_stream_t stream);
+/* lfs_fastgs_backward for a step with ONE view, fused with the optimizer (extension): sh_coefficients_rest and its Adam moments are updated in
+ * place by the SH backward (fast_gs::optimizer::adam_step arithmetic); the [N,total_rest,3] gradient is never stored. */
+LFS_API int lfs_fastgs_backward_adam(
+    uint32_t N, const float* means, const float* scales_raw, const float* rotations_raw, const float* sh_coefficients_0, float* sh_coefficients_rest,
+    uint32_t total_bases_sh_rest, const float* w2c, const float* cam_position, uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy,
+    float cx, float cy, float near_plane, float far_plane, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
+    void* instance_workspace, size_t instance_workspace_bytes, const float* grad_image, const float* grad_alpha, const float* alpha,
+    float* densification_info, float* grad_means, float* grad_scales_raw, float* grad_rotations_raw, float* grad_opacities_raw,
+    float* grad_sh_coefficients_0, float* sh_rest_exp_avg, float* sh_rest_exp_avg_sq, float lr, float beta1, float beta2, float eps,
+    float bias_correction1_rcp, float bias_correction2_sqrt_rcp, lfs_stream_t stream);
 LFS_API void lfs_fastgs_set_debug_flags(uint32_t flags); /* bit 0: no per-cell culling (bit-identity test) */
 
 /* ---- "next" row 2 of SURVEY.md §8f: fused SSIM (fusedssim / fusedssim_backward, include/kernels/ssim.cuh:11-30,

@@ -16,7 +16,8 @@ namespace fgs {
 
 int launch_scatter(uint32_t N, const Frame& f, const PrimWs& w, int64_t* keys, hipStream_t s);
 int launch_preprocess_bwd(uint32_t N, const float* means, const float* scales_raw, const float* rot_raw, const float* sh0, const float* sh_rest, const Frame& f, const PrimWs& w,
-                          float* g_means, float* g_scales_raw, float* g_rot_raw, float* g_opac_raw, float* g_sh0, float* g_sh_rest, float* densification_info, hipStream_t s);
+                          float* g_means, float* g_scales_raw, float* g_rot_raw, float* g_opac_raw, float* g_sh0, float* g_sh_rest, float* densification_info, hipStream_t s,
+                          const ShAdamArgs* adam);
 
 // cell-level version of kernel_utils.cuh:108-148 on the record's conic in bits (A, B, C) = log2(e) (a/2, b, c/2): the ratios that
 // locate the maximum are scale free; thr already carries the safety margin
@@ -258,13 +259,13 @@ extern "C" int lfs_fastgs_render(
     return (int)hipGetLastError();
 }
 
-extern "C" int lfs_fastgs_backward(
+static int fastgs_backward_impl(
     uint32_t N, const float* means, const float* scales_raw, const float* rotations_raw, const float* sh_coefficients_0, const float* sh_coefficients_rest,
     uint32_t total_bases_sh_rest, const float* w2c, const float* cam_position, uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy,
     float cx, float cy, float near_plane, float far_plane, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
     void* instance_workspace, size_t instance_workspace_bytes, const float* grad_image, const float* grad_alpha, const float* alpha,
     float* densification_info, float* grad_means, float* grad_scales_raw, float* grad_rotations_raw, float* grad_opacities_raw,
-    float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest, lfs_stream_t stream) {
+    float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest, lfs_stream_t stream, const lfs::ShAdamArgs* adam) {
     if (!primitive_workspace || !w2c || !cam_position || !grad_image || !grad_alpha || !alpha || width == 0 || height == 0 || n_instances < 0) return LFS_E_INVALID;
     fgs::PrimWs w = fgs::prim_ws(primitive_workspace, N, width, height);
     if (primitive_workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
@@ -272,7 +273,7 @@ extern "C" int lfs_fastgs_backward(
     if (!instance_workspace || instance_workspace_bytes < iw.bytes) return LFS_E_WORKSPACE;
     if (N == 0) return LFS_OK;
     if (!means || !scales_raw || !rotations_raw || !grad_means || !grad_scales_raw || !grad_rotations_raw || !grad_opacities_raw || !grad_sh_coefficients_0 ||
-        (total_bases_sh_rest > 0 && (!sh_coefficients_rest || !grad_sh_coefficients_rest))) return LFS_E_INVALID;
+        (total_bases_sh_rest > 0 && (!sh_coefficients_rest || (!grad_sh_coefficients_rest && !adam)))) return LFS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const fgs::Frame f = make_frame(w2c, cam_position, active_sh_bases, total_bases_sh_rest, width, height, fx, fy, cx, cy, near_plane, far_plane);
     hipError_t e = hipMemsetAsync(w.acc, 0, sizeof(float) * ACC_STRIDE * size_t(N), s);
@@ -284,5 +285,36 @@ extern "C" int lfs_fastgs_backward(
                            alpha, w.n_contrib, grad_image, grad_alpha, w.acc);
     }
     return fgs::launch_preprocess_bwd(N, means, scales_raw, rotations_raw, sh_coefficients_0, sh_coefficients_rest, f, w, grad_means, grad_scales_raw, grad_rotations_raw,
-                                      grad_opacities_raw, grad_sh_coefficients_0, grad_sh_coefficients_rest, densification_info, s);
+                                      grad_opacities_raw, grad_sh_coefficients_0, grad_sh_coefficients_rest, densification_info, s, adam);
+}
+
+extern "C" int lfs_fastgs_backward(
+    uint32_t N, const float* means, const float* scales_raw, const float* rotations_raw, const float* sh_coefficients_0, const float* sh_coefficients_rest,
+    uint32_t total_bases_sh_rest, const float* w2c, const float* cam_position, uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy,
+    float cx, float cy, float near_plane, float far_plane, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
+    void* instance_workspace, size_t instance_workspace_bytes, const float* grad_image, const float* grad_alpha, const float* alpha,
+    float* densification_info, float* grad_means, float* grad_scales_raw, float* grad_rotations_raw, float* grad_opacities_raw,
+    float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest, lfs_stream_t stream) {
+    return fastgs_backward_impl(N, means, scales_raw, rotations_raw, sh_coefficients_0, sh_coefficients_rest, total_bases_sh_rest, w2c, cam_position, active_sh_bases,
+                                width, height, fx, fy, cx, cy, near_plane, far_plane, n_instances, primitive_workspace, primitive_workspace_bytes, instance_workspace,
+                                instance_workspace_bytes, grad_image, grad_alpha, alpha, densification_info, grad_means, grad_scales_raw, grad_rotations_raw,
+                                grad_opacities_raw, grad_sh_coefficients_0, grad_sh_coefficients_rest, stream, nullptr);
+}
+
+// lfs_fastgs_backward for a step with ONE view, fused with the optimizer: sh_coefficients_rest and its Adam moments are updated in place by the SH
+// backward (fast_gs::optimizer::adam_step arithmetic), its gradient is never stored. Everything else as lfs_fastgs_backward.
+extern "C" int lfs_fastgs_backward_adam(
+    uint32_t N, const float* means, const float* scales_raw, const float* rotations_raw, const float* sh_coefficients_0, float* sh_coefficients_rest,
+    uint32_t total_bases_sh_rest, const float* w2c, const float* cam_position, uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy,
+    float cx, float cy, float near_plane, float far_plane, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
+    void* instance_workspace, size_t instance_workspace_bytes, const float* grad_image, const float* grad_alpha, const float* alpha,
+    float* densification_info, float* grad_means, float* grad_scales_raw, float* grad_rotations_raw, float* grad_opacities_raw,
+    float* grad_sh_coefficients_0, float* sh_rest_exp_avg, float* sh_rest_exp_avg_sq, float lr, float beta1, float beta2, float eps,
+    float bias_correction1_rcp, float bias_correction2_sqrt_rcp, lfs_stream_t stream) {
+    if (total_bases_sh_rest == 0 || !sh_rest_exp_avg || !sh_rest_exp_avg_sq) return LFS_E_INVALID;
+    const lfs::ShAdamArgs adam{sh_rest_exp_avg, sh_rest_exp_avg_sq, lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp};
+    return fastgs_backward_impl(N, means, scales_raw, rotations_raw, sh_coefficients_0, sh_coefficients_rest, total_bases_sh_rest, w2c, cam_position, active_sh_bases,
+                                width, height, fx, fy, cx, cy, near_plane, far_plane, n_instances, primitive_workspace, primitive_workspace_bytes, instance_workspace,
+                                instance_workspace_bytes, grad_image, grad_alpha, alpha, densification_info, grad_means, grad_scales_raw, grad_rotations_raw,
+                                grad_opacities_raw, grad_sh_coefficients_0, nullptr, stream, &adam);
 }

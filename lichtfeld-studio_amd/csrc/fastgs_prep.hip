@@ -283,7 +283,8 @@ int launch_scatter(uint32_t N, const Frame& f, const PrimWs& w, int64_t* keys, h
     return (int)hipGetLastError();
 }
 int launch_preprocess_bwd(uint32_t N, const float* means, const float* scales_raw, const float* rot_raw, const float* sh0, const float* sh_rest, const Frame& f, const PrimWs& w,
-                          float* g_means, float* g_scales_raw, float* g_rot_raw, float* g_opac_raw, float* g_sh0, float* g_sh_rest, float* densification_info, hipStream_t s) {
+                          float* g_means, float* g_scales_raw, float* g_rot_raw, float* g_opac_raw, float* g_sh0, float* g_sh_rest, float* densification_info, hipStream_t s,
+                          const ShAdamArgs* adam) {
     {
         lfs::ProfScope prof("fastgs_preprocess_bwd", s);
         hipLaunchKernelGGL(fg_preprocess_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, means, scales_raw, rot_raw, f, w.rec, w.conic_opacity, w.n_touched, w.acc,
@@ -293,7 +294,7 @@ int launch_preprocess_bwd(uint32_t N, const float* means, const float* scales_ra
     // accumulator rows (floats 6..8 of 16), the clamp mask from the record's colour (floats 8..10 of 16), writes g_sh0 / g_sh_rest fully, adds dL/dposition to g_means
     const uint32_t degree = f.active_sh_bases >= 16 ? 3 : f.active_sh_bases >= 9 ? 2 : f.active_sh_bases >= 4 ? 1 : 0;
     return sh_records_bwd(N, 1 + f.total_rest, degree, means, f.cam_pos, sh0, sh_rest, w.n_touched, reinterpret_cast<const float*>(w.rec) + 8, 16, w.acc + 5, 16,
-                          g_sh0, g_sh_rest, g_means, s);
+                          g_sh0, g_sh_rest, g_means, s, adam);
 }
 
 } // namespace fgs

@@ -7,9 +7,11 @@ namespace lfs {
 // sh.hip: the SH kernels with strided colour operands (colours live inside the 64-B blend records / accumulator rows)
 int sh_records_fwd(uint32_t n, uint32_t K, uint32_t degree, const float* means, const float* campos, const float* sh0, const float* shN,
                    const uint32_t* mask_u32, float* colors, uint32_t colors_stride, hipStream_t s);
+// adam != NULL (single-view steps): v_shN is not written, shN and its moments are updated in place by the same kernel (sh_bwd_kernel<.., ADAM>)
+struct ShAdamArgs { float* exp_avg; float* exp_avg_sq; float lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp; };
 int sh_records_bwd(uint32_t n, uint32_t K, uint32_t degree, const float* means, const float* campos, const float* sh0, const float* shN,
                    const uint32_t* mask_u32, const float* colors, uint32_t colors_stride, const float* v_colors, uint32_t v_stride,
-                   float* v_sh0, float* v_shN, float* v_means, hipStream_t s);
+                   float* v_sh0, float* v_shN, float* v_means, hipStream_t s, const ShAdamArgs* adam = nullptr);
 namespace fgs {
 
 // fastgs/rasterization/include/rasterization_config.h:14-33

@@ -500,12 +500,17 @@ int sh_records_fwd(uint32_t n, uint32_t K, uint32_t degree, const float* means, 
     a.n = n; a.K = K; a.degree = int(degree); a.means = means; a.campos = campos; a.sh0 = sh0; a.shN = shN; a.mask_u32 = mask_u32; a.cs = colors_stride;
     return sh_launch_fwd<true>(a, (degree + 1) * (degree + 1), colors, s);
 }
+struct ShAdamArgs { float* exp_avg; float* exp_avg_sq; float lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp; }; // as declared in lfs_fastgs.cuh
 int sh_records_bwd(uint32_t n, uint32_t K, uint32_t degree, const float* means, const float* campos, const float* sh0, const float* shN,
                    const uint32_t* mask_u32, const float* colors, uint32_t colors_stride, const float* v_colors, uint32_t v_stride,
-                   float* v_sh0, float* v_shN, float* v_means, hipStream_t s) {
+                   float* v_sh0, float* v_shN, float* v_means, hipStream_t s, const ShAdamArgs* adam) {
     ShArgs a{};
     a.n = n; a.K = K; a.degree = int(degree); a.means = means; a.campos = campos; a.sh0 = sh0; a.shN = shN; a.mask_u32 = mask_u32;
     a.colors = colors; a.cs = colors_stride; a.vs = v_stride;
+    if (adam && K > 1) {
+        const ShAdam ad{adam->exp_avg, adam->exp_avg_sq, AdamScalars{adam->lr, adam->beta1, adam->beta2, adam->eps, adam->bc1_rcp, adam->bc2_sqrt_rcp}};
+        return sh_launch_bwd_adam(a, v_colors, v_sh0, v_means, ad, s);
+    }
     return sh_launch_bwd<true, false>(a, v_colors, nullptr, v_sh0, v_shN, v_means, s);
 }
 

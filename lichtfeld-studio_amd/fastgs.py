@@ -65,9 +65,12 @@ def forward_wrapper(means, scales_raw, rotations_raw, opacities_raw, sh_coeffici
 
 
 def backward_wrapper(densification_info: Optional[torch.Tensor], grad_image, grad_alpha, image, alpha, means, scales_raw, rotations_raw,
-                     sh_coefficients_0, sh_coefficients_rest, primitive_workspace, instance_workspace, w2c, s: FastGSSettings, n_instances: int, out=None):
+                     sh_coefficients_0, sh_coefficients_rest, primitive_workspace, instance_workspace, w2c, s: FastGSSettings, n_instances: int, out=None,
+                     adam_sh_rest: Optional[dict] = None):
     """-> (grad_means, grad_scales_raw, grad_rotations_raw, grad_opacities_raw [N,1], grad_sh_coefficients_0, grad_sh_coefficients_rest);
-    densification_info [2,N] (when given and non-empty) is accumulated into in place (kernels_backward.cuh:229-232)."""
+    densification_info [2,N] (when given and non-empty) is accumulated into in place (kernels_backward.cuh:229-232).
+    Extension `adam_sh_rest` (FusedAdam.prepare_inline of sh_coefficients_rest; single-view steps): the rest-coefficient gradient is not
+    written, the coefficients and their moments are updated in place by the SH backward (lfs_fastgs_backward_adam)."""
     w2c = w2c.reshape(-1, 4, 4)[0].contiguous()
     cam_position = s.cam_position.reshape(-1)[:3].contiguous()
     grad_image, grad_alpha, alpha = grad_image.contiguous(), grad_alpha.contiguous(), alpha.contiguous()
@@ -87,6 +90,17 @@ def backward_wrapper(densification_info: Optional[torch.Tensor], grad_image, gra
         g_opac = torch.empty((N, 1), dtype=means.dtype, device=means.device)
         g_sh0 = torch.empty((N, 1, 3), dtype=means.dtype, device=means.device)
         g_shr = torch.empty_like(shr)
+    if adam_sh_rest is not None and total_rest > 0:
+        a = adam_sh_rest
+        if not sh_coefficients_rest.is_contiguous():
+            raise LfsError("adam_sh_rest needs the parameter tensor itself (contiguous), it is updated in place")
+        check(load_library().lfs_fastgs_backward_adam(
+            C.c_uint32(N), ptr(means), ptr(scales_raw), ptr(rotations_raw), ptr(sh0), ptr(sh_coefficients_rest), C.c_uint32(total_rest), ptr(w2c), ptr(cam_position),
+            *_frame_args(s), C.c_int64(n_instances), ptr(primitive_workspace), C.c_size_t(primitive_workspace.numel()), ptr(instance_workspace),
+            C.c_size_t(instance_workspace.numel()), ptr(grad_image), ptr(grad_alpha), ptr(alpha), ptr(dens), ptr(g_means), ptr(g_scales), ptr(g_rot), ptr(g_opac),
+            ptr(g_sh0), ptr(a["exp_avg"]), ptr(a["exp_avg_sq"]), C.c_float(a["lr"]), C.c_float(a["beta1"]), C.c_float(a["beta2"]), C.c_float(a["eps"]),
+            C.c_float(a["bc1_rcp"]), C.c_float(a["bc2_sqrt_rcp"]), stream()), "fastgs_backward_adam")
+        return g_means, g_scales, g_rot, g_opac, g_sh0, g_shr
     check(load_library().lfs_fastgs_backward(
         C.c_uint32(N), ptr(means), ptr(scales_raw), ptr(rotations_raw), ptr(sh0), ptr(shr), C.c_uint32(total_rest), ptr(w2c), ptr(cam_position), *_frame_args(s),
         C.c_int64(n_instances), ptr(primitive_workspace), C.c_size_t(primitive_workspace.numel()), ptr(instance_workspace), C.c_size_t(instance_workspace.numel()),
@@ -138,7 +152,8 @@ def mse_loss_chw_fwd_bwd(render_chw: torch.Tensor, target_chw: torch.Tensor, wei
 
 
 def render_and_backward(settings: FastGSSettings, w2c: torch.Tensor, model: SplatModel, target_chw: torch.Tensor, weight: float, grads, loss_acc: torch.Tensor,
-                        densification_info: Optional[torch.Tensor] = None, loss: str = "mse", lambda_dssim: float = 0.2, bilateral=None, image_idx: int = 0):
+                        densification_info: Optional[torch.Tensor] = None, loss: str = "mse", lambda_dssim: float = 0.2, bilateral=None, image_idx: int = 0,
+                        adam_shN: Optional[dict] = None):
     """One training view without an autograd graph (black background; loss "mse" or the trainer's "l1_ssim", trainer.cpp:122-125):
     forward, [bilateral-grid slice, trainer.cpp:662-664,] loss, backward; the gradients of (means, sh0, shN, raw_scales, raw_quats,
     raw_opacities) are WRITTEN into `grads` (param-group order); the bilateral grid's gradient is accumulated into its .grad."""
@@ -159,5 +174,5 @@ def render_and_backward(settings: FastGSSettings, w2c: torch.Tensor, model: Spla
         if not hasattr(render_and_backward, "_zero") or render_and_backward._zero.shape != alpha.shape or render_and_backward._zero.device != alpha.device:
             render_and_backward._zero = torch.zeros_like(alpha)
         backward_wrapper(densification_info, v_image, render_and_backward._zero, image, alpha, means, raw_scales, raw_quats, sh0, shN, pws, iws, w2c, settings, n_inst,
-                         out=(g_means, g_scales, g_quats, g_opac.view(-1, 1), g_sh0, g_shN))
+                         out=(g_means, g_scales, g_quats, g_opac.view(-1, 1), g_sh0, g_shN), adam_sh_rest=adam_shN)
     return image, alpha, n_inst

@@ -125,11 +125,15 @@ class GutTrainer:
             dens = self.densification_info
         if len(views) > 1 and (not hasattr(self, "_fg_tmp") or self._fg_tmp[0].shape[0] != N):
             self._fg_tmp = [torch.empty_like(v) for v in self.bucket.views]
+        inline = None   # one view on one rank, Adam reading shN: the SH backward inside lfs_fastgs_backward_adam updates shN itself
+        if (self.inline_shN_adam and self.world == 1 and len(views) == 1 and self.strategy is None and self.iteration > 1000 and self.model.shN.shape[1] > 0
+                and getattr(self.optimizer, "fused", False)):
+            inline = self.optimizer.prepare_inline(self.model.shN)
         for k, v in enumerate(views):
             dst = self.bucket.views if k == 0 else self._fg_tmp
             _, _, self.last_n_isects = fg_step(self._fastgs_settings(v), self.scene.viewmats[v:v + 1].contiguous(), self.model, targets[k % len(targets)],
                                                1.0 / total_views, dst, self.loss_acc, densification_info=dens, loss=self.loss_kind,
-                                               lambda_dssim=self.lambda_dssim, bilateral=self.bilateral, image_idx=v)
+                                               lambda_dssim=self.lambda_dssim, bilateral=self.bilateral, image_idx=v, adam_shN=inline)
             if k > 0:
                 for a, b in zip(self.bucket.views, self._fg_tmp):
                     a.add_(b)
