@@ -107,6 +107,7 @@ def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
 
 
 FUSE_MSE_INTO_BACKWARD = True   # False: separate lfs_mse_loss_fwd_bwd launch (tests compare the two)
+OVERLAP_SH_WITH_READBACK = True  # False: SH colours first, then the blocking n_isects read-back (A/B timing)
 
 
 @dataclass
@@ -142,11 +143,17 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         quats, scales, opac = activations_fwd(raw_quats, raw_scales, raw_opac)
         radii, means2d, depths, _, _ = ops.projection_ut_3dgs_fused(means, quats, scales, opac, viewmat, None, Kmat, W, H, 0.3, 0.01, 10000.0, 0.0,
                                                                     False, CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None)
-        if sh_exchange is None:
-            colors = sh_model_fwd(deg, means, viewmat, sh0, shN, radii)
+        # SH colours do not depend on the tile lists: they are enqueued while the host waits for n_isects (ops.intersect_tile `overlap`)
+        def sh_stage():
+            if sh_exchange is None:
+                return sh_model_fwd(deg, means, viewmat, sh0, shN, radii), None
+            return sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd_views)
+        if OVERLAP_SH_WITH_READBACK:
+            _, _, flatten_ids, offsets, (colors, sh_ctx) = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True,
+                                                                               overlap=sh_stage)
         else:
-            colors, sh_ctx = sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd_views)
-        _, _, flatten_ids, offsets = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True)
+            colors, sh_ctx = sh_stage()
+            _, _, flatten_ids, offsets = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True)
         bg = None if bg_color is None else bg_color.view(1, -1).contiguous()
         fwd_args = (means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, None, W, H, tile, viewmat, None, Kmat,
                     CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None, offsets, flatten_ids)
