@@ -250,6 +250,9 @@ LFS_API int lfs_fastgs_preprocess(
     const float* sh_coefficients_0, const float* sh_coefficients_rest, uint32_t total_bases_sh_rest, const float* w2c, const float* cam_position,
     uint32_t active_sh_bases, uint32_t width, uint32_t height, float fx, float fy, float cx, float cy, float near_plane, float far_plane,
     int64_t* n_instances, void* primitive_workspace, size_t primitive_workspace_bytes, lfs_stream_t stream);
+/* n_instances of this process's last lfs_fastgs_preprocess call, read back asynchronously: blocks until the 8-byte copy (queued before the SH kernel)
+ * has landed, not until the stream is idle. Alternative to reading the device value with a stream synchronisation. */
+LFS_API int lfs_fastgs_wait_n_instances(int64_t* n_instances);
 LFS_API int lfs_fastgs_render(
     uint32_t N, uint32_t width, uint32_t height, int64_t n_instances, void* primitive_workspace, size_t primitive_workspace_bytes,
     void* instance_workspace, size_t instance_workspace_bytes, float* image, float* alpha, lfs_stream_t stream);

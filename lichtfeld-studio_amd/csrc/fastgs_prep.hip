@@ -302,6 +302,32 @@ int launch_preprocess_bwd(uint32_t N, const float* means, const float* scales_ra
 
 using namespace lfs;
 
+namespace lfs { namespace fgs {
+// one pinned int64 + event per process: the reference's trainer (and this one) has a single rendering thread
+struct Readback { int64_t* host = nullptr; hipEvent_t event = nullptr; bool armed = false; };
+static Readback& readback() {
+    static Readback rb = [] {
+        Readback r;
+        if (hipHostMalloc((void**)&r.host, sizeof(int64_t), hipHostMallocDefault) != hipSuccess) r.host = nullptr;
+        if (hipEventCreateWithFlags(&r.event, hipEventDisableTiming) != hipSuccess) r.event = nullptr;
+        return r;
+    }();
+    return rb;
+}
+} } // namespace lfs::fgs
+
+// n_instances of the last lfs_fastgs_preprocess call on this process: waits for the read-back event only (not for the SH kernel queued after it)
+extern "C" int lfs_fastgs_wait_n_instances(int64_t* n_instances) {
+    if (!n_instances) return LFS_E_INVALID;
+    lfs::fgs::Readback& rb = lfs::fgs::readback();
+    if (!rb.armed) return LFS_E_INVALID;
+    const hipError_t e = hipEventSynchronize(rb.event);
+    if (e != hipSuccess) return (int)e;
+    *n_instances = *rb.host;
+    rb.armed = false;
+    return LFS_OK;
+}
+
 extern "C" size_t lfs_fastgs_primitive_workspace_bytes(uint32_t N, uint32_t width, uint32_t height) { return fgs::prim_ws(nullptr, N, width, height).bytes; }
 extern "C" size_t lfs_fastgs_instance_workspace_bytes(uint32_t width, uint32_t height, int64_t n_instances) {
     return n_instances < 0 ? 0 : fgs::inst_ws(nullptr, width, height, uint64_t(n_instances)).bytes;
@@ -336,6 +362,15 @@ extern "C" int lfs_fastgs_preprocess(
                                    f, w.rec, w.mean2d, w.conic_opacity, w.bounds, w.n_touched, w.depth_bits, w.totals);
         }
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_instances);
+    }
+    // The host needs n_instances to size the instance workspace (the reference syncs here, forward.cu:114-117). Queue the read-back BEFORE the SH
+    // launch and mark it with an event: lfs_fastgs_wait_n_instances() then returns as soon as the count has landed while the GPU is already
+    // evaluating SH colours, instead of idling through the host round trip (~40 us).
+    {
+        fgs::Readback& rb = fgs::readback();
+        if (rb.host && rb.event) {
+            if (hipMemcpyAsync(rb.host, n_instances, sizeof(int64_t), hipMemcpyDeviceToHost, s) == hipSuccess) { (void)hipEventRecord(rb.event, s); rb.armed = true; }
+        }
     }
     if (N > 0) { // SH colour (convert_sh_to_color, kernel_utils.cuh:15-36) of the visible primitives, written into the records
         const uint32_t degree = active_sh_bases >= 16 ? 3 : active_sh_bases >= 9 ? 2 : active_sh_bases >= 4 ? 1 : 0;

@@ -32,6 +32,9 @@ class FastGSSettings:  # rasterization_api.h:12-24
     far_plane: float
 
 
+ASYNC_READBACK = True   # False: n_instances via a stream synchronisation (A/B timing)
+
+
 def _frame_args(s: FastGSSettings):
     return (C.c_uint32(s.active_sh_bases), C.c_uint32(s.width), C.c_uint32(s.height), C.c_float(s.focal_x), C.c_float(s.focal_y),
             C.c_float(s.center_x), C.c_float(s.center_y), C.c_float(s.near_plane), C.c_float(s.far_plane))
@@ -55,7 +58,14 @@ def forward_wrapper(means, scales_raw, rotations_raw, opacities_raw, sh_coeffici
     n_inst_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     check(lib.lfs_fastgs_preprocess(C.c_uint32(N), ptr(means), ptr(scales_raw), ptr(rotations_raw), ptr(opac), ptr(sh0), ptr(shr), C.c_uint32(total_rest),
                                     ptr(w2c), ptr(cam_position), *_frame_args(s), ptr(n_inst_dev), ptr(pws), C.c_size_t(pws.numel()), stream()), "fastgs_preprocess")
-    n_instances = int(n_inst_dev.item())  # the one host sync (forward.cu:114-117 reads n_visible_primitives and n_instances)
+    # the one host sync (forward.cu:114-117 reads n_visible_primitives and n_instances): waits for the read-back event the library queued before
+    # its SH kernel, so the GPU keeps working through the host round trip
+    if ASYNC_READBACK:
+        n_host = C.c_int64(0)
+        check(lib.lfs_fastgs_wait_n_instances(C.byref(n_host)), "fastgs_wait_n_instances")
+        n_instances = int(n_host.value)
+    else:
+        n_instances = int(n_inst_dev.item())
     iws = torch.empty(max(256, lib.lfs_fastgs_instance_workspace_bytes(C.c_uint32(s.width), C.c_uint32(s.height), C.c_int64(n_instances))), dtype=torch.uint8, device=dev)
     image = torch.empty((3, s.height, s.width), dtype=means.dtype, device=dev)
     alpha = torch.empty((1, s.height, s.width), dtype=means.dtype, device=dev)

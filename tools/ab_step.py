@@ -5,15 +5,19 @@ import torch
 import lichtfeld_studio_amd  # noqa
 from lichtfeld_studio_amd import fused, scenes
 from lichtfeld_studio_amd.trainer import GutTrainer
-flag = sys.argv[1]
+flag = sys.argv[1]            # fused.<FLAG> or fastgs.<FLAG> (the latter runs the fastgs rasterizer)
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+mod = fused
+if flag.startswith("fastgs."):
+    from lichtfeld_studio_amd import fastgs as mod
+flag = flag.split(".")[-1]
 dev = torch.device("cuda:0")
 sc = scenes.syn_b()
-tr = GutTrainer(sc, dev, iterations=7000)
+tr = GutTrainer(sc, dev, iterations=7000, rasterizer="fastgs" if mod is not fused else "gut")
 tr.iteration = 3000
 t = [scenes.target_image(sc.height, sc.width).to(dev)]
 def run(v, n=40):
-    setattr(fused, flag, v)
+    setattr(mod, flag, v)
     for _ in range(5): tr.train_step(t)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): tr.train_step(t)
