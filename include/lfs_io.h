@@ -83,8 +83,10 @@ LFS_IO_API int lfs_image_info(const char* path, int32_t* width, int32_t* height,
 /* load_image's output size (image_io.cpp:112-270): res_div in {<=1, 2, 4, 8}, then the max_width cap */
 LFS_IO_API int lfs_image_target_size(int32_t width, int32_t height, int32_t res_div, int32_t max_width, int32_t* out_width, int32_t* out_height);
 /* Decode to 8-bit RGB [h,w,3] (alpha dropped, 1 channel replicated, 2 channels -> (r, g, (r+g)/2) as image_io.cpp:222-247).
- * Native decoders: PNG (non-interlaced, 8/16 bit) and binary PNM; JPEG returns LFS_IO_E_UNSUPPORTED (the Python host
- * layer decodes those with Pillow). The buffer is owned by the library: release with lfs_io_free. */
+ * Native decoders: PNG (non-interlaced, 8/16 bit), binary PNM and JPEG (8-bit Huffman, baseline + progressive, 1 or 3 components,
+ * sampling factors <= 2: the libjpeg default pipeline - islow IDCT, fancy upsampling, fixed-point YCbCr->RGB - bit-identical to
+ * libjpeg-turbo); anything else returns LFS_IO_E_UNSUPPORTED (the Python host layer then tries Pillow). The buffer is owned by the
+ * library: release with lfs_io_free. */
 LFS_IO_API int lfs_image_load_rgb8(const char* path, uint8_t** data, int32_t* width, int32_t* height);
 LFS_IO_API int lfs_image_write_png_rgb8(const char* path, const uint8_t* data, int32_t width, int32_t height);
 LFS_IO_API void lfs_io_free(void* p);

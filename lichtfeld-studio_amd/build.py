@@ -83,11 +83,11 @@ IO_OUT = os.path.join(HERE, "liblfs_io.so")
 
 def build_io(force: bool = False) -> str:
     """Host-only data-format library (csrc_host/lfs_io.cpp: COLMAP, splat PLY, PNG/PNM) -> lichtfeld-studio_amd/liblfs_io.so (g++ + zlib)."""
-    src = os.path.join(HERE, "csrc_host", "lfs_io.cpp")
-    deps = [src, os.path.join(HERE, "..", "include", "lfs_io.h")]
+    srcs = [os.path.join(HERE, "csrc_host", "lfs_io.cpp"), os.path.join(HERE, "csrc_host", "lfs_jpeg.cpp")]
+    deps = srcs + [os.path.join(HERE, "..", "include", "lfs_io.h")]
     if not force and os.path.exists(IO_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(IO_OUT) for d in deps):
         return IO_OUT
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-Wall", "-Wextra", src, "-lz", "-o", IO_OUT]
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-Wall", "-Wextra", *srcs, "-lz", "-o", IO_OUT]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"liblfs_io build failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

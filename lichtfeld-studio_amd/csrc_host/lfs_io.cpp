@@ -29,6 +29,9 @@
 
 namespace fs = std::filesystem;
 
+// lfs_jpeg.cpp
+uint8_t* lfs_decode_jpeg_rgb8(const uint8_t* data, size_t size, int32_t* width, int32_t* height, bool* unsupported, std::string* error);
+
 namespace {
 
 thread_local std::string g_error;
@@ -891,7 +894,14 @@ int lfs_image_load_rgb8(const char* path, uint8_t** data, int32_t* width, int32_
             *data = out; *width = pnm.w; *height = pnm.h;
             return;
         }
-        if (f.size() >= 2 && u[0] == 0xFF && u[1] == 0xD8) fail(LFS_IO_E_UNSUPPORTED, "JPEG decoding is not built into liblfs_io (decode in the host layer)");
+        if (f.size() >= 2 && u[0] == 0xFF && u[1] == 0xD8) {
+            bool unsupported = false;
+            std::string err;
+            uint8_t* out = lfs_decode_jpeg_rgb8(u, f.size(), width, height, &unsupported, &err);
+            if (!out) fail(unsupported ? LFS_IO_E_UNSUPPORTED : LFS_IO_E_FORMAT, "%s (%s)", err.c_str(), path);
+            *data = out;
+            return;
+        }
         fail(LFS_IO_E_UNSUPPORTED, "Unrecognised image format: %s", path);
     });
 }

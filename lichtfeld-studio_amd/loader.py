@@ -10,9 +10,9 @@ liblfs_io.so (include/lfs_io.h; C++17, no GPU) plus the two GPU kernels of csrc/
   colmap_scene                           the Scene the trainer consumes (viewmats [R|t], K scaled to the loaded image size:
                                          src/core/camera.cpp:15-23, :77-98)
 
-JPEG decoding is the one step that is not native: liblfs_io decodes PNG / PNM itself and reports JPEG as unsupported, in which case
-this layer decodes with Pillow (the reference links OpenImageIO for the same job). Decoding is host work either way; everything
-after the decoded bytes (resample, CHW, float) runs in one HIP kernel.
+liblfs_io decodes PNG, PNM and JPEG itself (baseline and progressive Huffman JPEG, bit-identical to libjpeg-turbo's default pipeline, i.e. to what
+the reference gets through OpenImageIO); what it reports as unsupported (CMYK JPEG, interlaced PNG, TIFF ...) is decoded with Pillow here.
+Decoding is host work either way; everything after the decoded bytes (resample, CHW, float) runs in one HIP kernel.
 """
 from __future__ import annotations
 
@@ -176,7 +176,7 @@ def image_target_size(w: int, h: int, resize_factor: int = -1, max_width: int = 
 
 
 def decode_rgb8(path: str) -> np.ndarray:
-    """-> uint8 [h,w,3]; native decoder first, Pillow for what liblfs_io does not decode (JPEG ...)."""
+    """-> uint8 [h,w,3]; native decoder first, Pillow for what liblfs_io does not decode."""
     lib = io_library()
     data, w, h = C.POINTER(C.c_uint8)(), C.c_int32(), C.c_int32()
     rc = lib.lfs_image_load_rgb8(os.fsencode(path), C.byref(data), C.byref(w), C.byref(h))

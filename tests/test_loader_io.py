@@ -230,7 +230,7 @@ def test_image_headers_decoders_and_sizes(ld, tmp_path):
             assert np.array_equal(got[..., :2], rgb[..., :2]) and np.array_equal(got[..., 2], ((rgb[..., 0].astype(int) + rgb[..., 1]) // 2).astype(np.uint8))
         elif name == "pal.png":
             assert np.array_equal(got, np.asarray(Image.open(p).convert("RGB")))
-        else:                        # JPEG goes through Pillow
+        else:                        # JPEG: decoded natively, bit-identical to libjpeg-turbo (Pillow)
             assert np.array_equal(got, np.asarray(Image.open(p).convert("RGB")))
     # PNM, and our own PNG writer through Pillow
     pp = str(tmp_path / "a.ppm")
@@ -266,3 +266,71 @@ def test_dataset_split_and_camera_matrices(ld):
     assert np.array_equal(m[:3, 3], [1, 2, 3]) and np.array_equal(m[3], [0, 0, 0, 1])               # [R | t], camera.cpp:15-23
     K = ld.intrinsics(cams[0], 320, 240)
     assert np.array_equal(K, np.array([[250, 0, 160], [0, 255, 120], [0, 0, 1]], np.float32))          # camera.cpp:77-98
+
+
+def _native_rgb8(ld, path):
+    """liblfs_io only (no Pillow fallback)"""
+    import ctypes as C
+    lib = ld.io_library()
+    data, w, h = C.POINTER(C.c_uint8)(), C.c_int32(), C.c_int32()
+    rc = lib.lfs_image_load_rgb8(os.fsencode(path), C.byref(data), C.byref(w), C.byref(h))
+    if rc != 0:
+        return rc, lib.lfs_io_last_error().decode()
+    try:
+        return 0, np.ctypeslib.as_array(data, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib.lfs_io_free(data)
+
+
+def test_native_jpeg_decoder_is_bit_identical_to_libjpeg_turbo(ld, tmp_path):
+    """csrc_host/lfs_jpeg.cpp (islow IDCT, fancy upsampling, fixed-point YCbCr->RGB: the libjpeg defaults OpenImageIO decodes with) against Pillow's
+    libjpeg-turbo, byte for byte: baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0, grey, ragged and tiny sizes, optimised tables, restart markers, noise."""
+    from PIL import Image
+    rng = np.random.default_rng(4)
+
+    def picture(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([128 + 100 * np.sin(x / 7.0 + y / 13.0), 128 + 90 * np.cos(x / 11.0 - y / 5.0), 128 + 80 * np.sin((x + y) / 9.0)], -1)
+        return np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+
+    p = str(tmp_path / "t.jpg")
+    n = 0
+    for (h, w) in [(64, 64), (37, 53), (17, 9), (1, 1), (2, 2), (3, 1), (200, 303), (33, 2), (5, 3), (1, 40), (40, 1)]:
+        for sub in (0, 1, 2):
+            for prog in (False, True):
+                for q, extra in ((30, {}), (90, {"optimize": True}), (100, {})):
+                    try:
+                        Image.fromarray(picture(h, w)).save(p, quality=q, subsampling=sub, progressive=prog, **extra)
+                    except OSError:
+                        continue        # Pillow's encoder buffer on some tiny optimised files
+                    rc, got = _native_rgb8(ld, p)
+                    assert rc == 0, got
+                    assert np.array_equal(got, np.asarray(Image.open(p).convert("RGB"))), (h, w, sub, prog, q)
+                    n += 1
+    assert n > 150
+    for prog in (False, True):      # grey, and white noise at high quality (long EOB runs, every Huffman code length)
+        Image.fromarray(picture(40, 56)[..., 0]).save(p, quality=85, progressive=prog)
+        rc, got = _native_rgb8(ld, p)
+        assert rc == 0 and np.array_equal(got, np.asarray(Image.open(p).convert("RGB")))
+        assert ld.get_image_info(p) == (56, 40, 1)
+        Image.fromarray(rng.integers(0, 256, (120, 200, 3), dtype=np.uint8)).save(p, quality=97, subsampling=2, progressive=prog)
+        rc, got = _native_rgb8(ld, p)
+        assert rc == 0 and np.array_equal(got, np.asarray(Image.open(p).convert("RGB")))
+    try:                             # restart intervals (Pillow >= 10.2)
+        for kw in ({"restart_marker_blocks": 3}, {"restart_marker_rows": 1}):
+            for prog in (False, True):
+                Image.fromarray(picture(70, 90)).save(p, quality=80, subsampling=2, progressive=prog, **kw)
+                assert b"\xff\xdd" in open(p, "rb").read()
+                rc, got = _native_rgb8(ld, p)
+                assert rc == 0 and np.array_equal(got, np.asarray(Image.open(p).convert("RGB"))), (kw, prog)
+    except TypeError:
+        pass
+    # error behaviour: truncated data is a format error (or decodes what is there), CMYK is reported as unsupported so that the host layer can fall back
+    good = open(p, "rb").read()
+    open(p, "wb").write(good[:20])
+    rc, msg = _native_rgb8(ld, p)
+    assert rc == -3 and "JPEG" in msg
+    Image.fromarray(picture(16, 16)).convert("CMYK").save(p)
+    rc, msg = _native_rgb8(ld, p)
+    assert rc == -4 and "component" in msg
+    assert ld.decode_rgb8(p).shape == (16, 16, 3)       # Pillow fallback
