@@ -360,6 +360,23 @@ class CameraDataset:
         return cam, load_image(cam.image_path, self.resize_factor, self.max_width, device)
 
 
+def preload(ds: "CameraDataset", device="cuda:0", workers: int = 8) -> List[torch.Tensor]:
+    """All images of the split as resident f32 [3,h,w] device tensors. Decoding (liblfs_io, outside the GIL) runs on `workers` host threads;
+    upload + resample + layout change stay on the calling thread's stream, in dataset order."""
+    import concurrent.futures as cf
+    paths = [ds.cameras[i].image_path for i in ds.indices]
+    out = []
+    with cf.ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+        for rgb in ex.map(decode_rgb8, paths):
+            h, w = rgb.shape[:2]
+            ow, oh = image_target_size(w, h, ds.resize_factor, ds.max_width)
+            host = torch.from_numpy(rgb)
+            if torch.cuda.is_available():
+                host = host.pin_memory()
+            out.append(u8_to_chw_f32(host.to(device, non_blocking=True), ow, oh))
+    return out
+
+
 def world_to_view(cam: CameraData) -> np.ndarray:
     """camera.cpp:15-23: [R | t] with the COLMAP translation as is."""
     m = np.eye(4, dtype=np.float32)

@@ -49,7 +49,7 @@ def main():
     scene, ds, scene_scale = loader.colmap_scene(args.data_path, args.images, split=split, test_every=args.test_every, resize_factor=args.resize_factor,
                                                  max_width=args.max_width, sh_degree=args.sh_degree, init_scaling=init_scaling, init_opacity=init_opacity,
                                                  text=args.text, device=dev)
-    targets = [ds.get(k, dev)[1] for k in range(len(ds))]                   # resident in HBM: 288 GB hold a Mip-NeRF360 scene at full resolution
+    targets = loader.preload(ds, dev, workers=os.cpu_count() or 8)          # resident in HBM: 288 GB hold a Mip-NeRF360 scene at full resolution
     t_load = time.time() - t0
     rast = "gut" if args.gut else "fastgs"
     if args.bilateral_grid and rast != "fastgs":
@@ -73,8 +73,8 @@ def main():
         cams_all, _ = (loader.read_colmap_cameras_and_images_text if args.text else loader.read_colmap_cameras_and_images)(args.data_path, args.images)
         val = loader.CameraDataset(cams_all, "val", args.test_every, args.resize_factor, args.max_width)
         cameras, images = [], []
-        for k in range(len(val)):
-            cam, img = val.get(k, dev)
+        for k, img in enumerate(loader.preload(val, dev)):
+            cam = val.cameras[val.indices[k]]
             h, w = img.shape[1:]
             cameras.append(Camera(torch.from_numpy(loader.world_to_view(cam))[None].to(dev), torch.from_numpy(loader.intrinsics(cam, w, h))[None].to(dev), w, h))
             images.append(img)
