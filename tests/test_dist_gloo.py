@@ -177,9 +177,9 @@ def _sh_standins(oracle):
     return fwd, bwd, fwd_views, bwd_views
 
 
-def _sh_problem(world):
+def _sh_problem(world, N=203):
     g = torch.Generator().manual_seed(5)
-    N, K, deg = 203, 9, 2                                  # N not divisible by the world size: the last shard is short
+    K, deg = 9, 2                                          # N not divisible by the world size: the last shard is short
     means = torch.randn(N, 3, generator=g)
     sh0, shN = torch.randn(N, 1, 3, generator=g), torch.randn(N, K - 1, 3, generator=g)
     viewmats, radii, v_colors = [], [], []
@@ -192,7 +192,7 @@ def _sh_problem(world):
     return N, K, deg, means, sh0, shN, viewmats, radii, v_colors
 
 
-def _sh_worker(rank, world, port, q):
+def _sh_worker(rank, world, port, q, N=203):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import oracle
@@ -200,7 +200,7 @@ def _sh_worker(rank, world, port, q):
     from lichtfeld_studio_amd import dist as ld
     ld.init_distributed(backend="gloo")
     _, _, fwd, bwd = _sh_standins(oracle)
-    N, K, deg, means, sh0, shN, viewmats, radii, v_colors = _sh_problem(world)
+    N, K, deg, means, sh0, shN, viewmats, radii, v_colors = _sh_problem(world, N)
     ex = ld.ShExchange(N, world, rank)
     shN_shard = ex.shard(shN).clone()
     # two sub-steps (views_per_rank = 2): the second accumulates
@@ -221,14 +221,17 @@ def _sh_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sh_sharded_exchange_matches_replicated_computation():
+import pytest
+
+
+@pytest.mark.parametrize("world,N", [(2, 203), (3, 5), (4, 3)])      # uneven shards; more ranks than rows per shard; a rank that owns nothing
+def test_sh_sharded_exchange_matches_replicated_computation(world, N):
     import oracle
     oracle.lib()
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_sh_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 31500 + (os.getpid() % 2000) + 7 * world
+    procs = [ctx.Process(target=_sh_worker, args=(r, world, port, q, N)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
@@ -237,7 +240,7 @@ def test_sh_sharded_exchange_matches_replicated_computation():
         assert p.exitcode == 0
     # replicated reference: every rank evaluates SH for its own views on the full tensors, gradients summed over ranks
     fwd, bwd, _, _ = _sh_standins(oracle)
-    N, K, deg, means, sh0, shN, viewmats, radii, v_colors = _sh_problem(world)
+    N, K, deg, means, sh0, shN, viewmats, radii, v_colors = _sh_problem(world, N)
     ref_sh0, ref_shN, ref_means = torch.zeros(N, 1, 3), torch.zeros(N, K - 1, 3), torch.full((N, 3), float(world))
     for rank in range(world):
         for k in range(2):
@@ -246,9 +249,12 @@ def test_sh_sharded_exchange_matches_replicated_computation():
             vis = (radii[my] > 0).all(-1)
             assert np.allclose(results[rank][1][k][vis.numpy()], c.numpy()[vis.numpy()], atol=1e-6)      # colours of the visible Gaussians
             bwd(deg, means, viewmats[my], sh0, shN, radii[my], c, v_colors[my] * (k + 1), ref_sh0, ref_shN, ref_means, True)
-    assert results[0][5] == (0, 102) and results[1][5] == (102, 203)
+    S = (N + world - 1) // world
+    assert [r[5] for r in results] == [(min(j * S, N), min(min(j * S, N) + S, N)) for j in range(world)]
+    if (world, N) == (4, 3):
+        assert results[3][5] == (3, 3)                       # the fourth rank owns no rows and still takes part in every collective
     for rank in range(world):
         assert np.allclose(results[rank][2], ref_means.numpy(), atol=2e-5), "means gradient (rasterizer part + SH view-direction part)"
         assert np.allclose(results[rank][3], ref_sh0.numpy(), atol=2e-5)
         assert np.allclose(results[rank][4], ref_shN.numpy(), atol=2e-5), "all-gathered shard gradients == replicated shN gradient"
-    assert np.array_equal(results[0][4], results[1][4])
+        assert np.array_equal(results[0][4], results[rank][4])
