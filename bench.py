@@ -45,7 +45,7 @@ def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems
         "raster_pack": 60 * N + 64 * N + 32 * N,
         "raster_cull": 4 * (4 * I + 32 * I) + 8 * 4 * I,  # every 8x8 cell reads its tile's ids + 32-B culling records, writes <= 8 B per entry
         "raster_fwd": 60 * I + 20 * P,
-        "raster_bwd": 60 * I + 24 * P + 56 * N + 112 * V,
+        "raster_bwd": 60 * I + 24 * P + 56 * N + 112 * V,   # (with the MSE loss folded in it reads render + target instead of v_render: + 12 P, not charged)
         "raster_finish": 64 * N + 44 * N + 56 * N,
         "sh_bwd": 24 * V + 12 * K * V + 12 * K * N + 12 * K * V + 12 * V,
         # single-view steps: SH backward with shN's Adam update inside (no shN gradient tensor): read p, m, v + write p, m, v of shN,
