@@ -70,6 +70,7 @@ class FusedAdam:
                 bc2_sqrt_rcp = 1.0 / math.sqrt(1.0 - math.pow(beta2, st["step_count"]))
                 entries.append((p, st["exp_avg"], st["exp_avg_sq"], p.grad.contiguous(), float(lr), float(beta1), float(beta2),
                                 float(eps), float(bc1_rcp), float(bc2_sqrt_rcp)))
+        self._inline_done.clear()   # (ids of tensors replaced meanwhile must not linger: Python reuses ids)
         if self.fused:
             ops.adam_step_multi(entries)
         else:

@@ -31,9 +31,9 @@ class GutTrainer:
         # SH-sharded data parallelism (dist.ShExchange): shN and its Adam state live on one rank each. Default for the fused 3DGUT step
         # on more than one rank; the strategies index all parameters by Gaussian and keep the replicated layout.
         if sh_sharded is None:
-            sh_sharded = world > 1 and fused_l2 and rasterizer == "gut" and strategy is None
-        if sh_sharded and not (fused_l2 and rasterizer == "gut" and strategy is None):
-            raise ValueError("sh_sharded needs the fused 3DGUT step without a densification strategy")
+            sh_sharded = world > 1 and fused_l2 and rasterizer == "gut" and strategy in (None, "mcmc")
+        if sh_sharded and not (fused_l2 and rasterizer == "gut" and strategy in (None, "mcmc")):
+            raise ValueError("sh_sharded needs the fused 3DGUT step (no strategy, or MCMC: its refinement steps run on the gathered tensors)")
         self.sh_exchange = lfs_dist.ShExchange(sc.means.shape[0], world, rank) if sh_sharded else None
         shN0 = self.sh_exchange.shard(sc.shN) if sh_sharded else sc.shN
         self.model = SplatModel(mk(sc.means), mk(sc.sh0), mk(shN0), mk(sc.raw_scales), mk(sc.raw_quats), mk(sc.raw_opacities), sc.sh_degree)
@@ -172,6 +172,31 @@ class GutTrainer:
             self.scheduler.step()
         return self.loss_acc
 
+    def _refine_with_full_shN(self, fn) -> None:
+        """SH-sharded + a densification strategy: the strategy's index surgery (relocation, growth, pruning) addresses Gaussians globally, so for a
+        refinement step shN and its Adam moments are all-gathered (3 x 180 B / Gaussian, every `refine_every` iterations: < 1 % of the traffic of
+        the steps in between), the unchanged replicated strategy code runs - identically on every rank - and the result is re-sharded for the new N."""
+        ex, opt = self.sh_exchange, self.optimizer
+        old = self.model.shN
+        st = opt._state(old)
+        m_full, v_full = ex.gather_rows(st["exp_avg"]), ex.gather_rows(st["exp_avg_sq"])
+        full = ex.gather_rows(old.detach()).contiguous().requires_grad_(True)
+        opt.replace_param(2, old, full, lambda t: m_full if t is st["exp_avg"] else v_full)
+        self.model.shN = full
+        self.sh_exchange = None
+        try:
+            fn()
+        finally:
+            cur = self.model.shN
+            st2 = opt._state(cur)
+            ex2 = lfs_dist.ShExchange(self.model.means.shape[0], self.world, self.rank)
+            ms, vs = ex2.shard(st2["exp_avg"]).clone(), ex2.shard(st2["exp_avg_sq"]).clone()
+            shard = ex2.shard(cur.detach()).clone().requires_grad_(True)
+            opt.replace_param(2, cur, shard, lambda t: ms if t is st2["exp_avg"] else vs)
+            self.model.shN = shard
+            self.sh_exchange = ex2
+            self._on_resize()
+
     def full_shN(self) -> torch.Tensor:
         """[N,K-1,3] on every rank (all-gathers the owners' rows when SH-sharded): export, evaluation."""
         return self.model.shN.detach() if self.sh_exchange is None else self.sh_exchange.gather_rows(self.model.shN.detach())
@@ -209,8 +234,9 @@ class GutTrainer:
                     and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False)):
                 inline = self.optimizer.prepare_inline(self.model.shN)
             inline_shard = None   # SH-sharded, one view per rank: the owners' multi-view SH backward applies the shard's Adam update
-            if (self.inline_shN_adam and self.sh_exchange is not None and len(views) == 1 and self.iteration > 1000 and self.sh_exchange.n
-                    and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False)):
+            refining = self.strategy is not None and self.strategy.is_refining(self.iteration)   # parameters are replaced before the optimizer step:
+            if (self.inline_shN_adam and self.sh_exchange is not None and len(views) == 1 and self.iteration > 1000 and self.sh_exchange.n   # no update then
+                    and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False) and not refining):
                 inline_shard = self.optimizer.prepare_inline(self.model.shN)
             for k, v in enumerate(views):
                 vm_all = None if every is None else [self.scene.viewmats[e[k]:e[k] + 1].contiguous() for e in every]
@@ -226,7 +252,10 @@ class GutTrainer:
             for p, gv in zip(params, self.bucket.views):
                 p.grad = gv
             if self.strategy is not None:  # trainer.cpp:741-760: post_backward (may replace the parameter tensors) then step
-                self.strategy.post_backward(self.iteration)
+                if self.sh_exchange is not None and self.strategy.is_refining(self.iteration):
+                    self._refine_with_full_shN(lambda: self.strategy.post_backward(self.iteration))
+                else:
+                    self.strategy.post_backward(self.iteration)
                 self.strategy.step(self.iteration)  # FusedAdam skips tensors without a gradient, as the reference's does after add_new_gs
             else:
                 self.optimizer.step(self.iteration)

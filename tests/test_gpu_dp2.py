@@ -78,3 +78,55 @@ def test_two_rank_step_matches_single_process(lfs, sharded):
 
 def _scene_param(sc, name):
     return {"means": sc.means, "sh0": sc.sh0, "shN": sc.shN, "raw_scales": sc.raw_scales, "raw_quats": sc.raw_quats, "raw_opacities": sc.raw_opacities}[name].numpy()
+
+
+def _mcmc_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import dist as ld, scenes, strategies
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    ld.init_distributed(backend="gloo")
+    dev = torch.device("cuda:0")
+    sc = _scene()
+    op = strategies.OptimizationParameters(iterations=400, start_refine=1002, refine_every=4, stop_refine=2000, max_cap=7000)
+    tr = GutTrainer(sc, dev, iterations=400, world=world, rank=rank, strategy="mcmc", opt_params=op)
+    assert tr.sh_exchange is not None, "MCMC keeps the SH-sharded layout"
+    tr.iteration = 1000
+    target = scenes.target_image(sc.height, sc.width).to(dev) * 0.6
+    n_seen, losses = [], []
+    for _ in range(14):
+        losses.append(float(tr.train_step([target])))
+        n_seen.append((tr.model.means.shape[0], tr.model.shN.shape[0], tr.sh_exchange.r0, tr.sh_exchange.r1))
+    st = tr.optimizer._state(tr.model.shN)
+    params = [p.detach().cpu().numpy() for p in tr.model.parameters()]
+    params[2] = tr.full_shN().cpu().numpy()
+    moments = tr.sh_exchange.gather_rows(st["exp_avg"]).cpu().numpy()
+    q.put((rank, params, losses, n_seen, moments, st["step_count"]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_mcmc_keeps_sh_sharded_layout(lfs):
+    """MCMC (relocation + growth + noise) on two SH-sharded ranks: refinement steps gather shN and its moments, run the replicated strategy code and
+    re-shard for the new N. Replicated parameters, the gathered shN and its gathered Adam moments stay bit-identical across ranks; shards follow N."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_mcmc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=600) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, p0, l0, n0, m0, c0), (_, p1, l1, n1, m1, c1) = results
+    for name, a, b in zip(["means", "sh0", "shN (gathered)", "raw_scales", "raw_quats", "raw_opacities"], p0, p1):
+        assert a.shape == b.shape and np.array_equal(a, b), f"{name}: ranks diverged"
+    assert np.array_equal(m0, m1) and c0 == c1 == 14 - 3      # the three refinement steps replace the tensors: no gradient, no optimizer update (as in the reference)
+    N0, N_end = 6001, n0[-1][0]
+    assert N_end > N0 and N_end <= 7000, "MCMC growth (5 % per refinement, capped)"
+    for (N, rows0, a0, b0), (N_, rows1, a1, b1) in zip(n0, n1):
+        S = (N + 1) // 2
+        assert N == N_ and (a0, b0) == (0, S) and (a1, b1) == (S, N) and rows0 == S and rows1 == N - S      # shards re-cut when N changes
+    assert p0[2].shape[0] == N_end and np.isfinite(l0).all() and np.isfinite(l1).all()
+    assert float(np.abs(m0).max()) > 0
