@@ -62,3 +62,22 @@ def test_product_never_imports_the_oracle():
             assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), f
             assert not re.search(r'#include\s+"[^"]*oracle', src), f
             assert "liboracle" not in src and "oracle_ops" not in src, f
+
+
+def test_io_library_exports_every_symbol_of_its_header():
+    """include/lfs_io.h <-> liblfs_io.so <-> loader.IO_EXPORTS (host-only library: loads without ROCm)."""
+    text = open(os.path.join(ROOT, "include", "lfs_io.h")).read()
+    declared = sorted(set(re.findall(r"LFS_IO_API\s+[\w\s\*]+?\b(lfs_\w+)\s*\(", text)))
+    assert len(declared) >= 25 and "lfs_colmap_open" in declared and "lfs_ply_write_splat" in declared and "lfs_image_load_rgb8" in declared
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import loader
+    raw = ctypes.CDLL(loader.io_library_path())
+    for s in declared:
+        assert hasattr(raw, s), f"liblfs_io.so does not export {s}"
+    assert sorted(loader.IO_EXPORTS) == declared
+    loader.io_library().lfs_io_version.restype = ctypes.c_char_p
+    assert loader.io_library().lfs_io_version().decode().startswith("lfs_io")
+    # nothing but libc / libstdc++ / zlib underneath: no HIP, no torch
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", loader.io_library_path()], capture_output=True, text=True).stdout
+    assert "amdhip" not in needed and "torch" not in needed and "libz" in needed
