@@ -295,6 +295,14 @@ LFS_API int lfs_photometric_loss_chw_fwd_bwd(uint32_t H, uint32_t W, const float
                                              float weight, float* v_render_chw, float* loss, void* workspace, size_t workspace_bytes,
                                              lfs_stream_t stream);
 
+/* general forms of the two losses: render / v_render in either layout (render_is_chw), clamped on the way in or not (an image that went through the
+ * bilateral grid reaches the loss un-clamped, trainer.cpp:662-676) */
+LFS_API int lfs_photometric_loss_ex_fwd_bwd(uint32_t H, uint32_t W, const float* render, uint32_t render_is_chw, uint32_t clamp_render, const float* target_chw,
+                                            float lambda_dssim, float weight, float* v_render, float* loss, void* workspace, size_t workspace_bytes,
+                                            lfs_stream_t stream);
+LFS_API int lfs_mse_loss_ex_fwd_bwd(uint32_t H, uint32_t W, const float* render, uint32_t render_is_chw, uint32_t clamp_render, const float* target_chw, float weight,
+                                    float* v_render, float* loss, lfs_stream_t stream);
+
 /* ---- bilateral-grid appearance model (row 2 of §8f, BASELINE config 5): gs::bilateral_grid::slice_forward_cuda /
  *      slice_backward_cuda / tv_loss_forward_cuda / tv_loss_backward_cuda (include/kernels/bilateral_grid.cuh:12-33,
  *      src/training/kernels/bilateral_grid_{forward,backward,tv}.cu). grid [12,L,H,W]; image h x w (both >= 2), uniform

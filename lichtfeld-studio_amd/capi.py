@@ -80,7 +80,7 @@ EXPORTS = [
     "lfs_rasterize_workspace_bytes", "lfs_set_debug_flags", "lfs_rasterize_to_pixels_from_world_3dgs_fwd", "lfs_rasterize_to_pixels_from_world_3dgs_bwd", "lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared", "lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse",
     "lfs_sh_model_fwd", "lfs_sh_model_bwd", "lfs_sh_model_bwd_adam", "lfs_sh_model_fwd_views", "lfs_sh_model_bwd_views", "lfs_activations_fwd", "lfs_activations_bwd", "lfs_mse_loss_fwd_bwd", "lfs_mse_loss_chw_fwd_bwd",
     "lfs_fastgs_primitive_workspace_bytes", "lfs_fastgs_instance_workspace_bytes", "lfs_fastgs_preprocess", "lfs_fastgs_wait_n_instances", "lfs_fastgs_render", "lfs_fastgs_backward", "lfs_fastgs_backward_adam",
-    "lfs_fastgs_set_debug_flags", "lfs_fused_ssim_fwd", "lfs_fused_ssim_bwd", "lfs_photometric_loss_workspace_bytes", "lfs_photometric_loss_fwd_bwd", "lfs_photometric_loss_chw_fwd_bwd",
+    "lfs_fastgs_set_debug_flags", "lfs_fused_ssim_fwd", "lfs_fused_ssim_bwd", "lfs_photometric_loss_workspace_bytes", "lfs_photometric_loss_fwd_bwd", "lfs_photometric_loss_chw_fwd_bwd", "lfs_photometric_loss_ex_fwd_bwd", "lfs_mse_loss_ex_fwd_bwd",
     "lfs_bilateral_slice_fwd", "lfs_bilateral_slice_bwd", "lfs_bilateral_tv_loss_fwd", "lfs_bilateral_tv_loss_bwd", "lfs_image_u8_to_chw_f32", "lfs_mean_neighbor_distances",
     "lfs_quats_to_rotmats", "lfs_relocation", "lfs_add_noise", "lfs_adam_step", "lfs_adam_step_multi", "lfs_version", "lfs_profile_enable", "lfs_profile_filter", "lfs_profile_collect",
 ]

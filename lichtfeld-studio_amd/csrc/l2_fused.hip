@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) activations_bwd_kernel(
 template <bool CHW>
 __global__ void __launch_bounds__(256) mse_loss_kernel(
     const uint32_t H, const uint32_t W, const float* __restrict__ render, const float* __restrict__ target,
-    const float scale, float* __restrict__ v_render, float* __restrict__ loss) {
+    const float scale, float* __restrict__ v_render, float* __restrict__ loss, const bool clamp = !CHW) {
     const uint32_t P = H * W;
     float acc = 0.f;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
@@ -73,9 +73,9 @@ __global__ void __launch_bounds__(256) mse_loss_kernel(
         for (int c = 0; c < 3; ++c) {
             const size_t ri = CHW ? size_t(c) * P + p : 3 * size_t(p) + c;
             const float x = render[ri];
-            const float d = (CHW ? x : fminf(fmaxf(x, 0.f), 1.f)) - target[size_t(c) * P + p];
+            const float d = (clamp ? fminf(fmaxf(x, 0.f), 1.f) : x) - target[size_t(c) * P + p];
             acc += d * d;
-            v_render[ri] = (CHW || (x >= 0.f && x <= 1.f)) ? 2.f * d * scale : 0.f;
+            v_render[ri] = (!clamp || (x >= 0.f && x <= 1.f)) ? 2.f * d * scale : 0.f;
         }
     }
 #pragma unroll
@@ -134,5 +134,19 @@ extern "C" int lfs_mse_loss_chw_fwd_bwd(uint32_t H, uint32_t W, const float* ren
     const uint32_t P = H * W;
     const uint32_t blocks = (P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048;
     hipLaunchKernelGGL(lfs::mse_loss_kernel<true>, dim3(blocks), dim3(256), 0, s, H, W, render_chw, target_chw, weight / float(3u * P), v_render_chw, loss);
+    return (int)hipGetLastError();
+}
+
+// general form (see lfs_photometric_loss_ex_fwd_bwd)
+extern "C" int lfs_mse_loss_ex_fwd_bwd(uint32_t H, uint32_t W, const float* render, uint32_t render_is_chw, uint32_t clamp_render, const float* target_chw, float weight,
+                                       float* v_render, float* loss, lfs_stream_t stream) {
+    if (H == 0 || W == 0) return LFS_OK;
+    if (!render || !target_chw || !v_render || !loss) return LFS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    lfs::ProfScope prof("mse_loss", s);
+    const uint32_t P = H * W;
+    const uint32_t blocks = (P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048;
+    if (render_is_chw) hipLaunchKernelGGL(lfs::mse_loss_kernel<true>, dim3(blocks), dim3(256), 0, s, H, W, render, target_chw, weight / float(3u * P), v_render, loss, clamp_render != 0);
+    else hipLaunchKernelGGL(lfs::mse_loss_kernel<false>, dim3(blocks), dim3(256), 0, s, H, W, render, target_chw, weight / float(3u * P), v_render, loss, clamp_render != 0);
     return (int)hipGetLastError();
 }

@@ -25,16 +25,17 @@ __constant__ float c_gauss[11] = {0.001028380123898387f, 0.0075987582094967365f,
                                   0.036000773310661316f, 0.0075987582094967365f, 0.001028380123898387f};
 
 struct SsimImg {
-    const float* p; int hwc_clamp; // 0: [B,CH,H,W] as is; 1: rasterizer output, values clamped to [0,1] on the way in:
-    int chw;                       //    [B,H,W,CH] (3DGUT rasterizer) or, with chw != 0, [B,CH,H,W] and NOT clamped (fastgs
-};                                 //    rasterizer: fast_rasterizer.cpp:63 hands the image to the loss as is)
+    const float* p; int hwc_clamp; // 0: [B,CH,H,W] as is; 1: a rasterizer output handed to the fused loss:
+    int chw;                       //    layout [B,H,W,CH] (3DGUT rasterizer) or, with chw != 0, [B,CH,H,W] (fastgs rasterizer),
+    int clamp;                     //    clamped to [0,1] on the way in (and the gradient masked) when clamp != 0
+};
 LFS_DI size_t ssim_index(const SsimImg& im, int b, int c, int y, int x, int CH, int H, int W) {
     return (im.hwc_clamp && !im.chw) ? ((size_t(b) * H + y) * W + x) * CH + c : ((size_t(b) * CH + c) * H + y) * W + x;
 }
 LFS_DI float ssim_fetch(const SsimImg& im, int b, int c, int y, int x, int CH, int H, int W) {
     if (x < 0 || x >= W || y < 0 || y >= H) return 0.f; // zero padding
     const float v = im.p[ssim_index(im, b, c, y, x, CH, H, W)];
-    return (im.hwc_clamp && !im.chw) ? fminf(fmaxf(v, 0.f), 1.f) : v;
+    return (im.hwc_clamp && im.clamp) ? fminf(fmaxf(v, 0.f), 1.f) : v;
 }
 
 struct SsimFwdArgs {
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(const SsimBwdArgs a) {
             if (a.img1.hwc_clamp) {
                 const size_t gi = ssim_index(a.img1, b, c, py, px, a.CH, a.H, a.W);
                 const float raw = a.img1.p[gi];
-                const bool clamped = !a.img1.chw;
+                const bool clamped = a.img1.clamp != 0;
                 const float p1 = clamped ? fminf(fmaxf(raw, 0.f), 1.f) : raw;
                 float g = s0 + (2.f * p1) * s1 + p2 * s2;
                 const float diff = p1 - p2;
@@ -221,7 +222,7 @@ extern "C" int lfs_fused_ssim_fwd(uint32_t B, uint32_t CH, uint32_t H, uint32_t 
     if ((dm_dmu1 != nullptr) != (dm_dsigma1_sq != nullptr) || (dm_dmu1 != nullptr) != (dm_dsigma12 != nullptr)) return LFS_E_INVALID;
     SsimFwdArgs a{};
     a.H = int(H); a.W = int(W); a.CH = int(CH); a.C1 = C1; a.C2 = C2;
-    a.img1 = SsimImg{img1, 0, 0}; a.img2 = img2; a.ssim_map = ssim_map;
+    a.img1 = SsimImg{img1, 0, 0, 0}; a.img2 = img2; a.ssim_map = ssim_map;
     a.dm_dmu1 = dm_dmu1; a.dm_dsigma1_sq = dm_dsigma1_sq; a.dm_dsigma12 = dm_dsigma12;
     hipStream_t s = (hipStream_t)stream;
     lfs::ProfScope prof("ssim_fwd", s);
@@ -237,7 +238,7 @@ extern "C" int lfs_fused_ssim_bwd(uint32_t B, uint32_t CH, uint32_t H, uint32_t 
     if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) return LFS_E_INVALID;
     SsimBwdArgs a{};
     a.H = int(H); a.W = int(W); a.CH = int(CH);
-    a.img1 = SsimImg{img1, 0, 0}; a.img2 = img2; a.dL_dmap = dL_dmap;
+    a.img1 = SsimImg{img1, 0, 0, 0}; a.img2 = img2; a.dL_dmap = dL_dmap;
     a.dm_dmu1 = dm_dmu1; a.dm_dsigma1_sq = dm_dsigma1_sq; a.dm_dsigma12 = dm_dsigma12; a.dL_dimg1 = dL_dimg1;
     hipStream_t s = (hipStream_t)stream;
     lfs::ProfScope prof("ssim_bwd", s);
@@ -249,7 +250,7 @@ extern "C" size_t lfs_photometric_loss_workspace_bytes(uint32_t H, uint32_t W) {
 
 // *loss += weight * ((1 - lambda) * mean|clamp(render) - target| + lambda * (1 - mean_valid SSIM(clamp(render), target)));
 // v_render = d(that)/d(render). render / v_render HWC [H,W,3] (un-clamped rasterizer output), target CHW [3,H,W].
-static int photometric_loss(uint32_t H, uint32_t W, const float* render_hwc, int render_is_chw, const float* target_chw, float lambda_dssim,
+static int photometric_loss(uint32_t H, uint32_t W, const float* render_hwc, int render_is_chw, int clamp, const float* target_chw, float lambda_dssim,
                             float weight, float* v_render_hwc, float* loss, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
     if (H == 0 || W == 0) return LFS_OK;
     if (!render_hwc || !target_chw || !v_render_hwc || !loss || !workspace) return LFS_E_INVALID;
@@ -262,7 +263,7 @@ static int photometric_loss(uint32_t H, uint32_t W, const float* render_hwc, int
     const size_t plane = size_t(CH) * H * W;
     SsimFwdArgs f{};
     f.H = int(H); f.W = int(W); f.CH = CH; f.C1 = 0.01f * 0.01f; f.C2 = 0.03f * 0.03f;
-    f.img1 = SsimImg{render_hwc, 1, render_is_chw}; f.img2 = target_chw; f.ssim_map = nullptr;
+    f.img1 = SsimImg{render_hwc, 1, render_is_chw, clamp}; f.img2 = target_chw; f.ssim_map = nullptr;
     f.dm_dmu1 = maps; f.dm_dsigma1_sq = maps + plane; f.dm_dsigma12 = maps + 2 * plane;
     f.fused = 1;
     // d loss / d ssim_map inside the crop. Reference quirk kept: when the image is too small to crop (H or W <= 10) the
@@ -275,7 +276,7 @@ static int photometric_loss(uint32_t H, uint32_t W, const float* render_hwc, int
     hipLaunchKernelGGL(ssim_fwd_kernel, ssim_grid(1, int(H), int(W)), dim3(256), 0, s, f);
     SsimBwdArgs b{};
     b.H = int(H); b.W = int(W); b.CH = CH;
-    b.img1 = SsimImg{render_hwc, 1, render_is_chw}; b.img2 = target_chw; b.dL_dmap = nullptr;
+    b.img1 = SsimImg{render_hwc, 1, render_is_chw, clamp}; b.img2 = target_chw; b.dL_dmap = nullptr;
     b.dm_dmu1 = f.dm_dmu1; b.dm_dsigma1_sq = f.dm_dsigma1_sq; b.dm_dsigma12 = f.dm_dsigma12; b.dL_dimg1 = v_render_hwc;
     b.g_l1 = f.w_l1;
     hipLaunchKernelGGL(ssim_bwd_kernel, ssim_grid(1, int(H), int(W)), dim3(256), 0, s, b);
@@ -285,12 +286,20 @@ static int photometric_loss(uint32_t H, uint32_t W, const float* render_hwc, int
 extern "C" int lfs_photometric_loss_fwd_bwd(uint32_t H, uint32_t W, const float* render_hwc, const float* target_chw, float lambda_dssim,
                                             float weight, float* v_render_hwc, float* loss, void* workspace, size_t workspace_bytes,
                                             lfs_stream_t stream) {
-    return photometric_loss(H, W, render_hwc, 0, target_chw, lambda_dssim, weight, v_render_hwc, loss, workspace, workspace_bytes, stream);
+    return photometric_loss(H, W, render_hwc, 0, 1, target_chw, lambda_dssim, weight, v_render_hwc, loss, workspace, workspace_bytes, stream);
 }
 
 // the same loss for the fastgs rasterizer's CHW image (trainer.cpp:656-695: fast_rasterize -> compute_photometric_loss)
 extern "C" int lfs_photometric_loss_chw_fwd_bwd(uint32_t H, uint32_t W, const float* render_chw, const float* target_chw, float lambda_dssim,
                                                 float weight, float* v_render_chw, float* loss, void* workspace, size_t workspace_bytes,
                                                 lfs_stream_t stream) {
-    return photometric_loss(H, W, render_chw, 1, target_chw, lambda_dssim, weight, v_render_chw, loss, workspace, workspace_bytes, stream);
+    return photometric_loss(H, W, render_chw, 1, 0, target_chw, lambda_dssim, weight, v_render_chw, loss, workspace, workspace_bytes, stream);
+}
+
+// general form: any of the two layouts, with or without the clamp (an image that went through the bilateral grid reaches the loss un-clamped
+// in either layout, trainer.cpp:662-676)
+extern "C" int lfs_photometric_loss_ex_fwd_bwd(uint32_t H, uint32_t W, const float* render, uint32_t render_is_chw, uint32_t clamp_render, const float* target_chw,
+                                               float lambda_dssim, float weight, float* v_render, float* loss, void* workspace, size_t workspace_bytes,
+                                               lfs_stream_t stream) {
+    return photometric_loss(H, W, render, render_is_chw ? 1 : 0, clamp_render ? 1 : 0, target_chw, lambda_dssim, weight, v_render, loss, workspace, workspace_bytes, stream);
 }

@@ -120,7 +120,7 @@ class FusedStepOutput:
 
 def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
                         grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool, loss: str = "mse",
-                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None, adam_shN: Optional[dict] = None, adam_shard: Optional[dict] = None) -> FusedStepOutput:
+                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None, adam_shN: Optional[dict] = None, adam_shard: Optional[dict] = None, bilateral=None, image_idx: int = 0) -> FusedStepOutput:
     """One view: forward, loss against `target_chw` ("mse": the rasterizer-only metric of SURVEY.md §8d; "l1_ssim": the reference's
     photometric loss, trainer.cpp:115-128), backward. `grads` = six tensors shaped like model.parameters()
     (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
@@ -128,7 +128,9 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
     With `sh_exchange` (dist.ShExchange; multi-GPU) model.shN / grads[2] hold only this rank's rows and the SH stages run on the
     owners: `viewmats_all[j]` is the view matrix rank j renders in this call (every rank calls this the same number of times).
     With `adam_shN` (FusedAdam.prepare_inline; one view per step on one rank) grads[2] is not written: shN is updated in place;
-    `adam_shard` is the same for the owner's rows under `sh_exchange` (one view per rank and step)."""
+    `adam_shard` is the same for the owner's rows under `sh_exchange` (one view per rank and step).
+    `bilateral` (bilateral_grid.BilateralGrid): the rendered image goes through grid `image_idx` before the loss (trainer.cpp:662-664); the grid's
+    gradient is accumulated into its .grad."""
     assert camera.camera_model_type == CameraModelType.PINHOLE and camera.radial_distortion is None and camera.tangential_distortion is None, \
         "the fused path covers the trainer's undistorted pinhole cameras; use rasterizer.rasterize for the rest"
     W, H = int(camera.image_width), int(camera.image_height)
@@ -158,8 +160,13 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         fwd_args = (means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, None, W, H, tile, viewmat, None, Kmat,
                     CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None, offsets, flatten_ids)
         render, alpha, last_ids, ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(*fwd_args, own_workspace=True)
-        fuse_mse = loss == "mse" and FUSE_MSE_INTO_BACKWARD and flatten_ids.shape[0] > 0
-        if fuse_mse:
+        fuse_mse = loss == "mse" and FUSE_MSE_INTO_BACKWARD and flatten_ids.shape[0] > 0 and bilateral is None
+        if bilateral is not None:    # clamp (rasterizer.cpp:399 / bilateral_grid.cpp:115) -> slice -> loss on the un-clamped result -> slice backward
+            from .losses import loss_fwd_bwd
+            shown = bilateral.apply_fused(render[0], image_idx, chw=False)
+            v_shown = loss_fwd_bwd(loss, shown, target_chw, weight, loss_acc, chw=False, clamp=False, lambda_dssim=lambda_dssim)
+            v_render = bilateral.apply_fused_backward(render[0], image_idx, v_shown, chw=False).unsqueeze(0)
+        elif fuse_mse:
             v_render = None          # derived inside the rasterizer backward from `render` and the target
         elif loss == "mse":
             v_render = mse_loss_fwd_bwd(render, target_chw, weight, loss_acc)

@@ -129,3 +129,27 @@ def photometric_loss_chw_fwd_bwd(render_chw: torch.Tensor, target_chw: torch.Ten
     check(lib.lfs_photometric_loss_chw_fwd_bwd(C.c_uint32(H), C.c_uint32(W), ptr(render_chw), ptr(target_chw), C.c_float(lambda_dssim), C.c_float(weight),
                                                ptr(v), ptr(loss_acc), ptr(ws), C.c_size_t(ws.numel()), stream()), "photometric_loss_chw_fwd_bwd")
     return v
+
+
+def loss_fwd_bwd(kind: str, render: torch.Tensor, target_chw: torch.Tensor, weight: float, loss_acc: torch.Tensor, chw: bool, clamp: bool,
+                 lambda_dssim: float = 0.2) -> torch.Tensor:
+    """General fused loss: kind "mse" | "l1_ssim"; render [H,W,3] (chw False) or [3,H,W]; clamp = clamp(render, 0, 1) first (gradient masked).
+    loss_acc += weight * loss; returns dL/d(render) in the render's layout."""
+    target_chw = target_chw.contiguous()
+    render = render.contiguous()
+    require_gpu(render, target_chw, loss_acc)
+    H, W = (render.shape[-2], render.shape[-1]) if chw else (render.shape[-3], render.shape[-2])
+    assert tuple(target_chw.shape) == (3, H, W) and render.shape[0 if chw else -1] == 3, (render.shape, target_chw.shape)
+    lib = load_library()
+    v = torch.empty_like(render)
+    if kind == "mse":
+        check(lib.lfs_mse_loss_ex_fwd_bwd(C.c_uint32(H), C.c_uint32(W), ptr(render), C.c_uint32(int(chw)), C.c_uint32(int(clamp)), ptr(target_chw), C.c_float(weight),
+                                          ptr(v), ptr(loss_acc), stream()), "mse_loss_ex_fwd_bwd")
+    elif kind == "l1_ssim":
+        ws = workspace(lib.lfs_photometric_loss_workspace_bytes(C.c_uint32(H), C.c_uint32(W)), render.device, "photometric")
+        check(lib.lfs_photometric_loss_ex_fwd_bwd(C.c_uint32(H), C.c_uint32(W), ptr(render), C.c_uint32(int(chw)), C.c_uint32(int(clamp)), ptr(target_chw),
+                                                  C.c_float(lambda_dssim), C.c_float(weight), ptr(v), ptr(loss_acc), ptr(ws), C.c_size_t(ws.numel()), stream()),
+              "photometric_loss_ex_fwd_bwd")
+    else:
+        raise ValueError(f"unknown loss {kind!r}")
+    return v

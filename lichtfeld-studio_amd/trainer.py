@@ -60,8 +60,8 @@ class GutTrainer:
         # appearance model of BASELINE config 5 (trainer.cpp:66-99: Adam(lr, eps 1e-15) + warm-up exponential schedule), fastgs path only
         self.bilateral, self.tv_loss_weight = None, tv_loss_weight
         if use_bilateral_grid:
-            if rasterizer != "fastgs":
-                raise ValueError("the bilateral grid is wired into the fastgs training step only")
+            if rasterizer == "gut" and not fused_l2:
+                raise ValueError("the bilateral grid is wired into the fused training steps (fastgs, or 3DGUT with fused_l2)")
             from .bilateral_grid import BilateralGrid
             from .fused_adam import WarmupExponentialLR
             gx, gy, gl = bilateral_grid_dims
@@ -147,18 +147,11 @@ class GutTrainer:
                     sg = torch.sigmoid(raw_opac)
                     self.bucket.views[5].add_((sg * (1 - sg)).view_as(self.bucket.views[5]), alpha=self.opacity_reg / self.world / raw_opac.numel())
                     self.loss_acc += self.opacity_reg / self.world * sg.mean()
-        if self.bilateral is not None and self.tv_loss_weight > 0:   # trainer.cpp:699-705
-            self.bilateral.tv_loss_fused(self.tv_loss_weight / self.world, self.loss_acc)
         self._last_radii = None
         self.bucket.all_reduce(skip_deferred=self.iteration <= 1000)
         for p, gv in zip(params, self.bucket.views):
             p.grad = gv
-        if self.bilateral is not None:
-            if self.world > 1:
-                lfs_dist.all_reduce_sum(self.bilateral.grids.grad)
-            self.bilateral_optimizer.step()
-            self.bilateral_optimizer.zero_grad(set_to_none=False)
-            self.bilateral_scheduler.step()
+        self._bilateral_step()
         if self.strategy is not None:
             if self.strategy_kind == "default":
                 if dens is not None and self.world > 1 and self.strategy.is_refining(self.iteration):
@@ -171,6 +164,18 @@ class GutTrainer:
             self.optimizer.step(self.iteration)
             self.scheduler.step()
         return self.loss_acc
+
+    def _bilateral_step(self) -> None:
+        """trainer.cpp:699-705, :758-761: TV regulariser (1/world of it per rank), sum of the ranks' grid gradients, Adam + warm-up schedule."""
+        if self.bilateral is None:
+            return
+        if self.tv_loss_weight > 0:
+            self.bilateral.tv_loss_fused(self.tv_loss_weight / self.world, self.loss_acc)
+        if self.world > 1:
+            lfs_dist.all_reduce_sum(self.bilateral.grids.grad)
+        self.bilateral_optimizer.step()
+        self.bilateral_optimizer.zero_grad(set_to_none=False)
+        self.bilateral_scheduler.step()
 
     def _refine_with_full_shN(self, fn) -> None:
         """SH-sharded + a densification strategy: the strategy's index surgery (relocation, growth, pruning) addresses Gaussians globally, so for a
@@ -245,10 +250,12 @@ class GutTrainer:
                                           # regularisers: once per step, and 1/world of them per rank (the all-reduce sums the ranks)
                                           scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
                                           opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0,
-                                          sh_exchange=self.sh_exchange, viewmats_all=vm_all, adam_shN=inline, adam_shard=inline_shard)
+                                          sh_exchange=self.sh_exchange, viewmats_all=vm_all, adam_shN=inline, adam_shard=inline_shard,
+                                          bilateral=self.bilateral, image_idx=v)
                 self.last_n_isects, self._last_radii = out.n_isects, out.radii
             # the deferred segment (shN) stays out of the all-reduce while Adam does not read it (iteration <= 1000) and, SH-sharded, always
             self.bucket.all_reduce(skip_deferred=self.iteration <= 1000 or self.sh_exchange is not None)
+            self._bilateral_step()
             for p, gv in zip(params, self.bucket.views):
                 p.grad = gv
             if self.strategy is not None:  # trainer.cpp:741-760: post_backward (may replace the parameter tensors) then step

@@ -123,3 +123,36 @@ def test_fused_photometric_loss_chw_matches_torch(lfs, H, W, lam):
     assert abs(float(loss) - float(lr)) < 2e-6
     assert float((v.cpu().double() - r.grad).abs().max()) < 1e-5 * float(r.grad.abs().max()) + 1e-12
     assert abs(float(losses.photometric_loss(render.to(DEV), target.to(DEV), lam)) * 0.5 - float(lr)) < 2e-6
+
+
+@pytest.mark.parametrize("kind", ["mse", "l1_ssim"])
+def test_general_loss_entry_points_cover_layout_and_clamp(lfs, kind):
+    """lfs_{mse,photometric}_loss_ex_fwd_bwd: the four (layout, clamp) combinations agree with the dedicated entry points where those exist and with
+    the torch fp64 reference everywhere (HWC without clamp = what the 3DGUT step needs after the bilateral grid)."""
+    from lichtfeld_studio_amd import fused, losses
+    from lichtfeld_studio_amd.fastgs import mse_loss_chw_fwd_bwd
+    g = torch.Generator().manual_seed(7)
+    H, W = 57, 83
+    hwc = (torch.rand(H, W, 3, generator=g) * 1.4 - 0.2).to(DEV)
+    target = torch.rand(3, H, W, generator=g).to(DEV)
+    chw = hwc.permute(2, 0, 1).contiguous()
+    for is_chw, clamp in ((False, True), (False, False), (True, True), (True, False)):
+        x = chw if is_chw else hwc
+        loss = torch.zeros(1, device=DEV)
+        v = losses.loss_fwd_bwd(kind, x, target, 0.5, loss, chw=is_chw, clamp=clamp, lambda_dssim=0.2)
+        r = x.double().cpu().requires_grad_(True)
+        img = (r if is_chw else r.permute(2, 0, 1))
+        img = torch.clamp(img, 0, 1) if clamp else img
+        t = target.double().cpu()
+        lr = 0.5 * (ref.photometric_loss(img[None], t[None], 0.2) if kind == "l1_ssim" else ((img - t) ** 2).mean())
+        lr.backward()
+        assert abs(float(loss) - float(lr)) < 2e-6, (is_chw, clamp)
+        assert float((v.cpu().double() - r.grad).abs().max()) < 1e-5 * float(r.grad.abs().max()) + 1e-12, (is_chw, clamp)
+        # the dedicated entry points are the same kernels
+        l2 = torch.zeros(1, device=DEV)
+        if (is_chw, clamp) == (False, True):
+            v2 = fused.mse_loss_fwd_bwd(x[None], target, 0.5, l2)[0] if kind == "mse" else losses.photometric_loss_fwd_bwd(x[None], target, 0.2, 0.5, l2)[0]
+            assert torch.equal(v, v2)
+        if (is_chw, clamp) == (True, False):
+            v2 = mse_loss_chw_fwd_bwd(x, target, 0.5, l2) if kind == "mse" else losses.photometric_loss_chw_fwd_bwd(x, target, 0.2, 0.5, l2)
+            assert torch.equal(v, v2)
