@@ -48,6 +48,10 @@ typedef struct lfs_colmap_scene lfs_colmap_scene;
  * base/sparse/0, base/sparse, base (filesystem_utils.hpp:26-69). images_folder "images_4" scales widths, heights and
  * intrinsics by 1/4 (colmap.cpp:265-283); if the first image exists its real size overrides the database's (:836-865). */
 LFS_IO_API int lfs_colmap_open(const char* base, const char* images_folder, int format, lfs_colmap_scene** scene);
+/* Blender / NeRF-synthetic transforms file (read_transforms_cameras_and_images, src/loader/formats/transforms.cpp:73-265): `path` is the json or a
+ * directory holding transforms_train.json / transforms.json. Views come back through the same accessors (PINHOLE, camera ids 0..n-1, scene
+ * centre = origin). */
+LFS_IO_API int lfs_transforms_open(const char* path, lfs_colmap_scene** scene);
 LFS_IO_API void lfs_colmap_close(lfs_colmap_scene* scene);
 LFS_IO_API uint64_t lfs_colmap_num_views(const lfs_colmap_scene* scene);
 LFS_IO_API int lfs_colmap_view_at(const lfs_colmap_scene* scene, uint64_t i, lfs_colmap_view* out);

@@ -683,6 +683,195 @@ void png_chunk(std::vector<unsigned char>& out, const char type[4], const unsign
 
 } // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Blender / NeRF-synthetic transforms.json (src/loader/formats/transforms.cpp:62-265)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// A small JSON reader (objects, arrays, numbers, strings, literals, // and /* */ comments: nlohmann::json::parse(.., ignore_comments = true))
+struct Json {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    double num = 0; bool b = false; std::string str;
+    std::vector<Json> arr; std::vector<std::pair<std::string, Json>> obj;
+    const Json* find(const std::string& k) const {
+        for (const auto& kv : obj) if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+    bool contains(const std::string& k) const { return kind == Obj && find(k) != nullptr; }
+    double number(const char* what) const { if (kind != Num) fail(LFS_IO_E_FORMAT, "transforms: '%s' is not a number", what); return num; }
+};
+class JsonParser {
+  public:
+    explicit JsonParser(const std::vector<char>& b) : p_(b.data()), end_(b.data() + b.size()) {}
+    Json parse() { Json j = value(); ws(); if (p_ != end_) fail(LFS_IO_E_FORMAT, "transforms: trailing characters after the JSON document"); return j; }
+  private:
+    const char* p_; const char* end_;
+    void ws() {
+        for (;;) {
+            while (p_ < end_ && std::isspace((unsigned char)*p_)) ++p_;
+            if (p_ + 1 < end_ && p_[0] == '/' && p_[1] == '/') { while (p_ < end_ && *p_ != '\n') ++p_; continue; }
+            if (p_ + 1 < end_ && p_[0] == '/' && p_[1] == '*') { p_ += 2; while (p_ + 1 < end_ && !(p_[0] == '*' && p_[1] == '/')) ++p_; p_ = p_ + 2 <= end_ ? p_ + 2 : end_; continue; }
+            return;
+        }
+    }
+    [[noreturn]] void bad(const char* what) { fail(LFS_IO_E_FORMAT, "transforms: JSON parse error (%s)", what); }
+    std::string string() {
+        ++p_; std::string out;
+        while (p_ < end_ && *p_ != '"') {
+            if (*p_ == '\\' && p_ + 1 < end_) {
+                ++p_;
+                switch (*p_) {
+                case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break; case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                case 'u': { if (p_ + 4 >= end_) bad("\\u"); unsigned cp = (unsigned)std::strtoul(std::string(p_ + 1, p_ + 5).c_str(), nullptr, 16); p_ += 4;
+                            if (cp < 0x80) out += (char)cp; else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 63)); }
+                            else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 63)); out += (char)(0x80 | (cp & 63)); } break; }
+                default: out += *p_;
+                }
+                ++p_;
+            } else out += *p_++;
+        }
+        if (p_ >= end_) bad("unterminated string");
+        ++p_;
+        return out;
+    }
+    Json value() {
+        ws();
+        if (p_ >= end_) bad("unexpected end");
+        Json j;
+        if (*p_ == '{') {
+            j.kind = Json::Obj; ++p_; ws();
+            if (p_ < end_ && *p_ == '}') { ++p_; return j; }
+            for (;;) {
+                ws(); if (p_ >= end_ || *p_ != '"') bad("object key");
+                std::string k = string(); ws();
+                if (p_ >= end_ || *p_ != ':') bad("':'");
+                ++p_;
+                j.obj.emplace_back(std::move(k), value()); ws();
+                if (p_ < end_ && *p_ == ',') { ++p_; continue; }
+                if (p_ < end_ && *p_ == '}') { ++p_; return j; }
+                bad("',' or '}'");
+            }
+        }
+        if (*p_ == '[') {
+            j.kind = Json::Arr; ++p_; ws();
+            if (p_ < end_ && *p_ == ']') { ++p_; return j; }
+            for (;;) {
+                j.arr.push_back(value()); ws();
+                if (p_ < end_ && *p_ == ',') { ++p_; continue; }
+                if (p_ < end_ && *p_ == ']') { ++p_; return j; }
+                bad("',' or ']'");
+            }
+        }
+        if (*p_ == '"') { j.kind = Json::Str; j.str = string(); return j; }
+        if (end_ - p_ >= 4 && !std::strncmp(p_, "true", 4)) { j.kind = Json::Bool; j.b = true; p_ += 4; return j; }
+        if (end_ - p_ >= 5 && !std::strncmp(p_, "false", 5)) { j.kind = Json::Bool; p_ += 5; return j; }
+        if (end_ - p_ >= 4 && !std::strncmp(p_, "null", 4)) { p_ += 4; return j; }
+        const std::string tmp(p_, std::min(end_, p_ + 64));
+        char* e = nullptr;
+        const double v = std::strtod(tmp.c_str(), &e);
+        if (e == tmp.c_str()) bad("value");
+        p_ += e - tmp.c_str();
+        j.kind = Json::Num; j.num = v;
+        return j;
+    }
+};
+
+fs::path transform_image_path(const fs::path& dir, const Json& frame) { // :62-71: Blender sets carry no extension: ".png" is tried
+    const Json* fp = frame.find("file_path");
+    if (!fp || fp->kind != Json::Str) fail(LFS_IO_E_FORMAT, "transforms: frame without file_path");
+    fs::path p = dir / fp->str;
+    const fs::path png = fs::path(p.string() + ".png");
+    return fs::exists(png) ? png : p;
+}
+
+// 4x4 inverse in double (the reference: torch::inverse = LAPACK in float32; a rigid matrix is well conditioned, results agree to ~1e-7)
+bool invert4(const double m[16], double inv[16]) {
+    double a[4][8];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = m[4 * r + c]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) return false;
+        if (piv != c) for (int k = 0; k < 8; ++k) std::swap(a[piv][k], a[c][k]);
+        const double d = a[c][c];
+        for (int k = 0; k < 8; ++k) a[c][k] /= d;
+        for (int r = 0; r < 4; ++r) if (r != c) { const double f = a[r][c]; if (f != 0.0) for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k]; }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) inv[4 * r + c] = a[r][4 + c];
+    return true;
+}
+
+void transforms_load(lfs_colmap_scene& sc, const fs::path& given) {
+    fs::path file = given;
+    if (fs::is_directory(given)) {
+        if (fs::is_regular_file(given / "transforms_train.json")) file = given / "transforms_train.json";
+        else if (fs::is_regular_file(given / "transforms.json")) file = given / "transforms.json";
+        else fail(LFS_IO_E_NOT_FOUND, "could not find transforms_train.json nor transforms.json in %s", given.string().c_str());
+    }
+    if (!fs::is_regular_file(file)) fail(LFS_IO_E_NOT_FOUND, "%s is not a valid file", file.string().c_str());
+    const fs::path dir = file.parent_path();
+    const Json t = JsonParser(slurp(file)).parse();
+    if (t.kind != Json::Obj) fail(LFS_IO_E_FORMAT, "transforms: the document is not an object");
+    const Json* frames = t.find("frames");
+    int w = -1, h = -1;
+    if (!t.contains("w") || !t.contains("h")) { // :101-121: size of the first image
+        if (!frames || frames->kind != Json::Arr || frames->arr.empty()) fail(LFS_IO_E_FORMAT, "Error while trying to read image dimensions: no frames");
+        int32_t iw = 0, ih = 0, ic = 0;
+        try { image_info_impl(transform_image_path(dir, frames->arr[0]), iw, ih, ic); }
+        catch (const IoError& e) { fail(e.code, "Error while trying to read image dimensions: %s", e.what()); }
+        w = iw; h = ih;
+    } else { w = (int)t.find("w")->number("w"); h = (int)t.find("h")->number("h"); }
+    auto focal = [](int res, float fov_rad) { return 0.5f * (float)res / std::tan(0.5f * fov_rad); }; // :30-32
+    float fl_x = -1.f, fl_y = -1.f;
+    if (t.contains("fl_x")) fl_x = (float)t.find("fl_x")->number("fl_x");
+    else if (t.contains("camera_angle_x")) fl_x = focal(w, (float)t.find("camera_angle_x")->number("camera_angle_x"));
+    if (t.contains("fl_y")) fl_y = (float)t.find("fl_y")->number("fl_y");
+    else if (t.contains("camera_angle_y")) fl_y = focal(h, (float)t.find("camera_angle_y")->number("camera_angle_y"));
+    else { if (w != h) fail(LFS_IO_E_FORMAT, "no camera_angle_y expected w!=h"); fl_y = fl_x; }
+    const float cx = t.contains("cx") ? (float)t.find("cx")->number("cx") : (float)(0.5 * w);
+    const float cy = t.contains("cy") ? (float)t.find("cy")->number("cy") : (float)(0.5 * h);
+    float dist[4] = {0, 0, 0, 0};
+    const char* dn[4] = {"k1", "k2", "p1", "p2"};
+    for (int i = 0; i < 4; ++i) if (t.contains(dn[i])) dist[i] = (float)t.find(dn[i])->number(dn[i]);
+    if (dist[0] > 0 || dist[1] > 0 || dist[2] > 0 || dist[3] > 0)
+        fail(LFS_IO_E_UNSUPPORTED, "GS don't support distortion for now: k1=%g, k2=%g, p1=%g, p2=%g", dist[0], dist[1], dist[2], dist[3]);
+    // fixMat = rotation about Y by float(pi) (createYRotationMatrix): cos = -1, sin = -8.742278e-08
+    const float ang = (float)M_PI, cs = std::cos(ang), sn = std::sin(ang);
+    const float fix[16] = {cs, 0, sn, 0, 0, 1, 0, 0, -sn, 0, cs, 0, 0, 0, 0, 1};
+    if (frames && frames->kind == Json::Arr) {
+        uint32_t counter = 0;
+        for (const Json& fr : frames->arr) {
+            const Json* tm = fr.find("transform_matrix");
+            if (!tm) fail(LFS_IO_E_FORMAT, "expected all frames to contain transform_matrix");
+            if (tm->kind != Json::Arr || tm->arr.size() != 4) fail(LFS_IO_E_FORMAT, "transform_matrix has the wrong dimensions");
+            double c2w[16];
+            for (int i = 0; i < 4; ++i) {
+                if (tm->arr[i].kind != Json::Arr || tm->arr[i].arr.size() < 4) fail(LFS_IO_E_FORMAT, "transform_matrix has the wrong dimensions");
+                for (int j = 0; j < 4; ++j) c2w[4 * i + j] = (double)(float)tm->arr[i].arr[j].number("transform_matrix");
+            }
+            for (int i = 0; i < 3; ++i) { c2w[4 * i + 1] = -c2w[4 * i + 1]; c2w[4 * i + 2] = -c2w[4 * i + 2]; } // OpenGL -> COLMAP axes (:219)
+            double inv[16];
+            if (!invert4(c2w, inv)) fail(LFS_IO_E_FORMAT, "transform_matrix is singular");
+            float w2c[16], m[16];
+            for (int i = 0; i < 16; ++i) w2c[i] = (float)inv[i];
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { float acc = 0.f; for (int k = 0; k < 4; ++k) acc += w2c[4 * r + k] * fix[4 * k + c]; m[4 * r + c] = acc; }
+            lfs_colmap_view v{};
+            v.camera_id = counter++; v.colmap_model = LFS_COLMAP_PINHOLE; v.camera_model_type = 0;
+            v.width = (uint64_t)w; v.height = (uint64_t)h;
+            v.focal_x = fl_x; v.focal_y = fl_y; v.center_x = cx; v.center_y = cy;
+            for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) v.R[3 * r + c] = m[4 * r + c]; v.T[r] = m[4 * r + 3]; }
+            v.n_params = 4; v.params[0] = fl_x; v.params[1] = fl_y; v.params[2] = cx; v.params[3] = cy;
+            const fs::path img = transform_image_path(dir, fr);
+            sc.views.push_back(v);
+            sc.paths.push_back(img.string());
+            sc.names.push_back(img.filename().string());
+        }
+    }
+    sc.center[0] = sc.center[1] = sc.center[2] = 0.f; // (:252: the scene centre of a transforms set is the origin)
+}
+
+} // namespace
+
 // =====================================================================================================================
 // C ABI
 // =====================================================================================================================
@@ -702,6 +891,15 @@ int lfs_colmap_open(const char* base, const char* images_folder, int format, lfs
         const auto images = txt ? images_txt(sparse_file(base, "images.txt")) : images_bin(sparse_file(base, "images.bin"));
         auto sc = std::make_unique<lfs_colmap_scene>();
         assemble(*sc, base, images_folder, cams, images);
+        *scene = sc.release();
+    });
+}
+int lfs_transforms_open(const char* path, lfs_colmap_scene** scene) {
+    return guarded([&] {
+        if (!path || !scene) fail(LFS_IO_E_INVALID, "lfs_transforms_open: bad arguments");
+        *scene = nullptr;
+        auto sc = std::make_unique<lfs_colmap_scene>();
+        transforms_load(*sc, path);
         *scene = sc.release();
     });
 }

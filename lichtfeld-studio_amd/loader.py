@@ -28,7 +28,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _IO = None
 
 IO_EXPORTS = [
-    "lfs_io_last_error", "lfs_io_version", "lfs_io_free", "lfs_colmap_open", "lfs_colmap_close", "lfs_colmap_num_views", "lfs_colmap_view_at",
+    "lfs_io_last_error", "lfs_io_version", "lfs_io_free", "lfs_colmap_open", "lfs_transforms_open", "lfs_colmap_close", "lfs_colmap_num_views", "lfs_colmap_view_at",
     "lfs_colmap_image_name", "lfs_colmap_image_path", "lfs_colmap_scene_center", "lfs_colmap_points_open", "lfs_point_cloud_size",
     "lfs_point_cloud_copy", "lfs_point_cloud_close", "lfs_ply_write_splat", "lfs_ply_open", "lfs_ply_num_vertices", "lfs_ply_num_properties",
     "lfs_ply_property_name", "lfs_ply_read", "lfs_ply_close", "lfs_image_info", "lfs_image_target_size", "lfs_image_load_rgb8",
@@ -111,10 +111,13 @@ class PointCloud:
     colors: np.ndarray              # [N,3] uint8
 
 
-def _read_colmap(base: str, images_folder: str, fmt: int) -> Tuple[List[CameraData], np.ndarray]:
+def _read_colmap(base: str, images_folder: Optional[str], fmt: int) -> Tuple[List[CameraData], np.ndarray]:
     lib = io_library()
     h = C.c_void_p()
-    _check(lib.lfs_colmap_open(os.fsencode(base), images_folder.encode(), C.c_int(fmt), C.byref(h)))
+    if images_folder is None:
+        _check(lib.lfs_transforms_open(os.fsencode(base), C.byref(h)))
+    else:
+        _check(lib.lfs_colmap_open(os.fsencode(base), images_folder.encode(), C.c_int(fmt), C.byref(h)))
     try:
         out = []
         v = _View()
@@ -137,6 +140,19 @@ def read_colmap_cameras_and_images(base: str, images_folder: str = "images") -> 
 
 def read_colmap_cameras_and_images_text(base: str, images_folder: str = "images") -> Tuple[List[CameraData], np.ndarray]:
     return _read_colmap(base, images_folder, 1)
+
+
+def read_transforms_cameras_and_images(path: str) -> Tuple[List[CameraData], np.ndarray]:
+    """Blender / NeRF-synthetic transforms.json (src/loader/formats/transforms.cpp:73-265)."""
+    return _read_colmap(path, None, 0)
+
+
+def generate_random_point_cloud() -> PointCloud:
+    """transforms.cpp:267-283: 10 000 points in [-1,1]^3 with random colours, torch CPU generator seeded with 8128 (so the same bits as the reference)."""
+    g = torch.Generator().manual_seed(8128)
+    positions = torch.rand((10000, 3), generator=g) * 2.0 - 1.0
+    colors = torch.randint(0, 256, (10000, 3), dtype=torch.uint8, generator=g)
+    return PointCloud(positions.numpy(), colors.numpy())
 
 
 def _read_points(base: str, fmt: int) -> PointCloud:

@@ -302,3 +302,43 @@ def ply_bytes(means, sh0, shN, opacity, scaling, rotation):
     names = ply_attribute_names(f_dc.shape[1], f_rest.shape[1])
     hdr = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % N + "".join(f"property float {n}\n" for n in names) + "end_header\n"
     return hdr.encode() + rows.tobytes()
+
+
+# ---- Blender / NeRF-synthetic transforms.json (src/loader/formats/transforms.cpp:73-265), with the reference's own torch float32 operations ----
+def read_transforms(path, first_image_size=None):
+    import json
+    import math
+    import re
+
+    import torch
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"(?m)//[^\n\"]*$", "", text)           # comments (nlohmann: ignore_comments = true)
+    t = json.loads(text)
+    if "w" in t and "h" in t:
+        w, h = int(t["w"]), int(t["h"])
+    else:
+        w, h = first_image_size
+    f32 = np.float32
+    focal = lambda res, fov: f32(0.5) * f32(res) / f32(math.tan(f32(0.5) * f32(fov)))
+    fl_x = f32(t["fl_x"]) if "fl_x" in t else focal(w, t["camera_angle_x"])
+    if "fl_y" in t:
+        fl_y = f32(t["fl_y"])
+    elif "camera_angle_y" in t:
+        fl_y = focal(h, t["camera_angle_y"])
+    else:
+        assert w == h
+        fl_y = fl_x
+    cx = f32(t["cx"]) if "cx" in t else f32(0.5 * w)
+    cy = f32(t["cy"]) if "cy" in t else f32(0.5 * h)
+    ang = f32(math.pi)
+    fix = torch.eye(4)
+    fix[0, 0] = float(np.cos(ang)); fix[0, 2] = float(np.sin(ang)); fix[2, 0] = -float(np.sin(ang)); fix[2, 2] = float(np.cos(ang))
+    out = []
+    for k, fr in enumerate(t.get("frames", [])):
+        c2w = torch.tensor(fr["transform_matrix"], dtype=torch.float32)
+        c2w[:3, 1:3] *= -1
+        w2c = torch.mm(torch.inverse(c2w), fix)
+        out.append(dict(camera_id=k, width=w, height=h, focal_x=fl_x, focal_y=fl_y, center_x=cx, center_y=cy, R=w2c[:3, :3].numpy().copy(),
+                        T=w2c[:3, 3].numpy().copy(), file_path=fr["file_path"]))
+    return out

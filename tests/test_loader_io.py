@@ -334,3 +334,66 @@ def test_native_jpeg_decoder_is_bit_identical_to_libjpeg_turbo(ld, tmp_path):
     rc, msg = _native_rgb8(ld, p)
     assert rc == -4 and "component" in msg
     assert ld.decode_rgb8(p).shape == (16, 16, 3)       # Pillow fallback
+
+
+def test_blender_transforms_loader_matches_reference_operations(ld, tmp_path):
+    """lfs_transforms_open (transforms.cpp:73-265) against the restatement that uses the reference's own torch float32 ops (inverse, mm): synthetic
+    NeRF-style set (camera_angle_x, extension-less file paths, comments), an instant-ngp style set (fl_x / fl_y / cx / cy / w / h), error behaviour."""
+    import json
+    import math
+    rng = np.random.default_rng(2)
+    base = tmp_path / "lego"
+    (base / "train").mkdir(parents=True)
+    frames = []
+    for i in range(7):
+        a, b = rng.uniform(0, 2 * math.pi), rng.uniform(-1, 1)
+        Rz = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]])
+        Rx = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+        m = np.eye(4)
+        m[:3, :3] = Rz @ Rx
+        m[:3, 3] = rng.uniform(-4, 4, 3)
+        frames.append({"file_path": f"./train/r_{i}", "rotation": 0.1, "transform_matrix": m.tolist()})
+        ld.write_png(str(base / "train" / f"r_{i}.png"), np.zeros((40, 40, 3), np.uint8))
+    text = "{\n  // NeRF synthetic\n  \"camera_angle_x\": 0.6911112070083618, /* fov */\n  \"frames\": " + json.dumps(frames) + "\n}\n"
+    (base / "transforms_train.json").write_text(text)
+    views, center = ld.read_transforms_cameras_and_images(str(base))
+    ref = oc.read_transforms(str(base / "transforms_train.json"), first_image_size=(40, 40))
+    assert len(views) == len(ref) == 7 and np.array_equal(center, np.zeros(3, np.float32))
+    for v, r in zip(views, ref):
+        assert (v.camera_id, v.width, v.height, v.camera_model_type) == (r["camera_id"], 40, 40, 0)
+        assert v.image_name == os.path.basename(r["file_path"]) + ".png" and os.path.exists(v.image_path)
+        assert v.focal_x == r["focal_x"] and v.focal_y == r["focal_y"] and v.center_x == r["center_x"] == 20.0
+        np.testing.assert_allclose(v.R, r["R"], rtol=0, atol=3e-7)
+        np.testing.assert_allclose(v.T, r["T"], rtol=0, atol=2e-6)
+        assert abs(np.linalg.det(v.R.astype(np.float64)) - 1) < 1e-5
+    # instant-ngp style: explicit intrinsics, file path of the json itself, images with extension that do not exist
+    ngp = {"w": 800, "h": 600, "fl_x": 700.5, "fl_y": 701.25, "cx": 399.5, "cy": 301.0, "k1": 0.0, "aabb_scale": 4,
+           "frames": [{"file_path": "images/a.jpg", "transform_matrix": frames[0]["transform_matrix"]}]}
+    p = tmp_path / "ngp.json"
+    p.write_text(json.dumps(ngp))
+    views, _ = ld.read_transforms_cameras_and_images(str(p))
+    assert (views[0].width, views[0].height, views[0].focal_x, views[0].focal_y, views[0].center_x, views[0].center_y) == (800, 600, 700.5, 701.25, 399.5, 301.0)
+    assert views[0].image_path == str(tmp_path / "images" / "a.jpg")
+    # errors
+    with pytest.raises(ld.LoaderError, match="could not find transforms_train.json nor transforms.json"):
+        ld.read_transforms_cameras_and_images(str(tmp_path))
+    ngp["k1"] = 0.1
+    p.write_text(json.dumps(ngp))
+    with pytest.raises(ld.LoaderError, match="GS don't support distortion"):
+        ld.read_transforms_cameras_and_images(str(p))
+    ngp["k1"] = 0.0
+    del ngp["fl_y"]
+    p.write_text(json.dumps(ngp))
+    with pytest.raises(ld.LoaderError, match="no camera_angle_y expected w!=h"):
+        ld.read_transforms_cameras_and_images(str(p))
+    ngp["frames"][0]["transform_matrix"] = [[1, 0, 0, 0]] * 3
+    ngp["fl_y"] = 1.0
+    p.write_text(json.dumps(ngp))
+    with pytest.raises(ld.LoaderError, match="transform_matrix has the wrong dimensions"):
+        ld.read_transforms_cameras_and_images(str(p))
+    p.write_text("{\"frames\": [")
+    with pytest.raises(ld.LoaderError, match="JSON parse error"):
+        ld.read_transforms_cameras_and_images(str(p))
+    pc = ld.generate_random_point_cloud()
+    assert pc.means.shape == (10000, 3) and pc.colors.dtype == np.uint8 and -1 <= pc.means.min() and pc.means.max() <= 1
+    assert np.array_equal(pc.means, ld.generate_random_point_cloud().means)       # seeded: every call (and the reference) sees the same cloud
