@@ -206,6 +206,12 @@ class GutTrainer:
         """[N,K-1,3] on every rank (all-gathers the owners' rows when SH-sharded): export, evaluation."""
         return self.model.shN.detach() if self.sh_exchange is None else self.sh_exchange.gather_rows(self.model.shN.detach())
 
+    def export_model(self) -> SplatModel:
+        """The complete model on this rank (SH-sharded: shN all-gathered; every rank must call it): what loader.save_ply / evaluate.evaluate take."""
+        m = self.model
+        out = SplatModel(m.means.detach(), m.sh0.detach(), self.full_shN(), m.raw_scales.detach(), m.raw_quats.detach(), m.raw_opacities.detach(), m.active_sh_degree)
+        return out
+
     def camera(self, view: int) -> Camera:
         sc = self.scene
         return Camera(sc.viewmats[view:view + 1].contiguous(), sc.Ks[view:view + 1].contiguous(), sc.width, sc.height)

@@ -37,6 +37,8 @@ def _worker(rank, world, port, sharded, q):
     losses = [float(tr.train_step([target])) for _ in range(STEPS)]
     params = [p.detach().cpu().numpy() for p in tr.model.parameters()]
     params[2] = tr.full_shN().cpu().numpy()
+    full = tr.export_model()
+    assert full.shN.shape[0] == full.means.shape[0] and np.array_equal(full.shN.cpu().numpy(), params[2])
     q.put((rank, params, losses, tuple(tr.model.shN.shape)))
     torch.distributed.destroy_process_group()
 
