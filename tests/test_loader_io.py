@@ -397,3 +397,15 @@ def test_blender_transforms_loader_matches_reference_operations(ld, tmp_path):
     pc = ld.generate_random_point_cloud()
     assert pc.means.shape == (10000, 3) and pc.colors.dtype == np.uint8 and -1 <= pc.means.min() and pc.means.max() <= 1
     assert np.array_equal(pc.means, ld.generate_random_point_cloud().means)       # seeded: every call (and the reference) sees the same cloud
+
+
+def test_native_jpeg_decoder_matches_committed_golden(ld):
+    """tests/golden/jpeg (made by tests/golden/make_jpeg_golden.py with Pillow / libjpeg-turbo): the native decoder reproduces the stored arrays bit for
+    bit - no Pillow needed at test time."""
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg")
+    expected = np.load(os.path.join(gdir, "expected_rgb.npz"))
+    assert len(expected.files) >= 8
+    for name in expected.files:
+        rc, got = _native_rgb8(ld, os.path.join(gdir, name + ".jpg"))
+        assert rc == 0, (name, got)
+        assert got.shape == expected[name].shape and np.array_equal(got, expected[name]), name
