@@ -43,38 +43,40 @@ def _worker(rank, world, port, sharded, q):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("sharded", [True, False])
-def test_two_rank_step_matches_single_process(lfs, sharded):
+@pytest.mark.parametrize("sharded,world", [(True, 2), (False, 2), (True, 4)])
+def test_multi_rank_step_matches_single_process(lfs, sharded, world):
     from lichtfeld_studio_amd import scenes
     from lichtfeld_studio_amd.trainer import GutTrainer
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + int(sharded)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, sharded, q)) for r in range(2)]
+    port = 33500 + (os.getpid() % 2000) + int(sharded) + 3 * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, sharded, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = sorted([q.get(timeout=600) for _ in range(2)], key=lambda x: x[0])
+    results = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     # single process, same global batch
     dev = torch.device("cuda:0")
     sc = _scene()
-    tr = GutTrainer(sc, dev, iterations=100, views_per_rank=2)
+    tr = GutTrainer(sc, dev, iterations=100, views_per_rank=world)
     tr.iteration = 1000
     target = scenes.target_image(sc.height, sc.width).to(dev) * 0.6
     ref_losses = [float(tr.train_step([target])) for _ in range(STEPS)]
     ref = [p.detach().cpu().numpy() for p in tr.model.parameters()]
-    (_, p0, l0, s0), (_, p1, l1, s1) = results
+    p0, l0 = results[0][1], results[0][2]
     N = sc.means.shape[0]
-    assert (s0[0], s1[0]) == ((3001, 3000) if sharded else (N, N))
-    for name, a, b, r in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], p0, p1, ref):
-        assert np.array_equal(a, b), f"{name}: ranks diverged"
+    S = (N + world - 1) // world
+    assert [r[3][0] for r in results] == ([min(S, N - j * S) for j in range(world)] if sharded else [N] * world)     # 6001 rows: 3001 + 3000, or 1501 x 3 + 1498
+    for name, a, r in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], p0, ref):
+        for other in results[1:]:
+            assert np.array_equal(a, other[1][["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"].index(name)]), f"{name}: ranks diverged"
         # Adam normalises the step: a gradient that differs in the last bits moves a parameter by the same lr - compare the update
         # (elements whose gradient is pure rounding noise may step the other way: allow 0.01 % of them)
         tol = 2e-3 * np.abs(r - _scene_param(sc, name)).max() + 1e-7
         assert (np.abs(a - r) > tol).mean() < 1e-4, (name, np.abs(a - r).max(), tol)
-    assert np.allclose(np.array(l0) + np.array(l1), ref_losses, rtol=1e-5)      # each rank reports its share of the loss
+    assert np.allclose(np.sum([r[2] for r in results], 0), ref_losses, rtol=1e-5)      # each rank reports its share of the loss
     assert float(np.abs(ref[2] - sc.shN.numpy()).max()) > 0                     # shN did train
 
 
