@@ -105,3 +105,33 @@ std::tuple<torch::Tensor, torch::Tensor> slice_backward_cuda(const torch::Tensor
 torch::Tensor tv_loss_forward_cuda(const torch::Tensor& grids);
 torch::Tensor tv_loss_backward_cuda(const torch::Tensor& grids, const torch::Tensor& grad_output);
 } // namespace gs::bilateral_grid
+
+// ---- the loaders behind libtorch types (src/loader/formats/colmap.hpp, transforms.hpp; CameraData of include/loader/...). ----
+// Thin adapters over liblfs_io.so (include/lfs_io.h): failures throw std::runtime_error with the reference's messages.
+#include <filesystem>
+#include <string>
+#include <vector>
+namespace gs::loader {
+struct CameraData {   // the fields read_colmap_cameras fills (colmap.cpp:645-830)
+    uint32_t _camera_ID = 0;
+    int _camera_model = 0;                 // COLMAP model id
+    int _camera_model_type = 0;            // gsplat::CameraModelType
+    uint64_t _width = 0, _height = 0;
+    float _focal_x = 0, _focal_y = 0, _center_x = 0, _center_y = 0;
+    torch::Tensor _R, _T, _radial_distortion, _tangential_distortion, _params;
+    std::string _image_name;
+    std::filesystem::path _image_path;
+};
+struct PointCloud { torch::Tensor means, colors; };   // float32 [N,3], uint8 [N,3] (core/point_cloud.hpp)
+std::tuple<std::vector<CameraData>, torch::Tensor> read_colmap_cameras_and_images(const std::filesystem::path& base, const std::string& images_folder = "images");
+std::tuple<std::vector<CameraData>, torch::Tensor> read_colmap_cameras_and_images_text(const std::filesystem::path& base, const std::string& images_folder = "images");
+std::tuple<std::vector<CameraData>, torch::Tensor> read_transforms_cameras_and_images(const std::filesystem::path& trans_path);
+PointCloud read_colmap_point_cloud(const std::filesystem::path& base);
+PointCloud read_colmap_point_cloud_text(const std::filesystem::path& base);
+// SplatData::save_ply's file (src/core/splat_data.cpp:113-169, 402-505): tensors of any device; sh0 [N,1,3] and shN [N,K,3] are written transposed
+// ([N,3,K] flattened) as there. load_ply (src/loader/formats/ply.cpp:186-640) returns the same six tensors on the CPU.
+struct SplatTensors { torch::Tensor means, sh0, shN, scaling, rotation, opacity; };
+void save_ply(const std::filesystem::path& path, const torch::Tensor& means, const torch::Tensor& sh0, const torch::Tensor& shN, const torch::Tensor& scaling,
+              const torch::Tensor& rotation, const torch::Tensor& opacity);
+SplatTensors load_ply(const std::filesystem::path& path);
+} // namespace gs::loader

@@ -104,8 +104,10 @@ def build_torch_ops(force: bool = False) -> str:
 
     import torch
     build()
+    build_io()
     srcs = [os.path.join(CSRC, "torch_ops.cpp"), os.path.join(CSRC, "torch_ops_pybind.cpp")]
-    deps = srcs + [os.path.join(HERE, "..", "include", "lfs_gsplat_torch.hpp"), os.path.join(HERE, "..", "include", "lfs_gsplat.h"), OUT]
+    deps = srcs + [os.path.join(HERE, "..", "include", "lfs_gsplat_torch.hpp"), os.path.join(HERE, "..", "include", "lfs_gsplat.h"),
+                   os.path.join(HERE, "..", "include", "lfs_io.h"), OUT, IO_OUT]
     if not force and os.path.exists(TORCH_OPS_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(TORCH_OPS_OUT) for d in deps):
         return TORCH_OPS_OUT
     tdir = os.path.dirname(torch.__file__)
@@ -115,7 +117,7 @@ def build_torch_ops(force: bool = False) -> str:
            f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include", "-I/opt/rocm/include", f"-I{pybind11.get_include()}",
            f"-I{sysconfig.get_paths()['include']}", *srcs,
            f"-L{tdir}/lib", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python",
-           f"-L{HERE}", "-llfs_gsplat", "-L/opt/rocm/lib", "-lamdhip64",
+           f"-L{HERE}", "-llfs_gsplat", "-llfs_io", "-L/opt/rocm/lib", "-lamdhip64",
            f"-Wl,-rpath,{tdir}/lib", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-o", TORCH_OPS_OUT]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -385,3 +385,107 @@ torch::Tensor gs::bilateral_grid::tv_loss_backward_cuda(const torch::Tensor& gri
                                        grad_output.item<float>(), 0, grad.data_ptr<float>(), cur_stream()), "bilateral_grid::tv_loss_backward_cuda");
     return grad;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// gs::loader (src/loader/formats/colmap.cpp:907-957, transforms.cpp:73-265) over liblfs_io.so
+// ---------------------------------------------------------------------------------------------------------
+#include "../../include/lfs_io.h"
+namespace {
+std::tuple<std::vector<gs::loader::CameraData>, torch::Tensor> views_to_torch(lfs_colmap_scene* sc) {
+    std::vector<gs::loader::CameraData> out;
+    const auto f32 = torch::TensorOptions().dtype(torch::kFloat32);
+    const uint64_t n = lfs_colmap_num_views(sc);
+    out.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        lfs_colmap_view v;
+        lfs_colmap_view_at(sc, i, &v);
+        gs::loader::CameraData c;
+        c._camera_ID = v.camera_id; c._camera_model = v.colmap_model; c._camera_model_type = v.camera_model_type;
+        c._width = v.width; c._height = v.height;
+        c._focal_x = v.focal_x; c._focal_y = v.focal_y; c._center_x = v.center_x; c._center_y = v.center_y;
+        c._R = torch::from_blob(v.R, {3, 3}, f32).clone();
+        c._T = torch::from_blob(v.T, {3}, f32).clone();
+        c._radial_distortion = torch::from_blob(v.radial, {v.n_radial}, f32).clone();
+        c._tangential_distortion = torch::from_blob(v.tangential, {v.n_tangential}, f32).clone();
+        c._params = torch::from_blob(v.params, {v.n_params}, f32).clone();
+        c._image_name = lfs_colmap_image_name(sc, i);
+        c._image_path = lfs_colmap_image_path(sc, i);
+        out.push_back(std::move(c));
+    }
+    float center[3];
+    lfs_colmap_scene_center(sc, center);
+    torch::Tensor ctr = torch::from_blob(center, {3}, f32).clone();
+    lfs_colmap_close(sc);
+    return {std::move(out), ctr};
+}
+std::tuple<std::vector<gs::loader::CameraData>, torch::Tensor> open_colmap(const std::filesystem::path& base, const std::string& folder, int format) {
+    lfs_colmap_scene* sc = nullptr;
+    if (lfs_colmap_open(base.string().c_str(), folder.c_str(), format, &sc) != LFS_IO_OK) throw std::runtime_error(lfs_io_last_error());
+    return views_to_torch(sc);
+}
+gs::loader::PointCloud open_points(const std::filesystem::path& base, int format) {
+    lfs_point_cloud* pc = nullptr;
+    if (lfs_colmap_points_open(base.string().c_str(), format, &pc) != LFS_IO_OK) throw std::runtime_error(lfs_io_last_error());
+    const int64_t n = (int64_t)lfs_point_cloud_size(pc);
+    gs::loader::PointCloud out{torch::empty({n, 3}, torch::kFloat32), torch::empty({n, 3}, torch::kUInt8)};
+    lfs_point_cloud_copy(pc, out.means.data_ptr<float>(), out.colors.data_ptr<uint8_t>());
+    lfs_point_cloud_close(pc);
+    return out;
+}
+} // namespace
+std::tuple<std::vector<gs::loader::CameraData>, torch::Tensor> gs::loader::read_colmap_cameras_and_images(const std::filesystem::path& base, const std::string& f) { return open_colmap(base, f, 0); }
+std::tuple<std::vector<gs::loader::CameraData>, torch::Tensor> gs::loader::read_colmap_cameras_and_images_text(const std::filesystem::path& base, const std::string& f) { return open_colmap(base, f, 1); }
+std::tuple<std::vector<gs::loader::CameraData>, torch::Tensor> gs::loader::read_transforms_cameras_and_images(const std::filesystem::path& trans_path) {
+    lfs_colmap_scene* sc = nullptr;
+    if (lfs_transforms_open(trans_path.string().c_str(), &sc) != LFS_IO_OK) throw std::runtime_error(lfs_io_last_error());
+    return views_to_torch(sc);
+}
+gs::loader::PointCloud gs::loader::read_colmap_point_cloud(const std::filesystem::path& base) { return open_points(base, 0); }
+gs::loader::PointCloud gs::loader::read_colmap_point_cloud_text(const std::filesystem::path& base) { return open_points(base, 1); }
+
+void gs::loader::save_ply(const std::filesystem::path& path, const torch::Tensor& means, const torch::Tensor& sh0, const torch::Tensor& shN, const torch::Tensor& scaling,
+                          const torch::Tensor& rotation, const torch::Tensor& opacity) {
+    auto host = [](const torch::Tensor& t) { return t.detach().to(torch::kCPU, torch::kFloat32).contiguous(); };
+    const int64_t N = means.size(0);
+    TORCH_CHECK(means.dim() == 2 && means.size(1) == 3 && sh0.size(0) == N && shN.size(0) == N && scaling.size(0) == N && rotation.size(0) == N && opacity.size(0) == N,
+                "save_ply: inconsistent shapes");
+    const torch::Tensor m = host(means), dc = host(sh0.transpose(1, 2).reshape({N, -1})), rest = host(shN.transpose(1, 2).reshape({N, -1})), sc = host(scaling), ro = host(torch::nn::functional::normalize(rotation, torch::nn::functional::NormalizeFuncOptions().dim(-1))),
+                        op = host(opacity.reshape({N}));
+    if (lfs_ply_write_splat(path.string().c_str(), (uint64_t)N, (uint32_t)dc.size(1), (uint32_t)rest.size(1), m.data_ptr<float>(), nullptr, dc.data_ptr<float>(),
+                            rest.size(1) ? rest.data_ptr<float>() : nullptr, op.data_ptr<float>(), sc.data_ptr<float>(), ro.data_ptr<float>()) != LFS_IO_OK)
+        throw std::runtime_error(lfs_io_last_error());
+}
+
+gs::loader::SplatTensors gs::loader::load_ply(const std::filesystem::path& path) {
+    lfs_ply* ply = nullptr;
+    if (lfs_ply_open(path.string().c_str(), &ply) != LFS_IO_OK) throw std::runtime_error(lfs_io_last_error());
+    const int64_t N = (int64_t)lfs_ply_num_vertices(ply), P = (int64_t)lfs_ply_num_properties(ply);
+    std::vector<std::string> names;
+    for (int64_t i = 0; i < P; ++i) names.emplace_back(lfs_ply_property_name(ply, (uint32_t)i));
+    torch::Tensor all = torch::empty({N, P}, torch::kFloat32);
+    const int rc = lfs_ply_read(ply, all.data_ptr<float>());
+    lfs_ply_close(ply);
+    if (rc != LFS_IO_OK) throw std::runtime_error(lfs_io_last_error());
+    auto columns = [&](const std::string& prefix, bool exact) {      // property columns "prefix" or "prefix<k>", k ascending
+        std::vector<std::pair<int, int64_t>> cols;
+        for (int64_t i = 0; i < P; ++i) {
+            if (exact) { if (names[i] == prefix) cols.push_back({0, i}); }
+            else if (names[i].rfind(prefix, 0) == 0) cols.push_back({std::stoi(names[i].substr(prefix.size())), i});
+        }
+        std::sort(cols.begin(), cols.end());
+        std::vector<int64_t> idx;
+        for (auto& c : cols) idx.push_back(c.second);
+        return all.index_select(1, torch::tensor(idx, torch::kLong));
+    };
+    gs::loader::SplatTensors out;
+    out.means = torch::cat({columns("x", true), columns("y", true), columns("z", true)}, 1);
+    if (out.means.size(1) != 3) throw std::runtime_error("Only binary PLY with position supported");
+    // missing columns become zeros, as ply.cpp does (no identity rotation is assumed there either)
+    const torch::Tensor dc = columns("f_dc_", false), rest = columns("f_rest_", false), sc = columns("scale_", false), ro = columns("rot_", false), op = columns("opacity", true);
+    out.sh0 = dc.size(1) ? dc.reshape({N, 3, -1}).transpose(1, 2).contiguous() : torch::zeros({N, 1, 3}, torch::kFloat32);
+    out.shN = rest.size(1) ? rest.reshape({N, 3, -1}).transpose(1, 2).contiguous() : torch::zeros({N, 0, 3}, torch::kFloat32);
+    out.scaling = sc.size(1) == 3 ? sc.contiguous() : torch::zeros({N, 3}, torch::kFloat32);
+    out.rotation = ro.size(1) == 4 ? ro.contiguous() : torch::zeros({N, 4}, torch::kFloat32);
+    out.opacity = op.size(1) == 1 ? op.reshape({N}).contiguous() : torch::zeros({N}, torch::kFloat32);
+    return out;
+}

@@ -70,4 +70,26 @@ PYBIND11_MODULE(_lfs_torch_ops, m) {
     m.def("bilateral_slice_backward", [](at::Tensor grid, at::Tensor rgb, at::Tensor go) { return gs::bilateral_grid::slice_backward_cuda(grid, rgb, go); });
     m.def("bilateral_tv_loss_forward", [](at::Tensor grids) { return gs::bilateral_grid::tv_loss_forward_cuda(grids); });
     m.def("bilateral_tv_loss_backward", [](at::Tensor grids, at::Tensor go) { return gs::bilateral_grid::tv_loss_backward_cuda(grids, go); });
+    // gs::loader adapters (host only)
+    auto cams_to_py = [](const std::tuple<std::vector<gs::loader::CameraData>, torch::Tensor>& r) {
+        py::list cams;
+        for (const auto& c : std::get<0>(r)) {
+            py::dict d;
+            d["camera_ID"] = c._camera_ID; d["camera_model"] = c._camera_model; d["camera_model_type"] = c._camera_model_type;
+            d["width"] = c._width; d["height"] = c._height; d["focal_x"] = c._focal_x; d["focal_y"] = c._focal_y; d["center_x"] = c._center_x; d["center_y"] = c._center_y;
+            d["R"] = c._R; d["T"] = c._T; d["radial_distortion"] = c._radial_distortion; d["tangential_distortion"] = c._tangential_distortion; d["params"] = c._params;
+            d["image_name"] = c._image_name; d["image_path"] = c._image_path.string();
+            cams.append(d);
+        }
+        return py::make_tuple(cams, std::get<1>(r));
+    };
+    m.def("read_colmap_cameras_and_images", [cams_to_py](const std::string& base, const std::string& folder) { return cams_to_py(gs::loader::read_colmap_cameras_and_images(base, folder)); });
+    m.def("read_colmap_cameras_and_images_text", [cams_to_py](const std::string& base, const std::string& folder) { return cams_to_py(gs::loader::read_colmap_cameras_and_images_text(base, folder)); });
+    m.def("read_transforms_cameras_and_images", [cams_to_py](const std::string& path) { return cams_to_py(gs::loader::read_transforms_cameras_and_images(path)); });
+    m.def("read_colmap_point_cloud", [](const std::string& base) { auto pc = gs::loader::read_colmap_point_cloud(base); return py::make_tuple(pc.means, pc.colors); });
+    m.def("read_colmap_point_cloud_text", [](const std::string& base) { auto pc = gs::loader::read_colmap_point_cloud_text(base); return py::make_tuple(pc.means, pc.colors); });
+    m.def("save_ply", [](const std::string& path, at::Tensor means, at::Tensor sh0, at::Tensor shN, at::Tensor scaling, at::Tensor rotation, at::Tensor opacity) {
+        gs::loader::save_ply(path, means, sh0, shN, scaling, rotation, opacity);
+    });
+    m.def("load_ply", [](const std::string& path) { auto s = gs::loader::load_ply(path); return py::make_tuple(s.means, s.sh0, s.shN, s.scaling, s.rotation, s.opacity); });
 }

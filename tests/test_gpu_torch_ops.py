@@ -22,7 +22,9 @@ def test_torch_ops_module_surface_and_cpu_rejection():
     for name in ["spherical_harmonics_fwd", "spherical_harmonics_bwd", "intersect_tile", "intersect_offset", "quats_to_rotmats", "relocation",
                  "add_noise", "projection_ut_3dgs_fused", "rasterize_to_pixels_from_world_3dgs_fwd", "rasterize_to_pixels_from_world_3dgs_bwd",
                  "adam_step_wrapper", "fastgs_forward_wrapper", "fastgs_backward_wrapper", "fusedssim", "fusedssim_backward",
-                 "bilateral_slice_forward", "bilateral_slice_backward", "bilateral_tv_loss_forward", "bilateral_tv_loss_backward"]:
+                 "bilateral_slice_forward", "bilateral_slice_backward", "bilateral_tv_loss_forward", "bilateral_tv_loss_backward",
+                 "read_colmap_cameras_and_images", "read_colmap_cameras_and_images_text", "read_transforms_cameras_and_images", "read_colmap_point_cloud",
+                 "read_colmap_point_cloud_text", "save_ply", "load_ply"]:
         assert hasattr(m, name)
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         m.quats_to_rotmats(torch.randn(3, 4))

@@ -409,3 +409,64 @@ def test_native_jpeg_decoder_matches_committed_golden(ld):
         rc, got = _native_rgb8(ld, os.path.join(gdir, name + ".jpg"))
         assert rc == 0, (name, got)
         assert got.shape == expected[name].shape and np.array_equal(got, expected[name]), name
+
+
+def test_libtorch_loader_adapters_equal_python_host_layer(ld, tmp_path):
+    """gs::loader::read_colmap_* / read_transforms_* of include/lfs_gsplat_torch.hpp (the signatures of src/loader/formats/colmap.hpp, transforms.hpp
+    with torch tensors in CameraData) return exactly what the Python host layer reads through the same C ABI; failures surface as exceptions with
+    the reference's message."""
+    import json
+    import torch
+    try:
+        from lichtfeld_studio_amd import _lfs_torch_ops as m
+    except ImportError:
+        pytest.skip("_lfs_torch_ops.so not built (python lichtfeld-studio_amd/build.py --torch-ops)")
+    rng = np.random.default_rng(3)
+    cams, images, xyz, rgb = _dataset(rng)
+    base = str(tmp_path / "scene")
+    _write(base, cams, images, xyz, rgb, txt=False)
+    _write(base, cams, images, xyz, rgb, txt=True)
+    for fn, ref in [(m.read_colmap_cameras_and_images, ld.read_colmap_cameras_and_images), (m.read_colmap_cameras_and_images_text, ld.read_colmap_cameras_and_images_text)]:
+        got, center = fn(base, "images")
+        views, ref_center = ref(base, "images")
+        assert len(got) == len(views) and center.dtype == torch.float32 and np.array_equal(center.numpy(), ref_center)
+        for g, v in zip(got, views):
+            assert (g["camera_ID"], g["camera_model"], g["camera_model_type"], g["width"], g["height"], g["image_name"], g["image_path"]) == \
+                   (v.camera_id, v.colmap_model, v.camera_model_type, v.width, v.height, v.image_name, v.image_path)
+            assert (np.float32(g["focal_x"]), np.float32(g["focal_y"]), np.float32(g["center_x"]), np.float32(g["center_y"])) == (v.focal_x, v.focal_y, v.center_x, v.center_y)
+            assert g["R"].shape == (3, 3) and np.array_equal(g["R"].numpy(), v.R) and np.array_equal(g["T"].numpy(), v.T)
+            assert np.array_equal(g["radial_distortion"].numpy(), v.radial_distortion) and np.array_equal(g["tangential_distortion"].numpy(), v.tangential_distortion)
+            assert np.array_equal(g["params"].numpy(), v.params)
+    for fn in (m.read_colmap_point_cloud, m.read_colmap_point_cloud_text):
+        means, colors = fn(base)
+        assert means.dtype == torch.float32 and colors.dtype == torch.uint8
+        assert np.array_equal(means.numpy(), xyz.astype(np.float32)) and np.array_equal(colors.numpy(), rgb.astype(np.uint8))
+    frame = {"file_path": "images/a.jpg", "transform_matrix": [[1, 0, 0, 1], [0, 1, 0, 2], [0, 0, 1, 3], [0, 0, 0, 1]]}
+    p = tmp_path / "ngp.json"
+    p.write_text(json.dumps({"w": 80, "h": 60, "fl_x": 70.5, "fl_y": 71.25, "cx": 39.5, "cy": 31.0, "frames": [frame]}))
+    got, center = m.read_transforms_cameras_and_images(str(p))
+    views, _ = ld.read_transforms_cameras_and_images(str(p))
+    assert len(got) == 1 and np.array_equal(got[0]["R"].numpy(), views[0].R) and np.array_equal(got[0]["T"].numpy(), views[0].T)
+    assert got[0]["width"] == 80 and got[0]["focal_y"] == 71.25 and not center.any()
+    with pytest.raises(RuntimeError, match="could not find transforms_train.json nor transforms.json"):
+        m.read_transforms_cameras_and_images(str(tmp_path / "scene"))
+    with pytest.raises(RuntimeError):
+        m.read_colmap_cameras_and_images(str(tmp_path / "nothing"), "images")
+    # splat PLY: the C++ adapter writes the same bytes as the Python host layer and reads them back
+    from lichtfeld_studio_amd.rasterizer import SplatModel
+    N, K = 37, 16
+    t = dict(means=torch.randn(N, 3), sh0=torch.randn(N, 1, 3), shN=torch.randn(N, K - 1, 3), scales=torch.randn(N, 3), quats=torch.randn(N, 4) * 2, opac=torch.randn(N))
+    a, b = str(tmp_path / "cpp.ply"), str(tmp_path / "py.ply")
+    m.save_ply(a, t["means"], t["sh0"], t["shN"], t["scales"], t["quats"], t["opac"].unsqueeze(1))   # [N,1] opacity, as SplatData holds it
+    ld.save_ply(SplatModel(t["means"], t["sh0"], t["shN"], t["scales"], t["quats"], t["opac"], 3), b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    back = m.load_ply(a)
+    ref = ld.load_ply(b, device="cpu")
+    for x, y in zip(back, ref.parameters()):
+        assert x.shape == y.shape and torch.equal(x, y.detach())
+    open(a, "wb").write(b"ply\nformat binary_little_endian 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\nend_header\n" + bytes(12))
+    back = m.load_ply(a)
+    assert back[1].shape == (1, 1, 3) and back[2].shape == (1, 0, 3) and back[4].shape == (1, 4) and not back[4].any() and back[5].shape == (1,)
+    with pytest.raises(RuntimeError, match="No end_header"):
+        open(a, "wb").write(b"ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty float x\n" + b" " * 8)
+        m.load_ply(a)
