@@ -39,6 +39,7 @@ struct Huff {
         for (int l = 1; l <= 16; ++l) {
             valptr[l] = k; mincode[l] = code;
             k += bits[l]; code += bits[l];
+            if (code > (1 << l)) throw Corrupt("JPEG: over-subscribed Huffman table"); // more codes of length l than the prefix tree has room for
             maxcode[l] = bits[l] ? code - 1 : -1;
             code <<= 1;
         }
@@ -181,7 +182,8 @@ struct Decoder {
     void block_baseline(BitReader& br, Component& c, int16_t* blk) {
         const Huff& hd = dc[c.td]; const Huff& ha = ac[c.ta];
         const int s = br.decode(hd);
-        c.dc_pred += br.receive_extend(s);
+        if (s > 16) throw Corrupt("JPEG: bad DC difference category");
+        c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)br.receive_extend(s)); // wraps on corrupt streams instead of overflowing
         blk[0] = (int16_t)c.dc_pred;
         for (int k = 1; k < 64;) {
             const int rs = br.decode(ha), r = rs >> 4, ss = rs & 15;
@@ -191,8 +193,9 @@ struct Decoder {
     }
     void block_dc_first(BitReader& br, Component& c, int16_t* blk, int al) {
         const int s = br.decode(dc[c.td]);
-        c.dc_pred += br.receive_extend(s);
-        blk[0] = (int16_t)(c.dc_pred * (1 << al));
+        if (s > 16) throw Corrupt("JPEG: bad DC difference category");
+        c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)br.receive_extend(s));
+        blk[0] = (int16_t)((unsigned)c.dc_pred << al);
     }
     void block_dc_refine(BitReader& br, int16_t* blk, int al) { if (br.bit()) blk[0] |= (int16_t)(1 << al); }
     void block_ac_first(BitReader& br, Component& c, int16_t* blk, int ss, int se, int al) {

@@ -470,3 +470,54 @@ def test_libtorch_loader_adapters_equal_python_host_layer(ld, tmp_path):
     with pytest.raises(RuntimeError, match="No end_header"):
         open(a, "wb").write(b"ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty float x\n" + b" " * 8)
         m.load_ply(a)
+
+
+def test_decoders_reject_corrupt_input_without_crashing(ld, tmp_path):
+    """Untrusted-input hardening of the native decoders (tools/fuzz_io.cpp is the AddressSanitizer harness these cases came from): crafted Huffman
+    tables / DC categories are rejected with an error, and randomly mutated files only ever produce an image or an error code with a message."""
+    import glob
+    src = open(os.path.join(os.path.dirname(__file__), "golden", "jpeg", "baseline_444_q90.jpg"), "rb").read()
+    p = str(tmp_path / "bad.jpg")
+    dht = src.index(b"\xff\xc4")
+    assert src[dht + 4] >> 4 == 0                                   # the first table is a DC table: Tc = 0
+    over = bytearray(src)
+    k = max(range(16), key=lambda i: src[dht + 5 + i])              # the most populated code length gives up three codes ...
+    assert src[dht + 5 + k] >= 3 and k > 0
+    over[dht + 5 + k] -= 3
+    over[dht + 5] += 3                                              # ... to length 1, which has room for two
+    open(p, "wb").write(bytes(over))
+    rc, msg = _native_rgb8(ld, p)
+    assert rc == -3 and "Huffman" in msg, (rc, msg)                 # LFS_IO_E_FORMAT
+    cat = bytearray(src)
+    n_vals = sum(src[dht + 5:dht + 21])
+    cat[dht + 21:dht + 21 + n_vals] = bytes([200]) * n_vals         # every DC symbol claims a 200-bit difference
+    open(p, "wb").write(bytes(cat))
+    rc, msg = _native_rgb8(ld, p)
+    assert rc == -3 and "DC difference category" in msg, (rc, msg)
+    rng = np.random.default_rng(9)
+    seeds = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "jpeg", "*.jpg")))]
+    img = rng.integers(0, 256, (19, 23, 3)).astype(np.uint8)
+    ld.write_png(str(tmp_path / "s.png"), img)
+    seeds.append(open(tmp_path / "s.png", "rb").read())
+    outcomes = {"ok": 0, "error": 0}
+    for it in range(400):
+        d = bytearray(seeds[it % len(seeds)])
+        for _ in range(int(rng.integers(1, 4))):
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                d[int(rng.integers(0, len(d)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                del d[int(rng.integers(1, len(d))):]
+            else:
+                a = int(rng.integers(0, len(d)))
+                d[a:a + 4] = bytes(rng.integers(0, 256, 4).astype(np.uint8))
+        q = str(tmp_path / ("m.png" if seeds[it % len(seeds)][:4] == b"\x89PNG" else "m.jpg"))
+        open(q, "wb").write(bytes(d))
+        rc, out = _native_rgb8(ld, q)
+        if rc == 0:
+            assert out.ndim == 3 and out.shape[2] == 3 and out.dtype == np.uint8
+            outcomes["ok"] += 1
+        else:
+            assert rc in (-3, -4) and out, (rc, out)                # LFS_IO_E_FORMAT / _UNSUPPORTED with a message
+            outcomes["error"] += 1
+    assert outcomes["ok"] > 20 and outcomes["error"] > 20, outcomes
