@@ -39,11 +39,12 @@
 #include "lfs_camera.cuh"
 #include "lfs_prof.h"
 #include "lfs_raster_common.cuh"
+#include "lfs_cull_conic.cuh"
 
 namespace lfs {
 
 static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
-// Per-Gaussian culling record (camera space, divided by depth, r^2 folded in): see raster_pack_kernel.
+// Per-Gaussian culling record (the silhouette conic of the alpha >= 1/255 ellipsoid in normalised camera coordinates): see raster_pack_kernel.
 struct __attribute__((aligned(16))) CullRec { float4 a, b; };
 
 constexpr uint32_t LOSS_SLOTS = 256; // fused MSE: the wavefronts' partial sums are spread over this many addresses (one hot address costs ~0.08 ms)
@@ -113,50 +114,32 @@ __global__ void __launch_bounds__(256) raster_pack_kernel(
     rec.r3 = make_float4(opac, c0, c1, c2);
     recs[idx] = rec;
 
-    // Culling record for raster_cull_kernel. A pixel can only composite this Gaussian when
-    // opac * exp(-d^2/2) >= 1/255, d = Mahalanobis distance from the centre to the pixel's ray LINE, i.e.
-    // d^2 <= r^2 = 2 ln(255 opac). For a plane x = t z through the camera centre (camera space) that has all
-    // rays of a cell on one side and the centre p on the other, d >= |p.x - t p.z| / sqrt(w^T Sigma w),
-    // w = (1,0,-t). Stored divided by p.z^2 with r^2 (plus a safety margin) folded into Sigma:
-    //   a = {p.x/p.z, p.y/p.z, Sxx, Syy}, b = {Sxz, Syz, Szz, -}   with S = r^2 Sigma_cam / p.z^2.
-    // NaN in a.x/a.y = "never cull" (centre too close to the camera plane for the backward half of the ray
-    // lines to be excluded, rolling shutter, non-finite input); +inf in a.x = "always culled" (opac < 1/255).
-    CullRec cr;
-    const float qnan = __builtin_nanf("");
-    cr.a = make_float4(qnan, qnan, 0.f, 0.f);
-    cr.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Culling record for raster_cull_kernel: the silhouette conic of the alpha >= 1/255 ellipsoid (lfs_cull_conic.cuh). Rolling
+    // shutters have no single camera frame: never culled.
+    ConicRec k = conic_never();
     if (UNIFORM_ORIGIN) {
         const m3& Ri = cams[cid].Rinv;                // camera -> world, so world -> camera is its transpose
-        const f3 pc = mul_t(Ri, mu - cams[cid].origin);
-        m3 A;                                         // A = Rc R S  (Sigma_cam = A A^T)
+        const f3 pcv = mul_t(Ri, mu - cams[cid].origin);
+        const float pc[3] = {pcv.x, pcv.y, pcv.z};
+        float A[3][3];                                // A = Rc R S  (Sigma_cam = A A^T)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                A.m[r][c] = (Ri.m[0][r] * R.m[0][c] + Ri.m[1][r] * R.m[1][c] + Ri.m[2][r] * R.m[2][c]) * scales[3 * gid + c];
-        const float Sxx = A.m[0][0] * A.m[0][0] + A.m[0][1] * A.m[0][1] + A.m[0][2] * A.m[0][2];
-        const float Syy = A.m[1][0] * A.m[1][0] + A.m[1][1] * A.m[1][1] + A.m[1][2] * A.m[1][2];
-        const float Szz = A.m[2][0] * A.m[2][0] + A.m[2][1] * A.m[2][1] + A.m[2][2] * A.m[2][2];
-        const float Sxz = A.m[0][0] * A.m[2][0] + A.m[0][1] * A.m[2][1] + A.m[0][2] * A.m[2][2];
-        const float Syz = A.m[1][0] * A.m[2][0] + A.m[1][1] * A.m[2][1] + A.m[1][2] * A.m[2][2];
-        const float r2 = fmaxf(0.f, 2.f * logf(255.f * opac)) * 1.02f + 0.02f;
-        if (opac < (1.f / 255.f)) {
-            cr.a.x = __builtin_inff();
-        } else if (pc.z > 0.f && pc.z * pc.z > 1.5f * r2 * Szz) {
-            const float inv = 1.f / pc.z;
-            const float k = r2 * inv * inv;
-            cr.a = make_float4(pc.x * inv, pc.y * inv, k * Sxx, k * Syy);
-            cr.b = make_float4(k * Sxz, k * Syz, k * Szz, 0.f);
-        }
+                A[r][c] = (Ri.m[0][r] * R.m[0][c] + Ri.m[1][r] * R.m[1][c] + Ri.m[2][r] * R.m[2][c]) * scales[3 * gid + c];
+        k = conic_record(pc, A, opac);
     }
+    CullRec cr;
+    cr.a = make_float4(k.px, k.py, k.a, k.b);
+    cr.b = make_float4(k.d, k.e, k.g, k.ia);
     cull[idx] = cr;
 }
 
 // ---------------------------------------------------------------------------
 // cull: per 8x8 cell, compact the tile's depth-sorted list down to the entries that CAN reach the
 // 1/255 alpha threshold on at least one of the cell's rays (conservative: never drops a contributor, so
-// fwd/bwd results are exactly those of walking the full tile list). Lane = list entry; the four side
-// planes of the cell's ray pyramid are wave-uniform. Output per cell: count + (gaussian, list index)
+// fwd/bwd results are exactly those of walking the full tile list). Lane = list entry; the cell's box of rays in normalised
+// camera coordinates is wave-uniform and tested against the entry's silhouette conic (lfs_cull_conic.cuh). Output per cell: count + (gaussian, list index)
 // pairs in list order, stored in the cell's slice of a [cells_per_tile * n_isects] array.
 // ---------------------------------------------------------------------------
 // Workgroup -> (tile, 16x8 cell) of the wide kernels: cell_ctx's XCD-banded tile order; (i, j) is the lane's FIRST pixel, the second is (i, j + 8).
@@ -248,14 +231,6 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
 
     int2* __restrict__ out = cell_list + (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
     int32_t count = 0;
-    // one plane: centre coordinate c (x/z or y/z), slope t, S = (Scc, Scz, Szz); sgn = +1 for the upper side
-    auto outside = [](float c, float t, float sgn, float Scc, float Scz, float Szz) {
-        const float s = sgn * (c - t);
-        const float tt = t * t;
-        const float q = Scc - 2.f * t * Scz + tt * Szz;
-        const float Q = Scc + 2.f * fabsf(t * Scz) + tt * Szz;
-        return s > 0.f && s * s > q + 4e-6f * Q;
-    };
     const int32_t E = int32_t(blockDim.x);          // entries per batch
     const int32_t nsub = E >> 6;                    // = waves in the workgroup
     auto fetch = [&](int32_t base, int32_t& g, CullRec& cr) {
@@ -282,9 +257,7 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
             bool hit = valid;
             if (can_cull) {
                 const float4 a = s_a[buf][slot], b = s_b[buf][slot];
-                const bool culled = outside(a.x, tu_hi, 1.f, a.z, b.x, b.z) || outside(a.x, tu_lo, -1.f, a.z, b.x, b.z) ||
-                                    outside(a.y, tv_hi, 1.f, a.w, b.y, b.z) || outside(a.y, tv_lo, -1.f, a.w, b.y, b.z);
-                hit = valid && !culled;
+                hit = valid && !conic_culled(ConicRec{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, tu_lo, tu_hi, tv_lo, tv_hi);
             }
             const uint64_t m = __ballot(hit);
             if (hit) {
