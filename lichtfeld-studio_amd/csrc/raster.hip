@@ -48,9 +48,10 @@ static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 struct __attribute__((aligned(16))) CullRec { float4 a, b; };
 
 constexpr uint32_t LOSS_SLOTS = 256; // fused MSE: the wavefronts' partial sums are spread over this many addresses (one hot address costs ~0.08 ms)
-struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; CullRec* cull; int32_t* cell_count; int2* cell_list; size_t bytes; };
+struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; CullRec* cull; int32_t* cell_count; int2* cell_list; int32_t* quad_count; int2* quad_list; size_t bytes; };
 // cells = C * tiles * (tile_size/8)^2 ; the compacted per-cell lists hold at most (tile_size/8)^2 * n_isects entries
-static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, uint64_t cell_entries) {
+// quads (experimental row kernels): four quadrant lists per cell on top
+static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, uint64_t cell_entries, bool quads) {
     RasterWs w; char* p = (char*)base; size_t o = 0;
     w.cams = (CamDev*)(p + o); o += align256(sizeof(CamDev) * C);
     w.recs = (GaussRec*)(p + o); o += align256(sizeof(GaussRec) * size_t(C) * N);
@@ -58,6 +59,11 @@ static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, ui
     w.cull = (CullRec*)(p + o); o += align256(sizeof(CullRec) * size_t(C) * N);
     w.cell_count = (int32_t*)(p + o); o += align256(sizeof(int32_t) * cells);
     w.cell_list = (int2*)(p + o); o += align256(sizeof(int2) * cell_entries);
+    w.quad_count = nullptr; w.quad_list = nullptr;
+    if (quads) {
+        w.quad_count = (int32_t*)(p + o); o += align256(sizeof(int32_t) * 4 * cells);
+        w.quad_list = (int2*)(p + o); o += align256(sizeof(int2) * 4 * cell_entries);
+    }
     w.bytes = o;
     return w;
 }
@@ -889,6 +895,8 @@ __global__ void __launch_bounds__(256) raster_bwd_wide_kernel(
     walk_cell_list_2buf<-1>(cl, recs, n_walk - 1, n_walk, eval, []() { return true; });
 }
 
+#include "lfs_raster_rows.cuh" // experimental quadrant-row kernels (opt-in)
+
 // ---------------------------------------------------------------------------
 // finish: accumulator -> dL/d(means, quats, scales, colors, opacities)
 // ---------------------------------------------------------------------------
@@ -978,14 +986,15 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
 
 // "wide" = the experimental 16x8 cells with two pixels per lane (see the file header; opt-in). The workspace is always sized for the 8x8
 // geometry (ws_*: at least as many cells and list entries), so the choice never changes lfs_rasterize_workspace_bytes.
-struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid, wpt, ws_wpt; uint64_t cells, ws_cells; bool wide; };
-static uint32_t g_debug_flags = 0; // bit 0: keep every tile-list entry in the cell lists (no culling); bit 1: use the wide (two pixels per lane) kernels
+struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid, wpt, ws_wpt; uint64_t cells, ws_cells; bool wide, rows; };
+static uint32_t g_debug_flags = 0; // bit 0: keep every tile-list entry in the cell lists (no culling); bit 1: the wide (two pixels per lane) kernels; bit 2: the quadrant-row kernels
 static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom& g) {
     if (tile_size < 8 || tile_size > 64 || (tile_size & 7)) return false;
     g.tw = (cams->image_width + tile_size - 1) / tile_size;
     g.th = (cams->image_height + tile_size - 1) / tile_size;
     g.ws_wpt = (tile_size / 8) * (tile_size / 8);
     g.wide = (tile_size & 15) == 0 && (g_debug_flags & 2u) != 0;
+    g.rows = !g.wide && (g_debug_flags & 4u) != 0;
     g.wpt = g.wide ? (tile_size / 16) * (tile_size / 8) : g.ws_wpt;
     g.waves_per_block = (g.wpt % 4 == 0) ? 4 : (g.wpt % 2 == 0) ? 2 : 1; // whole workgroups per tile (9, 25, 49 cells: one wave each)
     g.blocks_per_tile = g.wpt / g.waves_per_block;
@@ -1011,7 +1020,7 @@ extern "C" size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t
     cams.C = C; cams.image_width = image_width; cams.image_height = image_height;
     RasterGeom g;
     if (!raster_geom(&cams, tile_size, g) || n_isects < 0) return 0;
-    return raster_ws(nullptr, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects)).bytes;
+    return raster_ws(nullptr, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), (g_debug_flags & 4u) != 0).bytes;
 }
 
 static int raster_mode(const lfs_cameras* cams) {
@@ -1052,6 +1061,14 @@ static void raster_prepare(const RasterWs& w, const RasterGeom& g, uint32_t N, u
     if (uniform) { if (g.wide) LFS_CULL(true, true); else LFS_CULL(true, false); }
     else { if (g.wide) LFS_CULL(false, true); else LFS_CULL(false, false); }
 #undef LFS_CULL
+    if (g.rows) { // split the cell lists into quadrant lists
+        if (uniform) hipLaunchKernelGGL(raster_quad_lists_kernel<true>, dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, tile_size,
+                                        g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, int32_t(n_isects), w.cell_count, w.cell_list,
+                                        w.quad_count, w.quad_list);
+        else hipLaunchKernelGGL(raster_quad_lists_kernel<false>, dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, tile_size,
+                                g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, int32_t(n_isects), w.cell_count, w.cell_list,
+                                w.quad_count, w.quad_list);
+    }
 }
 
 extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
@@ -1069,7 +1086,7 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
     if (uint64_t(n_isects) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
     const uint32_t C = cams->C;
-    RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects));
+    RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), g.rows);
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N > 0 && (!means || !quats || !scales || !colors || !opacities)) return LFS_E_INVALID;
     if (n_isects > 0 && !flatten_ids) return LFS_E_INVALID;
@@ -1081,7 +1098,12 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
                        cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, int32_t(n_isects), \
                        render_colors, render_alphas, last_ids)
-#define LFS_FWD(CD, MODE) do { if (g.wide) LFS_FWD_K(raster_fwd_wide_kernel, CD, MODE); else LFS_FWD_K(raster_fwd_kernel, CD, MODE); } while (0)
+#define LFS_FWD_ROWS(CD, MODE)                                                                                    \
+    hipLaunchKernelGGL((raster_fwd_rows_kernel<CD, MODE>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,   \
+                       cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
+                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.quad_count, w.quad_list, int32_t(n_isects), \
+                       render_colors, render_alphas, last_ids)
+#define LFS_FWD(CD, MODE) do { if (g.rows) LFS_FWD_ROWS(CD, MODE); else if (g.wide) LFS_FWD_K(raster_fwd_wide_kernel, CD, MODE); else LFS_FWD_K(raster_fwd_kernel, CD, MODE); } while (0)
     switch (channels * 2 + raster_mode(cams)) {
     case 2: LFS_FWD(1, 0); break; case 3: LFS_FWD(1, 1); break;
     case 4: LFS_FWD(2, 0); break; case 5: LFS_FWD(2, 1); break;
@@ -1089,6 +1111,7 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     case 8: LFS_FWD(4, 0); break; default: LFS_FWD(4, 1); break;
     }
 #undef LFS_FWD_K
+#undef LFS_FWD_ROWS
 #undef LFS_FWD
     return (int)hipGetLastError();
 }
@@ -1110,7 +1133,7 @@ static int raster_bwd_impl(
     if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
     if (uint64_t(n_isects) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
     const uint32_t C = cams->C;
-    RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects));
+    RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), g.rows);
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N == 0) return LFS_OK;
     if (!means || !quats || !scales || !colors || !opacities || !v_means || !v_quats || !v_scales || !v_colors || !v_opacities) return LFS_E_INVALID;
@@ -1133,10 +1156,15 @@ static int raster_bwd_impl(
                        cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, int32_t(n_isects), \
                        render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors, mse_dev)
-#define LFS_BWD(CD, MODE) do { if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, CD, MODE); else LFS_BWD_K(raster_bwd_kernel, CD, MODE); } while (0)
+#define LFS_BWD_ROWS(CD, MODE, ...)                                                                              \
+    hipLaunchKernelGGL((raster_bwd_rows_kernel<CD, MODE, ##__VA_ARGS__>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th, \
+                       cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
+                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.quad_count, w.quad_list, int32_t(n_isects), \
+                       render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors, mse_dev)
+#define LFS_BWD(CD, MODE) do { if (g.rows) LFS_BWD_ROWS(CD, MODE); else if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, CD, MODE); else LFS_BWD_K(raster_bwd_kernel, CD, MODE); } while (0)
         if (mse) {
-            if (raster_mode(cams) == 0) { if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, 3, 0, true); else LFS_BWD_K(raster_bwd_kernel, 3, 0, true); }
-            else { if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, 3, 1, true); else LFS_BWD_K(raster_bwd_kernel, 3, 1, true); }
+            if (raster_mode(cams) == 0) { if (g.rows) LFS_BWD_ROWS(3, 0, true); else if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, 3, 0, true); else LFS_BWD_K(raster_bwd_kernel, 3, 0, true); }
+            else { if (g.rows) LFS_BWD_ROWS(3, 1, true); else if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, 3, 1, true); else LFS_BWD_K(raster_bwd_kernel, 3, 1, true); }
         } else
         switch (channels * 2 + raster_mode(cams)) {
         case 2: LFS_BWD(1, 0); break; case 3: LFS_BWD(1, 1); break;
@@ -1145,6 +1173,7 @@ static int raster_bwd_impl(
         case 8: LFS_BWD(4, 0); break; default: LFS_BWD(4, 1); break;
         }
 #undef LFS_BWD_K
+#undef LFS_BWD_ROWS
 #undef LFS_BWD
     }
     const dim3 fg((N + 255) / 256);
