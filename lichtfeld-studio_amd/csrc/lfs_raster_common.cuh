@@ -71,6 +71,12 @@ LFS_DI f3 cross_fma(const f3& a, const f3& b) {
 // waits for group B right BEFORE refilling group A (and vice versa), which gives each record load two full
 // evaluations (~300 cycles) in flight and never copies a buffer. Entries are visited at positions
 // first, first+step, ... (n of them); eval(rec, entry) per entry; alive() is polled every two entries.
+// (LFS_EMULATE: the host build of tests/emul - no registers to pin there)
+#ifdef LFS_EMULATE
+#define LFS_SGPR_PIN2(text, a, b) ((void)(a), (void)(b))
+#else
+#define LFS_SGPR_PIN2(text, a, b) asm volatile(text ::"s"(a), "s"(b))
+#endif
 template <int STEP, class Eval, class Alive>
 LFS_DI void walk_cell_list(const int2* __restrict__ cl, const GaussRec* __restrict__ recs, const int32_t first, const int32_t n,
                            Eval&& eval, Alive&& alive) {
@@ -88,14 +94,14 @@ LFS_DI void walk_cell_list(const int2* __restrict__ cl, const GaussRec* __restri
         if (!alive()) break;
         eval(A0, eA0);
         if (k + 1 < n) eval(A1, eA1);
-        asm volatile("; group B must have landed before group A is refilled" ::"s"(B0.r0.x), "s"(B1.r0.x));
+        LFS_SGPR_PIN2("; group B must have landed before group A is refilled", B0.r0.x, B1.r0.x);
         eA0 = nA0; eA1 = nA1;
         A0 = rec_at(eA0.x); A1 = rec_at(eA1.x);
         nB0 = ent(k + 6); nB1 = ent(k + 7);
         if (k + 2 >= n || !alive()) break;
         eval(B0, eB0);
         if (k + 3 < n) eval(B1, eB1);
-        asm volatile("; group A must have landed before group B is refilled" ::"s"(A0.r0.x), "s"(A1.r0.x));
+        LFS_SGPR_PIN2("; group A must have landed before group B is refilled", A0.r0.x, A1.r0.x);
         eB0 = nB0; eB1 = nB1;
         B0 = rec_at(eB0.x); B1 = rec_at(eB1.x);
         nA0 = ent(k + 8); nA1 = ent(k + 9);

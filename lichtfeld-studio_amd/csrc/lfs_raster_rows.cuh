@@ -1,6 +1,8 @@
-// "Row" kernels of the world-space rasterizer - EXPERIMENT, opt-in (lfs_set_debug_flags bit 2), NOT YET RUN ON A GPU (written after the
-// round's GPU budget was spent; compiles for gfx950, to be verified first thing next round with the existing parity tests - the forward is
-// built to be bit-identical to the default kernels: same ray_eval, same compositing order per pixel).
+// "Row" kernels of the world-space rasterizer - EXPERIMENT, opt-in (lfs_set_debug_flags bit 2), NOT YET RUN ON A GPU: written after the
+// round's GPU budget was spent. They compile for gfx950 and their logic is verified on the CPU under the wavefront emulator
+// (tests/test_emulated_raster.py: forward bit-identical to the default kernels, backward to summation order, 7 scene variants); what is
+// left for the first GPU minutes of the next round is the ISA level (DPP encodings / hazards / the inline asm) and the timing:
+// LFS_EXPERIMENTAL_ROWS=1 python -m pytest tests/test_gpu_raster_rows.py ; python bench.py --row-kernels
 //
 // Why: after the conic culling a SYN-B Gaussian is evaluated on 8.4 cells x 64 lanes but can composite only ~235 of those 537 pixels; with
 // wave-uniform records a wavefront cannot skip the quadrants of its 8x8 cell that the Gaussian misses. Here every 16-lane DPP row owns a 4x4
@@ -59,6 +61,11 @@ LFS_DI uint32_t row_bits(uint64_t ballot, uint32_t row) { return uint32_t(ballot
 // costs no instruction of its own. DPP reads lanes of the whole row, so these run in wave-converged code only (a source lane that is masked
 // off would read as 0), and the record register comes straight from a load (a VALU write right before a DPP read needs two wait states).
 template <int F> LFS_DI float row_field(float rec) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(rec), DPP_NEWBCAST0 + F, 0xf, 0xf, true)); }
+#ifdef LFS_EMULATE // host build of tests/emul: the DPP operand spelled out
+template <int F> LFS_DI float mul_field(float rec, float b) { return row_field<F>(rec) * b; }
+template <int F> LFS_DI float fma_field(float rec, float b, float acc) { return __builtin_fmaf(row_field<F>(rec), b, acc); }
+LFS_DI float dpp_ready(float rec) { return rec; }
+#else
 template <int F> LFS_DI float mul_field(float rec, float b) { // field F * b
     float d;
     asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(rec), "v"(b), "n"(F));
@@ -70,6 +77,7 @@ template <int F> LFS_DI float fma_field(float rec, float b, float acc) { // fma(
 }
 // two wait states between the last VALU write of the record register (a register copy the compiler may have placed) and its first DPP read
 LFS_DI float dpp_ready(float rec) { asm volatile("s_nop 1" : "+v"(rec)); return rec; }
+#endif
 // fma3(row F, F+1, F+2 of the record matrix; x) = the chain of lfs_raster_common.cuh's fma3: x.x * m0, then fma with m1, then with m2
 template <int F> LFS_DI float row_dot(float rec, const f3& x) { return fma_field<F + 2>(rec, x.z, fma_field<F + 1>(rec, x.y, mul_field<F>(rec, x.x))); }
 

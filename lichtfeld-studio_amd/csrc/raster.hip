@@ -575,8 +575,12 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 // every field of the record has to be in SGPRs here: keeps the compiler from splitting the 64-byte scalar load and sinking the pieces to
 // their first use (which would turn the prefetch into a load-and-wait in front of every evaluation)
 LFS_DI void pin_record(const GaussRec& r) {
+#ifdef LFS_EMULATE
+    (void)r;
+#else
     asm volatile("; record landed" ::"s"(r.r0.x), "s"(r.r0.y), "s"(r.r0.z), "s"(r.r0.w), "s"(r.r1.x), "s"(r.r1.y), "s"(r.r1.z), "s"(r.r1.w),
                  "s"(r.r2.x), "s"(r.r2.y), "s"(r.r2.z), "s"(r.r2.w), "s"(r.r3.x), "s"(r.r3.y), "s"(r.r3.z), "s"(r.r3.w));
+#endif
 }
 template <int STEP, class Eval, class Alive>
 LFS_DI void walk_cell_list_2buf(const int2* __restrict__ cl, const GaussRec* __restrict__ recs, const int32_t first, const int32_t n,
