@@ -3,7 +3,10 @@ wavefronts of fibers, cross-lane operations in lock-step) and driven through the
 Checks the kernels' LOGIC without a GPU: the default kernels against the CPU oracle, and every alternative code path against the default
 one - culling off, the two-pixels-per-lane kernels, the quadrant-row kernels: forward BIT-identical (they perform the same per-pixel
 operation sequence; the emulator's arithmetic is host float, so this is equality between emulated runs, not with the GPU), backward equal
-up to summation order. What it cannot check is ISA-level behaviour (DPP encodings, hazards, inline asm): tests/test_gpu_raster*.py."""
+up to summation order. What it cannot check is ISA-level behaviour (DPP encodings, hazards, inline asm): tests/test_gpu_raster*.py.
+Memory-safety run of the kernels (AddressSanitizer sees every global-memory access of the emulated lanes; tensors are exact-size heap blocks):
+    LFS_EMUL_SANITIZE=1 ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 \
+    LD_PRELOAD=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so) python -m pytest tests/test_emulated_raster.py"""
 import ctypes as C
 import os
 import subprocess
@@ -26,6 +29,8 @@ def emu(tmp_path_factory):
     cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-DLFS_EMULATE", "-fPIC", "-shared", "-ffp-contract=on", "-I" + os.path.join(HERE, "emul"),
            "-Wno-unused-value", "-Wno-unknown-attributes", os.path.join(ROOT, "lichtfeld-studio_amd", "csrc", "raster.hip"),
            os.path.join(HERE, "emul", "emul_stubs.cpp"), "-o", out]
+    if os.environ.get("LFS_EMUL_SANITIZE"):  # memory-safety run of the kernels (see the module docstring)
+        cmd[1:1] = ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     lib = C.CDLL(out)
