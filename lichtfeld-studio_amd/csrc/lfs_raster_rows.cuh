@@ -261,7 +261,9 @@ __global__ void __launch_bounds__(256) raster_fwd_rows_kernel(
         ray_eval_row<MODE>(rec, ro, rd, re);
         const float alpha = fminf(0.999f, mul_field<12>(rec, re.vis));
         const bool pass = mine && !(alpha < thr);
+        LFS_EMUL_COUNT(0);
         if (__ballot(pass) == 0ull) continue;
+        LFS_EMUL_COUNT(1);
         const float next_T = T * (1.f - alpha);
         const bool fin = pass && next_T <= 1e-4f;
         const bool contrib = pass && !fin;
@@ -418,7 +420,9 @@ __global__ void __launch_bounds__(256) raster_bwd_rows_kernel(
         const float alpha = fminf(0.999f, araw);
         const bool valid = mine && e.y <= bin_final && !(alpha < (1.f / 255.f));
         const uint64_t vb = __ballot(valid);
+        LFS_EMUL_COUNT(2);
         if (vb == 0ull) continue;
+        LFS_EMUL_COUNT(3);
 
         const float ra = fast_rcp(1.f - alpha);
         const float Tn = T * ra;

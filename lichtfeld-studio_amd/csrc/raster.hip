@@ -41,6 +41,14 @@
 #include "lfs_raster_common.cuh"
 #include "lfs_cull_conic.cuh"
 
+// Host build on the wavefront emulator (tests/emul) only: wave-evaluation counters [fwd, fwd that composited, bwd, bwd that accumulated]
+#ifdef LFS_EMULATE
+extern "C" { __attribute__((visibility("default"))) unsigned long long lfs_emul_counters[4] = {0, 0, 0, 0}; }
+#define LFS_EMUL_COUNT(i) do { if ((threadIdx.x & 63) == 0) ++lfs_emul_counters[i]; } while (0)
+#else
+#define LFS_EMUL_COUNT(i) do { } while (0)
+#endif
+
 namespace lfs {
 
 static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -377,7 +385,9 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
         ray_eval<MODE>(rec, ro, rd, re);
         const float alpha = fminf(0.999f, rec.r3.x * re.vis);
         const bool pass = !(alpha < thr); // live pixel and alpha >= 1/255 (a NaN alpha passes, as in the reference's `if (alpha < 1/255) continue`)
+        LFS_EMUL_COUNT(0);
         if (__ballot(pass) == 0ull) return;
+        LFS_EMUL_COUNT(1);
         const float next_T = T * (1.f - alpha);
         const bool fin = pass && next_T <= 1e-4f; // the terminating Gaussian is not composited
         const bool contrib = pass && !fin;
@@ -510,7 +520,9 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         const float araw = opac * vis;
         const float alpha = fminf(0.999f, araw);
         const bool valid = e.y <= bin_final && !(alpha < (1.f / 255.f)); // (inactive lanes carry bin_final = -1; vis > 1 cannot happen)
+        LFS_EMUL_COUNT(2);
         if (__ballot(valid) == 0ull) return;
+        LFS_EMUL_COUNT(3);
 
         // Invalid lanes are masked by zeroing three scalars (fac, v_op, and through it s): every reduced value below is
         // a product with one of them. (All factors are finite for an inactive lane: its direction is 0, so w = gro, t = 0.)
