@@ -89,7 +89,7 @@ LFS_CONIC_FN bool conic_culled(const ConicRec& k, const float u0, const float u1
     const float best = fmaxf(fmaxf(eu0, eu1), fmaxf(ev0, ev1));
     const float R2 = fmaxf(U0 * U0, U1 * U1) + fmaxf(V0 * V0, V1 * V1);
     const float tol = 8e-6f * (fabsf(k.a) + 2.f * fabsf(k.b) + 1.f) * R2;
-    return !centre_in && !(best > -tol);
+    return !centre_in && best <= -tol; // (a NaN - inf - inf for rays within 1e-19 rad of the camera plane - compares false: not culled)
 }
 
 } // namespace lfs
