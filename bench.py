@@ -159,6 +159,7 @@ def main() -> None:
                          "FusedAdam updating shN (the reference skips shN while iteration <= 1000, fused_adam.cpp:68-70; pass 0 for that cheaper phase)")
     ap.add_argument("--replicated", action="store_true", help="multi-GPU: keep shN replicated (59 floats / Gaussian all-reduced) instead of SH-sharded")
     ap.add_argument("--wide-cells", action="store_true", help="developer A/B: the experimental two-pixels-per-lane 16x8-cell rasterizer kernels (slower on SYN-B; see raster.hip)")
+    ap.add_argument("--row-lists", default="split", choices=["split", "merged"], help="with --row-kernels: quadrant lists split from the cell lists (two kernels) or built in one pass")
     ap.add_argument("--row-kernels", action="store_true", help="developer A/B: the experimental quadrant-row rasterizer kernels (csrc/lfs_raster_rows.cuh; not yet verified on a GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -172,7 +173,7 @@ def main() -> None:
     if args.wide_cells:
         lfs.load_library().lfs_set_debug_flags(2)
     if args.row_kernels:
-        lfs.load_library().lfs_set_debug_flags(4)
+        lfs.load_library().lfs_set_debug_flags(12 if args.row_lists == "merged" else 4)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")

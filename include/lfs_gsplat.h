@@ -143,7 +143,7 @@ LFS_API size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t ch
 /*      developer switch, not part of the reference API: bit 0 = build the per-cell lists without culling
  *      (fwd output must be bit-identical either way; tests/test_gpu_raster.py); bit 1 = the experimental kernels with
  *      16x8 cells and two pixels per lane (bit-identical forward, slower on the benchmark scene: csrc/raster.hip); bit 2 = the
- *      experimental quadrant-row kernels (csrc/lfs_raster_rows.cuh; lfs_rasterize_workspace_bytes grows while the bit is set). */
+ *      experimental quadrant-row kernels (csrc/lfs_raster_rows.cuh; lfs_rasterize_workspace_bytes grows while the bit is set); bit 3 with bit 2 = their quadrant lists built in one pass. */
 LFS_API void lfs_set_debug_flags(uint32_t flags);
 LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,

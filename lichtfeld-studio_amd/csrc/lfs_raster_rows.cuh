@@ -185,6 +185,110 @@ __global__ void __launch_bounds__(256) raster_quad_lists_kernel(
     if (lane < 4) quad_count[cell * 4 + lane] = lane == 0 ? cq[0] : lane == 1 ? cq[1] : lane == 2 ? cq[2] : cq[3];
 }
 
+// Variant (lfs_set_debug_flags bit 3 on top of bit 2): the quadrant lists straight from the tile list in ONE kernel - raster_cull_kernel's
+// batching (the workgroup gathers 64 x waves entries and their culling records once and shares them through LDS), four quadrant tests per
+// entry instead of one cell test, no cell lists and no second gather. Which of the two is cheaper is a measurement for the next round.
+template <bool UNIFORM_ORIGIN>
+__global__ void __launch_bounds__(256) raster_cull_quads_kernel(
+    const uint32_t C, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
+    const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block, const uint32_t cull_enabled,
+    const CamDev* __restrict__ cams, const CullRec* __restrict__ cull, const uint8_t* __restrict__ masks,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ ids, const int32_t n_isects,
+    int32_t* __restrict__ quad_count, int2* __restrict__ quad_list) {
+    __shared__ float4 s_a[2][256], s_b[2][256];
+    __shared__ int32_t s_g[2][256];
+    const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
+    const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
+    if (!cc.in_grid) return; // (uniform per workgroup)
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wpt = cells_per_tile(tile_size, false);
+    const size_t cell = size_t(cc.tile_global) * wpt + cc.wl;
+    const int32_t start = offsets[cc.tile_global];
+    const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
+    const int32_t len = end - start;
+    const bool tile_masked = masks != nullptr && !masks[cc.tile_global];
+    if (tile_masked || len <= 0) { // uniform per workgroup
+        if (lane < 4) quad_count[cell * 4 + lane] = 0;
+        return;
+    }
+    const RowCtx rc = row_ctx(cc);
+    const CamDev& cam = cams[cc.cid];
+    const float big = 3.0e38f;
+    f3 ro, rd;
+    const bool ok = cam_pixel_ray(cam, f2{float(rc.j) + 0.5f, float(rc.i) + 0.5f}, ro, rd);
+    const bool act = rc.i < H && rc.j < W && ok;
+    bool behind = false;
+    float tu = 0.f, tv = 0.f;
+    if (UNIFORM_ORIGIN) {
+        const f3 cd = mul_t(cam.Rinv, rd);
+        const bool front = cd.z > 0.f;
+        behind = act && !front;
+        const float iz = front ? 1.f / cd.z : 0.f;
+        tu = cd.x * iz; tv = cd.y * iz;
+    }
+    const uint64_t act_b = __ballot(act);
+    const bool cell_live = act_b != 0ull;
+    const bool wave_can_cull = UNIFORM_ORIGIN && cull_enabled != 0 && __ballot(behind) == 0ull;
+    const float mu_ = 0.25f / cam.fx, mv_ = 0.25f / cam.fy;
+    const float r_ulo = row_min(act ? tu : big) - mu_, r_uhi = row_max(act ? tu : -big) + mu_;
+    const float r_vlo = row_min(act ? tv : big) - mv_, r_vhi = row_max(act ? tv : -big) + mv_;
+    float ulo[4], uhi[4], vlo[4], vhi[4];
+    bool live[4], can[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ulo[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r_ulo), 16 * q));
+        uhi[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r_uhi), 16 * q));
+        vlo[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r_vlo), 16 * q));
+        vhi[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r_vhi), 16 * q));
+        live[q] = ((act_b >> (16 * q)) & 0xffffull) != 0ull;
+        can[q] = wave_can_cull && (uhi[q] - ulo[q] < 1e30f) && (vhi[q] - vlo[q] < 1e30f);
+    }
+    const bool need_recs = UNIFORM_ORIGIN && cull_enabled != 0; // workgroup-uniform
+    int2* __restrict__ out = quad_list + 4 * (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(len));
+    int32_t cq[4] = {0, 0, 0, 0};
+    const int32_t E = int32_t(blockDim.x), nsub = E >> 6;
+    auto fetch = [&](int32_t base, int32_t& g, CullRec& cr) {
+        const int32_t i = base + int32_t(threadIdx.x);
+        g = i < end ? ids[i] : 0;
+        if (need_recs) cr = cull[g];
+    };
+    int32_t g_reg; CullRec cr_reg;
+    cr_reg.a = make_float4(0.f, 0.f, 0.f, 0.f); cr_reg.b = cr_reg.a;
+    fetch(start, g_reg, cr_reg);
+    int buf = 0;
+    for (int32_t base = start; base < end; base += E, buf ^= 1) {
+        s_g[buf][threadIdx.x] = g_reg;
+        if (need_recs) { s_a[buf][threadIdx.x] = cr_reg.a; s_b[buf][threadIdx.x] = cr_reg.b; }
+        __syncthreads();
+        if (base + E < end) fetch(base + E, g_reg, cr_reg);
+        if (!cell_live) continue;
+        for (int32_t sub = 0; sub < nsub; ++sub) {
+            const int32_t slot = (sub << 6) + int32_t(lane);
+            const int32_t my_idx = base + slot;
+            if (base + (sub << 6) >= end) break; // uniform
+            const bool valid = my_idx < end;
+            const int2 e = make_int2(s_g[buf][slot], my_idx);
+            ConicRec k = conic_never();
+            if (need_recs) {
+                const float4 a = s_a[buf][slot], b = s_b[buf][slot];
+                k = ConicRec{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bool hit = valid && live[q];
+                if (can[q]) hit = hit && !conic_culled(k, ulo[q], uhi[q], vlo[q], vhi[q]);
+                const uint64_t m = __ballot(hit);
+                if (hit) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+                    out[size_t(q) * size_t(len) + size_t(cq[q]) + rank] = e;
+                }
+                cq[q] += __popcll(m);
+            }
+        }
+    }
+    if (lane < 4) quad_count[cell * 4 + lane] = lane == 0 ? cq[0] : lane == 1 ? cq[1] : lane == 2 ? cq[2] : cq[3];
+}
+
 // The row's list walker state: entry k of the row's list (clamped to the last one; rows without entries read a dummy), the record dword
 // of this lane. Vector loads return in order, so plain program order gives the compiler counted vmcnt waits: entries three and records
 // two evaluations ahead.

@@ -1002,8 +1002,8 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
 
 // "wide" = the experimental 16x8 cells with two pixels per lane (see the file header; opt-in). The workspace is always sized for the 8x8
 // geometry (ws_*: at least as many cells and list entries), so the choice never changes lfs_rasterize_workspace_bytes.
-struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid, wpt, ws_wpt; uint64_t cells, ws_cells; bool wide, rows; };
-static uint32_t g_debug_flags = 0; // bit 0: keep every tile-list entry in the cell lists (no culling); bit 1: the wide (two pixels per lane) kernels; bit 2: the quadrant-row kernels
+struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid, wpt, ws_wpt; uint64_t cells, ws_cells; bool wide, rows, rows_merged; };
+static uint32_t g_debug_flags = 0; // bit 0: keep every tile-list entry in the cell lists (no culling); bit 1: the wide (two pixels per lane) kernels; bit 2: the quadrant-row kernels; bit 3: (with bit 2) quadrant lists straight from the tile lists
 static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom& g) {
     if (tile_size < 8 || tile_size > 64 || (tile_size & 7)) return false;
     g.tw = (cams->image_width + tile_size - 1) / tile_size;
@@ -1011,6 +1011,7 @@ static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom&
     g.ws_wpt = (tile_size / 8) * (tile_size / 8);
     g.wide = (tile_size & 15) == 0 && (g_debug_flags & 2u) != 0;
     g.rows = !g.wide && (g_debug_flags & 4u) != 0;
+    g.rows_merged = g.rows && (g_debug_flags & 8u) != 0;
     g.wpt = g.wide ? (tile_size / 16) * (tile_size / 8) : g.ws_wpt;
     g.waves_per_block = (g.wpt % 4 == 0) ? 4 : (g.wpt % 2 == 0) ? 2 : 1; // whole workgroups per tile (9, 25, 49 cells: one wave each)
     g.blocks_per_tile = g.wpt / g.waves_per_block;
@@ -1070,6 +1071,13 @@ static void raster_prepare(const RasterWs& w, const RasterGeom& g, uint32_t N, u
     }
     lfs::ProfScope prof_cull("raster_cull", s);
     const uint32_t cull_on = (g_debug_flags & 1u) ? 0u : 1u;
+    if (g.rows_merged) { // quadrant lists in one pass: no cell lists
+        if (uniform) hipLaunchKernelGGL(raster_cull_quads_kernel<true>, dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, tile_size,
+                                        g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, flatten_ids, int32_t(n_isects), w.quad_count, w.quad_list);
+        else hipLaunchKernelGGL(raster_cull_quads_kernel<false>, dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, tile_size,
+                                g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, flatten_ids, int32_t(n_isects), w.quad_count, w.quad_list);
+        return;
+    }
 #define LFS_CULL(U, WD)                                                                                                                       \
     hipLaunchKernelGGL((raster_cull_kernel<U, WD>), dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, \
                        tile_size, g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, flatten_ids,              \

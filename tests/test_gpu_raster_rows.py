@@ -13,10 +13,10 @@ from gpu_util import make_gaussians, n, pinhole_K, rel_l2, small_rotation_viewma
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.environ.get("LFS_EXPERIMENTAL_ROWS"), reason="experimental kernels: set LFS_EXPERIMENTAL_ROWS=1")]
 
 
-def _rows(lfs, fn):
+def _rows(lfs, fn, flags=4):
     lib = lfs.load_library()
     try:
-        lib.lfs_set_debug_flags(4)
+        lib.lfs_set_debug_flags(flags)
         return fn()
     finally:
         lib.lfs_set_debug_flags(0)
@@ -57,6 +57,12 @@ def test_row_kernels_match_the_default_kernels(lfs, oracle_mod, case):
     for name, a, b in zip(["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"], g0, g1):
         assert torch.isfinite(b).all(), name
         assert rel_l2(n(b), n(a)) < 1e-4, (name, rel_l2(n(b), n(a)))
+    # the quadrant lists built in one pass from the tile lists (bit 3) instead of split from the cell lists
+    mc, ma, ml = _rows(lfs, lambda: ops.rasterize_to_pixels_from_world_3dgs_fwd(*args), flags=12)
+    assert torch.equal(rc, mc) and torch.equal(ra, ma) and torch.equal(li, ml)
+    g2 = _rows(lfs, lambda: ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra), flags=12)
+    for name, a, b in zip(["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"], g0, g2):
+        assert rel_l2(n(b), n(a)) < 1e-4, ("merged lists", name, rel_l2(n(b), n(a)))
 
 
 def test_row_kernels_full_size_and_fused_step(lfs):
