@@ -91,12 +91,27 @@ LFS_DI void sh_basis(const int degree, const float x, const float y, const float
     }
 }
 
+// Sum over the LPG lanes of a group, result in every lane. Default: xor butterfly through ds_bpermute (LDS pipe). LFS_SH_DPP_SUM (compile-time,
+// off until it has run on a GPU - DESIGN.md §6b): the same additions as DPP operands - row_ror:8 is lane^8; after that step the values are
+// symmetric under ^8, so row_ror:4 delivers the lane^4 partner (in either rotation direction); quad_perm for lane^2 and lane^1. Bit-identical
+// sums, no LDS traffic. LPG is 1, 4, 16 or 32 (lanes_for): only the lane^16 step of LPG = 32 crosses a DPP row.
+#ifdef LFS_SH_DPP_SUM
+template <int CTRL> LFS_DI float sh_dpp(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false)); }
+template <int LPG>
+LFS_DI float group_sum(float v) {
+    if (LPG >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPG >= 16) { v += sh_dpp<0x128>(v); v += sh_dpp<0x124>(v); }
+    if (LPG >= 4) { v += sh_dpp<0x4E>(v); v += sh_dpp<0xB1>(v); }
+    return v;
+}
+#else
 template <int LPG>
 LFS_DI float group_sum(float v) {
 #pragma unroll
     for (int m = LPG / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+#endif
 
 LFS_DI f3 campos_of(const float* __restrict__ vm) { // -R^T t of a rigid row-major [4,4] world->camera matrix
     return {-(vm[0] * vm[3] + vm[4] * vm[7] + vm[8] * vm[11]),
