@@ -88,60 +88,47 @@ def reference_torch_impl_baseline(threads: int):
             "sample": "tests/torch_impl.cpp: fully_fused_projection + spherical_harmonics + isect_tiles, forward, SYN-A (10000 Gaussians, 256x256, SH deg 0), median of 5"}
 
 
-def cpu_baseline(scene, view: int, target, threads: int) -> dict:
+def cpu_baseline(scene, view: int, target, threads: int, hip_step: dict | None = None) -> dict:
     """Oracle ("port" of the reference CUDA kernels) on the host cores: ONE training image of the
     same workload — activations, UT projection, SH, tile intersection + stable sort, compositing fwd,
-    MSE gradient, compositing bwd, SH bwd, activation bwd, Adam on all 59*N parameters."""
+    MSE gradient, compositing bwd, SH bwd, activation bwd (oracle/pipeline.py), Adam on all 59*N parameters.
+    With `hip_step` (the HIP path's results for the same view from the same initial parameters) the oracle's
+    results are not thrown away: `parity_vs_oracle` carries the comparison, so every bench line has its own parity evidence."""
     import numpy as np
 
     import oracle
+    from oracle import pipeline
     oracle.lib()
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-    sc = scene
-    W, H, deg = sc.width, sc.height, sc.sh_degree
-    means = sc.means.numpy()
-    raw_q, raw_s, raw_o = sc.raw_quats.numpy(), sc.raw_scales.numpy(), sc.raw_opacities.numpy()
-    sh0, shN = sc.sh0.numpy(), sc.shN.numpy()
-    vm, Kmat = sc.viewmats[view:view + 1].numpy(), sc.Ks[view:view + 1].numpy()
-    tgt = target.numpy()
+    sa = pipeline.scene_arrays(scene)
     t0 = time.perf_counter()
-    quats = raw_q / np.linalg.norm(raw_q, axis=-1, keepdims=True)
-    scales, opac = np.exp(raw_s), 1.0 / (1.0 + np.exp(-raw_o))
-    sh = np.concatenate([sh0, shN], 1)
-    radii, m2, d, con, _ = oracle.projection_ut_3dgs_fused(means, quats, scales, opac, vm, None, Kmat, W, H)
-    dirs = means - np.linalg.inv(vm[0])[:3, 3].astype(np.float32)
-    mask = (radii[0] > 0).all(-1)
-    col = oracle.spherical_harmonics_fwd(deg, dirs, sh, mask)
-    colors = np.maximum(col + 0.5, 0.0)[None]
-    ts = 16
-    tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
-    tpg, ids, flat = oracle.intersect_tile(m2, radii, d, 1, ts, tw, th, True)
-    offs = oracle.intersect_offset(ids, 1, tw, th)
-    bg = np.zeros((1, 3), np.float32)
-    rc, ra, li = oracle.rasterize_fwd(means, quats, scales, colors, opac[None], bg, None, W, H, ts, vm, None, Kmat, 0, 4, None, None, None, offs, flat)
-    img = np.clip(rc[0].transpose(2, 0, 1), 0, 1)
-    v_img = 2.0 * (img - tgt) / img.size
-    v_img = np.where((rc[0].transpose(2, 0, 1) > 0) & (rc[0].transpose(2, 0, 1) < 1), v_img, 0.0)
-    v_rc = np.ascontiguousarray(v_img.transpose(1, 2, 0))[None].astype(np.float32)
-    v_ra = np.zeros_like(ra)
-    g_means, g_quats, g_scales, g_colors, g_opac = oracle.rasterize_bwd(
-        means, quats, scales, colors, opac[None], bg, None, W, H, ts, vm, None, Kmat, 0, 4, None, None, None, offs, flat, ra, li, v_rc, v_ra)
-    g_col = np.where(col + 0.5 > 0, g_colors[0], 0.0).astype(np.float32)
-    g_sh, g_dirs = oracle.spherical_harmonics_bwd(deg, dirs, sh, mask, g_col, True)
-    g_means = g_means + g_dirs
-    g_raw_o = g_opac[0] * opac * (1 - opac)
-    g_raw_s = g_scales * scales
-    dotq = (g_quats * quats).sum(-1, keepdims=True)
-    g_raw_q = (g_quats - dotq * quats) / np.linalg.norm(raw_q, axis=-1, keepdims=True)
-    params = [means, sh0, shN, raw_s, raw_q, raw_o]
-    grads = [g_means, g_sh[:, :1], g_sh[:, 1:], g_raw_s, g_raw_q, g_raw_o]
-    for p, g in zip(params, grads):
+    orc = pipeline.train_image(sa, view, target.numpy())
+    params = [sa["means"], sa["sh0"], sa["shN"], sa["raw_scales"], sa["raw_quats"], sa["raw_opacities"]]
+    names = ["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"]
+    for p, k in zip(params, names):
         z = np.zeros_like(p)
-        oracle.adam_step(p, z, z, np.ascontiguousarray(g, dtype=np.float32), 1e-3, 0.9, 0.999, 1e-15, 10.0, 31.6)
+        oracle.adam_step(p, z, z, np.ascontiguousarray(orc["grads"][k], dtype=np.float32), 1e-3, 0.9, 0.999, 1e-15, 10.0, 31.6)
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "train-images/sec", "cores": threads, "kind": "port",
-            "sample": f"1 training image of the same workload (N={means.shape[0]}, {W}x{H}, SH deg {deg}; "
-                      f"V={int(mask.sum())}, I={int(len(ids))}): oracle fwd+bwd+Adam, {dt:.1f} s wall, OpenMP x{threads}"}
+    out = {"value": 1.0 / dt, "unit": "train-images/sec", "cores": threads, "kind": "port",
+           "sample": f"1 training image of the same workload (N={sa['means'].shape[0]}, {sa['width']}x{sa['height']}, SH deg {sa['sh_degree']}; "
+                     f"V={int(orc['visible'].sum())}, I={int(len(orc['flatten_ids']))}): oracle fwd+bwd+Adam, {dt:.1f} s wall, OpenMP x{threads}"}
+    if hip_step is not None:
+        out["parity_vs_oracle"] = dict(pipeline.compare_step(hip_step, orc), view=view,
+                                       note="HIP fused step vs oracle, same view, initial parameters; activations computed on each side")
+    return out
+
+
+def hip_reference_step(trainer, view: int, target_dev) -> dict:
+    """One fused forward + backward of the HIP path at `view` from the trainer's CURRENT parameters, results on the host (for parity_vs_oracle)."""
+    from lichtfeld_studio_amd.fused import render_and_backward
+    grads = [torch.zeros_like(p) for p in trainer.model.parameters()]
+    loss = torch.zeros(1, device=target_dev.device)
+    out = render_and_backward(trainer.camera(view), trainer.model, trainer.bg, target_dev, 1.0, grads, loss, accumulate=False)
+    names = ["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"]
+    res = {"render": out.image_hwc.cpu().numpy(), "alpha": out.alpha.cpu().numpy(), "radii": out.radii.cpu().numpy(), "loss": float(loss),
+           "grads": {k: g.cpu().numpy() for k, g in zip(names, grads)}}
+    res["n_isects"] = out.n_isects
+    return res
 
 
 def main() -> None:
@@ -196,6 +183,9 @@ def main() -> None:
                          sh_sharded=False if args.replicated else None)
     trainer.iteration = args.start_iteration
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
+    hip_step = None
+    if world == 1 and not args.no_cpu_baseline and args.rasterizer == "gut" and trainer.sh_exchange is None:
+        hip_step = hip_reference_step(trainer, 0, targets[0])   # before any update: the oracle starts from the same parameters
 
     # Warm-up. Its last (up to 3) steps run with every kernel scope timed (HIP events on the launch stream): that gives the
     # per-kernel table and names the dominant kernel. Inside the timed region only that kernel is bracketed with events
@@ -280,7 +270,7 @@ def main() -> None:
     if world == 1 and not args.no_cpu_baseline:
         threads = args.cpu_threads or (os.cpu_count() or 1)
         try:
-            cpu = cpu_baseline(scene, 0, scenes.target_image(scene.height, scene.width, seed=43), threads)
+            cpu = cpu_baseline(scene, 0, scenes.target_image(scene.height, scene.width, seed=43), threads, hip_step)
         except Exception as e:  # the oracle is optional at bench time; say so instead of failing the run
             cpu = {"value": None, "unit": "train-images/sec", "cores": threads, "kind": "port", "sample": f"failed: {e}"}
         try:  # and the reference's own CPU code at the size it can run (north star: "the reference's CPU torch_impl path timed on the same box")

@@ -24,7 +24,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=h
 # when HBM-bound); the VALU-bound rasterizer uses fused multiply-adds.
 SOURCES = {
     "projection_ut.hip": ["-ffp-contract=off"],
-    "sh.hip": ["-ffp-contract=off"],
+    # LFS_SH_DPP_SUM: the 16-lane sums as DPP row operations instead of ds_bpermute - bit-identical sums (tests/test_emulated_sh.py),
+    # GPU-verified in round 2 (tests/test_gpu_projection_sh.py + test_gpu_fused.py green on the variant build; sh_fwd 0.0755 -> 0.0704 ms)
+    "sh.hip": ["-ffp-contract=off", "-DLFS_SH_DPP_SUM"],
     "intersect.hip": ["-ffp-contract=off"],
     "mcmc.hip": ["-ffp-contract=off"],
     "adam.hip": ["-ffp-contract=off"],

@@ -87,7 +87,8 @@ EXPORTS = [
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "liblfs_gsplat.so")
+    # LFS_GSPLAT_LIB: developer A/B of a differently built variant of the SAME library (tools/build_variant.sh); never a fallback
+    return os.environ.get("LFS_GSPLAT_LIB") or os.path.join(_HERE, "liblfs_gsplat.so")
 
 
 def load_library():

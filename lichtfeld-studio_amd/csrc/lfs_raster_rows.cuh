@@ -56,30 +56,70 @@ LFS_DI int32_t wave_max_i32(int32_t v) {
 // this lane's 16 bits of a wavefront ballot, i.e. "any / which lanes of my row"
 LFS_DI uint32_t row_bits(uint64_t ballot, uint32_t row) { return uint32_t(ballot >> (row * 16u)) & 0xffffu; }
 
-// Field F (dword index inside the 64-byte record) of the row's record: lane l of the row holds dword l. The broadcast rides on the DPP
-// operand of the consuming VOP2 instruction (the compiler folds row_newbcast into v_mul but not into v_fmac, hence the asm): a record field
-// costs no instruction of its own. DPP reads lanes of the whole row, so these run in wave-converged code only (a source lane that is masked
-// off would read as 0), and the record register comes straight from a load (a VALU write right before a DPP read needs two wait states).
+// Field F (dword index inside the 64-byte record) of the row's record: lane l of the row holds dword l, `row_newbcast:F` hands it to all 16
+// lanes. DPP reads lanes of the whole row, so everything here runs in wave-converged code only (a masked-off source lane would read as 0).
+// Single fields go through the builtin: the compiler folds the broadcast into a consuming v_mul / v_sub and keeps the gfx9 DPP hazard itself
+// (ANY VGPR a DPP instruction reads - the permuted operand, the plain one, the accumulator of v_fmac - must have been written two wait states
+// earlier by a VALU instruction). It does not fold DPP into v_fmac, so the two places with three parallel chains are asm blocks that keep the
+// hazard by construction: a leading `s_nop 1` covers the inputs, inside a block an instruction only reads registers written >= 3 instructions
+// earlier. (First GPU run of round 2: single-instruction asm statements without the nops were WRONG on hardware - lanes 0-3 / 8-11 of each row
+// - while the emulator, which has no pipeline, agreed; tools/debug_rows.py.) Asm outputs must never feed a DPP builtin directly: the hazard
+// recognizer does not look inside inline asm.
 template <int F> LFS_DI float row_field(float rec) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(rec), DPP_NEWBCAST0 + F, 0xf, 0xf, true)); }
-#ifdef LFS_EMULATE // host build of tests/emul: the DPP operand spelled out
 template <int F> LFS_DI float mul_field(float rec, float b) { return row_field<F>(rec) * b; }
-template <int F> LFS_DI float fma_field(float rec, float b, float acc) { return __builtin_fmaf(row_field<F>(rec), b, acc); }
-LFS_DI float dpp_ready(float rec) { return rec; }
+#if defined(LFS_EMULATE) || defined(LFS_ROWS_NO_ASM) // host build of tests/emul (and a developer A/B build): the DPP operands spelled out
+// (rows 0, 4, 8 of the record matrix) . x: per row the chain x.x * m0, then fma with m1, then with m2 (lfs_raster_common.cuh's fma3)
+LFS_DI f3 row_mat3(float rec, const f3& x) {
+    return {__builtin_fmaf(row_field<2>(rec), x.z, __builtin_fmaf(row_field<1>(rec), x.y, row_field<0>(rec) * x.x)),
+            __builtin_fmaf(row_field<6>(rec), x.z, __builtin_fmaf(row_field<5>(rec), x.y, row_field<4>(rec) * x.x)),
+            __builtin_fmaf(row_field<10>(rec), x.z, __builtin_fmaf(row_field<9>(rec), x.y, row_field<8>(rec) * x.x))};
+}
+// pix[c] = fma(colour c (fields 13..15), s, pix[c])
+template <int CDIM> LFS_DI void row_color_fma(float rec, float s, float (&pix)[CDIM]) {
+    pix[0] = __builtin_fmaf(row_field<13>(rec), s, pix[0]);
+    if (CDIM > 1) pix[1] = __builtin_fmaf(row_field<14>(rec), s, pix[1]);
+    if (CDIM > 2) pix[2] = __builtin_fmaf(row_field<15>(rec), s, pix[2]);
+}
+// sum_c colour c * vc[c]
+template <int CDIM> LFS_DI float row_color_dot(float rec, const float (&vc)[CDIM]) {
+    float cv = row_field<13>(rec) * vc[0];
+    if (CDIM > 1) cv += row_field<14>(rec) * vc[1];
+    if (CDIM > 2) cv += row_field<15>(rec) * vc[2];
+    return cv;
+}
 #else
-template <int F> LFS_DI float mul_field(float rec, float b) { // field F * b
-    float d;
-    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(rec), "v"(b), "n"(F));
-    return d;
+#define LFS_NB(F) " row_newbcast:" #F " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+LFS_DI f3 row_mat3(float rec, const f3& x) {
+    float q0, q1, q2;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %3, %4" LFS_NB(0) "v_mul_f32_dpp %1, %3, %4" LFS_NB(4) "v_mul_f32_dpp %2, %3, %4" LFS_NB(8)
+        "v_fmac_f32_dpp %0, %3, %5" LFS_NB(1) "v_fmac_f32_dpp %1, %3, %5" LFS_NB(5) "v_fmac_f32_dpp %2, %3, %5" LFS_NB(9)
+        "v_fmac_f32_dpp %0, %3, %6" LFS_NB(2) "v_fmac_f32_dpp %1, %3, %6" LFS_NB(6) "v_fmac_f32_dpp %2, %3, %6" LFS_NB(10)
+        : "=&v"(q0), "=&v"(q1), "=&v"(q2) : "v"(rec), "v"(x.x), "v"(x.y), "v"(x.z));
+    return {q0, q1, q2};
 }
-template <int F> LFS_DI float fma_field(float rec, float b, float acc) { // fma(field F, b, acc)
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(rec), "v"(b), "n"(F));
-    return acc;
+template <int CDIM> LFS_DI void row_color_fma(float rec, float s, float (&pix)[CDIM]) {
+    if constexpr (CDIM == 1) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2" LFS_NB(13) : "+v"(pix[0]) : "v"(rec), "v"(s));
+    if constexpr (CDIM == 2) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %2, %3" LFS_NB(13) "v_fmac_f32_dpp %1, %2, %3" LFS_NB(14) : "+v"(pix[0]), "+v"(pix[1]) : "v"(rec), "v"(s));
+    if constexpr (CDIM >= 3) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %3, %4" LFS_NB(13) "v_fmac_f32_dpp %1, %3, %4" LFS_NB(14) "v_fmac_f32_dpp %2, %3, %4" LFS_NB(15)
+                                 : "+v"(pix[0]), "+v"(pix[1]), "+v"(pix[2]) : "v"(rec), "v"(s));
 }
-// two wait states between the last VALU write of the record register (a register copy the compiler may have placed) and its first DPP read
-LFS_DI float dpp_ready(float rec) { asm volatile("s_nop 1" : "+v"(rec)); return rec; }
+template <int CDIM> LFS_DI float row_color_dot(float rec, const float (&vc)[CDIM]) {
+    if constexpr (CDIM == 1) {
+        return row_field<13>(rec) * vc[0];
+    } else if constexpr (CDIM == 2) {
+        float p0, p1;
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %2, %3" LFS_NB(13) "v_mul_f32_dpp %1, %2, %4" LFS_NB(14) : "=&v"(p0), "=&v"(p1) : "v"(rec), "v"(vc[0]), "v"(vc[1]));
+        return p0 + p1;
+    } else {
+        float p0, p1, p2;
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %3, %4" LFS_NB(13) "v_mul_f32_dpp %1, %3, %5" LFS_NB(14) "v_mul_f32_dpp %2, %3, %6" LFS_NB(15)
+            : "=&v"(p0), "=&v"(p1), "=&v"(p2) : "v"(rec), "v"(vc[0]), "v"(vc[1]), "v"(vc[2]));
+        return (p0 + p1) + p2;
+    }
+}
+#undef LFS_NB
 #endif
-// fma3(row F, F+1, F+2 of the record matrix; x) = the chain of lfs_raster_common.cuh's fma3: x.x * m0, then fma with m1, then with m2
-template <int F> LFS_DI float row_dot(float rec, const f3& x) { return fma_field<F + 2>(rec, x.z, fma_field<F + 1>(rec, x.y, mul_field<F>(rec, x.x))); }
 
 // ray_eval (raster.hip) with the record in the row: the same operations in the same order, operand for operand
 template <int MODE>
@@ -88,9 +128,9 @@ LFS_DI void ray_eval_row(const float rec, const f3& ro, const f3& d, RayEval& e)
     f3 gro{row_field<3>(rec), row_field<7>(rec), row_field<11>(rec)};
     if (MODE == RAY_ROLLING) {
         e.om = {ro.x - gro.x, ro.y - gro.y, ro.z - gro.z};
-        gro = {row_dot<0>(rec, e.om), row_dot<4>(rec, e.om), row_dot<8>(rec, e.om)};
+        gro = row_mat3(rec, e.om);
     }
-    const f3 q{row_dot<0>(rec, d), row_dot<4>(rec, d), row_dot<8>(rec, d)};
+    const f3 q = row_mat3(rec, d);
     const float l = fma3(q.x, q.x, q.y, q.y, q.z, q.z);
     const float rl = l > 0.f ? fast_rcp(l) : 0.f;
     e.t = fma3(gro.x, q.x, gro.y, q.y, gro.z, q.z) * rl;
@@ -357,7 +397,7 @@ __global__ void __launch_bounds__(256) raster_fwd_rows_kernel(
         const bool mine = k < rl.cnt; // this row still has an entry at position k
         if ((k & 1) == 0 && __ballot(mine && thr < INF) == 0ull) break;
         const int2 e = e0;
-        const float rec = dpp_ready(r0);
+        const float rec = r0;
         e0 = e1; e1 = e2; e2 = rl.ent(min(k + 3, last));
         r0 = r1; r1 = rl.rec(e1.x);
 
@@ -374,10 +414,7 @@ __global__ void __launch_bounds__(256) raster_fwd_rows_kernel(
         const float vis = alpha * T;
         // (the DPP operands need the whole row: compute unconditionally, select afterwards)
         if (CDIM <= 3) {
-            const float p0 = fma_field<13>(rec, vis, pix[0]);
-            pix[0] = contrib ? p0 : pix[0];
-            if (CDIM > 1) { const float p1 = fma_field<14>(rec, vis, pix[1]); pix[1] = contrib ? p1 : pix[1]; }
-            if (CDIM > 2) { const float p2 = fma_field<15>(rec, vis, pix[2]); pix[2] = contrib ? p2 : pix[2]; }
+            row_color_fma<CDIM>(rec, contrib ? vis : 0.f, pix); // (fma with 0 leaves pix[c] bit for bit: colours are finite)
         } else if (contrib) {
             const float* cp = colors + size_t(e.x) * CDIM;
 #pragma unroll
@@ -513,14 +550,15 @@ __global__ void __launch_bounds__(256) raster_bwd_rows_kernel(
     for (int32_t k = 0; k < nmax; ++k) {
         const bool mine = k < n_walk;
         const int2 e = e0;
-        const float rec = dpp_ready(r0);
+        const float rec = r0;
         e0 = e1; e1 = e2; e2 = rw.ent(max(first - (k + 3), 0));
         r0 = r1; r1 = rw.rec(e1.x);
 
         RayEval re;
         ray_eval_row<MODE>(rec, ro, rd, re);
         const float vis = re.vis;
-        const float araw = mul_field<12>(rec, vis);
+        const float opac = row_field<12>(rec);
+        const float araw = opac * vis;
         const float alpha = fminf(0.999f, araw);
         const bool valid = mine && e.y <= bin_final && !(alpha < (1.f / 255.f));
         const uint64_t vb = __ballot(valid);
@@ -534,9 +572,7 @@ __global__ void __launch_bounds__(256) raster_bwd_rows_kernel(
         const float fac = valid ? alpha * Tn : 0.f;
         float v[16], v_extra = 0.f, cv;
         if (CDIM <= 3) {
-            cv = mul_field<13>(rec, vc[0]);
-            if (CDIM > 1) cv = fma_field<14>(rec, vc[1], cv);
-            if (CDIM > 2) cv = fma_field<15>(rec, vc[2], cv);
+            cv = row_color_dot<CDIM>(rec, vc);
         } else {
             const float* cp = colors + size_t(e.x) * CDIM;
             cv = cp[0] * vc[0];
@@ -554,7 +590,7 @@ __global__ void __launch_bounds__(256) raster_bwd_rows_kernel(
         for (int c = CDIM; c < 3; ++c) v[13 + c] = 0.f;
         const float v_op = (valid && araw <= 0.999f) ? vis * v_alpha : 0.f;
         v[12] = v_op;
-        const float sgeo = mul_field<12>(rec, v_op);
+        const float sgeo = opac * v_op;
         const f3 a = re.w * sgeo;
         const f3 vg = a * re.t;
         v[0] = vg.x * rd.x; v[1] = vg.x * rd.y; v[2] = vg.x * rd.z;

@@ -6,16 +6,17 @@ its own runs):
   forward : mean |rgb diff| <= 2e-6; <= 0.1 % of pixels deviate by more than 1/255 + 1e-4 (one
             alpha-threshold / early-termination flip moves a pixel by at most one contribution);
             alpha likewise; last_ids equal on >= 99.9 % of the pixels.
-  backward: per-tensor relative L2 error vs the fp64 oracle <= 1e-2 in total and <= 2e-4 once the 0.2 %
-            worst Gaussians are set aside (measured: ~1e-5; ONE alpha-threshold flip at one pixel moves
-            one Gaussian's geometry gradient by ~1e-3 of the tensor norm), same vs the fp32 oracle up to
-            its own distance from fp64; the oracle's forward outputs are fed to both sides.
+  backward: per-tensor relative L2 error vs the fp64 oracle <= 2e-4 (measured: ~1e-5) with the threshold-flip
+            Gaussians COUNTED (gpu_util.rows_check: <= 2 rows per tensor may be off by more than 1 % of the
+            largest row - ONE alpha-threshold flip at one pixel moves one Gaussian's geometry gradient by
+            ~1e-3 of the tensor norm), same vs the fp32 oracle up to its own distance from fp64; the
+            oracle's forward outputs are fed to both sides. At the full 1M / 3M sizes: test_gpu_headline_parity.py.
 """
 import numpy as np
 import pytest
 import torch
 
-from gpu_util import make_gaussians, n, pinhole_K, rel_l2, rel_l2_rows, small_rotation_viewmat, t
+from gpu_util import make_gaussians, n, pinhole_K, rel_l2, rows_check, small_rotation_viewmat, t
 
 pytestmark = pytest.mark.gpu
 
@@ -40,7 +41,7 @@ def _lists(oracle, means, quats, scales, opac, vm0, vm1, K, W, H, ts, model, shu
 
 
 def _run(oracle, lfs, ops, rng, N, W, H, ts=16, C=1, cdim=3, bg=True, masks=None, model=None, shutter=None, rad=None, tan=None, thin=None,
-         vm1=None, spread=1.0, smin=0.01, smax=0.06, check_bwd=True):
+         vm1=None, spread=1.0, smin=0.01, smax=0.06, check_bwd=True, bwd_bar=2e-4):
     model = lfs.CameraModelType.PINHOLE if model is None else model
     shutter = lfs.ShutterType.GLOBAL if shutter is None else shutter
     means, quats, scales, opac = make_gaussians(rng, N, spread=spread, smin=smin, smax=smax)
@@ -81,11 +82,16 @@ def _run(oracle, lfs, ops, rng, N, W, H, ts=16, C=1, cdim=3, bg=True, masks=None
     for name, a, b, c in zip(["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"], gg, og, og64):
         assert a.shape == tuple(b.shape), name
         assert np.isfinite(n(a)).all(), name
-        # fp64 oracle = truth. Threshold flips (alpha vs 1/255 with __expf vs exp) hit single (pixel, Gaussian)
-        # pairs: bound their total effect loosely and require tight agreement once the 0.2 % worst rows are set aside.
-        assert rel_l2(n(a), c) < 1e-2, (name, rel_l2(n(a), c))
-        assert rel_l2_rows(n(a), c, drop_frac=0.002) < 2e-4, (name, rel_l2_rows(n(a), c, 0.002))
-        assert rel_l2_rows(n(a), b, drop_frac=0.002) < max(2e-4, 3 * rel_l2(b, c)), (name, rel_l2_rows(n(a), b, 0.002))
+        # fp64 oracle = truth. An alpha-threshold flip (alpha vs 1/255 or the 0.999 cap, v_exp_f32 vs exp) hits single (pixel, Gaussian) pairs:
+        # such rows are counted (<= 2 per tensor in these 3 000 - 10 000-Gaussian scenes) and everything else has to agree to 2e-4.
+        def per_gauss(x):   # one row per Gaussian (per (camera, Gaussian) for colours and opacities)
+            x = np.asarray(x)
+            return x.reshape(-1, 1) if name == "v_opacities" else x.reshape(-1, x.shape[-1])
+        e64, flips64, rest64 = rows_check(per_gauss(n(a)), per_gauss(c), bar=bwd_bar, max_flips=2)
+        e32, flips32, rest32 = rows_check(per_gauss(n(a)), per_gauss(b), bar=max(bwd_bar, 3 * rel_l2(b, c)), max_flips=2)
+        print(f"raster bwd {name}: vs fp64 oracle rel-L2 {e64:.2e} flips {flips64} rest {rest64:.2e} | vs fp32 oracle {e32:.2e} flips {flips32} rest {rest32:.2e}")
+        assert rest64 < bwd_bar, (name, e64, flips64, rest64)
+        assert rest32 < max(bwd_bar, 3 * rel_l2(b, c)), (name, e32, flips32, rest32)
     return gg
 
 

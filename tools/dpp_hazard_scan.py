@@ -1,5 +1,5 @@
 """Developer check for hand-written DPP inline asm (csrc/lfs_raster_rows.cuh): on gfx9 a VALU instruction that writes a VGPR must be followed by two
-wait states before a DPP instruction reads that VGPR as its DPP operand; the compiler guarantees that for its own DPP instructions but cannot see
+wait states before a DPP instruction reads that VGPR (ANY operand: the first GPU run of round 2 showed the plain operand counts too); the compiler guarantees that for its own DPP instructions but cannot see
 into inline asm. Scans the disassembly of the built rasterizer object, straight-line code only (the first DPP use after a loop back-edge is
 covered by dpp_ready()'s s_nop).
     python tools/dpp_hazard_scan.py            # after python lichtfeld-studio_amd/build.py"""
@@ -39,7 +39,10 @@ def main():
             if "_dpp" not in l:
                 continue
             total += 1
-            src0 = regs(l.split(None, 1)[1].split(",")[1].split()[0])
+            ops_ = [o.split()[0] for o in l.split(None, 1)[1].split(",")]
+            src0 = set().union(*[regs(o) for o in ops_[1:]])   # every VGPR the DPP instruction reads ...
+            if l.startswith(("v_fmac", "v_mac")):
+                src0 |= regs(ops_[0])                          # ... including the accumulator of v_fmac
             ws, j = 0, i - 1
             while j >= 0 and ws < 2:
                 p = lines[j]
