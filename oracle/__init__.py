@@ -28,6 +28,8 @@ def build(ref: bool = True) -> None:
     subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True, capture_output=True)
     if ref and os.path.exists("/root/reference/tests/torch_impl.cpp"):
         subprocess.run(["make", "-C", _HERE, "ref"], check=True, capture_output=True)
+    if ref and os.path.exists("/root/reference/gsplat/ProjectionUT3DGSFused.cu"):   # the reference's device kernels as host code (ref_kernels.cpp)
+        subprocess.run(["make", "-C", _HERE, "refk"], check=True, capture_output=True)
 
 
 def lib():
@@ -340,3 +342,123 @@ def fastgs_backward(fwd, means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c
     dens = np.zeros((2, N), dt) if densification_info is None else _c(densification_info, dt).copy()
     getattr(lib(), f"orc_fastgs_backward_{sfx}")(*args, _p(img), _p(al), _p(nc), _p(gi), _p(ga), *[_p(x) for x in g], _p(dens))
     return (*g, dens)
+
+
+# ---- the reference's own DEVICE kernels on the CPU (oracle/_ref/libref_kernels.so; ref_kernels.cpp + ref_emul/) -------------------
+_REFK = None
+
+
+def refk_lib():
+    """gsplat/*.cu + fastgs Adam kernels of the reference, compiled in place as host code (`make -C oracle refk`); None when absent."""
+    global _REFK
+    if _REFK is None:
+        path = os.path.join(_HERE, "_ref", "libref_kernels.so")
+        if not os.path.exists(path):
+            return None
+        _REFK = C.CDLL(path)
+    return _REFK
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _coeffs(camera_model, radial, tangential, thin_prism):
+    """the kernels read fixed-size arrays per camera: pinhole 6 radial / 2 tangential / 4 thin-prism, fisheye 4 radial (Fwd.cu:100-121)"""
+    def pad(a, n):
+        if a is None:
+            return None
+        a = _f32(a)
+        out = np.zeros((a.shape[0], n), np.float32)
+        out[:, :min(n, a.shape[1])] = a[:, :n]
+        return out
+    if camera_model == FISHEYE:
+        return pad(radial, 4), None, None
+    return pad(radial, 6), pad(tangential, 2), pad(thin_prism, 4)
+
+
+def refk_projection_ut(means, quats, scales, opacities, viewmats0, viewmats1, Ks, width, height, eps2d=0.3, near_plane=0.01, far_plane=1e4,
+                       radius_clip=0.0, calc_compensations=False, camera_model=PINHOLE, ut_params=None, rs_type=GLOBAL,
+                       radial_coeffs=None, tangential_coeffs=None, thin_prism_coeffs=None):
+    means, quats, scales, opacities = _f32(means), _f32(quats), _f32(scales), _f32(opacities)
+    v0, v1, Ks = _f32(viewmats0), _f32(viewmats1), _f32(Ks)
+    rad, tan, thin = _coeffs(camera_model, radial_coeffs, tangential_coeffs, thin_prism_coeffs)
+    Cn, N = Ks.shape[0], means.shape[0]
+    radii = np.zeros((Cn, N, 2), np.int32)
+    means2d, depths, conics = np.zeros((Cn, N, 2), np.float32), np.zeros((Cn, N), np.float32), np.zeros((Cn, N, 3), np.float32)
+    comp = np.zeros((Cn, N), np.float32) if calc_compensations else None
+    ut = _ut(ut_params, np.float32)
+    refk_lib().refk_projection_ut(C.c_uint32(Cn), C.c_uint32(N), _p(means), _p(quats), _p(scales), _p(opacities), _p(v0), _p(v1), _p(Ks),
+                                  C.c_uint32(width), C.c_uint32(height), C.c_float(eps2d), C.c_float(near_plane), C.c_float(far_plane),
+                                  C.c_float(radius_clip), C.c_int(camera_model), _p(ut), C.c_int(rs_type), _p(rad), _p(tan), _p(thin),
+                                  _p(radii), _p(means2d), _p(depths), _p(conics), _p(comp))
+    return radii, means2d, depths, conics, comp
+
+
+def _refk_raster_args(means, quats, scales, colors, opacities, backgrounds, masks, width, height, tile_size, viewmats0, viewmats1, Ks,
+                      camera_model, rs_type, radial, tangential, thin, tile_offsets, flatten_ids, ut_params):
+    means, quats, scales, colors, opacities = _f32(means), _f32(quats), _f32(scales), _f32(colors), _f32(opacities)
+    bg = None if backgrounds is None or np.size(backgrounds) == 0 else _f32(backgrounds)
+    m = None if masks is None else np.ascontiguousarray(masks, np.uint8)
+    v0, v1, Ks = _f32(viewmats0), _f32(viewmats1), _f32(Ks)
+    rad, tan, th_ = _coeffs(camera_model, radial, tangential, thin)
+    offs, flat = _c(tile_offsets, np.int32), _c(flatten_ids, np.int32)
+    Cn, N, CD = offs.shape[0], means.shape[0], colors.shape[-1]
+    ut = _ut(ut_params, np.float32)
+    keep = (means, quats, scales, colors, opacities, bg, m, v0, v1, Ks, rad, tan, th_, offs, flat, ut)
+    args = [C.c_uint32(CD), C.c_uint32(Cn), C.c_uint32(N), C.c_uint32(flat.shape[0]), _p(means), _p(quats), _p(scales), _p(colors), _p(opacities), _p(bg),
+            _p(m), C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile_size), C.c_uint32(offs.shape[2]), C.c_uint32(offs.shape[1]), _p(v0), _p(v1), _p(Ks),
+            C.c_int(camera_model), _p(ut), C.c_int(rs_type), _p(rad), _p(tan), _p(th_), _p(offs), _p(flat)]
+    return keep, args, Cn, N, CD
+
+
+def refk_rasterize_fwd(means, quats, scales, colors, opacities, backgrounds, masks, width, height, tile_size, viewmats0, viewmats1, Ks,
+                       camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids, ut_params=None):
+    keep, args, Cn, N, CD = _refk_raster_args(means, quats, scales, colors, opacities, backgrounds, masks, width, height, tile_size, viewmats0, viewmats1,
+                                              Ks, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids, ut_params)
+    rc, ra, li = np.zeros((Cn, height, width, CD), np.float32), np.zeros((Cn, height, width, 1), np.float32), np.zeros((Cn, height, width), np.int32)
+    rcode = refk_lib().refk_rasterize_fwd(*args, _p(rc), _p(ra), _p(li))
+    assert rcode == 0
+    return rc, ra, li
+
+
+def refk_rasterize_bwd(means, quats, scales, colors, opacities, backgrounds, masks, width, height, tile_size, viewmats0, viewmats1, Ks,
+                       camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids,
+                       render_alphas, last_ids, v_render_colors, v_render_alphas, ut_params=None):
+    keep, args, Cn, N, CD = _refk_raster_args(means, quats, scales, colors, opacities, backgrounds, masks, width, height, tile_size, viewmats0, viewmats1,
+                                              Ks, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids, ut_params)
+    ra, li, vrc, vra = _f32(render_alphas), _c(last_ids, np.int32), _f32(v_render_colors), _f32(v_render_alphas)
+    v_means, v_quats, v_scales = np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32), np.zeros((N, 3), np.float32)
+    v_colors, v_opac = np.zeros((Cn, N, CD), np.float32), np.zeros((Cn, N), np.float32)
+    rcode = refk_lib().refk_rasterize_bwd(*args, _p(ra), _p(li), _p(vrc), _p(vra), _p(v_means), _p(v_quats), _p(v_scales), _p(v_colors), _p(v_opac))
+    assert rcode == 0
+    return v_means, v_quats, v_scales, v_colors, v_opac
+
+
+def refk_relocation(opacities, scales, ratios, binoms, n_max):
+    o, s, b, r = _f32(opacities).copy(), _f32(scales).copy(), _f32(binoms).copy(), np.ascontiguousarray(ratios, np.int32).copy()
+    no, ns = np.zeros_like(o), np.zeros_like(s)
+    refk_lib().refk_relocation(C.c_int64(o.shape[0]), _p(o), _p(s), _p(r), _p(b), C.c_int(n_max), _p(no), _p(ns))
+    return no, ns
+
+
+def refk_add_noise(raw_opacities, raw_scales, raw_quats, noise, means, current_lr):
+    o, s, q, n = _f32(raw_opacities).copy(), _f32(raw_scales).copy(), _f32(raw_quats).copy(), _f32(noise).copy()
+    m = np.array(means, dtype=np.float32, copy=True, order="C")
+    refk_lib().refk_add_noise(C.c_int64(o.shape[0]), _p(o), _p(s), _p(q), _p(n), _p(m), C.c_float(current_lr))
+    return m
+
+
+def refk_quats_to_rotmats(quats):
+    q = _f32(quats)
+    out = np.zeros((q.shape[0], 3, 3), np.float32)
+    refk_lib().refk_quats_to_rotmats(C.c_int64(q.shape[0]), _p(q), _p(out))
+    return out
+
+
+def refk_adam_step(param, exp_avg, exp_avg_sq, grad, lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp):
+    p, m, v = (np.array(x, dtype=np.float32, copy=True, order="C") for x in (param, exp_avg, exp_avg_sq))
+    g = _f32(grad)
+    refk_lib().refk_adam_step(C.c_int64(p.size), _p(p), _p(m), _p(v), _p(g), C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
+                              C.c_float(bc1_rcp), C.c_float(bc2_sqrt_rcp))
+    return p, m, v
