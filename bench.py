@@ -144,6 +144,10 @@ def main() -> None:
     ap.add_argument("--start-iteration", type=int, default=3000,
                     help="iteration counter the timed steps start from. Default 3000 = the steady state of a 7k-iteration run: SH degree 3 active and "
                          "FusedAdam updating shN (the reference skips shN while iteration <= 1000, fused_adam.cpp:68-70; pass 0 for that cheaper phase)")
+    ap.add_argument("--strategy", default="none", choices=["none", "mcmc"],
+                    help="mcmc = BASELINE.json configs[4]: strategies.MCMC (mcmc_optimization_params.json: SGLD noise every step, relocation of dead Gaussians "
+                         "every 100 iterations with the Relocation kernel, scale / opacity regularisers), max_cap = the scene's Gaussian count")
+    ap.add_argument("--bilateral-grid", action="store_true", help="BASELINE.json configs[4]: per-image 16x16x8 bilateral grid between render and loss (+ its TV loss and Adam)")
     ap.add_argument("--replicated", action="store_true", help="multi-GPU: keep shN replicated (59 floats / Gaussian all-reduced) instead of SH-sharded")
     ap.add_argument("--wide-cells", action="store_true", help="developer A/B: the experimental two-pixels-per-lane 16x8-cell rasterizer kernels (slower on SYN-B; see raster.hip)")
     ap.add_argument("--row-lists", default="split", choices=["split", "merged"], help="with --row-kernels: quadrant lists split from the cell lists (two kernels) or built in one pass")
@@ -179,8 +183,17 @@ def main() -> None:
         kw["sh_degree"] = 0
     scene = maker(**kw)
     n_views = scene.viewmats.shape[0]
-    trainer = GutTrainer(scene, device, iterations=7000, world=world, rank=rank, views_per_rank=args.views_per_rank, loss=args.loss, rasterizer=args.rasterizer,
-                         sh_sharded=False if args.replicated else None)
+    extra = {}
+    if args.strategy == "mcmc":
+        from lichtfeld_studio_amd import strategies
+        extra = dict(strategy="mcmc", opt_params=strategies.OptimizationParameters(iterations=30000, max_cap=scene.N))
+    trainer = GutTrainer(scene, device, iterations=30000 if args.strategy == "mcmc" else 7000, world=world, rank=rank, views_per_rank=args.views_per_rank,
+                         loss=args.loss, rasterizer=args.rasterizer, sh_sharded=False if args.replicated else None,
+                         use_bilateral_grid=args.bilateral_grid, **extra)
+    if args.strategy == "mcmc" and args.start_iteration == 3000:
+        # the warm-up must contain one refinement step (iteration 3000: relocation + its torch index kernels, whose first use loads ~20 code
+        # objects at 20 - 200 ms each); the timed window then holds warm steps only, one of them (every 100th) a refinement step
+        args.start_iteration = 3000 - max(2, args.warmup - 2)
     trainer.iteration = args.start_iteration
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
     hip_step = None
@@ -223,6 +236,14 @@ def main() -> None:
         capi.profile_filter(None)
     elapsed = lfs_dist.max_over_ranks(elapsed, device)
 
+    refine_ms = None
+    if args.strategy == "mcmc" and world == 1:   # one refinement step on its own (relocation of the dead Gaussians + the step around it)
+        trainer.iteration = (trainer.iteration // 100 + 1) * 100 - 1
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        trainer.train_step(targets)
+        torch.cuda.synchronize()
+        refine_ms = (time.perf_counter() - t1) * 1e3
     if rank != 0:
         return
     images = world * args.views_per_rank * args.steps
@@ -279,7 +300,7 @@ def main() -> None:
             cpu["reference_torch_impl"] = {"value": None, "sample": f"failed: {e}"}
 
     out = {
-        "metric": "train-images/sec (fwd+bwd+Adam), 1M Gaussians @1080p",
+        "metric": f"train-images/sec (fwd+bwd+Adam), {N / 1e6:g}M Gaussians @{scene.width}x{scene.height}",
         "value": round(images / elapsed, 3), "unit": "train-images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -289,6 +310,7 @@ def main() -> None:
                                f"16x16 tiles, {n_views} orbit cameras, {'MSE' if args.loss == 'mse' else 'L1 + 0.2 D-SSIM'} loss, default_optimization_params lrs",
                    "global_batch": world * args.views_per_rank, "views_per_rank": args.views_per_rank,
                    "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ""), "start_iteration": args.start_iteration,
+                   "strategy": args.strategy, "bilateral_grid": bool(args.bilateral_grid), "refine_step_ms": None if refine_ms is None else round(refine_ms, 3),
                    "visible_gaussians": V, "n_isects": I},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
     }

@@ -117,7 +117,14 @@ LFS_DI float dpp_mov(float v) { // row-local lane permutation (DPP): 0xB1 = lane
 // Every step but the last two HALVES the number of live values while folding lanes: v_permlane32_swap (lane halves),
 // v_permlane16_swap (row pairs), then lane^1 and lane^2 inside the quads (select + DPP add); two row rotations finish.
 // 35 VALU for 16 sums (a butterfly per value would be 16 x 6).
-LFS_DI void wave_sum16_atomic(const float (&v)[16], float* __restrict__ dst, const uint32_t lane) {
+// ACC selects what happens to the 16 totals. 0 (default): float atomics - the order in which the wavefronts of different cells reach a
+// Gaussian's row is not reproducible, so neither are the last bits of the sums (the reference's atomicAdd backward has the same property).
+// 1 / 2: the two passes of the DETERMINISTIC mode (lfs_set_debug_flags bit 4; tests and the PSNR comparison of DESIGN.md): pass 1 takes the
+// maximum of |total| per slot with an integer atomicMax on the float bits (order-independent), pass 2 converts every total to fixed point
+// with 40 fractional bits below that maximum's exponent and adds it with a 64-bit integer atomic (exact, associative): two runs give
+// bit-identical gradients. det64 = the int64 accumulator rows (16 per Gaussian), dst doubles as the uint32 maxima in passes 1 / 2.
+template <int ACC = 0>
+LFS_DI void wave_sum16_atomic(const float (&v)[16], float* __restrict__ dst, const uint32_t lane, unsigned long long* __restrict__ det64 = nullptr) {
     float w[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -140,7 +147,20 @@ LFS_DI void wave_sum16_atomic(const float (&v)[16], float* __restrict__ dst, con
     t += dpp_mov<0x124>(t);
     t += dpp_mov<0x128>(t);
     // lane L holds the total of v[4 * (L >> 4) + 2 * (L & 1) + ((L >> 1) & 1)]
-    if ((lane & 12) == 0) unsafeAtomicAdd(dst + 4 * (lane >> 4) + 2 * (lane & 1) + ((lane >> 1) & 1), t);
+    if ((lane & 12) == 0) {
+        const uint32_t slot = 4 * (lane >> 4) + 2 * (lane & 1) + ((lane >> 1) & 1);
+        if (ACC == 0) unsafeAtomicAdd(dst + slot, t);
+#ifndef LFS_EMULATE
+        else if (ACC == 1) atomicMax(reinterpret_cast<uint32_t*>(dst) + slot, __float_as_uint(t) & 0x7fffffffu);
+        else {
+            const uint32_t mbits = reinterpret_cast<const uint32_t*>(dst)[slot];
+            if (mbits != 0u && t != 0.f) {
+                const int e = max(int((mbits >> 23) & 0xffu), 1) - 127;                 // exponent of the slot's largest |total|
+                atomicAdd(det64 + slot, (unsigned long long)__float2ll_rn(ldexpf(t, 40 - e))); // |fixed| < 2^41; two's complement adds
+            }
+        }
+#endif
+    }
 }
 
 

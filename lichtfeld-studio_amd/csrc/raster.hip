@@ -56,10 +56,10 @@ static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 struct __attribute__((aligned(16))) CullRec { float4 a, b; };
 
 constexpr uint32_t LOSS_SLOTS = 256; // fused MSE: the wavefronts' partial sums are spread over this many addresses (one hot address costs ~0.08 ms)
-struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; CullRec* cull; int32_t* cell_count; int2* cell_list; int32_t* quad_count; int2* quad_list; size_t bytes; };
+struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; CullRec* cull; int32_t* cell_count; int2* cell_list; int32_t* quad_count; int2* quad_list; unsigned long long* det64; size_t bytes; };
 // cells = C * tiles * (tile_size/8)^2 ; the compacted per-cell lists hold at most (tile_size/8)^2 * n_isects entries
 // quads (experimental row kernels): four quadrant lists per cell on top
-static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, uint64_t cell_entries, bool quads) {
+static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, uint64_t cell_entries, bool quads, bool det = false) {
     RasterWs w; char* p = (char*)base; size_t o = 0;
     w.cams = (CamDev*)(p + o); o += align256(sizeof(CamDev) * C);
     w.recs = (GaussRec*)(p + o); o += align256(sizeof(GaussRec) * size_t(C) * N);
@@ -72,6 +72,8 @@ static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, ui
         w.quad_count = (int32_t*)(p + o); o += align256(sizeof(int32_t) * 4 * cells);
         w.quad_list = (int2*)(p + o); o += align256(sizeof(int2) * 4 * cell_entries);
     }
+    w.det64 = nullptr;
+    if (det) { w.det64 = (unsigned long long*)(p + o); o += align256(sizeof(unsigned long long) * ACC_STRIDE * size_t(C) * N); } // deterministic backward (debug bit 4)
     w.bytes = o;
     return w;
 }
@@ -424,9 +426,9 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 // weight * mean((clamp(render, 0, 1) - target)^2) from the forward image and the CHW target itself and adds the loss to *loss -
 // the arithmetic of l2_fused.hip's mse_loss_kernel per pixel, so v_render_colors is never materialised and the loss kernel's
 // pass over the image disappears.
-struct MseFuse { const float* render; const float* target; float scale; float* loss; };
+struct MseFuse { const float* render; const float* target; float scale; float* loss; unsigned long long* det64; };
 
-template <int CDIM, int MODE, bool LOSS = false>
+template <int CDIM, int MODE, bool LOSS = false, int ACC = 0>
 __global__ void __launch_bounds__(256) raster_bwd_kernel(
     const uint32_t C, const uint32_t N, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
     const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block,
@@ -486,7 +488,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) lsum += __shfl_xor(lsum, m, 64);
-        if (lane == 0 && lsum != 0.f) unsafeAtomicAdd(mse.loss + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (LOSS_SLOTS - 1)), lsum * mse.scale);
+        if (ACC != 1 && lane == 0 && lsum != 0.f) unsafeAtomicAdd(mse.loss + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (LOSS_SLOTS - 1)), lsum * mse.scale);
     }
     float T = T_final;
     // T_final * (v_alpha_out - bg . v_color_out): the transmittance-tail term of d/d(alpha)
@@ -568,7 +570,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
             v[6] -= a.z * om.x; v[7] -= a.z * om.y; v[8] -= a.z * om.z;
         }
         v[9] = a.x; v[10] = a.y; v[11] = a.z;
-        wave_sum16_atomic(v, acc + size_t(e.x) * ACC_STRIDE, lane);
+        wave_sum16_atomic<ACC>(v, acc + size_t(e.x) * ACC_STRIDE, lane, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
         if (CDIM > 3) {
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) v_extra += __shfl_xor(v_extra, m, 64);
@@ -1000,10 +1002,23 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
     v_scales[3 * gid] = vs[0]; v_scales[3 * gid + 1] = vs[1]; v_scales[3 * gid + 2] = vs[2];
 }
 
+// deterministic mode, after pass 2: acc[i] = fixed-point sum * 2^(e - 40) (e from the pass-1 maximum that acc[i] still holds as bits)
+__global__ void __launch_bounds__(256) raster_det_resolve_kernel(const size_t n, float* __restrict__ acc, const unsigned long long* __restrict__ det64) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t mbits = reinterpret_cast<const uint32_t*>(acc)[i];
+    float out = 0.f;
+    if (mbits != 0u) {
+        const int e = max(int((mbits >> 23) & 0xffu), 1) - 127;
+        out = float(ldexp(double((long long)det64[i]), e - 40)); // exact scaling; one rounding to float
+    }
+    acc[i] = out;
+}
+
 // "wide" = the experimental 16x8 cells with two pixels per lane (see the file header; opt-in). The workspace is always sized for the 8x8
 // geometry (ws_*: at least as many cells and list entries), so the choice never changes lfs_rasterize_workspace_bytes.
 struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid, wpt, ws_wpt; uint64_t cells, ws_cells; bool wide, rows, rows_merged; };
-static uint32_t g_debug_flags = 0; // bit 0: keep every tile-list entry in the cell lists (no culling); bit 1: the wide (two pixels per lane) kernels; bit 2: the quadrant-row kernels; bit 3: (with bit 2) quadrant lists straight from the tile lists
+static uint32_t g_debug_flags = 0; // bit 4: deterministic backward accumulation (two passes, 64-bit fixed point; 3 channels); bit 0: keep every tile-list entry in the cell lists (no culling); bit 1: the wide (two pixels per lane) kernels; bit 2: the quadrant-row kernels; bit 3: (with bit 2) quadrant lists straight from the tile lists
 static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom& g) {
     if (tile_size < 8 || tile_size > 64 || (tile_size & 7)) return false;
     g.tw = (cams->image_width + tile_size - 1) / tile_size;
@@ -1037,7 +1052,7 @@ extern "C" size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t
     cams.C = C; cams.image_width = image_width; cams.image_height = image_height;
     RasterGeom g;
     if (!raster_geom(&cams, tile_size, g) || n_isects < 0) return 0;
-    return raster_ws(nullptr, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), (g_debug_flags & 4u) != 0).bytes;
+    return raster_ws(nullptr, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), (g_debug_flags & 4u) != 0, (g_debug_flags & 16u) != 0).bytes;
 }
 
 static int raster_mode(const lfs_cameras* cams) {
@@ -1110,7 +1125,7 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
     if (uint64_t(n_isects) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
     const uint32_t C = cams->C;
-    RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), g.rows);
+    RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), g.rows, (g_debug_flags & 16u) != 0);
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N > 0 && (!means || !quats || !scales || !colors || !opacities)) return LFS_E_INVALID;
     if (n_isects > 0 && !flatten_ids) return LFS_E_INVALID;
@@ -1157,7 +1172,8 @@ static int raster_bwd_impl(
     if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
     if (uint64_t(n_isects) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
     const uint32_t C = cams->C;
-    RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), g.rows);
+    const bool det = (g_debug_flags & 16u) != 0 && channels == 3 && !g.rows && !g.wide;
+    RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), g.rows, (g_debug_flags & 16u) != 0);
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N == 0) return LFS_OK;
     if (!means || !quats || !scales || !colors || !opacities || !v_means || !v_quats || !v_scales || !v_colors || !v_opacities) return LFS_E_INVALID;
@@ -1169,6 +1185,7 @@ static int raster_bwd_impl(
     MseFuse mse_dev{};
     if (mse) { mse_dev = *mse; mse_dev.loss = w.acc + ACC_STRIDE * CN; } // the kernel adds into the slots, raster_finish folds them into *loss
     if (e != hipSuccess) return (int)e;
+    if (det) { e = hipMemsetAsync(w.det64, 0, sizeof(unsigned long long) * ACC_STRIDE * CN, s); if (e != hipSuccess) return (int)e; mse_dev.det64 = w.det64; }
     if (channels > 3) { e = hipMemsetAsync(v_colors, 0, sizeof(float) * channels * CN, s); if (e != hipSuccess) return (int)e; }
     // self-contained call: camera state, records and cell lists are rebuilt; "prepared" = the caller guarantees
     // the workspace still holds what the forward call with the same inputs left there
@@ -1186,7 +1203,14 @@ static int raster_bwd_impl(
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.quad_count, w.quad_list, int32_t(n_isects), \
                        render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors, mse_dev)
 #define LFS_BWD(CD, MODE) do { if (g.rows) LFS_BWD_ROWS(CD, MODE); else if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, CD, MODE); else LFS_BWD_K(raster_bwd_kernel, CD, MODE); } while (0)
-        if (mse) {
+        if (det) { // pass 1: per-slot maxima of |total| (integer atomicMax), pass 2: 64-bit fixed-point sums, then back to float
+#define LFS_BWD_DET(MODE, LOSSV) do { LFS_BWD_K(raster_bwd_kernel, 3, MODE, LOSSV, 1); LFS_BWD_K(raster_bwd_kernel, 3, MODE, LOSSV, 2); } while (0)
+            if (mse) { if (raster_mode(cams) == 0) LFS_BWD_DET(0, true); else LFS_BWD_DET(1, true); }
+            else { if (raster_mode(cams) == 0) LFS_BWD_DET(0, false); else LFS_BWD_DET(1, false); }
+#undef LFS_BWD_DET
+            const size_t n_acc = ACC_STRIDE * CN;
+            hipLaunchKernelGGL(raster_det_resolve_kernel, dim3(uint32_t((n_acc + 255) / 256)), dim3(256), 0, s, n_acc, w.acc, w.det64);
+        } else if (mse) {
             if (raster_mode(cams) == 0) { if (g.rows) LFS_BWD_ROWS(3, 0, true); else if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, 3, 0, true); else LFS_BWD_K(raster_bwd_kernel, 3, 0, true); }
             else { if (g.rows) LFS_BWD_ROWS(3, 1, true); else if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, 3, 1, true); else LFS_BWD_K(raster_bwd_kernel, 3, 1, true); }
         } else

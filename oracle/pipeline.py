@@ -25,8 +25,9 @@ def scene_arrays(scene):
                 viewmats=scene.viewmats.numpy(), Ks=scene.Ks.numpy(), width=scene.width, height=scene.height, sh_degree=scene.sh_degree)
 
 
-def train_image(sa: dict, view: int, target_chw: np.ndarray, tile: int = 16, backward: bool = True, bwd_dtype=np.float32) -> dict:
-    """-> dict of every stage's outputs; `seconds` = wall time of the whole image."""
+def train_image(sa: dict, view: int, target_chw: np.ndarray, tile: int = 16, backward: bool = True, bwd_dtype=np.float32, loss_fn=None) -> dict:
+    """-> dict of every stage's outputs; `seconds` = wall time of the whole image. `loss_fn(raw_render_chw, target_chw) -> (loss, dL/d raw_render_chw)`
+    replaces the clamped MSE (tests/convergence_l1ssim.py passes the reference's L1 + D-SSIM photometric loss, trainer.cpp:115-128)."""
     t0 = time.perf_counter()
     W, H, deg = sa["width"], sa["height"], sa["sh_degree"]
     means, raw_q, raw_s, raw_o = sa["means"], sa["raw_quats"], sa["raw_scales"], sa["raw_opacities"]
@@ -56,7 +57,11 @@ def train_image(sa: dict, view: int, target_chw: np.ndarray, tile: int = 16, bac
     img = np.clip(raw, 0.0, 1.0)
     out["loss"] = float(((img.astype(np.float64) - target_chw) ** 2).mean())
     if backward:
-        v_img = (2.0 * (img - target_chw) / img.size * ((raw >= 0) & (raw <= 1))).astype(np.float32)
+        if loss_fn is not None:
+            out["loss"], v_img = loss_fn(np.ascontiguousarray(raw), target_chw)
+            v_img = np.asarray(v_img, np.float32)
+        else:
+            v_img = (2.0 * (img - target_chw) / img.size * ((raw >= 0) & (raw <= 1))).astype(np.float32)
         v_rc = np.ascontiguousarray(v_img.transpose(1, 2, 0))[None]
         out["v_render"] = v_rc
         gm, gq, gs, gc, go = rasterize_bwd(*args, ra, li, v_rc, np.zeros_like(ra), dtype=bwd_dtype)

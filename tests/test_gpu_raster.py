@@ -311,3 +311,44 @@ def test_prepared_backward_equals_self_contained_backward(lfs, oracle_mod):
     gb = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra)
     for a, b in zip(ga, gb):
         assert float((a - b).norm() / (b.norm() + 1e-30)) < 1e-5
+
+
+def test_deterministic_backward_mode_is_bit_reproducible(lfs, oracle_mod):
+    """lfs_set_debug_flags(16): the backward's per-Gaussian sums go through order-independent integer atomics (maximum of |total| per slot, then
+    64-bit fixed-point adds 40 bits below it) instead of float atomics: repeated runs are BIT-identical, and the result agrees with the
+    default mode to the float-atomics' own rounding noise. Also through the fused training step (loss folded into the backward)."""
+    from lichtfeld_studio_amd import ops, scenes
+    from lichtfeld_studio_amd.fused import render_and_backward
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    rng = np.random.default_rng(77)
+    N, W, H = 20000, 320, 240
+    means, quats, scales, opac = make_gaussians(rng, N, smin=0.01, smax=0.08)
+    vm0 = np.stack([small_rotation_viewmat(rng, 0.05, 0.1)])
+    K = pinhole_K(0.8 * W, W, H, 1)
+    colors = rng.random((1, N, 3)).astype(np.float32)
+    offs, flat = _lists(oracle_mod, means, quats, scales, opac, vm0, None, K, W, H, 16, lfs.CameraModelType.PINHOLE, lfs.ShutterType.GLOBAL, None, None, None)
+    args = (t(means), t(quats), t(scales), t(colors), t(opac[None]), t(rng.random((1, 3)).astype(np.float32)), None, W, H, 16, t(vm0), None, t(K),
+            lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, t(offs, torch.int32), t(flat, torch.int32))
+    rc, ra, li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
+    v_rc, v_ra = torch.randn_like(rc), torch.randn_like(ra)
+    ref = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra)
+    lib = lfs.load_library()
+    try:
+        lib.lfs_set_debug_flags(16)
+        runs = [ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra) for _ in range(3)]
+        sc = scenes.syn_a(n=8000, sh_degree=1)
+        target = scenes.target_image(sc.height, sc.width).to("cuda:0")
+        fused = []
+        for _ in range(2):
+            tr = GutTrainer(sc, torch.device("cuda:0"), iterations=100)
+            grads = [torch.zeros_like(p) for p in tr.model.parameters()]
+            loss = torch.zeros(1, device="cuda:0")
+            render_and_backward(tr.camera(0), tr.model, tr.bg, target, 1.0, grads, loss, accumulate=False)
+            fused.append([g.clone() for g in grads])
+    finally:
+        lib.lfs_set_debug_flags(0)
+    for name, a, b, c, r in zip(["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"], *runs, ref):
+        assert torch.equal(a, b) and torch.equal(a, c), name
+        assert torch.isfinite(a).all() and rel_l2(n(a), n(r)) < 1e-5, (name, rel_l2(n(a), n(r)))
+    for a, b in zip(*fused):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
