@@ -170,6 +170,7 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     capi.load_library()
     rank, world, local_rank = lfs_dist.init_distributed()
+    lfs_dist.stats_enable(timing=world > 1 or bool(os.environ.get("LFS_DIST_FORCE_COLLECTIVES")))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if os.environ.get("LFS_DIST_BACKEND") == "gloo":   # smoke mode: all ranks share the visible device(s)
@@ -220,6 +221,8 @@ def main() -> None:
     dom = max(table.items(), key=lambda kv: kv[1][0])[0] if table else None
     lfs_dist.barrier()
     torch.cuda.synchronize()
+    seen = lfs_dist.ranks_seen(device)
+    lfs_dist.stats_enable(timing=world > 1 or bool(os.environ.get("LFS_DIST_FORCE_COLLECTIVES")))   # count the timed steps only
     if dom:
         capi.profile_filter(dom)
         capi.profile_enable(True)
@@ -235,6 +238,7 @@ def main() -> None:
         kernels = capi.profile_collect()
         capi.profile_filter(None)
     elapsed = lfs_dist.max_over_ranks(elapsed, device)
+    coll = lfs_dist.stats_collect()   # this rank's collectives inside the timed steps: calls, payload bytes, device ms (ms of the async early all-reduce = until its wait)
 
     refine_ms = None
     if args.strategy == "mcmc" and world == 1:   # one refinement step on its own (relocation of the dead Gaussians + the step around it)
@@ -312,6 +316,8 @@ def main() -> None:
                    "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ""), "start_iteration": args.start_iteration,
                    "strategy": args.strategy, "bilateral_grid": bool(args.bilateral_grid), "refine_step_ms": None if refine_ms is None else round(refine_ms, 3),
                    "visible_gaussians": V, "n_isects": I},
+        "collectives": {"backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None), "ranks_seen": seen,
+                        "per_step": {k: {"calls": v["calls"] / args.steps, "MB": round(v["bytes"] / args.steps / 1e6, 3), "ms": round(v["ms"] / args.steps, 4)} for k, v in coll.items()}},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
     }
     print(json.dumps(out), flush=True)

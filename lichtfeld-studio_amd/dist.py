@@ -20,13 +20,65 @@ def init_distributed(backend: Optional[str] = None) -> tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:  # LFS_DIST_BACKEND=gloo: several ranks on one GPU (tests / smoke runs; collectives staged through the host)
             backend = os.environ.get("LFS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+# LFS_DIST_FORCE_COLLECTIVES=1: issue every collective even at world size 1 (tests/test_gpu_rccl_world1.py: the RCCL code path - device
+# tensors handed to backend "nccl" - executes on a single GPU; RCCL refuses two ranks per device, so this is the only way to run it there).
+_FORCE = bool(os.environ.get("LFS_DIST_FORCE_COLLECTIVES"))
+
+
+def _active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+
+
+# ---- per-collective accounting (bench.py --gpus N prints it): calls, payload bytes and, when timing is on, device milliseconds -------------
+STATS: dict = {}
+_TIMING = False
+_PENDING: list = []
+
+
+def stats_enable(timing: bool) -> None:
+    global _TIMING
+    STATS.clear(); _PENDING.clear()
+    _TIMING = timing
+
+
+def _account(kind: str, t: torch.Tensor):
+    st = STATS.setdefault(kind, {"calls": 0, "bytes": 0, "ms": 0.0})
+    st["calls"] += 1
+    st["bytes"] += t.numel() * t.element_size()
+    if _TIMING and t.is_cuda:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _PENDING.append((kind, a, b))
+        return b
+    return None
+
+
+def stats_collect() -> dict:
+    """resolves the recorded event pairs (synchronises) and returns {kind: {calls, bytes, ms}}"""
+    if _PENDING:
+        torch.cuda.synchronize()
+        for kind, a, b in _PENDING:
+            STATS[kind]["ms"] += a.elapsed_time(b)
+        _PENDING.clear()
+    return {k: dict(v, ms=round(v["ms"], 4)) for k, v in STATS.items()}
+
+
+def ranks_seen(device) -> int:
+    """how many ranks a sum all-reduce of ones reaches (bench line: proves the process group spans what --gpus claims)"""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
 
 
 def views_for_step(step: int, rank: int, world: int, n_views: int, views_per_rank: int = 1) -> List[int]:
@@ -52,12 +104,15 @@ class GradBucket:
         total = sum(self.sizes)
         self.flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
         self.views: List[Optional[torch.Tensor]] = [None] * len(params)
+        self.offsets = [0] * len(params)
+        self._early = None
         o = 0
         self.active_numel = total
         for i in order:
             if deferred and i == deferred[0]:
                 self.active_numel = o
             n, s = self.sizes[i], self.shapes[i]
+            self.offsets[i] = o
             self.views[i] = self.flat[o:o + n].view(s)
             o += n
 
@@ -68,17 +123,50 @@ class GradBucket:
             else:
                 v.copy_(g)
 
+    def _reduce(self, buf: torch.Tensor, kind: str, async_op: bool = False):
+        end = _account(kind, buf)
+        work = None
+        if _staged(buf):
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
+        else:
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=async_op)
+        if end is not None and not async_op:
+            end.record()
+        return work, end
+
     def all_reduce(self, average: bool = False, skip_deferred: bool = False) -> None:
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            buf = self.flat[:self.active_numel] if skip_deferred else self.flat
-            if _staged(buf):
-                host = buf.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                buf.copy_(host)
+        """Sum over ranks of the whole bucket (or its non-deferred prefix), minus whatever `all_reduce_early` already has in flight."""
+        if _active():
+            hi = self.active_numel if skip_deferred else self.flat.numel()
+            if self._early is not None:       # [lo_e, hi_e) is being reduced on RCCL's stream: reduce the two pieces around it, then wait
+                lo_e, hi_e, work, end = self._early
+                self._early = None
+                if lo_e > 0:
+                    self._reduce(self.flat[:lo_e], "all_reduce")
+                if hi > hi_e:
+                    self._reduce(self.flat[hi_e:hi], "all_reduce")
+                if work is not None:
+                    work.wait()               # the current stream waits for the collective's stream
+                if end is not None:
+                    end.record()
             else:
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                self._reduce(self.flat[:hi], "all_reduce")
             if average:
-                buf.div_(dist.get_world_size())
+                self.flat[:hi].div_(dist.get_world_size())
+
+    def all_reduce_early(self, indices: List[int]) -> None:
+        """Start the all-reduce of the parameters `indices` (contiguous in the flat buffer) NOW, asynchronously: RCCL runs it on its own
+        stream, ordered after what the current stream has enqueued so far, while the caller keeps launching kernels that do not touch those
+        gradients (the SH backward). `all_reduce()` later reduces the rest and waits. No-op at world 1."""
+        if not _active() or self._early is not None:
+            return
+        lo = min(self.offsets[i] for i in indices)
+        hi = max(self.offsets[i] + self.sizes[i] for i in indices)
+        assert sum(self.sizes[i] for i in indices) == hi - lo, "early segment must be contiguous in the bucket"
+        work, end = self._reduce(self.flat[lo:hi], "all_reduce_early", async_op=True)
+        self._early = (lo, hi, work, end)
 
 
 def _staged(t: torch.Tensor) -> bool:
@@ -121,29 +209,38 @@ class ShExchange:
     def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
         """send[j] goes to rank j; recv[j] came from rank j"""
         send = send.contiguous()
-        if self.world == 1 or not dist.is_initialized():
+        if not _active():
             return send.clone()
+        end = _account("all_to_all", send)
         if _staged(send):
             host, out = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
             dist.all_to_all_single(out, host)
-            return out.to(send.device)
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send)
+            recv = out.to(send.device)
+        else:
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send)
+        if end is not None:
+            end.record()
         return recv
 
     def gather_rows(self, shard_rows: torch.Tensor) -> torch.Tensor:
         """Owner shards [n_r, ...] -> the full [N, ...] tensor on every rank (export, evaluation, strategies)."""
         pad = torch.zeros((self.S,) + tuple(shard_rows.shape[1:]), dtype=shard_rows.dtype, device=shard_rows.device)
         pad[:self.n] = shard_rows
-        if self.world == 1 or not dist.is_initialized():
+        if not _active():
             return pad[:self.N]
+        end = _account("all_gather", pad)
         if _staged(pad):
             parts = [torch.empty(pad.shape, dtype=pad.dtype) for _ in range(self.world)]
             dist.all_gather(parts, pad.cpu())
-            return torch.cat(parts)[:self.N].to(pad.device)
-        parts = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(parts, pad)
-        return torch.cat(parts)[:self.N]
+            out = torch.cat(parts)[:self.N].to(pad.device)
+        else:
+            parts = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(parts, pad)
+            out = torch.cat(parts)[:self.N]
+        if end is not None:
+            end.record()
+        return out
 
     def forward(self, deg: int, means, sh0, shN_shard, radii, viewmats_all, sh_fwd_views):
         """radii [N,2] int32 of THIS rank's view; viewmats_all[j] = the [1,4,4] view matrix rank j renders now.
@@ -173,13 +270,16 @@ class ShExchange:
 
 def all_reduce_sum(t: torch.Tensor) -> None:
     """In-place sum over ranks of a replicated-side tensor (bilateral-grid gradient, densification_info); no-op at world 1."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
+        end = _account("all_reduce_small", t)
         if _staged(t):
             host = t.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             t.copy_(host)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if end is not None:
+            end.record()
 
 
 def barrier() -> None:

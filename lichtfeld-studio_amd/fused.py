@@ -120,7 +120,8 @@ class FusedStepOutput:
 
 def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
                         grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool, loss: str = "mse",
-                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None, adam_shN: Optional[dict] = None, adam_shard: Optional[dict] = None, bilateral=None, image_idx: int = 0) -> FusedStepOutput:
+                        lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None, adam_shN: Optional[dict] = None, adam_shard: Optional[dict] = None, bilateral=None, image_idx: int = 0,
+                        on_geometry_grads=None) -> FusedStepOutput:
     """One view: forward, loss against `target_chw` ("mse": the rasterizer-only metric of SURVEY.md §8d; "l1_ssim": the reference's
     photometric loss, trainer.cpp:115-128), backward. `grads` = six tensors shaped like model.parameters()
     (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
@@ -130,7 +131,9 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
     With `adam_shN` (FusedAdam.prepare_inline; one view per step on one rank) grads[2] is not written: shN is updated in place;
     `adam_shard` is the same for the owner's rows under `sh_exchange` (one view per rank and step).
     `bilateral` (bilateral_grid.BilateralGrid): the rendered image goes through grid `image_idx` before the loss (trainer.cpp:662-664); the grid's
-    gradient is accumulated into its .grad."""
+    gradient is accumulated into its .grad.
+    `on_geometry_grads()` (multi-GPU, last view of the step) is called as soon as the raw scale / quaternion / opacity gradients are final - before the
+    SH backward is enqueued - so their all-reduce (dist.GradBucket.all_reduce_early) overlaps with it on RCCL's stream."""
     assert camera.camera_model_type == CameraModelType.PINHOLE and camera.radial_distortion is None and camera.tangential_distortion is None, \
         "the fused path covers the trainer's undistorted pinhole cameras; use rasterizer.rasterize for the rest"
     W, H = int(camera.image_width), int(camera.image_height)
@@ -182,6 +185,10 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         else:
             v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
                 *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws)
+        # the regularisers of trainer.cpp:132-158 are per step, not per view: the caller passes them with the first view only
+        activations_bwd(raw_quats, scales, opac, v_quats, v_scales, v_opac.squeeze(0), g_quats, g_scales, g_opac, accumulate, scale_reg, opacity_reg)
+        if on_geometry_grads is not None:
+            on_geometry_grads()
         # SH backward adds dL/d(dirs) onto the rasterizer's dL/d(means) in place, then the means gradient lands in the caller's buffer
         if adam_shN is not None:     # single view, single rank: shN's gradient is consumed by its Adam update inside the SH backward
             assert sh_exchange is None and not accumulate
@@ -195,6 +202,4 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         if sh_exchange is not None:  # owners: SH backward of every rank's view for their rows (dL/d(dirs) straight into g_means)
             sh_exchange.backward(sh_ctx, deg, means, sh0, shN, viewmats_all, v_colors.squeeze(0), g_sh0, g_shN, g_means, accumulate, sh_model_bwd_views,
                                  adam=adam_shard)
-        # the regularisers of trainer.cpp:132-158 are per step, not per view: the caller passes them with the first view only
-        activations_bwd(raw_quats, scales, opac, v_quats, v_scales, v_opac.squeeze(0), g_quats, g_scales, g_opac, accumulate, scale_reg, opacity_reg)
     return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]))

@@ -257,7 +257,9 @@ class GutTrainer:
                                           scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
                                           opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0,
                                           sh_exchange=self.sh_exchange, viewmats_all=vm_all, adam_shN=inline, adam_shard=inline_shard,
-                                          bilateral=self.bilateral, image_idx=v)
+                                          bilateral=self.bilateral, image_idx=v,
+                                          # last view: scales / quats / opacities gradients are final before the SH backward starts - their all-reduce overlaps with it
+                                          on_geometry_grads=(lambda: self.bucket.all_reduce_early([3, 4, 5])) if (self.world > 1 and k == len(views) - 1) else None)
                 self.last_n_isects, self._last_radii = out.n_isects, out.radii
             # the deferred segment (shN) stays out of the all-reduce while Adam does not read it (iteration <= 1000) and, SH-sharded, always
             self.bucket.all_reduce(skip_deferred=self.iteration <= 1000 or self.sh_exchange is not None)

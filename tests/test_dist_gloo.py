@@ -258,3 +258,51 @@ def test_sh_sharded_exchange_matches_replicated_computation(world, N):
         assert np.allclose(results[rank][3], ref_sh0.numpy(), atol=2e-5)
         assert np.allclose(results[rank][4], ref_shN.numpy(), atol=2e-5), "all-gathered shard gradients == replicated shN gradient"
         assert np.array_equal(results[0][4], results[rank][4])
+
+
+def _worker_early(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import dist as ld
+    ld.init_distributed(backend="gloo")
+    ld.stats_enable(False)
+    N = 11
+    params = [torch.zeros(N, 3), torch.zeros(N, 1, 3), torch.zeros(N, 15, 3), torch.zeros(N, 3), torch.zeros(N, 4), torch.zeros(N)]   # the model's parameter order
+    g = torch.Generator().manual_seed(5 + rank)
+    grads = [torch.randn(p.shape, generator=g) for p in params]
+    out = {}
+    for skip in (True, False):
+        a = ld.GradBucket(params, deferred=[2]); a.gather(grads); a.all_reduce(skip_deferred=skip)
+        b = ld.GradBucket(params, deferred=[2]); b.gather(grads)
+        b.all_reduce_early([3, 4, 5])          # scales, quats, opacities: contiguous [6N, 14N) of the flat buffer
+        b.all_reduce(skip_deferred=skip)
+        out[skip] = ([v.clone().numpy() for v in a.views], [v.clone().numpy() for v in b.views])
+    st = ld.stats_collect()
+    q.put((rank, out, st, ld.ranks_seen(torch.device("cpu"))))
+    dist.destroy_process_group()
+
+
+def test_early_segment_all_reduce_equals_the_single_collective():
+    """GradBucket.all_reduce_early([scales, quats, opacities]) + all_reduce() (what the trainer does so that the geometry gradients travel
+    while the SH backward runs) gives exactly the sums of one all_reduce() over the same bucket; the deferred shN segment stays local when
+    skipped; the per-collective accounting counts three collectives and the right payload."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_early, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, out, st, seen in res:
+        assert seen == 2
+        for skip in (True, False):
+            single, split = out[skip]
+            for x, y in zip(single, split):
+                assert np.array_equal(x, y)
+        assert st["all_reduce_early"]["calls"] == 2 and st["all_reduce_early"]["bytes"] == 2 * 4 * 11 * 8
+        assert st["all_reduce"]["calls"] == 2 + 1 + 2   # two single collectives; the split ones: [0,6N) (+ [14N, 59N) when not skipped)
+    assert np.array_equal(res[0][1][False][1][2], res[1][1][False][1][2])            # shN summed over both ranks
+    assert not np.array_equal(res[0][1][True][1][2], res[1][1][True][1][2])          # ... and left local when deferred
