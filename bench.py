@@ -43,7 +43,9 @@ def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems
         "isect_scatter": 28 * N + 12 * I,
         "isect_tile_sort": 24 * I,
         "raster_pack": 60 * N + 64 * N + 32 * N,
-        "raster_cull": 4 * (4 * I + 32 * I) + 8 * 4 * I,  # every 8x8 cell reads its tile's ids + 32-B culling records, writes <= 8 B per entry
+        # the workgroup of a tile gathers id + 32-B culling record ONCE per list entry and shares it with its 4 cells through LDS (36 I); each cell keeps
+        # ~45 % of its tile's entries on SYN-B (measured: 8.1 M cell-list entries for 4.46 M intersections), 8 B each
+        "raster_cull": 36 * I + 8 * int(1.8 * I),
         "raster_fwd": 60 * I + 20 * P,
         "raster_bwd": 60 * I + 24 * P + 56 * N + 112 * V,   # (with the MSE loss folded in it reads render + target instead of v_render: + 12 P, not charged)
         "raster_finish": 64 * N + 44 * N + 56 * N,
@@ -55,6 +57,15 @@ def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems
         "mse_loss": 36 * P, "photometric_loss": 36 * P + 2 * 36 * P,
         "adam_multi": 28 * adam_elems,
         "adam": 28 * adam_elems,
+        # fastgs (EWA) path, SURVEY.md §8f row 1 - same accounting as the 3DGUT kernels: 64-B blend record + 4-B id per intersection, per-pixel
+        # state, the 64-B accumulator rows; preprocess reads the 44 B of raw geometry and writes record (64) + mean2d / conic / bounds (32)
+        "fastgs_preprocess": 44 * N + 96 * V + 8 * N,
+        "fastgs_scatter": 16 * V + 12 * I,
+        "fastgs_tile_sort": 24 * I,
+        "fastgs_cull": 36 * I + 8 * int(1.8 * I),
+        "fastgs_blend_fwd": 68 * I + 20 * P,
+        "fastgs_blend_bwd": 68 * I + 28 * P + 64 * N + 64 * V,
+        "fastgs_preprocess_bwd": 64 * N + 96 * V + 44 * N,
     }
 
 
@@ -277,8 +288,7 @@ def main() -> None:
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "alg_bytes_per_launch": int(bytes_per.get(dom, 0)), "avg_launch_ms": round(avg_s * 1e3, 4),
-                    "launches_timed": kernels[dom][1],
-                    "evals_per_s": round(256.0 * I / avg_s, 1) if dom.startswith("raster") else None}
+                    "launches_timed": kernels[dom][1]}
         # PMC-measured HBM traffic (separate rocprofv3 --pmc passes, see profiles/): filled when a
         # measurement for this exact workload has been committed.
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -288,6 +298,13 @@ def main() -> None:
                 ent = tj.get(f"{args.workload}:{N}", {}).get(dom)
                 if ent is not None:
                     roofline["traffic"] = ent
+                # the rasterizer kernels are VALU-issue bound, not HBM bound: next to the HBM fraction, the share of the launch during which the
+                # vector ALUs were issuing, from the PMC pass (SQ_INSTS_VALU wave-instructions x 4 cycles on a SIMD16, 1024 SIMDs, 2.4 GHz)
+                valu = tj.get(f"{args.workload}:{N}", {}).get("_valu_insts", {}).get(dom)
+                if valu is not None:
+                    roofline["valu"] = {"wave_insts_per_launch": valu, "issue_ms": round(valu * 4 / 1024 / 2.4e9 * 1e3, 4),
+                                        "issue_frac_of_launch": round(valu * 4 / 1024 / 2.4e9 / avg_s, 4),
+                                        "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/), 4 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz"}
             except Exception:
                 pass
 

@@ -6,7 +6,7 @@
  * /root/reference/fastgs/optimizer/include/adam.h, with the at::Tensor
  * arguments flattened to raw DEVICE pointers + sizes + a hipStream_t.
  * The libtorch wrappers that restore the exact Ops.h signatures live in
- * include/gsplat/Ops.h + lichtfeld-studio_amd/csrc/torch_ops.cpp.
+ * include/lfs_gsplat_torch.hpp + lichtfeld-studio_amd/csrc/torch_ops.cpp.
  *
  * Conventions (same as the reference):
  *   - all pointers are device pointers, contiguous, fp32 unless noted;

@@ -284,7 +284,8 @@ def init_model_from_pointcloud(pcd: PointCloud, scene_center, sh_degree: int = 3
     sh0 = ((colors - 0.5) / 0.28209479177387814).unsqueeze(1).contiguous()           # [N,1,3]
     shN = torch.zeros((means.shape[0], K - 1, 3), device=device)
     mk = lambda t: t.contiguous().requires_grad_(True)
-    model = SplatModel(mk(means), mk(sh0), mk(shN), mk(scaling), mk(rotation), mk(opacity.squeeze(-1)), sh_degree)
+    # a point-cloud initialisation starts at SH degree 0 (SplatData::_active_sh_degree{0}, splat_data.cpp:211); the strategies raise it
+    model = SplatModel(mk(means), mk(sh0), mk(shN), mk(scaling), mk(rotation), mk(opacity.squeeze(-1)), sh_degree, active_sh_degree=0)
     return model, scene_scale
 
 
@@ -426,5 +427,5 @@ def colmap_scene(base: str, images_folder: str = "images", split: str = "train",
     Ks = torch.from_numpy(np.stack([intrinsics(c, w, h) for c in used]))
     means, sh0, shN, scales, quats, opac = [p.detach().clone() for p in model.parameters()]
     scene = Scene(os.path.basename(os.path.normpath(base)), w, h, sh_degree, means, quats, scales, opac, sh0, shN, viewmats, Ks,
-                  {"scene_scale": scene_scale, "scene_center": center})
+                  {"scene_scale": scene_scale, "scene_center": center, "active_sh_degree": 0})   # GutTrainer starts the schedule at degree 0
     return scene.to(device), ds, scene_scale

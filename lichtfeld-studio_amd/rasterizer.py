@@ -40,10 +40,14 @@ class SplatModel:
     """Raw parameters + activations of gs::SplatData (src/core/splat_data.cpp:267-286):
     get_opacity = sigmoid, get_scaling = exp, get_rotation = normalize, get_shs = cat(sh0, shN)."""
 
-    def __init__(self, means, sh0, shN, raw_scales, raw_quats, raw_opacities, sh_degree: int):
+    def __init__(self, means, sh0, shN, raw_scales, raw_quats, raw_opacities, sh_degree: int, active_sh_degree: Optional[int] = None):
+        """sh_degree: the degree the coefficient tensors hold (max_sh_degree of SplatData); active_sh_degree: the degree evaluated now - the
+        reference starts a point-cloud initialisation at 0 (splat_data.cpp:211) and raises it every sh_degree_interval iterations
+        (increment_sh_degree, :387-391); loaded / synthetic models are born at the maximum (the default here)."""
         self.means, self.sh0, self.shN = means, sh0, shN
         self.raw_scales, self.raw_quats, self.raw_opacities = raw_scales, raw_quats, raw_opacities
-        self.active_sh_degree = sh_degree
+        self.max_sh_degree = sh_degree
+        self.active_sh_degree = sh_degree if active_sh_degree is None else min(active_sh_degree, sh_degree)
 
     def parameters(self):
         # param-group order of strategy_utils.cpp:35-40: means, sh0, shN, scaling, rotation, opacity

@@ -52,6 +52,14 @@ class OptimizationParameters:
     pause_refine_after_reset: int = 0
     revised_opacity: bool = False
 
+    @staticmethod
+    def for_strategy(strategy: str, **kw) -> "OptimizationParameters":
+        """The reference keeps one JSON per strategy; the class defaults are eval/mcmc_optimization_params.json, and ADC differs in
+        stop_refine (15000) and the regularisers (0) - eval/default_optimization_params.json."""
+        if strategy == "default":
+            kw = dict(dict(stop_refine=15000, opacity_reg=0.0, scale_reg=0.0), **kw)
+        return OptimizationParameters(**kw)
+
 
 _PARAM_NAMES = ["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"]  # param-group order, strategy_utils.cpp:35-40
 

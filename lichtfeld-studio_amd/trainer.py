@@ -36,16 +36,22 @@ class GutTrainer:
             raise ValueError("sh_sharded needs the fused 3DGUT step (no strategy, or MCMC: its refinement steps run on the gathered tensors)")
         self.sh_exchange = lfs_dist.ShExchange(sc.means.shape[0], world, rank) if sh_sharded else None
         shN0 = self.sh_exchange.shard(sc.shN) if sh_sharded else sc.shN
-        self.model = SplatModel(mk(sc.means), mk(sc.sh0), mk(shN0), mk(sc.raw_scales), mk(sc.raw_quats), mk(sc.raw_opacities), sc.sh_degree)
+        # scenes built from a point cloud (loader.colmap_scene) carry active_sh_degree = 0: the SH schedule of the reference starts there
+        self.model = SplatModel(mk(sc.means), mk(sc.sh0), mk(shN0), mk(sc.raw_scales), mk(sc.raw_quats), mk(sc.raw_opacities), sc.sh_degree,
+                                active_sh_degree=sc.extra.get("active_sh_degree"))
         self.rasterizer = rasterizer  # "gut" (3DGUT, the north-star path) | "fastgs" (the reference's default EWA rasterizer)
         self._fg_settings = {}
         self.strategy = None
         self.strategy_kind = strategy
         self.densification_info = None   # [2,N]: fastgs backward's (visibility count, screen-space gradient norm) for ADC
         self.scale_reg = self.opacity_reg = 0.0
+        if strategy == "default" and rasterizer != "fastgs":
+            # ADC reads densification_info (per-Gaussian visibility counts and screen-space gradient norms), which only the fastgs backward
+            # produces (kernels_backward.cuh:233-236); on the 3DGUT path grow / prune would silently never run. The reference pairs --gut with MCMC.
+            raise ValueError("strategy='default' (ADC) needs rasterizer='fastgs': the 3DGUT backward has no densification_info")
         if strategy is not None:
             from . import strategies
-            op = opt_params or strategies.OptimizationParameters(iterations=iterations)
+            op = opt_params or strategies.OptimizationParameters.for_strategy(strategy, iterations=iterations)
             gen = torch.Generator(device=device).manual_seed(seed)
             cls = {"mcmc": strategies.MCMC, "default": strategies.DefaultStrategy}[strategy]
             self.strategy = cls(self.model, op, scene_scale=scene_scale, generator=gen, on_resize=self._on_resize)
@@ -56,6 +62,7 @@ class GutTrainer:
         else:
             self.optimizer = FusedAdam(default_param_groups(self.model), fused=fused_adam)
             self.scheduler = ExponentialLR(self.optimizer, gamma=0.01 ** (1.0 / iterations), param_group_index=0)
+        self.sh_degree_interval = 1000     # without a strategy the trainer keeps the SH schedule itself (strategies do it in post_backward)
         self.bg = torch.zeros(3, device=device)
         # appearance model of BASELINE config 5 (trainer.cpp:66-99: Adam(lr, eps 1e-15) + warm-up exponential schedule), fastgs path only
         self.bilateral, self.tv_loss_weight = None, tv_loss_weight
@@ -220,6 +227,8 @@ class GutTrainer:
         """One optimisation step on this rank's share of the global view batch. `views` overrides this rank's views of the round-robin
         schedule; SH-sharded, the owners must know every rank's views: pass `views_all` (one list per rank) with an explicit schedule."""
         self.iteration += 1
+        if self.strategy is None and self.iteration % self.sh_degree_interval == 0 and self.model.active_sh_degree < self.model.max_sh_degree:
+            self.model.active_sh_degree += 1   # the strategies do this in post_backward (mcmc.cpp:366-368); without one the trainer keeps the schedule
         if views_all is not None:
             views = views_all[self.rank]
         elif views is not None and self.sh_exchange is not None and self.world > 1:

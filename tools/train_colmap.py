@@ -42,7 +42,7 @@ def main():
 
     dev = torch.device("cuda:0")
     mcmc = args.strategy == "mcmc"
-    op = strategies.OptimizationParameters(iterations=args.iterations)
+    op = strategies.OptimizationParameters.for_strategy(args.strategy, iterations=args.iterations)   # ADC: stop_refine 15000, no regularisers
     init_scaling, init_opacity = (0.1, 0.5) if mcmc else (1.0, 0.1)        # parameter/{mcmc,default}_optimization_params.json
     t0 = time.time()
     split = "train" if args.eval else "all"
