@@ -345,6 +345,24 @@ LFS_API int lfs_add_noise(
     uint32_t N, const float* raw_opacities, const float* raw_scales, const float* raw_quats, const float* noise,
     float* means, float current_lr, lfs_stream_t stream);
 
+/* Extension ("device-side index ops with no host syncs"): MCMC::relocate_gs of the reference
+ * (src/training/strategies/mcmc.cpp:113-194) as ONE enqueue without a host round trip. The reference finds the dead Gaussians with nonzero()
+ * (a device->host sync for the count), draws as many sources from the alive ones with torch::multinomial(opacity), calls gsplat::relocation on
+ * them, copies every parameter row source -> dead and zeroes the sources' Adam moments. Here, all on `stream`:
+ *   dead_i   = sigmoid(raw_opacities_i) <= min_opacity  ||  |raw_quats_i|^2 < 1e-8
+ *   source_i = inverse-CDF sample over the alive opacities with the caller's uniform number uniforms[i] in [0,1) (dead i only; fp64 prefix sums in a
+ *              fixed order: the same uniforms give the same sources on every rank), count_j = how often j was drawn
+ *   for every drawn j: (opacity, scale)_j <- relocation(opacity_j, scale_j, min(count_j + 1, n_max)), opacity clamped to [min_opacity, 1 - 1e-7]
+ *                      (mcmc.cpp:149-164), raw values written back; Adam moments of ALL rows[] of j zeroed (mcmc.cpp:87-111)
+ *   for every dead i : every parameter row of rows[] <- the (updated) row of source_i
+ * rows[k] = {param, exp_avg, exp_avg_sq, width} for the six parameter tensors in the order means, sh0, shN, raw_scales, raw_quats, raw_opacities
+ * (exp_avg / exp_avg_sq may be NULL). *n_dead (device, optional) receives the number of dead Gaussians. Nothing happens when no Gaussian is alive. */
+typedef struct lfs_param_rows { float* param; float* exp_avg; float* exp_avg_sq; uint32_t width; } lfs_param_rows;
+LFS_API size_t lfs_mcmc_relocate_workspace_bytes(uint32_t N);
+LFS_API int lfs_mcmc_relocate(
+    uint32_t N, const lfs_param_rows* rows /* [6], host */, const double* uniforms /* [N] device */, const float* binoms, int32_t n_max,
+    float min_opacity, int32_t* n_dead, void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+
 /* ---- fast_gs::optimizer::adam_step (fastgs/optimizer/include/adam.h:9-20, adam_kernels.cuh:13-36).
  *      bias_correction1_rcp = 1/(1-beta1^t), bias_correction2_sqrt_rcp = 1/sqrt(1-beta2^t)
  *      (fused_adam.cpp:78-79). In place on param / exp_avg / exp_avg_sq. Unlike the reference

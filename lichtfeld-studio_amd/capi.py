@@ -71,6 +71,10 @@ class AdamTensor(C.Structure):
                 ("eps", C.c_float), ("bias_correction1_rcp", C.c_float), ("bias_correction2_sqrt_rcp", C.c_float)]
 
 
+class ParamRows(C.Structure):  # lfs_param_rows
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("width", C.c_uint32)]
+
+
 ADAM_MAX_TENSORS = 8
 
 # every symbol include/lfs_gsplat.h declares
@@ -82,7 +86,7 @@ EXPORTS = [
     "lfs_fastgs_primitive_workspace_bytes", "lfs_fastgs_instance_workspace_bytes", "lfs_fastgs_preprocess", "lfs_fastgs_wait_n_instances", "lfs_fastgs_render", "lfs_fastgs_backward", "lfs_fastgs_backward_adam",
     "lfs_fastgs_set_debug_flags", "lfs_fused_ssim_fwd", "lfs_fused_ssim_bwd", "lfs_photometric_loss_workspace_bytes", "lfs_photometric_loss_fwd_bwd", "lfs_photometric_loss_chw_fwd_bwd", "lfs_photometric_loss_ex_fwd_bwd", "lfs_mse_loss_ex_fwd_bwd",
     "lfs_bilateral_slice_fwd", "lfs_bilateral_slice_bwd", "lfs_bilateral_tv_loss_fwd", "lfs_bilateral_tv_loss_bwd", "lfs_image_u8_to_chw_f32", "lfs_mean_neighbor_distances",
-    "lfs_quats_to_rotmats", "lfs_relocation", "lfs_add_noise", "lfs_adam_step", "lfs_adam_step_multi", "lfs_version", "lfs_profile_enable", "lfs_profile_filter", "lfs_profile_collect",
+    "lfs_quats_to_rotmats", "lfs_relocation", "lfs_add_noise", "lfs_mcmc_relocate_workspace_bytes", "lfs_mcmc_relocate", "lfs_adam_step", "lfs_adam_step_multi", "lfs_version", "lfs_profile_enable", "lfs_profile_filter", "lfs_profile_collect",
 ]
 
 
@@ -109,6 +113,7 @@ def load_library():
         lib.lfs_photometric_loss_workspace_bytes.restype = C.c_size_t
         lib.lfs_fastgs_primitive_workspace_bytes.restype = C.c_size_t
         lib.lfs_fastgs_instance_workspace_bytes.restype = C.c_size_t
+        lib.lfs_mcmc_relocate_workspace_bytes.restype = C.c_size_t
         lib.lfs_version.restype = C.c_char_p
         _LIB = lib
     return _LIB

@@ -159,26 +159,31 @@ class MCMC(_StrategyBase):
         m.raw_scales.data.index_put_((sampled_idxs,), torch.log(new_s))
 
     @torch.no_grad()
-    def relocate_gs(self) -> int:  # mcmc.cpp:113-194
-        m = self.model
-        opac = m.get_opacity().detach()
-        dead = (opac <= self.params.min_opacity) | ((m.raw_quats.detach() ** 2).sum(-1) < 1e-8)
-        dead_idx = dead.nonzero().squeeze(-1)
-        n_dead = int(dead_idx.numel())
-        if n_dead == 0:
-            return 0
-        alive_idx = (~dead).nonzero().squeeze(-1)
-        if alive_idx.numel() == 0:
-            return 0
-        sampled = alive_idx.index_select(0, self.multinomial_sample(opac.index_select(0, alive_idx), n_dead, True))
-        ratios = torch.ones_like(opac, dtype=torch.int32)
-        ratios.index_add_(0, sampled, torch.ones_like(sampled, dtype=torch.int32))
-        ratios = ratios.index_select(0, sampled).clamp_max_(self.n_max)
-        self._relocation(sampled, ratios)
-        for name in _PARAM_NAMES:
-            p = getattr(m, name).data
-            p.index_put_((dead_idx,), p.index_select(0, sampled))
-        self._zero_state(sampled)
+    def relocate_gs(self) -> torch.Tensor:  # mcmc.cpp:113-194
+        """Dead Gaussians (opacity <= min_opacity or a degenerate quaternion) become copies of alive ones drawn in proportion to opacity; the
+        drawn sources get the relocated opacity / scale (gsplat::relocation) and zeroed Adam moments. ONE enqueue, no host round trip
+        (lfs_mcmc_relocate: the reference's nonzero() / multinomial() pipeline as fixed-size device passes). The random
+        numbers come from this strategy's generator, so identically seeded replicas relocate identically. -> n_dead as a DEVICE tensor."""
+        import ctypes as C
+
+        from .capi import ParamRows, check, load_library, ptr, stream, workspace
+        m, lib = self.model, load_library()
+        N = int(m.means.shape[0])
+        n_dead = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if N == 0:
+            return n_dead
+        u = torch.rand(N, dtype=torch.float64, device=self.device, generator=self.generator)
+        rows = (ParamRows * 6)()
+        for i, name in enumerate(_PARAM_NAMES):
+            p = getattr(m, name)
+            st = self.optimizer.state.get(id(p)) or {}
+            rows[i].param = p.data.data_ptr()
+            rows[i].exp_avg = st["exp_avg"].data_ptr() if "exp_avg" in st else None
+            rows[i].exp_avg_sq = st["exp_avg_sq"].data_ptr() if "exp_avg_sq" in st else None
+            rows[i].width = p[0].numel() if p.dim() > 1 else 1
+        ws = workspace(lib.lfs_mcmc_relocate_workspace_bytes(C.c_uint32(N)), self.device, "mcmc_relocate")
+        check(lib.lfs_mcmc_relocate(C.c_uint32(N), rows, ptr(u), ptr(self.binoms), C.c_int32(self.n_max), C.c_float(self.params.min_opacity), ptr(n_dead),
+                                    ptr(ws), C.c_size_t(ws.numel()), stream()), "mcmc_relocate")
         return n_dead
 
     @torch.no_grad()

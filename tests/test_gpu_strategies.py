@@ -42,11 +42,14 @@ def test_mcmc_relocate_rewrites_dead_gaussians_and_resets_state(lfs, oracle_mod)
     _prime_optimizer(st)
     before = {k: n(getattr(model, k)).copy() for k in strategies._PARAM_NAMES}
     opac0, scales0 = n(model.get_opacity()).copy(), n(model.get_scaling()).copy()
-    # replay the sampling with an identically seeded generator
+    # replay the sampling on the host: the same uniforms (identically seeded generator), inverse CDF over the alive opacities in fp64
     g2 = torch.Generator(device=DEV).manual_seed(3)
-    alive = (~dead).nonzero().squeeze(-1).to(DEV)
-    sampled = alive[torch.multinomial(torch.from_numpy(opac0).to(DEV)[alive], int(dead.sum()), True, generator=g2)].cpu().numpy()
-    n_dead = st.relocate_gs()
+    u = torch.rand(len(opac0), dtype=torch.float64, device=DEV, generator=g2).cpu().numpy()
+    w = np.where(dead.numpy(), 0.0, opac0.astype(np.float64))
+    cdf = np.cumsum(w)
+    sampled = np.searchsorted(cdf, u[dead.numpy()] * cdf[-1], side="right")
+    assert not dead.numpy()[sampled].any()
+    n_dead = int(st.relocate_gs())            # a device tensor: the relocation itself needs no host round trip
     assert n_dead == int(dead.sum()) > 0
     dead_idx = dead.nonzero().squeeze(-1).numpy()
     counts = np.bincount(sampled, minlength=len(opac0))
@@ -187,3 +190,26 @@ def test_mcmc_training_grows_the_model_and_fits_the_views(lfs):
     assert m.means.shape[0] == 1500 and m.active_sh_degree == 1
     assert all(torch.isfinite(p).all() for p in m.parameters())
     assert psnr1 > psnr0 + 4.0, (psnr0, psnr1)
+
+
+def test_mcmc_refinement_step_needs_no_host_sync(lfs):
+    """at the cap (N == max_cap, the steady state of an MCMC run) a refinement step - relocation of the dead Gaussians, Adam-state
+    surgery, noise - is enqueued without a single device->host synchronisation: torch's sync debug mode turns any .item() / nonzero() / blocking copy
+    into an error. (The reference synchronises for the dead count, mcmc.cpp:121-146.) add_new_gs, which changes N, is not part of this step."""
+    from lichtfeld_studio_amd import strategies
+    model, dead = _model(N=6000, dead_frac=0.05)
+    st = strategies.MCMC(model, strategies.OptimizationParameters(max_cap=6000), generator=torch.Generator(device=DEV).manual_seed(4))
+    _prime_optimizer(st)
+    st.post_backward(600)                      # warm-up: first use of every kernel (module loads may synchronise)
+    torch.cuda.synchronize()
+    before = n(model.raw_opacities).copy()
+    model.raw_opacities.data[::17] = -9.0      # new dead Gaussians
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        assert st.is_refining(700)
+        st.post_backward(700)
+        st.post_backward(701)                  # a plain step: noise only
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    after = n(model.raw_opacities)
+    assert (after[::17] > -9.0).all() and np.isfinite(after).all() and not np.array_equal(after, before)
