@@ -57,6 +57,8 @@ def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems
         "mse_loss": 36 * P, "photometric_loss": 36 * P + 2 * 36 * P,
         "adam_multi": 28 * adam_elems,
         "adam": 28 * adam_elems,
+        # all-inline step: accumulator row (64) + means, raw and activated quats / scales / opacity (76) + 11 floats of each Adam moment (88) in, 3 x 44 out
+        "finish_adam": (64 + 76 + 88 + 132) * N,
         # fastgs (EWA) path, SURVEY.md §8f row 1 - same accounting as the 3DGUT kernels: 64-B blend record + 4-B id per intersection, per-pixel
         # state, the 64-B accumulator rows; preprocess reads the 44 B of raw geometry and writes record (64) + mean2d / conic / bounds (32)
         "fastgs_preprocess": 44 * N + 96 * V + 8 * N,
@@ -163,6 +165,7 @@ def main() -> None:
     ap.add_argument("--wide-cells", action="store_true", help="developer A/B: the experimental two-pixels-per-lane 16x8-cell rasterizer kernels (slower on SYN-B; see raster.hip)")
     ap.add_argument("--row-lists", default="split", choices=["split", "merged"], help="with --row-kernels: quadrant lists split from the cell lists (two kernels) or built in one pass")
     ap.add_argument("--row-kernels", action="store_true", help="developer A/B: the experimental quadrant-row rasterizer kernels (csrc/lfs_raster_rows.cuh; not yet verified on a GPU)")
+    ap.add_argument("--no-inline-all", action="store_true", help="developer A/B: separate raster_finish / activations_bwd / adam_multi kernels instead of the all-inline backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -207,6 +210,8 @@ def main() -> None:
         # objects at 20 - 200 ms each); the timed window then holds warm steps only, one of them (every 100th) a refinement step
         args.start_iteration = 3000 - max(2, args.warmup - 2)
     trainer.iteration = args.start_iteration
+    if args.no_inline_all:
+        trainer.inline_all_adam = False
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
     hip_step = None
     if world == 1 and not args.no_cpu_baseline and args.rasterizer == "gut" and trainer.sh_exchange is None:

@@ -345,6 +345,31 @@ LFS_API int lfs_add_noise(
     uint32_t N, const float* raw_opacities, const float* raw_scales, const float* raw_quats, const float* noise,
     float* means, float current_lr, lfs_stream_t stream);
 
+/* Extension: the all-inline training step of the fused 3DGUT path (one camera, global shutter, 3 channels, ONE view per step on one rank - the
+ * reference's training configuration). No parameter gradient is materialised:
+ *   lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc : ..._bwd_prepared_mse without its last kernel - the per-Gaussian sums (rows of 16
+ *       floats: dL/dA 9 | -dL/dg 3 | dL/dopacity | dL/dcolour 3) stay in the workspace at lfs_rasterize_workspace_acc_offset(C, N);
+ *   lfs_sh_model_bwd_adam_all : SH backward reading dL/dcolour from those rows, Adam on sh0 AND shN in place, dL/d(dirs) written to v_dirs [N,3];
+ *   lfs_gut_finish_adam       : rows -> dL/d(means, quats, scales, opacity) (raster_finish) -> raw-parameter gradients (normalize / exp / sigmoid vjp +
+ *       the regularisers) -> Adam on means, raw_scales, raw_quats, raw_opacities, in one pass; *loss += the fused MSE.
+ * Element for element the operations of the separate kernels (lfs_..._bwd_prepared_mse, lfs_sh_model_bwd_adam, lfs_activations_bwd, lfs_adam_step_multi). */
+LFS_API size_t lfs_rasterize_workspace_acc_offset(uint32_t C, uint32_t N);
+LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc(
+    uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
+    const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+    int64_t n_isects, const float* render_colors, const float* render_alphas, const int32_t* last_ids, const float* target_chw, float weight,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+LFS_API int lfs_sh_model_bwd_adam_all(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, float* sh0, float* shN,
+    const int32_t* radii, const float* colors, const float* acc_rows, float* v_dirs /* [n,3], written */,
+    float* sh0_exp_avg, float* sh0_exp_avg_sq, const float* sh0_scalars /* host: lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp */,
+    float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, lfs_stream_t stream);
+LFS_API int lfs_gut_finish_adam(
+    uint32_t N, float* means, float* raw_scales, float* raw_quats, float* raw_opacities, const float* quats, const float* scales, const float* opacities,
+    const float* v_dirs /* [N,3] from lfs_sh_model_bwd_adam_all */, float* const* exp_avg /* [4] host: means, raw_scales, raw_quats, raw_opacities */,
+    float* const* exp_avg_sq, const float* scalars /* [4][6] host */, float scale_reg, float opacity_reg, float* loss, void* workspace, size_t workspace_bytes,
+    lfs_stream_t stream);
+
 /* Extension ("device-side index ops with no host syncs"): MCMC::relocate_gs of the reference
  * (src/training/strategies/mcmc.cpp:113-194) as ONE enqueue without a host round trip. The reference finds the dead Gaussians with nonzero()
  * (a device->host sync for the count), draws as many sources from the alive ones with torch::multinomial(opacity), calls gsplat::relocation on

@@ -40,6 +40,7 @@
 #include "lfs_prof.h"
 #include "lfs_raster_common.cuh"
 #include "lfs_cull_conic.cuh"
+#include "lfs_adam.cuh"
 
 // Host build on the wavefront emulator (tests/emul) only: wave-evaluation counters [fwd, fwd that composited, bwd, bwd that accumulated]
 #ifdef LFS_EMULATE
@@ -1002,6 +1003,120 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
     v_scales[3 * gid] = vs[0]; v_scales[3 * gid + 1] = vs[1]; v_scales[3 * gid + 2] = vs[2];
 }
 
+// The all-inline training step (ONE camera, global shutter, one view per step on one rank): raster_finish_kernel + the activation backward
+// (l2_fused.hip: normalize / exp / sigmoid vjp + the MCMC regularisers) + the Adam updates of means, raw scales, raw quaternions and raw
+// opacities (adam.hip) in ONE pass over the Gaussians - no gradient tensor is written or re-read. acc row: dL/dA (9) | -dL/dg (3) | dL/dopacity |
+// dL/dcolour (3: consumed by lfs_sh_model_bwd_adam_all, which hands back dL/d(dirs) in v_dirs). Same operations in the same order as
+// the three separate kernels (the activation and Adam arithmetic is un-fused there: pinned with fp contract(off) here).
+struct FinishAdam { float* m[4]; float* v[4]; AdamScalars s[4]; float scale_reg, opacity_reg; }; // order: means, raw_scales, raw_quats, raw_opacities
+__global__ void __launch_bounds__(256) raster_finish_adam_kernel(
+    const uint32_t N, float* __restrict__ means, float* __restrict__ raw_scales, float* __restrict__ raw_quats, float* __restrict__ raw_opacities,
+    const float* __restrict__ quats, const float* __restrict__ scales, const float* __restrict__ opacities,
+    const CamDev* __restrict__ cams, const float* __restrict__ acc, const float* __restrict__ v_dirs, const FinishAdam ad, const float* __restrict__ loss_slots,
+    float* __restrict__ loss) {
+    if (loss_slots != nullptr && blockIdx.x == 0) {
+        float v = threadIdx.x < LOSS_SLOTS ? loss_slots[threadIdx.x] : 0.f;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0.f) unsafeAtomicAdd(loss, v);
+    }
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= N) return;
+    float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+    const float4* a4 = reinterpret_cast<const float4*>(acc + size_t(gid) * ACC_STRIDE);
+    const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
+    const float v_opac = a3.x;
+    const float A[9] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x};
+    const f3 G{-a2.y, -a2.z, -a2.w};
+    bool any = G.x != 0.f || G.y != 0.f || G.z != 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) any |= A[k] != 0.f;
+    const f3 mu{means[3 * gid], means[3 * gid + 1], means[3 * gid + 2]};
+    const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
+    if (any) { // exactly raster_finish_kernel<true> for C == 1
+        const float4 q = reinterpret_cast<const float4*>(quats)[gid];
+        const m3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
+        const float is[3] = {1.f / sc[0], 1.f / sc[1], 1.f / sc[2]};
+        m3 M;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
+        m3 vM;
+        const m3& Ri = cams[0].Rinv;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vM.m[r][c] = A[3 * r] * Ri.m[c][0] + A[3 * r + 1] * Ri.m[c][1] + A[3 * r + 2] * Ri.m[c][2];
+        const f3 om = cams[0].origin - mu;
+        const float gv[3] = {G.x, G.y, G.z}, ov[3] = {om.x, om.y, om.z};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vM.m[r][c] += gv[r] * ov[c];
+        const f3 vom = mul_t(M, G);
+        vm[0] -= vom.x; vm[1] -= vom.y; vm[2] -= vom.z;
+        m3 GR;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) GR.m[r][c] = vM.m[c][r] * is[c];
+        quat_to_rotmat_vjp(q.x, q.y, q.z, q.w, GR, vq);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            vs[c] += -is[c] * is[c] * (R.m[0][c] * vM.m[c][0] + R.m[1][c] * vM.m[c][1] + R.m[2][c] * vM.m[c][2]);
+    }
+    {
+#pragma clang fp contract(off)
+        // + dL/d(dirs) of the SH backward (sh.hip adds it onto the rasterizer's dL/dmeans in the separate path)
+        float gm[3] = {vm[0] + v_dirs[3 * gid], vm[1] + v_dirs[3 * gid + 1], vm[2] + v_dirs[3 * gid + 2]};
+        // activations_bwd_kernel<false> (l2_fused.hip)
+        const float4 rq = reinterpret_cast<const float4*>(raw_quats)[gid];
+        const float nrm = sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
+        float gq[4];
+        if (nrm > 1e-12f) {
+            const float inv = 1.f / nrm;
+            const float y[4] = {rq.x * inv, rq.y * inv, rq.z * inv, rq.w * inv};
+            const float d = vq[0] * y[0] + vq[1] * y[1] + vq[2] * y[2] + vq[3] * y[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gq[k] = (vq[k] - d * y[k]) * inv;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gq[k] = vq[k] * 1e12f;
+        }
+        float gs[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gs[k] = (vs[k] + ad.scale_reg) * sc[k];
+        const float o = opacities[gid];
+        const float go = (v_opac + ad.opacity_reg) * o * (1.f - o);
+        // Adam (adam_multi_kernel's per-element update)
+        float p[3] = {mu.x, mu.y, mu.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t e = size_t(gid) * 3 + k;
+            float m = ad.m[0][e], v = ad.v[0][e];
+            adam_elem(p[k], m, v, gm[k], ad.s[0]);
+            means[e] = p[k]; ad.m[0][e] = m; ad.v[0][e] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t e = size_t(gid) * 3 + k;
+            float pp = raw_scales[e], m = ad.m[1][e], v = ad.v[1][e];
+            adam_elem(pp, m, v, gs[k], ad.s[1]);
+            raw_scales[e] = pp; ad.m[1][e] = m; ad.v[1][e] = v;
+        }
+        float pq[4] = {rq.x, rq.y, rq.z, rq.w};
+        float4 mq = reinterpret_cast<const float4*>(ad.m[2])[gid], vq4 = reinterpret_cast<const float4*>(ad.v[2])[gid];
+        adam_elem(pq[0], mq.x, vq4.x, gq[0], ad.s[2]); adam_elem(pq[1], mq.y, vq4.y, gq[1], ad.s[2]);
+        adam_elem(pq[2], mq.z, vq4.z, gq[2], ad.s[2]); adam_elem(pq[3], mq.w, vq4.w, gq[3], ad.s[2]);
+        reinterpret_cast<float4*>(raw_quats)[gid] = make_float4(pq[0], pq[1], pq[2], pq[3]);
+        reinterpret_cast<float4*>(ad.m[2])[gid] = mq; reinterpret_cast<float4*>(ad.v[2])[gid] = vq4;
+        float po = raw_opacities[gid], mo = ad.m[3][gid], vo = ad.v[3][gid];
+        adam_elem(po, mo, vo, go, ad.s[3]);
+        raw_opacities[gid] = po; ad.m[3][gid] = mo; ad.v[3][gid] = vo;
+    }
+}
+
 // deterministic mode, after pass 2: acc[i] = fixed-point sum * 2^(e - 40) (e from the pass-1 maximum that acc[i] still holds as bits)
 __global__ void __launch_bounds__(256) raster_det_resolve_kernel(const size_t n, float* __restrict__ acc, const unsigned long long* __restrict__ det64) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1163,7 +1278,7 @@ static int raster_bwd_impl(
     const float* render_alphas, const int32_t* last_ids,
     const float* v_render_colors, const float* v_render_alphas,
     float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream, bool prepared, const MseFuse* mse = nullptr) {
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream, bool prepared, const MseFuse* mse = nullptr, bool finish = true) {
     RasterGeom g;
     int rc = raster_check(N, channels, cams, tile_size, g);
     if (rc) return rc;
@@ -1176,7 +1291,9 @@ static int raster_bwd_impl(
     RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), g.rows, (g_debug_flags & 16u) != 0);
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N == 0) return LFS_OK;
-    if (!means || !quats || !scales || !colors || !opacities || !v_means || !v_quats || !v_scales || !v_colors || !v_opacities) return LFS_E_INVALID;
+    if (!means || !quats || !scales || !colors || !opacities) return LFS_E_INVALID;
+    if (finish && (!v_means || !v_quats || !v_scales || !v_colors || !v_opacities)) return LFS_E_INVALID;
+    if (!finish && (channels != 3 || C != 1 || !mse)) return LFS_E_INVALID; // the accumulator-only form feeds lfs_sh_model_bwd_adam_all + lfs_gut_finish_adam
     if (n_isects > 0 && (!flatten_ids || !render_alphas || !last_ids || (!v_render_colors && !mse))) return LFS_E_INVALID; // v_render_alphas == NULL: zeros
     hipStream_t s = (hipStream_t)stream;
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
@@ -1224,6 +1341,7 @@ static int raster_bwd_impl(
 #undef LFS_BWD_ROWS
 #undef LFS_BWD
     }
+    if (!finish) return (int)hipGetLastError();
     const dim3 fg((N + 255) / 256);
     lfs::ProfScope prof_fin("raster_finish", s);
     const float* slots = mse ? w.acc + ACC_STRIDE * CN : nullptr;
@@ -1272,9 +1390,56 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse(
     float* loss, float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
     lfs_stream_t stream) {
     if (!cams || !render_colors || !target_chw || !loss) return LFS_E_INVALID;
-    const MseFuse mse{render_colors, target_chw, weight / float(3u * cams->image_width * cams->image_height), loss};
+    const MseFuse mse{render_colors, target_chw, weight / float(3u * cams->image_width * cams->image_height), loss, nullptr};
     if (n_isects == 0) return LFS_E_UNSUPPORTED; // nothing rendered: use lfs_mse_loss_fwd_bwd (the loss of the background image)
     return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, n_isects,
                            render_alphas, last_ids, nullptr, nullptr, v_means, v_quats, v_scales, v_colors, v_opacities, workspace, workspace_bytes,
                            stream, true, &mse);
+}
+
+
+// ---- the all-inline training step (extension; one camera, global shutter, 3 channels): accumulator-only backward + fused finish / Adam ----
+// lfs_rasterize_..._bwd_prepared_mse without its last kernel: the per-Gaussian sums stay in the workspace (rows of 16 floats at
+// lfs_rasterize_workspace_acc_offset) together with the loss partial sums; lfs_sh_model_bwd_adam_all reads dL/dcolour from the rows and writes
+// dL/d(dirs) into them, lfs_gut_finish_adam turns them into the parameter updates.
+extern "C" size_t lfs_rasterize_workspace_acc_offset(uint32_t C, uint32_t N) {
+    const RasterWs w = raster_ws(nullptr, C, N, 0, 0, false);
+    return size_t(reinterpret_cast<const char*>(w.acc) - static_cast<const char*>(nullptr));
+}
+
+extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc(
+    uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
+    const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+    int64_t n_isects, const float* render_colors, const float* render_alphas, const int32_t* last_ids, const float* target_chw, float weight,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    if (!cams || !render_colors || !target_chw) return LFS_E_INVALID;
+    float dummy_loss;
+    const MseFuse mse{render_colors, target_chw, weight / float(3u * cams->image_width * cams->image_height), &dummy_loss, nullptr}; // (.loss is redirected to the slots)
+    if (n_isects == 0) return LFS_E_UNSUPPORTED;
+    return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, n_isects,
+                           render_alphas, last_ids, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream, true, &mse, false);
+}
+
+// scalars[k] = {lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp} for k = means, raw_scales, raw_quats, raw_opacities; *loss += the fused MSE of the backward
+extern "C" int lfs_gut_finish_adam(
+    uint32_t N, float* means, float* raw_scales, float* raw_quats, float* raw_opacities, const float* quats, const float* scales, const float* opacities,
+    const float* v_dirs, float* const* exp_avg /* [4] host */, float* const* exp_avg_sq /* [4] host */, const float* scalars /* [4][6] host */, float scale_reg,
+    float opacity_reg, float* loss, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    if (N == 0) return LFS_OK;
+    if (!v_dirs) return LFS_E_INVALID;
+    if (!means || !raw_scales || !raw_quats || !raw_opacities || !quats || !scales || !opacities || !exp_avg || !exp_avg_sq || !scalars || !workspace) return LFS_E_INVALID;
+    const RasterWs w = raster_ws(workspace, 1, N, 0, 0, false);
+    if (workspace_bytes < size_t(reinterpret_cast<const char*>(w.cull) - static_cast<const char*>(workspace))) return LFS_E_WORKSPACE;
+    FinishAdam ad;
+    for (int k = 0; k < 4; ++k) {
+        if (!exp_avg[k] || !exp_avg_sq[k]) return LFS_E_INVALID;
+        ad.m[k] = exp_avg[k]; ad.v[k] = exp_avg_sq[k];
+        ad.s[k] = AdamScalars{scalars[6 * k], scalars[6 * k + 1], scalars[6 * k + 2], scalars[6 * k + 3], scalars[6 * k + 4], scalars[6 * k + 5]};
+    }
+    ad.scale_reg = scale_reg; ad.opacity_reg = opacity_reg;
+    hipStream_t s = (hipStream_t)stream;
+    lfs::ProfScope prof("finish_adam", s);
+    hipLaunchKernelGGL(raster_finish_adam_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, means, raw_scales, raw_quats, raw_opacities, quats, scales, opacities,
+                       w.cams, w.acc, v_dirs, ad, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss);
+    return (int)hipGetLastError();
 }

@@ -133,6 +133,8 @@ struct ShArgs {
     const float* campos;      // camera centre [3] instead of a view matrix
     const uint32_t* mask_u32; // visibility = mask_u32[g] != 0 instead of radii
     uint32_t cs, vs;          // element stride of colors / v_colors rows (0 = 3)
+    uint32_t ds;              // model bwd: element stride of the v_dirs rows (0 = 3)
+    bool dirs_store;          // model bwd: v_dirs rows are WRITTEN (0 for invisible Gaussians) instead of added to
 };
 template <bool MODEL> LFS_DI bool sh_on(const ShArgs& a, uint32_t g) {
     if (MODEL) return a.mask_u32 ? a.mask_u32[g] != 0u : (a.radii[2 * g] > 0 && a.radii[2 * g + 1] > 0);
@@ -213,7 +215,8 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
 // ADAM (model form, single view): the higher-degree gradient rows are not stored at all - basis * dL/dcolour is consumed by the
 //        Adam update of shN on the spot (v_shN unused; adam.m / adam.v = its moments). Saves the 180 B / Gaussian write here and the
 //        180 B / Gaussian read in the optimizer kernel; element-wise identical to sh_bwd followed by adam_step on shN.
-struct ShAdam { float* m; float* v; AdamScalars s; };
+// m0 / v0 / s0 (optional): the same for the degree-0 coefficients sh0 (then v_sh0 is not written either) - the all-inline training step.
+struct ShAdam { float* m; float* v; AdamScalars s; float* m0 = nullptr; float* v0 = nullptr; AdamScalars s0 = AdamScalars{}; };
 
 template <int LPG, bool MODEL, bool ACCUM, bool ADAM = false>
 __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float* __restrict__ v_colors,
@@ -264,7 +267,15 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
         const float v0 = ldv[gl * 3], v1 = ldv[gl * 3 + 1], v2 = ldv[gl * 3 + 2];
         const float o0 = bk * v0, o1 = bk * v1, o2 = bk * v2;
         float sk = 0.f;
-        if (ADAM && k >= 1) {
+        if (ADAM && k == 0 && adam.m0 != nullptr) { // sh0 row: basis 0 is constant (no direction gradient); update in place, nothing stored
+            const size_t e = size_t(g) * 3;
+            float* pp = const_cast<float*>(a.sh0) + e;
+            float p0 = pp[0], p1 = pp[1], p2 = pp[2];
+            float m0 = adam.m0[e], m1 = adam.m0[e + 1], m2 = adam.m0[e + 2], q0 = adam.v0[e], q1 = adam.v0[e + 1], q2 = adam.v0[e + 2];
+            adam_elem(p0, m0, q0, o0, adam.s0); adam_elem(p1, m1, q1, o1, adam.s0); adam_elem(p2, m2, q2, o2, adam.s0);
+            pp[0] = p0; pp[1] = p1; pp[2] = p2;
+            adam.m0[e] = m0; adam.m0[e + 1] = m1; adam.m0[e + 2] = m2; adam.v0[e] = q0; adam.v0[e + 1] = q1; adam.v0[e + 2] = q2;
+        } else if (ADAM && k >= 1) {
             // shN[g][k-1][:] : read once (the direction gradient needs the pre-update value), update, write back.
             // (Loading four rows ahead per lane was measured slower: 0.31 vs 0.23 ms.)
             const size_t e = (size_t(g) * (a.K - 1) + (k - 1)) * 3;
@@ -304,7 +315,8 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
         ox = (gx - dd * d.x) * inorm; oy = (gy - dd * d.y) * inorm; oz = (gz - dd * d.z) * inorm;
     }
     if (gmine < a.n) {
-        if (MODEL) { if (on && want_dirs) { v_dirs[3 * gmine] += ox; v_dirs[3 * gmine + 1] += oy; v_dirs[3 * gmine + 2] += oz; } }
+        if (MODEL && a.dirs_store) { const size_t ds = a.ds ? a.ds : 3; v_dirs[ds * gmine] = ox; v_dirs[ds * gmine + 1] = oy; v_dirs[ds * gmine + 2] = oz; } // (0 when off)
+        else if (MODEL) { if (on && want_dirs) { v_dirs[3 * gmine] += ox; v_dirs[3 * gmine + 1] += oy; v_dirs[3 * gmine + 2] += oz; } }
         else { v_dirs[3 * gmine] = ox; v_dirs[3 * gmine + 1] = oy; v_dirs[3 * gmine + 2] = oz; }
     }
 }
@@ -594,6 +606,28 @@ extern "C" int lfs_sh_model_bwd_adam(
     a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
     const lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp}};
     return lfs::sh_launch_bwd_adam(a, v_colors, v_sh0, v_means, adam, (hipStream_t)stream);
+}
+
+// The all-inline training step (one view, one rank): dL/dcolour is read from the rasterizer's accumulator rows (acc_rows + 13, stride 16 floats),
+// dL/d(dirs) is WRITTEN to v_dirs [n,3] (raster_finish_adam_kernel adds it to the means gradient), and BOTH coefficient tensors
+// are updated in place by their Adam steps: no gradient tensor of the spherical harmonics exists.
+extern "C" int lfs_sh_model_bwd_adam_all(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, float* sh0, float* shN,
+    const int32_t* radii, const float* colors, const float* acc_rows, float* v_dirs,
+    float* sh0_exp_avg, float* sh0_exp_avg_sq, const float* sh0_scalars /* lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp */,
+    float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, lfs_stream_t stream) {
+    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
+    if (degrees_to_use > 4 || Kd > K || K > 32 || K < 2) return LFS_E_INVALID;
+    if (n == 0) return LFS_OK;
+    if (!means || !viewmat || !sh0 || !shN || !radii || !colors || !acc_rows || !v_dirs || !sh0_exp_avg || !sh0_exp_avg_sq || !sh0_scalars || !shN_exp_avg ||
+        !shN_exp_avg_sq || !shN_scalars) return LFS_E_INVALID;
+    lfs::ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
+    a.vs = 16; a.dirs_store = true; // dL/dcolour: slots 13..15 of the 16-float rows; dL/d(dirs): its own contiguous [n,3] (partial-row writes into the rows cost more than they save)
+    lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{shN_scalars[0], shN_scalars[1], shN_scalars[2], shN_scalars[3], shN_scalars[4], shN_scalars[5]}};
+    adam.m0 = sh0_exp_avg; adam.v0 = sh0_exp_avg_sq;
+    adam.s0 = lfs::AdamScalars{sh0_scalars[0], sh0_scalars[1], sh0_scalars[2], sh0_scalars[3], sh0_scalars[4], sh0_scalars[5]};
+    return lfs::sh_launch_bwd_adam(a, acc_rows + 13, nullptr, v_dirs, adam, (hipStream_t)stream);
 }
 
 static bool sh_views_ok(uint32_t n, uint32_t K, uint32_t degree, uint32_t V, uint32_t stride) {

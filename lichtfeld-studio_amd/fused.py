@@ -69,6 +69,39 @@ def sh_model_bwd_adam(sh_degree: int, means, viewmat, sh0, shN, radii, colors, v
                                                C.c_float(adam["bc1_rcp"]), C.c_float(adam["bc2_sqrt_rcp"]), stream()), "sh_model_bwd_adam")
 
 
+def _adam_scalars(a: dict):
+    return (C.c_float * 6)(a["lr"], a["beta1"], a["beta2"], a["eps"], a["bc1_rcp"], a["bc2_sqrt_rcp"])
+
+
+def backward_adam_all(sh_degree: int, means, raw_quats, raw_scales, raw_opac, sh0, shN, quats, scales, opac, colors, radii, bg, W: int, H: int, tile: int,
+                      viewmat, Kmat, offsets, flatten_ids, render, alpha, last_ids, target_chw, weight: float, loss_acc, ws, adam: dict,
+                      scale_reg: float = 0.0, opacity_reg: float = 0.0) -> None:
+    """The all-inline backward of a one-view step on one rank (the reference's training configuration): rasterizer backward with the MSE folded in
+    -> SH backward with Adam on sh0 / shN -> finish + activation backward + Adam on means / scales / quaternions / opacities. Three launches after the
+    rasterizer kernel, no gradient tensor; `adam[name]` = FusedAdam.prepare_inline(param) for the six parameters. Element for element the operations
+    of the separate kernels (tests/test_gpu_fused.py)."""
+    from .capi import cameras_struct
+    lib = load_library()
+    N, Kc = means.shape[0], 1 + shN.shape[1]
+    cams = cameras_struct(viewmat, None, Kmat, W, H, CameraModelType.PINHOLE, ShutterType.GLOBAL, None, None, None)
+    check(lib.lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc(
+        C.c_uint32(N), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opac), ptr(bg), C.byref(cams), C.c_uint32(tile), ptr(offsets), ptr(flatten_ids),
+        C.c_int64(flatten_ids.shape[0]), ptr(render), ptr(alpha), ptr(last_ids), ptr(target_chw), C.c_float(weight), ptr(ws), C.c_size_t(ws.numel()), stream()),
+        "rasterize_bwd_prepared_mse_acc")
+    acc_rows = C.c_void_p(ws.data_ptr() + lib.lfs_rasterize_workspace_acc_offset(C.c_uint32(1), C.c_uint32(N)))
+    a0, aN = adam["sh0"], adam["shN"]
+    v_dirs = torch.empty_like(means)
+    check(lib.lfs_sh_model_bwd_adam_all(C.c_uint32(N), C.c_uint32(Kc), C.c_uint32(sh_degree), ptr(means), ptr(viewmat), ptr(sh0), ptr(shN), ptr(radii), ptr(colors),
+                                        acc_rows, ptr(v_dirs), ptr(a0["exp_avg"]), ptr(a0["exp_avg_sq"]), _adam_scalars(a0), ptr(aN["exp_avg"]), ptr(aN["exp_avg_sq"]),
+                                        _adam_scalars(aN), stream()), "sh_model_bwd_adam_all")
+    order = ["means", "raw_scales", "raw_quats", "raw_opacities"]
+    m = (C.c_void_p * 4)(*[adam[k]["exp_avg"].data_ptr() for k in order])
+    v = (C.c_void_p * 4)(*[adam[k]["exp_avg_sq"].data_ptr() for k in order])
+    sc = (C.c_float * 24)(*[x for k in order for x in (adam[k]["lr"], adam[k]["beta1"], adam[k]["beta2"], adam[k]["eps"], adam[k]["bc1_rcp"], adam[k]["bc2_sqrt_rcp"])])
+    check(lib.lfs_gut_finish_adam(C.c_uint32(N), ptr(means), ptr(raw_scales), ptr(raw_quats), ptr(raw_opac), ptr(quats), ptr(scales), ptr(opac), ptr(v_dirs), m, v, sc,
+                                  C.c_float(scale_reg), C.c_float(opacity_reg), ptr(loss_acc), ptr(ws), C.c_size_t(ws.numel()), stream()), "gut_finish_adam")
+
+
 def sh_model_fwd_views(sh_degree: int, means, viewmats, sh0, shN, radii_views):
     """Owner side of dist.ShExchange: means / sh0 / shN = the owner's n rows; viewmats [V,4,4]; radii_views [V,S,2] (first n rows of each view
     used) -> colours [V,S,3] (rows >= n zero)."""
@@ -121,7 +154,7 @@ class FusedStepOutput:
 def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
                         grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool, loss: str = "mse",
                         lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None, adam_shN: Optional[dict] = None, adam_shard: Optional[dict] = None, bilateral=None, image_idx: int = 0,
-                        on_geometry_grads=None) -> FusedStepOutput:
+                        on_geometry_grads=None, adam_all: Optional[dict] = None) -> FusedStepOutput:
     """One view: forward, loss against `target_chw` ("mse": the rasterizer-only metric of SURVEY.md §8d; "l1_ssim": the reference's
     photometric loss, trainer.cpp:115-128), backward. `grads` = six tensors shaped like model.parameters()
     (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
@@ -133,7 +166,9 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
     `bilateral` (bilateral_grid.BilateralGrid): the rendered image goes through grid `image_idx` before the loss (trainer.cpp:662-664); the grid's
     gradient is accumulated into its .grad.
     `on_geometry_grads()` (multi-GPU, last view of the step) is called as soon as the raw scale / quaternion / opacity gradients are final - before the
-    SH backward is enqueued - so their all-reduce (dist.GradBucket.all_reduce_early) overlaps with it on RCCL's stream."""
+    SH backward is enqueued - so their all-reduce (dist.GradBucket.all_reduce_early) overlaps with it on RCCL's stream.
+    `adam_all` ({parameter name: FusedAdam.prepare_inline(...)} for all six; one view per step on one rank, MSE loss): nothing is written to `grads` -
+    every parameter is updated in place by the backward kernels themselves (backward_adam_all)."""
     assert camera.camera_model_type == CameraModelType.PINHOLE and camera.radial_distortion is None and camera.tangential_distortion is None, \
         "the fused path covers the trainer's undistorted pinhole cameras; use rasterizer.rasterize for the rest"
     W, H = int(camera.image_width), int(camera.image_height)
@@ -178,6 +213,14 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
             v_render = photometric_loss_fwd_bwd(render, target_chw, lambda_dssim, weight, loss_acc)
         else:
             raise ValueError(f"unknown loss {loss!r}")
+        adam_fallback = None
+        if adam_all is not None and not fuse_mse:   # nothing was rendered (no intersections): separate kernels, then the prepared Adam steps by hand
+            adam_fallback, adam_all = adam_all, None
+        if adam_all is not None:
+            assert sh_exchange is None and not accumulate and adam_shN is None, "the all-inline step: one view, one rank, MSE folded into the backward"
+            backward_adam_all(deg, means, raw_quats, raw_scales, raw_opac, sh0, shN, quats, scales, opac, colors, radii, bg, W, H, tile, viewmat, Kmat, offsets,
+                              flatten_ids, render, alpha, last_ids, target_chw, weight, loss_acc, ws, adam_all, scale_reg, opacity_reg)
+            return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]))
         if fuse_mse:
             v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_bwd_prepared_mse(
                 means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, W, H, tile, viewmat, Kmat, CameraModelType.PINHOLE, ShutterType.GLOBAL,

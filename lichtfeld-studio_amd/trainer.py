@@ -82,6 +82,7 @@ class GutTrainer:
         self.loss_kind, self.lambda_dssim = loss, lambda_dssim  # "mse" | "l1_ssim" (trainer.cpp:115-128)
         self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2]) if (world > 1 or fused_l2) else None  # 2 = shN
         self.loss_acc = torch.zeros(1, device=device)
+        self.inline_all_adam = True   # one view / one rank / MSE: all six parameters are updated inside the backward kernels (fused.backward_adam_all)
         self.inline_shN_adam = True   # see train_step; False keeps the SH backward and the optimizer separate (tests compare the two)
         self.iteration = 0
         self.last_n_isects = 0
@@ -253,6 +254,14 @@ class GutTrainer:
             if (self.inline_shN_adam and self.world == 1 and len(views) == 1 and self.strategy is None and self.iteration > 1000
                     and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False)):
                 inline = self.optimizer.prepare_inline(self.model.shN)
+            # ... and when the MSE is folded into the rasterizer backward as well, EVERY parameter is updated by the backward kernels (fused.backward_adam_all):
+            # no gradient tensor, no separate activation-backward / optimizer launches
+            inline_all = None
+            if inline is not None and self.inline_all_adam and self.loss_kind == "mse" and self.bilateral is None:
+                inline_all = {"shN": inline}
+                for name in ("means", "sh0", "raw_scales", "raw_quats", "raw_opacities"):
+                    inline_all[name] = self.optimizer.prepare_inline(getattr(self.model, name))
+                inline = None
             inline_shard = None   # SH-sharded, one view per rank: the owners' multi-view SH backward applies the shard's Adam update
             refining = self.strategy is not None and self.strategy.is_refining(self.iteration)   # parameters are replaced before the optimizer step:
             if (self.inline_shN_adam and self.sh_exchange is not None and len(views) == 1 and self.iteration > 1000 and self.sh_exchange.n   # no update then
@@ -265,7 +274,7 @@ class GutTrainer:
                                           # regularisers: once per step, and 1/world of them per rank (the all-reduce sums the ranks)
                                           scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
                                           opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0,
-                                          sh_exchange=self.sh_exchange, viewmats_all=vm_all, adam_shN=inline, adam_shard=inline_shard,
+                                          sh_exchange=self.sh_exchange, viewmats_all=vm_all, adam_shN=inline, adam_shard=inline_shard, adam_all=inline_all,
                                           bilateral=self.bilateral, image_idx=v,
                                           # last view: scales / quats / opacities gradients are final before the SH backward starts - their all-reduce overlaps with it
                                           on_geometry_grads=(lambda: self.bucket.all_reduce_early([3, 4, 5])) if (self.world > 1 and k == len(views) - 1) else None)

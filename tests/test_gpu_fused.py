@@ -253,3 +253,32 @@ def test_mse_folded_into_backward_matches_separate_loss_kernel(lfs):
         noise = float((b - c).abs().max())                    # run-to-run noise of the float atomics
         assert float((a - b).abs().max()) <= max(5 * noise, 1e-4 * float(b.abs().max())), (name, float((a - b).abs().max()), noise)
         assert float(b.abs().max()) > 0
+
+
+def test_all_inline_adam_step_is_bit_identical_to_the_separate_kernels(lfs):
+    """fused.backward_adam_all (rasterizer backward -> SH backward with Adam on sh0 / shN -> finish + activation backward + Adam on the rest, no
+    gradient tensors) against the same steps through raster_finish, lfs_sh_model_bwd_adam, lfs_activations_bwd and lfs_adam_step_multi. Both
+    trainers run in the deterministic accumulation mode (lfs_set_debug_flags(16)), so the rasterizer hands both exactly the same sums and every
+    parameter and every Adam moment has to agree BIT FOR BIT over several steps."""
+    from lichtfeld_studio_amd import scenes
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    sc = scenes.syn_a(n=7000, sh_degree=2)
+    target = torch.rand(3, sc.height, sc.width, generator=torch.Generator().manual_seed(3)).to(DEV) * 0.7
+    lib = lfs.load_library()
+    try:
+        lib.lfs_set_debug_flags(16)
+        a = GutTrainer(sc, DEV, iterations=7000)
+        b = GutTrainer(sc, DEV, iterations=7000)
+        b.inline_all_adam = False
+        a.iteration = b.iteration = 1500          # shN is being optimised
+        for _ in range(4):
+            la, lb = a.train_step([target], views=[0]), b.train_step([target], views=[0])
+        torch.cuda.synchronize()
+    finally:
+        lib.lfs_set_debug_flags(0)
+    assert float(la) == float(lb) and float(la) > 0
+    for name, pa, pb in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], a.model.parameters(), b.model.parameters()):
+        assert torch.equal(pa, pb), (name, float((pa - pb).abs().max()))
+        sa, sb = a.optimizer.state[id(pa)], b.optimizer.state[id(pb)]
+        assert sa["step_count"] == sb["step_count"] == 4
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), name
