@@ -38,6 +38,8 @@ def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems
     """Compulsory HBM bytes per launch, keyed by the event names of csrc/."""
     return {
         "projection_ut": 52 * N + 24 * V,
+        "activations_projection_ut": 44 * N + 32 * N + 8 * N + 12 * V,          # raw parameters in; activated values, radii, means2d + depth of the visible out
+        "sh_fwd_pack": 13 * N + (12 * K + 12) * V + 44 * V + 96 * V,           # sh_fwd + the activated geometry of the visible in, record + culling record out
         "sh_fwd": 13 * N + (12 * K + 12) * V,
         "isect_count_scan": 32 * N + 4 * T,
         "isect_scatter": 28 * N + 12 * I,
@@ -165,6 +167,8 @@ def main() -> None:
     ap.add_argument("--wide-cells", action="store_true", help="developer A/B: the experimental two-pixels-per-lane 16x8-cell rasterizer kernels (slower on SYN-B; see raster.hip)")
     ap.add_argument("--row-lists", default="split", choices=["split", "merged"], help="with --row-kernels: quadrant lists split from the cell lists (two kernels) or built in one pass")
     ap.add_argument("--row-kernels", action="store_true", help="developer A/B: the experimental quadrant-row rasterizer kernels (csrc/lfs_raster_rows.cuh; not yet verified on a GPU)")
+    ap.add_argument("--fuse-sh-pack", action="store_true", help="developer A/B: SH colours + rasterizer records in one kernel (fused.FUSE_SH_PACK; no gain measured)")
+    ap.add_argument("--no-fuse-act-proj", action="store_true", help="developer A/B: separate activations and projection kernels")
     ap.add_argument("--no-inline-all", action="store_true", help="developer A/B: separate raster_finish / activations_bwd / adam_multi kernels instead of the all-inline backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -212,6 +216,8 @@ def main() -> None:
     trainer.iteration = args.start_iteration
     if args.no_inline_all:
         trainer.inline_all_adam = False
+    from lichtfeld_studio_amd import fused as _fused
+    _fused.FUSE_SH_PACK, _fused.FUSE_ACT_PROJ = bool(args.fuse_sh_pack), not args.no_fuse_act_proj
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
     hip_step = None
     if world == 1 and not args.no_cpu_baseline and args.rasterizer == "gut" and trainer.sh_exchange is None:

@@ -345,6 +345,32 @@ LFS_API int lfs_add_noise(
     uint32_t N, const float* raw_opacities, const float* raw_scales, const float* raw_quats, const float* noise,
     float* means, float current_lr, lfs_stream_t stream);
 
+/* Extension: the front half of the fused 3DGUT training step (one camera, global shutter, 3 channels).
+ *   lfs_activations_project_ut : lfs_activations_fwd + lfs_projection_ut_3dgs_fused in one pass over the raw parameters (normalize / exp / sigmoid, then the
+ *       projection on the activated values - the same operations in the same order); quats / scales / opacities receive the activated values.
+ *   lfs_gut_prepare_cameras    : the device-side camera state at the start of a rasterizer workspace (what the forward call would compute first).
+ *   lfs_sh_model_fwd_pack      : lfs_sh_model_fwd whose lanes also write the rasterizer's 64-byte records and 32-byte culling records of the visible
+ *       Gaussians into that workspace (offsets: lfs_rasterize_workspace_offsets; they do not depend on n_isects, so the workspace can be sized - and,
+ *       if it must grow once n_isects is known, its prefix copied - before the intersection count exists).
+ *   lfs_rasterize_to_pixels_from_world_3dgs_fwd_prepacked : the forward call on such a workspace (no camera / pack kernels). */
+LFS_API int lfs_activations_project_ut(
+    uint32_t N, const float* means, const float* raw_quats, const float* raw_scales, const float* raw_opacities, const lfs_cameras* cams,
+    float eps2d, float near_plane, float far_plane, float radius_clip, const lfs_ut_params* ut_params,
+    float* quats, float* scales, float* opacities, int32_t* radii, float* means2d, float* depths, lfs_stream_t stream);
+LFS_API void lfs_rasterize_workspace_offsets(uint32_t C, uint32_t N, size_t* cams, size_t* recs, size_t* acc, size_t* cull, size_t* prefix_bytes);
+LFS_API int lfs_gut_prepare_cameras(const lfs_cameras* cams, void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+LFS_API int lfs_sh_model_fwd_pack(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+    const int32_t* radii, const float* quats, const float* scales, const float* opacities, float* colors,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_fwd_prepacked(
+    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
+    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
+    const lfs_cameras* cams, uint32_t tile_size,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    float* render_colors, float* render_alphas, int32_t* last_ids,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+
 /* Extension: the all-inline training step of the fused 3DGUT path (one camera, global shutter, 3 channels, ONE view per step on one rank - the
  * reference's training configuration). No parameter gradient is materialised:
  *   lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc : ..._bwd_prepared_mse without its last kernel - the per-Gaussian sums (rows of 16

@@ -1,0 +1,57 @@
+// The per-(camera, Gaussian) staging of the world-space rasterizer, shared by raster_pack_kernel (raster.hip: the Ops.h entry points) and by the
+// fused training step, where the SH colour kernel writes the finished records itself (sh.hip, lfs_sh_model_fwd_pack): the 64-byte record the
+// fwd / bwd kernels walk and the 32-byte culling record (silhouette conic of the alpha >= 1/255 ellipsoid, lfs_cull_conic.cuh).
+#pragma once
+#include "lfs_camera.cuh"
+#include "lfs_raster_common.cuh"
+#include "lfs_cull_conic.cuh"
+
+namespace lfs {
+
+// Per-Gaussian culling record (the silhouette conic of the alpha >= 1/255 ellipsoid in normalised camera coordinates)
+struct __attribute__((aligned(16))) CullRec { float4 a, b; };
+
+// UNIFORM_ORIGIN (global shutter): the record matrix is S^-1 R^T Rinv (camera-space ray directions -> Gaussian frame) and g = S^-1 R^T (o - mu);
+// rolling shutters keep S^-1 R^T and g = mu (per-pixel origins) and are never culled.
+template <bool UNIFORM_ORIGIN>
+LFS_DI void pack_gaussian(const CamDev& cam, const f3 mu, const float4 q, const float sc[3], const float opac, const float c0, const float c1, const float c2,
+                          GaussRec& rec, CullRec& cr) {
+    const m3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
+    const float is[3] = {1.f / sc[0], 1.f / sc[1], 1.f / sc[2]};
+    m3 M;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
+    f3 g = mu;
+    m3 Mr = M;
+    if (UNIFORM_ORIGIN) {
+        g = mul(M, cam.origin - mu);
+        const m3& Ri = cam.Rinv; // camera -> world: the kernels then work on CAMERA-space ray directions
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Mr.m[r][c] = M.m[r][0] * Ri.m[0][c] + M.m[r][1] * Ri.m[1][c] + M.m[r][2] * Ri.m[2][c];
+    }
+    rec.r0 = make_float4(Mr.m[0][0], Mr.m[0][1], Mr.m[0][2], g.x);
+    rec.r1 = make_float4(Mr.m[1][0], Mr.m[1][1], Mr.m[1][2], g.y);
+    rec.r2 = make_float4(Mr.m[2][0], Mr.m[2][1], Mr.m[2][2], g.z);
+    rec.r3 = make_float4(opac, c0, c1, c2);
+    ConicRec k = conic_never();
+    if (UNIFORM_ORIGIN) {
+        const m3& Ri = cam.Rinv;                      // camera -> world, so world -> camera is its transpose
+        const f3 pcv = mul_t(Ri, mu - cam.origin);
+        const float pc[3] = {pcv.x, pcv.y, pcv.z};
+        float A[3][3];                                // A = Rc R S  (Sigma_cam = A A^T)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                A[r][c] = (Ri.m[0][r] * R.m[0][c] + Ri.m[1][r] * R.m[1][c] + Ri.m[2][r] * R.m[2][c]) * sc[c];
+        k = conic_record(pc, A, opac);
+    }
+    cr.a = make_float4(k.px, k.py, k.a, k.b);
+    cr.b = make_float4(k.d, k.e, k.g, k.ia);
+}
+
+} // namespace lfs

@@ -12,6 +12,10 @@
 
 namespace lfs {
 
+// ACT (fused training step): quats / scales / opacities are the RAW parameters; the kernel applies gs::SplatData's activations first (the arithmetic of
+// activations_fwd_kernel, l2_fused.hip: x / max(|x|, 1e-12), exp, sigmoid), stores the activated values (act_*) and projects those - bit for bit what the
+// two separate kernels compute. conics are not needed by the world-space rasterizer and not written then.
+template <bool ACT>
 __global__ void __launch_bounds__(256) projection_ut_kernel(
     const uint32_t N,
     const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
@@ -19,7 +23,8 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
     const float eps2d, const float near_plane, const float far_plane, const float radius_clip,
     const lfs_ut_params ut,
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
-    float* __restrict__ conics, float* __restrict__ compensations) {
+    float* __restrict__ conics, float* __restrict__ compensations,
+    float* __restrict__ act_quats = nullptr, float* __restrict__ act_scales = nullptr, float* __restrict__ act_opacities = nullptr) {
     const uint32_t cid = blockIdx.y;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= N) return;
@@ -33,8 +38,21 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
 
     do {
         const f3 mean{means[3 * gid], means[3 * gid + 1], means[3 * gid + 2]};
-        const f3 scale{scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
-        const quat rot = qnormalize(quat{quats[4 * gid], quats[4 * gid + 1], quats[4 * gid + 2], quats[4 * gid + 3]});
+        f3 scale{scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
+        float4 qin = reinterpret_cast<const float4*>(quats)[gid];
+        float opac_in = opacities != nullptr ? opacities[gid] : 0.f;
+        if (ACT) {
+            const float den = fmaxf(sqrtf(qin.x * qin.x + qin.y * qin.y + qin.z * qin.z + qin.w * qin.w), 1e-12f);
+            qin = make_float4(qin.x / den, qin.y / den, qin.z / den, qin.w / den);
+            scale = {expf(scale.x), expf(scale.y), expf(scale.z)};
+            opac_in = 1.f / (1.f + expf(-opac_in));
+            if (cid == 0) {
+                reinterpret_cast<float4*>(act_quats)[gid] = qin;
+                act_scales[3 * gid] = scale.x; act_scales[3 * gid + 1] = scale.y; act_scales[3 * gid + 2] = scale.z;
+                act_opacities[gid] = opac_in;
+            }
+        }
+        const quat rot = qnormalize(quat{qin.x, qin.y, qin.z, qin.w});
 
         // depth test at the centre-of-exposure pose
         quat qc; f3 tc;
@@ -93,7 +111,7 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
 
         float extend = 3.33f;
         if (opacities != nullptr) {
-            const float op = opacities[gid] * compensation;
+            const float op = opac_in * compensation;
             if (op < (1.f / 255.f)) break;
             extend = fminf(extend, sqrtf(2.f * logf(op / (1.f / 255.f))));
         }
@@ -114,7 +132,7 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
     reinterpret_cast<int2*>(radii)[idx] = make_int2(out_rx, out_ry);
     reinterpret_cast<float2*>(means2d)[idx] = make_float2(o_m2x, o_m2y);
     depths[idx] = o_depth;
-    conics[3 * idx] = o_c0; conics[3 * idx + 1] = o_c1; conics[3 * idx + 2] = o_c2;
+    if (conics != nullptr) { conics[3 * idx] = o_c0; conics[3 * idx + 1] = o_c1; conics[3 * idx + 2] = o_c2; }
     if (compensations != nullptr) compensations[idx] = o_comp;
 }
 
@@ -134,8 +152,26 @@ extern "C" int lfs_projection_ut_3dgs_fused(
     if (ut_params) ut = *ut_params;
     dim3 grid((N + 255) / 256, cams->C);
     lfs::ProfScope prof("projection_ut", (hipStream_t)stream);
-    hipLaunchKernelGGL(lfs::projection_ut_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(lfs::projection_ut_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
                        N, means, quats, scales, opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
-                       radii, means2d, depths, conics, compensations);
+                       radii, means2d, depths, conics, compensations, nullptr, nullptr, nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int lfs_activations_project_ut(
+    uint32_t N, const float* means, const float* raw_quats, const float* raw_scales, const float* raw_opacities, const lfs_cameras* cams,
+    float eps2d, float near_plane, float far_plane, float radius_clip, const lfs_ut_params* ut_params,
+    float* quats, float* scales, float* opacities, int32_t* radii, float* means2d, float* depths, lfs_stream_t stream) {
+    if (!cams || !cams->viewmats0 || !cams->Ks) return LFS_E_INVALID;
+    if (cams->camera_model != LFS_CAMERA_PINHOLE && cams->camera_model != LFS_CAMERA_FISHEYE) return LFS_E_UNSUPPORTED;
+    if (N == 0 || cams->C == 0) return LFS_OK;
+    if (!means || !raw_quats || !raw_scales || !raw_opacities || !quats || !scales || !opacities || !radii || !means2d || !depths) return LFS_E_INVALID;
+    lfs_ut_params ut = {0.1f, 2.f, 0.f, 0.1f, 1};
+    if (ut_params) ut = *ut_params;
+    dim3 grid((N + 255) / 256, cams->C);
+    lfs::ProfScope prof("activations_projection_ut", (hipStream_t)stream);
+    hipLaunchKernelGGL(lfs::projection_ut_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+                       N, means, raw_quats, raw_scales, raw_opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
+                       radii, means2d, depths, nullptr, nullptr, quats, scales, opacities);
     return (int)hipGetLastError();
 }

@@ -40,6 +40,7 @@
 #include "lfs_prof.h"
 #include "lfs_raster_common.cuh"
 #include "lfs_cull_conic.cuh"
+#include "lfs_raster_pack.cuh"
 #include "lfs_adam.cuh"
 
 // Host build on the wavefront emulator (tests/emul) only: wave-evaluation counters [fwd, fwd that composited, bwd, bwd that accumulated]
@@ -53,9 +54,6 @@ extern "C" { __attribute__((visibility("default"))) unsigned long long lfs_emul_
 namespace lfs {
 
 static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
-// Per-Gaussian culling record (the silhouette conic of the alpha >= 1/255 ellipsoid in normalised camera coordinates): see raster_pack_kernel.
-struct __attribute__((aligned(16))) CullRec { float4 a, b; };
-
 constexpr uint32_t LOSS_SLOTS = 256; // fused MSE: the wavefronts' partial sums are spread over this many addresses (one hot address costs ~0.08 ms)
 struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; CullRec* cull; int32_t* cell_count; int2* cell_list; int32_t* quad_count; int2* quad_list; unsigned long long* det64; size_t bytes; };
 // cells = C * tiles * (tile_size/8)^2 ; the compacted per-cell lists hold at most (tile_size/8)^2 * n_isects entries
@@ -101,54 +99,12 @@ __global__ void __launch_bounds__(256) raster_pack_kernel(
     const uint32_t cid = uint32_t(idx / N), gid = uint32_t(idx % N);
     const f3 mu{means[3 * gid], means[3 * gid + 1], means[3 * gid + 2]};
     const float4 q = reinterpret_cast<const float4*>(quats)[gid];
-    const m3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
-    const float is[3] = {1.f / scales[3 * gid], 1.f / scales[3 * gid + 1], 1.f / scales[3 * gid + 2]};
-    m3 M;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
-    f3 g = mu;
-    m3 Mr = M; // what the record carries: M for rolling shutters (world-space rays), M * Rinv for a global shutter
-    if (UNIFORM_ORIGIN) {
-        g = mul(M, cams[cid].origin - mu);
-        const m3& Ri = cams[cid].Rinv; // camera -> world: the kernels then work on CAMERA-space ray directions
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Mr.m[r][c] = M.m[r][0] * Ri.m[0][c] + M.m[r][1] * Ri.m[1][c] + M.m[r][2] * Ri.m[2][c];
-    }
-    GaussRec rec;
-    rec.r0 = make_float4(Mr.m[0][0], Mr.m[0][1], Mr.m[0][2], g.x);
-    rec.r1 = make_float4(Mr.m[1][0], Mr.m[1][1], Mr.m[1][2], g.y);
-    rec.r2 = make_float4(Mr.m[2][0], Mr.m[2][1], Mr.m[2][2], g.z);
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    const float sc[3] = {scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
     const float* cp = colors + idx * channels;
-    c0 = cp[0];
-    if (channels > 1) c1 = cp[1];
-    if (channels > 2) c2 = cp[2];
-    const float opac = opacities[idx];
-    rec.r3 = make_float4(opac, c0, c1, c2);
-    recs[idx] = rec;
-
-    // Culling record for raster_cull_kernel: the silhouette conic of the alpha >= 1/255 ellipsoid (lfs_cull_conic.cuh). Rolling
-    // shutters have no single camera frame: never culled.
-    ConicRec k = conic_never();
-    if (UNIFORM_ORIGIN) {
-        const m3& Ri = cams[cid].Rinv;                // camera -> world, so world -> camera is its transpose
-        const f3 pcv = mul_t(Ri, mu - cams[cid].origin);
-        const float pc[3] = {pcv.x, pcv.y, pcv.z};
-        float A[3][3];                                // A = Rc R S  (Sigma_cam = A A^T)
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                A[r][c] = (Ri.m[0][r] * R.m[0][c] + Ri.m[1][r] * R.m[1][c] + Ri.m[2][r] * R.m[2][c]) * scales[3 * gid + c];
-        k = conic_record(pc, A, opac);
-    }
+    GaussRec rec;
     CullRec cr;
-    cr.a = make_float4(k.px, k.py, k.a, k.b);
-    cr.b = make_float4(k.d, k.e, k.g, k.ia);
+    pack_gaussian<UNIFORM_ORIGIN>(cams[cid], mu, q, sc, opacities[idx], cp[0], channels > 1 ? cp[1] : 0.f, channels > 2 ? cp[2] : 0.f, rec, cr);
+    recs[idx] = rec;
     cull[idx] = cr;
 }
 
@@ -1188,12 +1144,12 @@ static int raster_check(uint32_t N, uint32_t channels, const lfs_cameras* cams, 
 static void raster_prepare(const RasterWs& w, const RasterGeom& g, uint32_t N, uint32_t channels, const float* means, const float* quats,
                            const float* scales, const float* colors, const float* opacities, const uint8_t* masks,
                            const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
-                           int64_t n_isects, hipStream_t s) {
+                           int64_t n_isects, hipStream_t s, bool prepacked = false) {
     const uint32_t C = cams->C;
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
-    hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
+    if (!prepacked) hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
     const size_t CN = size_t(C) * N;
-    if (CN > 0) {
+    if (CN > 0 && !prepacked) {
         lfs::ProfScope prof_pack("raster_pack", s);
         const dim3 pg(uint32_t((CN + 255) / 256));
         if (uniform) hipLaunchKernelGGL(raster_pack_kernel<true>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs, w.cull);
@@ -1225,14 +1181,13 @@ static void raster_prepare(const RasterWs& w, const RasterGeom& g, uint32_t N, u
     }
 }
 
-extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
+static int raster_fwd_impl(
     uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
     const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
-    const lfs_cameras* cams, uint32_t tile_size, const lfs_ut_params* ut_params,
+    const lfs_cameras* cams, uint32_t tile_size,
     const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
     float* render_colors, float* render_alphas, int32_t* last_ids,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
-    (void)ut_params; // carried by the reference signature, unused by its rasterizer as well
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream, bool prepacked) {
     RasterGeom g;
     int rc = raster_check(N, channels, cams, tile_size, g);
     if (rc) return rc;
@@ -1245,7 +1200,7 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     if (N > 0 && (!means || !quats || !scales || !colors || !opacities)) return LFS_E_INVALID;
     if (n_isects > 0 && !flatten_ids) return LFS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects, s);
+    raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects, s, prepacked);
     lfs::ProfScope prof("raster_fwd", s);
 #define LFS_FWD_K(KERNEL, CD, MODE)                                                                              \
     hipLaunchKernelGGL((KERNEL<CD, MODE>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,                   \
@@ -1267,6 +1222,51 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
 #undef LFS_FWD_K
 #undef LFS_FWD_ROWS
 #undef LFS_FWD
+    return (int)hipGetLastError();
+}
+
+extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
+    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
+    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
+    const lfs_cameras* cams, uint32_t tile_size, const lfs_ut_params* ut_params,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    float* render_colors, float* render_alphas, int32_t* last_ids,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    (void)ut_params; // carried by the reference signature, unused by its rasterizer as well
+    return raster_fwd_impl(N, channels, means, quats, scales, colors, opacities, backgrounds, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects,
+                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, stream, false);
+}
+
+// Extension (fused training step): the camera state, the 64-byte records and the culling records are ALREADY in the workspace - lfs_gut_prepare_cameras
+// and lfs_sh_model_fwd_pack put them there (offsets: lfs_rasterize_workspace_offsets) - so only the cell lists are built before the forward kernel.
+extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd_prepacked(
+    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
+    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
+    const lfs_cameras* cams, uint32_t tile_size,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    float* render_colors, float* render_alphas, int32_t* last_ids,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    if (!cams || cams->rs_type != LFS_SHUTTER_GLOBAL || cams->C != 1 || channels != 3) return LFS_E_UNSUPPORTED;
+    return raster_fwd_impl(N, channels, means, quats, scales, colors, opacities, backgrounds, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects,
+                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, stream, true);
+}
+
+// byte offsets of the camera state, the records, the accumulator rows and the culling records inside a rasterizer workspace, and the size of that
+// prefix: they do not depend on n_isects, so a workspace can be filled before the intersection count is known (and its prefix copied if it has to grow)
+extern "C" void lfs_rasterize_workspace_offsets(uint32_t C, uint32_t N, size_t* cams, size_t* recs, size_t* acc, size_t* cull, size_t* prefix_bytes) {
+    const RasterWs w = raster_ws(nullptr, C, N, 0, 0, false);
+    const char* z = nullptr;
+    if (cams) *cams = size_t(reinterpret_cast<const char*>(w.cams) - z);
+    if (recs) *recs = size_t(reinterpret_cast<const char*>(w.recs) - z);
+    if (acc) *acc = size_t(reinterpret_cast<const char*>(w.acc) - z);
+    if (cull) *cull = size_t(reinterpret_cast<const char*>(w.cull) - z);
+    if (prefix_bytes) *prefix_bytes = size_t(reinterpret_cast<const char*>(w.cell_count) - z);
+}
+
+extern "C" int lfs_gut_prepare_cameras(const lfs_cameras* cams, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    if (!cams || !cams->viewmats0 || !cams->Ks || cams->C == 0 || !workspace) return LFS_E_INVALID;
+    if (workspace_bytes < align256(sizeof(CamDev) * cams->C)) return LFS_E_WORKSPACE;
+    hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *cams, reinterpret_cast<CamDev*>(workspace));
     return (int)hipGetLastError();
 }
 

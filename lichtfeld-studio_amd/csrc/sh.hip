@@ -12,6 +12,7 @@
 #include "lfs_math.cuh"
 #include "lfs_prof.h"
 #include "lfs_adam.cuh"
+#include "lfs_raster_pack.cuh"
 #include "../../include/lfs_gsplat.h"
 
 namespace lfs {
@@ -158,9 +159,15 @@ template <bool MODEL, class T> LFS_DI T* sh_coef(T* coeffs, T* sh0, T* shN, uint
 //   3. (bwd) lane = Gaussian : dL/d(dir) = sum_k s_k grad b_k, evaluated once per Gaussian.
 // The previous layout evaluated the polynomial in every one of the LPG lanes of a Gaussian and was VALU-bound
 // (rocprof: 8.1e7 VALU instructions = 0.13 ms of the 0.20 ms backward at 1M Gaussians, K = 16).
-template <int LPG, bool MODEL>
-__global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors) {
+// PACK (fused training step, model form, one global-shutter camera): the lane that owns a Gaussian in phase 1 also stages it for the world-space
+// rasterizer once its colour is known - the 64-byte record and the 32-byte culling record of raster_pack_kernel (lfs_raster_pack.cuh), written
+// straight into the rasterizer workspace. The pack kernel, its re-read of means / quats / scales / opacities / colours and one launch disappear.
+struct ShPack { const float* quats; const float* scales; const float* opacities; const CamDev* cam; GaussRec* recs; CullRec* cull; };
+
+template <int LPG, bool MODEL, bool PACK = false>
+__global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors, const ShPack pk = ShPack{}) {
     __shared__ float lds[64 * (LPG + 1)];
+    __shared__ float ldc[PACK ? 64 * 3 : 1];
     const uint32_t lane = threadIdx.x;
     const uint32_t g0 = blockIdx.x * 64u;
     const int degree = a.degree;
@@ -205,6 +212,21 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
             if (MODEL) { r0 = fmaxf(r0 + 0.5f, 0.f); r1 = fmaxf(r1 + 0.5f, 0.f); r2 = fmaxf(r2 + 0.5f, 0.f); }
             const size_t cs = (MODEL && a.cs) ? a.cs : 3;
             colors[cs * g] = r0; colors[cs * g + 1] = r1; colors[cs * g + 2] = r2;
+            if (PACK) { ldc[gl * 3] = r0; ldc[gl * 3 + 1] = r1; ldc[gl * 3 + 2] = r2; }
+        }
+    }
+    if (PACK) {
+        __syncthreads();
+        const uint32_t g = g0 + lane;
+        if (g < a.n && sh_on<MODEL>(a, g)) { // only Gaussians that reach a tile list are ever looked up
+            const f3 mu{a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
+            const float4 q = reinterpret_cast<const float4*>(pk.quats)[g];
+            const float sc[3] = {pk.scales[3 * g], pk.scales[3 * g + 1], pk.scales[3 * g + 2]};
+            GaussRec rec;
+            CullRec cr;
+            pack_gaussian<true>(*pk.cam, mu, q, sc, pk.opacities[g], ldc[lane * 3], ldc[lane * 3 + 1], ldc[lane * 3 + 2], rec, cr);
+            pk.recs[g] = rec;
+            pk.cull[g] = cr;
         }
     }
 }
@@ -322,6 +344,18 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
 }
 
 static inline int lanes_for(uint32_t k) { return k <= 1 ? 1 : k <= 4 ? 4 : k <= 16 ? 16 : 32; }
+
+static int sh_launch_fwd_pack(const ShArgs& a, uint32_t Kcover, float* colors, const ShPack& pk, hipStream_t s) {
+    const dim3 grid((a.n + 63) / 64), block(64);
+    lfs::ProfScope prof("sh_fwd_pack", s);
+    switch (lanes_for(Kcover)) {
+    case 1: hipLaunchKernelGGL((sh_fwd_kernel<1, true, true>), grid, block, 0, s, a, colors, pk); break;
+    case 4: hipLaunchKernelGGL((sh_fwd_kernel<4, true, true>), grid, block, 0, s, a, colors, pk); break;
+    case 16: hipLaunchKernelGGL((sh_fwd_kernel<16, true, true>), grid, block, 0, s, a, colors, pk); break;
+    default: hipLaunchKernelGGL((sh_fwd_kernel<32, true, true>), grid, block, 0, s, a, colors, pk); break;
+    }
+    return (int)hipGetLastError();
+}
 
 template <bool MODEL>
 static int sh_launch_fwd(const ShArgs& a, uint32_t Kcover, float* colors, hipStream_t s) {
@@ -578,6 +612,29 @@ extern "C" int lfs_sh_model_fwd(
     a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii;
     return lfs::sh_launch_fwd<true>(a, Kd, colors, (hipStream_t)stream);
 }
+
+#ifndef LFS_EMULATE // (the host build of tests/emul links sh.hip alone)
+// lfs_sh_model_fwd that also stages every visible Gaussian for the rasterizer (see ShPack): quats / scales / opacities are the ACTIVATED values,
+// `workspace` a rasterizer workspace whose camera state lfs_gut_prepare_cameras has filled (one camera, global shutter).
+extern "C" int lfs_sh_model_fwd_pack(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+    const int32_t* radii, const float* quats, const float* scales, const float* opacities, float* colors,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
+    if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
+    if (n == 0) return LFS_OK;
+    if (!means || !viewmat || !sh0 || (K > 1 && !shN) || !radii || !colors || !quats || !scales || !opacities || !workspace) return LFS_E_INVALID;
+    size_t o_cams, o_recs, o_cull, prefix;
+    lfs_rasterize_workspace_offsets(1, n, &o_cams, &o_recs, nullptr, &o_cull, &prefix);
+    if (workspace_bytes < prefix) return LFS_E_WORKSPACE;
+    lfs::ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii;
+    char* ws = static_cast<char*>(workspace);
+    const lfs::ShPack pk{quats, scales, opacities, reinterpret_cast<const lfs::CamDev*>(ws + o_cams), reinterpret_cast<lfs::GaussRec*>(ws + o_recs),
+                         reinterpret_cast<lfs::CullRec*>(ws + o_cull)};
+    return lfs::sh_launch_fwd_pack(a, Kd, colors, pk, (hipStream_t)stream);
+}
+#endif
 
 extern "C" int lfs_sh_model_bwd(
     uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,

@@ -69,6 +69,84 @@ def sh_model_bwd_adam(sh_degree: int, means, viewmat, sh0, shN, radii, colors, v
                                                C.c_float(adam["bc1_rcp"]), C.c_float(adam["bc2_sqrt_rcp"]), stream()), "sh_model_bwd_adam")
 
 
+# ---- the front half of the fused step: activations + projection in one kernel, SH colours + rasterizer records in one kernel --------------------
+_FRONT_WS: dict = {}   # device index -> (workspace tensor, last n_isects): filled BEFORE the intersection count is known, so it is sized from the last step
+
+
+def front_workspace(N: int, W: int, H: int, tile: int, dev) -> torch.Tensor:
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws, last = _FRONT_WS.get(key, (None, 0))
+    need = load_library().lfs_rasterize_workspace_bytes(C.c_uint32(1), C.c_uint32(N), C.c_uint32(3), C.c_uint32(W), C.c_uint32(H), C.c_uint32(tile),
+                                                        C.c_int64(max(int(last * 1.25), 1 << 20)))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        _FRONT_WS[key] = (ws, last)
+    return ws
+
+
+def front_workspace_fit(ws: torch.Tensor, N: int, W: int, H: int, tile: int, n_isects: int) -> torch.Tensor:
+    """the workspace for the real n_isects: the same tensor, or a larger one that received the records already written (they live in a prefix whose
+    layout does not depend on n_isects)"""
+    lib = load_library()
+    dev = ws.device
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    need = lib.lfs_rasterize_workspace_bytes(C.c_uint32(1), C.c_uint32(N), C.c_uint32(3), C.c_uint32(W), C.c_uint32(H), C.c_uint32(tile), C.c_int64(n_isects))
+    if need > ws.numel():
+        prefix = C.c_size_t(0)
+        lib.lfs_rasterize_workspace_offsets(C.c_uint32(1), C.c_uint32(N), None, None, None, None, C.byref(prefix))
+        new = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
+        new[:prefix.value].copy_(ws[:prefix.value])
+        ws = new
+    _FRONT_WS[key] = (ws, n_isects)
+    return ws
+
+
+def activations_project(means, raw_quats, raw_scales, raw_opacities, viewmat, Kmat, W: int, H: int, ut, camera_model=CameraModelType.PINHOLE):
+    """activations_fwd + ops.projection_ut_3dgs_fused (trainer constants of rasterizer.cpp:176-181) in one kernel -> (quats, scales, opacities, radii, means2d, depths)"""
+    require_gpu(means, raw_quats, raw_scales, raw_opacities, viewmat, Kmat)
+    N, dev = means.shape[0], means.device
+    quats, scales, opac = torch.empty_like(raw_quats), torch.empty_like(raw_scales), torch.empty_like(raw_opacities)
+    radii = torch.empty((1, N, 2), dtype=torch.int32, device=dev)
+    means2d, depths = torch.empty((1, N, 2), dtype=means.dtype, device=dev), torch.empty((1, N), dtype=means.dtype, device=dev)
+    cams = cameras_struct(viewmat, None, Kmat, W, H, camera_model, ShutterType.GLOBAL, None, None, None)
+    from .capi import ut_struct
+    u = ut_struct(ut)
+    check(load_library().lfs_activations_project_ut(C.c_uint32(N), ptr(means), ptr(raw_quats), ptr(raw_scales), ptr(raw_opacities), C.byref(cams), C.c_float(0.3),
+                                                    C.c_float(0.01), C.c_float(10000.0), C.c_float(0.0), C.byref(u), ptr(quats), ptr(scales), ptr(opac), ptr(radii),
+                                                    ptr(means2d), ptr(depths), stream()), "activations_project_ut")
+    return quats, scales, opac, radii, means2d, depths
+
+
+def sh_model_fwd_pack(sh_degree: int, means, viewmat, sh0, shN, radii, quats, scales, opac, ws):
+    """sh_model_fwd that also writes the rasterizer's records / culling records of the visible Gaussians into the workspace `ws`"""
+    N, K = means.shape[0], 1 + shN.shape[1]
+    colors = torch.empty((N, 3), dtype=means.dtype, device=means.device)
+    check(load_library().lfs_sh_model_fwd_pack(C.c_uint32(N), C.c_uint32(K), C.c_uint32(sh_degree), ptr(means), ptr(viewmat), ptr(sh0), ptr(shN), ptr(radii), ptr(quats),
+                                               ptr(scales), ptr(opac), ptr(colors), ptr(ws), C.c_size_t(ws.numel()), stream()), "sh_model_fwd_pack")
+    return colors
+
+
+def rasterize_fwd_prepacked(means, quats, scales, colors, opac, bg, W: int, H: int, tile: int, viewmat, Kmat, offsets, flatten_ids, ws):
+    N, dev = means.shape[0], means.device
+    renders = torch.empty((1, H, W, 3), dtype=means.dtype, device=dev)
+    alphas = torch.empty((1, H, W, 1), dtype=means.dtype, device=dev)
+    last_ids = torch.empty((1, H, W), dtype=torch.int32, device=dev)
+    cams = cameras_struct(viewmat, None, Kmat, W, H, CameraModelType.PINHOLE, ShutterType.GLOBAL, None, None, None)
+    check(load_library().lfs_rasterize_to_pixels_from_world_3dgs_fwd_prepacked(
+        C.c_uint32(N), C.c_uint32(3), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opac), ptr(bg), None, C.byref(cams), C.c_uint32(tile),
+        ptr(offsets), ptr(flatten_ids), C.c_int64(flatten_ids.shape[0]), ptr(renders), ptr(alphas), ptr(last_ids), ptr(ws), C.c_size_t(ws.numel()), stream()),
+        "rasterize_fwd_prepacked")
+    return renders, alphas, last_ids
+
+
+FUSE_ACT_PROJ = True   # activations + projection in one kernel (bit-identical outputs; saves one launch and the re-read of the activated values)
+# SH colours + rasterizer records in one kernel. Measured on MI355X (SYN-B, same-box A/B, profiles/r02/fuse_front_ab.txt): sh_fwd_pack 0.098 ms against
+# sh_fwd 0.067 + raster_pack 0.043, but raster_cull + raster_fwd lose 0.012 ms - the separate pack kernel runs right before them and leaves the records
+# hot in L2 / Infinity Cache, the fused one writes them a sort and a host round trip earlier - and the step time does not move (1.707 vs 1.702 ms).
+# Off by default; kept, tested (tests/test_gpu_fused.py), as the measured answer to "fuse raster_pack into the streaming pass before it".
+FUSE_SH_PACK = False
+
+
 def _adam_scalars(a: dict):
     return (C.c_float * 6)(a["lr"], a["beta1"], a["beta2"], a["eps"], a["bc1_rcp"], a["bc2_sqrt_rcp"])
 
@@ -180,11 +258,22 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
     tile = 16
     tw, th = (W + tile - 1) // tile, (H + tile - 1) // tile
     with torch.no_grad():
-        quats, scales, opac = activations_fwd(raw_quats, raw_scales, raw_opac)
-        radii, means2d, depths, _, _ = ops.projection_ut_3dgs_fused(means, quats, scales, opac, viewmat, None, Kmat, W, H, 0.3, 0.01, 10000.0, 0.0,
-                                                                    False, CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None)
+        bg = None if bg_color is None else bg_color.view(1, -1).contiguous()
+        front = FUSE_SH_PACK and sh_exchange is None      # (SH-sharded: the colours come back from the owners, the pack kernel stays separate)
+        if front:
+            ws = front_workspace(means.shape[0], W, H, tile, means.device)
+            cams_c = cameras_struct(viewmat, None, Kmat, W, H, CameraModelType.PINHOLE, ShutterType.GLOBAL, None, None, None)
+            check(load_library().lfs_gut_prepare_cameras(C.byref(cams_c), ptr(ws), C.c_size_t(ws.numel()), stream()), "gut_prepare_cameras")
+        if front or FUSE_ACT_PROJ:
+            quats, scales, opac, radii, means2d, depths = activations_project(means, raw_quats, raw_scales, raw_opac, viewmat, Kmat, W, H, ut)
+        else:
+            quats, scales, opac = activations_fwd(raw_quats, raw_scales, raw_opac)
+            radii, means2d, depths, _, _ = ops.projection_ut_3dgs_fused(means, quats, scales, opac, viewmat, None, Kmat, W, H, 0.3, 0.01, 10000.0, 0.0,
+                                                                        False, CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None)
         # SH colours do not depend on the tile lists: they are enqueued while the host waits for n_isects (ops.intersect_tile `overlap`)
         def sh_stage():
+            if front:
+                return sh_model_fwd_pack(deg, means, viewmat, sh0, shN, radii, quats, scales, opac, ws), None
             if sh_exchange is None:
                 return sh_model_fwd(deg, means, viewmat, sh0, shN, radii), None
             return sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd_views)
@@ -194,10 +283,14 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         else:
             colors, sh_ctx = sh_stage()
             _, _, flatten_ids, offsets = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True)
-        bg = None if bg_color is None else bg_color.view(1, -1).contiguous()
         fwd_args = (means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, None, W, H, tile, viewmat, None, Kmat,
                     CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None, offsets, flatten_ids)
-        render, alpha, last_ids, ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(*fwd_args, own_workspace=True)
+        if front:
+            ws = front_workspace_fit(ws, means.shape[0], W, H, tile, int(flatten_ids.shape[0]))
+            render, alpha, last_ids = rasterize_fwd_prepacked(means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, W, H, tile, viewmat, Kmat, offsets,
+                                                              flatten_ids, ws)
+        else:
+            render, alpha, last_ids, ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(*fwd_args, own_workspace=True)
         fuse_mse = loss == "mse" and FUSE_MSE_INTO_BACKWARD and flatten_ids.shape[0] > 0 and bilateral is None
         if bilateral is not None:    # clamp (rasterizer.cpp:399 / bilateral_grid.cpp:115) -> slice -> loss on the un-clamped result -> slice backward
             from .losses import loss_fwd_bwd

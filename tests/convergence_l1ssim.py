@@ -33,7 +33,7 @@ def psnr(a, b):
 
 
 def oracle_targets(gt):
-    """the ground-truth views rendered by the oracle (CPU); the HIP side reads them from the .npz so both sides fit the same pixels"""
+    """the ground-truth views rendered by the oracle (CPU); the HIP side renders them with the HIP kernels (mean difference ~1e-7)"""
     from oracle import pipeline
     sa = pipeline.scene_arrays(gt)
     z = np.zeros((3, gt.height, gt.width), np.float32)
@@ -98,7 +98,7 @@ def main():
             fin = dict(pipeline.scene_arrays(init), **P)
             z = np.zeros((3, gt.height, gt.width), np.float32)
             ps = [psnr(np.clip(pipeline.train_image(fin, v, z, backward=False)["render"][0].transpose(2, 0, 1), 0, 1), targets[v]) for v in range(len(targets))]
-            np.savez_compressed(args.out.replace(".json", f"_seed{seed}.npz"), targets=np.stack(targets), **{k: P[k] for k in NAMES})
+            np.savez_compressed(args.out.replace(".json", f"_seed{seed}.npz"), **{k: P[k] for k in NAMES})   # (the HIP side renders its own targets: 1e-7 apart)
             res["seeds"][str(seed)] = {"oracle_psnr_oracle_renderer": round(float(np.mean(ps)), 4), "seconds": round(time.time() - t0, 1)}
             json.dump(res, open(args.out, "w"), indent=1)
             print(seed, res["seeds"][str(seed)], flush=True)
@@ -136,7 +136,7 @@ def main():
         gt, init = make_task(seed=100 + seed)
         f = args.oracle_json.replace(".json", f"_seed{seed}.npz")
         o = dict(np.load(f)) if os.path.exists(f) else None
-        targets = [torch.from_numpy(t).to(dev) for t in o["targets"]] if o is not None else render_views_hip(gt, dev)
+        targets = render_views_hip(gt, dev)
         r = {"psnr_start": round(eval_psnr(init, targets), 4)}
         d1, d2 = train(init, targets, True), train(init, targets, True)
         r["deterministic_runs_bit_identical"] = bool(all(np.array_equal(d1[k], d2[k]) for k in NAMES))

@@ -115,7 +115,7 @@ def test_profile_hooks_report_every_hot_kernel(lfs):
     tr.train_step([target]); tr.train_step([target])
     capi.profile_enable(False)
     k = capi.profile_collect()
-    for name in ["projection_ut", "sh_fwd", "isect_count_scan", "isect_scatter", "isect_tile_sort", "raster_fwd", "raster_bwd", "sh_bwd", "adam_multi"]:
+    for name in ["activations_projection_ut", "sh_fwd", "isect_count_scan", "isect_scatter", "isect_tile_sort", "raster_fwd", "raster_bwd", "sh_bwd", "adam_multi"]:
         assert name in k and k[name][1] == 2 and k[name][0] > 0, (name, k)
     assert capi.profile_collect() == {}
 
