@@ -266,7 +266,10 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
             if (degree >= 1) { inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
             sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
             const size_t vs = (MODEL && a.vs) ? a.vs : 3, cs = (MODEL && a.cs) ? a.cs : 3;
-            v0 = v_colors[vs * gmine]; v1 = v_colors[vs * gmine + 1]; v2 = v_colors[vs * gmine + 2];
+            if (MODEL && a.vs == 16 && ((reinterpret_cast<uintptr_t>(v_colors) - 4) & 15) == 0) { // rows of a rasterizer accumulator (3DGUT: slots 13..15, fastgs: 5..7): ONE aligned 16-byte load instead of three strided dwords
+                const float4 r = *reinterpret_cast<const float4*>(v_colors + 16 * size_t(gmine) - 1);
+                v0 = r.y; v1 = r.z; v2 = r.w;
+            } else { v0 = v_colors[vs * gmine]; v1 = v_colors[vs * gmine + 1]; v2 = v_colors[vs * gmine + 2]; }
             if (MODEL) {
                 if (!(a.colors[cs * gmine] > 0.f)) v0 = 0.f;
                 if (!(a.colors[cs * gmine + 1] > 0.f)) v1 = 0.f;

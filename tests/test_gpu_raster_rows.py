@@ -1,7 +1,7 @@
-"""EXPERIMENTAL quadrant-row rasterizer kernels (csrc/lfs_raster_rows.cuh, lfs_set_debug_flags bit 2). They were written after round 1's GPU
-budget was spent and have not run on a GPU yet, so these checks are opt-in:  LFS_EXPERIMENTAL_ROWS=1 python -m pytest tests/test_gpu_raster_rows.py
-The forward has to be BIT-identical to the default kernels (same per-pixel operation sequence; the quadrant lists only drop entries that cannot
-reach alpha >= 1/255 on any ray of the quadrant), the backward equal up to the float-atomic summation order."""
+"""The quadrant-row rasterizer kernels (csrc/lfs_raster_rows.cuh, lfs_set_debug_flags bit 2): an opt-in alternative to the default 8x8-cell kernels
+that round 2 verified on the GPU (after a DPP hazard fix: tools/debug_rows.py) and measured SLOWER (profiles/r02/raster_rows_vs_default_pmc.txt) - they
+stay in the tree as a tested negative result. The forward has to be BIT-identical to the default kernels (same per-pixel operation sequence; the
+quadrant lists only drop entries that cannot reach alpha >= 1/255 on any ray of the quadrant), the backward equal up to the float-atomic summation order."""
 import os
 
 import numpy as np
@@ -10,7 +10,7 @@ import torch
 
 from gpu_util import make_gaussians, n, pinhole_K, rel_l2, small_rotation_viewmat, t
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.environ.get("LFS_EXPERIMENTAL_ROWS"), reason="experimental kernels: set LFS_EXPERIMENTAL_ROWS=1")]
+pytestmark = pytest.mark.gpu
 
 
 def _rows(lfs, fn, flags=4):
