@@ -340,6 +340,9 @@ extern "C" int lfs_intersect_tile_emit(
             ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_bins_kernel<256>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4096 * 8);
             if (ae != hipSuccess) return (int)ae;
+            ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_bins_kernel<1024, 1024, false, 64>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            if (ae != hipSuccess) return (int)ae;
             big_lds_enabled = true;
         }
         const uint32_t pb = isect_per_block(total);
@@ -354,11 +357,12 @@ extern "C" int lfs_intersect_tile_emit(
         lfs::prof_end(tok, s);
         lfs::ProfScope prof_sort("isect_tile_sort", s);
         const uint32_t n_tiles_ = tile_width * tile_height;
-        // size classes (LDS sized to the class so that small tiles do not cap the occupancy): <= 1024 / 4096 entries with the
-        // counting kernel (256 threads), <= 16384 (128 KiB LDS, bitonic, 1024 threads), larger -> bitonic on global memory
+        // size classes (LDS sized to the class so that small tiles do not cap the occupancy): <= 1024 / 4096 entries with the counting kernel on 256 bins
+        // (256 threads, keys staged in LDS), <= 16384 with the counting kernel on 1024 bins (1024 threads, 128 KiB LDS for the binned copy only; a bin
+        // of more than 64 keys falls back to the bitonic network inside the kernel), larger -> bitonic on global memory
         hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 1024 * 8, s, 1u, 1024u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
         hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 4096 * 8, s, 1025u, 4096u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
-        hipLaunchKernelGGL(tile_sort_lds_kernel<1024>, dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
+        hipLaunchKernelGGL((tile_sort_bins_kernel<1024, 1024, false, 64>), dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
         hipLaunchKernelGGL(tile_sort_global_kernel, dim3(T), dim3(1024), 0, s, 16385u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
     } else {
         if (!tiles_per_gauss) return LFS_E_INVALID;

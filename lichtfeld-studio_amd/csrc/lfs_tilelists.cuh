@@ -72,32 +72,37 @@ LFS_DI void bitonic_sort_lds(uint64_t* __restrict__ keys, const uint32_t n_pad) 
 }
 
 // Per-tile sort, fast path: the keys of one tile are spread over a depth range, so ONE counting pass on a monotone
-// 8-bit quantisation of the (unsigned) depth bits leaves 256 bins of ~n/256 keys, each finished by a single-thread
+// NBINS-level quantisation of the (unsigned) depth bits leaves NBINS bins of ~n/NBINS keys, each finished by a single-thread
 // rank count: ~10 LDS operations per key instead of the ~110 of the bitonic network (which was LDS-pipe bound:
 // 0.17 ms at 4.4 M intersections). Exact: the quantisation is monotone in the key, ties fall into one bin, and a bin
 // with more than BIN_LIMIT keys (degenerate depth distributions) sends the tile through the bitonic network instead.
-template <int THREADS>
+// COPY: the tile's keys are staged in LDS (A) next to the binned copy (B); COPY = false (round 2: lists of 4 097 .. 16 384 keys, the
+// common case at 3 M Gaussians / 1600x1200 where this stage was 0.53 ms per view on the bitonic path) re-reads them from global memory
+// in the two passes instead, so only B (128 KB at 16 384 keys) lives in LDS.
+template <int THREADS, int NBINS = 256, bool COPY = true, uint32_t BIN_LIMIT = 32>
 __global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
     const uint32_t n_min, const uint32_t n_max, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets,
     int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    __shared__ uint32_t s_hist[256], s_off[257], s_minmax[2], s_big;
-    constexpr uint32_t BIN_LIMIT = 32;
+    __shared__ uint32_t s_hist[NBINS], s_off[NBINS + 1], s_minmax[2], s_big;
+    static_assert(NBINS % 64 == 0, "one wave scans the bin counts");
+    constexpr int PER = NBINS / 64;
     const uint32_t t = blockIdx.x;
     const uint32_t start = uint32_t(offsets[t]);
     const uint32_t n = uint32_t(offsets[t + 1]) - start;
     if (n < n_min || n > n_max) return;
     uint32_t n_pad = 2; while (n_pad < n) n_pad <<= 1;
-    uint64_t* A = lds64;          // [n_pad] input copy
-    uint64_t* B = lds64 + n_pad;  // [n_pad] binned / sorted
+    uint64_t* A = lds64;                          // [n_pad] input copy (COPY only)
+    uint64_t* B = COPY ? lds64 + n_pad : lds64;   // [n_pad] binned / sorted
     const uint64_t hi_bits = ((uint64_t(t / n_tiles) << tile_n_bits) | uint64_t(t % n_tiles)) << 32;
-    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0u;
+    for (uint32_t b = threadIdx.x; b < uint32_t(NBINS); b += THREADS) s_hist[b] = 0u;
     if (threadIdx.x == 0) { s_minmax[0] = 0xFFFFFFFFu; s_minmax[1] = 0u; s_big = 0u; }
     __syncthreads();
+    auto key_at = [&](uint32_t i) { return COPY ? A[i] : uint64_t(isect_ids[start + i]); };
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
     for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
         const uint64_t k = uint64_t(isect_ids[start + i]);
-        A[i] = k;
+        if (COPY) A[i] = k;
         const uint32_t d = uint32_t(k >> 32);
         lo = min(lo, d); hi = max(hi, d);
     }
@@ -106,26 +111,27 @@ __global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
     if ((threadIdx.x & 63) == 0) { atomicMin(&s_minmax[0], lo); atomicMax(&s_minmax[1], hi); }
     __syncthreads();
     const uint32_t dmin = s_minmax[0];
-    const float scale = 256.f / (float(s_minmax[1] - dmin) + 1.f); // monotone map of the unsigned depth bits onto [0, 256)
-    auto bin_of = [&](uint64_t k) { return min(255u, uint32_t(float(uint32_t(k >> 32) - dmin) * scale)); };
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) atomicAdd(&s_hist[bin_of(A[i])], 1u);
+    const float scale = float(NBINS) / (float(s_minmax[1] - dmin) + 1.f); // monotone map of the unsigned depth bits onto [0, NBINS)
+    auto bin_of = [&](uint64_t k) { return min(uint32_t(NBINS - 1), uint32_t(float(uint32_t(k >> 32) - dmin) * scale)); };
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) atomicAdd(&s_hist[bin_of(key_at(i))], 1u);
     __syncthreads();
-    if (threadIdx.x < 64) { // exclusive scan of the 256 counts by one wave (4 per lane)
+    if (threadIdx.x < 64) { // exclusive scan of the NBINS counts by one wave (PER per lane)
         const uint32_t l = threadIdx.x;
-        const uint32_t c0 = s_hist[4 * l], c1 = s_hist[4 * l + 1], c2 = s_hist[4 * l + 2], c3 = s_hist[4 * l + 3];
-        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t c[PER], tot = 0, big = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { c[q] = s_hist[PER * l + q]; tot += c[q]; big = max(big, c[q]); }
         uint32_t inc = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(inc), d, 64)); if (int(l) >= d) inc += o; }
-        const uint32_t ex = inc - tot;
-        s_off[4 * l] = ex; s_off[4 * l + 1] = ex + c0; s_off[4 * l + 2] = ex + c0 + c1; s_off[4 * l + 3] = ex + c0 + c1 + c2;
-        if (l == 63) s_off[256] = inc;
-        if (max(max(c0, c1), max(c2, c3)) > BIN_LIMIT) atomicOr(&s_big, 1u);
-        s_hist[4 * l] = 0u; s_hist[4 * l + 1] = 0u; s_hist[4 * l + 2] = 0u; s_hist[4 * l + 3] = 0u; // reused as fill cursors
+        uint32_t run = inc - tot;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { s_off[PER * l + q] = run; run += c[q]; s_hist[PER * l + q] = 0u; } // (s_hist: reused as fill cursors)
+        if (l == 63) s_off[NBINS] = inc;
+        if (big > BIN_LIMIT) atomicOr(&s_big, 1u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-        const uint64_t k = A[i];
+        const uint64_t k = key_at(i);
         const uint32_t b = bin_of(k);
         B[s_off[b] + atomicAdd(&s_hist[b], 1u)] = k;
     }
