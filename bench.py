@@ -167,6 +167,7 @@ def main() -> None:
     ap.add_argument("--wide-cells", action="store_true", help="developer A/B: the experimental two-pixels-per-lane 16x8-cell rasterizer kernels (slower on SYN-B; see raster.hip)")
     ap.add_argument("--row-lists", default="split", choices=["split", "merged"], help="with --row-kernels: quadrant lists split from the cell lists (two kernels) or built in one pass")
     ap.add_argument("--row-kernels", action="store_true", help="developer A/B: the experimental quadrant-row rasterizer kernels (csrc/lfs_raster_rows.cuh; not yet verified on a GPU)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="developer A/B switches (include/lfs_gsplat.h: lfs_set_debug_flags), e.g. 32 = one-pass intersection scatter")
     ap.add_argument("--fuse-sh-pack", action="store_true", help="developer A/B: SH colours + rasterizer records in one kernel (fused.FUSE_SH_PACK; no gain measured)")
     ap.add_argument("--no-fuse-act-proj", action="store_true", help="developer A/B: separate activations and projection kernels")
     ap.add_argument("--no-inline-all", action="store_true", help="developer A/B: separate raster_finish / activations_bwd / adam_multi kernels instead of the all-inline backward")
@@ -183,6 +184,8 @@ def main() -> None:
         lfs.load_library().lfs_set_debug_flags(2)
     if args.row_kernels:
         lfs.load_library().lfs_set_debug_flags(12 if args.row_lists == "merged" else 4)
+    if args.debug_flags:
+        lfs.load_library().lfs_set_debug_flags(args.debug_flags)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
@@ -206,9 +209,10 @@ def main() -> None:
     if args.strategy == "mcmc":
         from lichtfeld_studio_amd import strategies
         extra = dict(strategy="mcmc", opt_params=strategies.OptimizationParameters(iterations=30000, max_cap=scene.N))
-    trainer = GutTrainer(scene, device, iterations=30000 if args.strategy == "mcmc" else 7000, world=world, rank=rank, views_per_rank=args.views_per_rank,
-                         loss=args.loss, rasterizer=args.rasterizer, sh_sharded=False if args.replicated else None,
-                         use_bilateral_grid=args.bilateral_grid, **extra)
+    def make_trainer(sh_sharded):
+        return GutTrainer(scene, device, iterations=30000 if args.strategy == "mcmc" else 7000, world=world, rank=rank, views_per_rank=args.views_per_rank,
+                          loss=args.loss, rasterizer=args.rasterizer, sh_sharded=sh_sharded, use_bilateral_grid=args.bilateral_grid, **extra)
+    trainer = make_trainer(False if args.replicated else None)
     if args.strategy == "mcmc" and args.start_iteration == 3000:
         # the warm-up must contain one refinement step (iteration 3000: relocation + its torch index kernels, whose first use loads ~20 code
         # objects at 20 - 200 ms each); the timed window then holds warm steps only, one of them (every 100th) a refinement step
@@ -219,6 +223,24 @@ def main() -> None:
     from lichtfeld_studio_amd import fused as _fused
     _fused.FUSE_SH_PACK, _fused.FUSE_ACT_PROJ = bool(args.fuse_sh_pack), not args.no_fuse_act_proj
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
+    parallelism_fallback = None
+    if world > 1 and trainer.sh_exchange is not None:
+        # one trial step of the SH-sharded layout (all_to_all + all_gather + all_reduce); if the collective library refuses any of them on this node,
+        # every rank falls back to the replicated layout (one all_reduce per step) together and the JSON line says so
+        ok = 1
+        try:
+            trainer.train_step(targets)
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            ok, parallelism_fallback = 0, str(e).splitlines()[0][:200]
+        flag = torch.tensor([float(ok)], device=device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if float(flag) == 0.0:
+            parallelism_fallback = parallelism_fallback or "another rank failed its SH-sharded trial step"
+            trainer = make_trainer(False)
+            if args.no_inline_all:
+                trainer.inline_all_adam = False
+        trainer.iteration = args.start_iteration
     hip_step = None
     if world == 1 and not args.no_cpu_baseline and args.rasterizer == "gut" and trainer.sh_exchange is None:
         hip_step = hip_reference_step(trainer, 0, targets[0])   # before any update: the oracle starts from the same parameters
@@ -342,6 +364,7 @@ def main() -> None:
                                f"16x16 tiles, {n_views} orbit cameras, {'MSE' if args.loss == 'mse' else 'L1 + 0.2 D-SSIM'} loss, default_optimization_params lrs",
                    "global_batch": world * args.views_per_rank, "views_per_rank": args.views_per_rank,
                    "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ""), "start_iteration": args.start_iteration,
+                   **({"parallelism_fallback": parallelism_fallback} if parallelism_fallback else {}),
                    "strategy": args.strategy, "bilateral_grid": bool(args.bilateral_grid), "refine_step_ms": None if refine_ms is None else round(refine_ms, 3),
                    "visible_gaussians": V, "n_isects": I},
         "collectives": {"backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None), "ranks_seen": seen,

@@ -121,6 +121,26 @@ LFS_API int lfs_intersect_tile_emit(
     const int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* tile_offsets,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 
+/*      Extended forms (what the fused training step and the libtorch wrapper call; same results):
+ *      _count_ex: tile_offsets (nullable, int32 [C*tile_h*tile_w]) is written by the scan kernel instead of a device copy in _emit;
+ *                 flags & LFS_ISECT_COUNTERS_ZERO: the workspace is the one of the caller's previous _count_ex call with the same C, N and tile
+ *                 grid (the kernels leave its counters zero) - skips the memset. n_isects and max_tile_isects (nullable: the longest tile list) may
+ *                 point to pinned host memory (written by the kernel).
+ *      _emit_ex : scratch (nullable, int64 [n_isects]): with it the scatter runs as two binning passes with coalesced stores
+ *                 (C*tile_h <= 512 and bits(C*N) + bits(tile_w) <= 32; otherwise, or without it, the one-pass scatter). max_tile_isects: the value
+ *                 _count_ex reported (the per-tile sort then launches only the size classes that occur), or -1. */
+#define LFS_ISECT_COUNTERS_ZERO 1u
+LFS_API int lfs_intersect_tile_count_ex(
+    uint32_t C, uint32_t N, const float* means2d, const int32_t* radii,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    int32_t* tiles_per_gauss, int64_t* n_isects, int64_t* max_tile_isects, int32_t* tile_offsets, uint32_t flags,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+LFS_API int lfs_intersect_tile_emit_ex(
+    uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int sort, int64_t n_isects,
+    const int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* tile_offsets, int64_t* scratch, int64_t max_tile_isects,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+
 /* ---- gsplat::intersect_offset (gsplat/Ops.h:39-43, IntersectTile.cu:206-286).
  *      offsets int32 [C,tile_h,tile_w] from SORTED isect_ids. */
 LFS_API int lfs_intersect_offset(
@@ -143,8 +163,10 @@ LFS_API size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t ch
 /*      developer switch, not part of the reference API: bit 0 = build the per-cell lists without culling
  *      (fwd output must be bit-identical either way; tests/test_gpu_raster.py); bit 1 = the experimental kernels with
  *      16x8 cells and two pixels per lane (bit-identical forward, slower on the benchmark scene: csrc/raster.hip); bit 2 = the
- *      experimental quadrant-row kernels (csrc/lfs_raster_rows.cuh; lfs_rasterize_workspace_bytes grows while the bit is set); bit 3 with bit 2 = their quadrant lists built in one pass. */
+ *      experimental quadrant-row kernels (csrc/lfs_raster_rows.cuh; lfs_rasterize_workspace_bytes grows while the bit is set); bit 3 with bit 2 = their quadrant lists built in one pass;
+ *      bit 4 = deterministic backward accumulation; bit 5 = the one-pass intersection scatter even when a scratch array is given. */
 LFS_API void lfs_set_debug_flags(uint32_t flags);
+LFS_API uint32_t lfs_get_debug_flags(void);
 LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
     const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
@@ -377,7 +399,7 @@ LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_fwd_prepacked(
  *       floats: dL/dA 9 | -dL/dg 3 | dL/dopacity | dL/dcolour 3) stay in the workspace at lfs_rasterize_workspace_acc_offset(C, N);
  *   lfs_sh_model_bwd_adam_all : SH backward reading dL/dcolour from those rows, Adam on sh0 AND shN in place, dL/d(dirs) written to v_dirs [N,3];
  *   lfs_gut_finish_adam       : rows -> dL/d(means, quats, scales, opacity) (raster_finish) -> raw-parameter gradients (normalize / exp / sigmoid vjp +
- *       the regularisers) -> Adam on means, raw_scales, raw_quats, raw_opacities, in one pass; *loss += the fused MSE.
+ *       the regularisers) -> Adam on means, raw_scales, raw_quats, raw_opacities, in one pass; *loss = the fused MSE (stored, not added).
  * Element for element the operations of the separate kernels (lfs_..._bwd_prepared_mse, lfs_sh_model_bwd_adam, lfs_activations_bwd, lfs_adam_step_multi). */
 LFS_API size_t lfs_rasterize_workspace_acc_offset(uint32_t C, uint32_t N);
 LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc(

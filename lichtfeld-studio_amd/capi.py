@@ -80,7 +80,7 @@ ADAM_MAX_TENSORS = 8
 # every symbol include/lfs_gsplat.h declares
 EXPORTS = [
     "lfs_projection_ut_3dgs_fused", "lfs_spherical_harmonics_fwd", "lfs_spherical_harmonics_bwd",
-    "lfs_intersect_tile_workspace_bytes", "lfs_intersect_tile_count", "lfs_intersect_tile_emit", "lfs_intersect_offset",
+    "lfs_intersect_tile_workspace_bytes", "lfs_intersect_tile_count", "lfs_intersect_tile_emit", "lfs_intersect_tile_count_ex", "lfs_intersect_tile_emit_ex", "lfs_get_debug_flags", "lfs_intersect_offset",
     "lfs_rasterize_workspace_bytes", "lfs_set_debug_flags", "lfs_rasterize_to_pixels_from_world_3dgs_fwd", "lfs_rasterize_to_pixels_from_world_3dgs_bwd", "lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared", "lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse",
     "lfs_sh_model_fwd", "lfs_sh_model_bwd", "lfs_sh_model_bwd_adam", "lfs_sh_model_fwd_views", "lfs_sh_model_bwd_views", "lfs_activations_fwd", "lfs_activations_bwd", "lfs_mse_loss_fwd_bwd", "lfs_mse_loss_chw_fwd_bwd",
     "lfs_fastgs_primitive_workspace_bytes", "lfs_fastgs_instance_workspace_bytes", "lfs_fastgs_preprocess", "lfs_fastgs_wait_n_instances", "lfs_fastgs_render", "lfs_fastgs_backward", "lfs_fastgs_backward_adam",

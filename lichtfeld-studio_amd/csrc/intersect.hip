@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(1024) isect_count_kernel(
     const float* __restrict__ means2d, const int32_t* __restrict__ radii,
     const float tile_size_f, const uint32_t tw, const uint32_t th,
     int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ totals) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    LFS_DYN_LDS(uint32_t, hist);
     const uint32_t T = C * tw * th, n_tiles = tw * th;
     if (LDS_HIST) {
         for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) hist[t] = 0u;
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(1024) isect_scatter_kernel(
     const float tile_size_f, const uint32_t tw, const uint32_t th, const uint32_t tile_n_bits,
     const int32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
     int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    LFS_DYN_LDS(uint32_t, lds);
     const uint32_t T = C * tw * th, n_tiles = tw * th;
     uint32_t* cnt = lds;        // [T] local count, then local rank counter
     uint32_t* base_s = lds + T; // [T] start of this workgroup's slice inside the tile bucket
@@ -147,6 +147,161 @@ __global__ void __launch_bounds__(1024) isect_scatter_kernel(
                 // bytes doubled the number of scattered partial-line writes, the cost of this kernel: WRITE_SIZE 297 MB for 53 MB.)
                 isect_ids[pos] = int64_t((dbits << 32) | uint64_t(uint32_t(idx)));
             }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Two-pass scatter (the default when the caller provides a scratch array): the one-pass kernel above writes every intersection as an isolated
+// 8-byte store (a workgroup's ~9 000 intersections fall into ~8 000 different tile buckets), and HBM writes in 32-byte sectors: 158 MB written for
+// 36 MB of payload (PMC, SYN-B). Binning in two steps keeps every store part of a run of hundreds of bytes:
+//   pass 1 (isect_rows_kernel) : Gaussians -> tile ROW buckets (C * tile_h <= 512 of them) in `scratch`; a workgroup stages its intersections in LDS
+//                                sorted by row and copies each row's run out contiguously. The entry carries the tile column in the bits above
+//                                the flatten id: (depth bits << 32 | tile_x << idx_bits | flatten id).
+//   pass 2 (isect_tiles_kernel): a workgroup takes 8192 consecutive entries of `scratch` (one or two rows), bins them by tile in LDS and copies each
+//                                tile's run into the tile's bucket of isect_ids, as (depth bits << 32 | flatten id) - what the one-pass kernel
+//                                leaves there. The row range of the scratch array IS the row's range of the final array (tile buckets are laid
+//                                out in tile order), so a position alone identifies the row.
+// The per-tile sort that follows orders each bucket by (depth, flatten id): the result does not depend on how the bucket was filled.
+// ---------------------------------------------------------------------------
+#ifndef LFS_ROWS_STAGE
+#define LFS_ROWS_STAGE 8192
+#endif
+#ifndef LFS_TILES_CHUNK
+#define LFS_TILES_CHUNK 8192
+#endif
+#ifndef LFS_TILES_SPAN
+#define LFS_TILES_SPAN 1024
+#endif
+constexpr uint32_t ROWS_MAX = 512;                // pass 1: row buckets per launch (LDS tables)
+constexpr uint32_t ROWS_STAGE = LFS_ROWS_STAGE;   // pass 1: staged entries per workgroup (64 KiB); more than that -> direct stores
+constexpr uint32_t ROWS_PER_BLOCK = 1024;         // pass 1: Gaussians per workgroup (one per thread)
+constexpr uint32_t TILES_CHUNK = LFS_TILES_CHUNK; // pass 2: entries per workgroup (64 KiB staged)
+constexpr uint32_t TILES_SPAN = LFS_TILES_SPAN;   // pass 2: tiles a chunk may span with LDS binning (two workgroups per CU at 1024); more (many empty rows) -> direct stores
+
+// exclusive scan of a[0..L) (LDS) into out[0..L] (out[L] = total); all 1024 threads call it; tmp: 17 words of LDS
+LFS_DI void block_scan_1024(const uint32_t* a, uint32_t* out, uint32_t L, uint32_t* tmp) {
+    const uint32_t ipt = (L + 1023u) / 1024u, b = threadIdx.x * ipt;
+    uint32_t local = 0;
+    for (uint32_t k = 0; k < ipt; ++k) if (b + k < L) local += a[b + k];
+    uint32_t s = local;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(s, d, 64); if (int(lane) >= d) s += o; }
+    if (lane == 63) tmp[wave] = s;
+    __syncthreads();
+    uint32_t off = s - local;
+    for (uint32_t w = 0; w < wave; ++w) off += tmp[w];
+    __syncthreads(); // a may alias out: every thread has read its items before anyone writes
+    for (uint32_t k = 0; k < ipt; ++k) if (b + k < L) { const uint32_t v = a[b + k]; out[b + k] = off; off += v; }
+    if (threadIdx.x == 1023) out[L] = off;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) isect_rows_kernel(
+    const uint32_t C, const uint32_t N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+    const float tile_size_f, const uint32_t tw, const uint32_t th, const uint32_t idx_bits,
+    const int32_t* __restrict__ offsets, uint32_t* __restrict__ row_cursor, uint64_t* __restrict__ scratch) {
+    LFS_DYN_LDS(uint64_t, stage); // [ROWS_STAGE]
+    __shared__ uint32_t cnt[ROWS_MAX], lbase[ROWS_MAX + 1], gbase[ROWS_MAX], tmp[17];
+    const uint32_t R = C * th;
+    const size_t total = size_t(C) * N;
+    const size_t begin = size_t(blockIdx.x) * ROWS_PER_BLOCK + threadIdx.x; // one Gaussian per thread
+    for (uint32_t r = threadIdx.x; r < R; r += 1024) cnt[r] = 0u;
+    __syncthreads();
+    TileRect rc{0, 0, 0, 0};
+    const bool have = begin < total && tile_rect(means2d, radii, begin, tile_size_f, tw, th, rc) && rc.x1 > rc.x0 && rc.y1 > rc.y0;
+    const uint32_t nx = rc.x1 - rc.x0, rb = uint32_t(begin / N) * th;
+    if (have) for (uint32_t i = rc.y0; i < rc.y1; ++i) atomicAdd(&cnt[rb + i], nx);
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < R; r += 1024) { const uint32_t c = cnt[r]; gbase[r] = c ? atomicAdd(&row_cursor[r], c) : 0u; }
+    block_scan_1024(cnt, lbase, R, tmp);
+    const uint32_t E = lbase[R];
+    const bool staged = E <= ROWS_STAGE;
+    for (uint32_t r = threadIdx.x; r < R; r += 1024) cnt[r] = 0u; // now the running rank inside the row
+    __syncthreads();
+    if (have) {
+        const uint64_t hi = uint64_t(__float_as_uint(depths[begin])) << 32 | uint64_t(uint32_t(begin));
+        for (uint32_t i = rc.y0; i < rc.y1; ++i) {
+            const uint32_t row = rb + i;
+            const uint32_t k = atomicAdd(&cnt[row], nx);
+            if (staged) {
+                uint64_t* dst = stage + lbase[row] + k;
+                for (uint32_t j = 0; j < nx; ++j) dst[j] = hi | (uint64_t(rc.x0 + j) << idx_bits);
+            } else {
+                uint64_t* dst = scratch + size_t(offsets[size_t(row) * tw]) + gbase[row] + k;
+                for (uint32_t j = 0; j < nx; ++j) dst[j] = hi | (uint64_t(rc.x0 + j) << idx_bits);
+            }
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t r = wave; r < R; r += 16) {
+        const uint32_t lb = lbase[r], n = lbase[r + 1] - lb;
+        if (n == 0) continue;
+        uint64_t* dst = scratch + size_t(offsets[size_t(r) * tw]) + gbase[r];
+        for (uint32_t k = lane; k < n; k += 64) dst[k] = stage[lb + k];
+    }
+}
+
+__global__ void __launch_bounds__(1024) isect_tiles_kernel(
+    const uint32_t R, const uint32_t tw, const uint32_t idx_bits, const int64_t n_isects,
+    const int32_t* __restrict__ offsets, uint32_t* __restrict__ cursor, const uint64_t* __restrict__ scratch, int64_t* __restrict__ isect_ids) {
+    LFS_DYN_LDS(uint64_t, stage); // [TILES_CHUNK]
+    __shared__ uint32_t cnt[TILES_SPAN], lpre[TILES_SPAN + 1], gb[TILES_SPAN], tmp[17];
+    __shared__ uint32_t rows_s[2];
+    constexpr uint32_t PER = TILES_CHUNK / 1024;
+    const int64_t p0 = int64_t(blockIdx.x) * TILES_CHUNK, p1 = min(p0 + int64_t(TILES_CHUNK), n_isects);
+    if (threadIdx.x < 2) { // the row that holds p0 / p1 - 1: the largest r with row_start(r) <= p
+        const int64_t p = threadIdx.x == 0 ? p0 : p1 - 1;
+        uint32_t lo = 0, hi = R; // invariant: row_start(lo) <= p < row_start(hi) (row_start(R) = n_isects)
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (int64_t(offsets[size_t(mid) * tw]) <= p) lo = mid; else hi = mid; }
+        rows_s[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const uint32_t r_lo = rows_s[0], r_hi = rows_s[1];
+    const uint32_t t_lo = r_lo * tw, span = (r_hi - r_lo + 1) * tw;
+    const uint64_t idx_mask = (uint64_t(1) << idx_bits) - 1;
+    if (span > TILES_SPAN) { // a chunk across many (mostly empty) rows: plain scatter
+        for (int64_t p = p0 + threadIdx.x; p < p1; p += 1024) {
+            const uint64_t e = scratch[p];
+            uint32_t r = r_lo;
+            while (r < r_hi && int64_t(offsets[size_t(r + 1) * tw]) <= p) ++r;
+            const uint32_t t = r * tw + uint32_t((e & 0xFFFFFFFFull) >> idx_bits);
+            const uint32_t slot = atomicAdd(&cursor[t], 1u);
+            isect_ids[size_t(offsets[t]) + slot] = int64_t((e & 0xFFFFFFFF00000000ull) | (e & idx_mask));
+        }
+        return;
+    }
+    for (uint32_t t = threadIdx.x; t < span; t += 1024) cnt[t] = 0u;
+    __syncthreads();
+    uint64_t ent[PER]; uint32_t where[PER]; // where = local tile << 16 | rank   (rank < 8192, local tile < 2048)
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const int64_t p = p0 + threadIdx.x + int64_t(k) * 1024;
+        where[k] = 0xFFFFFFFFu;
+        if (p < p1) {
+            const uint64_t e = scratch[p];
+            uint32_t r = r_lo;
+            while (r < r_hi && int64_t(offsets[size_t(r + 1) * tw]) <= p) ++r;
+            const uint32_t tl = (r - r_lo) * tw + uint32_t((e & 0xFFFFFFFFull) >> idx_bits);
+            ent[k] = (e & 0xFFFFFFFF00000000ull) | (e & idx_mask);
+            where[k] = tl << 16 | atomicAdd(&cnt[tl], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < span; t += 1024) { const uint32_t c = cnt[t]; gb[t] = c ? atomicAdd(&cursor[t_lo + t], c) : 0u; }
+    block_scan_1024(cnt, lpre, span, tmp);
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k)
+        if (where[k] != 0xFFFFFFFFu) stage[lpre[where[k] >> 16] + (where[k] & 0xFFFFu)] = ent[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t t = wave; t < span; t += 16) {
+        const uint32_t lb = lpre[t], n = lpre[t + 1] - lb;
+        if (n == 0) continue;
+        int64_t* dst = isect_ids + size_t(offsets[t_lo + t]) + gb[t];
+        for (uint32_t k = lane; k < n; k += 64) dst[k] = int64_t(stage[lb + k]);
     }
 }
 
@@ -251,6 +406,7 @@ __global__ void __launch_bounds__(256) isect_offset_kernel(
 struct IsectWs {
     uint32_t* totals;   // [T]
     uint32_t* cursor;   // [T]
+    uint32_t* row_cursor; // [C * tile_h]   (two-pass scatter)
     int32_t* offsets;   // [T+1]
     int64_t* block_sums; // [ceil(CN / SCAN_ITEMS) + 1]
     size_t bytes;
@@ -262,6 +418,7 @@ static IsectWs isect_ws(void* base, uint32_t C, uint32_t N, uint32_t tw, uint32_
     IsectWs w; char* p = (char*)base; size_t o = 0;
     w.totals = (uint32_t*)(p + o); o += align256(T * 4);
     w.cursor = (uint32_t*)(p + o); o += align256(T * 4);
+    w.row_cursor = (uint32_t*)(p + o); o += align256(size_t(C) * th * 4);
     w.offsets = (int32_t*)(p + o); o += align256((T + 1) * 4);
     w.block_sums = (int64_t*)(p + o); o += align256(nb * 8);
     w.bytes = o;
@@ -283,18 +440,23 @@ extern "C" size_t lfs_intersect_tile_workspace_bytes(uint32_t C, uint32_t N, uin
     return isect_ws(nullptr, C, N, tile_width, tile_height).bytes;
 }
 
-extern "C" int lfs_intersect_tile_count(
+extern "C" int lfs_intersect_tile_count_ex(
     uint32_t C, uint32_t N, const float* means2d, const int32_t* radii,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
-    int32_t* tiles_per_gauss, int64_t* n_isects, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    int32_t* tiles_per_gauss, int64_t* n_isects, int64_t* max_tile_isects, int32_t* tile_offsets, uint32_t flags,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
     if (!n_isects || !workspace || tile_size == 0 || tile_width == 0 || tile_height == 0 || C == 0) return LFS_E_INVALID;
     if (bit_width_u32(tile_width * tile_height) + bit_width_u32(C) > 32) return LFS_E_UNSUPPORTED; // IntersectTile.cu:154
     IsectWs w = isect_ws(workspace, C, N, tile_width, tile_height);
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t T = C * tile_width * tile_height;
-    hipError_t e = hipMemsetAsync(w.totals, 0, (char*)w.offsets - (char*)w.totals, s); // totals + cursor
-    if (e != hipSuccess) return (int)e;
+    // the scan kernel leaves totals[] zero again and zeroes both cursors itself: a caller that passes the workspace of its previous call
+    // (same C, N, tile grid) sets LFS_ISECT_COUNTERS_ZERO and saves the memset
+    if (!(flags & LFS_ISECT_COUNTERS_ZERO)) {
+        hipError_t e = hipMemsetAsync(w.totals, 0, size_t(T) * 4, s);
+        if (e != hipSuccess) return (int)e;
+    }
     const size_t total = size_t(C) * N;
     lfs::ProfScope prof("isect_count_scan", s);
     if (total > 0) {
@@ -308,14 +470,22 @@ extern "C" int lfs_intersect_tile_count(
             hipLaunchKernelGGL(isect_count_kernel<false>, dim3(blocks), dim3(1024), 0, s, C, N, pb, means2d, radii,
                                float(tile_size), tile_width, tile_height, tiles_per_gauss, w.totals);
     }
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets, max_tile_isects);
     return (int)hipGetLastError();
 }
 
-extern "C" int lfs_intersect_tile_emit(
+extern "C" int lfs_intersect_tile_count(
+    uint32_t C, uint32_t N, const float* means2d, const int32_t* radii,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    int32_t* tiles_per_gauss, int64_t* n_isects, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    return lfs_intersect_tile_count_ex(C, N, means2d, radii, tile_size, tile_width, tile_height, tiles_per_gauss, n_isects, nullptr, nullptr, 0u, workspace,
+                                       workspace_bytes, stream);
+}
+
+extern "C" int lfs_intersect_tile_emit_ex(
     uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int sort, int64_t n_isects,
-    const int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* tile_offsets,
+    const int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* tile_offsets, int64_t* scratch, int64_t max_tile_isects,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
     if (!workspace || C == 0 || tile_size == 0) return LFS_E_INVALID;
     IsectWs w = isect_ws(workspace, C, N, tile_width, tile_height);
@@ -343,12 +513,25 @@ extern "C" int lfs_intersect_tile_emit(
             ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_bins_kernel<1024, 1024, false, 64>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
             if (ae != hipSuccess) return (int)ae;
+            ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&isect_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_STAGE * 8);
+            if (ae != hipSuccess) return (int)ae;
+            ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&isect_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TILES_CHUNK * 8);
+            if (ae != hipSuccess) return (int)ae;
             big_lds_enabled = true;
         }
         const uint32_t pb = isect_per_block(total);
         const uint32_t blocks = uint32_t((total + pb - 1) / pb);
         int tok = lfs::prof_begin("isect_scatter", s);
-        if (size_t(T) * 8 <= LDS_HIST_LIMIT)
+        const uint32_t R = C * tile_height;
+        const uint32_t idx_bits = bit_width_u32(uint32_t(total - 1)) ? bit_width_u32(uint32_t(total - 1)) : 1u;
+        const bool two_pass = scratch != nullptr && R <= ROWS_MAX && total <= 0xFFFFFFFFull && idx_bits + bit_width_u32(tile_width - 1) <= 32 &&
+                              !(lfs_get_debug_flags() & 32u);
+        if (two_pass) {
+            hipLaunchKernelGGL(isect_rows_kernel, dim3(uint32_t((total + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(1024), ROWS_STAGE * 8, s, C, N, means2d, radii,
+                               depths, float(tile_size), tile_width, tile_height, idx_bits, w.offsets, w.row_cursor, reinterpret_cast<uint64_t*>(scratch));
+            hipLaunchKernelGGL(isect_tiles_kernel, dim3(uint32_t((n_isects + TILES_CHUNK - 1) / TILES_CHUNK)), dim3(1024), TILES_CHUNK * 8, s, R, tile_width, idx_bits,
+                               n_isects, w.offsets, w.cursor, reinterpret_cast<const uint64_t*>(scratch), isect_ids);
+        } else if (size_t(T) * 8 <= LDS_HIST_LIMIT)
             hipLaunchKernelGGL(isect_scatter_kernel<true>, dim3(blocks), dim3(1024), size_t(T) * 8, s, C, N, pb, means2d, radii, depths,
                                float(tile_size), tile_width, tile_height, tile_n_bits, w.offsets, w.cursor, isect_ids, flatten_ids);
         else
@@ -360,10 +543,15 @@ extern "C" int lfs_intersect_tile_emit(
         // size classes (LDS sized to the class so that small tiles do not cap the occupancy): <= 1024 / 4096 entries with the counting kernel on 256 bins
         // (256 threads, keys staged in LDS), <= 16384 with the counting kernel on 1024 bins (1024 threads, 128 KiB LDS for the binned copy only; a bin
         // of more than 64 keys falls back to the bitonic network inside the kernel), larger -> bitonic on global memory
+        // (max_tile_isects >= 0: the longest tile list, from lfs_intersect_tile_count_ex - classes no tile falls into are not launched: ~9 us each at T = 8160)
+        const int64_t longest = max_tile_isects >= 0 ? max_tile_isects : INT64_MAX;
         hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 1024 * 8, s, 1u, 1024u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
-        hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 4096 * 8, s, 1025u, 4096u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
-        hipLaunchKernelGGL((tile_sort_bins_kernel<1024, 1024, false, 64>), dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
-        hipLaunchKernelGGL(tile_sort_global_kernel, dim3(T), dim3(1024), 0, s, 16385u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
+        if (longest > 1024)
+            hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 4096 * 8, s, 1025u, 4096u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
+        if (longest > 4096)
+            hipLaunchKernelGGL((tile_sort_bins_kernel<1024, 1024, false, 64>), dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
+        if (longest > 16384)
+            hipLaunchKernelGGL(tile_sort_global_kernel, dim3(T), dim3(1024), 0, s, 16385u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
     } else {
         if (!tiles_per_gauss) return LFS_E_INVALID;
         const uint32_t nb = uint32_t((total + SCAN_ITEMS - 1) / SCAN_ITEMS);
@@ -373,6 +561,15 @@ extern "C" int lfs_intersect_tile_emit(
                            w.block_sums, float(tile_size), tile_width, tile_height, tile_n_bits, isect_ids, flatten_ids);
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int lfs_intersect_tile_emit(
+    uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int sort, int64_t n_isects,
+    const int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* tile_offsets,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    return lfs_intersect_tile_emit_ex(C, N, means2d, radii, depths, tile_size, tile_width, tile_height, sort, n_isects, tiles_per_gauss, isect_ids, flatten_ids,
+                                      tile_offsets, nullptr, -1, workspace, workspace_bytes, stream);
 }
 
 extern "C" int lfs_intersect_offset(

@@ -16,6 +16,16 @@ struct quat { float w, x, y, z; };   // reference order (w, x, y, z)
 struct m3 { float m[3][3]; };
 
 #define LFS_DI __device__ __forceinline__
+// the workgroup's dynamic LDS block as an array `name` of `type` (the host emulator of tests/emul hands out a heap block instead)
+// LFS_WAVE_LOCKSTEP(): a point where the code relies on the lanes of a wavefront executing in lock-step with an in-order LDS pipeline (nothing to
+// emit on the GPU; the emulator's lanes are independent fibers and meet here)
+#ifdef LFS_EMULATE
+#define LFS_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(emu::dyn_lds())
+#define LFS_WAVE_LOCKSTEP() ((void)emu::ballot(true))
+#else
+#define LFS_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#define LFS_WAVE_LOCKSTEP() ((void)0)
+#endif
 
 LFS_DI f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 LFS_DI f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }

@@ -10,17 +10,32 @@ namespace lfs {
 // ---------------------------------------------------------------------------
 // single-workgroup exclusive scan of totals[T] -> offsets[T+1] (int32), n_isects (int64)
 // ---------------------------------------------------------------------------
+// zero_totals: totals[] is left zero for the next call (zero-on-consume: the caller may then skip its memset); cursor / aux (nullable) are zeroed for
+// the scatter kernels of THIS call; offsets_out (nullable, [T]) receives a second copy of the offsets (the caller's tile_offsets tensor); max_total
+// (nullable) the longest tile list (the caller skips the sort launches of the size classes no tile falls into)
 static __global__ void __launch_bounds__(1024) tile_scan_kernel(
-    const uint32_t T, const uint32_t* __restrict__ totals, int32_t* __restrict__ offsets, int64_t* __restrict__ n_isects) {
+    const uint32_t T, uint32_t* __restrict__ totals, int32_t* __restrict__ offsets, int64_t* __restrict__ n_isects,
+    const bool zero_totals = false, uint32_t* __restrict__ cursor = nullptr, uint32_t* __restrict__ aux = nullptr, const uint32_t n_aux = 0,
+    int32_t* __restrict__ offsets_out = nullptr, int64_t* __restrict__ max_total = nullptr) {
+    // slices of 8192 tiles staged in LDS: coalesced loads, every thread scans 8 consecutive values, coalesced stores (one slice = the whole array
+    // at 1080p; the round-1 version walked slices of 1024 with three barriers each: 13 us at T = 8160; a register-blocked version without the LDS
+    // transpose was slower still - 8-word strides between lanes make every store a partial 32-byte sector)
+    constexpr uint32_t SLICE = 8192, PER = SLICE / 1024;
+    __shared__ uint32_t vals[SLICE];
     __shared__ uint64_t wave_sums[16];
-    __shared__ uint64_t carry_s;
+    __shared__ uint32_t wave_max[16];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < T; base += 1024) {
-        const uint32_t t = base + threadIdx.x;
-        const uint64_t v = t < T ? totals[t] : 0u;
-        uint64_t s = v; // inclusive wave scan
+    if (aux != nullptr) for (uint32_t i = threadIdx.x; i < n_aux; i += 1024) aux[i] = 0u;
+    uint64_t carry = 0; uint32_t vmax = 0;
+    for (uint32_t base = 0; base < T; base += SLICE) {
+        const uint32_t n = min(SLICE, T - base);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) { const uint32_t i = threadIdx.x + k * 1024; vals[i] = i < n ? totals[base + i] : 0u; }
+        __syncthreads();
+        uint32_t v[PER]; uint32_t local = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) { v[k] = vals[threadIdx.x * PER + k]; local += v[k]; vmax = max(vmax, v[k]); }
+        uint64_t s = local; // inclusive wave scan of the threads' sums
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint64_t o = __shfl_up(s, d, 64);
@@ -28,15 +43,33 @@ static __global__ void __launch_bounds__(1024) tile_scan_kernel(
         }
         if (lane == 63) wave_sums[wave] = s;
         __syncthreads();
-        uint64_t wave_off = 0;
-        for (uint32_t w = 0; w < wave; ++w) wave_off += wave_sums[w];
-        const uint64_t carry = carry_s;
-        if (t < T) offsets[t] = int32_t(carry + wave_off + s - v);
+        uint64_t run = carry + s - local, total = 0;
+        for (uint32_t w = 0; w < 16; ++w) { if (w < wave) run += wave_sums[w]; total += wave_sums[w]; }
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) { vals[threadIdx.x * PER + k] = uint32_t(run); run += v[k]; } // (offsets are int32 in the reference API)
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + wave_off + s;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = threadIdx.x + k * 1024;
+            if (i < n) {
+                const int32_t o = int32_t(vals[i]);
+                offsets[base + i] = o;
+                if (offsets_out != nullptr) offsets_out[base + i] = o;
+                if (zero_totals) totals[base + i] = 0u;
+                if (cursor != nullptr) cursor[base + i] = 0u;
+            }
+        }
+        carry += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { offsets[T] = int32_t(carry_s); *n_isects = int64_t(carry_s); }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) vmax = max(vmax, uint32_t(__shfl_xor(int(vmax), m, 64)));
+    if (lane == 0) wave_max[wave] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        offsets[T] = int32_t(carry); *n_isects = int64_t(carry);
+        if (max_total != nullptr) { uint32_t m = 0; for (int w = 0; w < 16; ++w) m = max(m, wave_max[w]); *max_total = int64_t(m); }
+    }
 }
 
 // Ascending bitonic network over n_pad (power of two) 64-bit keys in LDS; all THREADS threads of the workgroup call it.
@@ -49,7 +82,7 @@ LFS_DI void bitonic_sort_lds(uint64_t* __restrict__ keys, const uint32_t n_pad) 
     bool prev_cross = false;
     for (uint32_t k = 2; k <= n_pad; k <<= 1) {
         const bool flip_cross = k > 128;
-        if (flip_cross || prev_cross) __syncthreads();
+        if (flip_cross || prev_cross) __syncthreads(); else LFS_WAVE_LOCKSTEP();
         prev_cross = flip_cross;
         for (uint32_t i = threadIdx.x; i < n_pad / 2; i += THREADS) { // flip step
             const uint32_t blk = i / (k >> 1), off = i % (k >> 1);
@@ -59,7 +92,7 @@ LFS_DI void bitonic_sort_lds(uint64_t* __restrict__ keys, const uint32_t n_pad) 
         }
         for (uint32_t j = k >> 2; j >= 1; j >>= 1) {
             const bool cross = j >= 128;
-            if (cross || prev_cross) __syncthreads();
+            if (cross || prev_cross) __syncthreads(); else LFS_WAVE_LOCKSTEP();
             prev_cross = cross;
             for (uint32_t i = threadIdx.x; i < n_pad / 2; i += THREADS) {
                 const uint32_t a = ((i / j) * (j << 1)) + (i % j), b = a + j;
@@ -83,7 +116,7 @@ template <int THREADS, int NBINS = 256, bool COPY = true, uint32_t BIN_LIMIT = 3
 __global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
     const uint32_t n_min, const uint32_t n_max, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets,
     int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    LFS_DYN_LDS(uint64_t, lds64);
     __shared__ uint32_t s_hist[NBINS], s_off[NBINS + 1], s_minmax[2], s_big;
     static_assert(NBINS % 64 == 0, "one wave scans the bin counts");
     constexpr int PER = NBINS / 64;
@@ -168,7 +201,7 @@ template <int THREADS>
 __global__ void __launch_bounds__(THREADS) tile_sort_lds_kernel(
     const uint32_t n_min, const uint32_t n_max, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets,
     int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    LFS_DYN_LDS(uint64_t, keys);
     const uint32_t t = blockIdx.x;
     const uint32_t start = uint32_t(offsets[t]);
     const uint32_t n = uint32_t(offsets[t + 1]) - start;

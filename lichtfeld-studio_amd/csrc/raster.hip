@@ -970,11 +970,14 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
     const float* __restrict__ quats, const float* __restrict__ scales, const float* __restrict__ opacities,
     const CamDev* __restrict__ cams, const float* __restrict__ acc, const float* __restrict__ v_dirs, const FinishAdam ad, const float* __restrict__ loss_slots,
     float* __restrict__ loss) {
-    if (loss_slots != nullptr && blockIdx.x == 0) {
+    if (loss_slots != nullptr && blockIdx.x == 0) { // *loss = the fused MSE (a store in a fixed order: the step needs no zeroed accumulator)
+        __shared__ float wave_sum[4];
         float v = threadIdx.x < LOSS_SLOTS ? loss_slots[threadIdx.x] : 0.f;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-        if ((threadIdx.x & 63) == 0 && v != 0.f) unsafeAtomicAdd(loss, v);
+        if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) *loss = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
     }
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= N) return;
@@ -1115,6 +1118,7 @@ static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom&
 using namespace lfs;
 
 extern "C" void lfs_set_debug_flags(uint32_t flags) { g_debug_flags = flags; }
+extern "C" uint32_t lfs_get_debug_flags(void) { return g_debug_flags; }
 
 extern "C" size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t channels, uint32_t image_width, uint32_t image_height,
                                                 uint32_t tile_size, int64_t n_isects) {
@@ -1420,7 +1424,7 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc(
                            render_alphas, last_ids, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream, true, &mse, false);
 }
 
-// scalars[k] = {lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp} for k = means, raw_scales, raw_quats, raw_opacities; *loss += the fused MSE of the backward
+// scalars[k] = {lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp} for k = means, raw_scales, raw_quats, raw_opacities; *loss = the fused MSE of the backward (stored, not added)
 extern "C" int lfs_gut_finish_adam(
     uint32_t N, float* means, float* raw_scales, float* raw_quats, float* raw_opacities, const float* quats, const float* scales, const float* opacities,
     const float* v_dirs, float* const* exp_avg /* [4] host */, float* const* exp_avg_sq /* [4] host */, const float* scalars /* [4][6] host */, float scale_reg,

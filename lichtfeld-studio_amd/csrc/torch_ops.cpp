@@ -112,10 +112,11 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor m
     const int64_t n_isects = n_dev.item<int64_t>(); // the one host sync, as Intersect.cpp:76
     at::Tensor isect_ids = at::empty({n_isects}, depths.options().dtype(at::kLong));
     at::Tensor flatten_ids = at::empty({n_isects}, depths.options().dtype(at::kInt));
-    check_rc(lfs_intersect_tile_emit(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size, tile_width,
-                                     tile_height, sort ? 1 : 0, n_isects, tiles_per_gauss.data_ptr<int32_t>(),
-                                     n_isects ? isect_ids.data_ptr<int64_t>() : nullptr, n_isects ? flatten_ids.data_ptr<int32_t>() : nullptr, nullptr,
-                                     ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+    at::Tensor binned = at::empty({sort ? n_isects : 0}, depths.options().dtype(at::kLong)); // the two-pass scatter's intermediate (row-binned) array
+    check_rc(lfs_intersect_tile_emit_ex(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size, tile_width,
+                                        tile_height, sort ? 1 : 0, n_isects, tiles_per_gauss.data_ptr<int32_t>(),
+                                        n_isects ? isect_ids.data_ptr<int64_t>() : nullptr, n_isects ? flatten_ids.data_ptr<int32_t>() : nullptr, nullptr,
+                                        (sort && n_isects) ? binned.data_ptr<int64_t>() : nullptr, (int64_t)-1, ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
              "intersect_tile(emit)");
     return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids);
 }

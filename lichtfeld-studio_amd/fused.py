@@ -299,6 +299,9 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
             v_render = bilateral.apply_fused_backward(render[0], image_idx, v_shown, chw=False).unsqueeze(0)
         elif fuse_mse:
             v_render = None          # derived inside the rasterizer backward from `render` and the target
+        elif adam_all is not None:   # the all-inline caller does not zero loss_acc (lfs_gut_finish_adam stores); nothing was rendered: separate kernels below
+            loss_acc.zero_()
+            v_render = mse_loss_fwd_bwd(render, target_chw, weight, loss_acc)
         elif loss == "mse":
             v_render = mse_loss_fwd_bwd(render, target_chw, weight, loss_acc)
         elif loss == "l1_ssim":

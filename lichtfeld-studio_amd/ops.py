@@ -89,41 +89,51 @@ def intersect_tile(means2d: Tensor, radii: Tensor, depths: Tensor, camera_ids: O
     tiles_per_gauss = torch.empty(depths.shape, dtype=torch.int32, device=dev)
     ws_bytes = lib.lfs_intersect_tile_workspace_bytes(C.c_uint32(C_), C.c_uint32(N), C.c_uint32(tile_width), C.c_uint32(tile_height))
     ws = workspace(ws_bytes, dev, "isect")
-    n_dev = torch.empty(1, dtype=torch.int64, device=dev)
-    rc = lib.lfs_intersect_tile_count(
+    offsets = torch.empty((C_, tile_height, tile_width), dtype=torch.int32, device=dev) if (return_offsets and sort) else None
+    # the scan kernel leaves the workspace counters zero: the memset is only needed on a workspace this exact problem shape has not used last
+    shape_key = (ws.data_ptr(), C_, N, tile_width, tile_height)
+    flags = 1 if _ISECT_LAST.get(dev.index) == shape_key else 0
+    _ISECT_LAST[dev.index] = None
+    # without `overlap` the count lands in device memory and .item() reads it; with it the scan kernel writes it straight into pinned host memory
+    # (no copy kernel) and the host waits for an event recorded behind that kernel
+    host = _pinned_i64() if overlap is not None else None   # [n_isects, longest tile list]
+    n_dev = torch.empty(2, dtype=torch.int64, device=dev) if overlap is None else None
+    counts = host if host is not None else n_dev
+    rc = lib.lfs_intersect_tile_count_ex(
         C.c_uint32(C_), C.c_uint32(N), ptr(means2d), ptr(radii), C.c_uint32(tile_size), C.c_uint32(tile_width), C.c_uint32(tile_height),
-        ptr(tiles_per_gauss), ptr(n_dev), ptr(ws), C.c_size_t(ws.numel()), stream())
+        ptr(tiles_per_gauss), C.c_void_p(counts.data_ptr()), C.c_void_p(counts.data_ptr() + 8), ptr(offsets), C.c_uint32(flags),
+        ptr(ws), C.c_size_t(ws.numel()), stream())
     check(rc, "intersect_tile (count)")
     if overlap is None:
-        n_isects = int(n_dev.item())  # the one D2H sync of the path
+        n_isects, longest = (int(x) for x in n_dev.tolist())  # the one D2H sync of the path
         extra = None
     else:
-        host = _pinned_i64()
-        host.copy_(n_dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         extra = overlap()
         ev.synchronize()
-        n_isects = int(host.item())
+        n_isects, longest = (int(x) for x in host.tolist())
     isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
-    offsets = torch.empty((C_, tile_height, tile_width), dtype=torch.int32, device=dev) if (return_offsets and sort) else None
-    rc = lib.lfs_intersect_tile_emit(
+    binned = torch.empty(n_isects, dtype=torch.int64, device=dev) if (sort and n_isects) else None   # two-pass scatter: the row-binned intermediate
+    rc = lib.lfs_intersect_tile_emit_ex(
         C.c_uint32(C_), C.c_uint32(N), ptr(means2d), ptr(radii), ptr(depths), C.c_uint32(tile_size), C.c_uint32(tile_width),
         C.c_uint32(tile_height), C.c_int(int(bool(sort))), C.c_int64(n_isects), ptr(tiles_per_gauss), ptr(isect_ids), ptr(flatten_ids),
-        ptr(offsets), ptr(ws), C.c_size_t(ws.numel()), stream())
+        None, ptr(binned), C.c_int64(longest), ptr(ws), C.c_size_t(ws.numel()), stream())
     check(rc, "intersect_tile (emit)")
+    _ISECT_LAST[dev.index] = shape_key
     out = (tiles_per_gauss, isect_ids, flatten_ids) + ((offsets,) if return_offsets else ())
     return out + (extra,) if overlap is not None else out
 
 
 _PINNED = {}
+_ISECT_LAST = {}   # device index -> (workspace pointer, C, N, tile_w, tile_h) of the last completed intersect_tile
 
 
 def _pinned_i64() -> Tensor:
     t = _PINNED.get("i64")
     if t is None:
-        t = torch.empty(1, dtype=torch.int64).pin_memory()
+        t = torch.zeros(2, dtype=torch.int64).pin_memory()
         _PINNED["i64"] = t
     return t
 

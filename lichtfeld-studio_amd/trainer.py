@@ -244,7 +244,6 @@ class GutTrainer:
         if self.fused_l2:
             from .fused import render_and_backward
             params = self.model.parameters()
-            self.loss_acc.zero_()
             every = None
             if self.sh_exchange is not None:  # what every rank renders at sub-step k (the owners evaluate SH for all of them)
                 every = self._views_all or [lfs_dist.views_for_step(self.iteration - 1, j, self.world, self.scene.viewmats.shape[0], len(views))
@@ -262,6 +261,8 @@ class GutTrainer:
                 for name in ("means", "sh0", "raw_scales", "raw_quats", "raw_opacities"):
                     inline_all[name] = self.optimizer.prepare_inline(getattr(self.model, name))
                 inline = None
+            if inline_all is None:
+                self.loss_acc.zero_()   # (the all-inline step stores the loss: no fill launch)
             inline_shard = None   # SH-sharded, one view per rank: the owners' multi-view SH backward applies the shard's Adam update
             refining = self.strategy is not None and self.strategy.is_refining(self.iteration)   # parameters are replaced before the optimizer step:
             if (self.inline_shN_adam and self.sh_exchange is not None and len(views) == 1 and self.iteration > 1000 and self.sh_exchange.n   # no update then

@@ -29,6 +29,9 @@ typedef void* hipStream_t;
 enum { hipSuccess = 0 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+enum { hipMemcpyDeviceToDevice = 3, hipMemcpyDeviceToHost = 2, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 
 #define __global__
 #define __device__
@@ -52,6 +55,8 @@ struct Block {
     void (*body)(void*) = nullptr; void* body_arg = nullptr;
 };
 inline Block*& blk() { static Block* b = nullptr; return b; }
+inline std::vector<uint64_t>& dyn_store() { static std::vector<uint64_t> v; return v; }
+inline void* dyn_lds() { return dyn_store().data(); }   // the workgroup's dynamic LDS block (LFS_DYN_LDS in csrc/lfs_math.cuh)
 inline Fiber*& cur() { static Fiber* f = nullptr; return f; }
 inline void yield() { Fiber* f = cur(); swapcontext(&f->ctx, &blk()->main_ctx); }
 inline void fiber_entry() {
@@ -88,8 +93,9 @@ inline void block_barrier() {
 }
 template <class F> void trampoline(void* p) { (*static_cast<F*>(p))(); }
 template <class F>
-void launch(dim3 grid, dim3 block, F&& f) {
+void launch(dim3 grid, dim3 block, size_t shm, F&& f) {
     static Block* b = nullptr;
+    if (dyn_store().size() * 8 < shm + 16) dyn_store().resize((shm + 16) / 8 + 1);
     if (!b) {
         b = new Block();
         for (int i = 0; i < MAX_THREADS; ++i) b->fib[i].stack = (char*)malloc(STACK_BYTES);
@@ -160,7 +166,7 @@ inline u32x2 permlane16_swap(uint32_t vdst, uint32_t src, bool, bool) {
 #define blockIdx (emu::blk()->bid)
 #define blockDim (emu::blk()->bdim)
 #define gridDim (emu::blk()->gdim)
-#define hipLaunchKernelGGL(kern, grid, block, shm, stream, ...) emu::launch((grid), (block), [&]() { kern(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kern, grid, block, shm, stream, ...) emu::launch((grid), (block), size_t(shm), [&]() { kern(__VA_ARGS__); })
 
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -169,6 +175,22 @@ static inline uint64_t __ballot(bool p) { return emu::ballot(p); }
 static inline void __syncthreads() { emu::block_barrier(); }
 static inline float __shfl_xor(float v, int m, int = 64) { return __uint_as_float(emu::xlane_u32(__float_as_uint(v), int(emu::lane_id()) ^ m)); }
 static inline int __shfl_xor(int v, int m, int = 64) { return int(emu::xlane_u32(uint32_t(v), int(emu::lane_id()) ^ m)); }
+static inline uint32_t __shfl_xor(uint32_t v, int m, int = 64) { return emu::xlane_u32(v, int(emu::lane_id()) ^ m); }
+// __shfl_up: lane i reads lane i - d; lanes below d keep their own value
+static inline uint64_t emu_shfl_up64(uint64_t v, int d) { uint64_t o[2][64]; emu::wave_exchange(v, 0, o); const int l = int(emu::lane_id()); return l >= d ? o[0][l - d] : v; }
+static inline uint64_t __shfl_up(uint64_t v, int d, int = 64) { return emu_shfl_up64(v, d); }
+static inline int64_t __shfl_up(int64_t v, int d, int = 64) { return int64_t(emu_shfl_up64(uint64_t(v), d)); }
+static inline uint32_t __shfl_up(uint32_t v, int d, int = 64) { return uint32_t(emu_shfl_up64(v, d)); }
+static inline int __shfl_up(int v, int d, int = 64) { return int(uint32_t(emu_shfl_up64(uint32_t(v), d))); }
+static inline int64_t __shfl_xor(int64_t v, int m, int = 64) { uint64_t o[2][64]; emu::wave_exchange(uint64_t(v), 0, o); return int64_t(o[0][(int(emu::lane_id()) ^ m) & 63]); }
+// fibers switch only at cross-lane operations and barriers: a plain read-modify-write is atomic
+template <class T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
+static inline size_t min(size_t a, size_t b) { return a < b ? a : b; }
+static inline long long min(long long a, long long b) { return a < b ? a : b; }
+static inline long min(long a, long b) { return a < b ? a : b; }
 static inline float unsafeAtomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }

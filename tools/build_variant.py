@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Developer A/B builds: one source recompiled with extra flags and linked against the standard objects.
+
+    python tools/build_variant.py <name> <source.hip> [-DX=1 ...]   ->  lichtfeld-studio_amd/liblfs_gsplat_<name>.so
+
+Run a bench / test on it with LFS_GSPLAT_LIB=<that path> (capi.library_path). The .so files are git-ignored and travel to the GPU box."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("lfs_build", os.path.join(ROOT, "lichtfeld-studio_amd", "build.py"))
+b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+
+
+def main():
+    name, src, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
+    b.build()
+    objs = [os.path.join(b.BUILD, s + ".o") for s in b.SOURCES if s != src]
+    vobj = os.path.join(b.BUILD, f"{src}.{name}.o")
+    cmd = [b.HIPCC, *b.COMMON, *b.SOURCES[src], *extra, "-c", os.path.join(b.CSRC, src), "-o", vobj]
+    subprocess.run(cmd, check=True)
+    out = os.path.join(b.HERE, f"liblfs_gsplat_{name}.so")
+    subprocess.run([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, vobj, "-o", out], check=True)
+    print(out)
+
+
+if __name__ == "__main__":
+    main()
