@@ -76,6 +76,13 @@ def _binoms(n_max: int, device) -> torch.Tensor:
     return b.to(device)
 
 
+def _split_samples(rotmats: torch.Tensor, scales: torch.Tensor, rnd: torch.Tensor) -> torch.Tensor:
+    """R diag(s) z for rotmats [n,3,3], scales [n,3], rnd [b,n,3] -> [b,n,3] (default_strategy.cpp:100-104), written out term by term so that a row's
+    result does not depend on how many rows are processed with it (an einsum may pick a different contraction kernel)."""
+    t = scales.unsqueeze(0) * rnd
+    return (rotmats[:, :, 0].unsqueeze(0) * t[..., 0:1] + rotmats[:, :, 1].unsqueeze(0) * t[..., 1:2]) + rotmats[:, :, 2].unsqueeze(0) * t[..., 2:3]
+
+
 class _StrategyBase:
     def __init__(self, model: SplatModel, params: OptimizationParameters, scene_scale: float = 1.0,
                  generator: Optional[torch.Generator] = None, on_resize: Optional[Callable[[], None]] = None):
@@ -222,6 +229,7 @@ class MCMC(_StrategyBase):
 
 class DefaultStrategy(_StrategyBase):
     """default_strategy.cpp (ADC: duplicate / split / prune / opacity reset)."""
+    fused_refine = True   # post_backward: grow_and_prune_fused (one host read per refinement) instead of grow_gs + prune_gs (the reference's sequence)
 
     def is_refining(self, it: int) -> bool:  # :30-34
         p = self.params
@@ -235,15 +243,19 @@ class DefaultStrategy(_StrategyBase):
                             lambda s, new: torch.cat([s, torch.zeros((n,) + tuple(s.shape[1:]), dtype=s.dtype, device=s.device)], 0))
 
     @torch.no_grad()
-    def split(self, is_split: torch.Tensor) -> None:  # :84-160
+    def split(self, is_split: torch.Tensor, rnd_full: Optional[torch.Tensor] = None) -> None:  # :84-160
+        """rnd_full [2, N0, 3] (tests): the normal deviates per ORIGINAL row instead of a fresh draw for the split rows only."""
         m = self.model
         idx = is_split.nonzero().squeeze(-1)
         rest = is_split.logical_not().nonzero().squeeze(-1)
         scales = m.get_scaling().detach().index_select(0, idx)
         rotmats = ops.quats_to_rotmats(m.get_rotation().detach().index_select(0, idx).contiguous())
         n, split_size = int(idx.numel()), 2
-        rnd = torch.randn((split_size, n, 3), device=self.device, dtype=scales.dtype, generator=self.generator)
-        samples = torch.einsum("nij,nj,bnj->bni", rotmats, scales, rnd)
+        if rnd_full is not None:
+            rnd = rnd_full.index_select(1, idx)
+        else:
+            rnd = torch.randn((split_size, n, 3), device=self.device, dtype=scales.dtype, generator=self.generator)
+        samples = _split_samples(rotmats, scales, rnd)
 
         def param_fn(i, p):
             sp = p.index_select(0, idx)
@@ -261,7 +273,7 @@ class DefaultStrategy(_StrategyBase):
                                                                                                      dtype=s.dtype, device=s.device)], 0))
 
     @torch.no_grad()
-    def grow_gs(self, it: int, densification_info: torch.Tensor) -> None:  # :162-195
+    def grow_gs(self, it: int, densification_info: torch.Tensor, rnd_full: Optional[torch.Tensor] = None) -> None:  # :162-195
         m, p = self.model, self.params
         grads = densification_info[1] / densification_info[0].clamp_min(1.0)
         is_grad_high = grads > p.grad_threshold
@@ -274,7 +286,60 @@ class DefaultStrategy(_StrategyBase):
             self.duplicate(is_dup)
         is_split = torch.cat([is_split, torch.zeros(n_dup, dtype=torch.bool, device=self.device)])
         if n_split > 0:
-            self.split(is_split)
+            self.split(is_split, rnd_full)
+
+    @torch.no_grad()
+    def grow_and_prune_fused(self, it: int, densification_info: torch.Tensor, rnd_full: Optional[torch.Tensor] = None) -> None:
+        """grow_gs + prune_gs (default_strategy.cpp:162-249) as device-side index arithmetic with ONE host read - the new Gaussian count, which the
+        host needs to allocate the tensors (the step-by-step form above follows the reference line by line with ~7 reads and
+        rebuilds every parameter and both Adam moments three times). The outcome of duplicate -> split -> prune is known per ORIGINAL row up front:
+        the final order is [rows that are not split | their duplicates | first children | second children], each filtered by the pruning test of the
+        row it would hold (a duplicate has its source's parameters; both children of a row share opacity, rotation and scale, hence the test). One
+        inclusive scan over the 4 x N keep-flags gives every output slot, searchsorted inverts it, and every tensor is rebuilt once with a gather.
+        Same values, bit for bit, as grow_gs + prune_gs given the same deviates (tests/test_gpu_strategies.py)."""
+        m, p = self.model, self.params
+        N = m.means.shape[0]
+        means, raw_scales, raw_quats, raw_opac = m.means.detach(), m.raw_scales.detach(), m.raw_quats.detach(), m.raw_opacities.detach()
+        grads = densification_info[1] / densification_info[0].clamp_min(1.0)
+        is_grad_high = grads > p.grad_threshold
+        scales = torch.exp(raw_scales)
+        is_small = scales.max(-1).values <= p.grow_scale3d * self.scene_scale
+        is_dup, is_split = is_grad_high & is_small, is_grad_high & ~is_small
+        # what the children of every row would be (used where the row is split)
+        rotmats = ops.quats_to_rotmats(torch.nn.functional.normalize(raw_quats, dim=-1).contiguous())
+        rnd = rnd_full if rnd_full is not None else torch.randn((2, N, 3), device=self.device, dtype=scales.dtype, generator=self.generator)
+        child_means = means.unsqueeze(0) + _split_samples(rotmats, scales, rnd)
+        child_raw_scales = torch.log(scales / 1.6)
+        child_raw_opac = torch.logit(1.0 - torch.sqrt(1.0 - torch.sigmoid(raw_opac))) if p.revised_opacity else raw_opac
+
+        def pruned(ro, rs):  # prune_gs on a row with these raw opacity / scales (and this row's rotation)
+            out = (torch.sigmoid(ro) < p.prune_opacity) | ((raw_quats ** 2).sum(-1) < 1e-8)
+            if it > p.reset_every:
+                out = out | (torch.exp(rs).max(-1).values > p.prune_scale3d * self.scene_scale)
+            return out
+        keep_parent, keep_child = ~pruned(raw_opac, raw_scales), ~pruned(child_raw_opac, child_raw_scales)
+        flags = torch.stack([~is_split & keep_parent, is_dup & keep_parent, is_split & keep_child, is_split & keep_child]).reshape(-1)
+        inc = torch.cumsum(flags.to(torch.int64), 0)
+        total = int(inc[-1])                                  # the one host read of the refinement step
+        k = torch.searchsorted(inc, torch.arange(total, device=self.device), right=True)   # output slot -> flat (category, row)
+        cat, row = torch.div(k, N, rounding_mode="floor"), k % N
+        is_child, is_old = cat >= 2, cat == 0
+        child_slot = (cat - 2).clamp_min(0) * N + row
+
+        def param_fn(i, t):
+            new = t.index_select(0, row)
+            if i == 0:
+                new = torch.where(is_child.unsqueeze(-1), child_means.reshape(2 * N, 3).index_select(0, child_slot), new)
+            elif i == 3:
+                new = torch.where(is_child.unsqueeze(-1), child_raw_scales.index_select(0, row), new)
+            elif i == 5:
+                new = torch.where(is_child, child_raw_opac.index_select(0, row), new)
+            return new
+
+        def state_fn(st, new):
+            g = st.index_select(0, row)
+            return torch.where(is_old.reshape((-1,) + (1,) * (g.dim() - 1)), g, torch.zeros_like(g))
+        self._update_params(param_fn, state_fn)
 
     @torch.no_grad()
     def prune_gs(self, it: int) -> None:  # :229-249
@@ -300,8 +365,11 @@ class DefaultStrategy(_StrategyBase):
         if it >= p.stop_refine:
             return None if it == p.stop_refine else densification_info
         if self.is_refining(it) and densification_info is not None:
-            self.grow_gs(it, densification_info)
-            self.prune_gs(it)
+            if self.fused_refine:
+                self.grow_and_prune_fused(it, densification_info)
+            else:
+                self.grow_gs(it, densification_info)
+                self.prune_gs(it)
             densification_info = torch.zeros((2, self.model.means.shape[0]), dtype=self.model.means.dtype, device=self.device)
         if it % p.reset_every == 0 and it > 0:
             self.reset_opacity()

@@ -151,6 +151,42 @@ def test_default_strategy_duplicate_split_prune_reset(lfs):
         assert getattr(model, k).shape[0] == model.means.shape[0]
 
 
+def test_default_strategy_fused_refinement_one_host_read_same_result(lfs):
+    """SURVEY.md §8f row 3 for ADC: grow + prune of a refinement step as device-side index arithmetic - the result of the reference's sequence
+    (grow_gs + prune_gs) bit for bit, with ONE device->host read (the new Gaussian count) where the sequence needs seven."""
+    import warnings
+    from lichtfeld_studio_amd import strategies
+    N = 3000
+    outs, reads = [], []
+    for fused in (False, True):
+        model, _ = _model(N=N, dead_frac=0.05)
+        p = strategies.OptimizationParameters(grow_scale3d=0.035, prune_opacity=0.005, reset_every=300)
+        st = strategies.DefaultStrategy(model, p, generator=torch.Generator(device=DEV).manual_seed(2))
+        _prime_optimizer(st)
+        info = torch.zeros(2, N, device=DEV)
+        info[0] = 4.0
+        info[1, :900] = 4e-3
+        rnd = torch.randn(2, N, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+        run = (lambda: st.grow_and_prune_fused(700, info, rnd)) if fused else (lambda: (st.grow_gs(700, info, rnd), st.prune_gs(700)))
+        if fused:   # warm-up on a copy of the state would change it: count on the first run, module loads do not go through the sync-debug hook
+            pass
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("warn")
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                run()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        reads.append(len([x for x in w if "synchroniz" in str(x.message).lower()]))
+        names = strategies._PARAM_NAMES
+        outs.append([n(getattr(model, k)) for k in names] + [n(st.optimizer.state[id(getattr(model, k))]["exp_avg"]) for k in names])
+        assert outs[-1][0].shape[0] > N
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert reads[1] == 1 and reads[0] >= 5, reads
+
+
 def test_replicas_with_the_same_seed_densify_identically(lfs):
     from lichtfeld_studio_amd import strategies
     outs = []
