@@ -598,8 +598,10 @@ uint8_t* decode_png(const std::vector<char>& f, int32_t& w, int32_t& h) {
     w = (int32_t)be32(u + 16); h = (int32_t)be32(u + 20);
     const int depth = u[24], ct = u[25], interlace = u[28];
     if (interlace) fail(LFS_IO_E_UNSUPPORTED, "PNG: interlaced files are not supported");
-    if (depth != 8 && depth != 16 && !(ct == 3 && (depth == 1 || depth == 2 || depth == 4)) && !(ct == 0 && depth < 8))
-        fail(LFS_IO_E_UNSUPPORTED, "PNG: bit depth %d is not supported", depth);
+    if (ct != 0 && ct != 2 && ct != 3 && ct != 4 && ct != 6) fail(LFS_IO_E_FORMAT, "PNG: bad colour type %d", ct);
+    if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16) fail(LFS_IO_E_FORMAT, "PNG: bad bit depth %d", depth);
+    if ((depth < 8 && ct != 0 && ct != 3) || (depth == 16 && ct == 3)) // PNG spec table 11.1: packed samples only for grey / palette, no 16-bit palette
+        fail(LFS_IO_E_FORMAT, "PNG: bit depth %d is not allowed for colour type %d", depth, ct);
     if (w <= 0 || h <= 0 || (uint64_t)w * h > (uint64_t(1) << 31)) fail(LFS_IO_E_FORMAT, "PNG: bad dimensions");
     std::vector<unsigned char> idat, palette;
     std::vector<unsigned char> trns;
@@ -662,8 +664,12 @@ uint8_t* decode_png(const std::vector<char>& f, int32_t& w, int32_t& h) {
         if (ch == samples) to_rgb(pix.data(), samples, (size_t)w * h, out);
         else {
             std::vector<uint8_t> ga((size_t)w * h * 2);
-            const int key = trns.size() >= 2 ? (int)be16(trns.data()) : -1;
-            for (size_t i = 0; i < (size_t)w * h; ++i) { ga[2 * i] = pix[i]; ga[2 * i + 1] = (depth <= 8 && pix[i] == key) ? 0 : 255; }
+            // the tRNS key is a sample value at the file's bit depth; pix[] holds samples rescaled to 0..255 (depth < 8) or their high byte
+            // (depth 16: the low byte is gone, so a 16-bit key matches on the high byte only when its low byte equals the sample's - not tracked:
+            // such files keep every pixel opaque, as before)
+            int key = -1;
+            if (trns.size() >= 2 && depth <= 8) { const int raw = (int)be16(trns.data()); if (raw < (1 << depth)) key = raw * 255 / ((1 << depth) - 1); }
+            for (size_t i = 0; i < (size_t)w * h; ++i) { ga[2 * i] = pix[i]; ga[2 * i + 1] = (pix[i] == key) ? 0 : 255; }
             to_rgb(ga.data(), 2, (size_t)w * h, out);
         }
     }

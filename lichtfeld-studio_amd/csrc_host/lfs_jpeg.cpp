@@ -160,6 +160,7 @@ struct Decoder {
         if (len < 6 || p[0] != 8) throw Unsupported("JPEG: only 8-bit precision is supported");
         height = be16(p + 1); width = be16(p + 3); ncomp = p[5];
         if (width <= 0 || height <= 0) throw Corrupt("JPEG: empty image");
+        if ((uint64_t)width * (uint64_t)height > (uint64_t(1) << 28)) throw Corrupt("JPEG: implausible dimensions"); // 268 Mpixel: the coefficient planes alone would take > 1.5 GB
         if (ncomp != 1 && ncomp != 3) throw Unsupported("JPEG: only 1- and 3-component images are supported");
         if (len < 6 + 3 * ncomp) throw Corrupt("JPEG: short SOF");
         for (int i = 0; i < ncomp; ++i) {

@@ -43,6 +43,7 @@ class GutTrainer:
         self._fg_settings = {}
         self.strategy = None
         self.strategy_kind = strategy
+        self._resize_suspended, self._resize_pending = False, False
         self.densification_info = None   # [2,N]: fastgs backward's (visibility count, screen-space gradient norm) for ADC
         self.scale_reg = self.opacity_reg = 0.0
         if strategy == "default" and rasterizer != "fastgs":
@@ -91,6 +92,9 @@ class GutTrainer:
 
     def _on_resize(self) -> None:
         """The strategy replaced parameter tensors (densification): the flat gradient bucket has to follow."""
+        if self._resize_suspended:      # (_refine_with_full_shN: shN is gathered right now - one rebuild when the shard is back)
+            self._resize_pending = True
+            return
         if self.bucket is not None:
             self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2])
 
@@ -191,6 +195,8 @@ class GutTrainer:
         the steps in between), the unchanged replicated strategy code runs - identically on every rank - and the result is re-sharded for the new N."""
         ex, opt = self.sh_exchange, self.optimizer
         old = self.model.shN
+        n_before, grad_before = self.model.means.shape[0], old.grad
+        self._resize_suspended, self._resize_pending = True, False
         st = opt._state(old)
         m_full, v_full = ex.gather_rows(st["exp_avg"]), ex.gather_rows(st["exp_avg_sq"])
         full = ex.gather_rows(old.detach()).contiguous().requires_grad_(True)
@@ -206,9 +212,15 @@ class GutTrainer:
             ms, vs = ex2.shard(st2["exp_avg"]).clone(), ex2.shard(st2["exp_avg_sq"]).clone()
             shard = ex2.shard(cur.detach()).clone().requires_grad_(True)
             opt.replace_param(2, cur, shard, lambda t: ms if t is st2["exp_avg"] else vs)
+            # nothing was added or removed and the strategy kept the tensor (relocation works in place): the shard keeps its gradient, so this
+            # step's Adam update of shN happens as it does in the replicated layout and in the reference
+            if cur is full and self.model.means.shape[0] == n_before and grad_before is not None:
+                shard.grad = grad_before
             self.model.shN = shard
             self.sh_exchange = ex2
-            self._on_resize()
+            self._resize_suspended = False
+            if self._resize_pending or self.model.means.shape[0] != n_before:
+                self._on_resize()
 
     def full_shN(self) -> torch.Tensor:
         """[N,K-1,3] on every rank (all-gathers the owners' rows when SH-sharded): export, evaluation."""
