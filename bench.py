@@ -298,11 +298,20 @@ def main() -> None:
     N = scene.N
     K = (scene.sh_degree + 1) ** 2
     V = int(trainer.last_visible.sum().item()) if trainer.last_visible is not None else 0
+    v_source = None
+    if V == 0 and args.rasterizer == "fastgs":
+        # the fastgs wrappers do not hand back a visibility mask; the byte table needs V: the 3DGUT projection of the same view (the EWA culling of
+        # fastgs differs from it by a few rows per million)
+        with torch.no_grad():
+            m, cam = trainer.model, trainer.camera(0)
+            radii = _fused.activations_project(m.means.detach(), m.raw_quats.detach(), m.raw_scales.detach(), m.raw_opacities.detach(), cam.world_view_transform, cam.K,
+                                               scene.width, scene.height, None)[3]
+        V, v_source = int((radii[0] > 0).all(-1).sum().item()), "3DGUT projection of the same view"
     I = int(trainer.last_n_isects)
     P = scene.width * scene.height
     T = ((scene.width + 15) // 16) * ((scene.height + 15) // 16)
     adam_elems = sum(p.numel() for p in trainer.model.parameters())
-    if trainer.iteration <= 1000 or (world == 1 and args.views_per_rank == 1 and trainer.inline_shN_adam and args.rasterizer == "gut"):
+    if trainer.iteration <= 1000 or "sh_bwd_adam" in table:
         # shN is not in the optimizer launch: skipped while iteration <= 1000 (fused_adam.cpp:68-70), updated inside sh_bwd_adam afterwards
         adam_elems -= trainer.model.shN.numel()
     bytes_per = algorithmic_bytes(N, V, I, P, T, K, adam_elems)
@@ -366,7 +375,7 @@ def main() -> None:
                    "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ""), "start_iteration": args.start_iteration,
                    **({"parallelism_fallback": parallelism_fallback} if parallelism_fallback else {}),
                    "strategy": args.strategy, "bilateral_grid": bool(args.bilateral_grid), "refine_step_ms": None if refine_ms is None else round(refine_ms, 3),
-                   "visible_gaussians": V, "n_isects": I},
+                   "visible_gaussians": V, **({"visible_gaussians_source": v_source} if v_source else {}), "n_isects": I},
         "collectives": {"backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None), "ranks_seen": seen,
                         "per_step": {k: {"calls": v["calls"] / args.steps, "MB": round(v["bytes"] / args.steps / 1e6, 3), "ms": round(v["ms"] / args.steps, 4)} for k, v in coll.items()}},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
