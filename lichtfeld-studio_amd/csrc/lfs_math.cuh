@@ -12,6 +12,9 @@ namespace lfs {
 
 struct f3 { float x, y, z; };
 struct f2 { float x, y; };
+// row i of a packed [n,3] float array as ONE 12-byte access (global_load / store_dwordx3): written element by element the compiler emits three
+// single-dword accesses at a 12-byte lane stride
+struct alignas(4) V3f { float a[3]; };
 struct quat { float w, x, y, z; };   // reference order (w, x, y, z)
 struct m3 { float m[3][3]; };
 
@@ -27,6 +30,8 @@ struct m3 { float m[3][3]; };
 #define LFS_WAVE_LOCKSTEP() ((void)0)
 #endif
 
+LFS_DI f3 ld3(const float* __restrict__ base, size_t i) { const V3f t = reinterpret_cast<const V3f*>(base)[i]; return {t.a[0], t.a[1], t.a[2]}; }
+LFS_DI void st3(float* __restrict__ base, size_t i, f3 v) { V3f t; t.a[0] = v.x; t.a[1] = v.y; t.a[2] = v.z; reinterpret_cast<V3f*>(base)[i] = t; }
 LFS_DI f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 LFS_DI f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 LFS_DI f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }

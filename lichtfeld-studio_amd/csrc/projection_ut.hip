@@ -37,8 +37,8 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
     float o_m2x = 0.f, o_m2y = 0.f, o_depth = 0.f, o_c0 = 0.f, o_c1 = 0.f, o_c2 = 0.f, o_comp = 0.f;
 
     do {
-        const f3 mean{means[3 * gid], means[3 * gid + 1], means[3 * gid + 2]};
-        f3 scale{scales[3 * gid], scales[3 * gid + 1], scales[3 * gid + 2]};
+        const f3 mean = ld3(means, gid);
+        f3 scale = ld3(scales, gid);
         float4 qin = reinterpret_cast<const float4*>(quats)[gid];
         float opac_in = opacities != nullptr ? opacities[gid] : 0.f;
         if (ACT) {
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
             opac_in = 1.f / (1.f + expf(-opac_in));
             if (cid == 0) {
                 reinterpret_cast<float4*>(act_quats)[gid] = qin;
-                act_scales[3 * gid] = scale.x; act_scales[3 * gid + 1] = scale.y; act_scales[3 * gid + 2] = scale.z;
+                st3(act_scales, gid, scale);
                 act_opacities[gid] = opac_in;
             }
         }

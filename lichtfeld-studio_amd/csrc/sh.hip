@@ -142,8 +142,8 @@ template <bool MODEL> LFS_DI bool sh_on(const ShArgs& a, uint32_t g) {
     return a.masks == nullptr || a.masks[g] != 0;
 }
 template <bool MODEL> LFS_DI f3 sh_dir(const ShArgs& a, uint32_t g) {
-    if (MODEL) { const f3 cp = a.campos ? f3{a.campos[0], a.campos[1], a.campos[2]} : campos_of(a.viewmat); return {a.means[3 * g] - cp.x, a.means[3 * g + 1] - cp.y, a.means[3 * g + 2] - cp.z}; }
-    return {a.dirs[3 * g], a.dirs[3 * g + 1], a.dirs[3 * g + 2]};
+    if (MODEL) { const f3 cp = a.campos ? f3{a.campos[0], a.campos[1], a.campos[2]} : campos_of(a.viewmat); const f3 m = ld3(a.means, g); return {m.x - cp.x, m.y - cp.y, m.z - cp.z}; }
+    return ld3(a.dirs, g);
 }
 template <bool MODEL, class T> LFS_DI T* sh_coef(T* coeffs, T* sh0, T* shN, uint32_t K, uint32_t g, int k) {
     if (MODEL) return k == 0 ? sh0 + size_t(g) * 3 : shN + (size_t(g) * (K - 1) + (k - 1)) * 3;
@@ -219,9 +219,10 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
         __syncthreads();
         const uint32_t g = g0 + lane;
         if (g < a.n && sh_on<MODEL>(a, g)) { // only Gaussians that reach a tile list are ever looked up
-            const f3 mu{a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
+            const f3 mu = ld3(a.means, g);
             const float4 q = reinterpret_cast<const float4*>(pk.quats)[g];
-            const float sc[3] = {pk.scales[3 * g], pk.scales[3 * g + 1], pk.scales[3 * g + 2]};
+            const f3 s3 = ld3(pk.scales, g);
+            const float sc[3] = {s3.x, s3.y, s3.z};
             GaussRec rec;
             CullRec cr;
             pack_gaussian<true>(*pk.cam, mu, q, sc, pk.opacities[g], ldc[lane * 3], ldc[lane * 3 + 1], ldc[lane * 3 + 2], rec, cr);
@@ -340,9 +341,12 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
         ox = (gx - dd * d.x) * inorm; oy = (gy - dd * d.y) * inorm; oz = (gz - dd * d.z) * inorm;
     }
     if (gmine < a.n) {
-        if (MODEL && a.dirs_store) { const size_t ds = a.ds ? a.ds : 3; v_dirs[ds * gmine] = ox; v_dirs[ds * gmine + 1] = oy; v_dirs[ds * gmine + 2] = oz; } // (0 when off)
-        else if (MODEL) { if (on && want_dirs) { v_dirs[3 * gmine] += ox; v_dirs[3 * gmine + 1] += oy; v_dirs[3 * gmine + 2] += oz; } }
-        else { v_dirs[3 * gmine] = ox; v_dirs[3 * gmine + 1] = oy; v_dirs[3 * gmine + 2] = oz; }
+        if (MODEL && a.dirs_store) {
+            const size_t ds = a.ds ? a.ds : 3;
+            if (ds == 3) st3(v_dirs, gmine, f3{ox, oy, oz});
+            else { v_dirs[ds * gmine] = ox; v_dirs[ds * gmine + 1] = oy; v_dirs[ds * gmine + 2] = oz; } // (0 when off)
+        } else if (MODEL) { if (on && want_dirs) { const f3 o = ld3(v_dirs, gmine); st3(v_dirs, gmine, f3{o.x + ox, o.y + oy, o.z + oz}); } }
+        else st3(v_dirs, gmine, f3{ox, oy, oz});
     }
 }
 
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__(64) sh_views_fwd_kernel(const ShViews a, float
         }
     }
     f3 m{0.f, 0.f, 0.f};
-    if (gmine < a.n) m = {a.means[3 * gmine], a.means[3 * gmine + 1], a.means[3 * gmine + 2]};
+    if (gmine < a.n) m = ld3(a.means, gmine);
     for (uint32_t v = 0; v < a.V; ++v) {
         {   // phase 1 (lane = Gaussian)
             float b[25];
@@ -474,7 +478,7 @@ __global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const
 #pragma unroll
     for (int it = 0; it < LPG; ++it) a0[it] = a1[it] = a2[it] = 0.f;
     f3 m{0.f, 0.f, 0.f};
-    if (gmine < a.n) m = {a.means[3 * gmine], a.means[3 * gmine + 1], a.means[3 * gmine + 2]};
+    if (gmine < a.n) m = ld3(a.means, gmine);
     float ox = 0.f, oy = 0.f, oz = 0.f;
     for (uint32_t v = 0; v < a.V; ++v) {
         f3 d{0.f, 0.f, 0.f};
@@ -553,7 +557,7 @@ __global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const
         } else if (accumulate) { v_shN[e] += a0[it]; v_shN[e + 1] += a1[it]; v_shN[e + 2] += a2[it]; }
         else { v_shN[e] = a0[it]; v_shN[e + 1] = a1[it]; v_shN[e + 2] = a2[it]; }
     }
-    if (gmine < a.n && want_dirs) { v_means[3 * gmine] += ox; v_means[3 * gmine + 1] += oy; v_means[3 * gmine + 2] += oz; }
+    if (gmine < a.n && want_dirs) { const f3 o = ld3(v_means, gmine); st3(v_means, gmine, f3{o.x + ox, o.y + oy, o.z + oz}); }
 }
 
 // used by fastgs_{prep,blend}.hip: SH colour of visible primitives written straight into the blend records (stride in floats),
