@@ -108,3 +108,39 @@ def test_intersect_full_size_properties(lfs):
     assert torch.equal(ops.intersect_offset(ids, 1, tw, th), off)
     # depth bits of every entry are the depth of its Gaussian
     assert torch.equal((ids & 0xFFFFFFFF).int(), d.view(-1)[flat.long()].view(torch.int32))
+
+
+def test_two_pass_scatter_equals_one_pass_over_random_shapes(lfs):
+    """The binned two-pass scatter (default) against the one-pass kernel (debug bit 5) over random problem shapes - cameras, image sizes down to one
+    tile and up to thousands of tiles per row, tile sizes, dense and sparse lists, a reused workspace (LFS_ISECT_COUNTERS_ZERO) and the overlap form
+    (counts written to pinned host memory): every output identical. (Each path against the oracle: the tests above and tests/test_emulated_intersect.py.)"""
+    from lichtfeld_studio_amd import ops
+    lib = lfs.load_library()
+    g = np.random.default_rng(7)
+    for trial in range(24):
+        C = int(g.integers(1, 4))
+        N = int(g.choice([1, 37, 1000, 20000, 150000]))
+        ts = int(g.choice([8, 16, 32]))
+        W, H = int(g.integers(ts, 2400)), int(g.integers(ts, 1400))
+        if trial % 6 == 5:
+            W, H = ts * int(g.integers(1, 4)), int(g.integers(4000, 9000))   # tall and narrow: more than 512 tile rows at tile 8 -> the fallback
+        tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
+        rmax = int(g.choice([3, 20, 120]))
+        m = np.stack([g.uniform(-0.05 * W, 1.05 * W, (C, N)), g.uniform(-0.05 * H, 1.05 * H, (C, N))], -1).astype(np.float32)
+        r = g.integers(0, rmax + 1, (C, N, 2)).astype(np.int32)
+        d = (np.round(g.uniform(0.2, 30.0, (C, N)) * 8) / 8).astype(np.float32)
+        tm, tr, td = t(m), t(r, torch.int32), t(d)
+        outs = []
+        for flags, overlap in ((0, None), (0, lambda: 1), (32, None)):
+            lib.lfs_set_debug_flags(flags)
+            try:
+                res = ops.intersect_tile(tm, tr, td, None, None, C, ts, tw, th, True, return_offsets=True, overlap=overlap)
+            finally:
+                lib.lfs_set_debug_flags(0)
+            outs.append([n(x) for x in res[:4]])
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert a.shape == b.shape and np.array_equal(a, b), (trial, C, N, W, H, ts)
+        ids = outs[0][1]
+        assert (np.diff(ids) >= 0).all()                       # sorted by (camera | tile | depth)
+        assert int(outs[0][0].sum()) == ids.shape[0]
