@@ -164,6 +164,8 @@ def main() -> None:
                          "every 100 iterations with the Relocation kernel, scale / opacity regularisers), max_cap = the scene's Gaussian count")
     ap.add_argument("--bilateral-grid", action="store_true", help="BASELINE.json configs[4]: per-image 16x16x8 bilateral grid between render and loss (+ its TV loss and Adam)")
     ap.add_argument("--replicated", action="store_true", help="multi-GPU: keep shN replicated (59 floats / Gaussian all-reduced) instead of SH-sharded")
+    ap.add_argument("--sh-sharded", action="store_true", help="force the SH-sharded layout (the default for more than one rank) - with LFS_DIST_FORCE_COLLECTIVES=1 this runs its collectives on ONE GPU")
+    ap.add_argument("--no-overlap-exchange", action="store_true", help="developer A/B: blocking all-to-alls in the SH-sharded forward")
     ap.add_argument("--wide-cells", action="store_true", help="developer A/B: the experimental two-pixels-per-lane 16x8-cell rasterizer kernels (slower on SYN-B; see raster.hip)")
     ap.add_argument("--row-lists", default="split", choices=["split", "merged"], help="with --row-kernels: quadrant lists split from the cell lists (two kernels) or built in one pass")
     ap.add_argument("--row-kernels", action="store_true", help="developer A/B: the experimental quadrant-row rasterizer kernels (csrc/lfs_raster_rows.cuh; not yet verified on a GPU)")
@@ -212,7 +214,7 @@ def main() -> None:
     def make_trainer(sh_sharded):
         return GutTrainer(scene, device, iterations=30000 if args.strategy == "mcmc" else 7000, world=world, rank=rank, views_per_rank=args.views_per_rank,
                           loss=args.loss, rasterizer=args.rasterizer, sh_sharded=sh_sharded, use_bilateral_grid=args.bilateral_grid, **extra)
-    trainer = make_trainer(False if args.replicated else None)
+    trainer = make_trainer(False if args.replicated else (True if args.sh_sharded else None))
     if args.strategy == "mcmc" and args.start_iteration == 3000:
         # the warm-up must contain one refinement step (iteration 3000: relocation + its torch index kernels, whose first use loads ~20 code
         # objects at 20 - 200 ms each); the timed window then holds warm steps only, one of them (every 100th) a refinement step
@@ -222,6 +224,7 @@ def main() -> None:
         trainer.inline_all_adam = False
     from lichtfeld_studio_amd import fused as _fused
     _fused.FUSE_SH_PACK, _fused.FUSE_ACT_PROJ = bool(args.fuse_sh_pack), not args.no_fuse_act_proj
+    _fused.OVERLAP_SH_EXCHANGE = not args.no_overlap_exchange
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
     parallelism_fallback = None
     if world > 1 and trainer.sh_exchange is not None:

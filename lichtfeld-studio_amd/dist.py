@@ -201,27 +201,42 @@ class ShExchange:
         return t[self.r0:self.r1]
 
     def _pad(self, t: torch.Tensor) -> torch.Tensor:
-        """[N, ...] -> [world, S, ...] (zero rows after N)"""
+        """[N, ...] -> [world, S, ...] (zero rows after N; a plain view when the ranks divide N - no fill, no copy)"""
+        if self.N == self.world * self.S and t.is_contiguous():
+            return t.view((self.world, self.S) + tuple(t.shape[1:]))
         out = torch.zeros((self.world * self.S,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         out[:self.N] = t
         return out.view((self.world, self.S) + tuple(t.shape[1:]))
 
-    def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
-        """send[j] goes to rank j; recv[j] came from rank j"""
+    def _all_to_all(self, send: torch.Tensor, defer: bool = False):
+        """send[j] goes to rank j; recv[j] came from rank j. defer=True (device collectives only): the exchange is enqueued asynchronously and
+        (recv, finish) is returned - the caller's stream keeps running kernels that do not need `recv` and calls finish() before the first one
+        that does (the collective runs on the library's own stream behind everything enqueued so far)."""
         send = send.contiguous()
         if not _active():
-            return send.clone()
+            out = send.clone()
+            return (out, lambda: None) if defer else out
         end = _account("all_to_all", send)
         if _staged(send):
             host, out = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
             dist.all_to_all_single(out, host)
             recv = out.to(send.device)
-        else:
-            recv = torch.empty_like(send)
+            if end is not None:
+                end.record()
+            return (recv, lambda: None) if defer else recv
+        recv = torch.empty_like(send)
+        if not defer:
             dist.all_to_all_single(recv, send)
-        if end is not None:
-            end.record()
-        return recv
+            if end is not None:
+                end.record()
+            return recv
+        work = dist.all_to_all_single(recv, send, async_op=True)
+
+        def finish():
+            work.wait()          # a stream-side wait: the host does not block
+            if end is not None:
+                end.record()
+        return recv, finish
 
     def gather_rows(self, shard_rows: torch.Tensor) -> torch.Tensor:
         """Owner shards [n_r, ...] -> the full [N, ...] tensor on every rank (export, evaluation, strategies)."""
@@ -242,24 +257,45 @@ class ShExchange:
             end.record()
         return out
 
-    def forward(self, deg: int, means, sh0, shN_shard, radii, viewmats_all, sh_fwd_views):
+    def begin_radii(self, radii):
+        """Start the exchange of this rank's radii [N,2] as soon as the projection has produced them; hand the result to forward(radii_pending=)."""
+        return self._all_to_all(self._pad(radii), defer=True)
+
+    def forward(self, deg: int, means, sh0, shN_shard, radii, viewmats_all, sh_fwd_views, radii_pending=None, defer: bool = False):
         """radii [N,2] int32 of THIS rank's view; viewmats_all[j] = the [1,4,4] view matrix rank j renders now.
-        -> (colours [N,3] of this rank's view, ctx for backward). `sh_fwd_views`: fused.sh_model_fwd_views (one launch for all views)."""
-        radii_recv = self._all_to_all(self._pad(radii))                     # [world, S, 2]: view j's radii for my rows
+        -> (colours [N,3] of this rank's view, ctx for backward). `sh_fwd_views`: fused.sh_model_fwd_views (one launch for all views).
+        Overlap (the fused step): radii_pending = begin_radii(radii) issued right after the projection, so that exchange runs next to the
+        intersection count; defer=True returns the colours before their exchange has finished - call finish_forward(ctx) before the first kernel
+        that reads them (the intersection scatter and sort run in between)."""
+        if radii_pending is not None:
+            radii_recv, fin = radii_pending
+            fin()
+        else:
+            radii_recv = self._all_to_all(self._pad(radii))                 # [world, S, 2]: view j's radii for my rows
         vms = torch.cat([v.reshape(1, 4, 4) for v in viewmats_all]).contiguous()
         if self.n:
             colors_send = sh_fwd_views(deg, self.shard(means), vms, self.shard(sh0), shN_shard, radii_recv)   # [world, S, 3]
         else:
             colors_send = torch.zeros((self.world, self.S, 3), dtype=means.dtype, device=means.device)
+        if defer:
+            recv, fin = self._all_to_all(colors_send, defer=True)
+            colors = recv.view(self.world * self.S, 3)[:self.N]
+            assert colors.is_contiguous()   # a row prefix of the receive buffer: no copy may read it before finish_forward
+            return colors, (radii_recv, colors_send, vms, fin)
         colors = self._all_to_all(colors_send).view(self.world * self.S, 3)[:self.N]
-        return colors.contiguous(), (radii_recv, colors_send, vms)
+        return colors.contiguous(), (radii_recv, colors_send, vms, None)
+
+    @staticmethod
+    def finish_forward(ctx) -> None:
+        if ctx is not None and len(ctx) > 3 and ctx[3] is not None:
+            ctx[3]()
 
     def backward(self, ctx, deg: int, means, sh0, shN_shard, viewmats_all, v_colors, g_sh0, g_shN_shard, g_means, accumulate: bool, sh_bwd_views,
                  adam=None) -> None:
         """v_colors [N,3] = dL/dcolours of this rank's view. Writes (accumulate False) or adds to g_shN_shard and MY rows of g_sh0 (the
         other rows are zeroed / left alone: the all-reduce brings their owners' values), adds dL/d(dirs) into my rows of g_means.
         `adam` (FusedAdam.prepare_inline of the shard; needs accumulate False): the shard is updated in place, g_shN_shard is not written."""
-        radii_recv, colors_send, vms = ctx
+        radii_recv, colors_send, vms = ctx[:3]
         v_recv = self._all_to_all(self._pad(v_colors))                      # [world, S, 3]: view j's dL/dcolour for my rows
         if not accumulate:
             g_sh0.zero_()

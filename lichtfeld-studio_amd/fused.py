@@ -218,6 +218,7 @@ def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
 
 
 FUSE_MSE_INTO_BACKWARD = True   # False: separate lfs_mse_loss_fwd_bwd launch (tests compare the two)
+OVERLAP_SH_EXCHANGE = True       # SH-sharded: the radii / colour all-to-alls run next to the intersection kernels (False: blocking, A/B and debugging)
 OVERLAP_SH_WITH_READBACK = True  # False: SH colours first, then the blocking n_isects read-back (A/B timing)
 
 
@@ -270,19 +271,25 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
             quats, scales, opac = activations_fwd(raw_quats, raw_scales, raw_opac)
             radii, means2d, depths, _, _ = ops.projection_ut_3dgs_fused(means, quats, scales, opac, viewmat, None, Kmat, W, H, 0.3, 0.01, 10000.0, 0.0,
                                                                         False, CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None)
+        # SH-sharded: this rank's radii start their way to the SH owners now (next to the intersection count), the colours come back while the
+        # intersection scatter and sort run; finish_forward() below is the stream-side wait in front of the first kernel that reads them
+        radii_pending = sh_exchange.begin_radii(radii[0]) if (sh_exchange is not None and OVERLAP_SH_EXCHANGE) else None
+
         # SH colours do not depend on the tile lists: they are enqueued while the host waits for n_isects (ops.intersect_tile `overlap`)
         def sh_stage():
             if front:
                 return sh_model_fwd_pack(deg, means, viewmat, sh0, shN, radii, quats, scales, opac, ws), None
             if sh_exchange is None:
                 return sh_model_fwd(deg, means, viewmat, sh0, shN, radii), None
-            return sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd_views)
+            return sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd_views, radii_pending=radii_pending, defer=OVERLAP_SH_EXCHANGE)
         if OVERLAP_SH_WITH_READBACK:
             _, _, flatten_ids, offsets, (colors, sh_ctx) = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True,
                                                                                overlap=sh_stage)
         else:
             colors, sh_ctx = sh_stage()
             _, _, flatten_ids, offsets = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True)
+        if sh_exchange is not None:
+            sh_exchange.finish_forward(sh_ctx)
         fwd_args = (means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, None, W, H, tile, viewmat, None, Kmat,
                     CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None, offsets, flatten_ids)
         if front:

@@ -262,7 +262,7 @@ class GutTrainer:
                                             for j in range(self.world)]
             # one view, one rank, Adam reading shN (iteration > 1000): the SH backward applies shN's Adam update itself (no shN gradient tensor)
             inline = None
-            if (self.inline_shN_adam and self.world == 1 and len(views) == 1 and self.strategy is None and self.iteration > 1000
+            if (self.inline_shN_adam and self.world == 1 and self.sh_exchange is None and len(views) == 1 and self.strategy is None and self.iteration > 1000
                     and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False)):
                 inline = self.optimizer.prepare_inline(self.model.shN)
             # ... and when the MSE is folded into the rasterizer backward as well, EVERY parameter is updated by the backward kernels (fused.backward_adam_all):
