@@ -243,7 +243,7 @@ extern "C" int lfs_fastgs_render(
         }
         lfs::ProfScope prof_sort("fastgs_tile_sort", s);
         hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 1024 * 8, s, 1u, 1024u, T, 0u, w.offsets, iw.keys, iw.ids);
-        hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 4096 * 8, s, 1025u, 4096u, T, 0u, w.offsets, iw.keys, iw.ids);
+        hipLaunchKernelGGL((tile_sort_bins_kernel<512, 512, false, 32>), dim3(T), dim3(512), 4096 * 8, s, 1025u, 4096u, T, 0u, w.offsets, iw.keys, iw.ids); // (as intersect.hip)
         hipLaunchKernelGGL(tile_sort_lds_kernel<1024>, dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, T, 0u, w.offsets, iw.keys, iw.ids);
         hipLaunchKernelGGL(tile_sort_global_kernel, dim3(T), dim3(1024), 0, s, 16385u, T, 0u, w.offsets, iw.keys, iw.ids);
     }

@@ -228,12 +228,13 @@ class FusedStepOutput:
     alpha: torch.Tensor          # [1,H,W,1]
     radii: torch.Tensor          # [1,N,2]
     n_isects: int
+    v_colors: Optional[torch.Tensor] = None   # [N,3] dL/dcolour (defer_sh_backward: the caller runs the SH backward)
 
 
 def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
                         grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool, loss: str = "mse",
                         lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None, adam_shN: Optional[dict] = None, adam_shard: Optional[dict] = None, bilateral=None, image_idx: int = 0,
-                        on_geometry_grads=None, adam_all: Optional[dict] = None) -> FusedStepOutput:
+                        on_geometry_grads=None, adam_all: Optional[dict] = None, given: Optional[tuple] = None, defer_sh_backward: bool = False) -> FusedStepOutput:
     """One view: forward, loss against `target_chw` ("mse": the rasterizer-only metric of SURVEY.md §8d; "l1_ssim": the reference's
     photometric loss, trainer.cpp:115-128), backward. `grads` = six tensors shaped like model.parameters()
     (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
@@ -247,7 +248,10 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
     `on_geometry_grads()` (multi-GPU, last view of the step) is called as soon as the raw scale / quaternion / opacity gradients are final - before the
     SH backward is enqueued - so their all-reduce (dist.GradBucket.all_reduce_early) overlaps with it on RCCL's stream.
     `adam_all` ({parameter name: FusedAdam.prepare_inline(...)} for all six; one view per step on one rank, MSE loss): nothing is written to `grads` -
-    every parameter is updated in place by the backward kernels themselves (backward_adam_all)."""
+    every parameter is updated in place by the backward kernels themselves (backward_adam_all).
+    `given` = (quats, scales, opacities, radii, means2d, depths, colours) of this view, computed by the caller (render_views_and_backward: projection of
+    all views first, then ONE SH launch for all of them); `defer_sh_backward`: the SH backward is the caller's too - dL/dcolour comes back in the
+    output, grads[1] / grads[2] are not touched, grads[0] receives the rasterizer's part of dL/dmeans."""
     assert camera.camera_model_type == CameraModelType.PINHOLE and camera.radial_distortion is None and camera.tangential_distortion is None, \
         "the fused path covers the trainer's undistorted pinhole cameras; use rasterizer.rasterize for the rest"
     W, H = int(camera.image_width), int(camera.image_height)
@@ -260,12 +264,14 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
     tw, th = (W + tile - 1) // tile, (H + tile - 1) // tile
     with torch.no_grad():
         bg = None if bg_color is None else bg_color.view(1, -1).contiguous()
-        front = FUSE_SH_PACK and sh_exchange is None      # (SH-sharded: the colours come back from the owners, the pack kernel stays separate)
+        front = FUSE_SH_PACK and sh_exchange is None and given is None   # (SH-sharded: the colours come back from the owners, the pack kernel stays separate)
         if front:
             ws = front_workspace(means.shape[0], W, H, tile, means.device)
             cams_c = cameras_struct(viewmat, None, Kmat, W, H, CameraModelType.PINHOLE, ShutterType.GLOBAL, None, None, None)
             check(load_library().lfs_gut_prepare_cameras(C.byref(cams_c), ptr(ws), C.c_size_t(ws.numel()), stream()), "gut_prepare_cameras")
-        if front or FUSE_ACT_PROJ:
+        if given is not None:
+            quats, scales, opac, radii, means2d, depths, given_colors = given
+        elif front or FUSE_ACT_PROJ:
             quats, scales, opac, radii, means2d, depths = activations_project(means, raw_quats, raw_scales, raw_opac, viewmat, Kmat, W, H, ut)
         else:
             quats, scales, opac = activations_fwd(raw_quats, raw_scales, raw_opac)
@@ -277,6 +283,8 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
 
         # SH colours do not depend on the tile lists: they are enqueued while the host waits for n_isects (ops.intersect_tile `overlap`)
         def sh_stage():
+            if given is not None:
+                return given_colors, None
             if front:
                 return sh_model_fwd_pack(deg, means, viewmat, sh0, shN, radii, quats, scales, opac, ws), None
             if sh_exchange is None:
@@ -336,6 +344,10 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         if on_geometry_grads is not None:
             on_geometry_grads()
         # SH backward adds dL/d(dirs) onto the rasterizer's dL/d(means) in place, then the means gradient lands in the caller's buffer
+        if defer_sh_backward:
+            assert sh_exchange is None and adam_shN is None
+            (g_means.add_ if accumulate else g_means.copy_)(v_means)
+            return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]), v_colors.squeeze(0))
         if adam_shN is not None:     # single view, single rank: shN's gradient is consumed by its Adam update inside the SH backward
             assert sh_exchange is None and not accumulate
             sh_model_bwd_adam(deg, means, viewmat, sh0, shN, radii, colors, v_colors.squeeze(0), g_sh0, v_means, adam_shN)
@@ -349,3 +361,43 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
             sh_exchange.backward(sh_ctx, deg, means, sh0, shN, viewmats_all, v_colors.squeeze(0), g_sh0, g_shN, g_means, accumulate, sh_model_bwd_views,
                                  adam=adam_shard)
     return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]))
+
+
+def render_views_and_backward(cameras: List[Camera], model: SplatModel, bg_color: Optional[torch.Tensor], targets: List[torch.Tensor], weight: float,
+                              grads: List[torch.Tensor], loss_acc: torch.Tensor, loss: str = "mse", lambda_dssim: float = 0.2, scale_reg: float = 0.0,
+                              opacity_reg: float = 0.0, adam_shN: Optional[dict] = None, bilateral=None, image_idxs: Optional[List[int]] = None) -> List[FusedStepOutput]:
+    """Several views of ONE step on one rank (BASELINE config 4: 8 views per GPU and step): what render_and_backward does view by view, with the
+    spherical-harmonics stages batched over the views - the projections of all views first, ONE launch for the colours of all views
+    (lfs_sh_model_fwd_views: a Gaussian's coefficient row is read once, not once per view), the rasterizer forward / loss / backward view by view, then
+    ONE SH backward over all views (lfs_sh_model_bwd_views) that sums basis x dL/dcolour over the views in registers - the 180 B / Gaussian shN
+    gradient is written once instead of read-modify-written per view, or, with `adam_shN` (FusedAdam.prepare_inline), not at all: the kernel applies
+    shN's Adam update on the spot. Same arithmetic per (view, Gaussian) as the view-by-view path; the sums over the views are formed in a different
+    order (tests/test_gpu_fused.py). grads are written (not added to). The regularisers count once per step, as in render_and_backward."""
+    V = len(cameras)
+    assert V >= 1 and len(targets) == V
+    means, sh0, shN, raw_scales, raw_quats, raw_opac = [p.detach() for p in model.parameters()]
+    g_means, g_sh0, g_shN = grads[0], grads[1], grads[2]
+    deg = model.get_active_sh_degree()
+    ut = UnscentedTransformParameters()
+    with torch.no_grad():
+        pre = []
+        for cam in cameras:
+            W, H = int(cam.image_width), int(cam.image_height)
+            pre.append(activations_project(means, raw_quats, raw_scales, raw_opac, cam.world_view_transform.contiguous(), cam.K.contiguous(), W, H, ut))
+        radii_all = torch.cat([p[3] for p in pre]).contiguous()                                   # [V,N,2]
+        vms = torch.cat([cam.world_view_transform.reshape(1, 4, 4) for cam in cameras]).contiguous()
+        colors_all = sh_model_fwd_views(deg, means, vms, sh0, shN, radii_all)                      # [V,N,3]
+        v_colors_all = torch.empty_like(colors_all)
+    outs = []
+    for k, cam in enumerate(cameras):
+        quats, scales, opac, radii, means2d, depths = pre[k]
+        out = render_and_backward(cam, model, bg_color, targets[k], weight, grads, loss_acc, accumulate=k > 0, loss=loss, lambda_dssim=lambda_dssim,
+                                  scale_reg=scale_reg if k == 0 else 0.0, opacity_reg=opacity_reg if k == 0 else 0.0, bilateral=bilateral,
+                                  image_idx=image_idxs[k] if image_idxs is not None else k,
+                                  given=(quats, scales, opac, radii, means2d, depths, colors_all[k]), defer_sh_backward=True)
+        v_colors_all[k].copy_(out.v_colors)
+        out.v_colors = None
+        outs.append(out)
+    with torch.no_grad():
+        sh_model_bwd_views(deg, means, vms, sh0, shN, radii_all, colors_all, v_colors_all, g_sh0, g_shN, g_means, False, adam_shN)
+    return outs

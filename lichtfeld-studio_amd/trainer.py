@@ -44,6 +44,7 @@ class GutTrainer:
         self.strategy = None
         self.strategy_kind = strategy
         self._resize_suspended, self._resize_pending = False, False
+        self.batch_views = True          # one rank, several views per step: SH forward / backward once over all views (False: view by view, A/B and tests)
         self.densification_info = None   # [2,N]: fastgs backward's (visibility count, screen-space gradient norm) for ADC
         self.scale_reg = self.opacity_reg = 0.0
         if strategy == "default" and rasterizer != "fastgs":
@@ -280,7 +281,23 @@ class GutTrainer:
             if (self.inline_shN_adam and self.sh_exchange is not None and len(views) == 1 and self.iteration > 1000 and self.sh_exchange.n   # no update then
                     and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False) and not refining):
                 inline_shard = self.optimizer.prepare_inline(self.model.shN)
-            for k, v in enumerate(views):
+            if self.batch_views and self.world == 1 and self.sh_exchange is None and len(views) > 1:
+                # several views per step on one rank: the SH stages run ONCE over all views (fused.render_views_and_backward), and shN's Adam update
+                # moves into that one SH backward when the optimizer would read the gradient anyway
+                from .fused import render_views_and_backward
+                inline_v = None
+                if (self.inline_shN_adam and self.strategy is None and self.iteration > 1000 and self.model.shN.shape[1] > 0
+                        and getattr(self.optimizer, "fused", False)):
+                    inline_v = self.optimizer.prepare_inline(self.model.shN)
+                outs = render_views_and_backward([self.camera(v) for v in views], self.model, self.bg, [targets[k % len(targets)] for k in range(len(views))],
+                                                 1.0 / total_views, self.bucket.views, self.loss_acc, loss=self.loss_kind, lambda_dssim=self.lambda_dssim,
+                                                 scale_reg=self.scale_reg, opacity_reg=self.opacity_reg, adam_shN=inline_v, bilateral=self.bilateral,
+                                                 image_idxs=list(views))
+                self.last_n_isects, self._last_radii = outs[-1].n_isects, outs[-1].radii
+                views_loop = []
+            else:
+                views_loop = list(enumerate(views))
+            for k, v in views_loop:
                 vm_all = None if every is None else [self.scene.viewmats[e[k]:e[k] + 1].contiguous() for e in every]
                 out = render_and_backward(self.camera(v), self.model, self.bg, targets[k % len(targets)], 1.0 / total_views,
                                           self.bucket.views, self.loss_acc, accumulate=k > 0, loss=self.loss_kind, lambda_dssim=self.lambda_dssim,

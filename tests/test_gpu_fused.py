@@ -313,3 +313,34 @@ def test_fused_front_half_matches_the_separate_kernels(lfs):
     assert abs(la - lb) < 1e-6
     for name, x, y in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], ga, gb):
         assert rel_l2(n(x), n(y)) < 1e-4, (name, rel_l2(n(x), n(y)))
+
+
+def test_batched_views_step_matches_the_view_by_view_step(lfs):
+    """Several views per step on one rank (BASELINE config 4): fused.render_views_and_backward - projections of all views, ONE SH forward and ONE SH
+    backward (with shN's Adam update inside) over all views - against the same step view by view (per-view SH kernels accumulating the shN
+    gradient, shN in the optimizer launch). Deterministic rasterizer sums (debug bit 4), so what differs is only the order in which the per-view SH
+    terms are added: loss identical, parameters and moments to a few ulp of the update."""
+    import convergence_check as cc
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    _, sc = cc.make_task(n=4000, size=96, n_views=6, sh_degree=2)
+    g = torch.Generator().manual_seed(5)
+    targets = [(torch.rand(3, sc.height, sc.width, generator=g) * 0.7).to(DEV) for _ in range(4)]
+    lib = lfs.load_library()
+    try:
+        lib.lfs_set_debug_flags(16)
+        a = GutTrainer(sc, DEV, iterations=7000, views_per_rank=4)
+        b = GutTrainer(sc, DEV, iterations=7000, views_per_rank=4)
+        b.batch_views = False
+        for it0 in (500, 1500):                   # shN out of / in the optimizer (fused_adam.cpp:68-70)
+            a.iteration = b.iteration = it0
+            for _ in range(3):
+                la, lb = a.train_step(targets), b.train_step(targets)
+        torch.cuda.synchronize()
+    finally:
+        lib.lfs_set_debug_flags(0)
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb)) and float(la) > 0
+    for name, pa, pb in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], a.model.parameters(), b.model.parameters()):
+        sa, sb = a.optimizer.state[id(pa)], b.optimizer.state[id(pb)]
+        assert sa["step_count"] == sb["step_count"], name
+        assert float((pa - pb).abs().max()) <= 2e-5 * float(pb.abs().max()), (name, float((pa - pb).abs().max()))
+        assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) <= 1e-4 * float(sb["exp_avg"].abs().max()) + 1e-12, name
