@@ -137,6 +137,9 @@ LFS_DI CellCtx cell_ctx_wide(uint32_t n_tiles, uint32_t total_tiles, uint32_t tw
 }
 LFS_DI uint32_t cells_per_tile(uint32_t tile_size, bool wide) { return wide ? (tile_size >> 4) * (tile_size >> 3) : (tile_size >> 3) * (tile_size >> 3); }
 
+#ifndef LFS_CULL_DEPTH
+#define LFS_CULL_DEPTH 1   // batches of look-ahead per thread in raster_cull_kernel; 2 and 4 measured: no gain (0.072 -> 0.073 / 0.078 ms on SYN-B) - the kernel is
+#endif                     // bound by the gather throughput (L2 / texture-address unit), not by the latency of a workgroup's dependent loads
 template <bool UNIFORM_ORIGIN, bool WIDE = false>
 __global__ void __launch_bounds__(256) raster_cull_kernel(
     const uint32_t C, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
@@ -211,33 +214,45 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
         g = i < end ? ids[i] : 0;
         if (need_recs) cr = cull[g];
     };
-    int32_t g_reg; CullRec cr_reg;
-    cr_reg.a = make_float4(0.f, 0.f, 0.f, 0.f); cr_reg.b = cr_reg.a;
-    fetch(start, g_reg, cr_reg);
+    // DEPTH batches are in flight per thread (id load -> dependent record gather: two memory round trips each)
+    constexpr int DEPTH = LFS_CULL_DEPTH;
+    int32_t g_reg[DEPTH]; CullRec cr_reg[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        cr_reg[d].a = make_float4(0.f, 0.f, 0.f, 0.f); cr_reg[d].b = cr_reg[d].a; g_reg[d] = 0;
+        if (start + d * E < end) fetch(start + d * E, g_reg[d], cr_reg[d]);
+    }
     int buf = 0;
-    for (int32_t base = start; base < end; base += E, buf ^= 1) {
-        s_g[buf][threadIdx.x] = g_reg;
-        if (need_recs) { s_a[buf][threadIdx.x] = cr_reg.a; s_b[buf][threadIdx.x] = cr_reg.b; }
-        __syncthreads();
-        if (base + E < end) fetch(base + E, g_reg, cr_reg); // in flight during the tests below
-        if (!cell_live) continue;
-        for (int32_t sub = 0; sub < nsub; ++sub) {
-            const int32_t slot = (sub << 6) + int32_t(lane);
-            const int32_t my_idx = base + slot;
-            if (base + (sub << 6) >= end) break; // uniform
-            const bool valid = my_idx < end;
-            const int32_t my_g = s_g[buf][slot];
-            bool hit = valid;
-            if (can_cull) {
-                const float4 a = s_a[buf][slot], b = s_b[buf][slot];
-                hit = valid && !conic_culled(ConicRec{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, tu_lo, tu_hi, tv_lo, tv_hi);
+    for (int32_t base0 = start; base0 < end; base0 += DEPTH * E) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int32_t base = base0 + d * E;
+            if (base >= end) break; // uniform
+            s_g[buf][threadIdx.x] = g_reg[d];
+            if (need_recs) { s_a[buf][threadIdx.x] = cr_reg[d].a; s_b[buf][threadIdx.x] = cr_reg[d].b; }
+            __syncthreads();
+            if (base + DEPTH * E < end) fetch(base + DEPTH * E, g_reg[d], cr_reg[d]); // in flight during the tests below
+            if (cell_live) {
+                for (int32_t sub = 0; sub < nsub; ++sub) {
+                    const int32_t slot = (sub << 6) + int32_t(lane);
+                    const int32_t my_idx = base + slot;
+                    if (base + (sub << 6) >= end) break; // uniform
+                    const bool valid = my_idx < end;
+                    const int32_t my_g = s_g[buf][slot];
+                    bool hit = valid;
+                    if (can_cull) {
+                        const float4 a = s_a[buf][slot], b = s_b[buf][slot];
+                        hit = valid && !conic_culled(ConicRec{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, tu_lo, tu_hi, tv_lo, tv_hi);
+                    }
+                    const uint64_t m = __ballot(hit);
+                    if (hit) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+                        out[count + int32_t(rank)] = make_int2(my_g, my_idx);
+                    }
+                    count += __popcll(m);
+                }
             }
-            const uint64_t m = __ballot(hit);
-            if (hit) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-                out[count + int32_t(rank)] = make_int2(my_g, my_idx);
-            }
-            count += __popcll(m);
+            buf ^= 1;
         }
     }
     if (lane == 0) cell_count[cell] = count;
