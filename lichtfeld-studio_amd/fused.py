@@ -101,12 +101,13 @@ def front_workspace_fit(ws: torch.Tensor, N: int, W: int, H: int, tile: int, n_i
     return ws
 
 
-def activations_project(means, raw_quats, raw_scales, raw_opacities, viewmat, Kmat, W: int, H: int, ut, camera_model=CameraModelType.PINHOLE):
+def activations_project(means, raw_quats, raw_scales, raw_opacities, viewmat, Kmat, W: int, H: int, ut, camera_model=CameraModelType.PINHOLE, radii_out=None):
     """activations_fwd + ops.projection_ut_3dgs_fused (trainer constants of rasterizer.cpp:176-181) in one kernel -> (quats, scales, opacities, radii, means2d, depths)"""
     require_gpu(means, raw_quats, raw_scales, raw_opacities, viewmat, Kmat)
     N, dev = means.shape[0], means.device
     quats, scales, opac = torch.empty_like(raw_quats), torch.empty_like(raw_scales), torch.empty_like(raw_opacities)
-    radii = torch.empty((1, N, 2), dtype=torch.int32, device=dev)
+    radii = radii_out if radii_out is not None else torch.empty((1, N, 2), dtype=torch.int32, device=dev)   # (radii_out: a [1,N,2] slice of a multi-view buffer)
+    assert tuple(radii.shape) == (1, N, 2) and radii.dtype == torch.int32 and radii.is_contiguous()
     means2d, depths = torch.empty((1, N, 2), dtype=means.dtype, device=dev), torch.empty((1, N), dtype=means.dtype, device=dev)
     cams = cameras_struct(viewmat, None, Kmat, W, H, camera_model, ShutterType.GLOBAL, None, None, None)
     from .capi import ut_struct
@@ -185,7 +186,9 @@ def sh_model_fwd_views(sh_degree: int, means, viewmats, sh0, shN, radii_views):
     used) -> colours [V,S,3] (rows >= n zero)."""
     require_gpu(means, viewmats, sh0, shN, radii_views)
     n, K, V, S = means.shape[0], 1 + shN.shape[1], radii_views.shape[0], radii_views.shape[1]
-    colors = torch.zeros((V, S, 3), dtype=means.dtype, device=means.device)
+    colors = torch.empty((V, S, 3), dtype=means.dtype, device=means.device)   # the kernel writes every row < n of every view
+    if S > n:
+        colors[:, n:].zero_()
     check(load_library().lfs_sh_model_fwd_views(C.c_uint32(n), C.c_uint32(K), C.c_uint32(sh_degree), C.c_uint32(V), C.c_uint32(S), ptr(means), ptr(viewmats),
                                                 ptr(sh0), ptr(shN), ptr(radii_views), ptr(colors), stream()), "sh_model_fwd_views")
     return colors
@@ -219,6 +222,7 @@ def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
 
 FUSE_MSE_INTO_BACKWARD = True   # False: separate lfs_mse_loss_fwd_bwd launch (tests compare the two)
 OVERLAP_SH_EXCHANGE = True       # SH-sharded: the radii / colour all-to-alls run next to the intersection kernels (False: blocking, A/B and debugging)
+BEGIN_ALL_INTERSECTIONS = True   # multi-view steps: the count kernels of all views up front, one host wait per step (False: one per view)
 OVERLAP_SH_WITH_READBACK = True  # False: SH colours first, then the blocking n_isects read-back (A/B timing)
 
 
@@ -234,7 +238,8 @@ class FusedStepOutput:
 def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float,
                         grads: List[torch.Tensor], loss_acc: torch.Tensor, accumulate: bool, loss: str = "mse",
                         lambda_dssim: float = 0.2, scale_reg: float = 0.0, opacity_reg: float = 0.0, sh_exchange=None, viewmats_all=None, adam_shN: Optional[dict] = None, adam_shard: Optional[dict] = None, bilateral=None, image_idx: int = 0,
-                        on_geometry_grads=None, adam_all: Optional[dict] = None, given: Optional[tuple] = None, defer_sh_backward: bool = False) -> FusedStepOutput:
+                        on_geometry_grads=None, adam_all: Optional[dict] = None, given: Optional[tuple] = None, defer_sh_backward: bool = False,
+                        v_colors_out: Optional[torch.Tensor] = None) -> FusedStepOutput:
     """One view: forward, loss against `target_chw` ("mse": the rasterizer-only metric of SURVEY.md §8d; "l1_ssim": the reference's
     photometric loss, trainer.cpp:115-128), backward. `grads` = six tensors shaped like model.parameters()
     (means, sh0, shN, raw_scales, raw_quats, raw_opacities); written when accumulate is False, added to otherwise.
@@ -269,8 +274,10 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
             ws = front_workspace(means.shape[0], W, H, tile, means.device)
             cams_c = cameras_struct(viewmat, None, Kmat, W, H, CameraModelType.PINHOLE, ShutterType.GLOBAL, None, None, None)
             check(load_library().lfs_gut_prepare_cameras(C.byref(cams_c), ptr(ws), C.c_size_t(ws.numel()), stream()), "gut_prepare_cameras")
+        isect_state = None
         if given is not None:
-            quats, scales, opac, radii, means2d, depths, given_colors = given
+            quats, scales, opac, radii, means2d, depths, given_colors = given[:7]
+            isect_state = given[7] if len(given) > 7 else None      # ops.intersect_tile_begin of this view, issued by the caller
         elif front or FUSE_ACT_PROJ:
             quats, scales, opac, radii, means2d, depths = activations_project(means, raw_quats, raw_scales, raw_opac, viewmat, Kmat, W, H, ut)
         else:
@@ -290,7 +297,10 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
             if sh_exchange is None:
                 return sh_model_fwd(deg, means, viewmat, sh0, shN, radii), None
             return sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd_views, radii_pending=radii_pending, defer=OVERLAP_SH_EXCHANGE)
-        if OVERLAP_SH_WITH_READBACK:
+        if isect_state is not None:
+            (colors, sh_ctx) = sh_stage()
+            _, _, flatten_ids, offsets = ops.intersect_tile_finish(isect_state)
+        elif OVERLAP_SH_WITH_READBACK:
             _, _, flatten_ids, offsets, (colors, sh_ctx) = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True,
                                                                                overlap=sh_stage)
         else:
@@ -335,10 +345,10 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         if fuse_mse:
             v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_bwd_prepared_mse(
                 means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, W, H, tile, viewmat, Kmat, CameraModelType.PINHOLE, ShutterType.GLOBAL,
-                offsets, flatten_ids, render, alpha, last_ids, target_chw, weight, loss_acc, ws)
+                offsets, flatten_ids, render, alpha, last_ids, target_chw, weight, loss_acc, ws, v_colors_out=v_colors_out)
         else:
             v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
-                *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws)
+                *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws, v_colors_out=v_colors_out)
         # the regularisers of trainer.cpp:132-158 are per step, not per view: the caller passes them with the first view only
         activations_bwd(raw_quats, scales, opac, v_quats, v_scales, v_opac.squeeze(0), g_quats, g_scales, g_opac, accumulate, scale_reg, opacity_reg)
         if on_geometry_grads is not None:
@@ -381,11 +391,20 @@ def render_views_and_backward(cameras: List[Camera], model: SplatModel, bg_color
     ut = UnscentedTransformParameters()
     with torch.no_grad():
         pre = []
-        for cam in cameras:
+        radii_all = torch.empty((V, means.shape[0], 2), dtype=torch.int32, device=means.device)   # [V,N,2]: every projection writes its slice
+        for k, cam in enumerate(cameras):
             W, H = int(cam.image_width), int(cam.image_height)
-            pre.append(activations_project(means, raw_quats, raw_scales, raw_opac, cam.world_view_transform.contiguous(), cam.K.contiguous(), W, H, ut))
-        radii_all = torch.cat([p[3] for p in pre]).contiguous()                                   # [V,N,2]
+            pre.append(activations_project(means, raw_quats, raw_scales, raw_opac, cam.world_view_transform.contiguous(), cam.K.contiguous(), W, H, ut,
+                                           radii_out=radii_all[k:k + 1]))
         vms = torch.cat([cam.world_view_transform.reshape(1, 4, 4) for cam in cameras]).contiguous()
+        # the intersection counts of all views now, each into its own workspace and pinned counter pair: the per-view host wait for n_isects
+        # (the GPU idles ~30 us through each: the queue has to drain first) happens once per step
+        isect = []
+        if BEGIN_ALL_INTERSECTIONS:
+            for k, cam in enumerate(cameras):
+                W, H = int(cam.image_width), int(cam.image_height)
+                isect.append(ops.intersect_tile_begin(pre[k][4], pre[k][3], pre[k][5], 1, 16, (W + 15) // 16, (H + 15) // 16, True, return_offsets=True,
+                                                      pinned=True, slot=k))
         colors_all = sh_model_fwd_views(deg, means, vms, sh0, shN, radii_all)                      # [V,N,3]
         v_colors_all = torch.empty_like(colors_all)
     outs = []
@@ -394,8 +413,8 @@ def render_views_and_backward(cameras: List[Camera], model: SplatModel, bg_color
         out = render_and_backward(cam, model, bg_color, targets[k], weight, grads, loss_acc, accumulate=k > 0, loss=loss, lambda_dssim=lambda_dssim,
                                   scale_reg=scale_reg if k == 0 else 0.0, opacity_reg=opacity_reg if k == 0 else 0.0, bilateral=bilateral,
                                   image_idx=image_idxs[k] if image_idxs is not None else k,
-                                  given=(quats, scales, opac, radii, means2d, depths, colors_all[k]), defer_sh_backward=True)
-        v_colors_all[k].copy_(out.v_colors)
+                                  given=(quats, scales, opac, radii, means2d, depths, colors_all[k]) + ((isect[k],) if isect else ()), defer_sh_backward=True,
+                                  v_colors_out=v_colors_all[k:k + 1])          # dL/dcolour of the view lands in its slice: no copy
         out.v_colors = None
         outs.append(out)
     with torch.no_grad():

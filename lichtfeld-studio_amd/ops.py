@@ -78,6 +78,17 @@ def intersect_tile(means2d: Tensor, radii: Tensor, depths: Tensor, camera_ids: O
     `overlap` (extension): a callable that enqueues independent GPU work (the SH colours in the fused step); it runs after the asynchronous
     read-back of n_isects has been queued, and the host then waits for the read-back EVENT only, so the GPU executes that work instead of
     idling through the host round trip (~40 us per step at 1M Gaussians). Its return value is appended to the result."""
+    st = intersect_tile_begin(means2d, radii, depths, C_, tile_size, tile_width, tile_height, sort, return_offsets=return_offsets, pinned=overlap is not None)
+    extra = overlap() if overlap is not None else None
+    out = intersect_tile_finish(st)
+    return out + (extra,) if overlap is not None else out
+
+
+def intersect_tile_begin(means2d: Tensor, radii: Tensor, depths: Tensor, C_: int, tile_size: int, tile_width: int, tile_height: int, sort: bool,
+                         *, return_offsets: bool = False, pinned: bool = True, slot: int = 0) -> dict:
+    """First half of intersect_tile (extension): enqueue the count + scan kernels and return the state intersect_tile_finish() needs. A multi-view
+    step begins the intersections of ALL its views first (slot = view index: each gets its own workspace and its own pinned counter pair) and
+    finishes them one by one - the host then waits once per step instead of once per view (fused.render_views_and_backward)."""
     require_gpu(means2d, radii, depths)
     if means2d.dim() == 2:
         raise LfsError("packed mode is not supported (the reference's trainer never uses it: rasterizer.cpp:56)")
@@ -88,53 +99,62 @@ def intersect_tile(means2d: Tensor, radii: Tensor, depths: Tensor, camera_ids: O
     dev = means2d.device
     tiles_per_gauss = torch.empty(depths.shape, dtype=torch.int32, device=dev)
     ws_bytes = lib.lfs_intersect_tile_workspace_bytes(C.c_uint32(C_), C.c_uint32(N), C.c_uint32(tile_width), C.c_uint32(tile_height))
-    ws = workspace(ws_bytes, dev, "isect")
+    tag = "isect" if slot == 0 else f"isect{slot}"
+    ws = workspace(ws_bytes, dev, tag)
     offsets = torch.empty((C_, tile_height, tile_width), dtype=torch.int32, device=dev) if (return_offsets and sort) else None
     # the scan kernel leaves the workspace counters zero: the memset is only needed on a workspace this exact problem shape has not used last
     shape_key = (ws.data_ptr(), C_, N, tile_width, tile_height)
-    flags = 1 if _ISECT_LAST.get(dev.index) == shape_key else 0
-    _ISECT_LAST[dev.index] = None
-    # without `overlap` the count lands in device memory and .item() reads it; with it the scan kernel writes it straight into pinned host memory
-    # (no copy kernel) and the host waits for an event recorded behind that kernel
-    host = _pinned_i64() if overlap is not None else None   # [n_isects, longest tile list]
-    n_dev = torch.empty(2, dtype=torch.int64, device=dev) if overlap is None else None
+    last_key = (dev.index, tag)
+    flags = 1 if _ISECT_LAST.get(last_key) == shape_key else 0
+    _ISECT_LAST[last_key] = None
+    # pinned: the scan kernel writes the counts straight into pinned host memory (no copy kernel) and the host waits for an event recorded behind
+    # that kernel; otherwise they land in device memory and .tolist() reads them
+    host = _pinned_i64(slot) if pinned else None   # [n_isects, longest tile list]
+    n_dev = None if pinned else torch.empty(2, dtype=torch.int64, device=dev)
     counts = host if host is not None else n_dev
     rc = lib.lfs_intersect_tile_count_ex(
         C.c_uint32(C_), C.c_uint32(N), ptr(means2d), ptr(radii), C.c_uint32(tile_size), C.c_uint32(tile_width), C.c_uint32(tile_height),
         ptr(tiles_per_gauss), C.c_void_p(counts.data_ptr()), C.c_void_p(counts.data_ptr() + 8), ptr(offsets), C.c_uint32(flags),
         ptr(ws), C.c_size_t(ws.numel()), stream())
     check(rc, "intersect_tile (count)")
-    if overlap is None:
-        n_isects, longest = (int(x) for x in n_dev.tolist())  # the one D2H sync of the path
-        extra = None
-    else:
+    ev = None
+    if pinned:
         ev = torch.cuda.Event()
         ev.record()
-        extra = overlap()
-        ev.synchronize()
-        n_isects, longest = (int(x) for x in host.tolist())
+    return dict(means2d=means2d, radii=radii, depths=depths, C=C_, N=N, tile_size=tile_size, tw=tile_width, th=tile_height, sort=sort, tpg=tiles_per_gauss,
+                ws=ws, offsets=offsets, return_offsets=return_offsets, host=host, n_dev=n_dev, ev=ev, last_key=last_key, shape_key=shape_key)
+
+
+def intersect_tile_finish(st: dict):
+    """Second half of intersect_tile: wait for the counts (the one host sync of the path), allocate the outputs, enqueue scatter + sort."""
+    lib, dev = load_library(), st["means2d"].device
+    if st["ev"] is not None:
+        st["ev"].synchronize()
+        n_isects, longest = (int(x) for x in st["host"].tolist())
+    else:
+        n_isects, longest = (int(x) for x in st["n_dev"].tolist())  # the one D2H sync of the path
+    sort = st["sort"]
     isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
     binned = torch.empty(n_isects, dtype=torch.int64, device=dev) if (sort and n_isects) else None   # two-pass scatter: the row-binned intermediate
     rc = lib.lfs_intersect_tile_emit_ex(
-        C.c_uint32(C_), C.c_uint32(N), ptr(means2d), ptr(radii), ptr(depths), C.c_uint32(tile_size), C.c_uint32(tile_width),
-        C.c_uint32(tile_height), C.c_int(int(bool(sort))), C.c_int64(n_isects), ptr(tiles_per_gauss), ptr(isect_ids), ptr(flatten_ids),
-        None, ptr(binned), C.c_int64(longest), ptr(ws), C.c_size_t(ws.numel()), stream())
+        C.c_uint32(st["C"]), C.c_uint32(st["N"]), ptr(st["means2d"]), ptr(st["radii"]), ptr(st["depths"]), C.c_uint32(st["tile_size"]), C.c_uint32(st["tw"]),
+        C.c_uint32(st["th"]), C.c_int(int(bool(sort))), C.c_int64(n_isects), ptr(st["tpg"]), ptr(isect_ids), ptr(flatten_ids),
+        None, ptr(binned), C.c_int64(longest), ptr(st["ws"]), C.c_size_t(st["ws"].numel()), stream())
     check(rc, "intersect_tile (emit)")
-    _ISECT_LAST[dev.index] = shape_key
-    out = (tiles_per_gauss, isect_ids, flatten_ids) + ((offsets,) if return_offsets else ())
-    return out + (extra,) if overlap is not None else out
+    _ISECT_LAST[st["last_key"]] = st["shape_key"]
+    return (st["tpg"], isect_ids, flatten_ids) + ((st["offsets"],) if st["return_offsets"] else ())
 
 
 _PINNED = {}
-_ISECT_LAST = {}   # device index -> (workspace pointer, C, N, tile_w, tile_h) of the last completed intersect_tile
+_ISECT_LAST = {}   # (device index, workspace tag) -> (workspace pointer, C, N, tile_w, tile_h) of the last completed intersect_tile
 
 
-def _pinned_i64() -> Tensor:
-    t = _PINNED.get("i64")
+def _pinned_i64(slot: int = 0) -> Tensor:
+    t = _PINNED.get(("i64", slot))
     if t is None:
         t = torch.zeros(2, dtype=torch.int64).pin_memory()
-        _PINNED["i64"] = t
+        _PINNED[("i64", slot)] = t
     return t
 
 
@@ -266,6 +286,14 @@ def rasterize_to_pixels_from_world_3dgs_fwd(
     return renders, alphas, last_ids
 
 
+def _out_like(out: Optional[Tensor], like: Tensor) -> Tensor:
+    if out is None:
+        return torch.empty_like(like)
+    if tuple(out.shape) != tuple(like.shape) or out.dtype != like.dtype or not out.is_contiguous() or out.device != like.device:
+        raise LfsError("output buffer: shape / dtype / contiguity mismatch")
+    return out
+
+
 def rasterize_to_pixels_from_world_3dgs_bwd(
         means: Tensor, quats: Tensor, scales: Tensor, colors: Tensor, opacities: Tensor,
         backgrounds: Optional[Tensor], masks: Optional[Tensor],
@@ -274,8 +302,10 @@ def rasterize_to_pixels_from_world_3dgs_bwd(
         ut_params: Optional[UnscentedTransformParameters], rs_type: ShutterType,
         radial_coeffs: Optional[Tensor], tangential_coeffs: Optional[Tensor], thin_prism_coeffs: Optional[Tensor],
         tile_offsets: Tensor, flatten_ids: Tensor, render_alphas: Tensor, last_ids: Tensor,
-        v_render_colors: Tensor, v_render_alphas: Tensor, prepared_workspace: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
-    """-> (v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,ch], v_opacities [C,N])."""
+        v_render_colors: Tensor, v_render_alphas: Tensor, prepared_workspace: Optional[Tensor] = None,
+        v_colors_out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """-> (v_means [N,3], v_quats [N,4], v_scales [N,3], v_colors [C,N,ch], v_opacities [C,N]). v_colors_out (extension): a contiguous tensor of
+    v_colors' shape to write into (a slice of a caller's multi-view buffer) instead of a fresh one."""
     backgrounds, masks, viewmats1 = _opt(backgrounds), _opt(masks), _opt(viewmats1)
     radial_coeffs, tangential_coeffs, thin_prism_coeffs = _opt(radial_coeffs), _opt(tangential_coeffs), _opt(thin_prism_coeffs)
     require_gpu(means, quats, scales, colors, opacities, backgrounds, masks, viewmats0, viewmats1, Ks,
@@ -284,7 +314,7 @@ def rasterize_to_pixels_from_world_3dgs_bwd(
     Cn, N, channels = tile_offsets.shape[0], means.shape[0], colors.shape[-1]
     dev = means.device
     v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
-    v_colors, v_opacities = torch.empty_like(colors), torch.empty_like(opacities)
+    v_colors, v_opacities = _out_like(v_colors_out, colors), torch.empty_like(opacities)
     cams = cameras_struct(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type,
                           radial_coeffs, tangential_coeffs, thin_prism_coeffs)
     ut = ut_struct(ut_params)
@@ -307,7 +337,7 @@ def rasterize_to_pixels_from_world_3dgs_bwd(
 def rasterize_bwd_prepared_mse(means: Tensor, quats: Tensor, scales: Tensor, colors: Tensor, opacities: Tensor, backgrounds: Optional[Tensor],
                                image_width: int, image_height: int, tile_size: int, viewmats0: Tensor, Ks: Tensor, camera_model: CameraModelType,
                                rs_type: ShutterType, tile_offsets: Tensor, flatten_ids: Tensor, render_colors: Tensor, render_alphas: Tensor, last_ids: Tensor,
-                               target_chw: Tensor, weight: float, loss_acc: Tensor, prepared_workspace: Tensor):
+                               target_chw: Tensor, weight: float, loss_acc: Tensor, prepared_workspace: Tensor, v_colors_out: Optional[Tensor] = None):
     """Extension: the prepared backward with the clamped MSE loss folded in (lfs_..._bwd_prepared_mse): loss_acc += weight * mse(clamp(render), target),
     dL/d(render) stays in registers. -> (v_means, v_quats, v_scales, v_colors [1,N,3], v_opacities [1,N])."""
     backgrounds = _opt(backgrounds)
@@ -316,7 +346,7 @@ def rasterize_bwd_prepared_mse(means: Tensor, quats: Tensor, scales: Tensor, col
     N = means.shape[0]
     assert colors.shape[-1] == 3 and tile_offsets.shape[0] == 1 and tuple(target_chw.shape) == (3, image_height, image_width)
     v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
-    v_colors, v_opacities = torch.empty_like(colors), torch.empty_like(opacities)
+    v_colors, v_opacities = _out_like(v_colors_out, colors), torch.empty_like(opacities)
     cams = cameras_struct(viewmats0, None, Ks, image_width, image_height, camera_model, rs_type, None, None, None)
     rc = load_library().lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse(
         C.c_uint32(N), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opacities), ptr(backgrounds), C.byref(cams), C.c_uint32(tile_size),
