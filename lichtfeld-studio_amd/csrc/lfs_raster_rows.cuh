@@ -1,8 +1,9 @@
-// "Row" kernels of the world-space rasterizer - EXPERIMENT, opt-in (lfs_set_debug_flags bit 2), NOT YET RUN ON A GPU: written after the
-// round's GPU budget was spent. They compile for gfx950 and their logic is verified on the CPU under the wavefront emulator
-// (tests/test_emulated_raster.py: forward bit-identical to the default kernels, backward to summation order, 7 scene variants); what is
-// left for the first GPU minutes of the next round is the ISA level (DPP encodings / hazards / the inline asm) and the timing:
-// LFS_EXPERIMENTAL_ROWS=1 python -m pytest tests/test_gpu_raster_rows.py ; python bench.py --row-kernels
+// "Row" kernels of the world-space rasterizer - a MEASURED NEGATIVE RESULT, opt-in (lfs_set_debug_flags bit 2; bench.py --row-kernels). Written at
+// the end of round 1 and verified there on the CPU under the wavefront emulator (tests/test_emulated_raster.py); round 2 ran them on the GPU
+// (tests/test_gpu_raster_rows.py: forward bit-identical to the default kernels, backward 1e-7 - after the DPP-hazard fix described at row_mat3
+// below) and measured them SLOWER than the default 8x8-cell kernels: raster_fwd 0.258 -> 0.370 ms, raster_bwd 0.670 -> 0.757 ms, list building
+// 0.068 -> 0.143 - 0.201 ms (profiles/r02/raster_rows_vs_default_pmc.txt, DESIGN.md section 6b: 1.46x fewer wave-evaluations as predicted, but 63
+// VALU instructions each against 37 - the record fields arrive through DPP broadcasts instead of free SGPR operands). They stay in the tree, tested.
 //
 // Why: after the conic culling a SYN-B Gaussian is evaluated on 8.4 cells x 64 lanes but can composite only ~235 of those 537 pixels; with
 // wave-uniform records a wavefront cannot skip the quadrants of its 8x8 cell that the Gaussian misses. Here every 16-lane DPP row owns a 4x4
@@ -227,7 +228,8 @@ __global__ void __launch_bounds__(256) raster_quad_lists_kernel(
 
 // Variant (lfs_set_debug_flags bit 3 on top of bit 2): the quadrant lists straight from the tile list in ONE kernel - raster_cull_kernel's
 // batching (the workgroup gathers 64 x waves entries and their culling records once and shares them through LDS), four quadrant tests per
-// entry instead of one cell test, no cell lists and no second gather. Which of the two is cheaper is a measurement for the next round.
+// entry instead of one cell test, no cell lists and no second gather. Measured (round 2): 0.143 ms against 0.201 ms for the split form, both slower than
+// the 0.068 ms of the plain cell lists.
 template <bool UNIFORM_ORIGIN>
 __global__ void __launch_bounds__(256) raster_cull_quads_kernel(
     const uint32_t C, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
