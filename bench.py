@@ -61,6 +61,8 @@ def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems
         "adam": 28 * adam_elems,
         # all-inline step: accumulator row (64) + means, raw and activated quats / scales / opacity (76) + 11 floats of each Adam moment (88) in, 3 x 44 out
         "finish_adam": (64 + 76 + 88 + 132) * N,
+        # steps that need gradient tensors: accumulator row (64) + means, raw / activated quaternions, scales, opacity (60) in, five gradient tensors out (56)
+        "finish_grads": (64 + 60 + 56) * N,
         # fastgs (EWA) path, SURVEY.md §8f row 1 - same accounting as the 3DGUT kernels: 64-B blend record + 4-B id per intersection, per-pixel
         # state, the 64-B accumulator rows; preprocess reads the 44 B of raw geometry and writes record (64) + mean2d / conic / bounds (32)
         "fastgs_preprocess": 44 * N + 96 * V + 8 * N,

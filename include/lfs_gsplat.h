@@ -412,6 +412,19 @@ LFS_API int lfs_sh_model_bwd_adam_all(
     const int32_t* radii, const float* colors, const float* acc_rows, float* v_dirs /* [n,3], written */,
     float* sh0_exp_avg, float* sh0_exp_avg_sq, const float* sh0_scalars /* host: lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp */,
     float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, lfs_stream_t stream);
+/* For steps that need the gradient tensors (multi-GPU all-reduce, several views per step, any loss): lfs_..._bwd_prepared_acc = lfs_..._bwd_prepared without
+ * its last kernel (3 channels, one camera, no masks), then lfs_gut_finish_grads turns the accumulator rows into dL/d(means [rasterizer part], raw_scales,
+ * raw_quats, raw_opacities) - written, or added to when accumulate != 0 - and dL/dcolour [N,3] in ONE pass (raster_finish + lfs_activations_bwd + the copy of
+ * dL/dmeans; the regularisers as in lfs_activations_bwd); loss (nullable): += the fused MSE of lfs_..._bwd_prepared_mse_acc. */
+LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_acc(
+    uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
+    const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+    int64_t n_isects, const float* render_alphas, const int32_t* last_ids, const float* v_render_colors, const float* v_render_alphas,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+LFS_API int lfs_gut_finish_grads(
+    uint32_t N, const float* means, const float* raw_quats, const float* quats, const float* scales, const float* opacities, float scale_reg, float opacity_reg,
+    int accumulate, float* g_means, float* g_raw_scales, float* g_raw_quats, float* g_raw_opacities, float* v_colors, float* loss,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 LFS_API int lfs_gut_finish_adam(
     uint32_t N, float* means, float* raw_scales, float* raw_quats, float* raw_opacities, const float* quats, const float* scales, const float* opacities,
     const float* v_dirs /* [N,3] from lfs_sh_model_bwd_adam_all */, float* const* exp_avg /* [4] host: means, raw_scales, raw_quats, raw_opacities */,

@@ -980,11 +980,16 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
 // dL/dcolour (3: consumed by lfs_sh_model_bwd_adam_all, which hands back dL/d(dirs) in v_dirs). Same operations in the same order as
 // the three separate kernels (the activation and Adam arithmetic is un-fused there: pinned with fp contract(off) here).
 struct FinishAdam { float* m[4]; float* v[4]; AdamScalars s[4]; float scale_reg, opacity_reg; }; // order: means, raw_scales, raw_quats, raw_opacities
+// ADAM = false (multi-GPU / multi-view / non-MSE steps, which need gradient TENSORS): the same pass up to the raw-parameter gradients, written (or added,
+// `accumulate`) to g_* instead of being consumed - raster_finish_kernel + activations_bwd_kernel + the copy of dL/dmeans in one launch; dL/dcolour goes
+// to v_colors for the SH backward, which adds dL/d(dirs) onto g_means afterwards. *loss += the fused MSE (as raster_finish_kernel).
+struct FinishGrads { float* g_means; float* g_scales; float* g_quats; float* g_opac; float* v_colors; int accumulate; };
+template <bool ADAM>
 __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
     const uint32_t N, float* __restrict__ means, float* __restrict__ raw_scales, float* __restrict__ raw_quats, float* __restrict__ raw_opacities,
     const float* __restrict__ quats, const float* __restrict__ scales, const float* __restrict__ opacities,
-    const CamDev* __restrict__ cams, const float* __restrict__ acc, const float* __restrict__ v_dirs, const FinishAdam ad, const float* __restrict__ loss_slots,
-    float* __restrict__ loss) {
+    const CamDev* __restrict__ cams, const float* __restrict__ acc, const float* __restrict__ v_dirs, const FinishAdam ad, const FinishGrads gr,
+    const float* __restrict__ loss_slots, float* __restrict__ loss) {
     if (loss_slots != nullptr && blockIdx.x == 0) { // *loss = the fused MSE (a store in a fixed order: the step needs no zeroed accumulator)
         __shared__ float wave_sum[4];
         float v = threadIdx.x < LOSS_SLOTS ? loss_slots[threadIdx.x] : 0.f;
@@ -992,7 +997,10 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
         if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = v;
         __syncthreads();
-        if (threadIdx.x == 0) *loss = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+        if (threadIdx.x == 0) {
+            const float total = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+            if (ADAM) *loss = total; else if (total != 0.f) unsafeAtomicAdd(loss, total);
+        }
     }
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= N) return;
@@ -1008,9 +1016,10 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
     // (lfs_math.cuh ld3 / st3: three floats as one 12-byte access)
     auto ld3a = [&](const float* base, float (&dst)[3]) { const f3 t = ld3(base, gid); dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; };
     auto st3a = [&](float* base, const float (&src)[3]) { st3(base, gid, f3{src[0], src[1], src[2]}); };
-    float sc[3], vd[3];
+    float sc[3], vd[3] = {0.f, 0.f, 0.f};
     const f3 mu = ld3(means, gid);
-    ld3a(scales, sc); ld3a(v_dirs, vd);
+    ld3a(scales, sc);
+    if (ADAM) ld3a(v_dirs, vd);
     if (any) { // exactly raster_finish_kernel<true> for C == 1
         const float4 q = reinterpret_cast<const float4*>(quats)[gid];
         const m3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
@@ -1067,6 +1076,27 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
         for (int k = 0; k < 3; ++k) gs[k] = (vs[k] + ad.scale_reg) * sc[k];
         const float o = opacities[gid];
         const float go = (v_opac + ad.opacity_reg) * o * (1.f - o);
+        if (!ADAM) { // gradient tensors out (activations_bwd_kernel's stores; dL/dmeans = the rasterizer's part, the SH backward adds the rest)
+            const float v_col[3] = {a3.y, a3.z, a3.w};
+            st3a(gr.v_colors, v_col);
+            float4* gqo = reinterpret_cast<float4*>(gr.g_quats) + gid;
+            if (gr.accumulate) {
+                float om[3], os[3];
+                ld3a(gr.g_means, om); ld3a(gr.g_scales, os);
+                const float4 oq = *gqo;
+#pragma unroll
+                for (int k2 = 0; k2 < 3; ++k2) { gm[k2] = om[k2] + gm[k2]; gs[k2] = os[k2] + gs[k2]; }
+                gq[0] = oq.x + gq[0]; gq[1] = oq.y + gq[1]; gq[2] = oq.z + gq[2]; gq[3] = oq.w + gq[3];
+                st3a(gr.g_means, gm); st3a(gr.g_scales, gs);
+                *gqo = make_float4(gq[0], gq[1], gq[2], gq[3]);
+                gr.g_opac[gid] += go;
+            } else {
+                st3a(gr.g_means, gm); st3a(gr.g_scales, gs);
+                *gqo = make_float4(gq[0], gq[1], gq[2], gq[3]);
+                gr.g_opac[gid] = go;
+            }
+            return;
+        }
         // Adam (adam_multi_kernel's per-element update). Every moment is loaded before the first store (the moment arrays hang off a struct: no
         // __restrict__, a load could not move above an earlier store) and three-float rows move as 12-byte accesses (lfs_math.cuh). Measured on
         // one box against the element-by-element version: no difference (0.094 - 0.104 ms either way; the kernel walks 29 streams)
@@ -1313,7 +1343,7 @@ static int raster_bwd_impl(
     if (N == 0) return LFS_OK;
     if (!means || !quats || !scales || !colors || !opacities) return LFS_E_INVALID;
     if (finish && (!v_means || !v_quats || !v_scales || !v_colors || !v_opacities)) return LFS_E_INVALID;
-    if (!finish && (channels != 3 || C != 1 || !mse)) return LFS_E_INVALID; // the accumulator-only form feeds lfs_sh_model_bwd_adam_all + lfs_gut_finish_adam
+    if (!finish && (channels != 3 || C != 1)) return LFS_E_INVALID; // the accumulator-only forms feed lfs_gut_finish_adam / lfs_gut_finish_grads (one camera, RGB)
     if (n_isects > 0 && (!flatten_ids || !render_alphas || !last_ids || (!v_render_colors && !mse))) return LFS_E_INVALID; // v_render_alphas == NULL: zeros
     hipStream_t s = (hipStream_t)stream;
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
@@ -1440,6 +1470,40 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc(
                            render_alphas, last_ids, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream, true, &mse, false);
 }
 
+// the same for a caller-provided dL/d(render) (any loss): lfs_..._bwd_prepared without its last kernel
+extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_acc(
+    uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
+    const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+    int64_t n_isects, const float* render_alphas, const int32_t* last_ids, const float* v_render_colors, const float* v_render_alphas,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    if (!cams || !v_render_colors) return LFS_E_INVALID;
+    return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, n_isects,
+                           render_alphas, last_ids, v_render_colors, v_render_alphas, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream,
+                           true, nullptr, false);
+}
+
+// The accumulator rows -> gradient TENSORS of the raw parameters in one pass (raster_finish + lfs_activations_bwd + the copy of dL/dmeans): for steps
+// that need the gradients themselves (multi-GPU all-reduce, several views per step, non-MSE losses). g_* are written or, accumulate != 0, added to;
+// v_colors [N,3] is written (the SH backward consumes it and adds dL/d(dirs) onto g_means). loss (nullable): += the fused MSE partial sums.
+extern "C" int lfs_gut_finish_grads(
+    uint32_t N, const float* means, const float* raw_quats, const float* quats, const float* scales, const float* opacities, float scale_reg, float opacity_reg,
+    int accumulate, float* g_means, float* g_raw_scales, float* g_raw_quats, float* g_raw_opacities, float* v_colors, float* loss,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    if (N == 0) return LFS_OK;
+    if (!means || !raw_quats || !quats || !scales || !opacities || !g_means || !g_raw_scales || !g_raw_quats || !g_raw_opacities || !v_colors || !workspace) return LFS_E_INVALID;
+    const RasterWs w = raster_ws(workspace, 1, N, 0, 0, false);
+    if (workspace_bytes < size_t(reinterpret_cast<const char*>(w.cull) - static_cast<const char*>(workspace))) return LFS_E_WORKSPACE;
+    FinishAdam ad{};
+    // regularisers of trainer.cpp:132-158 (as lfs_activations_bwd): scale_reg * mean(scales) over 3N values, opacity_reg * mean(opacities)
+    ad.scale_reg = scale_reg / (3.f * float(N)); ad.opacity_reg = opacity_reg / float(N);
+    const FinishGrads gr{g_means, g_raw_scales, g_raw_quats, g_raw_opacities, v_colors, accumulate};
+    hipStream_t s = (hipStream_t)stream;
+    lfs::ProfScope prof("finish_grads", s);
+    hipLaunchKernelGGL(raster_finish_adam_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, s, N, const_cast<float*>(means), (float*)nullptr, const_cast<float*>(raw_quats),
+                       (float*)nullptr, quats, scales, opacities, w.cams, w.acc, (const float*)nullptr, ad, gr, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss);
+    return (int)hipGetLastError();
+}
+
 // scalars[k] = {lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp} for k = means, raw_scales, raw_quats, raw_opacities; *loss = the fused MSE of the backward (stored, not added)
 extern "C" int lfs_gut_finish_adam(
     uint32_t N, float* means, float* raw_scales, float* raw_quats, float* raw_opacities, const float* quats, const float* scales, const float* opacities,
@@ -1456,10 +1520,11 @@ extern "C" int lfs_gut_finish_adam(
         ad.m[k] = exp_avg[k]; ad.v[k] = exp_avg_sq[k];
         ad.s[k] = AdamScalars{scalars[6 * k], scalars[6 * k + 1], scalars[6 * k + 2], scalars[6 * k + 3], scalars[6 * k + 4], scalars[6 * k + 5]};
     }
-    ad.scale_reg = scale_reg; ad.opacity_reg = opacity_reg;
+    // regularisers of trainer.cpp:132-158 (as lfs_activations_bwd): scale_reg * mean(scales) over 3N values, opacity_reg * mean(opacities)
+    ad.scale_reg = scale_reg / (3.f * float(N)); ad.opacity_reg = opacity_reg / float(N);
     hipStream_t s = (hipStream_t)stream;
     lfs::ProfScope prof("finish_adam", s);
-    hipLaunchKernelGGL(raster_finish_adam_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, means, raw_scales, raw_quats, raw_opacities, quats, scales, opacities,
-                       w.cams, w.acc, v_dirs, ad, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss);
+    hipLaunchKernelGGL(raster_finish_adam_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, s, N, means, raw_scales, raw_quats, raw_opacities, quats, scales, opacities,
+                       w.cams, w.acc, v_dirs, ad, FinishGrads{}, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss);
     return (int)hipGetLastError();
 }

@@ -181,6 +181,38 @@ def backward_adam_all(sh_degree: int, means, raw_quats, raw_scales, raw_opac, sh
                                   C.c_float(scale_reg), C.c_float(opacity_reg), ptr(loss_acc), ptr(ws), C.c_size_t(ws.numel()), stream()), "gut_finish_adam")
 
 
+def backward_grads(means, raw_quats, quats, scales, opac, colors, bg, W: int, H: int, tile: int, viewmat, Kmat, offsets, flatten_ids, render, alpha, last_ids,
+                   ws, g_means, g_scales, g_quats, g_opac, accumulate: bool, scale_reg: float, opacity_reg: float, *, target_chw=None, weight: float = 0.0,
+                   loss_acc=None, v_render=None, v_colors_out=None):
+    """Rasterizer backward -> gradient tensors of the raw parameters in two launches (the backward kernel, then lfs_gut_finish_grads = raster_finish +
+    activations_bwd + the copy of dL/dmeans in one pass). With target_chw the clamped MSE is folded into the backward (loss_acc += it), otherwise
+    v_render [1,H,W,3] is the caller's dL/d(render). g_means receives the rasterizer's part of dL/dmeans (the SH backward adds dL/d(dirs) onto it);
+    returns dL/dcolour [1,N,3]."""
+    from .capi import cameras_struct
+    lib = load_library()
+    N = means.shape[0]
+    cams = cameras_struct(viewmat, None, Kmat, W, H, CameraModelType.PINHOLE, ShutterType.GLOBAL, None, None, None)
+    if target_chw is not None:
+        check(lib.lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc(
+            C.c_uint32(N), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opac), ptr(bg), C.byref(cams), C.c_uint32(tile), ptr(offsets), ptr(flatten_ids),
+            C.c_int64(flatten_ids.shape[0]), ptr(render), ptr(alpha), ptr(last_ids), ptr(target_chw), C.c_float(weight), ptr(ws), C.c_size_t(ws.numel()), stream()),
+            "rasterize_bwd_prepared_mse_acc")
+    else:
+        v_render = v_render.contiguous()
+        require_gpu(v_render)
+        check(lib.lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_acc(
+            C.c_uint32(N), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opac), ptr(bg), C.byref(cams), C.c_uint32(tile), ptr(offsets), ptr(flatten_ids),
+            C.c_int64(flatten_ids.shape[0]), ptr(alpha), ptr(last_ids), ptr(v_render), None, ptr(ws), C.c_size_t(ws.numel()), stream()),
+            "rasterize_bwd_prepared_acc")
+    v_colors = v_colors_out if v_colors_out is not None else torch.empty((1, N, 3), dtype=means.dtype, device=means.device)
+    assert tuple(v_colors.shape) == (1, N, 3) and v_colors.is_contiguous()
+    require_gpu(g_means, g_scales, g_quats, g_opac, raw_quats)
+    check(lib.lfs_gut_finish_grads(C.c_uint32(N), ptr(means), ptr(raw_quats), ptr(quats), ptr(scales), ptr(opac), C.c_float(scale_reg), C.c_float(opacity_reg),
+                                   C.c_int(int(accumulate)), ptr(g_means), ptr(g_scales), ptr(g_quats), ptr(g_opac), ptr(v_colors),
+                                   ptr(loss_acc) if target_chw is not None else None, ptr(ws), C.c_size_t(ws.numel()), stream()), "gut_finish_grads")
+    return v_colors
+
+
 def sh_model_fwd_views(sh_degree: int, means, viewmats, sh0, shN, radii_views):
     """Owner side of dist.ShExchange: means / sh0 / shN = the owner's n rows; viewmats [V,4,4]; radii_views [V,S,2] (first n rows of each view
     used) -> colours [V,S,3] (rows >= n zero)."""
@@ -222,6 +254,7 @@ def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
 
 FUSE_MSE_INTO_BACKWARD = True   # False: separate lfs_mse_loss_fwd_bwd launch (tests compare the two)
 OVERLAP_SH_EXCHANGE = True       # SH-sharded: the radii / colour all-to-alls run next to the intersection kernels (False: blocking, A/B and debugging)
+FUSE_FINISH_GRADS = True         # accumulator rows -> raw-parameter gradient tensors in one pass (False: raster_finish + activations_bwd + copy; tests compare)
 BEGIN_ALL_INTERSECTIONS = True   # multi-view steps: the count kernels of all views up front, one host wait per step (False: one per view)
 OVERLAP_SH_WITH_READBACK = True  # False: SH colours first, then the blocking n_isects read-back (A/B timing)
 
@@ -342,31 +375,42 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
             backward_adam_all(deg, means, raw_quats, raw_scales, raw_opac, sh0, shN, quats, scales, opac, colors, radii, bg, W, H, tile, viewmat, Kmat, offsets,
                               flatten_ids, render, alpha, last_ids, target_chw, weight, loss_acc, ws, adam_all, scale_reg, opacity_reg)
             return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]))
-        if fuse_mse:
-            v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_bwd_prepared_mse(
-                means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, W, H, tile, viewmat, Kmat, CameraModelType.PINHOLE, ShutterType.GLOBAL,
-                offsets, flatten_ids, render, alpha, last_ids, target_chw, weight, loss_acc, ws, v_colors_out=v_colors_out)
+        fused_finish = FUSE_FINISH_GRADS and flatten_ids.shape[0] > 0 and all(g.is_contiguous() for g in (g_means, g_scales, g_quats, g_opac))
+        if fused_finish:   # backward kernel + ONE pass from the accumulator rows to the raw-parameter gradients (g_means: the rasterizer's part so far)
+            v_colors = backward_grads(means, raw_quats, quats, scales, opac, colors.unsqueeze(0), bg, W, H, tile, viewmat, Kmat, offsets, flatten_ids, render, alpha,
+                                      last_ids, ws, g_means, g_scales, g_quats, g_opac, accumulate, scale_reg, opacity_reg,
+                                      target_chw=target_chw if fuse_mse else None, weight=weight, loss_acc=loss_acc, v_render=None if fuse_mse else v_render,
+                                      v_colors_out=v_colors_out)
+            sh_means = g_means          # the SH backward adds dL/d(dirs) straight onto the caller's dL/dmeans
         else:
-            v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
-                *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws, v_colors_out=v_colors_out)
-        # the regularisers of trainer.cpp:132-158 are per step, not per view: the caller passes them with the first view only
-        activations_bwd(raw_quats, scales, opac, v_quats, v_scales, v_opac.squeeze(0), g_quats, g_scales, g_opac, accumulate, scale_reg, opacity_reg)
+            if fuse_mse:
+                v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_bwd_prepared_mse(
+                    means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, W, H, tile, viewmat, Kmat, CameraModelType.PINHOLE, ShutterType.GLOBAL,
+                    offsets, flatten_ids, render, alpha, last_ids, target_chw, weight, loss_acc, ws, v_colors_out=v_colors_out)
+            else:
+                v_means, v_quats, v_scales, v_colors, v_opac = ops.rasterize_to_pixels_from_world_3dgs_bwd(
+                    *fwd_args, alpha, last_ids, v_render, None, prepared_workspace=ws, v_colors_out=v_colors_out)
+            # the regularisers of trainer.cpp:132-158 are per step, not per view: the caller passes them with the first view only
+            activations_bwd(raw_quats, scales, opac, v_quats, v_scales, v_opac.squeeze(0), g_quats, g_scales, g_opac, accumulate, scale_reg, opacity_reg)
+            sh_means = v_means
         if on_geometry_grads is not None:
             on_geometry_grads()
-        # SH backward adds dL/d(dirs) onto the rasterizer's dL/d(means) in place, then the means gradient lands in the caller's buffer
         if defer_sh_backward:
             assert sh_exchange is None and adam_shN is None
-            (g_means.add_ if accumulate else g_means.copy_)(v_means)
+            if not fused_finish:
+                (g_means.add_ if accumulate else g_means.copy_)(v_means)
             return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]), v_colors.squeeze(0))
+        # SH backward adds dL/d(dirs) onto the rasterizer's dL/d(means) in place, then the means gradient lands in the caller's buffer
         if adam_shN is not None:     # single view, single rank: shN's gradient is consumed by its Adam update inside the SH backward
             assert sh_exchange is None and not accumulate
-            sh_model_bwd_adam(deg, means, viewmat, sh0, shN, radii, colors, v_colors.squeeze(0), g_sh0, v_means, adam_shN)
+            sh_model_bwd_adam(deg, means, viewmat, sh0, shN, radii, colors, v_colors.squeeze(0), g_sh0, sh_means, adam_shN)
         elif sh_exchange is None:
-            sh_model_bwd(deg, means, viewmat, sh0, shN, radii, colors, v_colors.squeeze(0), g_sh0, g_shN, v_means, accumulate)
-        if accumulate:
-            g_means.add_(v_means)
-        else:
-            g_means.copy_(v_means)
+            sh_model_bwd(deg, means, viewmat, sh0, shN, radii, colors, v_colors.squeeze(0), g_sh0, g_shN, sh_means, accumulate)
+        if not fused_finish:
+            if accumulate:
+                g_means.add_(v_means)
+            else:
+                g_means.copy_(v_means)
         if sh_exchange is not None:  # owners: SH backward of every rank's view for their rows (dL/d(dirs) straight into g_means)
             sh_exchange.backward(sh_ctx, deg, means, sh0, shN, viewmats_all, v_colors.squeeze(0), g_sh0, g_shN, g_means, accumulate, sh_model_bwd_views,
                                  adam=adam_shard)

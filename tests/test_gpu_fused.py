@@ -344,3 +344,43 @@ def test_batched_views_step_matches_the_view_by_view_step(lfs):
         assert sa["step_count"] == sb["step_count"], name
         assert float((pa - pb).abs().max()) <= 2e-5 * float(pb.abs().max()), (name, float((pa - pb).abs().max()))
         assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) <= 1e-4 * float(sb["exp_avg"].abs().max()) + 1e-12, name
+
+
+def test_fused_finish_grads_matches_finish_plus_activation_backward(lfs):
+    """lfs_gut_finish_grads (accumulator rows -> raw-parameter gradient tensors in one pass) against raster_finish + lfs_activations_bwd + the copy of
+    dL/dmeans, through fused.render_and_backward with both losses, regularisers, and a second accumulating view. Deterministic rasterizer sums, so the
+    first view has to agree bit for bit; the accumulated one up to the order in which dL/d(dirs) joins dL/dmeans."""
+    import convergence_check as cc
+    from lichtfeld_studio_amd import fused
+    from lichtfeld_studio_amd.rasterizer import SplatModel
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    _, sc = cc.make_task(n=5000, size=128, n_views=3, sh_degree=2)
+    tr = GutTrainer(sc, DEV, iterations=100)
+    g = torch.Generator().manual_seed(9)
+    targets = [(torch.rand(3, sc.height, sc.width, generator=g) * 0.8).to(DEV) for _ in range(2)]
+    lib = lfs.load_library()
+    res = {}
+    try:
+        lib.lfs_set_debug_flags(16)
+        for loss in ("mse", "l1_ssim"):
+            for flag in (True, False):
+                fused.FUSE_FINISH_GRADS = flag
+                grads = [torch.zeros_like(p) for p in tr.model.parameters()]
+                acc = torch.zeros(1, device=DEV)
+                snaps = []
+                for k in range(2):
+                    fused.render_and_backward(tr.camera(k), tr.model, tr.bg, targets[k], 0.5, grads, acc, accumulate=k > 0, loss=loss,
+                                              scale_reg=0.01 if k == 0 else 0.0, opacity_reg=0.02 if k == 0 else 0.0)
+                    snaps.append([x.clone() for x in grads])
+                torch.cuda.synchronize()
+                res[(loss, flag)] = (snaps, float(acc))
+    finally:
+        fused.FUSE_FINISH_GRADS = True
+        lib.lfs_set_debug_flags(0)
+    for loss in ("mse", "l1_ssim"):
+        (a, la), (b, lb) = res[(loss, True)], res[(loss, False)]
+        assert abs(la - lb) <= 1e-6 * abs(lb) and la > 0   # (the 256 partial sums of the loss are folded in a different order: one ulp)
+        for name, x, y in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], a[0], b[0]):
+            assert torch.equal(x, y), (loss, name, float((x - y).abs().max()))
+        for name, x, y in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], a[1], b[1]):
+            assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max()) + 1e-12, (loss, name, float((x - y).abs().max()))
