@@ -385,8 +385,19 @@ def main() -> None:
                         "per_step": {k: {"calls": v["calls"] / args.steps, "MB": round(v["bytes"] / args.steps / 1e6, 3), "ms": round(v["ms"] / args.steps, 4)} for k, v in coll.items()}},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
     }
+    # C-level stdout first (RCCL prints its version banner through stdio; on a pipe that buffer would otherwise be flushed at exit, after our line):
+    # the JSON line is the last thing rank 0 prints
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
