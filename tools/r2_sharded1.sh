@@ -4,7 +4,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}; cd $REPO; export LFS_DIST_FORCE_COLLECTIVES=1 R
 for f in "" "--replicated"; do
 python bench.py --gpus 1 $([ -z "$f" ] && echo --sh-sharded) $f --steps 200 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$f]', d['value'], d['ms_per_step'], d['config']['parallelism'], d['collectives']['per_step']); print({k: (v['avg_ms'], v['launches_per_step']) for k, v in d['kernels'].items()}, sum(v['avg_ms'] * v['launches_per_step'] for v in d['kernels'].values()))"
+d = json.loads([l for l in sys.stdin.read().splitlines() if l[:1] == chr(123)][-1]); print('[$f]', d['value'], d['ms_per_step'], d['config']['parallelism'], d['collectives']['per_step']); print({k: (v['avg_ms'], v['launches_per_step']) for k, v in d['kernels'].items()}, sum(v['avg_ms'] * v['launches_per_step'] for v in d['kernels'].values()))"
 done
 cd /tmp && export TMPDIR=/tmp && mkdir -p $REPO/gpurun_out/sharded1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/sharded1/trace -o trace -- python $REPO/bench.py --gpus 1 --sh-sharded --steps 6 --warmup 4 --no-cpu-baseline --no-profile > $REPO/gpurun_out/sharded1/bench.log 2>&1
