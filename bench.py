@@ -167,6 +167,7 @@ def main() -> None:
     ap.add_argument("--bilateral-grid", action="store_true", help="BASELINE.json configs[4]: per-image 16x16x8 bilateral grid between render and loss (+ its TV loss and Adam)")
     ap.add_argument("--replicated", action="store_true", help="multi-GPU: keep shN replicated (59 floats / Gaussian all-reduced) instead of SH-sharded")
     ap.add_argument("--sh-sharded", action="store_true", help="force the SH-sharded layout (the default for more than one rank) - with LFS_DIST_FORCE_COLLECTIVES=1 this runs its collectives on ONE GPU")
+    ap.add_argument("--side-stream", action="store_true", help="developer A/B: SH colours on a second stream next to the intersection kernels (measured: no gain)")
     ap.add_argument("--no-overlap-exchange", action="store_true", help="developer A/B: blocking all-to-alls in the SH-sharded forward")
     ap.add_argument("--wide-cells", action="store_true", help="developer A/B: the experimental two-pixels-per-lane 16x8-cell rasterizer kernels (slower on SYN-B; see raster.hip)")
     ap.add_argument("--row-lists", default="split", choices=["split", "merged"], help="with --row-kernels: quadrant lists split from the cell lists (two kernels) or built in one pass")
@@ -227,6 +228,7 @@ def main() -> None:
     from lichtfeld_studio_amd import fused as _fused
     _fused.FUSE_SH_PACK, _fused.FUSE_ACT_PROJ = bool(args.fuse_sh_pack), not args.no_fuse_act_proj
     _fused.OVERLAP_SH_EXCHANGE = not args.no_overlap_exchange
+    _fused.SIDE_STREAM_SH = bool(args.side_stream)
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
     parallelism_fallback = None
     if world > 1 and trainer.sh_exchange is not None:

@@ -254,9 +254,22 @@ def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
 
 FUSE_MSE_INTO_BACKWARD = True   # False: separate lfs_mse_loss_fwd_bwd launch (tests compare the two)
 OVERLAP_SH_EXCHANGE = True       # SH-sharded: the radii / colour all-to-alls run next to the intersection kernels (False: blocking, A/B and debugging)
+SIDE_STREAM_SH = False           # True: SH colours on a second stream next to the intersection kernels. Measured (bench.py --side-stream, same box, 3 pairs):
+                                 # 1.680 - 1.707 ms against 1.690 - 1.694 ms on one stream - no gain, the two sets of kernels do not overlap usefully
 FUSE_FINISH_GRADS = True         # accumulator rows -> raw-parameter gradient tensors in one pass (False: raster_finish + activations_bwd + copy; tests compare)
 BEGIN_ALL_INTERSECTIONS = True   # multi-view steps: the count kernels of all views up front, one host wait per step (False: one per view)
 OVERLAP_SH_WITH_READBACK = True  # False: SH colours first, then the blocking n_isects read-back (A/B timing)
+
+
+_SIDE = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    st = _SIDE.get(device.index)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[device.index] = st
+    return st
 
 
 @dataclass
@@ -330,9 +343,23 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
             if sh_exchange is None:
                 return sh_model_fwd(deg, means, viewmat, sh0, shN, radii), None
             return sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd_views, radii_pending=radii_pending, defer=OVERLAP_SH_EXCHANGE)
+        side_done = None
         if isect_state is not None:
             (colors, sh_ctx) = sh_stage()
             _, _, flatten_ids, offsets = ops.intersect_tile_finish(isect_state)
+        elif SIDE_STREAM_SH and sh_exchange is None and given is None and means.is_cuda:
+            # the SH colours (HBM-bound) on a second stream, next to the intersection kernels (latency / LDS-bound) of this one: they need the
+            # projection's radii only, and nothing before the rasterizer's pack kernel needs them
+            side = _side_stream(means.device)
+            ready = torch.cuda.Event()
+            ready.record()
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                colors, sh_ctx = sh_stage()
+                side_done = torch.cuda.Event()
+                side_done.record()
+            _, _, flatten_ids, offsets = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True, overlap=lambda: None)[:4]
+            torch.cuda.current_stream().wait_event(side_done)
         elif OVERLAP_SH_WITH_READBACK:
             _, _, flatten_ids, offsets, (colors, sh_ctx) = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True,
                                                                                overlap=sh_stage)
