@@ -262,14 +262,18 @@ class GutTrainer:
                 every = self._views_all or [lfs_dist.views_for_step(self.iteration - 1, j, self.world, self.scene.viewmats.shape[0], len(views))
                                             for j in range(self.world)]
             # one view, one rank, Adam reading shN (iteration > 1000): the SH backward applies shN's Adam update itself (no shN gradient tensor)
+            # (with MCMC too, between refinements: post_backward then only adds noise to the means - mcmc.cpp:362-384 - and shN reaches optimizer.step() as the
+            # backward left it; on refining iterations relocation rewrites shN rows and moments first, so the update stays in the optimizer launch)
+            refining = self.strategy is not None and self.strategy.is_refining(self.iteration)   # parameters are replaced before the optimizer step
+            strat_ok = self.strategy is None or (self.strategy_kind == "mcmc" and not refining)
             inline = None
-            if (self.inline_shN_adam and self.world == 1 and self.sh_exchange is None and len(views) == 1 and self.strategy is None and self.iteration > 1000
+            if (self.inline_shN_adam and self.world == 1 and self.sh_exchange is None and len(views) == 1 and strat_ok and self.iteration > 1000
                     and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False)):
                 inline = self.optimizer.prepare_inline(self.model.shN)
             # ... and when the MSE is folded into the rasterizer backward as well, EVERY parameter is updated by the backward kernels (fused.backward_adam_all):
             # no gradient tensor, no separate activation-backward / optimizer launches
             inline_all = None
-            if inline is not None and self.inline_all_adam and self.loss_kind == "mse" and self.bilateral is None:
+            if inline is not None and self.inline_all_adam and self.strategy is None and self.loss_kind == "mse" and self.bilateral is None:
                 inline_all = {"shN": inline}
                 for name in ("means", "sh0", "raw_scales", "raw_quats", "raw_opacities"):
                     inline_all[name] = self.optimizer.prepare_inline(getattr(self.model, name))
@@ -277,7 +281,6 @@ class GutTrainer:
             if inline_all is None:
                 self.loss_acc.zero_()   # (the all-inline step stores the loss: no fill launch)
             inline_shard = None   # SH-sharded, one view per rank: the owners' multi-view SH backward applies the shard's Adam update
-            refining = self.strategy is not None and self.strategy.is_refining(self.iteration)   # parameters are replaced before the optimizer step:
             if (self.inline_shN_adam and self.sh_exchange is not None and len(views) == 1 and self.iteration > 1000 and self.sh_exchange.n   # no update then
                     and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False) and not refining):
                 inline_shard = self.optimizer.prepare_inline(self.model.shN)
@@ -286,7 +289,7 @@ class GutTrainer:
                 # moves into that one SH backward when the optimizer would read the gradient anyway
                 from .fused import render_views_and_backward
                 inline_v = None
-                if (self.inline_shN_adam and self.strategy is None and self.iteration > 1000 and self.model.shN.shape[1] > 0
+                if (self.inline_shN_adam and strat_ok and self.iteration > 1000 and self.model.shN.shape[1] > 0
                         and getattr(self.optimizer, "fused", False)):
                     inline_v = self.optimizer.prepare_inline(self.model.shN)
                 outs = render_views_and_backward([self.camera(v) for v in views], self.model, self.bg, [targets[k % len(targets)] for k in range(len(views))],

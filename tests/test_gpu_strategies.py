@@ -249,3 +249,34 @@ def test_mcmc_refinement_step_needs_no_host_sync(lfs):
         torch.cuda.set_sync_debug_mode("default")
     after = n(model.raw_opacities)
     assert (after[::17] > -9.0).all() and np.isfinite(after).all() and not np.array_equal(after, before)
+
+
+def test_mcmc_inline_shN_adam_between_refinements_is_bit_identical(lfs):
+    """With the MCMC strategy the SH backward applies shN's Adam update itself on the iterations between refinements (post_backward only adds noise to
+    the means there) and leaves it to the optimizer launch on refining iterations (relocation rewrites shN rows and moments first): parameters and
+    moments bit-identical to the path without the inline update, across a refinement, in the deterministic accumulation mode."""
+    import convergence_check as cc
+    from lichtfeld_studio_amd import strategies
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    gt, init = cc.make_task(n=3000, size=96, n_views=4, sh_degree=2)
+    targets = cc.render_views_hip(gt, DEV)
+    lib = lfs.load_library()
+    out = []
+    try:
+        lib.lfs_set_debug_flags(16)
+        for inline in (True, False):
+            op = strategies.OptimizationParameters(iterations=3000, start_refine=100, refine_every=5, stop_refine=2500, max_cap=3000)
+            tr = GutTrainer(init, DEV, iterations=3000, loss="l1_ssim", strategy="mcmc", opt_params=op, seed=5)
+            tr.inline_shN_adam = inline
+            tr.iteration = 1501
+            tr.model.raw_opacities.data[::13] = -9.0          # something to relocate at the refining iterations (1505, 1510)
+            for it in range(11):
+                tr.train_step([targets[it % 4]], views=[it % 4])
+            torch.cuda.synchronize()
+            out.append([n(p) for p in tr.model.parameters()] + [n(tr.optimizer.state[id(p)]["exp_avg"]) for p in tr.model.parameters()]
+                       + [tr.optimizer.state[id(tr.model.shN)]["step_count"]])
+    finally:
+        lib.lfs_set_debug_flags(0)
+    assert out[0][-1] == out[1][-1] == 11
+    for a, b in zip(out[0][:-1], out[1][:-1]):
+        assert a.shape == b.shape and np.array_equal(a, b)
