@@ -168,8 +168,20 @@ LFS_DI void wave_sum16_atomic(const float (&v)[16], float* __restrict__ dst, con
 // pairs V[j] = (v[2j], v[2j+1]); v_permlane32_swap / v_permlane16_swap exchange the components of pair j with those of pair j + 4 (resp. j + 2) in place, so
 // the two halves to add are register pairs again. Same values, same order of additions per slot as wave_sum16_atomic: bit-identical totals.
 typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef LFS_BWD_LIMITER_EXPERIMENT
+#define LFS_BWD_LIMITER_EXPERIMENT 0
+#endif
 template <int ACC = 0>
 LFS_DI void wave_sum16_atomic_pk(const v2f (&V)[8], float* __restrict__ dst, const uint32_t lane, unsigned long long* __restrict__ det64 = nullptr) {
+#if LFS_BWD_LIMITER_EXPERIMENT == 2   // (measurement only: no cross-lane reduction, no atomic)
+    {
+        v2f acc2 = V[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) acc2 += V[j];
+        if (acc2.x + acc2.y == 123.456f) dst[lane & 15] = acc2.x;
+        return;
+    }
+#endif
     v2f W[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { // v[2j], v[2j+1] with v[2j+8], v[2j+9]
@@ -194,6 +206,9 @@ LFS_DI void wave_sum16_atomic_pk(const v2f (&V)[8], float* __restrict__ dst, con
     t += dpp_mov<0x128>(t);
     if ((lane & 12) == 0) {
         const uint32_t slot = 4 * (lane >> 4) + 2 * (lane & 1) + ((lane >> 1) & 1);
+#if LFS_BWD_LIMITER_EXPERIMENT == 1   // (measurement only, wrong results: where does the time go? no atomic - a store nobody orders)
+        if (t == 123.456f) dst[slot] = t;
+#else
         if (ACC == 0) unsafeAtomicAdd(dst + slot, t);
 #ifndef LFS_EMULATE
         else if (ACC == 1) atomicMax(reinterpret_cast<uint32_t*>(dst) + slot, __float_as_uint(t) & 0x7fffffffu);
@@ -204,6 +219,7 @@ LFS_DI void wave_sum16_atomic_pk(const v2f (&V)[8], float* __restrict__ dst, con
                 atomicAdd(det64 + slot, (unsigned long long)__float2ll_rn(ldexpf(t, 40 - e)));
             }
         }
+#endif
 #endif
     }
 }
