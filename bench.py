@@ -196,7 +196,7 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     capi.load_library()
     rank, world, local_rank = lfs_dist.init_distributed()
-    lfs_dist.stats_enable(timing=world > 1 or bool(os.environ.get("LFS_DIST_FORCE_COLLECTIVES")))
+    lfs_dist.stats_enable(timing=False)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if os.environ.get("LFS_DIST_BACKEND") == "gloo":   # smoke mode: all ranks share the visible device(s)
@@ -260,20 +260,25 @@ def main() -> None:
     for _ in range(args.warmup - table_steps):
         trainer.train_step(targets)
     table = {}
+    coll_ms = {}
     if table_steps:
         torch.cuda.synchronize()
         capi.profile_collect()
         capi.profile_filter(None)
         capi.profile_enable(True)
+        # the collectives' device time is measured here as well (two timing events per collective), NOT inside the timed region: in the SH-sharded
+        # step the event pairs of four collectives cost ~0.3 ms of host time per step (measured at world 1: 2.05 ms with them, 1.68 ms without)
+        lfs_dist.stats_enable(timing=world > 1 or bool(os.environ.get("LFS_DIST_FORCE_COLLECTIVES")))
         for _ in range(table_steps):
             trainer.train_step(targets)
         capi.profile_enable(False)
         table = capi.profile_collect()
+        coll_ms = {k: v["ms"] / table_steps for k, v in lfs_dist.stats_collect().items()}
     dom = max(table.items(), key=lambda kv: kv[1][0])[0] if table else None
     lfs_dist.barrier()
     torch.cuda.synchronize()
     seen = lfs_dist.ranks_seen(device)
-    lfs_dist.stats_enable(timing=world > 1 or bool(os.environ.get("LFS_DIST_FORCE_COLLECTIVES")))   # count the timed steps only
+    lfs_dist.stats_enable(timing=False)   # calls and payload bytes of the timed steps only (no events)
     if dom:
         capi.profile_filter(dom)
         capi.profile_enable(True)
@@ -289,7 +294,7 @@ def main() -> None:
         kernels = capi.profile_collect()
         capi.profile_filter(None)
     elapsed = lfs_dist.max_over_ranks(elapsed, device)
-    coll = lfs_dist.stats_collect()   # this rank's collectives inside the timed steps: calls, payload bytes, device ms (ms of the async early all-reduce = until its wait)
+    coll = lfs_dist.stats_collect()   # this rank's collectives inside the timed steps: calls, payload bytes (device ms: from the profiled warm-up steps above)
 
     refine_ms = None
     if args.strategy == "mcmc" and world == 1:   # one refinement step on its own (relocation of the dead Gaussians + the step around it)
@@ -384,7 +389,7 @@ def main() -> None:
                    "strategy": args.strategy, "bilateral_grid": bool(args.bilateral_grid), "refine_step_ms": None if refine_ms is None else round(refine_ms, 3),
                    "visible_gaussians": V, **({"visible_gaussians_source": v_source} if v_source else {}), "n_isects": I},
         "collectives": {"backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None), "ranks_seen": seen,
-                        "per_step": {k: {"calls": v["calls"] / args.steps, "MB": round(v["bytes"] / args.steps / 1e6, 3), "ms": round(v["ms"] / args.steps, 4)} for k, v in coll.items()}},
+                        "per_step": {k: {"calls": v["calls"] / args.steps, "MB": round(v["bytes"] / args.steps / 1e6, 3), "ms": round(coll_ms.get(k, 0.0), 4)} for k, v in coll.items()}},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
     }
     # C-level stdout first (RCCL prints its version banner through stdio; on a pipe that buffer would otherwise be flushed at exit, after our line):

@@ -125,7 +125,8 @@ LFS_API int lfs_intersect_tile_emit(
  *      _count_ex: tile_offsets (nullable, int32 [C*tile_h*tile_w]) is written by the scan kernel instead of a device copy in _emit;
  *                 flags & LFS_ISECT_COUNTERS_ZERO: the workspace is the one of the caller's previous _count_ex call with the same C, N and tile
  *                 grid (the kernels leave its counters zero) - skips the memset. n_isects and max_tile_isects (nullable: the longest tile list) may
- *                 point to pinned host memory (written by the kernel).
+ *                 point to pinned host memory (written by the kernel); stamp_out (nullable) then receives `stamp` LAST, behind a system-scope fence: the
+ *                 host waits for the completion event and then for its own stamp before it trusts the counts.
  *      _emit_ex : scratch (nullable, int64 [n_isects]): with it the scatter runs as two binning passes with coalesced stores
  *                 (C*tile_h <= 512 and bits(C*N) + bits(tile_w) <= 32; otherwise, or without it, the one-pass scatter). max_tile_isects: the value
  *                 _count_ex reported (the per-tile sort then launches only the size classes that occur), or -1. */
@@ -133,7 +134,7 @@ LFS_API int lfs_intersect_tile_emit(
 LFS_API int lfs_intersect_tile_count_ex(
     uint32_t C, uint32_t N, const float* means2d, const int32_t* radii,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
-    int32_t* tiles_per_gauss, int64_t* n_isects, int64_t* max_tile_isects, int32_t* tile_offsets, uint32_t flags,
+    int32_t* tiles_per_gauss, int64_t* n_isects, int64_t* max_tile_isects, int32_t* tile_offsets, uint32_t flags, int64_t* stamp_out, int64_t stamp,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 LFS_API int lfs_intersect_tile_emit_ex(
     uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,

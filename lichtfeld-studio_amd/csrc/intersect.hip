@@ -443,7 +443,7 @@ extern "C" size_t lfs_intersect_tile_workspace_bytes(uint32_t C, uint32_t N, uin
 extern "C" int lfs_intersect_tile_count_ex(
     uint32_t C, uint32_t N, const float* means2d, const int32_t* radii,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
-    int32_t* tiles_per_gauss, int64_t* n_isects, int64_t* max_tile_isects, int32_t* tile_offsets, uint32_t flags,
+    int32_t* tiles_per_gauss, int64_t* n_isects, int64_t* max_tile_isects, int32_t* tile_offsets, uint32_t flags, int64_t* stamp_out, int64_t stamp,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
     if (!n_isects || !workspace || tile_size == 0 || tile_width == 0 || tile_height == 0 || C == 0) return LFS_E_INVALID;
     if (bit_width_u32(tile_width * tile_height) + bit_width_u32(C) > 32) return LFS_E_UNSUPPORTED; // IntersectTile.cu:154
@@ -470,7 +470,7 @@ extern "C" int lfs_intersect_tile_count_ex(
             hipLaunchKernelGGL(isect_count_kernel<false>, dim3(blocks), dim3(1024), 0, s, C, N, pb, means2d, radii,
                                float(tile_size), tile_width, tile_height, tiles_per_gauss, w.totals);
     }
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets, max_tile_isects);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets, max_tile_isects, stamp_out, stamp);
     return (int)hipGetLastError();
 }
 
@@ -478,7 +478,7 @@ extern "C" int lfs_intersect_tile_count(
     uint32_t C, uint32_t N, const float* means2d, const int32_t* radii,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     int32_t* tiles_per_gauss, int64_t* n_isects, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
-    return lfs_intersect_tile_count_ex(C, N, means2d, radii, tile_size, tile_width, tile_height, tiles_per_gauss, n_isects, nullptr, nullptr, 0u, workspace,
+    return lfs_intersect_tile_count_ex(C, N, means2d, radii, tile_size, tile_width, tile_height, tiles_per_gauss, n_isects, nullptr, nullptr, 0u, nullptr, 0, workspace,
                                        workspace_bytes, stream);
 }
 

@@ -25,7 +25,9 @@ struct m3 { float m[3][3]; };
 #ifdef LFS_EMULATE
 #define LFS_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(emu::dyn_lds())
 #define LFS_WAVE_LOCKSTEP() ((void)emu::ballot(true))
+#define LFS_SYSTEM_FENCE() ((void)0)
 #else
+#define LFS_SYSTEM_FENCE() __threadfence_system()
 #define LFS_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 #define LFS_WAVE_LOCKSTEP() ((void)0)
 #endif

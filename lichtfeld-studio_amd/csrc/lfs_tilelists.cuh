@@ -16,7 +16,7 @@ namespace lfs {
 static __global__ void __launch_bounds__(1024) tile_scan_kernel(
     const uint32_t T, uint32_t* __restrict__ totals, int32_t* __restrict__ offsets, int64_t* __restrict__ n_isects,
     const bool zero_totals = false, uint32_t* __restrict__ cursor = nullptr, uint32_t* __restrict__ aux = nullptr, const uint32_t n_aux = 0,
-    int32_t* __restrict__ offsets_out = nullptr, int64_t* __restrict__ max_total = nullptr) {
+    int32_t* __restrict__ offsets_out = nullptr, int64_t* __restrict__ max_total = nullptr, int64_t* __restrict__ stamp_out = nullptr, const int64_t stamp = 0) {
     // slices of 8192 tiles staged in LDS: coalesced loads, every thread scans 8 consecutive values, coalesced stores (one slice = the whole array
     // at 1080p; the round-1 version walked slices of 1024 with three barriers each: 13 us at T = 8160; a register-blocked version without the LDS
     // transpose was slower still - 8-word strides between lanes make every store a partial 32-byte sector)
@@ -69,6 +69,10 @@ static __global__ void __launch_bounds__(1024) tile_scan_kernel(
     if (threadIdx.x == 0) {
         offsets[T] = int32_t(carry); *n_isects = int64_t(carry);
         if (max_total != nullptr) { uint32_t m = 0; for (int w = 0; w < 16; ++w) m = max(m, wave_max[w]); *max_total = int64_t(m); }
+        if (stamp_out != nullptr) { // the counts may live in pinned HOST memory: the stamp is written last, behind a system-scope fence - a host that
+            LFS_SYSTEM_FENCE();     // sees the stamp of this call also sees its counts (it does not rely on the completion event alone)
+            *reinterpret_cast<volatile int64_t*>(stamp_out) = stamp;
+        }
     }
 }
 

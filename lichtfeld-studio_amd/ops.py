@@ -11,6 +11,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Tuple
 
+import time
+
 import torch
 
 from . import capi
@@ -109,20 +111,24 @@ def intersect_tile_begin(means2d: Tensor, radii: Tensor, depths: Tensor, C_: int
     _ISECT_LAST[last_key] = None
     # pinned: the scan kernel writes the counts straight into pinned host memory (no copy kernel) and the host waits for an event recorded behind
     # that kernel; otherwise they land in device memory and .tolist() reads them
-    host = _pinned_i64(slot) if pinned else None   # [n_isects, longest tile list]
+    host = _pinned_i64(slot) if pinned else None   # [n_isects, longest tile list, stamp of the call that wrote them]
+    stamp = 0
+    if pinned:
+        _STAMP[0] += 1
+        stamp = _STAMP[0]
     n_dev = None if pinned else torch.empty(2, dtype=torch.int64, device=dev)
     counts = host if host is not None else n_dev
     rc = lib.lfs_intersect_tile_count_ex(
         C.c_uint32(C_), C.c_uint32(N), ptr(means2d), ptr(radii), C.c_uint32(tile_size), C.c_uint32(tile_width), C.c_uint32(tile_height),
         ptr(tiles_per_gauss), C.c_void_p(counts.data_ptr()), C.c_void_p(counts.data_ptr() + 8), ptr(offsets), C.c_uint32(flags),
-        ptr(ws), C.c_size_t(ws.numel()), stream())
+        C.c_void_p(host.data_ptr() + 16) if pinned else None, C.c_int64(stamp), ptr(ws), C.c_size_t(ws.numel()), stream())
     check(rc, "intersect_tile (count)")
     ev = None
     if pinned:
         ev = torch.cuda.Event()
         ev.record()
     return dict(means2d=means2d, radii=radii, depths=depths, C=C_, N=N, tile_size=tile_size, tw=tile_width, th=tile_height, sort=sort, tpg=tiles_per_gauss,
-                ws=ws, offsets=offsets, return_offsets=return_offsets, host=host, n_dev=n_dev, ev=ev, last_key=last_key, shape_key=shape_key)
+                ws=ws, offsets=offsets, return_offsets=return_offsets, host=host, n_dev=n_dev, ev=ev, last_key=last_key, shape_key=shape_key, stamp=stamp)
 
 
 def intersect_tile_finish(st: dict):
@@ -130,7 +136,13 @@ def intersect_tile_finish(st: dict):
     lib, dev = load_library(), st["means2d"].device
     if st["ev"] is not None:
         st["ev"].synchronize()
-        n_isects, longest = (int(x) for x in st["host"].tolist())
+        host, t0 = st["host"], None
+        while int(host[2]) != st["stamp"]:     # the kernel writes its stamp behind a system-scope fence after the counts: normally there already
+            if t0 is None:
+                t0 = time.monotonic()
+            elif time.monotonic() - t0 > 5.0:
+                raise LfsError("intersect_tile: the counts of this call never arrived in pinned host memory")
+        n_isects, longest = int(host[0]), int(host[1])
     else:
         n_isects, longest = (int(x) for x in st["n_dev"].tolist())  # the one D2H sync of the path
     sort = st["sort"]
@@ -147,13 +159,14 @@ def intersect_tile_finish(st: dict):
 
 
 _PINNED = {}
+_STAMP = [0]
 _ISECT_LAST = {}   # (device index, workspace tag) -> (workspace pointer, C, N, tile_w, tile_h) of the last completed intersect_tile
 
 
 def _pinned_i64(slot: int = 0) -> Tensor:
     t = _PINNED.get(("i64", slot))
     if t is None:
-        t = torch.zeros(2, dtype=torch.int64).pin_memory()
+        t = torch.zeros(3, dtype=torch.int64).pin_memory()
         _PINNED[("i64", slot)] = t
     return t
 
