@@ -30,6 +30,8 @@ def build(ref: bool = True) -> None:
         subprocess.run(["make", "-C", _HERE, "ref"], check=True, capture_output=True)
     if ref and os.path.exists("/root/reference/gsplat/ProjectionUT3DGSFused.cu"):   # the reference's device kernels as host code (ref_kernels.cpp)
         subprocess.run(["make", "-C", _HERE, "refk"], check=True, capture_output=True)
+    if ref and os.path.exists("/root/reference/fastgs/rasterization/src/forward.cu"):   # the reference's fastgs rasterizer as host code (ref_kernels_fastgs.cpp)
+        subprocess.run(["make", "-C", _HERE, "refk_fastgs"], check=True, capture_output=True)
 
 
 def lib():
@@ -462,3 +464,45 @@ def refk_adam_step(param, exp_avg, exp_avg_sq, grad, lr, beta1, beta2, eps, bc1_
     refk_lib().refk_adam_step(C.c_int64(p.size), _p(p), _p(m), _p(v), _p(g), C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
                               C.c_float(bc1_rcp), C.c_float(bc2_sqrt_rcp))
     return p, m, v
+
+
+# ---- the reference's own fastgs rasterizer on the CPU (oracle/_ref/libref_fastgs.so; ref_kernels_fastgs.cpp + ref_emul/) ---------------
+_REFK_FG = None
+
+
+def refk_fastgs_lib():
+    """fastgs/rasterization of the reference (forward.cu, backward.cu and the kernels in its headers), compiled in place as host code
+    (`make -C oracle refk_fastgs`); None when absent."""
+    global _REFK_FG
+    if _REFK_FG is None:
+        path = os.path.join(_HERE, "_ref", "libref_fastgs.so")
+        if not os.path.exists(path):
+            return None
+        _REFK_FG = C.CDLL(path)
+    return _REFK_FG
+
+
+def refk_fastgs_fwd_bwd(means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c, cam_pos, active_sh_bases, W, H, fx, fy, cx, cy, g_image=None, g_alpha=None,
+                        near=0.01, far=1e10, densification_info=None):
+    """forward (+ backward when g_image is given) of the reference's fastgs rasterizer -> dict(image [3,H,W], alpha [1,H,W], counts (n_visible,
+    n_instances, n_buckets), and with gradients: g_means, g_scales_raw, g_rot_raw, g_opac_raw [N], g_sh0 [N,1,3], g_sh_rest, densification_info)."""
+    means, scales_raw, rot_raw, opac_raw = _f32(means), _f32(scales_raw), _f32(rot_raw), _f32(np.asarray(opac_raw).reshape(-1))
+    sh0, sh_rest, w2c, cam_pos = _f32(sh0), _f32(sh_rest), _f32(np.asarray(w2c).reshape(4, 4)), _f32(np.asarray(cam_pos).reshape(3))
+    N, total_rest = means.shape[0], (sh_rest.shape[1] if sh_rest.ndim == 3 else 0)
+    out = dict(image=np.zeros((3, H, W), np.float32), alpha=np.zeros((1, H, W), np.float32), counts=np.zeros(3, np.int32))
+    g = None
+    if g_image is not None:
+        g_image, g_alpha = _f32(g_image), _f32(np.asarray(g_alpha).reshape(1, H, W))
+        g = dict(g_means=np.zeros((N, 3), np.float32), g_scales_raw=np.zeros((N, 3), np.float32), g_rot_raw=np.zeros((N, 4), np.float32),
+                 g_opac_raw=np.zeros(N, np.float32), g_sh0=np.zeros((N, 1, 3), np.float32), g_sh_rest=np.zeros((N, max(total_rest, 0), 3), np.float32))
+        if densification_info is not None:
+            g["densification_info"] = _f32(densification_info).copy()
+    refk_fastgs_lib().refk_fastgs_fwd_bwd(
+        C.c_int(N), C.c_int(active_sh_bases), C.c_int(total_rest), C.c_int(W), C.c_int(H), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+        C.c_float(near), C.c_float(far), _p(means), _p(scales_raw), _p(rot_raw), _p(opac_raw), _p(sh0), _p(sh_rest), _p(w2c), _p(cam_pos),
+        _p(g_image) if g is not None else None, _p(g_alpha) if g is not None else None, _p(out["image"]), _p(out["alpha"]),
+        *([_p(g[k]) for k in ("g_means", "g_scales_raw", "g_rot_raw", "g_opac_raw", "g_sh0", "g_sh_rest")] if g is not None else [None] * 6),
+        _p(g["densification_info"]) if (g is not None and "densification_info" in g) else None, _p(out["counts"]))
+    if g is not None:
+        out.update(g)
+    return out

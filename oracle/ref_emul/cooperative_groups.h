@@ -42,6 +42,33 @@ template <unsigned SIZE, typename ParentT = void> struct thread_block_tile {
         }) != 0;
     }
     void sync() const { cuemu::warp_collective(0, [](cuemu::WarpState& w) { for (int l = 0; l < cuemu::WARP; ++l) w.result[l] = 0; }); }
+    unsigned meta_group_rank() const { return unsigned(cuemu::cur()->warp); }   // index of this tile inside its thread block
+    // shfl / shfl_up: every lane deposits, the last arriver snapshots the slots, every lane then reads its source's slot (the next collective cannot
+    // complete - and overwrite the snapshot - before every lane of the warp has arrived at it, i.e. has read this one)
+    template <typename T> T shfl(T v, unsigned src) const {
+        static thread_local uint64_t snap[cuemu::MAX_THREADS / cuemu::WARP][cuemu::WARP];
+        uint64_t u = 0; static_assert(sizeof(T) <= 8, "payload"); memcpy(&u, &v, sizeof(T));
+        const int wi = cuemu::cur()->warp;
+        cuemu::warp_collective(u, [wi](cuemu::WarpState& w) { for (int l = 0; l < cuemu::WARP; ++l) { snap[wi][l] = w.slot[l]; w.result[l] = 0; } });
+        T out; const uint64_t r = snap[wi][src & (cuemu::WARP - 1)]; memcpy(&out, &r, sizeof(T)); return out;
+    }
+    template <typename T> T shfl_up(T v, unsigned delta) const {   // lanes below delta keep their own value
+        const unsigned me = unsigned(cuemu::cur()->lane);
+        const T got = shfl(v, me >= delta ? me - delta : me);
+        return me >= delta ? got : v;
+    }
+    template <typename T> T shfl_down(T v, unsigned delta) const {
+        const unsigned me = unsigned(cuemu::cur()->lane);
+        const T got = shfl(v, me + delta < SIZE ? me + delta : me);
+        return me + delta < SIZE ? got : v;
+    }
+    unsigned ballot(int pred) const {
+        return unsigned(cuemu::warp_collective(pred ? 1 : 0, [](cuemu::WarpState& w) {
+            uint64_t r = 0;
+            for (int l = 0; l < cuemu::WARP; ++l) if (((w.live >> l) & 1) && w.slot[l]) r |= 1ull << l;
+            for (int l = 0; l < cuemu::WARP; ++l) w.result[l] = r;
+        }));
+    }
 };
 template <unsigned SIZE> inline thread_block_tile<SIZE> tiled_partition(const thread_block&) { return thread_block_tile<SIZE>(); }
 
