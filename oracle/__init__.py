@@ -32,6 +32,8 @@ def build(ref: bool = True) -> None:
         subprocess.run(["make", "-C", _HERE, "refk"], check=True, capture_output=True)
     if ref and os.path.exists("/root/reference/fastgs/rasterization/src/forward.cu"):   # the reference's fastgs rasterizer as host code (ref_kernels_fastgs.cpp)
         subprocess.run(["make", "-C", _HERE, "refk_fastgs"], check=True, capture_output=True)
+    if ref and os.path.exists("/root/reference/src/training/kernels/ssim.cu"):   # the reference's fused SSIM / bilateral-grid kernels as host code
+        subprocess.run(["make", "-C", _HERE, "refk_loss"], check=True, capture_output=True)
 
 
 def lib():
@@ -506,3 +508,60 @@ def refk_fastgs_fwd_bwd(means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c,
     if g is not None:
         out.update(g)
     return out
+
+
+# ---- the reference's own fused-SSIM and bilateral-grid kernels on the CPU (oracle/_ref/libref_loss.so; ref_kernels_loss.cpp + ref_emul/) -------
+_REFK_LOSS = None
+
+
+def refk_loss_lib():
+    global _REFK_LOSS
+    if _REFK_LOSS is None:
+        path = os.path.join(_HERE, "_ref", "libref_loss.so")
+        if not os.path.exists(path):
+            return None
+        _REFK_LOSS = C.CDLL(path)
+    return _REFK_LOSS
+
+
+def refk_fusedssim(C1, C2, img1, img2, train=True):
+    """fusedssim of the reference (ssim.cu): img [B,CH,H,W] -> (ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12)"""
+    img1, img2 = _f32(img1), _f32(img2)
+    B, CH, H, W = img1.shape
+    out = [np.zeros_like(img1) for _ in range(4)]
+    refk_loss_lib().refk_fusedssim(C.c_int(B), C.c_int(CH), C.c_int(H), C.c_int(W), C.c_float(C1), C.c_float(C2), _p(img1), _p(img2), C.c_int(int(train)),
+                                   *[_p(x) for x in out])
+    return tuple(out)
+
+
+def refk_fusedssim_backward(C1, C2, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12):
+    img1, img2, dL_dmap = _f32(img1), _f32(img2), _f32(dL_dmap)
+    B, CH, H, W = img1.shape
+    out = np.zeros_like(img1)
+    refk_loss_lib().refk_fusedssim_backward(C.c_int(B), C.c_int(CH), C.c_int(H), C.c_int(W), C.c_float(C1), C.c_float(C2), _p(img1), _p(img2), _p(dL_dmap),
+                                            _p(_f32(dm_dmu1)), _p(_f32(dm_dsigma1_sq)), _p(_f32(dm_dsigma12)), _p(out))
+    return out
+
+
+def refk_bilateral_slice(grid, rgb, grad_output=None):
+    """slice_forward (+ slice_backward with grad_output) of the reference: grid [12,L,H,W], rgb [h,w,3] -> out [, grad_grid, grad_rgb]"""
+    grid, rgb = _f32(grid), _f32(rgb)
+    _, L, H, W = grid.shape
+    h, w = rgb.shape[:2]
+    out = np.zeros_like(rgb)
+    refk_loss_lib().refk_bilateral_slice_forward(_p(grid), _p(rgb), _p(out), C.c_int(L), C.c_int(H), C.c_int(W), C.c_int(h), C.c_int(w))
+    if grad_output is None:
+        return out
+    gg, gr = np.zeros_like(grid), np.zeros_like(rgb)
+    refk_loss_lib().refk_bilateral_slice_backward(_p(grid), _p(rgb), _p(_f32(grad_output)), _p(gg), _p(gr), C.c_int(L), C.c_int(H), C.c_int(W), C.c_int(h), C.c_int(w))
+    return out, gg, gr
+
+
+def refk_bilateral_tv(grids, grad_output=1.0):
+    """tv_loss_forward / _backward of the reference: grids [N,12,L,H,W] -> (loss, grad_grids)"""
+    grids = _f32(grids)
+    N, _, L, H, W = grids.shape
+    loss, gg = np.zeros(1, np.float32), np.zeros_like(grids)
+    refk_loss_lib().refk_bilateral_tv_forward(_p(grids), _p(loss), C.c_int(N), C.c_int(L), C.c_int(H), C.c_int(W))
+    refk_loss_lib().refk_bilateral_tv_backward(_p(grids), C.c_float(grad_output), _p(gg), C.c_int(N), C.c_int(L), C.c_int(H), C.c_int(W))
+    return float(loss[0]), gg

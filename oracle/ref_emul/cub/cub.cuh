@@ -58,6 +58,7 @@ template <typename T, int BX, BlockReduceAlgorithm = BLOCK_REDUCE_WARP_REDUCTION
         cuemu::block_barrier(0);
         return r;
     }
+    T Sum(T v) { return Reduce(v, [](T a, T b) { return a + b; }); }
 };
 } // namespace cub
 namespace thrust {

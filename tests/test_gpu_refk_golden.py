@@ -97,3 +97,46 @@ def test_hip_fastgs_matches_the_reference_rasterizer(lfs, name):
     if "densification_info_in" in d:
         ref = d["out_densification_info"]
         assert np.abs(n(dens) - ref).max() < 2e-3 * np.abs(ref).max()
+
+
+# ---- fused SSIM and the bilateral grid against the reference's own kernels (tests/golden/refk_loss.npz) ------------------------------------------
+import test_oracle_refk_loss_golden as lg  # noqa: E402
+
+
+@pytest.mark.parametrize("name", lg.SSIM)
+def test_hip_fusedssim_matches_the_reference_kernel(lfs, name):
+    """csrc/ssim.hip through losses.fusedssim / fusedssim_backward against fusedssimCUDA / fusedssim_backwardCUDA of the reference run on the CPU."""
+    from gpu_util import n, t
+    from lichtfeld_studio_amd import losses
+    d = lg.CASES[name]
+    a, b = t(d["img1"]), t(d["img2"])
+    m, d1, d2, d3 = losses.fusedssim(lg.C1, lg.C2, a, b, True)
+    lg.close(n(m), d["ssim_map"], 3e-6, "ssim_map")
+    for got, key in zip((d1, d2, d3), ("dm_dmu1", "dm_dsigma1_sq", "dm_dsigma12")):
+        lg.close(n(got), d[key], 3e-5, key)
+    g = losses.fusedssim_backward(lg.C1, lg.C2, a, b, t(d["dL_dmap"]), d1, d2, d3)
+    lg.close(n(g), d["dL_dimg1"], 3e-5, "dL_dimg1")
+    # and with the reference's derivative maps handed in: the backward kernel alone
+    g2 = losses.fusedssim_backward(lg.C1, lg.C2, a, b, t(d["dL_dmap"]), t(d["dm_dmu1"]), t(d["dm_dsigma1_sq"]), t(d["dm_dsigma12"]))
+    lg.close(n(g2), d["dL_dimg1"], 1e-5, "dL_dimg1 from the reference's maps")
+
+
+@pytest.mark.parametrize("name", lg.SLICE)
+def test_hip_bilateral_slice_matches_the_reference_kernel(lfs, name):
+    from gpu_util import n, t
+    from lichtfeld_studio_amd import bilateral_grid as bg
+    d = lg.CASES[name]
+    lg.close(n(bg.slice_forward(t(d["grid"]), t(d["rgb"]))), d["output"], 3e-6, "slice output")
+    gg, gr = bg.slice_backward(t(d["grid"]), t(d["rgb"]), t(d["grad_output"]))
+    lg.close(n(gg), d["grad_grid"], 3e-5, "grad_grid")
+    lg.close(n(gr), d["grad_rgb"], 3e-5, "grad_rgb")
+
+
+@pytest.mark.parametrize("name", lg.TV)
+def test_hip_bilateral_tv_matches_the_reference_kernel(lfs, name):
+    from gpu_util import n, t
+    from lichtfeld_studio_amd import bilateral_grid as bg
+    d = lg.CASES[name]
+    loss = float(bg.tv_loss_forward(t(d["grids"])).item())
+    assert abs(loss - float(d["tv_loss"])) <= 1e-5 * float(d["tv_loss"])
+    lg.close(n(bg.tv_loss_backward(t(d["grids"]), float(d["grad_output"]))), d["grad_grids"], 3e-6, "tv grad")
