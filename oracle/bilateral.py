@@ -3,9 +3,10 @@
   slice_backward : src/training/kernels/bilateral_grid_backward.cu:14-153
   tv_forward     : src/training/kernels/bilateral_grid_tv.cu:12-77
   tv_backward    : src/training/kernels/bilateral_grid_tv.cu:80-135
-PARITY UNPINNED by the reference's own tests (none touch these kernels, and they are CUDA-only so cannot run here); the
-restatement is pinned instead by tests/test_oracle_bilateral.py: identity grid == identity map, analytic backward == central
-differences of the forward in float64 away from the z-cell boundaries, TV backward == d(TV forward).
+Pinned to the reference's own kernels: those four .cu files are run on the CPU under oracle/ref_emul/ (make -C oracle refk_loss), their outputs are committed
+as tests/golden/refk_loss.npz, and tests/test_oracle_refk_loss_golden.py holds this restatement to them (the reference's own tests do not touch these kernels).
+tests/test_oracle_bilateral.py adds: identity grid == identity map, analytic backward == central differences of the forward in float64 away from the z-cell
+boundaries, TV backward == d(TV forward).
 """
 import numpy as np
 
