@@ -34,6 +34,8 @@ def build(ref: bool = True) -> None:
         subprocess.run(["make", "-C", _HERE, "refk_fastgs"], check=True, capture_output=True)
     if ref and os.path.exists("/root/reference/src/training/kernels/ssim.cu"):   # the reference's fused SSIM / bilateral-grid kernels as host code
         subprocess.run(["make", "-C", _HERE, "refk_loss"], check=True, capture_output=True)
+    if ref and os.path.exists("/root/reference/src/loader/formats/colmap.cpp"):   # the reference's COLMAP reader against libtorch
+        subprocess.run(["make", "-C", _HERE, "refcolmap"], check=True, capture_output=True)
 
 
 def lib():
@@ -565,3 +567,64 @@ def refk_bilateral_tv(grids, grad_output=1.0):
     refk_loss_lib().refk_bilateral_tv_forward(_p(grids), _p(loss), C.c_int(N), C.c_int(L), C.c_int(H), C.c_int(W))
     refk_loss_lib().refk_bilateral_tv_backward(_p(grids), C.c_float(grad_output), _p(gg), C.c_int(N), C.c_int(L), C.c_int(H), C.c_int(W))
     return float(loss[0]), gg
+
+
+# ---- the reference's own COLMAP reader (oracle/_ref/libref_colmap.so; ref_colmap_shim.cpp + src/loader/formats/colmap.cpp compiled in place) -------------
+_REF_COLMAP = None
+
+
+class _RefView(C.Structure):
+    _fields_ = [("camera_id", C.c_uint32), ("colmap_model", C.c_int32), ("camera_model_type", C.c_int32), ("width", C.c_uint64), ("height", C.c_uint64),
+                ("focal_x", C.c_float), ("focal_y", C.c_float), ("center_x", C.c_float), ("center_y", C.c_float), ("R", C.c_float * 9), ("T", C.c_float * 3),
+                ("n_radial", C.c_int32), ("radial", C.c_float * 6), ("n_tangential", C.c_int32), ("tangential", C.c_float * 2),
+                ("n_params", C.c_int32), ("params", C.c_float * 12)]
+
+
+def ref_colmap_lib():
+    global _REF_COLMAP
+    if _REF_COLMAP is None:
+        path = os.path.join(_HERE, "_ref", "libref_colmap.so")
+        if not os.path.exists(path):
+            return None
+        lib = C.CDLL(path)
+        lib.refcolmap_last_error.restype = C.c_char_p
+        lib.refcolmap_image_name.restype = C.c_char_p
+        lib.refcolmap_image_path.restype = C.c_char_p
+        lib.refcolmap_num_views.restype = C.c_uint64
+        lib.refcolmap_points.restype = C.c_int64
+        _REF_COLMAP = lib
+    return _REF_COLMAP
+
+
+def ref_colmap_cameras(base, images_folder="images", text=False):
+    """read_colmap_cameras_and_images[_text] of the reference -> (list of dicts in oracle.colmap_io.assemble's vocabulary, scene centre); raises RuntimeError
+    with the reference's exception text."""
+    lib = ref_colmap_lib()
+    h = C.c_void_p()
+    if lib.refcolmap_open(os.fsencode(base), images_folder.encode(), C.c_int(int(text)), C.byref(h)):
+        raise RuntimeError(lib.refcolmap_last_error().decode())
+    try:
+        out, v = [], _RefView()
+        for i in range(lib.refcolmap_num_views(h)):
+            if lib.refcolmap_view_at(h, C.c_uint64(i), C.byref(v)):
+                raise RuntimeError(lib.refcolmap_last_error().decode())
+            out.append(dict(camera_id=v.camera_id, colmap_model=v.colmap_model, camera_model_type=v.camera_model_type, width=int(v.width), height=int(v.height),
+                            focal_x=np.float32(v.focal_x), focal_y=np.float32(v.focal_y), center_x=np.float32(v.center_x), center_y=np.float32(v.center_y),
+                            R=np.array(v.R, np.float32).reshape(3, 3), T=np.array(v.T, np.float32), radial=np.array(v.radial[:v.n_radial], np.float32),
+                            tangential=np.array(v.tangential[:v.n_tangential], np.float32), params=np.array(v.params[:v.n_params], np.float32),
+                            name=lib.refcolmap_image_name(h, C.c_uint64(i)).decode(), path=os.fsdecode(lib.refcolmap_image_path(h, C.c_uint64(i)))))
+        c = (C.c_float * 3)()
+        lib.refcolmap_scene_center(h, c)
+        return out, np.array(c, np.float32)
+    finally:
+        lib.refcolmap_close(h)
+
+
+def ref_colmap_points(base, text=False):
+    lib = ref_colmap_lib()
+    n = lib.refcolmap_points(os.fsencode(base), C.c_int(int(text)), None, None, C.c_int64(0))
+    if n < 0:
+        raise RuntimeError(lib.refcolmap_last_error().decode())
+    pos, col = np.empty((n, 3), np.float32), np.empty((n, 3), np.uint8)
+    lib.refcolmap_points(os.fsencode(base), C.c_int(int(text)), pos.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), C.c_int64(n))
+    return pos, col

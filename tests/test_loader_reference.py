@@ -1,0 +1,188 @@
+"""CPU: the product's COLMAP reader (liblfs_io.so through lichtfeld_studio_amd.loader) and its restatement (oracle/colmap_io.py) against the REFERENCE'S OWN
+reader - src/loader/formats/colmap.cpp compiled in place against libtorch (oracle/_ref/libref_colmap.so, `make -C oracle refcolmap`; oracle/ref_stub/ stands in
+for its logger and image_io headers). SURVEY.md §8f row 4.
+ * always: the committed dataset tests/golden/colmap_scene/ read by the product == tests/golden/ref_colmap.npz, the reference reader's output for it
+   (oracle/make_golden_ref_colmap.py). Integers, strings, params, T, intrinsics and R bit-exact (same float32 expressions); the scene centre (a mean over
+   views, summed in a different order) to 1e-6.
+ * where the .so exists (the build container): the same comparison live on freshly written datasets in every layout, the images_<k> scale factor, the
+   first-image size correction, the exception texts of the error paths, and the committed file regenerating bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import test_loader_io as T
+from oracle import colmap_io as oc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENE = os.path.join(HERE, "golden", "colmap_scene")
+GOLD = np.load(os.path.join(HERE, "golden", "ref_colmap.npz"))
+live = pytest.mark.skipif(oracle.ref_colmap_lib() is None, reason="oracle/_ref/libref_colmap.so not built (needs /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def ld():
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import loader
+    loader.io_library()
+    return loader
+
+
+def as_dict(v):
+    """a product CameraData in the vocabulary of the reference-side dicts"""
+    return dict(camera_id=v.camera_id, colmap_model=v.colmap_model, camera_model_type=v.camera_model_type, width=v.width, height=v.height,
+                focal_x=np.float32(v.focal_x), focal_y=np.float32(v.focal_y), center_x=np.float32(v.center_x), center_y=np.float32(v.center_y), R=v.R, T=v.T,
+                radial=v.radial_distortion, tangential=v.tangential_distortion, params=v.params, name=v.image_name, path=v.image_path)
+
+
+def same_views(got, ref, what):
+    assert len(got) == len(ref), what
+    for i, (g, r) in enumerate(zip(got, ref)):
+        for k in ("camera_id", "colmap_model", "camera_model_type", "width", "height", "name", "focal_x", "focal_y", "center_x", "center_y"):
+            assert g[k] == r[k], (what, i, k, g[k], r[k])
+        for k in ("R", "T", "radial", "tangential", "params"):
+            assert np.array_equal(np.asarray(g[k], np.float32).reshape(-1), np.asarray(r[k], np.float32).reshape(-1)), (what, i, k, g[k], r[k])
+        if "path" in r:
+            assert g["path"] == r["path"], (what, i)
+
+
+def golden_views(prefix):
+    n = len(GOLD[f"{prefix}/names"])
+    out = []
+    for i in range(n):
+        d = {k: GOLD[f"{prefix}/{k}"][i].item() for k in ("camera_id", "colmap_model", "camera_model_type", "width", "height")}
+        d.update({k: np.float32(GOLD[f"{prefix}/{k}"][i]) for k in ("focal_x", "focal_y", "center_x", "center_y")})
+        for k in ("R", "T", "radial", "tangential", "params"):
+            row = GOLD[f"{prefix}/{k}"][i]
+            d[k] = row[~np.isnan(row)]
+        d["name"] = str(GOLD[f"{prefix}/names"][i])
+        out.append(d)
+    return out, GOLD[f"{prefix}/center"]
+
+
+@pytest.mark.parametrize("fmt", ["bin", "txt"])
+def test_product_reader_equals_the_reference_reader_on_the_committed_scene(ld, fmt):
+    os.makedirs(os.path.join(SCENE, "images_2"), exist_ok=True)
+    read = ld.read_colmap_cameras_and_images_text if fmt == "txt" else ld.read_colmap_cameras_and_images
+    views, center = read(SCENE, "images_2")
+    ref, ref_center = golden_views(f"images_2/{fmt}")
+    same_views([as_dict(v) for v in views], ref, fmt)
+    assert views[0].width == 320 and views[0].height == 240          # images_2: the folder's scale factor applied (colmap.cpp:258-281, 364-377)
+    np.testing.assert_allclose(center, ref_center, rtol=0, atol=1e-6)
+    pc = (ld.read_colmap_point_cloud_text if fmt == "txt" else ld.read_colmap_point_cloud)(SCENE)
+    assert np.array_equal(pc.means, GOLD[f"points/{fmt}/means"]) and np.array_equal(pc.colors, GOLD[f"points/{fmt}/colors"])
+
+
+@pytest.mark.parametrize("fmt", ["bin", "txt"])
+def test_restatement_equals_the_reference_reader_on_the_committed_scene(fmt):
+    sp = os.path.join(SCENE, "sparse", "0")
+    if fmt == "bin":
+        views, center = oc.assemble(oc.read_cameras_bin(os.path.join(sp, "cameras.bin"), 2.0), oc.read_images_bin(os.path.join(sp, "images.bin")))
+    else:
+        views, center = oc.assemble(oc.read_cameras_txt(os.path.join(sp, "cameras.txt"), 2.0), oc.read_images_txt(os.path.join(sp, "images.txt")))
+    ref, ref_center = golden_views(f"images_2/{fmt}")
+    assert len(views) == len(ref)
+    for g, r in zip(views, ref):
+        assert (g["camera_id"], g["colmap_model"], g["camera_model_type"], g["width"], g["height"], g["name"]) == \
+               (r["camera_id"], r["colmap_model"], r["camera_model_type"], r["width"], r["height"], r["name"])
+        for k in ("focal_x", "focal_y", "center_x", "center_y"):
+            assert abs(float(g[k]) - float(r[k])) <= 2e-7 * abs(float(r[k]))
+        np.testing.assert_allclose(g["R"], r["R"].reshape(3, 3), rtol=0, atol=2e-7)      # numpy float32 vs libtorch float32: sqrt / rounding of the normalisation
+        assert np.array_equal(g["T"], r["T"]) and np.array_equal(g["params"], r["params"])
+        assert np.array_equal(g["radial"], r["radial"]) and np.array_equal(g["tangential"], r["tangential"])
+    np.testing.assert_allclose(center, ref_center, rtol=0, atol=2e-6)
+
+
+@live
+@pytest.mark.parametrize("layout,upper,folder", [("sparse/0", False, "images"), ("sparse", True, "images_4"), ("", False, "images_8")])
+def test_live_product_reader_equals_the_reference_reader(ld, tmp_path, layout, upper, folder):
+    cams, images, xyz, rgb = T._dataset(np.random.default_rng(hashless(layout, folder)), n_images=17)
+    base = str(tmp_path / "scene")
+    for txt in (False, True):
+        T._write(base, cams, images, xyz, rgb, layout, txt=txt, images_folder=folder, upper=upper)
+    for text, read, readp in ((False, ld.read_colmap_cameras_and_images, ld.read_colmap_point_cloud), (True, ld.read_colmap_cameras_and_images_text, ld.read_colmap_point_cloud_text)):
+        ref, ref_center = oracle.ref_colmap_cameras(base, folder, text)
+        views, center = read(base, folder)
+        same_views([as_dict(v) for v in views], ref, (layout, folder, text))
+        np.testing.assert_allclose(center, ref_center, rtol=0, atol=1e-6)
+        p, c = oracle.ref_colmap_points(base, text)
+        pc = readp(base)
+        assert np.array_equal(pc.means, p) and np.array_equal(pc.colors, c)
+    # the first image exists with another size: every camera is rescaled to it (colmap.cpp:851-877)
+    ld.write_png(os.path.join(base, folder, images[0][4]), np.zeros((90, 200, 3), np.uint8))
+    ref, _ = oracle.ref_colmap_cameras(base, folder, False)
+    views, _ = ld.read_colmap_cameras_and_images(base, folder)
+    assert (ref[3]["width"], ref[3]["height"]) == (200, 90)
+    same_views([as_dict(v) for v in views], ref, "size correction")
+
+
+def hashless(*parts):
+    import zlib
+    return zlib.crc32("|".join(parts).encode())
+
+
+def both_raise(ld, fn_ref, fn_got):
+    with pytest.raises(RuntimeError) as r:
+        fn_ref()
+    with pytest.raises(ld.LoaderError) as g:
+        fn_got()
+    return str(r.value), str(g.value)
+
+
+@live
+def test_live_error_paths_raise_where_the_reference_raises(ld, tmp_path):
+    """Every malformed input the reference's reader rejects is rejected by the product's; where the reference's text is a fixed sentence the product repeats it."""
+    import struct
+    cams, images, xyz, rgb = T._dataset(np.random.default_rng(7), n_images=3)
+    base = str(tmp_path / "scene")
+    sp = T._write(base, cams, images, xyz, rgb)
+    r, g = both_raise(ld, lambda: oracle.ref_colmap_cameras(base, "images_8"), lambda: ld.read_colmap_cameras_and_images(base, "images_8"))
+    assert r.startswith("Images folder does not exist") and g.startswith("Images folder does not exist")
+    r, g = both_raise(ld, lambda: oracle.ref_colmap_cameras(base, "images", True), lambda: ld.read_colmap_cameras_and_images_text(base, "images"))
+    assert r.startswith("Cannot find 'cameras.txt' in any of these locations:") and g.startswith("Cannot find 'cameras.txt' in any of these locations:")
+    assert r.splitlines()[1:4] == g.splitlines()[1:4]                      # the three directories searched, in the reference's order
+    for fname in ("cameras.bin", "images.bin", "points3D.bin"):
+        path = os.path.join(sp, fname)
+        good = open(path, "rb").read()
+        pts = fname.startswith("points")
+        open(path, "wb").write(good + b"\0")
+        r, g = both_raise(ld, (lambda: oracle.ref_colmap_points(base)) if pts else (lambda: oracle.ref_colmap_cameras(base, "images")),
+                          (lambda: ld.read_colmap_point_cloud(base)) if pts else (lambda: ld.read_colmap_cameras_and_images(base, "images")))
+        assert "trailing bytes" in r and "trailing bytes" in g
+        open(path, "wb").write(good)
+    for model, n_params in ((7, 5), (10, 12)):                               # FOV, THIN_PRISM_FISHEYE
+        oc.write_cameras_bin(os.path.join(sp, "cameras.bin"), [(cams[0][0], model, 640, 480, [1.0] * n_params)])
+        oc.write_images_bin(os.path.join(sp, "images.bin"), [(1, [1, 0, 0, 0], [0, 0, 0], cams[0][0], "a.png")])
+        r, g = both_raise(ld, lambda: oracle.ref_colmap_cameras(base, "images"), lambda: ld.read_colmap_cameras_and_images(base, "images"))
+        assert "not supported" in r and "not supported" in g, (r, g)
+    with open(os.path.join(sp, "cameras.bin"), "wb") as f:
+        f.write(struct.pack("<QIiQQ", 1, 1, 11, 640, 480))
+    both_raise(ld, lambda: oracle.ref_colmap_cameras(base, "images"), lambda: ld.read_colmap_cameras_and_images(base, "images"))
+    oc.write_cameras_bin(os.path.join(sp, "cameras.bin"), [(5, 1, 640, 480, [1.0, 1.0, 2.0, 2.0])])
+    oc.write_images_bin(os.path.join(sp, "images.bin"), [(1, [1, 0, 0, 0], [0, 0, 0], 6, "a.png")])
+    r, g = both_raise(ld, lambda: oracle.ref_colmap_cameras(base, "images"), lambda: ld.read_colmap_cameras_and_images(base, "images"))
+    assert r == g == "Camera ID 6 not found"
+    open(os.path.join(sp, "cameras.txt"), "w").write("5 PINHOLE 640 480 1 1 2 2\n")
+    open(os.path.join(sp, "images.txt"), "w").write("# c\n1 1 0 0 0 0 0 0 5 a.png\n\n2 1 0 0 0 0 0 0 5\n1 2 3\n")
+    r, g = both_raise(ld, lambda: oracle.ref_colmap_cameras(base, "images", True), lambda: ld.read_colmap_cameras_and_images_text(base, "images"))
+    assert r.startswith("Invalid format in images.txt line 3") and g.startswith("Invalid format in images.txt line 3")
+    open(os.path.join(sp, "cameras.txt"), "w").write("5 PINHOLEX 640 480 1 1 2 2\n")
+    r, g = both_raise(ld, lambda: oracle.ref_colmap_cameras(base, "images", True), lambda: ld.read_colmap_cameras_and_images_text(base, "images"))
+    assert "cameras.txt" in r and "cameras.txt" in g
+
+
+@live
+def test_live_golden_file_regenerates_from_the_reference_reader():
+    from oracle import make_golden_ref_colmap as mg
+    os.makedirs(os.path.join(SCENE, "images_2"), exist_ok=True)
+    out = {}
+    for text in (False, True):
+        views, center = oracle.ref_colmap_cameras(SCENE, "images_2", text)
+        mg.pack(f"images_2/{'txt' if text else 'bin'}", views, center, out)
+        p, c = oracle.ref_colmap_points(SCENE, text)
+        out[f"points/{'txt' if text else 'bin'}/means"], out[f"points/{'txt' if text else 'bin'}/colors"] = p, c
+    assert sorted(out) == sorted(GOLD.files)
+    for k in out:
+        a, b = np.asarray(out[k]), GOLD[k]
+        assert a.shape == b.shape and (np.array_equal(a, b) if a.dtype.kind in "US" else np.array_equal(a, b, equal_nan=True)), k
