@@ -350,10 +350,15 @@ LFS_API int lfs_bilateral_tv_loss_bwd(uint32_t N, uint32_t L, uint32_t H, uint32
  *      lfs_image_u8_to_chw_f32: Camera::load_and_get_image (src/core/camera.cpp:101-140) fused with load_image's downscale
  *      (src/core/image_io.cpp:33-57, OpenImageIO resample(interpolate = true)): src u8 [sh,sw,3] -> dst f32 [3,dh,dw] in [0,1];
  *      when the sizes differ the image is resampled bilinearly and re-quantised to 8 bit first, as the reference's host path does.
- *      lfs_mean_neighbor_distances: compute_mean_neighbor_distances (src/core/splat_data.cpp:64-111), points [N,3] -> out [N]. */
+ *      lfs_mean_neighbor_distances: compute_mean_neighbor_distances (src/core/splat_data.cpp:64-111), points [N,3] -> out [N], device pointers. The
+ *      reference's nanoflann query is (1 + 10)-approximate (SearchParameters(10) sets eps, :97), so its result depends on the kd-tree: the entry copies the
+ *      points to the host, builds nanoflann's tree there (single-threaded divideTree, leaf size 10), walks it on the GPU in searchLevel's order and
+ *      synchronises the stream before it returns. Bit-identical to the reference's function. LFS_E_UNSUPPORTED if the tree is deeper than 128 levels.
+ *      lfs_mean_neighbor_distances_exact (extension): the same quantity from an exact all-pairs search; asynchronous. */
 LFS_API int lfs_image_u8_to_chw_f32(const uint8_t* src_hwc, uint32_t src_width, uint32_t src_height, float* dst_chw, uint32_t dst_width,
                                     uint32_t dst_height, lfs_stream_t stream);
 LFS_API int lfs_mean_neighbor_distances(uint32_t N, const float* points, float* out, lfs_stream_t stream);
+LFS_API int lfs_mean_neighbor_distances_exact(uint32_t N, const float* points, float* out, lfs_stream_t stream);
 
 /* ---- gsplat::quats_to_rotmats (gsplat/Ops.h:45-48, QuatToRotmatCUDA.cu:14-39): rotmats [N,3,3] row-major */
 LFS_API int lfs_quats_to_rotmats(uint32_t N, const float* quats, float* rotmats, lfs_stream_t stream);

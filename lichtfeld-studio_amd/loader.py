@@ -258,13 +258,15 @@ def write_png(path: str, rgb: np.ndarray) -> None:
 # ---------------------------------------------------------------------------------------------------------------------
 # point cloud -> model, PLY
 # ---------------------------------------------------------------------------------------------------------------------
-def mean_neighbor_distances(points: torch.Tensor) -> torch.Tensor:
-    """compute_mean_neighbor_distances (splat_data.cpp:64-111) on the GPU: [N,3] -> [N]."""
+def mean_neighbor_distances(points: torch.Tensor, exact: bool = False) -> torch.Tensor:
+    """compute_mean_neighbor_distances (splat_data.cpp:64-111): [N,3] -> [N]. The default reproduces the reference's eps = 10 approximate nanoflann query bit
+    for bit (host-built kd-tree, GPU walk; see csrc/dataprep.hip); exact=True is the exact 3-nearest-neighbour mean (an extension)."""
     from .capi import check, load_library, ptr, require_gpu, stream
     points = points.contiguous().float()
     require_gpu(points)
     out = torch.empty(points.shape[0], dtype=torch.float32, device=points.device)
-    check(load_library().lfs_mean_neighbor_distances(C.c_uint32(points.shape[0]), ptr(points), ptr(out), stream()), "mean_neighbor_distances")
+    fn = load_library().lfs_mean_neighbor_distances_exact if exact else load_library().lfs_mean_neighbor_distances
+    check(fn(C.c_uint32(points.shape[0]), ptr(points), ptr(out), stream()), "mean_neighbor_distances")
     return out
 
 

@@ -36,6 +36,7 @@ def build(ref: bool = True) -> None:
         subprocess.run(["make", "-C", _HERE, "refk_loss"], check=True, capture_output=True)
     if ref and os.path.exists("/root/reference/src/loader/formats/colmap.cpp"):   # the reference's COLMAP reader against libtorch
         subprocess.run(["make", "-C", _HERE, "refcolmap"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "refsplatio"], check=True, capture_output=True)
 
 
 def lib():
@@ -628,3 +629,35 @@ def ref_colmap_points(base, text=False):
     pos, col = np.empty((n, 3), np.float32), np.empty((n, 3), np.uint8)
     lib.refcolmap_points(os.fsencode(base), C.c_int(int(text)), pos.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), C.c_int64(n))
     return pos, col
+
+
+# ---- compute_mean_neighbor_distances and write_ply_impl of the reference's splat_data.cpp (oracle/_ref/libref_splat_io.so; ref_splat_io_shim.cpp) --------
+_REF_SPLAT_IO = None
+
+
+def ref_splat_io_lib():
+    global _REF_SPLAT_IO
+    if _REF_SPLAT_IO is None:
+        path = os.path.join(_HERE, "_ref", "libref_splat_io.so")
+        if not os.path.exists(path):
+            return None
+        _REF_SPLAT_IO = C.CDLL(path)
+    return _REF_SPLAT_IO
+
+
+def ref_mean_neighbor_distances(points):
+    points = _f32(points)
+    out = np.empty(points.shape[0], np.float32)
+    ref_splat_io_lib().refsplat_mean_neighbor_distances(C.c_int64(points.shape[0]), _p(points), _p(out))
+    return out
+
+
+def ref_write_ply(root, stem, means, sh0, shN, opacity, scaling, rotation):
+    """SplatData::save_ply of the reference for the raw parameter tensors (sh0 [N,K0,3], shN [N,KN,3]) -> the bytes of <root>/<stem>.ply"""
+    means, sh0, shN, opacity, scaling, rotation = [_f32(x) for x in (means, sh0, shN, opacity, scaling, rotation)]
+    N = means.shape[0]
+    rc = ref_splat_io_lib().refsplat_write_ply(os.fsencode(root), stem.encode(), C.c_int64(N), C.c_int64(sh0.shape[1]), C.c_int64(shN.shape[1]), _p(means), _p(sh0),
+                                               _p(shN), _p(opacity), _p(scaling), _p(rotation))
+    if rc:
+        raise RuntimeError("refsplat_write_ply failed")
+    return open(os.path.join(root, stem + ".ply"), "rb").read()

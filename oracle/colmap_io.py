@@ -266,8 +266,9 @@ def image_to_chw(src_u8, dw=None, dh=None):
 
 
 # ---- point cloud ----
-def mean_neighbor_distances(points):
-    """splat_data.cpp:64-111 with an exact brute-force search (float32 squared distances accumulated in x, y, z order)."""
+def mean_neighbor_distances_exact(points):
+    """splat_data.cpp:64-111 with an exact brute-force search (float32 squared distances accumulated in x, y, z order): what the function's comment says it
+    computes. The reference's actual query is approximate - see mean_neighbor_distances."""
     p = points.astype(F32)
     n = len(p)
     if n <= 1:
@@ -277,12 +278,166 @@ def mean_neighbor_distances(points):
         d = p[i] - p
         d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(F32) + d[:, 2] * d[:, 2]).astype(F32)
         best = np.sort(d2, kind="stable")[:min(4, n)]
-        vals = [F32(np.sqrt(v)) for v in best if v > 1e-8][:3]
-        s = F32(0)
-        for v in vals:
-            s = F32(s + v)
-        out[i] = F32(s / F32(len(vals))) if vals else F32(0.01)
+        out[i] = _mean_of_results(best)
     return out
+
+
+def _mean_of_results(best):
+    """splat_data.cpp:99-109: up to 3 of the (ascending) results with d^2 > 1e-8"""
+    vals = [F32(np.sqrt(F32(v))) for v in best if v > F32(1e-8)][:3]
+    s = F32(0)
+    for v in vals:
+        s = F32(s + v)
+    return F32(s / F32(len(vals))) if vals else F32(0.01)
+
+
+class NanoflannTree:
+    """The kd-tree the reference queries (vendored include/external/nanoflann.hpp v1.7.1, KDTreeSingleIndexAdaptor<L2_Simple_Adaptor<float>, ., 3> built with
+    KDTreeSingleIndexAdaptorParams(10): leaf size 10, one build thread), restated from the published algorithm: divideTree (:1056-1108), middleSplit_
+    (:1199-1247), planeSplit (:1258-1297), computeMinMax (:1035-1047), searchLevel (:1740-1805), KNNResultSet::addPoint / worstDist (:222-257). float32
+    throughout, python floats only where a value is exactly representable. Pinned by tests/golden/ref_splat_io.npz (the reference's function run on the CPU)."""
+
+    def __init__(self, points, leaf=10):
+        self.p = np.ascontiguousarray(points, F32)
+        n = len(self.p)
+        self.order = list(range(n))
+        self.leaf = leaf
+        lo, hi = self.p.min(0), self.p.max(0)
+        box = [[F32(lo[d]), F32(hi[d])] for d in range(3)]
+        self.root = self._divide(0, n, box)
+        self.root_box = box                               # divideTree leaves the union of the leaves' boxes in root_bbox_
+
+    def _at(self, k, d):
+        return self.p[self.order[k], d]
+
+    def _plane_split(self, ind, count, d, cutval):
+        o, at = self.order, self._at
+        left, right = 0, count - 1
+        while True:
+            while left <= right and at(ind + left, d) < cutval:
+                left += 1
+            while right and left <= right and at(ind + right, d) >= cutval:
+                right -= 1
+            if left > right or not right:
+                break
+            o[ind + left], o[ind + right] = o[ind + right], o[ind + left]
+            left += 1
+            right -= 1
+        lim1 = left
+        right = count - 1
+        while True:
+            while left <= right and at(ind + left, d) <= cutval:
+                left += 1
+            while right and left <= right and at(ind + right, d) > cutval:
+                right -= 1
+            if left > right or not right:
+                break
+            o[ind + left], o[ind + right] = o[ind + right], o[ind + left]
+            left += 1
+            right -= 1
+        return lim1, left
+
+    def _middle_split(self, ind, count, box):
+        eps = F32(0.00001)
+        spans = [F32(box[d][1] - box[d][0]) for d in range(3)]
+        max_span = max(spans)
+        max_spread, cutfeat, min_elem, max_elem = F32(-1), 0, F32(0), F32(0)
+        sub = self.p[self.order[ind:ind + count]]
+        for d in range(3):
+            if spans[d] >= F32(F32(1 - eps) * max_span):
+                lo, hi = sub[:, d].min(), sub[:, d].max()
+                if F32(hi - lo) > max_spread:
+                    cutfeat, max_spread, min_elem, max_elem = d, F32(hi - lo), lo, hi
+        split = F32(F32(box[cutfeat][0] + box[cutfeat][1]) / F32(2))
+        cutval = min_elem if split < min_elem else max_elem if split > max_elem else split
+        lim1, lim2 = self._plane_split(ind, count, cutfeat, cutval)
+        half = count // 2
+        index = lim1 if lim1 > half else lim2 if lim2 < half else half
+        return index, cutfeat, cutval
+
+    def _divide(self, left, right, box):
+        if right - left <= self.leaf:
+            sub = self.p[self.order[left:right]]
+            for d in range(3):
+                box[d][0], box[d][1] = sub[:, d].min(), sub[:, d].max()
+            return ("leaf", left, right)
+        idx, cutfeat, cutval = self._middle_split(left, right - left, box)
+        lb, rb = [list(b) for b in box], [list(b) for b in box]
+        lb[cutfeat][1] = cutval
+        c1 = self._divide(left, left + idx, lb)
+        rb[cutfeat][0] = cutval
+        c2 = self._divide(left + idx, right, rb)
+        for d in range(3):
+            box[d][0], box[d][1] = min(lb[d][0], rb[d][0]), max(lb[d][1], rb[d][1])
+        return ("node", cutfeat, lb[cutfeat][1], rb[cutfeat][0], c1, c2)
+
+    def knn(self, vec, k, eps):
+        """findNeighbors (:1570-1596) with a KNNResultSet of capacity k -> ascending squared distances, zero-padded like the caller's std::vector"""
+        vec = np.asarray(vec, F32)
+        res = []                                          # ascending; worstDist() = FLT_MAX until k entries
+
+        def worst():
+            return F32(np.finfo(F32).max) if len(res) < k else res[-1]
+
+        def add(dist):
+            i = len(res)
+            while i > 0 and res[i - 1] > dist:
+                i -= 1
+            if i < k:
+                res.insert(i, dist)
+                del res[k:]
+
+        eps_error = F32(1 + eps)
+        side = [F32(0)] * 3
+        mind = F32(0)
+        for d in range(3):                                # computeInitialDistances (:1299-1316)
+            if vec[d] < self.root_box[d][0]:
+                side[d] = F32(F32(vec[d] - self.root_box[d][0]) * F32(vec[d] - self.root_box[d][0]))
+                mind = F32(mind + side[d])
+            if vec[d] > self.root_box[d][1]:
+                side[d] = F32(F32(vec[d] - self.root_box[d][1]) * F32(vec[d] - self.root_box[d][1]))
+                mind = F32(mind + side[d])
+
+        def level(node, mindist):
+            if node[0] == "leaf":
+                w = worst()                               # read once per leaf
+                for i in range(node[1], node[2]):
+                    diff = vec - self.p[self.order[i]]
+                    sq = (diff * diff).astype(F32)
+                    dist = F32(F32(sq[0] + sq[1]) + sq[2])
+                    if dist < w:
+                        add(dist)
+                return
+            _, feat, divlow, divhigh, c1, c2 = node
+            val = vec[feat]
+            diff1, diff2 = F32(val - divlow), F32(val - divhigh)
+            if F32(diff1 + diff2) < 0:
+                best, other, cut = c1, c2, F32(diff2 * diff2)
+            else:
+                best, other, cut = c2, c1, F32(diff1 * diff1)
+            level(best, mindist)
+            dst = side[feat]
+            mindist = F32(F32(mindist + cut) - dst)
+            side[feat] = cut
+            if F32(mindist * eps_error) <= worst():
+                level(other, mindist)
+            side[feat] = dst
+
+        level(self.root, mind)
+        return res + [F32(0)] * (k - len(res))
+
+
+def mean_neighbor_distances(points, eps=10.0):
+    """compute_mean_neighbor_distances (splat_data.cpp:64-111) as the reference runs it: nanoflann::SearchParameters(10) (:97) sets eps = 10, so each query is a
+    (1 + eps)-approximate 4-nearest search on the tree above; up to 3 of the results with d^2 > 1e-8 are averaged."""
+    p = np.ascontiguousarray(points, F32)
+    n = len(p)
+    if n <= 1:
+        return np.full(n, 0.01, F32)
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
+    tree = NanoflannTree(p)
+    return np.array([_mean_of_results(tree.knn(p[i], min(4, n), eps)) for i in range(n)], F32)
 
 
 # ---- PLY ----

@@ -1,0 +1,47 @@
+"""Generate tests/golden/ref_splat_io.npz from two host functions of the REFERENCE'S OWN src/core/splat_data.cpp compiled in place (oracle/_ref/libref_splat_io.so,
+`make -C oracle refsplatio`): compute_mean_neighbor_distances (the nanoflann query behind every Gaussian's initial scale) on point sets that exercise the tree
+(duplicates, a lattice, a plane, clusters, coordinates over six orders of magnitude, fewer points than neighbours), and write_ply_impl (the exported splat PLY,
+kept as bytes). Run in the build container, where /root/reference exists:   python oracle/make_golden_ref_splat_io.py
+tests/test_loader_reference.py (oracle restatement, emulated product kernel, PLY writer) and tests/test_gpu_refk_golden.py (the GPU kernel) compare with it."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+
+
+def point_sets():
+    rng = np.random.default_rng(77)
+    sets = {"gauss_1500": rng.standard_normal((1500, 3)), "n1": rng.standard_normal((1, 3)), "n2": rng.standard_normal((2, 3)), "n3": rng.standard_normal((3, 3)),
+            "n11": rng.standard_normal((11, 3)), "triplicates_600": np.repeat(rng.standard_normal((200, 3)), 3, 0),
+            "lattice_512": np.stack(np.meshgrid(*[np.arange(8.)] * 3), -1).reshape(-1, 3), "planar_800": np.concatenate([rng.standard_normal((800, 2)), np.zeros((800, 1))], 1),
+            "clusters_1600": np.concatenate([rng.standard_normal((200, 3)) * 0.01 + c for c in rng.standard_normal((8, 3)) * 5]),
+            "lognormal_1000": np.exp(rng.standard_normal((1000, 3)) * 3), "identical_40": np.ones((40, 3))}
+    return {k: v.astype(np.float32) for k, v in sets.items()}
+
+
+def ply_case():
+    rng = np.random.default_rng(3)
+    N, K = 101, 9
+    return dict(means=rng.standard_normal((N, 3)), sh0=rng.standard_normal((N, 1, 3)), shN=rng.standard_normal((N, K - 1, 3)), opacity=rng.standard_normal((N, 1)),
+                scaling=rng.standard_normal((N, 3)), rotation=rng.standard_normal((N, 4)) * 3)
+
+
+if __name__ == "__main__":
+    assert oracle.ref_splat_io_lib() is not None, "build oracle/_ref/libref_splat_io.so first (make -C oracle refsplatio)"
+    out = {}
+    for name, pts in point_sets().items():
+        out[f"knn/{name}/points"] = pts
+        out[f"knn/{name}/mean_dist"] = oracle.ref_mean_neighbor_distances(pts)
+    c = {k: v.astype(np.float32) for k, v in ply_case().items()}
+    for k, v in c.items():
+        out[f"ply/{k}"] = v
+    with tempfile.TemporaryDirectory() as d:
+        out["ply/file_bytes"] = np.frombuffer(oracle.ref_write_ply(d, "splat", c["means"], c["sh0"], c["shN"], c["opacity"], c["scaling"], c["rotation"]), np.uint8)
+    path = os.path.join(ROOT, "tests", "golden", "ref_splat_io.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path) // 1024, "KiB")

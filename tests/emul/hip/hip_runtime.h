@@ -29,7 +29,10 @@ typedef void* hipStream_t;
 enum { hipSuccess = 0 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
-enum { hipMemcpyDeviceToDevice = 3, hipMemcpyDeviceToHost = 2, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum { hipMemcpyDeviceToDevice = 3, hipMemcpyDeviceToHost = 2, hipMemcpyHostToDevice = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : 2; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 
@@ -188,6 +191,7 @@ template <class T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = o
 template <class T> static inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicExch(T* p, T v) { const T o = *p; *p = v; return o; }
 static inline size_t min(size_t a, size_t b) { return a < b ? a : b; }
 static inline long long min(long long a, long long b) { return a < b ? a : b; }
 static inline long min(long a, long b) { return a < b ? a : b; }

@@ -4,6 +4,8 @@ and fastgs' adam_kernels.cuh run on the CPU by oracle/ref_kernels.cpp; generator
 "HIP vs the reference" for the ops SURVEY.md §8c lists as unpinned, incl. BASELINE.json configs[0]'s shape (10k Gaussians, 256x256: `syn_a`).
 Bars: SURVEY.md §8c - integer radii +-1 on < 0.2 %, means2d 1e-2 px (UT fp32 noise floor), forward mean |diff| <= 2e-6 and last_ids >= 99.9 %,
 backward relative L2 <= 2e-4 with the alpha-threshold flip rows counted (gpu_util.rows_check), Adam bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -140,3 +142,16 @@ def test_hip_bilateral_tv_matches_the_reference_kernel(lfs, name):
     loss = float(bg.tv_loss_forward(t(d["grids"])).item())
     assert abs(loss - float(d["tv_loss"])) <= 1e-5 * float(d["tv_loss"])
     lg.close(n(bg.tv_loss_backward(t(d["grids"]), float(d["grad_output"]))), d["grad_grids"], 3e-6, "tv grad")
+
+
+# ---- the neighbour distances behind the initial scales against the reference's own function (tests/golden/ref_splat_io.npz) ----------------------------------
+@pytest.mark.parametrize("name", sorted({k.split("/")[1] for k in np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_splat_io.npz")).files
+                                         if k.startswith("knn/")}))
+def test_hip_mean_neighbor_distances_equal_the_reference_function(lfs, name):
+    """loader.mean_neighbor_distances (host-built nanoflann tree, GPU walk: csrc/dataprep.hip) against compute_mean_neighbor_distances of the reference's
+    splat_data.cpp run on the CPU: bit-identical, including the eps = 10 approximation the reference's query makes."""
+    from gpu_util import n, t
+    from lichtfeld_studio_amd import loader
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_splat_io.npz"))
+    got = n(loader.mean_neighbor_distances(t(z[f"knn/{name}/points"])))
+    assert np.array_equal(got, z[f"knn/{name}/mean_dist"]), (name, np.abs(got - z[f"knn/{name}/mean_dist"]).max())
