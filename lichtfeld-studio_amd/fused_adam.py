@@ -128,13 +128,17 @@ class WarmupExponentialLR:
 
 
 def default_param_groups(model, scene_scale: float = 1.0, means_lr=1.6e-4, shs_lr=2.5e-3, scaling_lr=5e-3, rotation_lr=1e-3, opacity_lr=5e-2):
-    """strategy_utils.cpp:20-45 with the learning rates of eval/default_optimization_params.json."""
+    """strategy_utils.cpp:20-45 with the learning rates of eval/default_optimization_params.json. The reference's OptimizationParameters fields and the scene
+    scale are `float`: `means_lr * scene_scale` and `shs_lr / 20.f` are fp32 expressions widened to the optimizer's double afterwards, and so they are here (the
+    scheduler then decays the double; the kernel receives static_cast<float>(lr) - one ulp of the start value can decide that cast)."""
+    import numpy as np
+    f32 = np.float32
     means, sh0, shN, scales, quats, opac = model.parameters()
     return [
-        {"params": [means], "lr": means_lr * scene_scale},
-        {"params": [sh0], "lr": shs_lr},
-        {"params": [shN], "lr": shs_lr / 20.0},
-        {"params": [scales], "lr": scaling_lr},
-        {"params": [quats], "lr": rotation_lr},
-        {"params": [opac], "lr": opacity_lr},
+        {"params": [means], "lr": float(f32(means_lr) * f32(scene_scale))},
+        {"params": [sh0], "lr": float(f32(shs_lr))},
+        {"params": [shN], "lr": float(f32(shs_lr) / f32(20.0))},
+        {"params": [scales], "lr": float(f32(scaling_lr))},
+        {"params": [quats], "lr": float(f32(rotation_lr))},
+        {"params": [opac], "lr": float(f32(opacity_lr))},
     ]

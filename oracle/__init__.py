@@ -37,6 +37,7 @@ def build(ref: bool = True) -> None:
     if ref and os.path.exists("/root/reference/src/loader/formats/colmap.cpp"):   # the reference's COLMAP reader against libtorch
         subprocess.run(["make", "-C", _HERE, "refcolmap"], check=True, capture_output=True)
         subprocess.run(["make", "-C", _HERE, "refsplatio"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "refstrategy"], check=True, capture_output=True)
 
 
 def lib():
@@ -661,3 +662,121 @@ def ref_write_ply(root, stem, means, sh0, shN, opacity, scaling, rotation):
     if rc:
         raise RuntimeError("refsplat_write_ply failed")
     return open(os.path.join(root, stem + ".ply"), "rb").read()
+
+
+# ---- the reference's own strategy layer + FusedAdam on CPU libtorch (oracle/_ref/libref_strategy.so; ref_strategy_shim.cpp) ---------------------------------
+_REF_STRATEGY = None
+
+
+class RefParams(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("iterations", "sh_degree_interval", "refine_every", "start_refine", "stop_refine", "reset_every", "pause_refine_after_reset")] + \
+               [(k, C.c_float) for k in ("means_lr", "shs_lr", "opacity_lr", "scaling_lr", "rotation_lr", "min_opacity", "grad_threshold", "prune_opacity", "grow_scale3d",
+                                         "prune_scale3d", "opacity_reg", "scale_reg", "lambda_dssim", "init_opacity", "init_scaling")] + \
+               [(k, C.c_int32) for k in ("max_cap", "revised_opacity", "sh_degree")]
+
+
+def ref_strategy_lib():
+    global _REF_STRATEGY
+    if _REF_STRATEGY is None:
+        path = os.path.join(_HERE, "_ref", "libref_strategy.so")
+        if not os.path.exists(path):
+            return None
+        lib = C.CDLL(path)
+        lib.refstrat_last_error.restype = C.c_char_p
+        lib.refstrat_log_name.restype = C.c_char_p
+        lib.refstrat_lr.restype = C.c_double
+        for f in ("refstrat_size", "refstrat_get", "refstrat_step_count", "refstrat_log_count", "refstrat_log_numel"):
+            getattr(lib, f).restype = C.c_int64
+        _REF_STRATEGY = lib
+    return _REF_STRATEGY
+
+
+def ref_strategy_default_params():
+    """gs::param::OptimizationParameters{} of the reference (include/core/parameters.hpp) -> dict"""
+    p = RefParams()
+    ref_strategy_lib().refstrat_default_params(C.byref(p))
+    return {k: getattr(p, k) for k, _ in RefParams._fields_}
+
+
+class RefStrategy:
+    """gs::training::MCMC (kind 'mcmc') or DefaultStrategy ('default') of the reference, initialised from raw parameter arrays: means [N,3], sh0 [N,1,3],
+    shN [N,K,3], scaling [N,3], rotation [N,4], opacity [N] (raw). State is read back as numpy arrays in the param-group order of strategy_utils.cpp:35-40."""
+    NAMES = ("means", "sh0", "shN", "scaling", "rotation", "opacity")
+
+    def __init__(self, kind, means, sh0, shN, scaling, rotation, opacity, scene_scale, sh_degree, **params):
+        self.lib = ref_strategy_lib()
+        p = RefParams()
+        self.lib.refstrat_default_params(C.byref(p))
+        for k, v in params.items():
+            assert hasattr(p, k), k
+            setattr(p, k, v)
+        arrs = [_f32(x) for x in (means, sh0, shN, scaling, rotation, opacity)]
+        N, K = arrs[0].shape[0], arrs[2].shape[1]
+        self.h = C.c_void_p()
+        self._ok(self.lib.refstrat_create(C.c_int({"mcmc": 0, "default": 1}[kind]), C.c_int64(N), C.c_int64(K), C.c_int(sh_degree), *[_p(a) for a in arrs],
+                                          C.c_float(scene_scale), C.byref(p), C.byref(self.h)))
+
+    def _ok(self, rc):
+        if rc:
+            raise RuntimeError(self.lib.refstrat_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.refstrat_destroy(self.h)
+            self.h = None
+
+    def size(self):
+        return self.lib.refstrat_size(self.h)
+
+    def get(self, which, what=0):
+        """what: 0 parameter, 1 exp_avg, 2 exp_avg_sq -> flat float32 array, or None when the optimizer has no state for it yet"""
+        n = self.lib.refstrat_get(self.h, C.c_int(which), C.c_int(what), None)
+        if n < 0:
+            return None
+        out = np.empty(n, np.float32)
+        self.lib.refstrat_get(self.h, C.c_int(which), C.c_int(what), _p(out))
+        return out
+
+    def state(self):
+        out = {}
+        for i, name in enumerate(self.NAMES):
+            out[name] = self.get(i, 0)
+            for what, tag in ((1, "exp_avg"), (2, "exp_avg_sq")):
+                a = self.get(i, what)
+                if a is not None:
+                    out[f"{name}.{tag}"] = a
+            out[f"{name}.step"] = np.int64(self.lib.refstrat_step_count(self.h, C.c_int(i)))
+        out["lr"] = np.array([self.lib.refstrat_lr(self.h, C.c_int(g)) for g in range(6)])
+        out["active_sh_degree"] = np.int64(self.lib.refstrat_active_sh_degree(self.h))
+        return out
+
+    def set_grads(self, grads):
+        arrs = [_f32(g) for g in grads]
+        ptrs = (C.c_void_p * 6)(*[a.ctypes.data for a in arrs])
+        self._ok(self.lib.refstrat_set_grads(self.h, ptrs))
+
+    def set_densification_info(self, info):
+        info = _f32(info)
+        assert info.shape == (2, self.size())
+        self._ok(self.lib.refstrat_set_densification_info(self.h, _p(info)))
+
+    def step(self, it):
+        self._ok(self.lib.refstrat_step(self.h, C.c_int(it)))
+
+    def is_refining(self, it):
+        return bool(self.lib.refstrat_is_refining(self.h, C.c_int(it)))
+
+    def post_backward(self, it, seed):
+        """-> the random draws the call made, in order: [(name, array)]"""
+        self._ok(self.lib.refstrat_post_backward(self.h, C.c_int(it), C.c_uint64(seed)))
+        draws = []
+        for i in range(self.lib.refstrat_log_count()):
+            n = self.lib.refstrat_log_numel(C.c_int64(i))
+            a = np.empty(n, np.int64 if self.lib.refstrat_log_is_int64(C.c_int64(i)) else np.float32)
+            self.lib.refstrat_log_copy(C.c_int64(i), a.ctypes.data_as(C.c_void_p))
+            draws.append((self.lib.refstrat_log_name(C.c_int64(i)).decode(), a))
+        return draws
+
+    def remove_gaussians(self, mask):
+        m = np.ascontiguousarray(mask, np.uint8)
+        self._ok(self.lib.refstrat_remove_gaussians(self.h, m.ctypes.data_as(C.c_void_p)))
