@@ -780,3 +780,19 @@ class RefStrategy:
     def remove_gaussians(self, mask):
         m = np.ascontiguousarray(mask, np.uint8)
         self._ok(self.lib.refstrat_remove_gaussians(self.h, m.ctypes.data_as(C.c_void_p)))
+
+
+def ref_init_model_from_pointcloud(positions, colors_u8, scene_center, sh_degree=3, init_scaling=1.0, init_opacity=0.1):
+    """SplatData::init_model_from_pointcloud of the reference (splat_data.cpp:508-614, non-random branch) -> dict of the six raw parameter arrays + scene_scale"""
+    positions, center = _f32(positions), _f32(scene_center)
+    colors = np.ascontiguousarray(colors_u8, np.uint8)
+    N, K = positions.shape[0], (sh_degree + 1) ** 2 - 1
+    out = dict(means=np.empty((N, 3), np.float32), sh0=np.empty((N, 1, 3), np.float32), shN=np.empty((N, K, 3), np.float32), scaling=np.empty((N, 3), np.float32),
+               rotation=np.empty((N, 4), np.float32), opacity=np.empty((N, 1), np.float32))
+    scale = C.c_float()
+    rc = ref_splat_io_lib().refsplat_init_model(C.c_int64(N), _p(positions), colors.ctypes.data_as(C.c_void_p), _p(center), C.c_int(sh_degree), C.c_float(init_scaling),
+                                                C.c_float(init_opacity), *[_p(out[k]) for k in ("means", "sh0", "shN", "scaling", "rotation", "opacity")], C.byref(scale))
+    if rc:
+        raise RuntimeError("refsplat_init_model failed")
+    out["scene_scale"] = np.float32(scale.value)
+    return out

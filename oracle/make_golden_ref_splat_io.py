@@ -1,7 +1,7 @@
 """Generate tests/golden/ref_splat_io.npz from two host functions of the REFERENCE'S OWN src/core/splat_data.cpp compiled in place (oracle/_ref/libref_splat_io.so,
 `make -C oracle refsplatio`): compute_mean_neighbor_distances (the nanoflann query behind every Gaussian's initial scale) on point sets that exercise the tree
-(duplicates, a lattice, a plane, clusters, coordinates over six orders of magnitude, fewer points than neighbours), and write_ply_impl (the exported splat PLY,
-kept as bytes). Run in the build container, where /root/reference exists:   python oracle/make_golden_ref_splat_io.py
+(duplicates, a lattice, a plane, clusters, coordinates over six orders of magnitude, fewer points than neighbours), write_ply_impl (the exported splat PLY,
+kept as bytes) and SplatData::init_model_from_pointcloud (point cloud -> initial Gaussians). Run in the build container, where /root/reference exists:   python oracle/make_golden_ref_splat_io.py
 tests/test_loader_reference.py (oracle restatement, emulated product kernel, PLY writer) and tests/test_gpu_refk_golden.py (the GPU kernel) compare with it."""
 import os
 import sys
@@ -24,6 +24,15 @@ def point_sets():
     return {k: v.astype(np.float32) for k, v in sets.items()}
 
 
+def init_cases():
+    """point clouds for SplatData::init_model_from_pointcloud: (positions, colours u8, scene centre, sh degree, init_scaling, init_opacity)"""
+    rng = np.random.default_rng(41)
+    a = (rng.standard_normal((700, 3)) * [3.0, 1.0, 0.3]).astype(np.float32)
+    b = np.repeat(rng.standard_normal((80, 3)), 2, 0).astype(np.float32)             # duplicates: the 1e-7 clamp of the neighbour distance
+    return {"sfm_700_deg3_default_json": (a, rng.integers(0, 256, (700, 3)).astype(np.uint8), np.array([0.2, -0.1, 0.4], np.float32), 3, 1.0, 0.1),
+            "dups_160_deg1_mcmc_json": (b, rng.integers(0, 256, (160, 3)).astype(np.uint8), np.array([0.0, 0.0, 0.0], np.float32), 1, 0.1, 0.5)}
+
+
 def ply_case():
     rng = np.random.default_rng(3)
     N, K = 101, 9
@@ -37,6 +46,12 @@ if __name__ == "__main__":
     for name, pts in point_sets().items():
         out[f"knn/{name}/points"] = pts
         out[f"knn/{name}/mean_dist"] = oracle.ref_mean_neighbor_distances(pts)
+    for name, (pos, col, center, deg, i_s, i_o) in init_cases().items():
+        r = oracle.ref_init_model_from_pointcloud(pos, col, center, deg, i_s, i_o)
+        out.update({f"init/{name}/positions": pos, f"init/{name}/colors": col, f"init/{name}/scene_center": center,
+                    f"init/{name}/config": np.array([deg, i_s, i_o], np.float64)})
+        # rotation (identity), opacity (one value) and shN (zeros) are constant: keep their first rows only
+        out.update({f"init/{name}/out_{k}": (v if k in ("means", "sh0", "scaling", "scene_scale") else v[:2]) for k, v in r.items()})
     c = {k: v.astype(np.float32) for k, v in ply_case().items()}
     for k, v in c.items():
         out[f"ply/{k}"] = v

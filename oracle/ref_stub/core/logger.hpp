@@ -30,6 +30,7 @@ namespace std {
         ref_stub_detail::emit(os, f, a...);
         return os.str();
     }
+    template <class... A> inline void println(std::string_view, const A&...) {} // <print> (C++23): progress messages only
 } // namespace std
 
 #define LOG_TRACE(...)       ((void)0)

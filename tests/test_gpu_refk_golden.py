@@ -155,3 +155,25 @@ def test_hip_mean_neighbor_distances_equal_the_reference_function(lfs, name):
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_splat_io.npz"))
     got = n(loader.mean_neighbor_distances(t(z[f"knn/{name}/points"])))
     assert np.array_equal(got, z[f"knn/{name}/mean_dist"]), (name, np.abs(got - z[f"knn/{name}/mean_dist"]).max())
+
+
+@pytest.mark.parametrize("name", ["sfm_700_deg3_default_json", "dups_160_deg1_mcmc_json"])
+def test_hip_init_model_from_pointcloud_equals_the_reference_function(lfs, name):
+    """loader.init_model_from_pointcloud against SplatData::init_model_from_pointcloud of the reference's splat_data.cpp run on the CPU: means and the neighbour
+    distances behind the scales are the same bits; log / sqrt / the colour conversion and the median distance differ by the GPU's libm (1e-6)."""
+    from gpu_util import n
+    from lichtfeld_studio_amd import loader
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_splat_io.npz"))
+    g = lambda k: z[f"init/{name}/{k}"]
+    deg, init_scaling, init_opacity = g("config")
+    model, scene_scale = loader.init_model_from_pointcloud(loader.PointCloud(g("positions"), g("colors")), g("scene_center"), int(deg), float(init_scaling),
+                                                          float(init_opacity))
+    N = g("positions").shape[0]
+    assert np.array_equal(n(model.means), g("out_means"))
+    np.testing.assert_allclose(n(model.sh0), g("out_sh0"), rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(n(model.raw_scales), g("out_scaling"), rtol=2e-6, atol=2e-6)
+    assert abs(scene_scale - float(g("out_scene_scale"))) <= 2e-6 * float(g("out_scene_scale"))
+    assert model.shN.shape == (N,) + g("out_shN").shape[1:] and float(model.shN.abs().max()) == 0 and float(np.abs(g("out_shN")).max()) == 0
+    assert np.array_equal(n(model.raw_quats), np.tile(g("out_rotation")[0], (N, 1))) and list(g("out_rotation")[0]) == [1, 0, 0, 0]
+    np.testing.assert_allclose(n(model.raw_opacities), np.full(N, g("out_opacity")[0, 0]), rtol=1e-6, atol=1e-7)
+    assert model.active_sh_degree == 0 and model.max_sh_degree == int(deg)

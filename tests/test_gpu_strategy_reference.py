@@ -5,7 +5,8 @@ same gradients, step(iter), post_backward(iter), with every random draw the refe
   * MCMC relocation: the reference's multinomial picks become the uniforms that make lfs_mcmc_relocate's inverse-CDF search pick the same sources;
   * MCMC growth: the multinomial indices; SGLD noise and ADC split offsets: the normal deviates.
 Compared after every refining / resetting iteration and at the end: Gaussian count, SH degree, per-group learning rate and Adam step counts exactly; the 6 parameter
-tensors and both Adam moments to 2e-5 relative + 1e-7 (gsplat::relocation sums ~1300 fp32 binomial terms; the SGLD kernel uses the fast exponential)."""
+tensors and both Adam moments to 2e-5 relative + 1e-7 (gsplat::relocation sums ~1300 fp32 binomial terms); the MCMC means to 2e-5 relative + 5e-5 (ten SGLD
+steps of magnitude ~10 each through the fast exponential)."""
 import os
 
 import numpy as np
@@ -68,7 +69,7 @@ def draws_of(name, it):
     return [(nm, GOLD[f"{name}/it{it}/draw{k}"]) for k, nm in enumerate(names)]
 
 
-def compare(st, name, it, full):
+def compare(st, name, it, full, means_atol=1e-7):
     m = st.model
     pre = f"{name}/it{it}/"
     assert m.means.shape[0] == int(GOLD[pre + "N"]), (it, m.means.shape[0], int(GOLD[pre + "N"]))
@@ -88,7 +89,7 @@ def compare(st, name, it, full):
                 continue
             ref, got = GOLD[pre + ref_name + key], n(got).reshape(-1)
             assert ref.shape == got.shape, (it, ref_name, key, ref.shape, got.shape)
-            err = np.abs(got - ref) / (2e-5 * np.abs(ref) + 1e-7)
+            err = np.abs(got - ref) / (2e-5 * np.abs(ref) + (means_atol if ref_name == "means" and not key else 1e-7))
             worst = max(worst, float(err.max()) if err.size else 0.0)
             assert np.isfinite(got).all() and (err <= 1).all(), (it, ref_name + key, float(err.max()), int(err.argmax()))
             if key and ref.size:                       # which rows carry zeroed moments is exact
@@ -136,7 +137,9 @@ def test_mcmc_follows_the_reference_strategy(lfs, name):
         with Patched(rand=rand, randn=lambda shape, **kw: t(noise).reshape(tuple(shape))):
             st.post_backward(it)
         assert bool(GOLD[f"{name}/it{it}/refining"]) == st.is_refining(it)
-        worst = max(worst, compare(st, name, it, it in sc["full_state"]))
+        # means: every iteration adds lr * 5e5 (= 100 here) x Sigma x noise x gate(opacity) - terms of magnitude 10, whose fp32 rounding (and the kernel's fast
+        # exponential in the gate) is what the two sides differ by: 5e-5 absolute after ten iterations, against displacements of order 1 - 10 per iteration
+        worst = max(worst, compare(st, name, it, it in sc["full_state"], means_atol=5e-5))
     print(f"{name}: worst deviation {worst:.3f} of the bar (2e-5 relative + 1e-7)")
 
 

@@ -256,6 +256,13 @@ def test_live_splat_io_golden_regenerates_and_random_sets_agree(emulated_datapre
     from oracle import make_golden_ref_splat_io as mg
     for name, pts in mg.point_sets().items():
         assert np.array_equal(pts, SPLAT[f"knn/{name}/points"]) and np.array_equal(oracle.ref_mean_neighbor_distances(pts), SPLAT[f"knn/{name}/mean_dist"]), name
+    for name, (pos, col, center, deg, i_s, i_o) in mg.init_cases().items():
+        r = oracle.ref_init_model_from_pointcloud(pos, col, center, deg, i_s, i_o)
+        for k, v in r.items():
+            ref = SPLAT[f"init/{name}/out_{k}"]
+            assert np.array_equal(v if k in ("means", "sh0", "scaling", "scene_scale") else v[:2], ref), (name, k)
+            if k in ("rotation", "opacity", "shN"):                  # constant tensors: the committed two rows stand for all
+                assert (v == v[:1]).all(), (name, k)
     rng = np.random.default_rng(2025)
     for k in range(6):                                           # fresh sets, larger than the committed ones
         n_pts = int(rng.integers(2000, 20000))
