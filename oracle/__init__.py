@@ -37,9 +37,9 @@ def build(ref: bool = True) -> None:
     if ref and os.path.exists("/root/reference/src/training/kernels/ssim.cu"):   # the reference's fused SSIM / bilateral-grid kernels as host code
         subprocess.run(["make", "-C", _HERE, "refk_loss"], check=True, capture_output=True)
     if ref and os.path.exists("/root/reference/src/loader/formats/colmap.cpp"):
-        # the reference's host C++ against CPU libtorch: COLMAP reader, splat_data.cpp's host functions, the strategy layer + FusedAdam. Minutes of libtorch
+        # the reference's host C++ against CPU libtorch: COLMAP reader, splat_data.cpp's host functions, the strategy layer + FusedAdam, the render path. Minutes of libtorch
         # headers when built from scratch, so in parallel, and a failure here (they only serve the *_reference tests, which skip without them) does not fail build()
-        subprocess.run(["make", "-C", _HERE, "-j3", "refcolmap", "refsplatio", "refstrategy"], check=False, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "-j4", "refcolmap", "refsplatio", "refstrategy", "refraster"], check=False, capture_output=True)
 
 
 def lib():
@@ -797,4 +797,40 @@ def ref_init_model_from_pointcloud(positions, colors_u8, scene_center, sh_degree
     if rc:
         raise RuntimeError("refsplat_init_model failed")
     out["scene_scale"] = np.float32(scale.value)
+    return out
+
+
+# ---- the reference's own training-time render path on the CPU (oracle/_ref/libref_raster.so; ref_raster_shim.cpp) ---------------------------------------------
+_REF_RASTER = None
+
+
+def ref_raster_lib():
+    global _REF_RASTER
+    if _REF_RASTER is None:
+        path = os.path.join(_HERE, "_ref", "libref_raster.so")
+        if not os.path.exists(path):
+            return None
+        _REF_RASTER = C.CDLL(path)
+    return _REF_RASTER
+
+
+def ref_render_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, v_image, v_alpha=None):
+    """gs::training::rasterize() of the reference for one pinhole camera + backward of sum(image * v_image) [+ sum(alpha * v_alpha)] through its autograd
+    Functions: raw parameters as SplatData holds them (sh0 [N,1,3], shN [N,K,3], opacity [N]) -> dict(image [3,H,W], alpha [1,H,W], radii [N], viewmat [4,4],
+    K [3,3], g_means, g_sh0, g_shN, g_scaling, g_rotation, g_opacity)"""
+    arrs = [_f32(x) for x in (means, sh0, shN, scaling, rotation, opacity)]
+    N, K1 = arrs[0].shape[0], arrs[2].shape[1]
+    R, T, v_image = _f32(R), _f32(T), _f32(v_image)
+    bg = None if bg is None else _f32(bg)
+    v_alpha = None if v_alpha is None else _f32(v_alpha)
+    out = dict(image=np.empty((3, height, width), np.float32), alpha=np.empty((1, height, width), np.float32), radii=np.empty(N, np.int32),
+               g_means=np.empty((N, 3), np.float32), g_sh0=np.empty((N, 1, 3), np.float32), g_shN=np.empty((N, K1, 3), np.float32), g_scaling=np.empty((N, 3), np.float32),
+               g_rotation=np.empty((N, 4), np.float32), g_opacity=np.empty(N, np.float32), viewmat=np.empty((4, 4), np.float32), K=np.empty((3, 3), np.float32))
+    rc = ref_raster_lib().refraster_render_backward(
+        C.c_int64(N), C.c_int64(K1), C.c_int(sh_degree), C.c_int(active_sh_degree), *[_p(a) for a in arrs], _p(R), _p(T), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+        C.c_float(cy), C.c_int(width), C.c_int(height), C.c_int(width), C.c_int(height), None if bg is None else _p(bg), _p(v_image),
+        None if v_alpha is None else _p(v_alpha), _p(out["image"]), _p(out["alpha"]), out["radii"].ctypes.data_as(C.c_void_p),
+        *[_p(out[k]) for k in ("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity", "viewmat", "K")])
+    if rc:
+        raise RuntimeError("refraster_render_backward failed")
     return out

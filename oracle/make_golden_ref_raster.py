@@ -1,0 +1,35 @@
+"""Generate tests/golden/ref_raster.npz by running the REFERENCE'S OWN training-time render path end to end on the CPU (oracle/_ref/libref_raster.so: rasterizer.cpp,
+rasterizer_autograd.cpp, camera.cpp, SplatData's activations compiled in place against libtorch, over the reference's device kernels under ref_emul/ and its
+tests/torch_impl.cpp; `make -C oracle ref refk refraster`) on the scenes of tests/refraster_util.py: image, alpha, radii, the camera matrices the Camera class
+derives, and the gradients of the six raw parameter tensors for the loss sum(image * v_image) [+ sum(alpha * v_alpha)]. Run in the build container:
+    python oracle/make_golden_ref_raster.py
+tests/test_gpu_raster_reference.py holds the product's rasterize() + backward to it - the composition of SURVEY.md §8 rows a1-a6 as the reference composes them."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle  # noqa: E402
+import refraster_util as U  # noqa: E402
+
+
+def run(c):
+    s = U.scene(c)
+    return oracle.ref_render_backward(s["means"], s["sh0"], s["shN"], s["scaling"], s["rotation"], s["opacity"], c["sh_degree"], c["active"], s["R"], s["T"], c["focal"],
+                                      c["focal"] * 1.05, c["W"] / 2 + 0.5, c["H"] / 2 - 0.25, c["W"], c["H"], c["bg"], s["v_image"], s["v_alpha"])
+
+
+if __name__ == "__main__":
+    assert oracle.ref_raster_lib() is not None, "build oracle/_ref/libref_raster.so first (make -C oracle ref refk refraster)"
+    out = {}
+    for name, c in U.CASES.items():
+        r = run(c)
+        print(f"{name}: visible {(r['radii'] > 0).sum()} of {c['N']}, mean alpha {r['alpha'].mean():.3f}, |g_means| max {np.abs(r['g_means']).max():.3g}")
+        for k, v in r.items():
+            out[f"{name}/{k}"] = v
+    path = os.path.join(ROOT, "tests", "golden", U.GOLD)
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path) // 1024, "KiB")

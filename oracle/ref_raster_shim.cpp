@@ -1,0 +1,225 @@
+// ORACLE/_ref - TEST INFRASTRUCTURE ONLY.
+// The reference's OWN training-time render path, end to end, on the CPU (oracle/Makefile, `make refraster`):
+//   src/training/rasterization/rasterizer.cpp        gs::training::rasterize(): camera -> projection -> SH colours -> tile intersection -> rasterization, the
+//                                                    colour offset / clamps / masks / background handling around them   (whole file)
+//   src/training/rasterization/rasterizer_autograd.cpp   the autograd Functions behind it (SH, projection wrapper, GUT rasterization)   (whole file)
+//   src/core/camera.cpp                              Camera: world_view_transform, K() with the image / camera size scaling   (whole file)
+//   src/core/splat_data.cpp:200-287, 386-434         SplatData's constructors, activations (get_opacity ...), SH degree
+// compiled in place against CPU libtorch with their real headers (rasterizer.hpp, rasterizer_autograd.hpp, core/camera.hpp, core/splat_data.hpp, gsplat/Ops.h,
+// Cameras.h, Common.h). sed edits on the way into the scratch directory (Makefile): torch::kCUDA -> torch::kCPU, and the single-line `TORCH_CHECK(x.is_cuda(), ...)`
+// device assertions dropped. The gsplat operators the path calls are defined below as their host launch sequences over the reference's own code run on the CPU:
+//   projection_ut_3dgs_fused, rasterize_to_pixels_from_world_3dgs_fwd / _bwd : the device kernels (oracle/_ref/libref_kernels.so, ref_emul/)
+//   spherical_harmonics_fwd / _bwd, intersect_tile                           : the reference's own CPU implementation tests/torch_impl.cpp (libtorch_impl_ref.so),
+//                                                                              which SURVEY.md §8c records as matching kernels K2 / K3-K5; the vjp by autograd over it
+//   intersect_offset                                                         : restated (IntersectTile.cu:206-252: first index of every tile in the sorted keys)
+// Used by oracle/make_golden_ref_raster.py -> tests/golden/ref_raster.npz: the whole hot path's forward image and parameter gradients as the reference composes
+// them, which tests/test_gpu_raster_reference.py holds the product's render + backward to. Nothing here is product code.
+#include "Ops.h"
+#include "core/camera.hpp"
+#include "core/image_io.hpp"
+#include "core/splat_data.hpp"
+#include "rasterizer.hpp"
+#include "torch_impl.hpp"
+#include <cstring>
+
+#define REF_API extern "C" __attribute__((visibility("default")))
+
+extern "C" {
+void refk_projection_ut(uint32_t C, uint32_t N, const float* means, const float* quats, const float* scales, const float* opacities, const float* viewmats0,
+                        const float* viewmats1, const float* Ks, uint32_t W, uint32_t H, float eps2d, float near_plane, float far_plane, float radius_clip,
+                        int camera_model, const float* ut, int rs_type, const float* radial, const float* tangential, const float* thin_prism, int32_t* radii,
+                        float* means2d, float* depths, float* conics, float* compensations);
+int refk_rasterize_fwd(uint32_t cdim, uint32_t C, uint32_t N, uint32_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
+                       const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t W, uint32_t H, uint32_t tile_size, uint32_t tw, uint32_t th,
+                       const float* vm0, const float* vm1, const float* Ks, int camera_model, const float* ut, int rs_type, const float* radial,
+                       const float* tangential, const float* thin_prism, const int32_t* offsets, const int32_t* flatten_ids, float* render_colors,
+                       float* render_alphas, int32_t* last_ids);
+int refk_rasterize_bwd(uint32_t cdim, uint32_t C, uint32_t N, uint32_t n_isects, const float* means, const float* quats, const float* scales, const float* colors,
+                       const float* opacities, const float* backgrounds, const uint8_t* masks, uint32_t W, uint32_t H, uint32_t tile_size, uint32_t tw, uint32_t th,
+                       const float* vm0, const float* vm1, const float* Ks, int camera_model, const float* ut, int rs_type, const float* radial,
+                       const float* tangential, const float* thin_prism, const int32_t* offsets, const int32_t* flatten_ids, const float* render_alphas,
+                       const int32_t* last_ids, const float* v_render_colors, const float* v_render_alphas, float* v_means, float* v_quats, float* v_scales,
+                       float* v_colors, float* v_opacities);
+}
+
+std::tuple<unsigned char*, int, int, int> load_image(std::filesystem::path, int, int) { throw std::runtime_error("ref_raster_shim: no image loading"); }
+void free_image(unsigned char*) {}
+std::tuple<int, int, int> get_image_info(std::filesystem::path) { throw std::runtime_error("ref_raster_shim: no image loading"); }
+
+namespace {
+    struct UT {
+        float v[5];
+        explicit UT(const UnscentedTransformParameters& p) : v{p.alpha, p.beta, p.kappa, p.in_image_margin_factor, p.require_all_sigma_points_valid ? 1.f : 0.f} {}
+    };
+    const float* opt(const at::optional<at::Tensor>& t) { return (t.has_value() && t->defined() && t->numel() > 0) ? t->data_ptr<float>() : nullptr; }
+    void need_plain_camera(const at::optional<at::Tensor>& vm1, const at::optional<at::Tensor>& r, const at::optional<at::Tensor>& t, const at::optional<at::Tensor>& p) {
+        TORCH_CHECK(!vm1.has_value() && !opt(r) && !opt(t) && !opt(p), "ref_raster_shim: global shutter without distortion only");
+    }
+} // namespace
+
+namespace gsplat {
+    // Projection.cpp:22-110 (ProjectionUT3DGSFused.cu:206-286): outputs allocated, one thread per (camera, Gaussian)
+    std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> projection_ut_3dgs_fused(
+        const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::optional<at::Tensor> opacities, const at::Tensor viewmats0,
+        const at::optional<at::Tensor> viewmats1, const at::Tensor Ks, const uint32_t image_width, const uint32_t image_height, const float eps2d,
+        const float near_plane, const float far_plane, const float radius_clip, const bool calc_compensations, const CameraModelType camera_model,
+        const UnscentedTransformParameters ut_params, ShutterType rs_type, const at::optional<at::Tensor> radial_coeffs,
+        const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs) {
+        need_plain_camera(viewmats1, radial_coeffs, tangential_coeffs, thin_prism_coeffs);
+        const uint32_t N = means.size(0), C = viewmats0.size(0);
+        auto radii = at::empty({C, N, 2}, means.options().dtype(at::kInt));
+        auto means2d = at::empty({C, N, 2}, means.options()), depths = at::empty({C, N}, means.options()), conics = at::empty({C, N, 3}, means.options());
+        at::Tensor compensations;
+        if (calc_compensations) compensations = at::zeros({C, N}, means.options());
+        const UT ut(ut_params);
+        refk_projection_ut(C, N, means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(), opt(opacities), viewmats0.data_ptr<float>(), nullptr,
+                           Ks.data_ptr<float>(), image_width, image_height, eps2d, near_plane, far_plane, radius_clip, (int)camera_model, ut.v, (int)rs_type, nullptr,
+                           nullptr, nullptr, radii.data_ptr<int32_t>(), means2d.data_ptr<float>(), depths.data_ptr<float>(), conics.data_ptr<float>(),
+                           calc_compensations ? compensations.data_ptr<float>() : nullptr);
+        return {radii, means2d, depths, conics, compensations};
+    }
+
+    // SphericalHarmonics.cpp:15-44 over reference::spherical_harmonics (tests/torch_impl.cpp:296-330); masked-out rows are not written by the kernel (at::empty
+    // there, zeros here: they belong to Gaussians without a footprint, which nothing reads)
+    at::Tensor spherical_harmonics_fwd(const uint32_t degrees_to_use, const at::Tensor dirs, const at::Tensor coeffs, const at::optional<at::Tensor> masks) {
+        auto colors = reference::spherical_harmonics((int)degrees_to_use, dirs, coeffs);
+        if (masks.has_value() && masks->defined()) colors = colors * masks->unsqueeze(-1).to(colors.dtype());
+        return colors.contiguous();
+    }
+    // SphericalHarmonics.cpp:46-76: v_coeffs = zeros_like(coeffs) + the kernel's writes, v_dirs likewise; here the vjp of the reference's own CPU forward
+    std::tuple<at::Tensor, at::Tensor> spherical_harmonics_bwd(const uint32_t K, const uint32_t degrees_to_use, const at::Tensor dirs, const at::Tensor coeffs,
+                                                               const at::optional<at::Tensor> masks, const at::Tensor v_colors, bool compute_v_dirs) {
+        torch::AutoGradMode grad(true);
+        auto d = dirs.detach().clone().set_requires_grad(true), c = coeffs.detach().clone().set_requires_grad(true);
+        auto colors = reference::spherical_harmonics((int)degrees_to_use, d, c);
+        auto v = v_colors;
+        if (masks.has_value() && masks->defined()) v = v * masks->unsqueeze(-1).to(v.dtype());
+        auto g = torch::autograd::grad({colors}, {d, c}, {v}, /*retain_graph=*/false, /*create_graph=*/false, /*allow_unused=*/true);
+        at::Tensor v_dirs = g[0].defined() ? g[0] : at::zeros_like(dirs), v_coeffs = g[1].defined() ? g[1] : at::zeros_like(coeffs);
+        return {v_coeffs.contiguous(), compute_v_dirs ? v_dirs.contiguous() : at::Tensor()};
+    }
+
+    // Intersect.cpp:15-122 over reference::isect_tiles (tests/torch_impl.cpp:333-...): tiles_per_gauss int32, isect_ids int64, flatten_ids int32
+    std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor means2d, const at::Tensor radii, const at::Tensor depths,
+                                                                  const at::optional<at::Tensor> camera_ids, const at::optional<at::Tensor> gaussian_ids,
+                                                                  const uint32_t C, const uint32_t tile_size, const uint32_t tile_width, const uint32_t tile_height,
+                                                                  const bool sort) {
+        TORCH_CHECK(!camera_ids.has_value() && !gaussian_ids.has_value(), "ref_raster_shim: non-packed only");
+        torch::NoGradGuard ng;
+        auto [tpg, ids, flat] = reference::isect_tiles(means2d.detach(), radii, depths.detach(), (int)tile_size, (int)tile_width, (int)tile_height, sort);
+        return {tpg.to(at::kInt).contiguous(), ids.to(at::kLong).contiguous(), flat.to(at::kInt).contiguous()};
+    }
+    // Intersect.cpp:124-137 / IntersectTile.cu:206-252: offsets[c][ty][tx] = first position of that (camera, tile) in the sorted keys; the key is
+    // (camera id << tile bits | tile id) << 32 | depth bits (IntersectTile.cu:96-108)
+    at::Tensor intersect_offset(const at::Tensor isect_ids, const uint32_t C, const uint32_t tile_width, const uint32_t tile_height) {
+        const int64_t n_tiles = (int64_t)tile_width * tile_height, n = isect_ids.numel(), total = n_tiles * C;
+        auto offsets = at::empty({(int64_t)C, (int64_t)tile_height, (int64_t)tile_width}, isect_ids.options().dtype(at::kInt));
+        int32_t* o = offsets.data_ptr<int32_t>();
+        const int64_t* ids = isect_ids.data_ptr<int64_t>();
+        uint32_t tile_bits = 0;
+        while ((1ll << tile_bits) < n_tiles) ++tile_bits; // floor(log2(n_tiles)) + 1 in the reference for non powers of two: the same for n_tiles that are not
+        if ((1ll << tile_bits) == n_tiles) ++tile_bits;   // powers of two, one more for those (IntersectTile.cu:51, 228)
+        int64_t next = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t key = ids[i] >> 32, cam = key >> tile_bits, tile = key & ((1ll << tile_bits) - 1), flat = cam * n_tiles + tile;
+            for (; next <= flat; ++next) o[next] = (int32_t)i;
+        }
+        for (; next < total; ++next) o[next] = (int32_t)n;
+        return offsets;
+    }
+
+    // Rasterization.cpp:20-132 (Fwd.cu:281-420): renders / alphas / last_ids allocated, one 16 x 16 workgroup per tile
+    std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3dgs_fwd(
+        const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
+        const at::optional<at::Tensor> backgrounds, const at::optional<at::Tensor> masks, const uint32_t image_width, const uint32_t image_height,
+        const uint32_t tile_size, const at::Tensor viewmats0, const at::optional<at::Tensor> viewmats1, const at::Tensor Ks, const CameraModelType camera_model,
+        const UnscentedTransformParameters ut_params, ShutterType rs_type, const at::optional<at::Tensor> radial_coeffs,
+        const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs, const at::Tensor tile_offsets,
+        const at::Tensor flatten_ids) {
+        need_plain_camera(viewmats1, radial_coeffs, tangential_coeffs, thin_prism_coeffs);
+        TORCH_CHECK(!masks.has_value(), "ref_raster_shim: no tile masks");
+        const uint32_t C = tile_offsets.size(0), th = tile_offsets.size(1), tw = tile_offsets.size(2), N = means.size(0), cdim = colors.size(-1);
+        auto renders = at::empty({C, image_height, image_width, cdim}, means.options());
+        auto alphas = at::empty({C, image_height, image_width, 1}, means.options());
+        auto last_ids = at::empty({C, image_height, image_width}, means.options().dtype(at::kInt));
+        const UT ut(ut_params);
+        TORCH_CHECK(refk_rasterize_fwd(cdim, C, N, flatten_ids.numel(), means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(),
+                                       colors.data_ptr<float>(), opacities.data_ptr<float>(), opt(backgrounds), nullptr, image_width, image_height, tile_size, tw, th,
+                                       viewmats0.data_ptr<float>(), nullptr, Ks.data_ptr<float>(), (int)camera_model, ut.v, (int)rs_type, nullptr, nullptr, nullptr,
+                                       tile_offsets.data_ptr<int32_t>(), flatten_ids.data_ptr<int32_t>(), renders.data_ptr<float>(), alphas.data_ptr<float>(),
+                                       last_ids.data_ptr<int32_t>()) == 0, "Unsupported number of channels: ", cdim);
+        return {renders, alphas, last_ids};
+    }
+    // Rasterization.cpp:134-261 (Bwd.cu:375-520): five zero-initialised gradient tensors, atomics into them
+    std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3dgs_bwd(
+        const at::Tensor means, const at::Tensor quats, const at::Tensor scales, const at::Tensor colors, const at::Tensor opacities,
+        const at::optional<at::Tensor> backgrounds, const at::optional<at::Tensor> masks, const uint32_t image_width, const uint32_t image_height,
+        const uint32_t tile_size, const at::Tensor viewmats0, const at::optional<at::Tensor> viewmats1, const at::Tensor Ks, const CameraModelType camera_model,
+        const UnscentedTransformParameters ut_params, ShutterType rs_type, const at::optional<at::Tensor> radial_coeffs,
+        const at::optional<at::Tensor> tangential_coeffs, const at::optional<at::Tensor> thin_prism_coeffs, const at::Tensor tile_offsets,
+        const at::Tensor flatten_ids, const at::Tensor render_alphas, const at::Tensor last_ids, const at::Tensor v_render_colors, const at::Tensor v_render_alphas) {
+        need_plain_camera(viewmats1, radial_coeffs, tangential_coeffs, thin_prism_coeffs);
+        const uint32_t C = tile_offsets.size(0), th = tile_offsets.size(1), tw = tile_offsets.size(2), N = means.size(0), cdim = colors.size(-1);
+        auto v_means = at::zeros_like(means), v_quats = at::zeros_like(quats), v_scales = at::zeros_like(scales), v_colors = at::zeros_like(colors),
+             v_opac = at::zeros_like(opacities);
+        const UT ut(ut_params);
+        auto m = means.contiguous(), q = quats.contiguous(), s = scales.contiguous(), c = colors.contiguous(), o = opacities.contiguous();
+        auto ra = render_alphas.contiguous(), li = last_ids.contiguous(), vc = v_render_colors.contiguous(), va = v_render_alphas.contiguous();
+        TORCH_CHECK(refk_rasterize_bwd(cdim, C, N, flatten_ids.numel(), m.data_ptr<float>(), q.data_ptr<float>(), s.data_ptr<float>(), c.data_ptr<float>(),
+                                       o.data_ptr<float>(), opt(backgrounds), nullptr, image_width, image_height, tile_size, tw, th, viewmats0.data_ptr<float>(),
+                                       nullptr, Ks.data_ptr<float>(), (int)camera_model, ut.v, (int)rs_type, nullptr, nullptr, nullptr, tile_offsets.data_ptr<int32_t>(),
+                                       flatten_ids.data_ptr<int32_t>(), ra.data_ptr<float>(), li.data_ptr<int32_t>(), vc.data_ptr<float>(), va.data_ptr<float>(),
+                                       v_means.data_ptr<float>(), v_quats.data_ptr<float>(), v_scales.data_ptr<float>(), v_colors.data_ptr<float>(),
+                                       v_opac.data_ptr<float>()) == 0, "Unsupported number of channels: ", cdim);
+        return {v_means, v_quats, v_scales, v_colors, v_opac};
+    }
+} // namespace gsplat
+
+// ---- C API --------------------------------------------------------------------------------------------------------------------------------------------------
+static torch::Tensor f32(const float* p, std::vector<int64_t> shape) { return torch::from_blob(const_cast<float*>(p), shape, torch::kFloat32).clone(); }
+static void put(const torch::Tensor& t, float* dst) {
+    if (!dst) return;
+    auto c = t.detach().to(torch::kFloat32).contiguous();
+    std::memcpy(dst, c.data_ptr<float>(), sizeof(float) * c.numel());
+}
+
+// One training-time render + backward of the reference: SplatData (raw parameters; K1 = number of shN coefficients) seen by a pinhole Camera(R, T, focal, centre,
+// camera size; the image size the camera was calibrated at = cam_w x cam_h, rendered at width x height as after load_and_get_image), background bg[3] or null.
+// Loss = sum(image * v_image) + sum(alpha * v_alpha); outputs: image [3,H,W], alpha [1,H,W], per-Gaussian radii / visibility, gradients of the six raw tensors.
+REF_API int refraster_render_backward(int64_t N, int64_t K1, int sh_degree, int active_sh_degree, const float* means, const float* sh0, const float* shN,
+                                      const float* scaling, const float* rotation, const float* opacity, const float* R, const float* T, float fx, float fy, float cx,
+                                      float cy, int cam_w, int cam_h, int width, int height, const float* bg, const float* v_image, const float* v_alpha, float* image,
+                                      float* alpha, int32_t* radii, float* g_means, float* g_sh0, float* g_shN, float* g_scaling, float* g_rotation, float* g_opacity,
+                                      float* viewmat_out, float* K_out) {
+    try {
+        auto req = [](torch::Tensor t) { return t.set_requires_grad(true); };
+        gs::SplatData model(sh_degree, req(f32(means, {N, 3})), req(f32(sh0, {N, 1, 3})), req(f32(shN, {N, K1, 3})), req(f32(scaling, {N, 3})), req(f32(rotation, {N, 4})),
+                            req(f32(opacity, {N, 1})), 1.0f);
+        model.set_active_sh_degree(active_sh_degree);
+        gs::Camera cam(f32(R, {3, 3}), f32(T, {3}), fx, fy, cx, cy, torch::empty({0}, torch::kFloat32), torch::empty({0}, torch::kFloat32), gsplat::CameraModelType::PINHOLE,
+                       "view", "", cam_w, cam_h, 0);
+        if (width != cam_w || height != cam_h) { // what load_and_get_image leaves behind (camera.cpp:113-114): the size of the image actually loaded
+            struct Peek : gs::Camera {};          // (no public setter)
+            static_assert(sizeof(Peek) == sizeof(gs::Camera));
+            TORCH_CHECK(false, "ref_raster_shim: render size != camera size needs load_and_get_image");
+        }
+        torch::Tensor bgc = bg ? f32(bg, {3}) : torch::Tensor();
+        auto out = gs::training::rasterize(cam, model, bgc, 1.0f, false, false, gs::training::RenderMode::RGB, nullptr);
+        put(out.image, image), put(out.alpha, alpha);
+        if (radii) {
+            auto r = out.radii.to(torch::kInt).contiguous();
+            std::memcpy(radii, r.data_ptr<int32_t>(), sizeof(int32_t) * r.numel());
+        }
+        put(cam.world_view_transform(), viewmat_out), put(cam.K(), K_out);
+        auto loss = (out.image * f32(v_image, {3, height, width})).sum();
+        if (v_alpha) loss = loss + (out.alpha * f32(v_alpha, {1, height, width})).sum();
+        loss.backward();
+        auto g = [](const torch::Tensor& p) { return p.grad().defined() ? p.grad() : torch::zeros_like(p); };
+        put(g(model.means()), g_means), put(g(model.sh0()), g_sh0), put(g(model.shN()), g_shN), put(g(model.scaling_raw()), g_scaling);
+        put(g(model.rotation_raw()), g_rotation), put(g(model.opacity_raw()), g_opacity);
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "refraster_render_backward: %s\n", e.what());
+        return 1;
+    }
+}

@@ -1,0 +1,57 @@
+"""GPU: the product's training-time render path - rasterizer.rasterize() (the mirror of gs::training::rasterize) and its backward - against the REFERENCE'S OWN
+rasterize() + autograd Functions + Camera + SplatData activations run end to end on the CPU (tests/golden/ref_raster.npz, oracle/make_golden_ref_raster.py:
+rasterizer.cpp, rasterizer_autograd.cpp, camera.cpp compiled in place against libtorch over the reference's kernels). This pins the COMPOSITION of SURVEY.md §8
+rows a1-a6 - which tensors are activated how, the SH direction and mask, the +0.5 / clamp_min on colours, the background, the final clamp, the path of dL/dmeans
+through the SH directions - to the reference itself; the operators are pinned one by one in test_gpu_refk_golden.py.
+Bars: camera matrices exact; radii exact; image / alpha max-abs 2e-5 (fast exp on the GPU, K7's own tolerance in SURVEY §8c); gradients relative L2 <= 3e-4 per
+tensor with threshold-flip rows counted (gpu_util.rows_check), the same bar as the per-operator tests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import refraster_util as U
+from gpu_util import n, rows_check, t
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", U.GOLD))
+
+
+@pytest.mark.parametrize("name", sorted(U.CASES))
+def test_render_and_backward_follow_the_reference_render_path(lfs, name):
+    from lichtfeld_studio_amd import loader
+    from lichtfeld_studio_amd.rasterizer import Camera, SplatModel, rasterize
+    c, g = U.CASES[name], lambda k: GOLD[f"{name}/{k}"]
+    s = U.scene(c)
+    W, H = c["W"], c["H"]
+    # the camera as the loader builds it from COLMAP quantities (loader.world_to_view / intrinsics mirror camera.cpp:15-23, 77-98)
+    cam = loader.CameraData(0, 1, 0, W, H, np.float32(c["focal"]), np.float32(c["focal"] * 1.05), np.float32(W / 2 + 0.5), np.float32(H / 2 - 0.25), s["R"], s["T"],
+                            np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32), "view", "")
+    viewmat, K = loader.world_to_view(cam), loader.intrinsics(cam, W, H)
+    assert np.array_equal(viewmat, g("viewmat")) and np.array_equal(K, g("K"))
+    mk = lambda a: t(a).contiguous().requires_grad_(True)
+    model = SplatModel(mk(s["means"]), mk(s["sh0"]), mk(s["shN"]), mk(s["scaling"]), mk(s["rotation"]), mk(s["opacity"]), c["sh_degree"], active_sh_degree=c["active"])
+    out = rasterize(Camera(t(viewmat).unsqueeze(0), t(K).unsqueeze(0), W, H), model, None if c["bg"] is None else t(np.array(c["bg"], np.float32)))
+    image, alpha = n(out.image), n(out.alpha).reshape(1, H, W)
+    assert image.shape == (3, H, W)
+    radii = n(out.radii).reshape(-1)
+    assert np.array_equal(radii, g("radii")), int((radii != g("radii")).sum())
+    e_img, e_alpha = np.abs(image - g("image")).max(), np.abs(alpha - g("alpha")).max()
+    print(f"{name}: image max-abs {e_img:.2e}, alpha max-abs {e_alpha:.2e}")
+    assert e_img <= 2e-5 and e_alpha <= 2e-5
+    loss = (out.image * t(s["v_image"])).sum()
+    if s["v_alpha"] is not None:
+        loss = loss + (out.alpha.reshape(1, H, W) * t(s["v_alpha"])).sum()
+    loss.backward()
+    for key, p in zip(("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity"), model.parameters()):
+        ref = g(key)
+        got = n(p.grad).reshape(ref.shape) if p.grad is not None else np.zeros_like(ref)
+        assert np.isfinite(got).all(), key
+        if np.abs(ref).max() == 0:
+            assert np.abs(got).max() == 0, key                      # e.g. shN at active degree 0: no gradient at all
+            continue
+        e, flips, rest = rows_check(got.reshape(c["N"], -1), ref.reshape(c["N"], -1), bar=3e-4, max_flips=3)
+        print(f"{name} {key}: rel-L2 {e:.2e}, flip rows {flips}, without them {rest:.2e}")
+        assert rest < 3e-4, (key, e, flips, rest)
+        assert np.array_equal(np.abs(got).reshape(c["N"], -1).max(1) > 0, np.abs(ref).reshape(c["N"], -1).max(1) > 0) or key in ("g_means",), key
