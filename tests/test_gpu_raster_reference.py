@@ -3,8 +3,8 @@ rasterize() + autograd Functions + Camera + SplatData activations run end to end
 rasterizer.cpp, rasterizer_autograd.cpp, camera.cpp compiled in place against libtorch over the reference's kernels). This pins the COMPOSITION of SURVEY.md §8
 rows a1-a6 - which tensors are activated how, the SH direction and mask, the +0.5 / clamp_min on colours, the background, the final clamp, the path of dL/dmeans
 through the SH directions - to the reference itself; the operators are pinned one by one in test_gpu_refk_golden.py.
-Bars: camera matrices exact; radii exact; image / alpha max-abs 2e-5 (fast exp on the GPU, K7's own tolerance in SURVEY §8c); gradients relative L2 <= 3e-4 per
-tensor with threshold-flip rows counted (gpu_util.rows_check), the same bar as the per-operator tests."""
+Bars: camera matrices exact; radii exact; image / alpha max-abs 2e-5 (fast exp on the GPU, K7's own tolerance in SURVEY §8c); gradients relative L2 <= 1e-4 per
+tensor with threshold-flip rows counted (gpu_util.rows_check; measured: 3e-6 .. 2e-5, no flip row)."""
 import os
 
 import numpy as np
@@ -51,7 +51,7 @@ def test_render_and_backward_follow_the_reference_render_path(lfs, name):
         if np.abs(ref).max() == 0:
             assert np.abs(got).max() == 0, key                      # e.g. shN at active degree 0: no gradient at all
             continue
-        e, flips, rest = rows_check(got.reshape(c["N"], -1), ref.reshape(c["N"], -1), bar=3e-4, max_flips=3)
+        e, flips, rest = rows_check(got.reshape(c["N"], -1), ref.reshape(c["N"], -1), bar=1e-4, max_flips=3)
         print(f"{name} {key}: rel-L2 {e:.2e}, flip rows {flips}, without them {rest:.2e}")
-        assert rest < 3e-4, (key, e, flips, rest)
+        assert rest < 1e-4, (key, e, flips, rest)
         assert np.array_equal(np.abs(got).reshape(c["N"], -1).max(1) > 0, np.abs(ref).reshape(c["N"], -1).max(1) > 0) or key in ("g_means",), key
