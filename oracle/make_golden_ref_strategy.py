@@ -1,6 +1,6 @@
 """Generate tests/golden/ref_strategy.npz by running the REFERENCE'S OWN strategy layer and optimizer on the CPU (oracle/_ref/libref_strategy.so: mcmc.cpp,
 default_strategy.cpp, strategy_utils.cpp, fused_adam.cpp, scheduler.cpp compiled in place against libtorch over the reference's kernels; `make -C oracle refk
-refstrategy`) through the scenarios of tests/refstrategy_util.py: per iteration set the gradients, step(iter), [set densification_info], post_backward(iter).
+refstrategy`) through the scenarios of tests/refstrategy_util.py: per iteration, in the trainer's order (trainer.cpp:744-756): set the gradients, [set densification_info], post_backward(iter), step(iter).
 Recorded: the reference's parameter defaults, every random draw it made (multinomial indices, normal deviates), the Gaussian count / learning rate / SH degree after
 every iteration, and the full state (6 parameters + both Adam moments + step counts) after the iterations that refine or reset and after the last one. Run in the build container:
     python oracle/make_golden_ref_strategy.py
@@ -28,7 +28,6 @@ def run(name, sc, out):
                             **sc["params"])
     for it in range(sc["it0"] + 1, sc["it0"] + sc["iters"] + 1):
         st.set_grads(U.grads(shapes_of(st, sc["K"]), it))
-        st.step(it)
         refining = st.is_refining(it) and it < sc["params"]["stop_refine"]
         if sc["kind"] == "default" and refining:
             info = U.densification_info(st.size(), it)
@@ -38,7 +37,8 @@ def run(name, sc, out):
             big = np.exp(st.get(3).reshape(-1, 3)).max(-1) > np.float32(sc["params"]["grow_scale3d"]) * np.float32(sc["scene_scale"])
             out[f"{name}/it{it}/split_idx"] = np.nonzero((g > np.float32(sc["params"]["grad_threshold"])) & big)[0]
         n_before = st.size()
-        draws = st.post_backward(it, 1000 + it)
+        draws = st.post_backward(it, 1000 + it)      # trainer.cpp:744-756: post_backward, then step - a refinement that replaces the parameter tensors leaves
+        st.step(it)                                   # them without gradients, and FusedAdam::step skips them (fused_adam.cpp:46-48)
         out[f"{name}/it{it}/draws"] = np.array([d[0] for d in draws] or [""])
         for k, (_, a) in enumerate(draws):
             out[f"{name}/it{it}/draw{k}"] = a

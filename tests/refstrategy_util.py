@@ -18,10 +18,10 @@ def hashed(shape, salt):
 
 
 SCENARIOS = {
-    # MCMC: refinement (relocate + add) at iterations 1002, 1005, 1008; SH degree raised at 1004; dead Gaussians by opacity and by a zero quaternion; the cap reached
+    # MCMC: refinement (relocate + add) at iterations 1002, 1005, 1008; SH degree raised at 1004; dead Gaussians by opacity and by a zero quaternion; the cap reached at 1008, so that 1011 relocates without growing (the one refinement after which Adam still steps)
     # (iterations 1001 .. 1010: past the first 1000, where FusedAdam skips the shN group - fused_adam.cpp:68-70)
-    "mcmc": dict(kind="mcmc", N=160, K=3, sh_degree=1, scene_scale=1.3, it0=1000, iters=10, full_state=(1002, 1005, 1008, 1010),
-                 params=dict(iterations=2000, start_refine=2, refine_every=3, stop_refine=1500, sh_degree_interval=4, max_cap=180, min_opacity=0.005)),
+    "mcmc": dict(kind="mcmc", N=160, K=3, sh_degree=1, scene_scale=1.3, it0=1000, iters=12, full_state=(1002, 1005, 1008, 1011, 1012),
+                 params=dict(iterations=2000, start_refine=2, refine_every=3, stop_refine=1500, sh_degree_interval=4, max_cap=180, min_opacity=0.005, opacity_lr=0.5)),
     # ADC: duplicate + split + prune at 3, 6, 9; opacity reset at 5 (after which "too big" pruning is active); SH degree raised at 4 and 8
     "default": dict(kind="default", N=90, K=3, sh_degree=1, scene_scale=1.3, it0=0, iters=10, full_state=(3, 5, 6, 9, 10),
                     params=dict(iterations=60, start_refine=1, refine_every=3, stop_refine=40, sh_degree_interval=4, reset_every=5, grad_threshold=2e-4,
@@ -44,7 +44,9 @@ def initial(sc):
 
 def grads(shapes, it):
     """synthetic parameter gradients of iteration `it` for the current parameter shapes"""
-    return [(hashed(s, 100 * it + i) * 2e-2).astype(np.float32) for i, s in enumerate(shapes)]
+    g = [(hashed(s, 100 * it + i) * 2e-2).astype(np.float32) for i, s in enumerate(shapes)]
+    g[5] = g[5] + np.float32(2e-2)      # a steady pull towards lower opacity: Gaussians keep dying, so every refinement has something to relocate / prune
+    return g
 
 
 def densification_info(n, it):

@@ -1,7 +1,7 @@
 """GPU: the product's strategy layer (strategies.MCMC / DefaultStrategy + FusedAdam + ExponentialLR over the HIP kernels) against the REFERENCE'S OWN strategy
 layer run on the CPU (tests/golden/ref_strategy.npz: mcmc.cpp, default_strategy.cpp, strategy_utils.cpp, fused_adam.cpp, scheduler.cpp compiled in place against
 libtorch over the reference's own kernels - oracle/make_golden_ref_strategy.py). Both sides go through the scenarios of refstrategy_util.py: same initial model,
-same gradients, step(iter), post_backward(iter), with every random draw the reference made replayed into the product (the MI355X generator produces other streams):
+same gradients, post_backward(iter) then step(iter) - the trainer's order, trainer.cpp:744-756 -, with every random draw the reference made replayed into the product (the MI355X generator produces other streams):
   * MCMC relocation: the reference's multinomial picks become the uniforms that make lfs_mcmc_relocate's inverse-CDF search pick the same sources;
   * MCMC growth: the multinomial indices; SGLD noise and ADC split offsets: the normal deviates.
 Compared after every refining / resetting iteration and at the end: Gaussian count, SH degree, per-group learning rate and Adam step counts exactly; the 6 parameter
@@ -121,7 +121,6 @@ def test_mcmc_follows_the_reference_strategy(lfs, name):
     for it in range(sc["it0"] + 1, sc["it0"] + sc["iters"] + 1):
         for p, g in zip(st.model.parameters(), U.grads([tuple(p.shape) for p in st.model.parameters()], it)):
             p.grad = t(g.reshape(p.shape))
-        st.step(it)
         draws = draws_of(name, it)
         multis = [a for nm, a in draws if nm == "multinomial"]
         noise = [a for nm, a in draws if nm == "randn_like"][0]
@@ -136,6 +135,7 @@ def test_mcmc_follows_the_reference_strategy(lfs, name):
         rand = (lambda *a, **kw: u) if u is not None else (lambda *a, **kw: torch.full((cur,), 0.5, dtype=torch.float64, device=DEV))
         with Patched(rand=rand, randn=lambda shape, **kw: t(noise).reshape(tuple(shape))):
             st.post_backward(it)
+        st.step(it)          # the trainer's order (trainer.cpp:744-756): tensors replaced by the refinement have no gradient and are skipped by FusedAdam
         assert bool(GOLD[f"{name}/it{it}/refining"]) == st.is_refining(it)
         # means: every iteration adds lr * 5e5 (= 100 here) x Sigma x noise x gate(opacity) - terms of magnitude 10, whose fp32 rounding (and the kernel's fast
         # exponential in the gate) is what the two sides differ by: 5e-5 absolute after ten iterations, against displacements of order 1 - 10 per iteration
@@ -153,7 +153,6 @@ def test_default_strategy_follows_the_reference_strategy(lfs, name, fused):
     for it in range(sc["it0"] + 1, sc["it0"] + sc["iters"] + 1):
         for p, g in zip(st.model.parameters(), U.grads([tuple(p.shape) for p in st.model.parameters()], it)):
             p.grad = t(g.reshape(p.shape))
-        st.step(it)
         refining = bool(GOLD[f"{name}/it{it}/refining"])
         assert refining == (st.is_refining(it) and it < st.params.stop_refine)
         draws = draws_of(name, it)
@@ -168,5 +167,6 @@ def test_default_strategy_follows_the_reference_strategy(lfs, name, fused):
             return t(full)
         with Patched(randn=randn):
             st.post_backward(it, info)
+        st.step(it)
         worst = max(worst, compare(st, name, it, it in sc["full_state"]))
     print(f"{name} fused={fused}: worst deviation {worst:.3f} of the bar")
