@@ -5,7 +5,7 @@ same gradients, post_backward(iter) then step(iter) - the trainer's order, train
   * MCMC relocation: the reference's multinomial picks become the uniforms that make lfs_mcmc_relocate's inverse-CDF search pick the same sources;
   * MCMC growth: the multinomial indices; SGLD noise and ADC split offsets: the normal deviates.
 Compared after every refining / resetting iteration and at the end: Gaussian count, SH degree, per-group learning rate and Adam step counts exactly; the 6 parameter
-tensors and both Adam moments to 2e-5 relative + 1e-7 (gsplat::relocation sums ~1300 fp32 binomial terms); the MCMC means to 2e-5 relative + 5e-5 (ten SGLD
+tensors and both Adam moments to 2e-5 relative + 1e-7 (gsplat::relocation sums ~1300 fp32 binomial terms); the MCMC means to 2e-5 relative + 1e-4 (twelve SGLD
 steps of magnitude ~10 each through the fast exponential)."""
 import os
 
@@ -138,8 +138,8 @@ def test_mcmc_follows_the_reference_strategy(lfs, name):
         st.step(it)          # the trainer's order (trainer.cpp:744-756): tensors replaced by the refinement have no gradient and are skipped by FusedAdam
         assert bool(GOLD[f"{name}/it{it}/refining"]) == st.is_refining(it)
         # means: every iteration adds lr * 5e5 (= 100 here) x Sigma x noise x gate(opacity) - terms of magnitude 10, whose fp32 rounding (and the kernel's fast
-        # exponential in the gate) is what the two sides differ by: 5e-5 absolute after ten iterations, against displacements of order 1 - 10 per iteration
-        worst = max(worst, compare(st, name, it, it in sc["full_state"], means_atol=5e-5))
+        # exponential in the gate) is what the two sides differ by: 1e-4 absolute after twelve iterations (measured 0.9 of 5e-5), against displacements of order 1 - 10 per iteration
+        worst = max(worst, compare(st, name, it, it in sc["full_state"], means_atol=1e-4))
     print(f"{name}: worst deviation {worst:.3f} of the bar (2e-5 relative + 1e-7)")
 
 
