@@ -39,7 +39,7 @@ def build(ref: bool = True) -> None:
     if ref and os.path.exists("/root/reference/src/loader/formats/colmap.cpp"):
         # the reference's host C++ against CPU libtorch: COLMAP reader, splat_data.cpp's host functions, the strategy layer + FusedAdam, the render path. Minutes of libtorch
         # headers when built from scratch, so in parallel, and a failure here (they only serve the *_reference tests, which skip without them) does not fail build()
-        subprocess.run(["make", "-C", _HERE, "-j4", "refcolmap", "refsplatio", "refstrategy", "refraster"], check=False, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "-j4", "refcolmap", "refsplatio", "refstrategy", "refraster", "reflosshost"], check=False, capture_output=True)
 
 
 def lib():
@@ -834,3 +834,55 @@ def ref_render_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, 
     if rc:
         raise RuntimeError("refraster_render_backward failed")
     return out
+
+
+# ---- the reference's loss-side host code on CPU libtorch (oracle/_ref/libref_loss_host.so; ref_loss_host_shim.cpp) --------------------------------------------
+_REF_LOSS_HOST = None
+
+
+def ref_loss_host_lib():
+    global _REF_LOSS_HOST
+    if _REF_LOSS_HOST is None:
+        path = os.path.join(_HERE, "_ref", "libref_loss_host.so")
+        if not os.path.exists(path):
+            return None
+        _REF_LOSS_HOST = C.CDLL(path)
+    return _REF_LOSS_HOST
+
+
+def ref_fused_ssim(img1, img2, padding="valid"):
+    """fused_ssim(img1, img2, padding, train=true) of the reference's fused_ssim.cuh on [3,H,W] images -> (mean SSIM, d/d img1)"""
+    a, b = _f32(img1), _f32(img2)
+    v, g = C.c_float(), np.empty_like(a)
+    assert ref_loss_host_lib().reflh_fused_ssim(C.c_int(a.shape[1]), C.c_int(a.shape[2]), _p(a), _p(b), C.c_int(int(padding == "valid")), C.byref(v), _p(g)) == 0
+    return np.float32(v.value), g
+
+
+def ref_photometric_loss(rendered, gt, lambda_dssim=0.2):
+    """Trainer::compute_photometric_loss (trainer.cpp:103-130) on [3,H,W] images -> (loss, d loss / d rendered)"""
+    a, b = _f32(rendered), _f32(gt)
+    v, g = C.c_float(), np.empty_like(a)
+    assert ref_loss_host_lib().reflh_photometric(C.c_int(a.shape[1]), C.c_int(a.shape[2]), _p(a), _p(b), C.c_float(lambda_dssim), C.byref(v), _p(g)) == 0
+    return np.float32(v.value), g
+
+
+def ref_bilateral_grid(num_images, gW, gH, gL, image_idx, delta, rgb, v_out, tv_weight):
+    """BilateralGrid(num_images, gW, gH, gL) of the reference with grids = identity + delta: apply(rgb [3,h,w], image_idx) and tv_loss(), and the gradients of
+    sum(out * v_out) + tv_weight * tv -> dict(identity, out, tv, g_grids, g_rgb)"""
+    delta, rgb, v_out = _f32(delta), _f32(rgb), _f32(v_out)
+    assert delta.shape == (num_images, 12, gL, gH, gW)
+    out = dict(identity=np.empty_like(delta), out=np.empty_like(rgb), g_grids=np.empty_like(delta), g_rgb=np.empty_like(rgb))
+    tv = C.c_float()
+    assert ref_loss_host_lib().reflh_bilateral(C.c_int(num_images), C.c_int(gW), C.c_int(gH), C.c_int(gL), C.c_int(image_idx), _p(delta), C.c_int(rgb.shape[1]),
+                                               C.c_int(rgb.shape[2]), _p(rgb), _p(v_out), C.c_float(tv_weight), _p(out["identity"]), _p(out["out"]), C.byref(tv),
+                                               _p(out["g_grids"]), _p(out["g_rgb"])) == 0
+    out["tv"] = np.float32(tv.value)
+    return out
+
+
+def ref_warmup_schedule(lr0, gamma, warmup_steps, warmup_start_factor, n):
+    """WarmupExponentialLR of the reference (scheduler.cpp:27-63) over one parameter group: the learning rate after each of n steps (float64)"""
+    lrs = np.empty(n, np.float64)
+    assert ref_loss_host_lib().reflh_warmup_schedule(C.c_double(lr0), C.c_double(gamma), C.c_int(warmup_steps), C.c_double(warmup_start_factor), C.c_int(n),
+                                                     lrs.ctypes.data_as(C.c_void_p)) == 0
+    return lrs

@@ -37,6 +37,28 @@ grids = rng.standard_normal((3, 12, 6, 9, 11)).astype(np.float32)
 loss, gg = oracle.refk_bilateral_tv(grids, 0.7)
 print("tv loss", loss)
 out.update({"tv_3x12x6x9x11/grids": grids, "tv_3x12x6x9x11/grad_output": np.float32(0.7), "tv_3x12x6x9x11/tv_loss": np.float32(loss), "tv_3x12x6x9x11/grad_grids": gg})
+# ---- the host code around the kernels (oracle/_ref/libref_loss_host.so: fused_ssim.cuh's autograd wrapper, Trainer::compute_photometric_loss's three lines,
+# BilateralGrid, WarmupExponentialLR compiled in place against CPU libtorch over the kernels above; `make -C oracle reflosshost`)
+assert oracle.ref_loss_host_lib() is not None, "build oracle/_ref/libref_loss_host.so first (make -C oracle reflosshost)"
+for name, (H, W, seed) in {"host/photometric_40x52": (40, 52, 6), "host/photometric_small_9x40": (9, 40, 7)}.items():   # <= 10 rows: the "valid" crop is skipped
+    rng = np.random.default_rng(seed)
+    gt = rng.random((3, H, W)).astype(np.float32)
+    img = np.clip(gt + 0.1 * rng.standard_normal((3, H, W)), 0, 1).astype(np.float32)
+    loss, g = oracle.ref_photometric_loss(img, gt, 0.2)
+    sv, sg = oracle.ref_fused_ssim(img, gt, "valid")
+    ss, ssg = oracle.ref_fused_ssim(img, gt, "same")
+    print(name, "loss", float(loss), "ssim valid / same", float(sv), float(ss))
+    out.update({f"{name}/rendered": img, f"{name}/gt": gt, f"{name}/loss": loss, f"{name}/grad": g, f"{name}/ssim_valid": sv, f"{name}/ssim_valid_grad": sg,
+                f"{name}/ssim_same": ss, f"{name}/ssim_same_grad": ssg})
+rng = np.random.default_rng(8)
+delta = (0.2 * rng.standard_normal((3, 12, 4, 5, 6))).astype(np.float32)
+rgb = (rng.random((3, 23, 31)) * 1.4 - 0.2).astype(np.float32)                       # outside [0, 1] in places: apply() clamps first
+v_out = rng.standard_normal((3, 23, 31)).astype(np.float32)
+r = oracle.ref_bilateral_grid(3, 6, 5, 4, 1, delta, rgb, v_out, 10.0)
+out.update({"host/bilateral/delta": delta, "host/bilateral/rgb": rgb, "host/bilateral/v_out": v_out, "host/bilateral/tv_weight": np.float32(10.0)})
+out.update({f"host/bilateral/{k}": v for k, v in r.items()})
+out["host/warmup/args"] = np.array([2e-3, 0.01 ** (1.0 / 300), 40, 0.01, 120], np.float64)   # lr0, gamma, warmup_steps, warmup_start_factor, n
+out["host/warmup/lrs"] = oracle.ref_warmup_schedule(2e-3, 0.01 ** (1.0 / 300), 40, 0.01, 120)
 path = os.path.join(ROOT, "tests", "golden", "refk_loss.npz")
 np.savez_compressed(path, **out)
 print(path, os.path.getsize(path) // 1024, "KiB")

@@ -177,3 +177,67 @@ def test_hip_init_model_from_pointcloud_equals_the_reference_function(lfs, name)
     assert np.array_equal(n(model.raw_quats), np.tile(g("out_rotation")[0], (N, 1))) and list(g("out_rotation")[0]) == [1, 0, 0, 0]
     np.testing.assert_allclose(n(model.raw_opacities), np.full(N, g("out_opacity")[0, 0]), rtol=1e-6, atol=1e-7)
     assert model.active_sh_degree == 0 and model.max_sh_degree == int(deg)
+
+
+# ---- the loss-side host code: fused_ssim wrapper / photometric loss / BilateralGrid against the reference's own host code (refk_loss.npz "host/...") ----------
+@pytest.mark.parametrize("name", ["photometric_40x52", "photometric_small_9x40"])
+def test_hip_photometric_loss_matches_the_reference_host_code(lfs, name):
+    """losses.photometric_loss (autograd) and the fused losses.photometric_loss_fwd_bwd against Trainer::compute_photometric_loss over fused_ssim.cuh, incl. the
+    wrapper's behaviour for images of <= 10 rows (whole map in the forward, no SSIM gradient in the backward)."""
+    from gpu_util import n, t
+    from lichtfeld_studio_amd import losses
+    h = lg.host
+    img, gt = t(h(f"{name}/rendered")), t(h(f"{name}/gt"))
+    x = img.clone().requires_grad_(True)
+    loss = losses.photometric_loss(x, gt, 0.2)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(h(f"{name}/loss"))) <= 2e-6
+    lg.close(n(x.grad), h(f"{name}/grad"), 3e-5, "d loss / d rendered")
+    for pad in ("valid", "same"):
+        y = img.clone().requires_grad_(True)
+        v = losses.fused_ssim(y, gt, pad, True)
+        v.backward()
+        assert abs(float(v.detach()) - float(h(f"{name}/ssim_{pad}"))) <= 2e-6
+        ref = h(f"{name}/ssim_{pad}_grad")
+        if np.abs(ref).max() == 0:
+            assert float(y.grad.abs().max()) == 0                # the <= 10 rows case of fused_ssim.cuh:92-97
+        else:
+            lg.close(n(y.grad), ref, 3e-5, f"ssim {pad} gradient")
+    acc = torch.zeros(1, device="cuda:0")
+    v = losses.photometric_loss_fwd_bwd(img.permute(1, 2, 0).contiguous(), gt, 0.2, 1.0, acc)      # the trainer's fused form, HWC render
+    assert abs(float(acc) - float(h(f"{name}/loss"))) <= 2e-6
+    lg.close(n(v.permute(2, 0, 1)), h(f"{name}/grad"), 3e-5, "fused d loss / d rendered")
+
+
+def test_hip_bilateral_grid_component_matches_the_reference_host_code(lfs):
+    """bilateral_grid.BilateralGrid (identity initialisation, apply(): clamp / layout / slice, tv_loss) through autograd, and the trainer's fused no-autograd entry
+    points, against gs::training::BilateralGrid of the reference."""
+    from gpu_util import n, t
+    from lichtfeld_studio_amd import bilateral_grid as bgm
+    h = lg.host
+    delta, rgb, v_out, w_tv = h("bilateral/delta"), h("bilateral/rgb"), h("bilateral/v_out"), float(h("bilateral/tv_weight"))
+    bg = bgm.BilateralGrid(3, 6, 5, 4)
+    assert np.array_equal(n(bg.parameters()), h("bilateral/identity"))
+    with torch.no_grad():
+        bg.parameters().add_(t(delta))
+    x = t(rgb).requires_grad_(True)
+    out = bg.apply(x, 1)
+    tv = bg.tv_loss()
+    ((out * t(v_out)).sum() + w_tv * tv).backward()
+    lg.close(n(out), h("bilateral/out"), 3e-6, "apply")
+    assert abs(float(tv.detach()) - float(h("bilateral/tv"))) <= 1e-5 * float(h("bilateral/tv"))
+    lg.close(n(bg.parameters().grad), h("bilateral/g_grids"), 3e-5, "d / d grids")
+    lg.close(n(x.grad), h("bilateral/g_rgb"), 3e-5, "d / d rgb")
+    # the fused path of the trainer: same numbers without autograd (CHW image, clamp inside the kernels, gradients accumulated in place)
+    bg2 = bgm.BilateralGrid(3, 6, 5, 4)
+    with torch.no_grad():
+        bg2.parameters().add_(t(delta))
+    img = t(rgb)
+    out2 = bg2.apply_fused(img, 1, chw=True)
+    lg.close(n(out2), h("bilateral/out"), 3e-6, "apply_fused")
+    g_img = bg2.apply_fused_backward(img, 1, t(v_out), chw=True)
+    acc = torch.zeros(1, device="cuda:0")
+    bg2.tv_loss_fused(w_tv, acc)
+    lg.close(n(bg2.parameters().grad), h("bilateral/g_grids"), 3e-5, "fused d / d grids")
+    lg.close(n(g_img), h("bilateral/g_rgb"), 3e-5, "fused d / d rgb")
+    assert abs(float(acc) - w_tv * float(h("bilateral/tv"))) <= 1e-5 * w_tv * float(h("bilateral/tv"))
