@@ -882,3 +882,48 @@ def ref_warmup_schedule(lr0, gamma, warmup_steps, warmup_start_factor, n):
     assert ref_loss_host_lib().reflh_warmup_schedule(C.c_double(lr0), C.c_double(gamma), C.c_int(warmup_steps), C.c_double(warmup_start_factor), C.c_int(n),
                                                      lrs.ctypes.data_as(C.c_void_p)) == 0
     return lrs
+
+
+# ---- SH and tile-intersection kernels of the reference on the CPU (libref_kernels.so: SphericalHarmonicsCUDA.cu, IntersectTile.cu under ref_emul/) ---------
+def refk_sh_fwd(degree, dirs, coeffs, masks=None):
+    dirs, coeffs = _f32(dirs), _f32(coeffs)
+    N, K = dirs.shape[0], coeffs.shape[1]
+    m = None if masks is None else np.ascontiguousarray(masks, np.uint8)
+    colors = np.zeros((N, 3), np.float32)             # at::empty in the reference: masked-out rows are not written
+    refk_lib().refk_sh_fwd(C.c_uint32(N), C.c_uint32(K), C.c_uint32(degree), _p(dirs), _p(coeffs), None if m is None else m.ctypes.data_as(C.c_void_p), _p(colors))
+    return colors
+
+
+def refk_sh_bwd(degree, dirs, coeffs, masks, v_colors, compute_v_dirs=True):
+    dirs, coeffs, v_colors = _f32(dirs), _f32(coeffs), _f32(v_colors)
+    N, K = dirs.shape[0], coeffs.shape[1]
+    m = None if masks is None else np.ascontiguousarray(masks, np.uint8)
+    v_coeffs, v_dirs = np.zeros_like(coeffs), np.zeros_like(dirs)
+    refk_lib().refk_sh_bwd(C.c_uint32(N), C.c_uint32(K), C.c_uint32(degree), _p(dirs), _p(coeffs), None if m is None else m.ctypes.data_as(C.c_void_p), _p(v_colors),
+                           _p(v_coeffs), _p(v_dirs) if compute_v_dirs else None)
+    return v_coeffs, (v_dirs if compute_v_dirs else None)
+
+
+def refk_intersect_tile(means2d, radii, depths, tile_size, tile_width, tile_height, sort=True):
+    """gsplat::intersect_tile (non-packed) over the reference's kernels -> (tiles_per_gauss int32 [C,N], isect_ids int64, flatten_ids int32)"""
+    means2d, depths = _f32(means2d), _f32(depths)
+    radii = np.ascontiguousarray(radii, np.int32)
+    Cn, N = depths.shape
+    lib = refk_lib()
+    lib.refk_intersect_tile.restype = C.c_int64
+    tpg = np.zeros((Cn, N), np.int32)
+    args = (C.c_uint32(Cn), C.c_uint32(N), _p(means2d), radii.ctypes.data_as(C.c_void_p), _p(depths), C.c_uint32(tile_size), C.c_uint32(tile_width),
+            C.c_uint32(tile_height), C.c_int(int(sort)), tpg.ctypes.data_as(C.c_void_p))
+    n = lib.refk_intersect_tile(*args, None, None, C.c_int64(0))
+    ids, flat = np.empty(n, np.int64), np.empty(n, np.int32)
+    if n:
+        lib.refk_intersect_tile(*args, ids.ctypes.data_as(C.c_void_p), flat.ctypes.data_as(C.c_void_p), C.c_int64(n))
+    return tpg, ids, flat
+
+
+def refk_intersect_offset(isect_ids, Cn, tile_width, tile_height):
+    ids = np.ascontiguousarray(isect_ids, np.int64)
+    off = np.empty((Cn, tile_height, tile_width), np.int32)
+    refk_lib().refk_intersect_offset(C.c_int64(len(ids)), ids.ctypes.data_as(C.c_void_p), C.c_uint32(Cn), C.c_uint32(tile_width), C.c_uint32(tile_height),
+                                     off.ctypes.data_as(C.c_void_p))
+    return off

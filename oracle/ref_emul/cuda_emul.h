@@ -34,6 +34,7 @@
 #define __shared__
 #define __constant__ static
 
+struct uint2 { unsigned x, y; };
 struct uint3 { unsigned x, y, z; };
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 
@@ -205,6 +206,10 @@ static inline float cuemu_powf(float x, float y) { return powf(x, y); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float pow(float a, int b) { return powf(a, float(b)); }   // CUDA's math overload set has pow(float, int) -> float (host <cmath> would promote to double)
 static inline float __fdividef(float a, float b) { return a / b; }
+// float -> unsigned conversion as the GPU does it (cvt.rzi.u32.f32 saturates: negative and NaN -> 0, too large -> 0xffffffff); in C++ it is undefined for those
+static inline unsigned cuemu_f2u(float v) { return !(v > 0.f) ? 0u : v >= 4294967296.f ? 0xffffffffu : (unsigned)v; }
+static inline unsigned cuemu_f2u_floor(float v) { return cuemu_f2u(floorf(v)); }
+static inline unsigned cuemu_f2u_ceil(float v) { return cuemu_f2u(ceilf(v)); }
 static inline float min(float a, float b) { return fminf(a, b); }
 static inline float max(float a, float b) { return fmaxf(a, b); }
 static inline double min(double a, double b) { return fmin(a, b); }

@@ -19,7 +19,6 @@ struct alignas(16) float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct int3 { int x, y, z; };
 struct int4 { int x, y, z, w; };
-struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct ushort4 { unsigned short x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return {x, y}; }

@@ -1,7 +1,8 @@
 // ORACLE/_ref — TEST INFRASTRUCTURE ONLY.
 // C entry points over the reference's OWN device kernels, run on the CPU: the kernel parts of
 //   /root/reference/gsplat/ProjectionUT3DGSFused.cu:1-203, RasterizeToPixelsFromWorld3DGSFwd.cu:1-279, ...Bwd.cu:1-373,
-//   RelocationCUDA.cu:1-43 + 87-144, QuatToRotmatCUDA.cu:1-39 (with Cameras.cuh, Utils.cuh, Common.h, Cameras.h as they include them)
+//   RelocationCUDA.cu:1-43 + 87-144, QuatToRotmatCUDA.cu:1-39, SphericalHarmonicsCUDA.cu:1-400 + 443-481, IntersectTile.cu:1-114 + 206-252
+//   (with Cameras.cuh, Utils.cuh, Common.h, Cameras.h as they include them)
 //   and fastgs/optimizer/include/adam_kernels.cuh
 // are compiled IN PLACE as host C++ by `make -C oracle refk` (the recipe pipes the kernel line ranges into a scratch directory that is
 // deleted after the compile: the launchers below them use the <<<...>>> syntax, which no host compiler parses; nothing of the reference is
@@ -16,7 +17,11 @@
 #include "k_raster_bwd.inc"
 #include "k_relocation.inc"
 #include "k_quat.inc"
+#include "k_sh.inc"      // SphericalHarmonicsCUDA.cu:1-400 + 443-481 (the basis evaluation, its vjp, the two kernels)
+#include "k_isect.inc"   // IntersectTile.cu:1-114 + 206-252 (intersect_tile_kernel, intersect_offset_kernel)
 #include "adam_kernels.cuh"
+#include <cmath>
+#include <cub/cub.cuh>
 
 namespace gsplat {
 alignas(64) int s[1 << 18]; // `extern __shared__ int s[]` of the rasterizer kernels: 1 MiB, one workgroup runs at a time
@@ -134,4 +139,76 @@ REFK_API void refk_adam_step(int64_t n, float* param, float* exp_avg, float* exp
         fast_gs::optimizer::kernels::adam::adam_step_cu(param, exp_avg, exp_avg_sq, grad, int(n), lr, beta1, beta2, eps, bias_correction1_rcp,
                                                         bias_correction2_sqrt_rcp);
     });
+}
+
+
+// ---- spherical harmonics (K2 / K9): launch geometry of launch_spherical_harmonics_{fwd,bwd}_kernel (SphericalHarmonicsCUDA.cu:402-441, 483-529): one thread per
+// (Gaussian, channel), 256 threads; the caller provides zeroed v_coeffs / v_dirs as SphericalHarmonics.cpp:60-66 does (zeros_like) ---------------------------
+REFK_API void refk_sh_fwd(uint32_t N, uint32_t K, uint32_t degrees_to_use, const float* dirs, const float* coeffs, const uint8_t* masks, float* colors) {
+    if (N == 0) return;
+    cuemu::launch(dim3(unsigned((3ull * N + 255) / 256)), dim3(256), false, [&]() {
+        gsplat::spherical_harmonics_fwd_kernel<float>(N, K, degrees_to_use, reinterpret_cast<const gsplat::vec3*>(dirs), coeffs,
+                                                      reinterpret_cast<const bool*>(masks), colors);
+    });
+}
+REFK_API void refk_sh_bwd(uint32_t N, uint32_t K, uint32_t degrees_to_use, const float* dirs, const float* coeffs, const uint8_t* masks, const float* v_colors,
+                          float* v_coeffs, float* v_dirs) {
+    if (N == 0) return;
+    cuemu::launch(dim3(unsigned((3ull * N + 255) / 256)), dim3(256), false, [&]() {
+        gsplat::spherical_harmonics_bwd_kernel<float>(N, K, degrees_to_use, reinterpret_cast<const gsplat::vec3*>(dirs), coeffs,
+                                                      reinterpret_cast<const bool*>(masks), v_colors, v_coeffs, v_dirs);
+    });
+}
+
+// ---- tile intersection (K3 - K6): the host sequence of gsplat::intersect_tile (Intersect.cpp:15-122) over the two passes of intersect_tile_kernel, at::cumsum
+// and radix_sort_double_buffer (IntersectTile.cu:290-342: cub::DeviceRadixSort::SortPairs over the key bits [0, 32 + tile bits + camera bits), restated in
+// ref_emul/cub/cub.cuh as the stable sort CUB documents). Returns n_isects; the id arrays are written when they fit `cap` (call with cap = 0 to size).
+static void isect_pass(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths, const int64_t* cum, uint32_t tile_size, uint32_t tw,
+                       uint32_t th, uint32_t tile_n_bits, int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids) {
+    const uint64_t n = uint64_t(C) * N;
+    cuemu::launch(dim3(unsigned((n + 255) / 256)), dim3(256), false, [&]() {
+        gsplat::intersect_tile_kernel<float>(false, C, N, 0, nullptr, nullptr, means2d, radii, depths, cum, tile_size, tw, th, tile_n_bits, tiles_per_gauss, isect_ids,
+                                             flatten_ids);
+    });
+}
+REFK_API int64_t refk_intersect_tile(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths, uint32_t tile_size, uint32_t tw,
+                                     uint32_t th, int sort, int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int64_t cap) {
+    const uint64_t n = uint64_t(C) * N;
+    if (n == 0) return 0;
+    const uint32_t n_tiles = tw * th;
+    const uint32_t tile_n_bits = (uint32_t)floor(log2(n_tiles)) + 1, cam_n_bits = (uint32_t)floor(log2(C)) + 1;   // Intersect.cpp:45-46
+    isect_pass(C, N, means2d, radii, depths, nullptr, tile_size, tw, th, tile_n_bits, tiles_per_gauss, nullptr, nullptr);
+    std::vector<int64_t> cum(n);
+    int64_t run = 0;
+    for (uint64_t i = 0; i < n; ++i) cum[i] = (run += tiles_per_gauss[i]);                                           // at::cumsum, :75
+    const int64_t n_isects = run;
+    if (n_isects == 0 || n_isects > cap) return n_isects;
+    std::vector<int64_t> ids(n_isects), ids2(n_isects);
+    std::vector<int32_t> flat(n_isects), flat2(n_isects);
+    isect_pass(C, N, means2d, radii, depths, cum.data(), tile_size, tw, th, tile_n_bits, nullptr, ids.data(), flat.data());
+    int64_t* ko = ids.data();
+    int32_t* vo = flat.data();
+    if (sort) {
+        cub::DoubleBuffer<int64_t> d_keys(ids.data(), ids2.data());
+        cub::DoubleBuffer<int32_t> d_values(flat.data(), flat2.data());
+        size_t bytes = 0;
+        cub::DeviceRadixSort::SortPairs(nullptr, bytes, d_keys, d_values, (int)n_isects, 0, int(32 + tile_n_bits + cam_n_bits));
+        char ws;
+        cub::DeviceRadixSort::SortPairs(&ws, bytes, d_keys, d_values, (int)n_isects, 0, int(32 + tile_n_bits + cam_n_bits));
+        ko = d_keys.Current(), vo = d_values.Current();
+    }
+    std::copy(ko, ko + n_isects, isect_ids);
+    std::copy(vo, vo + n_isects, flatten_ids);
+    return n_isects;
+}
+// gsplat::intersect_offset (Intersect.cpp:124-137, launch_intersect_offset_kernel IntersectTile.cu:254-288): offsets.fill_(0) when there is nothing
+REFK_API void refk_intersect_offset(int64_t n_isects, const int64_t* isect_ids, uint32_t C, uint32_t tw, uint32_t th, int32_t* offsets) {
+    const uint32_t n_tiles = tw * th;
+    if (n_isects == 0) {
+        std::fill(offsets, offsets + size_t(C) * n_tiles, 0);
+        return;
+    }
+    const uint32_t tile_n_bits = (uint32_t)floor(log2(n_tiles)) + 1;
+    cuemu::launch(dim3(unsigned((n_isects + 255) / 256)), dim3(256), false,
+                  [&]() { gsplat::intersect_offset_kernel(uint32_t(n_isects), isect_ids, C, n_tiles, tile_n_bits, offsets); });
 }

@@ -241,3 +241,37 @@ def test_hip_bilateral_grid_component_matches_the_reference_host_code(lfs):
     lg.close(n(bg2.parameters().grad), h("bilateral/g_grids"), 3e-5, "fused d / d grids")
     lg.close(n(g_img), h("bilateral/g_rgb"), 3e-5, "fused d / d rgb")
     assert abs(float(acc) - w_tv * float(h("bilateral/tv"))) <= 1e-5 * w_tv * float(h("bilateral/tv"))
+
+
+# ---- K2 / K9 and K3 - K6 against the reference's own kernels (tests/golden/refk_sh_isect.npz) -----------------------------------------------------------------
+import refk_sh_isect_util as shi  # noqa: E402
+import test_oracle_refk_sh_isect_golden as shg  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(shi.SH_CASES))
+def test_hip_sh_matches_the_reference_kernels(lfs, name):
+    from gpu_util import n, t
+    from lichtfeld_studio_amd import ops
+    c, g = shi.SH_CASES[name], lambda k: shg.GOLD[f"sh/{name}/{k}"]
+    dirs, coeffs, masks, v = shi.sh_inputs(c)
+    d, co, m = t(dirs), t(coeffs), t(masks, torch.bool)
+    col = n(ops.spherical_harmonics_fwd(c["degree"], d, co, m))
+    shg.close(np.where(masks[:, None], col, 0), g("colors"), 3e-6, "colors")
+    shg.close(n(ops.spherical_harmonics_fwd(c["degree"], d, co, None)), g("colors_unmasked"), 3e-6, "colors without mask")
+    v_coeffs, v_dirs = ops.spherical_harmonics_bwd(coeffs.shape[1], c["degree"], d, co, m, t(v), True)
+    shg.close(n(v_coeffs), g("v_coeffs"), 3e-6, "v_coeffs")
+    shg.close(n(v_dirs), g("v_dirs"), 1e-5, "v_dirs")
+
+
+@pytest.mark.parametrize("name", sorted(shi.ISECT_CASES))
+def test_hip_intersection_matches_the_reference_kernels(lfs, name):
+    from gpu_util import n, t
+    from lichtfeld_studio_amd import ops
+    c, g = shi.ISECT_CASES[name], lambda k: shg.GOLD[f"isect/{name}/{k}"]
+    m, r, d = shi.isect_inputs(c)
+    tw, th = (c["W"] + c["tile"] - 1) // c["tile"], (c["H"] + c["tile"] - 1) // c["tile"]
+    tpg, ids, flat = ops.intersect_tile(t(m), t(r, torch.int32), t(d), None, None, c["C"], c["tile"], tw, th, True)
+    assert np.array_equal(n(tpg), g("tiles_per_gauss")) and np.array_equal(n(ids), g("isect_ids")) and np.array_equal(n(flat), g("flatten_ids"))
+    _, ids_u, flat_u = ops.intersect_tile(t(m), t(r, torch.int32), t(d), None, None, c["C"], c["tile"], tw, th, False)
+    assert np.array_equal(n(ids_u), g("isect_ids_unsorted")) and np.array_equal(n(flat_u), g("flatten_ids_unsorted"))
+    assert np.array_equal(n(ops.intersect_offset(ids, c["C"], tw, th)), g("offsets"))
