@@ -6,9 +6,12 @@
   OpenImageIO resample              third-party (vcpkg "openimageio", version floating with the vcpkg baseline
                                     4334d8b4c8916018600212ab4dd4bbdc343065d1; not vendored): ImageBufAlgo::resample(interpolate=true)
                                     restated from its published algorithm (sample at the destination pixel centre, bilinear, clamp)
-  compute_mean_neighbor_distances   src/core/splat_data.cpp:64-111 (nanoflann kd-tree there; exact search either way)
-PARITY UNPINNED: the reference has no tests or fixtures for any of this, and its loaders need libtorch + OpenImageIO + tinyply to
-build. The writers below produce the byte layouts COLMAP documents; the readers are checked against them and against Pillow.
+  compute_mean_neighbor_distances   src/core/splat_data.cpp:64-111: nanoflann queried with eps = 10 (approximate) - NanoflannTree below restates the vendored
+                                    nanoflann's tree and search; mean_neighbor_distances_exact is the exact 3-NN mean the comment there promises
+PINNED to the reference's own code where it builds here (tests/test_loader_reference.py): the COLMAP readers and camera assembly to colmap.cpp compiled against
+libtorch (oracle/_ref/libref_colmap.so, tests/golden/ref_colmap.npz); the PLY bytes, the neighbour query and init_model_from_pointcloud to splat_data.cpp
+(libref_splat_io.so, tests/golden/ref_splat_io.npz). Still PARITY UNPINNED: load_image's sizes and the OpenImageIO resample (image_io.cpp needs OpenImageIO,
+absent here) - checked against Pillow and the published filter. The writers below produce the byte layouts COLMAP documents.
 """
 import os
 import struct

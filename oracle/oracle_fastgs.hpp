@@ -2,8 +2,10 @@
 // (SURVEY.md §8f row 1): fastgs/rasterization/include/kernels_forward.cuh:19-205 (preprocess), :207-330 (instances),
 // :353-459 (blend); kernel_utils.cuh:15-148 (SH colour, exact tile test); kernels_backward.cuh:19-233 (preprocess
 // backward), :236-448 (blend backward); constants rasterization_config.h:14-33.
-// PARITY UNPINNED for the blend (the reference has no CPU code for it); the EWA covariance / SH colour are cross-checked
-// against the reference's own tests/torch_impl.cpp in tests/test_oracle_fastgs.py.
+// PINNED to the reference's own fastgs code: forward.cu / backward.cu and the kernels of its headers are run on the CPU (oracle/ref_kernels_fastgs.cpp,
+// `make -C oracle refk_fastgs`), their outputs are committed as tests/golden/refk_fastgs.npz, and tests/test_oracle_refk_fastgs_golden.py holds this restatement
+// to them (counts identical, image 3e-7, gradients 1e-4 relative L2). The EWA covariance / SH colour are also cross-checked against the reference's
+// tests/torch_impl.cpp in tests/test_oracle_fastgs.py.
 // Ordering inside a tile: ascending (depth bits, primitive index) — the reference sorts by depth only and breaks ties by the
 // arrival order of an atomicAdd (kernels_forward.cuh:200-203), i.e. not deterministically.
 #pragma once

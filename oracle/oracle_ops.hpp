@@ -5,18 +5,15 @@
 // /root/reference/gsplat/Ops.h and the fastgs fused Adam. Each function names
 // the reference file:line it follows.
 //
-// PARITY PINNING STATUS:
-//   * spherical harmonics fwd, quat->rotmat and tile intersection are checked
-//     against the reference's own CPU code (tests/torch_impl.cpp, built in
-//     place into oracle/_ref) and against golden vectors generated from it
-//     (tests/golden/, script oracle/make_golden.py).
-//   * projection_ut_3dgs_fused, rasterize_to_pixels_from_world_3dgs_{fwd,bwd},
-//     relocation, add_noise and adam_step have NO reference CPU code, tests or
-//     golden vectors (the reference's test-suite is stale, its .pt fixture is
-//     absent, its CUDA path cannot be built here): for these ops this oracle is
-//     "PARITY UNPINNED" — it restates the CUDA kernels line by line and is
-//     validated only by internal consistency (finite differences, float vs
-//     double, Adam vs torch.optim.Adam).
+// PARITY PINNING STATUS: every operator restated here is held to the reference's own code run on this machine.
+//   * spherical harmonics fwd, quat->rotmat and tile intersection: the reference's CPU code tests/torch_impl.cpp (built in place into oracle/_ref) and golden
+//     vectors generated from it (tests/golden/, oracle/make_golden.py) - since round 1.
+//   * ALL device kernels of the path - projection_ut_3dgs_fused, spherical harmonics fwd / bwd, the tile-intersection kernels with the radix sort and the
+//     offsets, rasterize_to_pixels_from_world_3dgs_{fwd,bwd}, relocation, add_noise, quats_to_rotmats, adam_step: the reference's .cu kernels compiled in place as
+//     host code under oracle/ref_emul/ (ref_kernels.cpp, `make refk`), golden vectors tests/golden/refk_*.npz (oracle/make_golden_refk*.py), tests
+//     tests/test_oracle_refk_golden.py and tests/test_oracle_refk_sh_isect_golden.py - round 2. The reference's own test-suite has no tests or fixtures for them.
+//   * their composition into the render + backward of a training step: the reference's rasterize() + autograd Functions + Camera on CPU libtorch
+//     (ref_raster_shim.cpp, tests/golden/ref_raster.npz, tests/test_oracle_ref_raster_golden.py).
 #pragma once
 #include "oracle_cameras.hpp"
 #include <algorithm>
