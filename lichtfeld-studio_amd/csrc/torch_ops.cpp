@@ -481,12 +481,17 @@ gs::loader::SplatTensors gs::loader::load_ply(const std::filesystem::path& path)
     gs::loader::SplatTensors out;
     out.means = torch::cat({columns("x", true), columns("y", true), columns("z", true)}, 1);
     if (out.means.size(1) != 3) throw std::runtime_error("Only binary PLY with position supported");
-    // missing columns become zeros, as ply.cpp does (no identity rotation is assumed there either)
+    // the reference's defaults for missing columns (ply.cpp:531-600; held to its reader in tests/test_loader_reference.py): sh0 zeros [N,1,3], shN zeros
+    // [N,15,3], opacity 0, log-scale -5, the identity quaternion
     const torch::Tensor dc = columns("f_dc_", false), rest = columns("f_rest_", false), sc = columns("scale_", false), ro = columns("rot_", false), op = columns("opacity", true);
-    out.sh0 = dc.size(1) ? dc.reshape({N, 3, -1}).transpose(1, 2).contiguous() : torch::zeros({N, 1, 3}, torch::kFloat32);
-    out.shN = rest.size(1) ? rest.reshape({N, 3, -1}).transpose(1, 2).contiguous() : torch::zeros({N, 0, 3}, torch::kFloat32);
-    out.scaling = sc.size(1) == 3 ? sc.contiguous() : torch::zeros({N, 3}, torch::kFloat32);
-    out.rotation = ro.size(1) == 4 ? ro.contiguous() : torch::zeros({N, 4}, torch::kFloat32);
+    out.sh0 = (dc.size(1) && dc.size(1) % 3 == 0) ? dc.reshape({N, 3, -1}).transpose(1, 2).contiguous() : torch::zeros({N, 1, 3}, torch::kFloat32);
+    out.shN = (rest.size(1) && rest.size(1) % 3 == 0) ? rest.reshape({N, 3, -1}).transpose(1, 2).contiguous() : torch::zeros({N, 15, 3}, torch::kFloat32);
+    out.scaling = sc.size(1) == 3 ? sc.contiguous() : torch::full({N, 3}, -5.0f, torch::kFloat32);
+    if (ro.size(1) == 4) out.rotation = ro.contiguous();
+    else {
+        out.rotation = torch::zeros({N, 4}, torch::kFloat32);
+        out.rotation.select(1, 0).fill_(1.0f);
+    }
     out.opacity = op.size(1) == 1 ? op.reshape({N}).contiguous() : torch::zeros({N}, torch::kFloat32);
     return out;
 }

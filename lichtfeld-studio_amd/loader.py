@@ -321,9 +321,11 @@ def read_ply(path: str) -> Tuple[List[str], np.ndarray]:
         lib.lfs_ply_close(h)
 
 
-def load_ply(path: str, device="cuda:0"):
-    """load_ply (src/loader/formats/ply.cpp:186-640) -> SplatModel: sh degree from the f_rest count, missing opacity / scale /
-    rotation columns become zeros (identity rotation is NOT assumed there either)."""
+def load_ply(path: str, device="cuda:0", active_sh_degree: Optional[int] = 0):
+    """load_ply (src/loader/formats/ply.cpp:497-640) -> SplatModel, held to the reference's reader run on the CPU (tests/test_loader_reference.py).
+    Columns that the file lacks get the reference's defaults (:531-600): sh0 zeros [N,1,3]; shN zeros [N,15,3] (degree 3); opacity 0; log-scale -5 when there
+    is no scale_0; the identity quaternion (1,0,0,0) when there is no rot_0. SH degree from the shN width; the model starts at active degree 0, as the SplatData
+    the reference constructs does (splat_data.cpp:211; its viewer sets the degree per request) - pass active_sh_degree=None for the maximum."""
     from .rasterizer import SplatModel
     names, data = read_ply(path)
     col = {n: i for i, n in enumerate(names)}
@@ -334,15 +336,22 @@ def load_ply(path: str, device="cuda:0"):
     dc, rest = pick("f_dc_"), pick("f_rest_")
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
     means = t(data[:, [col["x"], col["y"], col["z"]]])
-    sh0 = t(data[:, dc]).reshape(N, 3, -1).transpose(1, 2) if dc else torch.zeros((N, 1, 3), device=device)
-    shN = t(data[:, rest]).reshape(N, 3, -1).transpose(1, 2) if rest else torch.zeros((N, 0, 3), device=device)
+    sh0 = t(data[:, dc]).reshape(N, 3, -1).transpose(1, 2) if dc and len(dc) % 3 == 0 else torch.zeros((N, 1, 3), device=device)
+    shN = t(data[:, rest]).reshape(N, 3, -1).transpose(1, 2) if rest and len(rest) % 3 == 0 else torch.zeros((N, 15, 3), device=device)
     opac = t(data[:, col["opacity"]]) if "opacity" in col else torch.zeros(N, device=device)
     sc, ro = pick("scale_"), pick("rot_")
-    scales = t(data[:, sc]) if len(sc) == 3 else torch.zeros((N, 3), device=device)
-    quats = t(data[:, ro]) if len(ro) == 4 else torch.zeros((N, 4), device=device)
+    if "scale_0" in col:
+        scales = t(data[:, [col[f"scale_{i}"] for i in range(3)]])
+    else:
+        scales = torch.full((N, 3), -5.0, device=device)
+    if "rot_0" in col:
+        quats = t(data[:, [col[f"rot_{i}"] for i in range(4)]])
+    else:
+        quats = torch.zeros((N, 4), device=device)
+        quats[:, 0] = 1.0
     sh_degree = int(np.sqrt(shN.shape[1] + 1)) - 1
     mk = lambda x: x.contiguous().requires_grad_(True)
-    return SplatModel(mk(means), mk(sh0), mk(shN), mk(scales), mk(quats), mk(opac), sh_degree)
+    return SplatModel(mk(means), mk(sh0), mk(shN), mk(scales), mk(quats), mk(opac), sh_degree, active_sh_degree=active_sh_degree)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ def build(ref: bool = True) -> None:
         # targets cost a minute or two of header parsing each when built from scratch. The four the core parity tests use must build; the others only serve the
         # *_reference tests, which skip without them, so their failure does not fail build().
         core = ["ref", "refk", "refk_fastgs", "refk_loss"]
-        more = ["refcolmap", "refsplatio", "refstrategy", "refraster", "reflosshost"]
+        more = ["refcolmap", "refsplatio", "refstrategy", "refraster", "reflosshost", "refply"]
         subprocess.run(["make", "-C", _HERE, "-k", "-j8", *core, *more], check=False, capture_output=True)
         subprocess.run(["make", "-C", _HERE, *core], check=True, capture_output=True)     # (up to date unless the parallel run failed: then this reports it)
 
@@ -927,3 +927,42 @@ def refk_intersect_offset(isect_ids, Cn, tile_width, tile_height):
     refk_lib().refk_intersect_offset(C.c_int64(len(ids)), ids.ctypes.data_as(C.c_void_p), C.c_uint32(Cn), C.c_uint32(tile_width), C.c_uint32(tile_height),
                                      off.ctypes.data_as(C.c_void_p))
     return off
+
+
+# ---- the reference's own PLY reader on CPU libtorch (oracle/_ref/libref_ply.so; ref_ply_shim.cpp) --------------------------------------------------------------
+_REF_PLY = None
+
+
+def ref_ply_lib():
+    global _REF_PLY
+    if _REF_PLY is None:
+        path = os.path.join(_HERE, "_ref", "libref_ply.so")
+        if not os.path.exists(path):
+            return None
+        lib = C.CDLL(path)
+        lib.refply_last_error.restype = C.c_char_p
+        lib.refply_load.restype = C.c_int64
+        lib.refply_get.restype = C.c_int64
+        lib.refply_scene_scale.restype = C.c_float
+        _REF_PLY = lib
+    return _REF_PLY
+
+
+def ref_load_ply(path):
+    """gs::loader::load_ply of the reference -> dict(means, sh0, shN, scaling, rotation, opacity (raw tensors as SplatData holds them), sh_degree, scene_scale);
+    raises RuntimeError with the reference's message"""
+    lib = ref_ply_lib()
+    if lib.refply_load(os.fsencode(path)) < 0:
+        raise RuntimeError(lib.refply_last_error().decode())
+    out = {}
+    for i, name in enumerate(("means", "sh0", "shN", "scaling", "rotation", "opacity")):
+        shape = (C.c_int64 * 3)()
+        n = lib.refply_get(C.c_int(i), shape, None)
+        a = np.empty(n, np.float32)
+        lib.refply_get(C.c_int(i), shape, _p(a))
+        dims = [int(s) for s in shape]
+        while len(dims) > 1 and dims[-1] == 0 and int(np.prod(dims[:-1])) == n:
+            dims.pop()
+        out[name] = a.reshape(dims) if int(np.prod(dims)) == n else a
+    out["sh_degree"], out["scene_scale"] = lib.refply_sh_degree(), lib.refply_scene_scale()
+    return out

@@ -33,6 +33,18 @@ def init_cases():
             "dups_160_deg1_mcmc_json": (b, rng.integers(0, 256, (160, 3)).astype(np.uint8), np.array([0.0, 0.0, 0.0], np.float32), 1, 0.1, 0.5)}
 
 
+def ply_reader_files(full_splat_bytes):
+    """name -> bytes of a binary little-endian PLY: the full splat file; positions only; positions + opacity + one scale column missing rot; f_dc without f_rest"""
+    hdr = lambda props, n: ("ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % n + "".join(f"property float {p}\n" for p in props) + "end_header\n").encode()
+    rng = np.random.default_rng(12)
+    f = lambda n, k: rng.standard_normal((n, k)).astype("<f4").tobytes()
+    return {"full_splat": full_splat_bytes,
+            "positions_only": hdr(["x", "y", "z"], 5) + f(5, 3),
+            "no_rotation_no_sh": hdr(["x", "y", "z", "opacity", "scale_0", "scale_1", "scale_2"], 7) + f(7, 7),
+            "dc_without_rest_reordered": hdr(["opacity", "x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2", "rot_0", "rot_1", "rot_2", "rot_3"], 4) + f(4, 11),
+            "degree1_rest": hdr(["x", "y", "z"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(9)], 6) + f(6, 15)}
+
+
 def ply_case():
     rng = np.random.default_rng(3)
     N, K = 101, 9
@@ -57,6 +69,17 @@ if __name__ == "__main__":
         out[f"ply/{k}"] = v
     with tempfile.TemporaryDirectory() as d:
         out["ply/file_bytes"] = np.frombuffer(oracle.ref_write_ply(d, "splat", c["means"], c["sh0"], c["shN"], c["opacity"], c["scaling"], c["rotation"]), np.uint8)
+    # ---- the reference's PLY READER (oracle/_ref/libref_ply.so: src/loader/formats/ply.cpp) on the file its writer made above and on sparse files: which defaults
+    # it fills in for columns a file lacks
+    if oracle.ref_ply_lib() is not None:
+        with tempfile.TemporaryDirectory() as d:
+            for name, data in ply_reader_files(out["ply/file_bytes"].tobytes()).items():
+                fn = os.path.join(d, name + ".ply")
+                open(fn, "wb").write(data)
+                r = oracle.ref_load_ply(fn)
+                out[f"plyread/{name}/file_bytes"] = np.frombuffer(data, np.uint8)
+                for k, v in r.items():
+                    out[f"plyread/{name}/{k}"] = np.asarray(v)
     path = os.path.join(ROOT, "tests", "golden", "ref_splat_io.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path) // 1024, "KiB")

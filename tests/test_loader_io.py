@@ -186,7 +186,8 @@ def test_ply_write_matches_reference_layout_and_reads_back(ld, tmp_path):
     for name, x, y in zip(["means", "sh0", "shN", "scales", "quats", "opac"], back.parameters(), [t["means"], t["sh0"], t["shN"], t["scales"],
                                                                                                  torch.nn.functional.normalize(t["quats"], dim=-1), t["opac"]]):
         assert x.shape == y.shape and torch.allclose(x.detach(), y, atol=1e-7), name
-    assert back.get_active_sh_degree() == 2
+    assert back.get_active_sh_degree() == 0 and back.max_sh_degree == 2          # a loaded model starts at degree 0, like the reference's SplatData
+    assert ld.load_ply(path, device="cpu", active_sh_degree=None).get_active_sh_degree() == 2
     # generic reader: ascii, mixed types, an element after the vertices, doubles
     p2 = str(tmp_path / "mixed.ply")
     open(p2, "w").write("ply\nformat ascii 1.0\ncomment hi\nelement vertex 2\nproperty double x\nproperty float y\nproperty uchar red\nelement face 1\n"
@@ -466,7 +467,9 @@ def test_libtorch_loader_adapters_equal_python_host_layer(ld, tmp_path):
         assert x.shape == y.shape and torch.equal(x, y.detach())
     open(a, "wb").write(b"ply\nformat binary_little_endian 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\nend_header\n" + bytes(12))
     back = m.load_ply(a)
-    assert back[1].shape == (1, 1, 3) and back[2].shape == (1, 0, 3) and back[4].shape == (1, 4) and not back[4].any() and back[5].shape == (1,)
+    # positions only: the reference's defaults (ply.cpp:531-600) - shN [N,15,3] zeros, log-scale -5, identity quaternion, opacity 0
+    assert back[1].shape == (1, 1, 3) and back[2].shape == (1, 15, 3) and not back[2].any() and back[5].shape == (1,) and not back[5].any()
+    assert back[3].tolist() == [[-5.0, -5.0, -5.0]] and back[4].tolist() == [[1.0, 0.0, 0.0, 0.0]]
     with pytest.raises(RuntimeError, match="No end_header"):
         open(a, "wb").write(b"ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty float x\n" + b" " * 8)
         m.load_ply(a)

@@ -268,3 +268,44 @@ def test_live_splat_io_golden_regenerates_and_random_sets_agree(emulated_datapre
         n_pts = int(rng.integers(2000, 20000))
         pts = (rng.standard_normal((n_pts, 3)) * rng.uniform(0.1, 10, 3)).astype(np.float32)
         assert np.array_equal(emulated_dataprep(pts), oracle.ref_mean_neighbor_distances(pts)), (k, n_pts)
+
+
+# ---- the PLY reader against the reference's own reader (src/loader/formats/ply.cpp on CPU libtorch, oracle/_ref/libref_ply.so; "plyread/..." in ref_splat_io.npz) --
+PLYREAD = sorted({k.split("/")[1] for k in SPLAT.files if k.startswith("plyread/")})
+
+
+@pytest.mark.parametrize("name", PLYREAD)
+def test_product_ply_reader_equals_the_reference_reader(ld, tmp_path, name):
+    """loader.load_ply on the same bytes: the six tensors, the SH degree the model holds and the degree it starts at - incl. the defaults the reference fills in
+    for missing columns (zeros [N,15,3] for shN, log-scale -5, identity quaternion), which round 1 had wrong (zeros) from reading ply.cpp's comments."""
+    g = lambda k: SPLAT[f"plyread/{name}/{k}"]
+    path = str(tmp_path / "in.ply")
+    open(path, "wb").write(g("file_bytes").tobytes())
+    m = ld.load_ply(path, device="cpu")
+    for key, p in zip(("means", "sh0", "shN", "scaling", "rotation", "opacity"), m.parameters()):
+        ref = g(key)
+        got = p.detach().numpy()
+        assert got.reshape(-1).shape == ref.reshape(-1).shape and np.array_equal(got.reshape(-1), ref.reshape(-1)), (name, key, got.shape, ref.shape)
+        if key != "opacity":                                     # (SplatModel holds opacity as [N], SplatData as [N,1])
+            assert got.shape == ref.shape, (name, key)
+    assert m.get_active_sh_degree() == int(g("sh_degree")) == 0
+    assert m.max_sh_degree == int(np.sqrt(g("shN").shape[1] + 1)) - 1
+
+
+@pytest.mark.skipif(oracle.ref_ply_lib() is None, reason="oracle/_ref/libref_ply.so not built (needs /root/reference)")
+def test_live_ply_reader_golden_regenerates_and_errors_agree(ld, tmp_path):
+    from oracle import make_golden_ref_splat_io as mg
+    for name, data in mg.ply_reader_files(SPLAT["ply/file_bytes"].tobytes()).items():
+        fn = str(tmp_path / (name + ".ply"))
+        open(fn, "wb").write(data)
+        assert data == SPLAT[f"plyread/{name}/file_bytes"].tobytes()
+        for k, v in oracle.ref_load_ply(fn).items():
+            assert np.array_equal(np.asarray(v), SPLAT[f"plyread/{name}/{k}"]), (name, k)
+    for bad, sentence in ((b"plx\n" + b" " * 20, "missing PLY header"), (b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n1\n", "Only binary PLY"),
+                          (b"ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty float x\n" + b" " * 8, "No end_header")):
+        fn = str(tmp_path / "bad.ply")
+        open(fn, "wb").write(bad)
+        with pytest.raises(RuntimeError, match=sentence):
+            oracle.ref_load_ply(fn)
+        with pytest.raises(ld.LoaderError):
+            ld.load_ply(fn, device="cpu")
