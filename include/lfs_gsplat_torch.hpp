@@ -129,7 +129,9 @@ std::tuple<std::vector<CameraData>, torch::Tensor> read_transforms_cameras_and_i
 PointCloud read_colmap_point_cloud(const std::filesystem::path& base);
 PointCloud read_colmap_point_cloud_text(const std::filesystem::path& base);
 // SplatData::save_ply's file (src/core/splat_data.cpp:113-169, 402-505): tensors of any device; sh0 [N,1,3] and shN [N,K,3] are written transposed
-// ([N,3,K] flattened) as there. load_ply (src/loader/formats/ply.cpp:186-640) returns the same six tensors on the CPU.
+// ([N,3,K] flattened) as there. load_ply (src/loader/formats/ply.cpp:186-640) returns the same six tensors on the CPU, with the reference's defaults for columns
+// the file lacks (:531-600: sh0 zeros [N,1,3], shN zeros [N,15,3], opacity 0, log-scale -5, identity quaternion); the file written by save_ply is byte-identical
+// to the reference writer's, and load_ply equals the reference's reader (tests/test_loader_reference.py).
 struct SplatTensors { torch::Tensor means, sh0, shN, scaling, rotation, opacity; };
 void save_ply(const std::filesystem::path& path, const torch::Tensor& means, const torch::Tensor& sh0, const torch::Tensor& shN, const torch::Tensor& scaling,
               const torch::Tensor& rotation, const torch::Tensor& opacity);
