@@ -33,7 +33,7 @@ def build(ref: bool = True) -> None:
         # targets cost a minute or two of header parsing each when built from scratch. The four the core parity tests use must build; the others only serve the
         # *_reference tests, which skip without them, so their failure does not fail build().
         core = ["ref", "refk", "refk_fastgs", "refk_loss"]
-        more = ["refcolmap", "refsplatio", "refstrategy", "refraster", "reflosshost", "refply"]
+        more = ["refcolmap", "refsplatio", "refstrategy", "refraster", "reflosshost", "refply", "refgsplat"]
         subprocess.run(["make", "-C", _HERE, "-k", "-j8", *core, *more], check=False, capture_output=True)
         subprocess.run(["make", "-C", _HERE, *core], check=True, capture_output=True)     # (up to date unless the parallel run failed: then this reports it)
 
@@ -800,8 +800,17 @@ def ref_init_model_from_pointcloud(positions, colors_u8, scene_center, sh_degree
 _REF_RASTER = None
 
 
-def ref_raster_lib():
+def ref_raster_lib(full=False):
+    """full=False: libref_raster.so (the reference's render path over the restated launch sequences of ref_raster_shim.cpp / ref_kernels.cpp);
+    full=True: libref_raster_full.so (`make -C oracle refgsplat`: the same over the reference's WHOLE gsplat library, nothing of the operator layer restated)"""
     global _REF_RASTER
+    if full:
+        path = os.path.join(_HERE, "_ref", "libref_raster_full.so")
+        if not os.path.exists(path):
+            return None
+        if "full" not in _REF_RASTER_FULL:
+            _REF_RASTER_FULL["full"] = C.CDLL(path)
+        return _REF_RASTER_FULL["full"]
     if _REF_RASTER is None:
         path = os.path.join(_HERE, "_ref", "libref_raster.so")
         if not os.path.exists(path):
@@ -810,7 +819,11 @@ def ref_raster_lib():
     return _REF_RASTER
 
 
-def ref_render_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, v_image, v_alpha=None):
+_REF_RASTER_FULL = {}
+
+
+def ref_render_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, v_image, v_alpha=None,
+                        full=False):
     """gs::training::rasterize() of the reference for one pinhole camera + backward of sum(image * v_image) [+ sum(alpha * v_alpha)] through its autograd
     Functions: raw parameters as SplatData holds them (sh0 [N,1,3], shN [N,K,3], opacity [N]) -> dict(image [3,H,W], alpha [1,H,W], radii [N], viewmat [4,4],
     K [3,3], g_means, g_sh0, g_shN, g_scaling, g_rotation, g_opacity)"""
@@ -822,7 +835,7 @@ def ref_render_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, 
     out = dict(image=np.empty((3, height, width), np.float32), alpha=np.empty((1, height, width), np.float32), radii=np.empty(N, np.int32),
                g_means=np.empty((N, 3), np.float32), g_sh0=np.empty((N, 1, 3), np.float32), g_shN=np.empty((N, K1, 3), np.float32), g_scaling=np.empty((N, 3), np.float32),
                g_rotation=np.empty((N, 4), np.float32), g_opacity=np.empty(N, np.float32), viewmat=np.empty((4, 4), np.float32), K=np.empty((3, 3), np.float32))
-    rc = ref_raster_lib().refraster_render_backward(
+    rc = ref_raster_lib(full).refraster_render_backward(
         C.c_int64(N), C.c_int64(K1), C.c_int(sh_degree), C.c_int(active_sh_degree), *[_p(a) for a in arrs], _p(R), _p(T), C.c_float(fx), C.c_float(fy), C.c_float(cx),
         C.c_float(cy), C.c_int(width), C.c_int(height), C.c_int(width), C.c_int(height), None if bg is None else _p(bg), _p(v_image),
         None if v_alpha is None else _p(v_alpha), _p(out["image"]), _p(out["alpha"]), out["radii"].ctypes.data_as(C.c_void_p),

@@ -1,6 +1,7 @@
-"""Generate tests/golden/ref_raster.npz by running the REFERENCE'S OWN training-time render path end to end on the CPU (oracle/_ref/libref_raster.so: rasterizer.cpp,
-rasterizer_autograd.cpp, camera.cpp, SplatData's activations compiled in place against libtorch, over the reference's device kernels under ref_emul/ and its
-tests/torch_impl.cpp; `make -C oracle ref refk refraster`) on the scenes of tests/refraster_util.py: image, alpha, radii, the camera matrices the Camera class
+"""Generate tests/golden/ref_raster.npz by running the REFERENCE'S OWN training-time render path end to end on the CPU (oracle/_ref/libref_raster_full.so:
+rasterizer.cpp, rasterizer_autograd.cpp, camera.cpp, SplatData's activations AND the whole gsplat library - every .cu with its launch functions, every .cpp operator -
+compiled in place against libtorch under oracle/ref_emul/; `make -C oracle refgsplat`). (oracle/_ref/libref_raster.so, `make refraster`, is the same render path
+over the restated launch sequences of ref_raster_shim.cpp with the reference's tests/torch_impl.cpp for SH and intersection: it reproduces this file to 5e-6.) on the scenes of tests/refraster_util.py: image, alpha, radii, the camera matrices the Camera class
 derives, and the gradients of the six raw parameter tensors for the loss sum(image * v_image) [+ sum(alpha * v_alpha)]. Run in the build container:
     python oracle/make_golden_ref_raster.py
 tests/test_gpu_raster_reference.py holds the product's rasterize() + backward to it - the composition of SURVEY.md §8 rows a1-a6 as the reference composes them."""
@@ -16,17 +17,17 @@ import oracle  # noqa: E402
 import refraster_util as U  # noqa: E402
 
 
-def run(c):
+def run(c, full=False):
     s = U.scene(c)
     return oracle.ref_render_backward(s["means"], s["sh0"], s["shN"], s["scaling"], s["rotation"], s["opacity"], c["sh_degree"], c["active"], s["R"], s["T"], c["focal"],
-                                      c["focal"] * 1.05, c["W"] / 2 + 0.5, c["H"] / 2 - 0.25, c["W"], c["H"], c["bg"], s["v_image"], s["v_alpha"])
+                                      c["focal"] * 1.05, c["W"] / 2 + 0.5, c["H"] / 2 - 0.25, c["W"], c["H"], c["bg"], s["v_image"], s["v_alpha"], full=full)
 
 
 if __name__ == "__main__":
-    assert oracle.ref_raster_lib() is not None, "build oracle/_ref/libref_raster.so first (make -C oracle ref refk refraster)"
+    assert oracle.ref_raster_lib(full=True) is not None, "build oracle/_ref/libref_raster_full.so first (make -C oracle refgsplat)"
     out = {}
     for name, c in U.CASES.items():
-        r = run(c)
+        r = run(c, full=True)      # the reference's whole gsplat library behind its render path: nothing of the operator layer restated
         print(f"{name}: visible {(r['radii'] > 0).sum()} of {c['N']}, mean alpha {r['alpha'].mean():.3f}, |g_means| max {np.abs(r['g_means']).max():.3g}")
         for k, v in r.items():
             out[f"{name}/{k}"] = v

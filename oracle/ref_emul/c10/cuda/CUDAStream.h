@@ -7,9 +7,14 @@
 namespace at::cuda {
     struct CUDAStream {
         void synchronize() const {}
+        operator void*() const { return nullptr; } // as the stream argument of a (stand-in) cub call
     };
     inline CUDAStream getStreamFromPool(bool = false) { return {}; }
     struct CUDAStreamGuard {
         explicit CUDAStreamGuard(const CUDAStream&) {}
     };
+    struct OptionalCUDAGuard { // DEVICE_GUARD of gsplat/Common.h
+        template <class T> explicit OptionalCUDAGuard(T&&) {}
+    };
+    inline CUDAStream getCurrentCUDAStream() { return {}; }
 } // namespace at::cuda

@@ -204,6 +204,7 @@ static inline float cuemu_powf(float x, float y) { return powf(x, y); }
 #define __logf cuemu_logf
 #define __powf cuemu_powf
 static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline double pow(double a, int b) { return ::pow(a, double(b)); }
 static inline float pow(float a, int b) { return powf(a, float(b)); }   // CUDA's math overload set has pow(float, int) -> float (host <cmath> would promote to double)
 static inline float __fdividef(float a, float b) { return a / b; }
 // float -> unsigned conversion as the GPU does it (cvt.rzi.u32.f32 saturates: negative and NaN -> 0, too large -> 0xffffffff); in C++ it is undefined for those
@@ -226,7 +227,7 @@ static inline unsigned min(int a, unsigned b) { return min(unsigned(a), b); }
 static inline unsigned max(unsigned a, int b) { return max(a, unsigned(b)); }
 static inline unsigned max(int a, unsigned b) { return max(unsigned(a), b); }
 
-template <typename T> static inline T gpuAtomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <typename T, typename U> static inline T gpuAtomicAdd(T* p, U v) { const T o = *p; *p = o + T(v); return o; }   // (ATen's overload set converts the addend)
 template <typename T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
 
 enum cudaError_t { cudaSuccess = 0 };

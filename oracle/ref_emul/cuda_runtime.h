@@ -56,6 +56,10 @@ template <class K> struct Launcher {
 template <class K> Launcher<K> launcher(K k, dim3 g, dim3 b) { return Launcher<K>{k, g, b}; }
 template <class K> Launcher<K> launcher(K k, long long g, long long b) { return Launcher<K>{k, dim3(unsigned(g)), dim3(unsigned(b))}; }
 } // namespace cuemu
+enum cudaFuncAttribute { cudaFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <class K> static inline cudaError_t cudaFuncSetAttribute(K, cudaFuncAttribute, long long) { return cudaSuccess; } // the emulator's arena is static
+namespace cuemu {
+} // namespace cuemu
 
 // ---- warp intrinsics (full-mask forms; a lane that has returned contributes 0 / false, as on the GPU for an exited lane) ----------------
 static inline unsigned __ballot_sync(unsigned, int pred) {

@@ -58,6 +58,7 @@ template <typename T, qualifier Q> struct vec<4, T, Q> {
     constexpr vec(T s) : x(s), y(s), z(s), w(s) {}
     template <typename A, typename B, typename C, typename D> constexpr vec(A a, B b, C c, D d) : x(T(a)), y(T(b)), z(T(c)), w(T(d)) {}
     template <typename D> constexpr vec(const vec<3, T, Q>& v, D d) : x(v.x), y(v.y), z(v.z), w(T(d)) {}
+    template <typename U> constexpr vec(const vec<4, U, Q>& v) : x(T(v.x)), y(T(v.y)), z(T(v.z)), w(T(v.w)) {}
     T& operator[](length_t i) { return (&x)[i]; }
     constexpr const T& operator[](length_t i) const { return (&x)[i]; }
     vec& operator+=(const vec& o) { x += o.x; y += o.y; z += o.z; w += o.w; return *this; }
@@ -143,7 +144,8 @@ template <length_t C, length_t R, typename T, qualifier Q> mat<C, R, T, Q> opera
 template <length_t C, length_t R, typename T, qualifier Q> mat<C, R, T, Q> operator*(T s, const mat<C, R, T, Q>& a) { mat<C, R, T, Q> r; for (length_t i = 0; i < C; ++i) r[i] = a[i] * s; return r; }
 template <length_t C, length_t R, typename T, qualifier Q> mat<C, R, T, Q> operator/(const mat<C, R, T, Q>& a, T s) { mat<C, R, T, Q> r; for (length_t i = 0; i < C; ++i) r[i] = a[i] / s; return r; }
 // mat * column vector: sum over the columns in index order (type_mat3x3.inl: m[0][i]*v.x + m[1][i]*v.y + m[2][i]*v.z)
-template <length_t C, length_t R, typename T, qualifier Q> vec<R, T, Q> operator*(const mat<C, R, T, Q>& m, const vec<C, T, Q>& v) {
+// (the vector is a non-deduced parameter, as GLM's `typename mat::row_type const&` is: a vec of another scalar type converts)
+template <length_t C, length_t R, typename T, qualifier Q> vec<R, T, Q> operator*(const mat<C, R, T, Q>& m, const typename mat<C, R, T, Q>::row_type& v) {
     vec<R, T, Q> r;
     for (length_t i = 0; i < R; ++i) { T s = m[0][i] * v[0]; for (length_t k = 1; k < C; ++k) s = s + m[k][i] * v[k]; r[i] = s; }
     return r;

@@ -24,6 +24,7 @@
 
 #define REF_API extern "C" __attribute__((visibility("default")))
 
+#ifndef REF_REAL_GSPLAT // (make refgsplat: the gsplat:: operators below are not restated but taken from the reference's own gsplat/*.cpp + *.cu - ref_gsplat_all.cpp)
 extern "C" {
 void refk_projection_ut(uint32_t C, uint32_t N, const float* means, const float* quats, const float* scales, const float* opacities, const float* viewmats0,
                         const float* viewmats1, const float* Ks, uint32_t W, uint32_t H, float eps2d, float near_plane, float far_plane, float radius_clip,
@@ -174,6 +175,12 @@ namespace gsplat {
         return {v_means, v_quats, v_scales, v_colors, v_opac};
     }
 } // namespace gsplat
+
+#else
+std::tuple<unsigned char*, int, int, int> load_image(std::filesystem::path, int, int) { throw std::runtime_error("ref_raster_shim: no image loading"); }
+void free_image(unsigned char*) {}
+std::tuple<int, int, int> get_image_info(std::filesystem::path) { throw std::runtime_error("ref_raster_shim: no image loading"); }
+#endif
 
 // ---- C API --------------------------------------------------------------------------------------------------------------------------------------------------
 static torch::Tensor f32(const float* p, std::vector<int64_t> shape) { return torch::from_blob(const_cast<float*>(p), shape, torch::kFloat32).clone(); }
