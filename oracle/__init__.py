@@ -354,9 +354,15 @@ def fastgs_backward(fwd, means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c
 _REFK = None
 
 
+REFK_WHOLE_LIBRARY = False   # True: the refk_* calls below go to libref_raster_full.so, whose refk_* entry points call the reference's own gsplat:: operators
+#                              (gsplat/*.cpp over gsplat/*.cu with their launch functions, ref_gsplat_capi.cpp) instead of the restated launch sequences
+
+
 def refk_lib():
     """gsplat/*.cu + fastgs Adam kernels of the reference, compiled in place as host code (`make -C oracle refk`); None when absent."""
     global _REFK
+    if REFK_WHOLE_LIBRARY:
+        return ref_raster_lib(full=True)
     if _REFK is None:
         path = os.path.join(_HERE, "_ref", "libref_kernels.so")
         if not os.path.exists(path):
