@@ -33,7 +33,7 @@ def build(ref: bool = True) -> None:
         # targets cost a minute or two of header parsing each when built from scratch. The four the core parity tests use must build; the others only serve the
         # *_reference tests, which skip without them, so their failure does not fail build().
         core = ["ref", "refk", "refk_fastgs", "refk_loss"]
-        more = ["refcolmap", "refsplatio", "refstrategy", "refraster", "reflosshost", "refply", "refgsplat"]
+        more = ["refcolmap", "refsplatio", "refstrategy", "refraster", "reflosshost", "refply", "refgsplat", "reffast"]
         subprocess.run(["make", "-C", _HERE, "-k", "-j8", *core, *more], check=False, capture_output=True)
         subprocess.run(["make", "-C", _HERE, *core], check=True, capture_output=True)     # (up to date unless the parallel run failed: then this reports it)
 
@@ -480,6 +480,43 @@ def refk_adam_step(param, exp_avg, exp_avg_sq, grad, lr, beta1, beta2, eps, bc1_
 _REFK_FG = None
 
 
+REFK_FASTGS_WHOLE = False   # True: refk_fastgs_fwd_bwd goes through the reference's own forward_wrapper / backward_wrapper (rasterization_api.cu, libref_fast_raster.so)
+_REF_FAST = None
+
+
+def ref_fast_raster_lib():
+    """the reference's fastgs training render path end to end (`make -C oracle reffast`: fast_rasterize + autograd + rasterization_api.cu + forward.cu / backward.cu)"""
+    global _REF_FAST
+    if _REF_FAST is None:
+        path = os.path.join(_HERE, "_ref", "libref_fast_raster.so")
+        if not os.path.exists(path):
+            return None
+        _REF_FAST = C.CDLL(path)
+    return _REF_FAST
+
+
+def ref_fast_render_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, v_image, v_alpha,
+                             densification_info=None):
+    """gs::training::fast_rasterize() of the reference for one pinhole camera + backward of sum(image * v_image) + sum(alpha * v_alpha) -> dict(image, alpha,
+    g_means, g_sh0, g_shN, g_scaling, g_rotation, g_opacity [, densification_info])"""
+    arrs = [_f32(x) for x in (means, sh0, shN, scaling, rotation, opacity)]
+    N, K1 = arrs[0].shape[0], arrs[2].shape[1]
+    R, T, bg, v_image, v_alpha = _f32(R), _f32(T), _f32(bg), _f32(v_image), _f32(v_alpha)
+    dens = None if densification_info is None else _f32(densification_info).copy()
+    out = dict(image=np.empty((3, height, width), np.float32), alpha=np.empty((1, height, width), np.float32), g_means=np.empty((N, 3), np.float32),
+               g_sh0=np.empty((N, 1, 3), np.float32), g_shN=np.empty((N, K1, 3), np.float32), g_scaling=np.empty((N, 3), np.float32),
+               g_rotation=np.empty((N, 4), np.float32), g_opacity=np.empty(N, np.float32))
+    rc = ref_fast_raster_lib().reffast_render_backward(
+        C.c_int64(N), C.c_int64(K1), C.c_int(sh_degree), C.c_int(active_sh_degree), *[_p(a) for a in arrs], _p(R), _p(T), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+        C.c_float(cy), C.c_int(width), C.c_int(height), _p(bg), _p(v_image), _p(v_alpha), None if dens is None else _p(dens), _p(out["image"]), _p(out["alpha"]),
+        *[_p(out[k]) for k in ("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity")])
+    if rc:
+        raise RuntimeError("reffast_render_backward failed")
+    if dens is not None:
+        out["densification_info"] = dens
+    return out
+
+
 def refk_fastgs_lib():
     """fastgs/rasterization of the reference (forward.cu, backward.cu and the kernels in its headers), compiled in place as host code
     (`make -C oracle refk_fastgs`); None when absent."""
@@ -507,7 +544,8 @@ def refk_fastgs_fwd_bwd(means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c,
                  g_opac_raw=np.zeros(N, np.float32), g_sh0=np.zeros((N, 1, 3), np.float32), g_sh_rest=np.zeros((N, max(total_rest, 0), 3), np.float32))
         if densification_info is not None:
             g["densification_info"] = _f32(densification_info).copy()
-    refk_fastgs_lib().refk_fastgs_fwd_bwd(
+    entry = ref_fast_raster_lib().reffast_wrappers if REFK_FASTGS_WHOLE else refk_fastgs_lib().refk_fastgs_fwd_bwd
+    entry(
         C.c_int(N), C.c_int(active_sh_bases), C.c_int(total_rest), C.c_int(W), C.c_int(H), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
         C.c_float(near), C.c_float(far), _p(means), _p(scales_raw), _p(rot_raw), _p(opac_raw), _p(sh0), _p(sh_rest), _p(w2c), _p(cam_pos),
         _p(g_image) if g is not None else None, _p(g_alpha) if g is not None else None, _p(out["image"]), _p(out["alpha"]),

@@ -84,3 +84,23 @@ def test_restated_launch_sequences_reproduce_the_whole_library():
                 assert np.array_equal(v, g), (name, k)
             else:
                 assert np.abs(v.astype(np.float64) - g).max() <= 5e-6 * max(np.abs(g).max(), 1e-30), (name, k)
+
+
+@pytest.mark.skipif(oracle.ref_fast_raster_lib() is None, reason="oracle/_ref/libref_fast_raster.so not built (make -C oracle reffast; needs /root/reference)")
+def test_fastgs_golden_files_regenerate_from_the_whole_reference_fastgs_path():
+    """(1) tests/golden/ref_fast_raster.npz from fast_rasterize() + autograd + rasterization_api.cu + forward.cu / backward.cu, bit for bit; (2) the wrapper-level file
+    refk_fastgs.npz - generated through the restated wrapper of ref_kernels_fastgs.cpp - through the reference's own forward_wrapper / backward_wrapper, bit for bit."""
+    from oracle import make_golden_ref_fast_raster as mg
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", mg.GOLD))
+    for name in mg.CASES:
+        for k, v in mg.run(name).items():
+            assert np.array_equal(v, G[f"{name}/{k}"]), (name, k)
+    import test_oracle_refk_fastgs_golden as fg
+    oracle.REFK_FASTGS_WHOLE = True
+    try:
+        for name, d in fg.CASES.items():
+            r = oracle.refk_fastgs_fwd_bwd(*fg.scene_args(d), d["g_image"], d["g_alpha"], densification_info=d.get("densification_info_in"))
+            for k, v in r.items():
+                assert np.array_equal(np.asarray(v).reshape(d["out_" + k].shape), d["out_" + k]), (name, k)
+    finally:
+        oracle.REFK_FASTGS_WHOLE = False
