@@ -64,8 +64,7 @@ FAST = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"
 def test_fastgs_render_and_backward_follow_the_reference_render_path(lfs, name):
     """fastgs.fast_rasterize (the mirror of gs::training::fast_rasterize, the reference's default training path) + autograd backward against the reference's own
     fast_rasterizer.cpp + fast_rasterizer_autograd.cpp + rasterization_api.cu + forward.cu / backward.cu + Camera run end to end on the CPU
-    (tests/golden/ref_fast_raster.npz): image / alpha 2e-5 max-abs, gradients 5e-4 relative L2 with threshold-flip rows counted (the bars of the wrapper-level
-    test above), densification_info accumulated alike."""
+    (tests/golden/ref_fast_raster.npz): image / alpha 5e-6 max-abs, gradients 2e-5 relative L2 with threshold-flip rows counted (measured: 2e-7 and 3e-7 .. 5e-7, no flip row), densification_info accumulated alike."""
     from lichtfeld_studio_amd import fastgs, loader
     from lichtfeld_studio_amd.rasterizer import Camera, SplatModel
     c, g = U.CASES[name], lambda k: FAST[f"{name}/{k}"]
@@ -79,7 +78,7 @@ def test_fastgs_render_and_backward_follow_the_reference_render_path(lfs, name):
     out = fastgs.fast_rasterize(Camera(t(loader.world_to_view(cam)).unsqueeze(0), t(loader.intrinsics(cam, W, H)).unsqueeze(0), W, H), model, t(g("bg")), dens)
     e_img, e_alpha = np.abs(n(out.image) - g("image")).max(), np.abs(n(out.alpha).reshape(1, H, W) - g("alpha")).max()
     print(f"fastgs {name}: image max-abs {e_img:.2e}, alpha max-abs {e_alpha:.2e}")
-    assert e_img <= 2e-5 and e_alpha <= 2e-5
+    assert e_img <= 5e-6 and e_alpha <= 5e-6
     ((out.image * t(s["v_image"])).sum() + (out.alpha.reshape(1, H, W) * t(g("v_alpha"))).sum()).backward()
     for key, p in zip(("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity"), model.parameters()):
         ref = g(key)
@@ -88,8 +87,8 @@ def test_fastgs_render_and_backward_follow_the_reference_render_path(lfs, name):
         if np.abs(ref).max() == 0:
             assert np.abs(got).max() == 0, key
             continue
-        e, flips, rest = rows_check(got.reshape(c["N"], -1), ref.reshape(c["N"], -1), bar=5e-4, max_flips=3)
+        e, flips, rest = rows_check(got.reshape(c["N"], -1), ref.reshape(c["N"], -1), bar=2e-5, max_flips=3)
         print(f"fastgs {name} {key}: rel-L2 {e:.2e}, flip rows {flips}, without them {rest:.2e}")
-        assert rest < 5e-4, (key, e, flips, rest)
+        assert rest < 2e-5, (key, e, flips, rest)
     ref = g("densification_info")
     assert np.abs(n(dens) - ref).max() <= 2e-3 * np.abs(ref).max()
