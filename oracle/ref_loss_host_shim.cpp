@@ -5,8 +5,8 @@
 //                                                     (whole file; sed: torch::kCUDA -> torch::kCPU and the two-line TORCH_CHECK(... is_cuda() ...) dropped)
 //   src/training/optimizers/scheduler.cpp, fused_adam.cpp   WarmupExponentialLR (the bilateral grid's schedule) over the optimizer base class
 // compiled in place against CPU libtorch. The host functions the wrappers call - fusedssim / fusedssim_backward (ssim.cu:426-520) and the four
-// gs::bilateral_grid::*_cuda launchers (bilateral_grid_forward.cu:96-115, _backward.cu:155-183, _tv.cu:137-188) - are defined below as allocation + launch over the
-// reference's own kernels run on the CPU (oracle/_ref/libref_loss.so). Trainer::compute_photometric_loss (trainer.cpp:103-130) is a member of the Trainer class;
+// gs::bilateral_grid::*_cuda launchers (bilateral_grid_forward.cu:96-115, _backward.cu:155-183, _tv.cu:137-188) - are the reference's own too: the four .cu files
+// are compiled whole under the emulator (ref_loss_all.cpp, through ref_cu_prep.py). Trainer::compute_photometric_loss (trainer.cpp:103-130) is a member of the Trainer class;
 // its three lines are restated in reflh_photometric, cited. Used by oracle/make_golden_refk_loss.py -> tests/golden/refk_loss.npz ("host/..." entries).
 #include "kernels/bilateral_grid.cuh"
 #include "kernels/fused_ssim.cuh"
@@ -18,6 +18,8 @@
 
 #define REF_API extern "C" __attribute__((visibility("default")))
 
+#ifndef REF_REAL_LOSS // (default build: -DREF_REAL_LOSS - these host functions come from the reference's own .cu files, ref_loss_all.cpp; the restated form below
+// is kept for reference and builds against libref_loss.so without the define)
 extern "C" {
 void refk_fusedssim(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2, int train, float* ssim_map, float* dm_dmu1,
                     float* dm_dsigma1_sq, float* dm_dsigma12);
@@ -76,6 +78,8 @@ namespace gs::bilateral_grid {
         return gg;
     }
 } // namespace gs::bilateral_grid
+
+#endif
 
 namespace fast_gs::optimizer { // fused_adam.cpp links against it; no Adam step is taken here
     void adam_step_wrapper(torch::Tensor&, torch::Tensor&, torch::Tensor&, const torch::Tensor&, const float, const float, const float, const float, const float,
