@@ -15,12 +15,24 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle  # noqa: E402
 import refraster_util as U  # noqa: E402
+from refstrategy_util import hashed as _h  # noqa: E402,F401
 
 
 def run(c, full=False):
     s = U.scene(c)
     return oracle.ref_render_backward(s["means"], s["sh0"], s["shN"], s["scaling"], s["rotation"], s["opacity"], c["sh_degree"], c["active"], s["R"], s["T"], c["focal"],
                                       c["focal"] * 1.05, c["W"] / 2 + 0.5, c["H"] / 2 - 0.25, c["W"], c["H"], c["bg"], s["v_image"], s["v_alpha"], full=full)
+
+
+TRAIN = dict(lambda_dssim=0.2, scale_reg=0.01, opacity_reg=0.01)      # eval/mcmc_optimization_params.json
+
+
+def run_train(c):
+    """the trainer's loss (L1 + D-SSIM + regularisers) and its gradients for a hashed target image: "train/..." entries"""
+    s = U.scene(c)
+    gt = U.target_image(c)
+    return oracle.ref_train_loss_backward(s["means"], s["sh0"], s["shN"], s["scaling"], s["rotation"], s["opacity"], c["sh_degree"], c["active"], s["R"], s["T"], c["focal"],
+                                          c["focal"] * 1.05, c["W"] / 2 + 0.5, c["H"] / 2 - 0.25, c["W"], c["H"], c["bg"], gt, **TRAIN)
 
 
 if __name__ == "__main__":
@@ -31,6 +43,11 @@ if __name__ == "__main__":
         print(f"{name}: visible {(r['radii'] > 0).sum()} of {c['N']}, mean alpha {r['alpha'].mean():.3f}, |g_means| max {np.abs(r['g_means']).max():.3g}")
         for k, v in r.items():
             out[f"{name}/{k}"] = v
+        tr = run_train(c)
+        print(f"   train loss {float(tr['loss']):.6f}")
+        for k, v in tr.items():
+            if k != "image":
+                out[f"{name}/train/{k}"] = v
     path = os.path.join(ROOT, "tests", "golden", U.GOLD)
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path) // 1024, "KiB")

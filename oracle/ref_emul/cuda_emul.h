@@ -42,10 +42,10 @@ namespace cuemu {
 
 constexpr int MAX_THREADS = 1024, WARP = 32, STACK_BYTES = 256 * 1024;
 
-extern "C" void cuemu_switch(void** save_sp, void* load_sp);
+extern "C" void cuemu_switch(void** save_sp, void* load_sp);   // (weak: several emulator translation units may meet in one library)
 asm(R"(
 .text
-.globl cuemu_switch
+.weak cuemu_switch
 .type cuemu_switch,@function
 cuemu_switch:
     pushq %rbp

@@ -19,7 +19,12 @@
 #include "core/image_io.hpp"
 #include "core/splat_data.hpp"
 #include "rasterizer.hpp"
+#ifndef REF_REAL_GSPLAT
 #include "torch_impl.hpp"
+#endif
+#ifdef REF_REAL_GSPLAT
+#include "kernels/fused_ssim.cuh" // the reference's fused-SSIM autograd wrapper (over its own ssim.cu, ref_loss_all.cpp): refraster_train_loss_backward
+#endif
 #include <cstring>
 
 #define REF_API extern "C" __attribute__((visibility("default")))
@@ -230,3 +235,51 @@ REF_API int refraster_render_backward(int64_t N, int64_t K1, int sh_degree, int 
         return 1;
     }
 }
+
+#ifdef REF_REAL_GSPLAT
+// The loss of one training step as Trainer::train_step composes it (trainer.cpp:640-715) and its gradients: rasterize() -> compute_photometric_loss (:103-130:
+// l1_loss, 1 - fused_ssim(..., "valid", train), the lambda mix) -> + compute_scale_reg_loss (:132-145: scale_reg * get_scaling().mean()) + compute_opacity_reg_loss
+// (:147-160: opacity_reg * get_opacity().mean()), each followed by backward(). The three loss functions are members of the Trainer class; their bodies are restated
+// here line by line, everything they call is the reference's own code.
+REF_API int refraster_train_loss_backward(int64_t N, int64_t K1, int sh_degree, int active_sh_degree, const float* means, const float* sh0, const float* shN,
+                                          const float* scaling, const float* rotation, const float* opacity, const float* R, const float* T, float fx, float fy, float cx,
+                                          float cy, int width, int height, const float* bg, const float* gt_image, float lambda_dssim, float scale_reg, float opacity_reg,
+                                          float* loss_out, float* image, float* g_means, float* g_sh0, float* g_shN, float* g_scaling, float* g_rotation,
+                                          float* g_opacity) {
+    try {
+        auto req = [](torch::Tensor t) { return t.set_requires_grad(true); };
+        gs::SplatData model(sh_degree, req(f32(means, {N, 3})), req(f32(sh0, {N, 1, 3})), req(f32(shN, {N, K1, 3})), req(f32(scaling, {N, 3})), req(f32(rotation, {N, 4})),
+                            req(f32(opacity, {N, 1})), 1.0f);
+        model.set_active_sh_degree(active_sh_degree);
+        gs::Camera cam(f32(R, {3, 3}), f32(T, {3}), fx, fy, cx, cy, torch::empty({0}, torch::kFloat32), torch::empty({0}, torch::kFloat32), gsplat::CameraModelType::PINHOLE,
+                       "view", "", width, height, 0);
+        torch::Tensor bgc = bg ? f32(bg, {3}) : torch::Tensor();
+        auto out = gs::training::rasterize(cam, model, bgc, 1.0f, false, false, gs::training::RenderMode::RGB, nullptr);
+        put(out.image, image);
+        torch::Tensor rendered = out.image.unsqueeze(0), gt = f32(gt_image, {3, height, width}).unsqueeze(0);       // :113-114
+        auto l1_loss = torch::l1_loss(rendered, gt);                                                                 // :121
+        auto ssim_loss = 1.f - fused_ssim(rendered, gt, "valid", /*train=*/true);                                    // :122
+        torch::Tensor loss = (1.f - lambda_dssim) * l1_loss + lambda_dssim * ssim_loss;                              // :123-124
+        loss.backward();                                                                                             // trainer.cpp:677
+        float loss_value = loss.item<float>();
+        if (scale_reg > 0.0f) {                                                                                      // :136-139, :686
+            loss = scale_reg * model.get_scaling().mean();
+            loss.backward();
+            loss_value += loss.item<float>();
+        }
+        if (opacity_reg > 0.0f) {                                                                                    // :151-154, :695
+            loss = opacity_reg * model.get_opacity().mean();
+            loss.backward();
+            loss_value += loss.item<float>();
+        }
+        *loss_out = loss_value;
+        auto g = [](const torch::Tensor& p) { return p.grad().defined() ? p.grad() : torch::zeros_like(p); };
+        put(g(model.means()), g_means), put(g(model.sh0()), g_sh0), put(g(model.shN()), g_shN), put(g(model.scaling_raw()), g_scaling);
+        put(g(model.rotation_raw()), g_rotation), put(g(model.opacity_raw()), g_opacity);
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "refraster_train_loss_backward: %s\n", e.what());
+        return 1;
+    }
+}
+#endif

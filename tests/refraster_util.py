@@ -37,3 +37,8 @@ def scene(c):
     s["v_image"] = f((3, c["H"], c["W"]), 17, 2.0)
     s["v_alpha"] = f((1, c["H"], c["W"]), 18, 1.0) if c["v_alpha"] else None
     return s
+
+
+def target_image(c):
+    """the ground-truth image of the "train/..." entries (the trainer's loss against it)"""
+    return (hashed((3, c["H"], c["W"]), 21) + 0.5).astype(np.float32)

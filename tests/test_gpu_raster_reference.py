@@ -92,3 +92,38 @@ def test_fastgs_render_and_backward_follow_the_reference_render_path(lfs, name):
         assert rest < 2e-5, (key, e, flips, rest)
     ref = g("densification_info")
     assert np.abs(n(dens) - ref).max() <= 2e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name", sorted(U.CASES))
+def test_fused_training_step_follows_the_reference_train_step(lfs, name):
+    """fused.render_and_backward - THE hot path of the trainer: forward, the fused L1 + D-SSIM loss kernels, backward with the regularisers folded into the activation
+    backward - against the loss Trainer::train_step composes and its gradients, computed by the reference's own rasterize() + autograd + fused_ssim over its whole
+    gsplat library and ssim.cu on the CPU ("train/..." entries of tests/golden/ref_raster.npz): loss 5e-6 relative, gradients 1e-4 relative L2 per tensor with
+    threshold-flip rows counted."""
+    from lichtfeld_studio_amd import fused, loader
+    from lichtfeld_studio_amd.rasterizer import Camera, SplatModel
+    c, g = U.CASES[name], lambda k: GOLD[f"{name}/train/{k}"]
+    s = U.scene(c)
+    W, H = c["W"], c["H"]
+    cam = loader.CameraData(0, 1, 0, W, H, np.float32(c["focal"]), np.float32(c["focal"] * 1.05), np.float32(W / 2 + 0.5), np.float32(H / 2 - 0.25), s["R"], s["T"],
+                            np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32), "view", "")
+    mk = lambda a: t(a).contiguous().requires_grad_(True)
+    model = SplatModel(mk(s["means"]), mk(s["sh0"]), mk(s["shN"]), mk(s["scaling"]), mk(s["rotation"]), mk(s["opacity"]), c["sh_degree"], active_sh_degree=c["active"])
+    camera = Camera(t(loader.world_to_view(cam)).unsqueeze(0), t(loader.intrinsics(cam, W, H)).unsqueeze(0), W, H)
+    grads = [torch.zeros_like(p) for p in model.parameters()]
+    loss = torch.zeros(1, device="cuda:0")
+    fused.render_and_backward(camera, model, None if c["bg"] is None else t(np.array(c["bg"], np.float32)), t(U.target_image(c)), 1.0, grads, loss, accumulate=False,
+                              loss="l1_ssim", lambda_dssim=0.2, scale_reg=0.01, opacity_reg=0.01)
+    torch.cuda.synchronize()
+    print(f"train step {name}: loss {float(loss):.6f} vs {float(g('loss')):.6f}")
+    assert abs(float(loss) - float(g("loss"))) <= 5e-6 * float(g("loss"))
+    for key, got in zip(("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity"), grads):
+        ref = g(key)
+        got = n(got).reshape(ref.shape)
+        assert np.isfinite(got).all(), key
+        if np.abs(ref).max() == 0:
+            assert np.abs(got).max() == 0, key
+            continue
+        e, flips, rest = rows_check(got.reshape(c["N"], -1), ref.reshape(c["N"], -1), bar=1e-4, max_flips=3)
+        print(f"train step {name} {key}: rel-L2 {e:.2e}, flip rows {flips}, without them {rest:.2e}")
+        assert rest < 1e-4, (key, e, flips, rest)

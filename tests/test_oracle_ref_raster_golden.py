@@ -60,6 +60,38 @@ def test_oracle_composition_equals_the_reference_render_path(oracle_mod, name):
         assert e < 1e-4, (k, e)
 
 
+@pytest.mark.parametrize("name", sorted(U.CASES))
+def test_trainer_loss_restatement_equals_the_reference_train_step(oracle_mod, name):
+    """"train/..." entries: the loss Trainer::train_step composes (rasterize -> L1 + 0.2 D-SSIM "valid" -> + 0.01 mean(scale) + 0.01 mean(opacity)) and its
+    gradients, from the reference's own code. Here: the oracle's render + the torch SSIM restatement (tests/ssim_reference.py) + the regularisers' closed-form
+    gradients (scale_reg / 3N * exp(s), opacity_reg / N * o (1 - o)) - the composition the product's fused step implements."""
+    import torch
+    import ssim_reference as ssim
+    from oracle import make_golden_ref_raster as mg
+    c = U.CASES[name]
+    s = U.scene(c)
+    g = lambda k: GOLD[f"{name}/train/{k}"]
+    gt = torch.from_numpy(U.target_image(c)).double()
+    base = oracle_render_backward(oracle_mod, c, dict(s, v_image=np.zeros_like(s["v_image"]), v_alpha=None))       # forward only: the clamped image
+    x = torch.from_numpy(base["image"]).double().requires_grad_(True)
+    photo = ssim.photometric_loss(x[None], gt[None], mg.TRAIN["lambda_dssim"])
+    photo.backward()
+    r = oracle_render_backward(oracle_mod, c, dict(s, v_image=x.grad.numpy().astype(np.float32), v_alpha=None))   # backward with dL/dimage of the photometric loss
+    N = c["N"]
+    scales, opac = np.exp(s["scaling"].astype(np.float64)), 1 / (1 + np.exp(-s["opacity"].astype(np.float64)))
+    loss = float(photo.detach()) + mg.TRAIN["scale_reg"] * scales.mean() + mg.TRAIN["opacity_reg"] * opac.mean()
+    assert abs(loss - float(g("loss"))) <= 2e-6 * float(g("loss"))
+    r["g_scaling"] = r["g_scaling"] + mg.TRAIN["scale_reg"] / (3 * N) * scales
+    r["g_opacity"] = r["g_opacity"] + mg.TRAIN["opacity_reg"] / N * opac * (1 - opac)
+    for k in ("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity"):
+        ref, got = g(k).astype(np.float64), np.asarray(r[k], np.float64).reshape(g(k).shape)
+        if np.abs(ref).max() == 0:
+            assert np.abs(got).max() == 0, k
+            continue
+        e = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert e < 1e-4, (k, e)
+
+
 @pytest.mark.skipif(oracle.ref_raster_lib(full=True) is None, reason="oracle/_ref/libref_raster_full.so not built (make -C oracle refgsplat; needs /root/reference)")
 def test_golden_file_regenerates_from_the_whole_reference_gsplat_library():
     """rasterize() + autograd + Camera over the reference's entire gsplat library (every .cu with its launchers, every .cpp operator) on the CPU: bit for bit"""
@@ -68,6 +100,9 @@ def test_golden_file_regenerates_from_the_whole_reference_gsplat_library():
         r = mg.run(c, full=True)
         for k, v in r.items():
             assert np.array_equal(v, GOLD[f"{name}/{k}"]), (name, k)
+        for k, v in mg.run_train(c).items():
+            if k != "image":
+                assert np.array_equal(v, GOLD[f"{name}/train/{k}"]), (name, "train", k)
 
 
 @pytest.mark.skipif(oracle.ref_raster_lib() is None, reason="oracle/_ref/libref_raster.so not built (needs /root/reference)")
