@@ -1044,3 +1044,26 @@ def ref_train_loss_backward(means, sh0, shN, scaling, rotation, opacity, sh_degr
         raise RuntimeError("refraster_train_loss_backward failed")
     out["loss"] = np.float32(loss.value)
     return out
+
+
+def ref_fast_train_loss_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, gt_image, lambda_dssim,
+                                 densification_info=None):
+    """The photometric loss of one training step on the reference's default path - fast_rasterize() -> L1 + D-SSIM (fused_ssim "valid", image not clamped) - and
+    its gradients, over its own fastgs code and ssim.cu (libref_fast_raster.so) -> dict(loss, g_* [, densification_info])"""
+    arrs = [_f32(x) for x in (means, sh0, shN, scaling, rotation, opacity)]
+    N, K1 = arrs[0].shape[0], arrs[2].shape[1]
+    R, T, gt, bg = _f32(R), _f32(T), _f32(gt_image), _f32(bg)
+    dens = None if densification_info is None else _f32(densification_info).copy()
+    out = dict(g_means=np.empty((N, 3), np.float32), g_sh0=np.empty((N, 1, 3), np.float32), g_shN=np.empty((N, K1, 3), np.float32), g_scaling=np.empty((N, 3), np.float32),
+               g_rotation=np.empty((N, 4), np.float32), g_opacity=np.empty(N, np.float32))
+    loss = C.c_float()
+    rc = ref_fast_raster_lib().reffast_train_loss_backward(
+        C.c_int64(N), C.c_int64(K1), C.c_int(sh_degree), C.c_int(active_sh_degree), *[_p(a) for a in arrs], _p(R), _p(T), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+        C.c_float(cy), C.c_int(width), C.c_int(height), _p(bg), _p(gt), C.c_float(lambda_dssim), None if dens is None else _p(dens), C.byref(loss),
+        *[_p(out[k]) for k in ("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity")])
+    if rc:
+        raise RuntimeError("reffast_train_loss_backward failed")
+    out["loss"] = np.float32(loss.value)
+    if dens is not None:
+        out["densification_info"] = dens
+    return out

@@ -31,6 +31,16 @@ def run(name):
     return r
 
 
+def run_train(name):
+    """the trainer's photometric loss on this path (black background, as the trainer's default) and its gradients: "train/..." entries"""
+    c = U.CASES[name]
+    s = U.scene(c)
+    dens = (U.hashed((2, c["N"]), 20) + 0.5).astype(np.float32)
+    r = oracle.ref_fast_train_loss_backward(s["means"], s["sh0"], s["shN"], s["scaling"], s["rotation"], s["opacity"], c["sh_degree"], c["active"], s["R"], s["T"], c["focal"],
+                                            c["focal"] * 1.05, c["W"] / 2 + 0.5, c["H"] / 2 - 0.25, c["W"], c["H"], np.zeros(3, np.float32), U.target_image(c), 0.2, dens)
+    return r
+
+
 if __name__ == "__main__":
     assert oracle.ref_fast_raster_lib() is not None, "build oracle/_ref/libref_fast_raster.so first (make -C oracle reffast)"
     out = {}
@@ -39,6 +49,8 @@ if __name__ == "__main__":
         print(f"{name}: mean alpha {r['alpha'].mean():.3f}, |g_means| max {np.abs(r['g_means']).max():.3g}")
         for k, v in r.items():
             out[f"{name}/{k}"] = v
+        for k, v in run_train(name).items():
+            out[f"{name}/train/{k}"] = v
     path = os.path.join(ROOT, "tests", "golden", GOLD)
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path) // 1024, "KiB")

@@ -13,6 +13,7 @@
 #include "core/image_io.hpp"
 #include "core/splat_data.hpp"
 #include "fast_rasterizer.hpp"
+#include "kernels/fused_ssim.cuh" // the reference's fused-SSIM autograd wrapper over its own ssim.cu (compiled whole under the emulator): reffast_train_loss_backward
 #include "rasterization_api.h"
 #include <cstring>
 
@@ -85,6 +86,39 @@ REF_API int reffast_wrappers(int n, int active_sh_bases, int total_bases_sh_rest
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "reffast_wrappers: %s\n", e.what());
+        return 1;
+    }
+}
+
+// The photometric loss of one training step on the default path as Trainer::train_step composes it (trainer.cpp:656, 668-677): fast_rasterize() (the image is NOT
+// clamped on this path) -> compute_photometric_loss (:103-130, restated line by line: l1_loss, 1 - fused_ssim(..., "valid", train), the lambda mix) -> backward().
+REF_API int reffast_train_loss_backward(int64_t N, int64_t K1, int sh_degree, int active_sh_degree, const float* means, const float* sh0, const float* shN,
+                                        const float* scaling, const float* rotation, const float* opacity, const float* R, const float* T, float fx, float fy, float cx,
+                                        float cy, int width, int height, const float* bg, const float* gt_image, float lambda_dssim, float* densification_info,
+                                        float* loss_out, float* g_means, float* g_sh0, float* g_shN, float* g_scaling, float* g_rotation, float* g_opacity) {
+    try {
+        auto req = [](torch::Tensor t) { return t.set_requires_grad(true); };
+        gs::SplatData model(sh_degree, req(f32(means, {N, 3})), req(f32(sh0, {N, 1, 3})), req(f32(shN, {N, K1, 3})), req(f32(scaling, {N, 3})), req(f32(rotation, {N, 4})),
+                            req(f32(opacity, {N, 1})), 1.0f);
+        model.set_active_sh_degree(active_sh_degree);
+        if (densification_info) model._densification_info = f32(densification_info, {2, N});
+        gs::Camera cam(f32(R, {3, 3}), f32(T, {3}), fx, fy, cx, cy, torch::empty({0}, torch::kFloat32), torch::empty({0}, torch::kFloat32), gsplat::CameraModelType::PINHOLE,
+                       "view", "", width, height, 0);
+        auto bgc = f32(bg, {3});
+        auto out = gs::training::fast_rasterize(cam, model, bgc);
+        torch::Tensor rendered = out.image.unsqueeze(0), gt = f32(gt_image, {3, height, width}).unsqueeze(0);       // :113-114
+        auto l1_loss = torch::l1_loss(rendered, gt);                                                                 // :121
+        auto ssim_loss = 1.f - fused_ssim(rendered, gt, "valid", /*train=*/true);                                    // :122
+        torch::Tensor loss = (1.f - lambda_dssim) * l1_loss + lambda_dssim * ssim_loss;                              // :123-124
+        loss.backward();
+        *loss_out = loss.item<float>();
+        auto g = [](const torch::Tensor& p) { return p.grad().defined() ? p.grad() : torch::zeros_like(p); };
+        put(g(model.means()), g_means), put(g(model.sh0()), g_sh0), put(g(model.shN()), g_shN), put(g(model.scaling_raw()), g_scaling);
+        put(g(model.rotation_raw()), g_rotation), put(g(model.opacity_raw()), g_opacity);
+        if (densification_info) put(model._densification_info, densification_info);
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "reffast_train_loss_backward: %s\n", e.what());
         return 1;
     }
 }

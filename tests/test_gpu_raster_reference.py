@@ -60,7 +60,10 @@ def test_render_and_backward_follow_the_reference_render_path(lfs, name):
 FAST = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fast_raster.npz"))
 
 
-@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in FAST.files}))
+FAST_CASES = sorted({k.split("/")[0] for k in FAST.files})
+
+
+@pytest.mark.parametrize("name", FAST_CASES)
 def test_fastgs_render_and_backward_follow_the_reference_render_path(lfs, name):
     """fastgs.fast_rasterize (the mirror of gs::training::fast_rasterize, the reference's default training path) + autograd backward against the reference's own
     fast_rasterizer.cpp + fast_rasterizer_autograd.cpp + rasterization_api.cu + forward.cu / backward.cu + Camera run end to end on the CPU
@@ -130,3 +133,41 @@ def test_fused_training_step_follows_the_reference_train_step(lfs, name):
         e, flips, rest = rows_check(got.reshape(c["N"], -1), ref.reshape(c["N"], -1), bar=1e-4, max_flips=3)
         print(f"train step {name} {key}: rel-L2 {e:.2e}, flip rows {flips}, without them {rest:.2e}")
         assert rest < 1e-4, (key, e, flips, rest)
+
+
+@pytest.mark.parametrize("name", FAST_CASES)
+def test_fastgs_fused_training_step_follows_the_reference_train_step(lfs, name):
+    """fastgs.render_and_backward (the fused, autograd-free training step of the default path: forward, the fused L1 + D-SSIM kernels on the un-clamped CHW image,
+    backward, densification_info) against fast_rasterize() -> compute_photometric_loss -> backward() of the reference's own code ("train/..." entries of
+    tests/golden/ref_fast_raster.npz): loss 5e-6 relative, gradients 2e-5 relative L2, densification_info alike."""
+    from lichtfeld_studio_amd import fastgs, loader
+    from lichtfeld_studio_amd.rasterizer import SplatModel
+    c, g = U.CASES[name], lambda k: FAST[f"{name}/train/{k}"]
+    s = U.scene(c)
+    W, H = c["W"], c["H"]
+    cam = loader.CameraData(0, 1, 0, W, H, np.float32(c["focal"]), np.float32(c["focal"] * 1.05), np.float32(W / 2 + 0.5), np.float32(H / 2 - 0.25), s["R"], s["T"],
+                            np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32), "view", "")
+    mk = lambda a: t(a).contiguous().requires_grad_(True)
+    model = SplatModel(mk(s["means"]), mk(s["sh0"]), mk(s["shN"]), mk(s["scaling"]), mk(s["rotation"]), mk(s["opacity"]), c["sh_degree"], active_sh_degree=c["active"])
+    w2c, K = t(loader.world_to_view(cam)).unsqueeze(0), loader.intrinsics(cam, W, H)
+    R, tt = s["R"].astype(np.float64), s["T"].astype(np.float64)
+    settings = fastgs.FastGSSettings(t((-(R.T @ tt)).astype(np.float32)), (c["active"] + 1) ** 2, W, H, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), 0.01, 1e10)
+    grads = [torch.zeros_like(p) for p in model.parameters()]
+    loss = torch.zeros(1, device="cuda:0")
+    dens = t(FAST[f"{name}/densification_info_in"]).clone()
+    fastgs.render_and_backward(settings, w2c, model, t(U.target_image(c)), 1.0, grads, loss, dens, loss="l1_ssim", lambda_dssim=0.2)
+    torch.cuda.synchronize()
+    print(f"fastgs train step {name}: loss {float(loss):.6f} vs {float(g('loss')):.6f}")
+    assert abs(float(loss) - float(g("loss"))) <= 5e-6 * float(g("loss"))
+    for key, got in zip(("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity"), grads):
+        ref = g(key)
+        got = n(got).reshape(ref.shape)
+        assert np.isfinite(got).all(), key
+        if np.abs(ref).max() == 0:
+            assert np.abs(got).max() == 0, key
+            continue
+        e, flips, rest = rows_check(got.reshape(c["N"], -1), ref.reshape(c["N"], -1), bar=2e-5, max_flips=3)
+        print(f"fastgs train step {name} {key}: rel-L2 {e:.2e}, flip rows {flips}, without them {rest:.2e}")
+        assert rest < 2e-5, (key, e, flips, rest)
+    ref = g("densification_info")
+    assert np.abs(n(dens) - ref).max() <= 2e-3 * np.abs(ref).max()

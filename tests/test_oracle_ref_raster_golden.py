@@ -130,6 +130,8 @@ def test_fastgs_golden_files_regenerate_from_the_whole_reference_fastgs_path():
     for name in mg.CASES:
         for k, v in mg.run(name).items():
             assert np.array_equal(v, G[f"{name}/{k}"]), (name, k)
+        for k, v in mg.run_train(name).items():
+            assert np.array_equal(v, G[f"{name}/train/{k}"]), (name, "train", k)
     import test_oracle_refk_fastgs_golden as fg
     oracle.REFK_FASTGS_WHOLE = True
     try:
