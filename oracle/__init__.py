@@ -1026,20 +1026,28 @@ def ref_load_ply(path):
 
 
 def ref_train_loss_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, gt_image, lambda_dssim,
-                            scale_reg, opacity_reg):
-    """The loss of one training step as Trainer::train_step composes it - rasterize() -> L1 + D-SSIM (fused_ssim "valid") -> + scale / opacity regularisers - and its
-    gradients w.r.t. the six raw tensors, over the reference's whole gsplat library and its own ssim.cu (libref_raster_full.so) -> dict(loss, image, g_*)"""
+                            scale_reg, opacity_reg, bilateral=None):
+    """The loss of one training step as Trainer::train_step composes it - rasterize() [-> BilateralGrid::apply] -> L1 + D-SSIM (fused_ssim "valid") -> + scale /
+    opacity regularisers [+ tv_weight * tv_loss()] - and its gradients w.r.t. the six raw tensors [and the grids], over the reference's whole gsplat library, its own
+    ssim.cu and bilateral-grid code (libref_raster_full.so) -> dict(loss, image, g_* [, g_grids]). bilateral = dict(n_images, gW, gH, gL, image_idx, delta
+    [n_images,12,gL,gH,gW] added to the identity grids, tv_weight)."""
     arrs = [_f32(x) for x in (means, sh0, shN, scaling, rotation, opacity)]
     N, K1 = arrs[0].shape[0], arrs[2].shape[1]
     R, T, gt = _f32(R), _f32(T), _f32(gt_image)
     bg = None if bg is None else _f32(bg)
     out = dict(image=np.empty((3, height, width), np.float32), g_means=np.empty((N, 3), np.float32), g_sh0=np.empty((N, 1, 3), np.float32),
                g_shN=np.empty((N, K1, 3), np.float32), g_scaling=np.empty((N, 3), np.float32), g_rotation=np.empty((N, 4), np.float32), g_opacity=np.empty(N, np.float32))
+    b = bilateral or dict(n_images=0, gW=0, gH=0, gL=0, image_idx=0, delta=None, tv_weight=0.0)
+    delta = None if b["delta"] is None else _f32(b["delta"])
+    if delta is not None:
+        out["g_grids"] = np.empty_like(delta)
     loss = C.c_float()
     rc = ref_raster_lib(full=True).refraster_train_loss_backward(
         C.c_int64(N), C.c_int64(K1), C.c_int(sh_degree), C.c_int(active_sh_degree), *[_p(a) for a in arrs], _p(R), _p(T), C.c_float(fx), C.c_float(fy), C.c_float(cx),
         C.c_float(cy), C.c_int(width), C.c_int(height), None if bg is None else _p(bg), _p(gt), C.c_float(lambda_dssim), C.c_float(scale_reg), C.c_float(opacity_reg),
-        C.byref(loss), _p(out["image"]), *[_p(out[k]) for k in ("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity")])
+        C.byref(loss), _p(out["image"]), *[_p(out[k]) for k in ("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity")],
+        C.c_int(b["n_images"]), C.c_int(b["gW"]), C.c_int(b["gH"]), C.c_int(b["gL"]), C.c_int(b["image_idx"]), None if delta is None else _p(delta), C.c_float(b["tv_weight"]),
+        _p(out["g_grids"]) if delta is not None else None)
     if rc:
         raise RuntimeError("refraster_train_loss_backward failed")
     out["loss"] = np.float32(loss.value)

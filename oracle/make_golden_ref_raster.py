@@ -27,12 +27,13 @@ def run(c, full=False):
 TRAIN = dict(lambda_dssim=0.2, scale_reg=0.01, opacity_reg=0.01)      # eval/mcmc_optimization_params.json
 
 
-def run_train(c):
-    """the trainer's loss (L1 + D-SSIM + regularisers) and its gradients for a hashed target image: "train/..." entries"""
+def run_train(c, bilateral=False):
+    """the trainer's loss (L1 + D-SSIM + regularisers [, through the bilateral grid, + TV]) and its gradients for a hashed target image: "train/..." entries"""
     s = U.scene(c)
     gt = U.target_image(c)
+    b = dict(U.BILATERAL, delta=U.bilateral_delta()) if bilateral else None
     return oracle.ref_train_loss_backward(s["means"], s["sh0"], s["shN"], s["scaling"], s["rotation"], s["opacity"], c["sh_degree"], c["active"], s["R"], s["T"], c["focal"],
-                                          c["focal"] * 1.05, c["W"] / 2 + 0.5, c["H"] / 2 - 0.25, c["W"], c["H"], c["bg"], gt, **TRAIN)
+                                          c["focal"] * 1.05, c["W"] / 2 + 0.5, c["H"] / 2 - 0.25, c["W"], c["H"], c["bg"], gt, bilateral=b, **TRAIN)
 
 
 if __name__ == "__main__":
@@ -48,6 +49,10 @@ if __name__ == "__main__":
         for k, v in tr.items():
             if k != "image":
                 out[f"{name}/train/{k}"] = v
+        if name == "deg1_96x64_background":          # config 5's step: the rendered image goes through the bilateral grid before the loss, + TV
+            for k, v in run_train(c, bilateral=True).items():
+                if k != "image":
+                    out[f"{name}/train_bilateral/{k}"] = v
     path = os.path.join(ROOT, "tests", "golden", U.GOLD)
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path) // 1024, "KiB")

@@ -24,6 +24,7 @@
 #endif
 #ifdef REF_REAL_GSPLAT
 #include "kernels/fused_ssim.cuh" // the reference's fused-SSIM autograd wrapper (over its own ssim.cu, ref_loss_all.cpp): refraster_train_loss_backward
+#include "bilateral_grid.hpp"     // gs::training::BilateralGrid (components/bilateral_grid.cpp over the bilateral_grid_*.cu files): config 5's appearance model
 #endif
 #include <cstring>
 
@@ -245,7 +246,10 @@ REF_API int refraster_train_loss_backward(int64_t N, int64_t K1, int sh_degree, 
                                           const float* scaling, const float* rotation, const float* opacity, const float* R, const float* T, float fx, float fy, float cx,
                                           float cy, int width, int height, const float* bg, const float* gt_image, float lambda_dssim, float scale_reg, float opacity_reg,
                                           float* loss_out, float* image, float* g_means, float* g_sh0, float* g_shN, float* g_scaling, float* g_rotation,
-                                          float* g_opacity) {
+                                          float* g_opacity,
+                                          // optional bilateral grid (trainer.cpp:662-664, 699-706): BilateralGrid(n_images, gW, gH, gL) with grids = identity + grid_delta,
+                                          // applied to the rendered image for image `image_idx`; + tv_weight * tv_loss(). Null grid_delta: no grid.
+                                          int n_images, int gW, int gH, int gL, int image_idx, const float* grid_delta, float tv_weight, float* g_grids) {
     try {
         auto req = [](torch::Tensor t) { return t.set_requires_grad(true); };
         gs::SplatData model(sh_degree, req(f32(means, {N, 3})), req(f32(sh0, {N, 1, 3})), req(f32(shN, {N, K1, 3})), req(f32(scaling, {N, 3})), req(f32(rotation, {N, 4})),
@@ -256,6 +260,13 @@ REF_API int refraster_train_loss_backward(int64_t N, int64_t K1, int sh_degree, 
         torch::Tensor bgc = bg ? f32(bg, {3}) : torch::Tensor();
         auto out = gs::training::rasterize(cam, model, bgc, 1.0f, false, false, gs::training::RenderMode::RGB, nullptr);
         put(out.image, image);
+        std::unique_ptr<gs::training::BilateralGrid> grid;
+        if (grid_delta) {
+            grid = std::make_unique<gs::training::BilateralGrid>(n_images, gW, gH, gL);
+            torch::NoGradGuard ng;
+            grid->parameters().add_(f32(grid_delta, {n_images, 12, gL, gH, gW}));
+        }
+        if (grid) out.image = grid->apply(out.image, image_idx);                                                     // :662-664
         torch::Tensor rendered = out.image.unsqueeze(0), gt = f32(gt_image, {3, height, width}).unsqueeze(0);       // :113-114
         auto l1_loss = torch::l1_loss(rendered, gt);                                                                 // :121
         auto ssim_loss = 1.f - fused_ssim(rendered, gt, "valid", /*train=*/true);                                    // :122
@@ -272,10 +283,16 @@ REF_API int refraster_train_loss_backward(int64_t N, int64_t K1, int sh_degree, 
             loss.backward();
             loss_value += loss.item<float>();
         }
+        if (grid && tv_weight > 0.f) {                                                                              // :162-173, :704
+            loss = tv_weight * grid->tv_loss();
+            loss.backward();
+            loss_value += loss.item<float>();
+        }
         *loss_out = loss_value;
         auto g = [](const torch::Tensor& p) { return p.grad().defined() ? p.grad() : torch::zeros_like(p); };
         put(g(model.means()), g_means), put(g(model.sh0()), g_sh0), put(g(model.shN()), g_shN), put(g(model.scaling_raw()), g_scaling);
         put(g(model.rotation_raw()), g_rotation), put(g(model.opacity_raw()), g_opacity);
+        if (grid) put(g(grid->parameters()), g_grids);
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "refraster_train_loss_backward: %s\n", e.what());

@@ -42,3 +42,11 @@ def scene(c):
 def target_image(c):
     """the ground-truth image of the "train/..." entries (the trainer's loss against it)"""
     return (hashed((3, c["H"], c["W"]), 21) + 0.5).astype(np.float32)
+
+
+BILATERAL = dict(n_images=3, gW=6, gH=5, gL=4, image_idx=1, tv_weight=10.0)      # config 5's appearance model on a small grid; tv_loss_weight 10 as in the json
+
+
+def bilateral_delta():
+    b = BILATERAL
+    return (hashed((b["n_images"], 12, b["gL"], b["gH"], b["gW"]), 22) * 0.4).astype(np.float32)

@@ -171,3 +171,43 @@ def test_fastgs_fused_training_step_follows_the_reference_train_step(lfs, name):
         assert rest < 2e-5, (key, e, flips, rest)
     ref = g("densification_info")
     assert np.abs(n(dens) - ref).max() <= 2e-3 * np.abs(ref).max()
+
+
+def test_fused_training_step_with_bilateral_grid_follows_the_reference_train_step(lfs):
+    """BASELINE config 5's step: fused.render_and_backward(bilateral=...) - the rendered image goes through the per-image bilateral grid before the L1 + D-SSIM loss -
+    plus the fused TV term, against rasterize() -> BilateralGrid::apply -> compute_photometric_loss -> regularisers -> tv_loss of the reference's own code
+    ("train_bilateral/..." entries): loss 5e-6, parameter gradients 1e-4, grid gradients 2e-5 of their maximum."""
+    from lichtfeld_studio_amd import bilateral_grid as bgm, fused, loader
+    from lichtfeld_studio_amd.rasterizer import Camera, SplatModel
+    name = "deg1_96x64_background"
+    c, g = U.CASES[name], lambda k: GOLD[f"{name}/train_bilateral/{k}"]
+    s = U.scene(c)
+    W, H = c["W"], c["H"]
+    cam = loader.CameraData(0, 1, 0, W, H, np.float32(c["focal"]), np.float32(c["focal"] * 1.05), np.float32(W / 2 + 0.5), np.float32(H / 2 - 0.25), s["R"], s["T"],
+                            np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32), "view", "")
+    mk = lambda a: t(a).contiguous().requires_grad_(True)
+    model = SplatModel(mk(s["means"]), mk(s["sh0"]), mk(s["shN"]), mk(s["scaling"]), mk(s["rotation"]), mk(s["opacity"]), c["sh_degree"], active_sh_degree=c["active"])
+    camera = Camera(t(loader.world_to_view(cam)).unsqueeze(0), t(loader.intrinsics(cam, W, H)).unsqueeze(0), W, H)
+    b = U.BILATERAL
+    grid = bgm.BilateralGrid(b["n_images"], b["gW"], b["gH"], b["gL"])
+    with torch.no_grad():
+        grid.parameters().add_(t(U.bilateral_delta()))
+    grid.grids.grad = torch.zeros_like(grid.grids)
+    grads = [torch.zeros_like(p) for p in model.parameters()]
+    loss = torch.zeros(1, device="cuda:0")
+    fused.render_and_backward(camera, model, t(np.array(c["bg"], np.float32)), t(U.target_image(c)), 1.0, grads, loss, accumulate=False, loss="l1_ssim", lambda_dssim=0.2,
+                              scale_reg=0.01, opacity_reg=0.01, bilateral=grid, image_idx=b["image_idx"])
+    grid.tv_loss_fused(b["tv_weight"], loss)                 # the trainer adds the TV term once per step (trainer.py _bilateral_step; trainer.cpp:699-706)
+    torch.cuda.synchronize()
+    reg = 0.01 * np.exp(s["scaling"].astype(np.float64)).mean() + 0.01 * (1 / (1 + np.exp(-s["opacity"].astype(np.float64)))).mean()
+    print(f"bilateral train step: loss {float(loss):.6f} + regularisers {reg:.6f} vs {float(g('loss')):.6f}")
+    assert abs(float(loss) + reg - float(g("loss"))) <= 5e-6 * float(g("loss"))
+    for key, got in zip(("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity"), grads):
+        ref = g(key)
+        e, flips, rest = rows_check(n(got).reshape(c["N"], -1), ref.reshape(c["N"], -1), bar=1e-4, max_flips=3)
+        print(f"bilateral train step {key}: rel-L2 {e:.2e}, flip rows {flips}, without them {rest:.2e}")
+        assert rest < 1e-4, (key, e, flips, rest)
+    gg, ref = n(grid.grids.grad), g("g_grids")
+    e = np.abs(gg - ref).max() / np.abs(ref).max()
+    print(f"bilateral train step g_grids: max-abs / max {e:.2e}")
+    assert e <= 2e-5

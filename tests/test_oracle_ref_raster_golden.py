@@ -103,6 +103,12 @@ def test_golden_file_regenerates_from_the_whole_reference_gsplat_library():
         for k, v in mg.run_train(c).items():
             if k != "image":
                 assert np.array_equal(v, GOLD[f"{name}/train/{k}"]), (name, "train", k)
+        if f"{name}/train_bilateral/loss" in GOLD.files:
+            for k, v in mg.run_train(c, bilateral=True).items():
+                if k != "image":
+                    close = np.array_equal(v, GOLD[f"{name}/train_bilateral/{k}"]) if k != "g_grids" else \
+                        np.abs(v - GOLD[f"{name}/train_bilateral/{k}"]).max() <= 1e-6 * np.abs(v).max()        # (atomics into the grid: order-dependent last bits)
+                    assert close, (name, "train_bilateral", k)
 
 
 @pytest.mark.skipif(oracle.ref_raster_lib() is None, reason="oracle/_ref/libref_raster.so not built (needs /root/reference)")
