@@ -93,3 +93,48 @@ def test_random_scene_oracle_equals_the_reference_operators(whole, seed):
             continue
         e = float(np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b.astype(np.float64)) + 1e-30))
         assert e < 2e-4, (seed, nme, e)
+
+
+# ---- the default (fastgs / EWA) path: oracle_fastgs.hpp against the reference's own forward_wrapper / backward_wrapper on random scenes ----------------------------
+fast_live = pytest.mark.skipif(oracle.ref_fast_raster_lib() is None, reason="oracle/_ref/libref_fast_raster.so not built (make -C oracle reffast; needs /root/reference)")
+
+
+@fast_live
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scene_fastgs_oracle_equals_the_reference_wrappers(oracle_mod, seed):
+    import math
+    import test_oracle_refk_fastgs_golden as fg
+    o = oracle_mod
+    g = np.random.default_rng(100 + seed)
+    N, W, H, deg = int(g.integers(300, 1200)), int(g.integers(48, 160)), int(g.integers(48, 128)), int(g.integers(0, 4))
+    means = g.standard_normal((N, 3)) * g.uniform(0.5, 2.0)
+    means[:, 2] = np.abs(means[:, 2]) + 2.5
+    ang = g.uniform(-0.3, 0.3)
+    R = np.array([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+    w2c = np.eye(4)
+    w2c[:3, :3], w2c[:3, 3] = R, g.standard_normal(3) * 0.15
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    d = dict(means=f32(means), scales_raw=f32(np.log(g.uniform(0.02, 0.3, (N, 3)))), rot_raw=f32(g.standard_normal((N, 4))), opac_raw=f32(g.standard_normal(N) * 1.5),
+             sh0=f32(g.standard_normal((N, 1, 3)) * 0.5), sh_rest=f32(g.standard_normal((N, 15, 3)) * 0.2), w2c=f32(w2c), cam_pos=f32(-R.T @ w2c[:3, 3]),
+             active_sh_bases=(deg + 1) ** 2, W=W, H=H, fx=float(g.uniform(50, 90)), fy=float(g.uniform(50, 90)), cx=W / 2 + 0.3, cy=H / 2 - 0.2,
+             g_image=f32(g.standard_normal((3, H, W))), g_alpha=f32(g.standard_normal((1, H, W))))
+    dens = f32(g.uniform(0, 2, (2, N))) if seed % 2 == 0 else None
+    o.REFK_FASTGS_WHOLE = True
+    try:
+        r = o.refk_fastgs_fwd_bwd(*fg.scene_args(d), d["g_image"], d["g_alpha"], densification_info=dens)
+    finally:
+        o.REFK_FASTGS_WHOLE = False
+    for k, v in r.items():
+        d["out_" + k] = v
+    f = o.fastgs_forward(*fg.scene_args(d))
+    fg.check_forward(d, f["image"], f["alpha"], len(f["ids"]), int((f["n_touched"] > 0).sum()))
+    got = o.fastgs_backward(f, *fg.scene_args(d), d["g_image"], d["g_alpha"], densification_info=dens)
+    for (gk, _), a in zip(fg.GRADS, got[:6]):
+        ref = d["out_" + gk]
+        a = np.asarray(a).reshape(ref.shape)
+        if np.abs(ref).max() == 0:
+            assert np.abs(a).max() == 0, gk
+            continue
+        assert fg.rel_l2(a, ref) < 5e-4, (seed, gk, fg.rel_l2(a, ref))
+    if dens is not None:
+        assert np.abs(np.asarray(got[6]) - d["out_densification_info"]).max() < 5e-4 * np.abs(d["out_densification_info"]).max()
