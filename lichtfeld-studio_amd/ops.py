@@ -104,11 +104,10 @@ def intersect_tile_begin(means2d: Tensor, radii: Tensor, depths: Tensor, C_: int
     tag = "isect" if slot == 0 else f"isect{slot}"
     ws = workspace(ws_bytes, dev, tag)
     offsets = torch.empty((C_, tile_height, tile_width), dtype=torch.int32, device=dev) if (return_offsets and sort) else None
-    # the scan kernel leaves the workspace counters zero: the memset is only needed on a workspace this exact problem shape has not used last
-    shape_key = (ws.data_ptr(), C_, N, tile_width, tile_height)
-    last_key = (dev.index, tag)
-    flags = 1 if _ISECT_LAST.get(last_key) == shape_key else 0
-    _ISECT_LAST[last_key] = None
+    # flags = 0: the library zeroes the workspace counters itself on every call (a 4-byte-per-tile memset). The LFS_ISECT_COUNTERS_ZERO elision is for
+    # callers that OWN their workspace memory exclusively (csrc/gut_step.cpp's step context); a Python-side cache of "this buffer is still clean" was
+    # removed in round 3: the ops-level path must not depend on interpreter state to stay inside its buffers.
+    flags = 0
     # pinned: the scan kernel writes the counts straight into pinned host memory (no copy kernel) and the host waits for an event recorded behind
     # that kernel; otherwise they land in device memory and .tolist() reads them
     host = _pinned_i64(slot) if pinned else None   # [n_isects, longest tile list, stamp of the call that wrote them]
@@ -128,7 +127,7 @@ def intersect_tile_begin(means2d: Tensor, radii: Tensor, depths: Tensor, C_: int
         ev = torch.cuda.Event()
         ev.record()
     return dict(means2d=means2d, radii=radii, depths=depths, C=C_, N=N, tile_size=tile_size, tw=tile_width, th=tile_height, sort=sort, tpg=tiles_per_gauss,
-                ws=ws, offsets=offsets, return_offsets=return_offsets, host=host, n_dev=n_dev, ev=ev, last_key=last_key, shape_key=shape_key, stamp=stamp)
+                ws=ws, offsets=offsets, return_offsets=return_offsets, host=host, n_dev=n_dev, ev=ev, stamp=stamp)
 
 
 def intersect_tile_finish(st: dict):
@@ -154,13 +153,11 @@ def intersect_tile_finish(st: dict):
         C.c_uint32(st["th"]), C.c_int(int(bool(sort))), C.c_int64(n_isects), ptr(st["tpg"]), ptr(isect_ids), ptr(flatten_ids),
         None, ptr(binned), C.c_int64(longest), ptr(st["ws"]), C.c_size_t(st["ws"].numel()), stream())
     check(rc, "intersect_tile (emit)")
-    _ISECT_LAST[st["last_key"]] = st["shape_key"]
     return (st["tpg"], isect_ids, flatten_ids) + ((st["offsets"],) if st["return_offsets"] else ())
 
 
 _PINNED = {}
 _STAMP = [0]
-_ISECT_LAST = {}   # (device index, workspace tag) -> (workspace pointer, C, N, tile_w, tile_h) of the last completed intersect_tile
 
 
 def _pinned_i64(slot: int = 0) -> Tensor:

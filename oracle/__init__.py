@@ -38,6 +38,12 @@ def build(ref: bool = True) -> None:
         subprocess.run(["make", "-C", _HERE, *core], check=True, capture_output=True)     # (up to date unless the parallel run failed: then this reports it)
 
 
+def have_ref(name: str) -> bool:
+    """Is oracle/_ref/<name> built? A file check only - NOTHING is dlopen'ed. The tests' import-time `skipif` marks use this, so that collecting
+    the suite (also for a `-m gpu` run, which imports every module) never loads a checker library into the process."""
+    return os.path.exists(os.path.join(_HERE, "_ref", name))
+
+
 def lib():
     global _LIB
     if _LIB is None:

@@ -33,7 +33,7 @@ def emu(tmp_path_factory):
     saved = {k: getattr(ops, k) for k in ("load_library", "require_gpu", "stream", "workspace")}
     store = {}
 
-    def workspace(nbytes, dev, tag):   # persistent, like the product's: the second call of a shape runs with LFS_ISECT_COUNTERS_ZERO
+    def workspace(nbytes, dev, tag):   # persistent, like the product's
         buf = store.get(tag)
         if buf is None or buf.numel() < nbytes:
             buf = torch.full((max(int(nbytes), 256),), 0xA5, dtype=torch.uint8)   # garbage: the first call must not rely on a clean workspace
@@ -43,11 +43,9 @@ def emu(tmp_path_factory):
     ops.require_gpu = lambda *a: None
     ops.stream = lambda: None
     ops.workspace = workspace
-    ops._ISECT_LAST.clear()
     yield ops, lib
     for k, v in saved.items():
         setattr(ops, k, v)
-    ops._ISECT_LAST.clear()
 
 
 def _inputs(seed, C_, N, W, H, rmax, dead=0.2, ties=True):

@@ -96,6 +96,7 @@ def test_hip_fastgs_matches_the_reference_rasterizer(lfs, name):
             continue
         e, flips, rest = rows_check(got.reshape(N, -1), ref.reshape(N, -1), bar=5e-4, max_flips=3)
         print(f"fastgs vs reference {name} {gk}: rel-L2 {e:.2e}, flip rows {flips}, without them {rest:.2e}")
+        assert rest < 5e-4, (name, gk, e, flips, rest)
     if "densification_info_in" in d:
         ref = d["out_densification_info"]
         assert np.abs(n(dens) - ref).max() < 2e-3 * np.abs(ref).max()

@@ -18,7 +18,7 @@ from oracle import colmap_io as oc
 HERE = os.path.dirname(os.path.abspath(__file__))
 SCENE = os.path.join(HERE, "golden", "colmap_scene")
 GOLD = np.load(os.path.join(HERE, "golden", "ref_colmap.npz"))
-live = pytest.mark.skipif(oracle.ref_colmap_lib() is None, reason="oracle/_ref/libref_colmap.so not built (needs /root/reference)")
+live = pytest.mark.skipif(not oracle.have_ref("libref_colmap.so"), reason="oracle/_ref/libref_colmap.so not built (needs /root/reference)")
 
 
 @pytest.fixture(scope="module")
@@ -191,7 +191,7 @@ def test_live_golden_file_regenerates_from_the_reference_reader():
 # ---- splat_data.cpp: compute_mean_neighbor_distances and write_ply_impl (tests/golden/ref_splat_io.npz) ------------------------------------------------------
 SPLAT = np.load(os.path.join(HERE, "golden", "ref_splat_io.npz"))
 KNN = sorted({k.split("/")[1] for k in SPLAT.files if k.startswith("knn/")})
-live_splat = pytest.mark.skipif(oracle.ref_splat_io_lib() is None, reason="oracle/_ref/libref_splat_io.so not built (needs /root/reference)")
+live_splat = pytest.mark.skipif(not oracle.have_ref("libref_splat_io.so"), reason="oracle/_ref/libref_splat_io.so not built (needs /root/reference)")
 
 
 @pytest.mark.parametrize("name", KNN)
@@ -292,7 +292,7 @@ def test_product_ply_reader_equals_the_reference_reader(ld, tmp_path, name):
     assert m.max_sh_degree == int(np.sqrt(g("shN").shape[1] + 1)) - 1
 
 
-@pytest.mark.skipif(oracle.ref_ply_lib() is None, reason="oracle/_ref/libref_ply.so not built (needs /root/reference)")
+@pytest.mark.skipif(not oracle.have_ref("libref_ply.so"), reason="oracle/_ref/libref_ply.so not built (needs /root/reference)")
 def test_live_ply_reader_golden_regenerates_and_errors_agree(ld, tmp_path):
     from oracle import make_golden_ref_splat_io as mg
     for name, data in mg.ply_reader_files(SPLAT["ply/file_bytes"].tobytes()).items():

@@ -92,7 +92,7 @@ def test_trainer_loss_restatement_equals_the_reference_train_step(oracle_mod, na
         assert e < 1e-4, (k, e)
 
 
-@pytest.mark.skipif(oracle.ref_raster_lib(full=True) is None, reason="oracle/_ref/libref_raster_full.so not built (make -C oracle refgsplat; needs /root/reference)")
+@pytest.mark.skipif(not oracle.have_ref("libref_raster_full.so"), reason="oracle/_ref/libref_raster_full.so not built (make -C oracle refgsplat; needs /root/reference)")
 def test_golden_file_regenerates_from_the_whole_reference_gsplat_library():
     """rasterize() + autograd + Camera over the reference's entire gsplat library (every .cu with its launchers, every .cpp operator) on the CPU: bit for bit"""
     from oracle import make_golden_ref_raster as mg
@@ -111,7 +111,7 @@ def test_golden_file_regenerates_from_the_whole_reference_gsplat_library():
                     assert close, (name, "train_bilateral", k)
 
 
-@pytest.mark.skipif(oracle.ref_raster_lib() is None, reason="oracle/_ref/libref_raster.so not built (needs /root/reference)")
+@pytest.mark.skipif(not oracle.have_ref("libref_raster.so"), reason="oracle/_ref/libref_raster.so not built (needs /root/reference)")
 def test_restated_launch_sequences_reproduce_the_whole_library():
     """The same render path over the RESTATED host launch sequences (ref_raster_shim.cpp: kernels of libref_kernels.so, SH / intersection through the reference's
     tests/torch_impl.cpp) - the form the per-operator golden files of round 2 were generated with: integers identical, floats within 5e-6 of the tensor maximum
@@ -127,7 +127,7 @@ def test_restated_launch_sequences_reproduce_the_whole_library():
                 assert np.abs(v.astype(np.float64) - g).max() <= 5e-6 * max(np.abs(g).max(), 1e-30), (name, k)
 
 
-@pytest.mark.skipif(oracle.ref_fast_raster_lib() is None, reason="oracle/_ref/libref_fast_raster.so not built (make -C oracle reffast; needs /root/reference)")
+@pytest.mark.skipif(not oracle.have_ref("libref_fast_raster.so"), reason="oracle/_ref/libref_fast_raster.so not built (make -C oracle reffast; needs /root/reference)")
 def test_fastgs_golden_files_regenerate_from_the_whole_reference_fastgs_path():
     """(1) tests/golden/ref_fast_raster.npz from fast_rasterize() + autograd + rasterization_api.cu + forward.cu / backward.cu, bit for bit; (2) the wrapper-level file
     refk_fastgs.npz - generated through the restated wrapper of ref_kernels_fastgs.cpp - through the reference's own forward_wrapper / backward_wrapper, bit for bit."""

@@ -58,7 +58,7 @@ def test_golden_trajectories_show_the_rules_they_pin():
             assert np.abs(GOLD[f"{name}/it5/shN.exp_avg"]).max() == 0 and int(GOLD[f"{name}/it5/shN.step"]) == 4
 
 
-@pytest.mark.skipif(oracle.ref_strategy_lib() is None, reason="oracle/_ref/libref_strategy.so not built (needs /root/reference)")
+@pytest.mark.skipif(not oracle.have_ref("libref_strategy.so"), reason="oracle/_ref/libref_strategy.so not built (needs /root/reference)")
 def test_golden_file_regenerates_from_the_reference_strategy_layer():
     from oracle import make_golden_ref_strategy as mg
     out = {}

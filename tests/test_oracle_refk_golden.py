@@ -114,7 +114,7 @@ def test_golden_files_reproduce_from_the_reference_kernels(oracle_mod):
     assert np.array_equal(p, s["p1"])
 
 
-@pytest.mark.skipif(__import__("oracle").ref_raster_lib(full=True) is None, reason="oracle/_ref/libref_raster_full.so not built (make -C oracle refgsplat; needs /root/reference)")
+@pytest.mark.skipif(not __import__("oracle").have_ref("libref_raster_full.so"), reason="oracle/_ref/libref_raster_full.so not built (make -C oracle refgsplat; needs /root/reference)")
 def test_every_golden_case_regenerates_through_the_references_own_operators(oracle_mod):
     """The committed refk_*.npz files were generated through restated launch sequences (ref_kernels.cpp: allocation + <<<grid, block>>> geometry per kernel). Here the
     SAME inputs go through the reference's own operator layer - gsplat/*.cpp calling the launch functions of gsplat/*.cu, all compiled in place

@@ -52,7 +52,7 @@ def test_oracle_intersection_matches_the_reference_kernels(oracle_mod, name):
         assert (np.diff(g("flatten_ids"))[same] > 0).all()
 
 
-@pytest.mark.skipif(oracle.refk_lib() is None or not hasattr(oracle.refk_lib(), "refk_sh_fwd"), reason="oracle/_ref/libref_kernels.so not built (needs /root/reference)")
+@pytest.mark.skipif(not oracle.have_ref("libref_kernels.so"), reason="oracle/_ref/libref_kernels.so not built (needs /root/reference)")
 def test_golden_file_regenerates_from_the_reference_kernels():
     from oracle import make_golden_refk_sh_isect as mg
     for name, c in U.SH_CASES.items():

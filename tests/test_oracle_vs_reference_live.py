@@ -9,7 +9,7 @@ import pytest
 import oracle
 from test_oracle_refk_golden import check_projection, raster_bwd_rows
 
-pytestmark = pytest.mark.skipif(oracle.ref_raster_lib(full=True) is None, reason="oracle/_ref/libref_raster_full.so not built (make -C oracle refgsplat; needs /root/reference)")
+pytestmark = pytest.mark.skipif(not oracle.have_ref("libref_raster_full.so"), reason="oracle/_ref/libref_raster_full.so not built (make -C oracle refgsplat; needs /root/reference)")
 
 
 @pytest.fixture()
@@ -96,7 +96,7 @@ def test_random_scene_oracle_equals_the_reference_operators(whole, seed):
 
 
 # ---- the default (fastgs / EWA) path: oracle_fastgs.hpp against the reference's own forward_wrapper / backward_wrapper on random scenes ----------------------------
-fast_live = pytest.mark.skipif(oracle.ref_fast_raster_lib() is None, reason="oracle/_ref/libref_fast_raster.so not built (make -C oracle reffast; needs /root/reference)")
+fast_live = pytest.mark.skipif(not oracle.have_ref("libref_fast_raster.so"), reason="oracle/_ref/libref_fast_raster.so not built (make -C oracle reffast; needs /root/reference)")
 
 
 @fast_live
