@@ -167,15 +167,10 @@ def main() -> None:
     ap.add_argument("--bilateral-grid", action="store_true", help="BASELINE.json configs[4]: per-image 16x16x8 bilateral grid between render and loss (+ its TV loss and Adam)")
     ap.add_argument("--replicated", action="store_true", help="multi-GPU: keep shN replicated (59 floats / Gaussian all-reduced) instead of SH-sharded")
     ap.add_argument("--sh-sharded", action="store_true", help="force the SH-sharded layout (the default for more than one rank) - with LFS_DIST_FORCE_COLLECTIVES=1 this runs its collectives on ONE GPU")
-    ap.add_argument("--side-stream", action="store_true", help="developer A/B: SH colours on a second stream next to the intersection kernels (measured: no gain)")
-    ap.add_argument("--no-overlap-exchange", action="store_true", help="developer A/B: blocking all-to-alls in the SH-sharded forward")
-    ap.add_argument("--wide-cells", action="store_true", help="developer A/B: the experimental two-pixels-per-lane 16x8-cell rasterizer kernels (slower on SYN-B; see raster.hip)")
-    ap.add_argument("--row-lists", default="split", choices=["split", "merged"], help="with --row-kernels: quadrant lists split from the cell lists (two kernels) or built in one pass")
-    ap.add_argument("--row-kernels", action="store_true", help="developer A/B: the experimental quadrant-row rasterizer kernels (csrc/lfs_raster_rows.cuh; not yet verified on a GPU)")
-    ap.add_argument("--debug-flags", type=int, default=0, help="developer A/B switches (include/lfs_gsplat.h: lfs_set_debug_flags), e.g. 32 = one-pass intersection scatter")
-    ap.add_argument("--fuse-sh-pack", action="store_true", help="developer A/B: SH colours + rasterizer records in one kernel (fused.FUSE_SH_PACK; no gain measured)")
-    ap.add_argument("--no-fuse-act-proj", action="store_true", help="developer A/B: separate activations and projection kernels")
-    ap.add_argument("--no-inline-all", action="store_true", help="developer A/B: separate raster_finish / activations_bwd / adam_multi kernels instead of the all-inline backward")
+    ap.add_argument("--path", default="step", choices=["step", "ops"],
+                    help="step (default) = the C++ training step (csrc/gut_step.hip, one host call per step); ops = the DROP-IN route: the sequence "
+                         "rasterizer.cpp:224-344 makes through the reference-signature C++ wrappers of _lfs_torch_ops.so, op by op under torch autograd, then six "
+                         "adam_step_wrapper launches (fused_adam.cpp:22-95) - what a reference build linking csrc/torch_ops.cpp gets without touching its trainer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -185,13 +180,6 @@ def main() -> None:
     from lichtfeld_studio_amd import capi, scenes
     from lichtfeld_studio_amd import dist as lfs_dist
     from lichtfeld_studio_amd.trainer import GutTrainer
-    if args.wide_cells:
-        lfs.load_library().lfs_set_debug_flags(2)
-    if args.row_kernels:
-        lfs.load_library().lfs_set_debug_flags(12 if args.row_lists == "merged" else 4)
-    if args.debug_flags:
-        lfs.load_library().lfs_set_debug_flags(args.debug_flags)
-
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     capi.load_library()
@@ -223,12 +211,7 @@ def main() -> None:
         # objects at 20 - 200 ms each); the timed window then holds warm steps only, one of them (every 100th) a refinement step
         args.start_iteration = 3000 - max(2, args.warmup - 2)
     trainer.iteration = args.start_iteration
-    if args.no_inline_all:
-        trainer.inline_all_adam = False
     from lichtfeld_studio_amd import fused as _fused
-    _fused.FUSE_SH_PACK, _fused.FUSE_ACT_PROJ = bool(args.fuse_sh_pack), not args.no_fuse_act_proj
-    _fused.OVERLAP_SH_EXCHANGE = not args.no_overlap_exchange
-    _fused.SIDE_STREAM_SH = bool(args.side_stream)
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
     parallelism_fallback = None
     if world > 1 and trainer.sh_exchange is not None:
@@ -245,8 +228,6 @@ def main() -> None:
         if float(flag) == 0.0:
             parallelism_fallback = parallelism_fallback or "another rank failed its SH-sharded trial step"
             trainer = make_trainer(False)
-            if args.no_inline_all:
-                trainer.inline_all_adam = False
         trainer.iteration = args.start_iteration
     hip_step = None
     if world == 1 and not args.no_cpu_baseline and args.rasterizer == "gut" and trainer.sh_exchange is None:

@@ -375,29 +375,47 @@ LFS_API int lfs_add_noise(
 
 /* Extension: the front half of the fused 3DGUT training step (one camera, global shutter, 3 channels).
  *   lfs_activations_project_ut : lfs_activations_fwd + lfs_projection_ut_3dgs_fused in one pass over the raw parameters (normalize / exp / sigmoid, then the
- *       projection on the activated values - the same operations in the same order); quats / scales / opacities receive the activated values.
- *   lfs_gut_prepare_cameras    : the device-side camera state at the start of a rasterizer workspace (what the forward call would compute first).
- *   lfs_sh_model_fwd_pack      : lfs_sh_model_fwd whose lanes also write the rasterizer's 64-byte records and 32-byte culling records of the visible
- *       Gaussians into that workspace (offsets: lfs_rasterize_workspace_offsets; they do not depend on n_isects, so the workspace can be sized - and,
- *       if it must grow once n_isects is known, its prefix copied - before the intersection count exists).
- *   lfs_rasterize_to_pixels_from_world_3dgs_fwd_prepacked : the forward call on such a workspace (no camera / pack kernels). */
+ *       projection on the activated values - the same operations in the same order); quats / scales / opacities receive the activated values. */
 LFS_API int lfs_activations_project_ut(
     uint32_t N, const float* means, const float* raw_quats, const float* raw_scales, const float* raw_opacities, const lfs_cameras* cams,
     float eps2d, float near_plane, float far_plane, float radius_clip, const lfs_ut_params* ut_params,
     float* quats, float* scales, float* opacities, int32_t* radii, float* means2d, float* depths, lfs_stream_t stream);
-LFS_API void lfs_rasterize_workspace_offsets(uint32_t C, uint32_t N, size_t* cams, size_t* recs, size_t* acc, size_t* cull, size_t* prefix_bytes);
-LFS_API int lfs_gut_prepare_cameras(const lfs_cameras* cams, void* workspace, size_t workspace_bytes, lfs_stream_t stream);
-LFS_API int lfs_sh_model_fwd_pack(
-    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
-    const int32_t* radii, const float* quats, const float* scales, const float* opacities, float* colors,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
-LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_fwd_prepacked(
-    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
-    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
-    const lfs_cameras* cams, uint32_t tile_size,
-    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
-    float* render_colors, float* render_alphas, int32_t* last_ids,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+
+/* ---- The --gut training step as ONE host call (csrc/gut_step.hip; replaces Trainer::train_step -> rasterize() -> the Ops.h sequence of
+ *      src/training/trainer.cpp:579-770 / rasterization/rasterizer.cpp:200-344 for one pinhole, global-shutter camera per step, RGB, MSE, fused Adam).
+ *      No host read on the critical path: the intersection lists are sized for `capacity` entries and sorted by the size classes that cover
+ *      `assumed_longest` entries per tile; the true count stays on the device. When it exceeds either assumption the kernels raise a device flag,
+ *      empty all lists and the Adam kernels return without updating anything: the caller learns it from the counts - written to PINNED host memory
+ *      host_counts[3] = {n_isects, longest tile list, stamp} early in the step - after it has enqueued everything (lfs_gut_step_wait, lfs_gut_step_fits),
+ *      enlarges the workspace and calls again with the same arguments.
+ *   lfs_gut_step_args: parameters are updated in place; exp_avg / exp_avg_sq / adam[k] in FusedAdam's group order (fused_adam.cpp:22-95, strategy_utils.cpp:35-40)
+ *      means, sh0, shN, raw_scales, raw_quats, raw_opacities; adam[k] = {lr, beta1, beta2, eps, 1/(1-beta1^t), 1/sqrt(1-beta2^t)} (fused_adam.cpp:78-92).
+ *      viewmat [4,4], Kmat [3,3], background [3] (nullable), target_chw [3,H,W] on the device; *loss = loss_weight * mse(clamp(render,0,1), target) (stored).
+ *   workspace: lfs_gut_step_layout_for(...).bytes; the layout names the byte offsets of what a caller may want to look at afterwards (the render
+ *      [H,W,3], alpha [H,W], radii int32 [N,2], ...). tile_offsets has T + 1 entries (the last one is n_isects).
+ *   lfs_gut_view_forward / lfs_gut_view_backward: the same step split for callers that need GRADIENT TENSORS (data-parallel ranks, several views per step,
+ *      losses other than MSE): forward into the workspace, then backward into grads[6] (group order; written or, accumulate != 0, added to). */
+typedef struct lfs_gut_step_args {
+    uint32_t N, K, sh_degree, image_width, image_height, tile_size;
+    float *means, *sh0, *shN, *raw_scales, *raw_quats, *raw_opacities;
+    float* exp_avg[6]; float* exp_avg_sq[6];
+    float adam[6][6];
+    const float* viewmat; const float* Kmat; const float* background; const float* target_chw;
+    float loss_weight, scale_reg, opacity_reg;
+    float* loss;
+} lfs_gut_step_args;
+typedef struct lfs_gut_step_layout {
+    size_t bytes, render, alpha, last_ids, radii, means2d, depths, colors, quats, scales, opacities, tile_offsets, flatten_ids, isect_ids, counts, abort_flag;
+} lfs_gut_step_layout;
+LFS_API int lfs_gut_step_layout_for(uint32_t N, uint32_t image_width, uint32_t image_height, uint32_t tile_size, int64_t capacity, lfs_gut_step_layout* out);
+LFS_API int lfs_gut_step_fits(int64_t n_isects, int64_t longest, int64_t capacity, int64_t assumed_longest); /* 1: the attempt with these assumptions was valid */
+LFS_API int lfs_gut_train_step(const lfs_gut_step_args* args, int64_t capacity, int64_t assumed_longest, void* workspace, size_t workspace_bytes,
+                               int64_t* host_counts /* pinned [3], or NULL: counts stay in the workspace */, int64_t stamp, lfs_stream_t stream);
+LFS_API int lfs_gut_view_forward(const lfs_gut_step_args* args, int64_t capacity, int64_t assumed_longest, void* workspace, size_t workspace_bytes,
+                                 int64_t* host_counts, int64_t stamp, lfs_stream_t stream);
+LFS_API int lfs_gut_view_backward(const lfs_gut_step_args* args, int64_t capacity, const float* v_render /* [H,W,3], used when args->target_chw == NULL */,
+                                  float* const* grads /* [6] host */, int accumulate, void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+LFS_API int lfs_gut_step_wait(const int64_t* host_counts, int64_t stamp, double timeout_s, int64_t* n_isects, int64_t* longest);
 
 /* Extension: the all-inline training step of the fused 3DGUT path (one camera, global shutter, 3 channels, ONE view per step on one rank - the
  * reference's training configuration). No parameter gradient is materialised:

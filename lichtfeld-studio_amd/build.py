@@ -40,8 +40,9 @@ SOURCES = {
     # no SLP packing: v_pk_* operand pairing forces SGPR shuffles right after the scalar record
     # load and defeats the software prefetch (measured on the ISA); plain v_fma with SGPR operands
     "raster.hip": ["-fno-slp-vectorize"],
+    "gut_step.hip": [],   # host code only: the C++ training-step driver
 }
-HEADERS = ["lfs_math.cuh", "lfs_adam.cuh", "lfs_camera.cuh", "lfs_prof.h", "lfs_raster_common.cuh", "lfs_cull_conic.cuh", "lfs_raster_rows.cuh", "lfs_raster_pack.cuh", "lfs_tilelists.cuh", "lfs_fastgs.cuh", os.path.join("..", "..", "include", "lfs_gsplat.h")]
+HEADERS = ["lfs_math.cuh", "lfs_adam.cuh", "lfs_camera.cuh", "lfs_prof.h", "lfs_raster_common.cuh", "lfs_cull_conic.cuh", "lfs_raster_pack.cuh", "lfs_tilelists.cuh", "lfs_fastgs.cuh", "lfs_step_internal.h", os.path.join("..", "..", "include", "lfs_gsplat.h")]
 
 
 def _stale(obj: str, src: str) -> bool:

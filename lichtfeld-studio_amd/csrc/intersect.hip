@@ -22,6 +22,7 @@
 #include "lfs_math.cuh"
 #include "lfs_prof.h"
 #include "lfs_tilelists.cuh"
+#include "lfs_step_internal.h"
 #include "../../include/lfs_gsplat.h"
 
 namespace lfs {
@@ -200,8 +201,10 @@ LFS_DI void block_scan_1024(const uint32_t* a, uint32_t* out, uint32_t L, uint32
 __global__ void __launch_bounds__(1024) isect_rows_kernel(
     const uint32_t C, const uint32_t N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths,
     const float tile_size_f, const uint32_t tw, const uint32_t th, const uint32_t idx_bits,
-    const int32_t* __restrict__ offsets, uint32_t* __restrict__ row_cursor, uint64_t* __restrict__ scratch) {
+    const int32_t* __restrict__ offsets, uint32_t* __restrict__ row_cursor, uint64_t* __restrict__ scratch, const int32_t* __restrict__ abort_flag = nullptr) {
     LFS_DYN_LDS(uint64_t, stage); // [ROWS_STAGE]
+    if (abort_flag != nullptr && *abort_flag != 0) return; // speculative step: the lists do not fit the caller's buffers (tile_scan_kernel) - this kernel derives its
+                                                           // write positions from the Gaussians, not from the (zeroed) offsets, so it has to stop itself
     __shared__ uint32_t cnt[ROWS_MAX], lbase[ROWS_MAX + 1], gbase[ROWS_MAX], tmp[17];
     const uint32_t R = C * th;
     const size_t total = size_t(C) * N;
@@ -245,13 +248,15 @@ __global__ void __launch_bounds__(1024) isect_rows_kernel(
 }
 
 __global__ void __launch_bounds__(1024) isect_tiles_kernel(
-    const uint32_t R, const uint32_t tw, const uint32_t idx_bits, const int64_t n_isects,
+    const uint32_t R, const uint32_t tw, const uint32_t idx_bits, const int64_t n_isects_arg,
     const int32_t* __restrict__ offsets, uint32_t* __restrict__ cursor, const uint64_t* __restrict__ scratch, int64_t* __restrict__ isect_ids) {
     LFS_DYN_LDS(uint64_t, stage); // [TILES_CHUNK]
     __shared__ uint32_t cnt[TILES_SPAN], lpre[TILES_SPAN + 1], gb[TILES_SPAN], tmp[17];
     __shared__ uint32_t rows_s[2];
     constexpr uint32_t PER = TILES_CHUNK / 1024;
+    const int64_t n_isects = n_isects_arg >= 0 ? n_isects_arg : int64_t(offsets[size_t(R) * tw]); // < 0: the count lives on the device (offsets[T]); the grid covers the caller's capacity
     const int64_t p0 = int64_t(blockIdx.x) * TILES_CHUNK, p1 = min(p0 + int64_t(TILES_CHUNK), n_isects);
+    if (p0 >= n_isects) return; // (uniform)
     if (threadIdx.x < 2) { // the row that holds p0 / p1 - 1: the largest r with row_start(r) <= p
         const int64_t p = threadIdx.x == 0 ? p0 : p1 - 1;
         uint32_t lo = 0, hi = R; // invariant: row_start(lo) <= p < row_start(hi) (row_start(R) = n_isects)
@@ -440,19 +445,18 @@ extern "C" size_t lfs_intersect_tile_workspace_bytes(uint32_t C, uint32_t N, uin
     return isect_ws(nullptr, C, N, tile_width, tile_height).bytes;
 }
 
-extern "C" int lfs_intersect_tile_count_ex(
+int lfs::isect_count_impl(
     uint32_t C, uint32_t N, const float* means2d, const int32_t* radii,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
     int32_t* tiles_per_gauss, int64_t* n_isects, int64_t* max_tile_isects, int32_t* tile_offsets, uint32_t flags, int64_t* stamp_out, int64_t stamp,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    void* workspace, size_t workspace_bytes, hipStream_t s, const IsectGuard* guard) {
     if (!n_isects || !workspace || tile_size == 0 || tile_width == 0 || tile_height == 0 || C == 0) return LFS_E_INVALID;
     if (bit_width_u32(tile_width * tile_height) + bit_width_u32(C) > 32) return LFS_E_UNSUPPORTED; // IntersectTile.cu:154
     IsectWs w = isect_ws(workspace, C, N, tile_width, tile_height);
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
     const uint32_t T = C * tile_width * tile_height;
-    // the scan kernel leaves totals[] zero again and zeroes both cursors itself: a caller that passes the workspace of its previous call
-    // (same C, N, tile grid) sets LFS_ISECT_COUNTERS_ZERO and saves the memset
+    // the scan kernel leaves totals[] zero again and zeroes both cursors itself: a caller that OWNS the workspace and passes the one of its previous call
+    // (same C, N, tile grid) may set LFS_ISECT_COUNTERS_ZERO and save the memset (nothing in this repository does any more: 32 KB, ~2 us)
     if (!(flags & LFS_ISECT_COUNTERS_ZERO)) {
         hipError_t e = hipMemsetAsync(w.totals, 0, size_t(T) * 4, s);
         if (e != hipSuccess) return (int)e;
@@ -470,8 +474,27 @@ extern "C" int lfs_intersect_tile_count_ex(
             hipLaunchKernelGGL(isect_count_kernel<false>, dim3(blocks), dim3(1024), 0, s, C, N, pb, means2d, radii,
                                float(tile_size), tile_width, tile_height, tiles_per_gauss, w.totals);
     }
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets, max_tile_isects, stamp_out, stamp);
+    if (guard != nullptr) {
+        if (guard->capacity < 0 || !guard->abort_flag) return LFS_E_INVALID;
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets,
+                           max_tile_isects, stamp_out, stamp, guard->capacity, sort_class_limit(guard->assumed_longest), guard->abort_flag);
+    } else
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets,
+                           max_tile_isects, stamp_out, stamp);
     return (int)hipGetLastError();
+}
+
+const int32_t* lfs::isect_workspace_offsets(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height) {
+    return isect_ws(workspace, C, N, tile_width, tile_height).offsets;
+}
+
+extern "C" int lfs_intersect_tile_count_ex(
+    uint32_t C, uint32_t N, const float* means2d, const int32_t* radii,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height,
+    int32_t* tiles_per_gauss, int64_t* n_isects, int64_t* max_tile_isects, int32_t* tile_offsets, uint32_t flags, int64_t* stamp_out, int64_t stamp,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    return lfs::isect_count_impl(C, N, means2d, radii, tile_size, tile_width, tile_height, tiles_per_gauss, n_isects, max_tile_isects, tile_offsets, flags, stamp_out,
+                                 stamp, workspace, workspace_bytes, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int lfs_intersect_tile_count(
@@ -482,16 +505,26 @@ extern "C" int lfs_intersect_tile_count(
                                        workspace_bytes, stream);
 }
 
-extern "C" int lfs_intersect_tile_emit_ex(
+int lfs::isect_emit_impl(
     uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
     uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int sort, int64_t n_isects,
     const int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* tile_offsets, int64_t* scratch, int64_t max_tile_isects,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    void* workspace, size_t workspace_bytes, hipStream_t s, const IsectGuard* guard) {
     if (!workspace || C == 0 || tile_size == 0) return LFS_E_INVALID;
     IsectWs w = isect_ws(workspace, C, N, tile_width, tile_height);
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
     const uint32_t T = C * tile_width * tile_height;
+    // guarded (speculative) call: the count is on the device. Grids cover the caller's capacity, the kernels read offsets[T]; the sort classes are the ones
+    // tile_scan_kernel was told about (anything longer raised the abort flag and emptied the lists)
+    const bool guarded = guard != nullptr;
+    const int64_t n_grid = guarded ? guard->capacity : n_isects;     // what the launch geometry covers
+    const int64_t n_arg = guarded ? int64_t(-1) : n_isects;          // what the kernels receive
+    if (guarded) {
+        if (!sort || !scratch || guard->capacity < 0) return LFS_E_INVALID;
+        n_isects = guard->capacity;
+        max_tile_isects = int64_t(sort_class_limit(guard->assumed_longest));
+        if (max_tile_isects == int64_t(0xFFFFFFFFu)) max_tile_isects = -1;
+    }
     if (tile_offsets) {
         hipError_t e = hipMemcpyAsync(tile_offsets, w.offsets, size_t(T) * 4, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return (int)e;
@@ -528,10 +561,12 @@ extern "C" int lfs_intersect_tile_emit_ex(
                               !(lfs_get_debug_flags() & 32u);
         if (two_pass) {
             hipLaunchKernelGGL(isect_rows_kernel, dim3(uint32_t((total + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(1024), ROWS_STAGE * 8, s, C, N, means2d, radii,
-                               depths, float(tile_size), tile_width, tile_height, idx_bits, w.offsets, w.row_cursor, reinterpret_cast<uint64_t*>(scratch));
-            hipLaunchKernelGGL(isect_tiles_kernel, dim3(uint32_t((n_isects + TILES_CHUNK - 1) / TILES_CHUNK)), dim3(1024), TILES_CHUNK * 8, s, R, tile_width, idx_bits,
-                               n_isects, w.offsets, w.cursor, reinterpret_cast<const uint64_t*>(scratch), isect_ids);
-        } else if (size_t(T) * 8 <= LDS_HIST_LIMIT)
+                               depths, float(tile_size), tile_width, tile_height, idx_bits, w.offsets, w.row_cursor, reinterpret_cast<uint64_t*>(scratch),
+                               guarded ? guard->abort_flag : nullptr);
+            hipLaunchKernelGGL(isect_tiles_kernel, dim3(uint32_t((n_grid + TILES_CHUNK - 1) / TILES_CHUNK)), dim3(1024), TILES_CHUNK * 8, s, R, tile_width, idx_bits,
+                               n_arg, w.offsets, w.cursor, reinterpret_cast<const uint64_t*>(scratch), isect_ids);
+        } else if (guarded) { lfs::prof_end(tok, s); return LFS_E_UNSUPPORTED; } // (the one-pass scatter does not watch the abort flag)
+        else if (size_t(T) * 8 <= LDS_HIST_LIMIT)
             hipLaunchKernelGGL(isect_scatter_kernel<true>, dim3(blocks), dim3(1024), size_t(T) * 8, s, C, N, pb, means2d, radii, depths,
                                float(tile_size), tile_width, tile_height, tile_n_bits, w.offsets, w.cursor, isect_ids, flatten_ids);
         else
@@ -563,6 +598,15 @@ extern "C" int lfs_intersect_tile_emit_ex(
                            w.block_sums, float(tile_size), tile_width, tile_height, tile_n_bits, isect_ids, flatten_ids);
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int lfs_intersect_tile_emit_ex(
+    uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths,
+    uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int sort, int64_t n_isects,
+    const int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids, int32_t* tile_offsets, int64_t* scratch, int64_t max_tile_isects,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    return lfs::isect_emit_impl(C, N, means2d, radii, depths, tile_size, tile_width, tile_height, sort, n_isects, tiles_per_gauss, isect_ids, flatten_ids, tile_offsets,
+                                scratch, max_tile_isects, workspace, workspace_bytes, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int lfs_intersect_tile_emit(

@@ -16,7 +16,12 @@ namespace lfs {
 static __global__ void __launch_bounds__(1024) tile_scan_kernel(
     const uint32_t T, uint32_t* __restrict__ totals, int32_t* __restrict__ offsets, int64_t* __restrict__ n_isects,
     const bool zero_totals = false, uint32_t* __restrict__ cursor = nullptr, uint32_t* __restrict__ aux = nullptr, const uint32_t n_aux = 0,
-    int32_t* __restrict__ offsets_out = nullptr, int64_t* __restrict__ max_total = nullptr, int64_t* __restrict__ stamp_out = nullptr, const int64_t stamp = 0) {
+    int32_t* __restrict__ offsets_out = nullptr, int64_t* __restrict__ max_total = nullptr, int64_t* __restrict__ stamp_out = nullptr, const int64_t stamp = 0,
+    const int64_t capacity = -1, const uint32_t max_list = 0xFFFFFFFFu, int32_t* __restrict__ abort_flag = nullptr) {
+    // capacity >= 0 (the speculative training step, csrc/gut_step.hip): the caller sized its list buffers for `capacity` intersections and launched the
+    // per-tile sort classes up to `max_list` entries BEFORE these counts existed. When either assumption fails, *abort_flag = 1, every offset is
+    // rewritten to 0 (all lists empty: nothing downstream indexes past its buffers) and the true counts are still reported - the host sees them after
+    // it has enqueued the rest of the step, and runs the step again with buffers that fit.
     // slices of 8192 tiles staged in LDS: coalesced loads, every thread scans 8 consecutive values, coalesced stores (one slice = the whole array
     // at 1080p; the round-1 version walked slices of 1024 with three barriers each: 13 us at T = 8160; a register-blocked version without the LDS
     // transpose was slower still - 8-word strides between lanes make every store a partial 32-byte sector)
@@ -66,9 +71,16 @@ static __global__ void __launch_bounds__(1024) tile_scan_kernel(
     for (int m = 32; m >= 1; m >>= 1) vmax = max(vmax, uint32_t(__shfl_xor(int(vmax), m, 64)));
     if (lane == 0) wave_max[wave] = vmax;
     __syncthreads();
+    uint32_t longest = 0;
+    for (int w = 0; w < 16; ++w) longest = max(longest, wave_max[w]);
+    const bool over = capacity >= 0 && (carry > uint64_t(capacity) || longest > max_list); // (uniform: every thread has the same carry and maxima)
+    if (over) {
+        for (uint32_t i = threadIdx.x; i < T; i += 1024) { offsets[i] = 0; if (offsets_out != nullptr) offsets_out[i] = 0; }
+    }
     if (threadIdx.x == 0) {
-        offsets[T] = int32_t(carry); *n_isects = int64_t(carry);
-        if (max_total != nullptr) { uint32_t m = 0; for (int w = 0; w < 16; ++w) m = max(m, wave_max[w]); *max_total = int64_t(m); }
+        offsets[T] = over ? 0 : int32_t(carry); *n_isects = int64_t(carry);
+        if (abort_flag != nullptr) *abort_flag = over ? 1 : 0;
+        if (max_total != nullptr) *max_total = int64_t(longest);
         if (stamp_out != nullptr) { // the counts may live in pinned HOST memory: the stamp is written last, behind a system-scope fence - a host that
             LFS_SYSTEM_FENCE();     // sees the stamp of this call also sees its counts (it does not rely on the completion event alone)
             *reinterpret_cast<volatile int64_t*>(stamp_out) = stamp;

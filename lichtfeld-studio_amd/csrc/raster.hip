@@ -25,23 +25,16 @@
 //             scalar atomics per (warp, Gaussian)).
 //  * finish : one pass maps the accumulator through the quaternion / scale /
 //             mean vjp (done per (pixel, Gaussian) in the reference).
-//  * wide   : EXPERIMENT, off by default (lfs_set_debug_flags bit 1; tile sizes that are multiples of 16): the wavefront owns a
-//             16x8 cell and every lane TWO pixels (j, i) and (j + 8, i), so that all per-pixel arithmetic is 2-wide and compiles
-//             to v_pk_mul / v_pk_fma_f32 with the SGPR record broadcast through op_sel, and the per-(wave, Gaussian) costs
-//             (record load, ballot, the backward's 16-value reduction + atomic) are paid once per 128 pixels. Per-pixel results
-//             are bit-identical to the one-pixel-per-lane kernels (same fma chains per component; tests/test_gpu_raster.py).
-//             Measured on SYN-B (MI355X, profiles/r01/raster_wide_cells_ab.json): raster_bwd 0.84 ms instead of 0.69, raster_fwd 0.49
-//             instead of 0.29. Not the instruction rate - v_pk_fma_f32 issues in 5.1 cycles per wavefront against 4.4 for v_fma_f32
-//             (tools/pk_rate.hip: 123 vs 71 TFLOP/s), and a wave-evaluation costs 132 VALU instructions for 128 pixels against 122 for
-//             64 - but the scene: SYN-B's Gaussians are small against an 8-pixel cell, most entries of a 16x8 cell's list reach only
-//             one of its halves, so the number of wave-evaluations hardly falls (PMC: bwd 2.4M vs 3.0M, fwd 3.8M vs 3.7M) while each
-//             costs more, and culling / early-out act on 128 pixels. Kept opt-in for scenes of large Gaussians.
+// Measured and removed in round 3 (kernels in git history up to e34272a, numbers under profiles/): 16x8 "wide" cells with two pixels per lane
+// (profiles/r01/raster_wide_cells_ab.json: bwd 0.84 vs 0.69 ms), quadrant-row kernels with DPP-broadcast records (profiles/r02/raster_rows_vs_default_pmc.txt:
+// 1.17x the VALU instructions), SH colours + record packing in one kernel (profiles/r02/fuse_front_ab.txt: no gain).
 #include "lfs_camera.cuh"
 #include "lfs_prof.h"
 #include "lfs_raster_common.cuh"
 #include "lfs_cull_conic.cuh"
 #include "lfs_raster_pack.cuh"
 #include "lfs_adam.cuh"
+#include "lfs_step_internal.h"
 
 // Host build on the wavefront emulator (tests/emul) only: wave-evaluation counters [fwd, fwd that composited, bwd, bwd that accumulated]
 #ifdef LFS_EMULATE
@@ -55,10 +48,9 @@ namespace lfs {
 
 static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 constexpr uint32_t LOSS_SLOTS = 256; // fused MSE: the wavefronts' partial sums are spread over this many addresses (one hot address costs ~0.08 ms)
-struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; CullRec* cull; int32_t* cell_count; int2* cell_list; int32_t* quad_count; int2* quad_list; unsigned long long* det64; size_t bytes; };
+struct RasterWs { CamDev* cams; GaussRec* recs; float* acc; CullRec* cull; int32_t* cell_count; int2* cell_list; unsigned long long* det64; size_t bytes; };
 // cells = C * tiles * (tile_size/8)^2 ; the compacted per-cell lists hold at most (tile_size/8)^2 * n_isects entries
-// quads (experimental row kernels): four quadrant lists per cell on top
-static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, uint64_t cell_entries, bool quads, bool det = false) {
+static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, uint64_t cell_entries, bool det = false) {
     RasterWs w; char* p = (char*)base; size_t o = 0;
     w.cams = (CamDev*)(p + o); o += align256(sizeof(CamDev) * C);
     w.recs = (GaussRec*)(p + o); o += align256(sizeof(GaussRec) * size_t(C) * N);
@@ -66,11 +58,6 @@ static RasterWs raster_ws(void* base, uint32_t C, uint32_t N, uint64_t cells, ui
     w.cull = (CullRec*)(p + o); o += align256(sizeof(CullRec) * size_t(C) * N);
     w.cell_count = (int32_t*)(p + o); o += align256(sizeof(int32_t) * cells);
     w.cell_list = (int2*)(p + o); o += align256(sizeof(int2) * cell_entries);
-    w.quad_count = nullptr; w.quad_list = nullptr;
-    if (quads) {
-        w.quad_count = (int32_t*)(p + o); o += align256(sizeof(int32_t) * 4 * cells);
-        w.quad_list = (int2*)(p + o); o += align256(sizeof(int2) * 4 * cell_entries);
-    }
     w.det64 = nullptr;
     if (det) { w.det64 = (unsigned long long*)(p + o); o += align256(sizeof(unsigned long long) * ACC_STRIDE * size_t(C) * N); } // deterministic backward (debug bit 4)
     w.bytes = o;
@@ -115,32 +102,11 @@ __global__ void __launch_bounds__(256) raster_pack_kernel(
 // camera coordinates is wave-uniform and tested against the entry's silhouette conic (lfs_cull_conic.cuh). Output per cell: count + (gaussian, list index)
 // pairs in list order, stored in the cell's slice of a [cells_per_tile * n_isects] array.
 // ---------------------------------------------------------------------------
-// Workgroup -> (tile, 16x8 cell) of the wide kernels: cell_ctx's XCD-banded tile order; (i, j) is the lane's FIRST pixel, the second is (i, j + 8).
-LFS_DI CellCtx cell_ctx_wide(uint32_t n_tiles, uint32_t total_tiles, uint32_t tw, uint32_t tile_size, uint32_t blocks_per_tile, uint32_t waves_per_block) {
-    CellCtx c;
-    const uint32_t nb = total_tiles * blocks_per_tile;
-    const uint32_t per_xcd = (nb + 7) / 8;
-    const uint32_t b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    c.in_grid = b < nb && (blockIdx.x >> 3) < per_xcd;
-    const uint32_t tg = b / blocks_per_tile, bt = b % blocks_per_tile;
-    c.tile_global = tg;
-    c.cid = tg / n_tiles;
-    const uint32_t tile = tg % n_tiles;
-    const uint32_t ty = tile / tw, tx = tile % tw;
-    const uint32_t cpr = tile_size >> 4; // 16-pixel-wide cells per tile row
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    c.wl = bt * waves_per_block + wave;
-    const uint32_t lane = threadIdx.x & 63;
-    c.i = ty * tile_size + (c.wl / cpr) * 8 + (lane >> 3);
-    c.j = tx * tile_size + (c.wl % cpr) * 16 + (lane & 7);
-    return c;
-}
-LFS_DI uint32_t cells_per_tile(uint32_t tile_size, bool wide) { return wide ? (tile_size >> 4) * (tile_size >> 3) : (tile_size >> 3) * (tile_size >> 3); }
 
 #ifndef LFS_CULL_DEPTH
 #define LFS_CULL_DEPTH 1   // batches of look-ahead per thread in raster_cull_kernel; 2 and 4 measured: no gain (0.072 -> 0.073 / 0.078 ms on SYN-B) - the kernel is
 #endif                     // bound by the gather throughput (L2 / texture-address unit), not by the latency of a workgroup's dependent loads
-template <bool UNIFORM_ORIGIN, bool WIDE = false>
+template <bool UNIFORM_ORIGIN>
 __global__ void __launch_bounds__(256) raster_cull_kernel(
     const uint32_t C, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
     const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block, const uint32_t cull_enabled,
@@ -154,21 +120,20 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
     __shared__ float4 s_a[2][256], s_b[2][256];
     __shared__ int32_t s_g[2][256];
     const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
-    const CellCtx cc = WIDE ? cell_ctx_wide(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block)
-                            : cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
+    const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
     if (!cc.in_grid) return; // (uniform per workgroup)
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wpt = cells_per_tile(tile_size, WIDE);
+    const uint32_t wpt = (tile_size >> 3) * (tile_size >> 3);
     const size_t cell = size_t(cc.tile_global) * wpt + cc.wl;
     const int32_t start = offsets[cc.tile_global];
-    const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
+    const int32_t end = (cc.tile_global == total_tiles - 1 && n_isects >= 0) ? n_isects : offsets[cc.tile_global + 1]; // n_isects < 0: offsets has T + 1 entries (guarded step)
     const bool tile_masked = masks != nullptr && !masks[cc.tile_global];
     if (tile_masked || end <= start) { // uniform per workgroup
         if (lane == 0) cell_count[cell] = 0;
         return;
     }
 
-    // cell bounds in normalised camera coordinates (x/z, y/z) over the rays that can composite at all (WIDE: both pixels of the lane)
+    // cell bounds in normalised camera coordinates (x/z, y/z) over the rays that can composite at all
     const CamDev& cam = cams[cc.cid];
     const float big = 3.0e38f;
     bool active = false, behind = false;
@@ -189,7 +154,6 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
         }
     };
     probe(cc.j, cc.i);
-    if (WIDE) probe(cc.j + 8, cc.i);
     const bool cell_live = __ballot(active) != 0ull; // a dead cell still helps with the loads and the barriers
     bool can_cull = UNIFORM_ORIGIN && cull_enabled != 0;
     float tu_lo = 0.f, tu_hi = 0.f, tv_lo = 0.f, tv_hi = 0.f;
@@ -343,7 +307,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 
     const uint32_t wpt = (tile_size >> 3) * (tile_size >> 3);
     const int32_t start = offsets[cc.tile_global];
-    const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
+    const int32_t end = (cc.tile_global == total_tiles - 1 && n_isects >= 0) ? n_isects : offsets[cc.tile_global + 1]; // n_isects < 0: offsets has T + 1 entries (guarded step)
     const int2* __restrict__ cl = cell_list + (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
     const int32_t cnt = cell_count[size_t(cc.tile_global) * wpt + cc.wl];
 
@@ -430,7 +394,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 
     const uint32_t wpt = (tile_size >> 3) * (tile_size >> 3);
     const int32_t start = offsets[cc.tile_global];
-    const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
+    const int32_t end = (cc.tile_global == total_tiles - 1 && n_isects >= 0) ? n_isects : offsets[cc.tile_global + 1]; // n_isects < 0: offsets has T + 1 entries (guarded step)
     const int2* __restrict__ cl = cell_list + (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
     const int32_t cnt = cell_count[size_t(cc.tile_global) * wpt + cc.wl];
 
@@ -575,341 +539,6 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// wide kernels (experiment, opt-in): 16x8 cell per wavefront, two pixels per lane, packed f32 arithmetic
-// ---------------------------------------------------------------------------
-// walk_cell_list with ONE record per group (two record buffers instead of four): a two-pixel evaluation is twice as long, so one
-// evaluation in flight per scalar load hides the same latency, and the 32 SGPRs this frees are what the packed instructions need for
-// their operand pairs (with four buffers the wide kernels spill SGPRs to VGPR lanes inside the loop).
-// every field of the record has to be in SGPRs here: keeps the compiler from splitting the 64-byte scalar load and sinking the pieces to
-// their first use (which would turn the prefetch into a load-and-wait in front of every evaluation)
-LFS_DI void pin_record(const GaussRec& r) {
-#ifdef LFS_EMULATE
-    (void)r;
-#else
-    asm volatile("; record landed" ::"s"(r.r0.x), "s"(r.r0.y), "s"(r.r0.z), "s"(r.r0.w), "s"(r.r1.x), "s"(r.r1.y), "s"(r.r1.z), "s"(r.r1.w),
-                 "s"(r.r2.x), "s"(r.r2.y), "s"(r.r2.z), "s"(r.r2.w), "s"(r.r3.x), "s"(r.r3.y), "s"(r.r3.z), "s"(r.r3.w));
-#endif
-}
-template <int STEP, class Eval, class Alive>
-LFS_DI void walk_cell_list_2buf(const int2* __restrict__ cl, const GaussRec* __restrict__ recs, const int32_t first, const int32_t n,
-                                Eval&& eval, Alive&& alive) {
-    if (n <= 0) return;
-    const int32_t last = n - 1;
-    auto ent = [&](int32_t k) { return *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(cl) + (uint32_t(first + STEP * min(k, last)) << 3)); };
-    auto rec_at = [&](int32_t g) { return *reinterpret_cast<const GaussRec*>(reinterpret_cast<const char*>(recs) + (uint32_t(g) << 6)); };
-    int2 eA = ent(0), eB = ent(1), nA = ent(2), nB = make_int2(0, 0);
-    GaussRec A = rec_at(eA.x), B = rec_at(eB.x);
-    for (int32_t k = 0; k < n; k += 2) {
-        if (!alive()) break;
-        eval(A, eA);
-        pin_record(B); // buffer B must have landed before buffer A is refilled
-        eA = nA;
-        A = rec_at(eA.x);
-        nB = ent(k + 3);
-        if (k + 1 >= n) break;
-        eval(B, eB);
-        pin_record(A); // buffer A must have landed before buffer B is refilled
-        eB = nB;
-        B = rec_at(eB.x);
-        nA = ent(k + 4);
-    }
-}
-
-typedef float v2 __attribute__((ext_vector_type(2)));
-struct f3x2 { v2 x, y, z; };
-LFS_DI v2 sp2(float s) { return v2{s, s}; } // an SGPR operand is broadcast by the instruction's op_sel bits: no code
-LFS_DI v2 fma2(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
-LFS_DI v2 fma3(v2 ax, v2 bx, v2 ay, v2 by, v2 az, v2 bz) { return fma2(az, bz, fma2(ay, by, ax * bx)); } // the scalar fma3's chain per component
-LFS_DI v2 sel2(bool c0, bool c1, v2 a, v2 b) { return v2{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
-
-// ray_eval for the lane's two rays: component k of every member is what ray_eval computes for pixel k, operation by operation
-struct RayEval2 { f3x2 om, w; v2 t, vis; };
-template <int MODE>
-LFS_DI void ray_eval2(const GaussRec& rec, const f3x2& ro, const f3x2& d, RayEval2& e) {
-    e.om = {sp2(0.f), sp2(0.f), sp2(0.f)};
-    f3x2 gro;
-    if (MODE != RAY_ROLLING) gro = {sp2(rec.r0.w), sp2(rec.r1.w), sp2(rec.r2.w)};
-    else {
-        e.om = {ro.x - sp2(rec.r0.w), ro.y - sp2(rec.r1.w), ro.z - sp2(rec.r2.w)};
-        gro = {fma3(sp2(rec.r0.x), e.om.x, sp2(rec.r0.y), e.om.y, sp2(rec.r0.z), e.om.z),
-               fma3(sp2(rec.r1.x), e.om.x, sp2(rec.r1.y), e.om.y, sp2(rec.r1.z), e.om.z),
-               fma3(sp2(rec.r2.x), e.om.x, sp2(rec.r2.y), e.om.y, sp2(rec.r2.z), e.om.z)};
-    }
-    const f3x2 q{fma3(sp2(rec.r0.x), d.x, sp2(rec.r0.y), d.y, sp2(rec.r0.z), d.z),
-                 fma3(sp2(rec.r1.x), d.x, sp2(rec.r1.y), d.y, sp2(rec.r1.z), d.z),
-                 fma3(sp2(rec.r2.x), d.x, sp2(rec.r2.y), d.y, sp2(rec.r2.z), d.z)};
-    const v2 l = fma3(q.x, q.x, q.y, q.y, q.z, q.z);
-    const v2 rl{l.x > 0.f ? fast_rcp(l.x) : 0.f, l.y > 0.f ? fast_rcp(l.y) : 0.f};
-    e.t = fma3(gro.x, q.x, gro.y, q.y, gro.z, q.z) * rl;
-    e.w = {fma2(-e.t, q.x, gro.x), fma2(-e.t, q.y, gro.y), fma2(-e.t, q.z, gro.z)};
-    const v2 a = sp2(-0.72134752044448170f) * fma3(e.w.x, e.w.x, e.w.y, e.w.y, e.w.z, e.w.z);
-    e.vis = v2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-}
-
-// the lane's two rays; ok[k] = pixel k has one
-template <int MODE>
-LFS_DI void lane_rays2(const CamDev& cam, const uint32_t j, const uint32_t i, f3x2& ro, f3x2& d, bool& ok0, bool& ok1) {
-    f3 o0, d0, o1, d1;
-    ok0 = lane_ray<MODE>(cam, j, i, o0, d0);
-    ok1 = lane_ray<MODE>(cam, j + 8, i, o1, d1);
-    ro = {v2{o0.x, o1.x}, v2{o0.y, o1.y}, v2{o0.z, o1.z}};
-    d = {v2{d0.x, d1.x}, v2{d0.y, d1.y}, v2{d0.z, d1.z}};
-}
-
-template <int CDIM, int MODE>
-__global__ void __launch_bounds__(256) raster_fwd_wide_kernel(
-    const uint32_t C, const uint32_t N, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
-    const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block,
-    const CamDev* __restrict__ cams, const GaussRec* __restrict__ recs, const float* __restrict__ colors,
-    const float* __restrict__ backgrounds, const uint8_t* __restrict__ masks,
-    const int32_t* __restrict__ offsets, const int32_t* __restrict__ cell_count, const int2* __restrict__ cell_list, const int32_t n_isects,
-    float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
-    const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
-    const CellCtx cc = cell_ctx_wide(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
-    if (!cc.in_grid) return;
-    const uint32_t cid = cc.cid;
-    const bool in0 = cc.i < H && cc.j < W, in1 = cc.i < H && cc.j + 8 < W;
-    const size_t pix0 = (size_t(cid) * H + cc.i) * W + cc.j, pix1 = pix0 + 8;
-    const float* bg = backgrounds ? backgrounds + cid * CDIM : nullptr;
-
-    if (masks != nullptr && !masks[cc.tile_global]) { // as the one-pixel kernel
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const size_t pix = p ? pix1 : pix0;
-            if (p ? in1 : in0) {
-#pragma unroll
-                for (int k = 0; k < CDIM; ++k) render_colors[pix * CDIM + k] = bg ? bg[k] : 0.f;
-                render_alphas[pix] = 0.f;
-                last_ids[pix] = 0;
-            }
-        }
-        return;
-    }
-
-    const CamDev& cam = cams[cid];
-    f3x2 ro, rd;
-    bool ok0, ok1;
-    lane_rays2<MODE>(cam, cc.j, cc.i, ro, rd, ok0, ok1);
-    const float INF = __builtin_inff();
-    v2 thr{(in0 && ok0) ? (1.f / 255.f) : INF, (in1 && ok1) ? (1.f / 255.f) : INF}; // see raster_fwd_kernel
-
-    const uint32_t wpt = cells_per_tile(tile_size, true);
-    const int32_t start = offsets[cc.tile_global];
-    const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
-    const int2* __restrict__ cl = cell_list + (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
-    const int32_t cnt = cell_count[size_t(cc.tile_global) * wpt + cc.wl];
-
-    v2 T = sp2(1.f);
-    v2 pix[CDIM];
-#pragma unroll
-    for (int k = 0; k < CDIM; ++k) pix[k] = sp2(0.f);
-    int32_t cur0 = 0, cur1 = 0;
-
-    auto eval = [&](const GaussRec& rec, const int2 e) {
-        RayEval2 re;
-        ray_eval2<MODE>(rec, ro, rd, re);
-        const v2 alpha = __builtin_elementwise_min(sp2(0.999f), sp2(rec.r3.x) * re.vis);
-        const bool pass0 = !(alpha.x < thr.x), pass1 = !(alpha.y < thr.y);
-        if (__ballot(pass0 || pass1) == 0ull) return;
-        const v2 next_T = T * (sp2(1.f) - alpha);
-        const bool fin0 = pass0 && next_T.x <= 1e-4f, fin1 = pass1 && next_T.y <= 1e-4f; // the terminating Gaussian is not composited
-        const bool con0 = pass0 && !fin0, con1 = pass1 && !fin1;
-        const v2 vis = alpha * T;
-        // a pixel that does not composite keeps its sums: select, not a multiplication by zero (inf / NaN colours stay where they belong)
-        if (CDIM <= 3) {
-            pix[0] = sel2(con0, con1, fma2(sp2(rec.r3.y), vis, pix[0]), pix[0]);
-            if (CDIM > 1) pix[1] = sel2(con0, con1, fma2(sp2(rec.r3.z), vis, pix[1]), pix[1]);
-            if (CDIM > 2) pix[2] = sel2(con0, con1, fma2(sp2(rec.r3.w), vis, pix[2]), pix[2]);
-        } else {
-            const float* cp = colors + size_t(e.x) * CDIM;
-#pragma unroll
-            for (int k = 0; k < CDIM; ++k) pix[k] = sel2(con0, con1, fma2(sp2(cp[k]), vis, pix[k]), pix[k]);
-        }
-        cur0 = con0 ? e.y : cur0; cur1 = con1 ? e.y : cur1;
-        T = sel2(con0, con1, next_T, T);
-        thr = sel2(fin0, fin1, sp2(INF), thr);
-    };
-    walk_cell_list_2buf<1>(cl, recs, 0, cnt, eval, [&]() { return __ballot(thr.x < INF || thr.y < INF) != 0ull; });
-
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const size_t pix_id = p ? pix1 : pix0;
-        if (p ? in1 : in0) {
-            const float Tp = p ? T.y : T.x;
-            render_alphas[pix_id] = 1.f - Tp;
-#pragma unroll
-            for (int k = 0; k < CDIM; ++k) { const float c = p ? pix[k].y : pix[k].x; render_colors[pix_id * CDIM + k] = bg ? c + Tp * bg[k] : c; }
-            last_ids[pix_id] = p ? cur1 : cur0;
-        }
-    }
-}
-
-template <int CDIM, int MODE, bool LOSS = false>
-__global__ void __launch_bounds__(256) raster_bwd_wide_kernel(
-    const uint32_t C, const uint32_t N, const uint32_t tw, const uint32_t th, const uint32_t W, const uint32_t H,
-    const uint32_t tile_size, const uint32_t blocks_per_tile, const uint32_t waves_per_block,
-    const CamDev* __restrict__ cams, const GaussRec* __restrict__ recs, const float* __restrict__ colors,
-    const float* __restrict__ backgrounds, const uint8_t* __restrict__ masks,
-    const int32_t* __restrict__ offsets, const int32_t* __restrict__ cell_count, const int2* __restrict__ cell_list, const int32_t n_isects,
-    const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
-    const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
-    float* __restrict__ acc, float* __restrict__ v_colors_extra, const MseFuse mse = MseFuse{}) {
-    const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
-    const CellCtx cc = cell_ctx_wide(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
-    if (!cc.in_grid) return;
-    const uint32_t cid = cc.cid;
-    if (masks != nullptr && !masks[cc.tile_global]) return; // masked tiles composited nothing
-    const uint32_t lane = threadIdx.x & 63;
-    const bool in0 = cc.i < H && cc.j < W, in1 = cc.i < H && cc.j + 8 < W;
-    const size_t pix0 = (size_t(cid) * H + cc.i) * W + cc.j, pix1 = pix0 + 8;
-    const float* bg = backgrounds ? backgrounds + cid * CDIM : nullptr;
-
-    const CamDev& cam = cams[cid];
-    f3x2 ro, rd;
-    bool ok0, ok1;
-    lane_rays2<MODE>(cam, cc.j, cc.i, ro, rd, ok0, ok1);
-    const bool act0 = in0 && ok0, act1 = in1 && ok1;
-
-    const uint32_t wpt = cells_per_tile(tile_size, true);
-    const int32_t start = offsets[cc.tile_global];
-    const int32_t end = (cc.tile_global == total_tiles - 1) ? n_isects : offsets[cc.tile_global + 1];
-    const int2* __restrict__ cl = cell_list + (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
-    const int32_t cnt = cell_count[size_t(cc.tile_global) * wpt + cc.wl];
-
-    v2 T_final = sp2(1.f), v_ra = sp2(0.f);
-    int32_t bin0 = -1, bin1 = -1; // see raster_bwd_kernel
-    v2 vc[CDIM], Bsum = sp2(0.f);
-#pragma unroll
-    for (int k = 0; k < CDIM; ++k) vc[k] = sp2(0.f);
-    if (act0) {
-        T_final.x = 1.f - render_alphas[pix0];
-        bin0 = last_ids[pix0];
-        v_ra.x = v_render_alphas ? v_render_alphas[pix0] : 0.f;
-        if (!LOSS) {
-#pragma unroll
-            for (int k = 0; k < CDIM; ++k) vc[k].x = v_render_colors[pix0 * CDIM + k];
-        }
-    }
-    if (act1) {
-        T_final.y = 1.f - render_alphas[pix1];
-        bin1 = last_ids[pix1];
-        v_ra.y = v_render_alphas ? v_render_alphas[pix1] : 0.f;
-        if (!LOSS) {
-#pragma unroll
-            for (int k = 0; k < CDIM; ++k) vc[k].y = v_render_colors[pix1 * CDIM + k];
-        }
-    }
-    if (LOSS) { // every pixel of the image belongs to exactly one (lane, half) of one wavefront
-        float lsum = 0.f;
-        const size_t P = size_t(H) * W;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const size_t pix_id = p ? pix1 : pix0;
-            if (p ? in1 : in0) {
-#pragma unroll
-                for (int k = 0; k < CDIM; ++k) {
-                    const float x = mse.render[pix_id * CDIM + k];
-                    const float d = fminf(fmaxf(x, 0.f), 1.f) - mse.target[size_t(k) * P + pix_id];
-                    lsum += d * d;
-                    const float g = (x >= 0.f && x <= 1.f) ? 2.f * d * mse.scale : 0.f;
-                    if (p ? act1 : act0) { if (p) vc[k].y = g; else vc[k].x = g; }
-                }
-            }
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) lsum += __shfl_xor(lsum, m, 64);
-        if (lane == 0 && lsum != 0.f) unsafeAtomicAdd(mse.loss + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (LOSS_SLOTS - 1)), lsum * mse.scale);
-    }
-    v2 T = T_final;
-    v2 tail = v_ra; // T_final * (v_alpha_out - bg . v_color_out)
-    if (bg) {
-        v2 bd = sp2(0.f);
-#pragma unroll
-        for (int k = 0; k < CDIM; ++k) bd += sp2(bg[k]) * vc[k];
-        tail -= bd;
-    }
-    tail *= T_final;
-
-    int32_t wmax = max(bin0, bin1);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) wmax = max(wmax, __shfl_xor(wmax, m, 64));
-    wmax = __builtin_amdgcn_readfirstlane(wmax);
-    int32_t lo = 0, hi = cnt;
-    while (lo < hi) {
-        const int32_t mid = (lo + hi) >> 1;
-        if (cl[mid].y <= wmax) lo = mid + 1; else hi = mid;
-    }
-    const int32_t n_walk = lo;
-    if (n_walk <= 0) return;
-
-    auto eval = [&](const GaussRec& rec, const int2 e) {
-        RayEval2 re;
-        ray_eval2<MODE>(rec, ro, rd, re);
-        const v2 vis = re.vis;
-        const float opac = rec.r3.x;
-        const v2 araw = sp2(opac) * vis;
-        const v2 alpha = __builtin_elementwise_min(sp2(0.999f), araw);
-        const bool val0 = e.y <= bin0 && !(alpha.x < (1.f / 255.f)), val1 = e.y <= bin1 && !(alpha.y < (1.f / 255.f));
-        if (__ballot(val0 || val1) == 0ull) return;
-
-        const v2 om_alpha = sp2(1.f) - alpha;
-        const v2 ra{fast_rcp(om_alpha.x), fast_rcp(om_alpha.y)};
-        const v2 Tn = T * ra;
-        T = sel2(val0, val1, Tn, T);
-        const v2 fac = sel2(val0, val1, alpha * Tn, sp2(0.f));
-        v2 cv;
-        float v_extra = 0.f;
-        if (CDIM <= 3) {
-            cv = sp2(rec.r3.y) * vc[0];
-            if (CDIM > 1) cv = fma2(sp2(rec.r3.z), vc[1], cv);
-            if (CDIM > 2) cv = fma2(sp2(rec.r3.w), vc[2], cv);
-        } else {
-            const float* cp = colors + size_t(e.x) * CDIM;
-            cv = sp2(cp[0]) * vc[0];
-#pragma unroll
-            for (int k = 1; k < CDIM; ++k) cv = fma2(sp2(cp[k]), vc[k], cv);
-        }
-        const v2 v_alpha = fma2(ra, tail - Bsum, Tn * cv);
-        Bsum = fma2(fac, cv, Bsum);
-        v2 v[16];
-#pragma unroll
-        for (int k = 0; k < CDIM; ++k) {
-            const v2 vrgb = fac * vc[k];
-            if (k < 3) v[13 + k] = vrgb; else v_extra = vrgb.x + vrgb.y;
-        }
-#pragma unroll
-        for (int k = CDIM; k < 3; ++k) v[13 + k] = sp2(0.f);
-        const v2 v_op = sel2(val0 && araw.x <= 0.999f, val1 && araw.y <= 0.999f, vis * v_alpha, sp2(0.f)); // dL/dopacity
-        v[12] = v_op;
-        const v2 sgeo = sp2(opac) * v_op;
-        const f3x2 a{re.w.x * sgeo, re.w.y * sgeo, re.w.z * sgeo};
-        const f3x2 vg{a.x * re.t, a.y * re.t, a.z * re.t};
-        v[0] = vg.x * rd.x; v[1] = vg.x * rd.y; v[2] = vg.x * rd.z;
-        v[3] = vg.y * rd.x; v[4] = vg.y * rd.y; v[5] = vg.y * rd.z;
-        v[6] = vg.z * rd.x; v[7] = vg.z * rd.y; v[8] = vg.z * rd.z;
-        if (MODE == RAY_ROLLING) {
-            const f3x2& om = re.om;
-            v[0] -= a.x * om.x; v[1] -= a.x * om.y; v[2] -= a.x * om.z;
-            v[3] -= a.y * om.x; v[4] -= a.y * om.y; v[5] -= a.y * om.z;
-            v[6] -= a.z * om.x; v[7] -= a.z * om.y; v[8] -= a.z * om.z;
-        }
-        v[9] = a.x; v[10] = a.y; v[11] = a.z;
-        float s[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s[k] = v[k].x + v[k].y; // the lane's two pixels first, then the 64 lanes
-        wave_sum16_atomic(s, acc + size_t(e.x) * ACC_STRIDE, lane);
-        if (CDIM > 3) {
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) v_extra += __shfl_xor(v_extra, m, 64);
-            if (lane == 0) unsafeAtomicAdd(v_colors_extra + size_t(e.x) * CDIM + 3, v_extra);
-        }
-    };
-    walk_cell_list_2buf<-1>(cl, recs, n_walk - 1, n_walk, eval, []() { return true; });
-}
-
-#include "lfs_raster_rows.cuh" // experimental quadrant-row kernels (opt-in)
-
-// ---------------------------------------------------------------------------
 // finish: accumulator -> dL/d(means, quats, scales, colors, opacities)
 // ---------------------------------------------------------------------------
 template <bool UNIFORM_ORIGIN>
@@ -1011,7 +640,8 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
     const uint32_t N, float* __restrict__ means, float* __restrict__ raw_scales, float* __restrict__ raw_quats, float* __restrict__ raw_opacities,
     const float* __restrict__ quats, const float* __restrict__ scales, const float* __restrict__ opacities,
     const CamDev* __restrict__ cams, const float* __restrict__ acc, const float* __restrict__ v_dirs, const FinishAdam ad, const FinishGrads gr,
-    const float* __restrict__ loss_slots, float* __restrict__ loss) {
+    const float* __restrict__ loss_slots, float* __restrict__ loss, const int32_t* __restrict__ abort_flag = nullptr) {
+    if (ADAM && abort_flag != nullptr && *abort_flag != 0) return; // (uniform) speculative step that did not fit its buffers: no update, the host runs it again
     if (loss_slots != nullptr && blockIdx.x == 0) { // *loss = the fused MSE (a store in a fixed order: the step needs no zeroed accumulator)
         __shared__ float wave_sum[4];
         float v = threadIdx.x < LOSS_SLOTS ? loss_slots[threadIdx.x] : 0.f;
@@ -1157,29 +787,23 @@ __global__ void __launch_bounds__(256) raster_det_resolve_kernel(const size_t n,
     acc[i] = out;
 }
 
-// "wide" = the experimental 16x8 cells with two pixels per lane (see the file header; opt-in). The workspace is always sized for the 8x8
-// geometry (ws_*: at least as many cells and list entries), so the choice never changes lfs_rasterize_workspace_bytes.
-struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid, wpt, ws_wpt; uint64_t cells, ws_cells; bool wide, rows, rows_merged; };
-static uint32_t g_debug_flags = 0; // bit 4: deterministic backward accumulation (two passes, 64-bit fixed point; 3 channels); bit 0: keep every tile-list entry in the cell lists (no culling); bit 1: the wide (two pixels per lane) kernels; bit 2: the quadrant-row kernels; bit 3: (with bit 2) quadrant lists straight from the tile lists
+// Launch geometry of cull / fwd / bwd: one wavefront per 8x8 cell, whole workgroups per tile.
+struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid, wpt; uint64_t cells; };
+static uint32_t g_debug_flags = 0; // bit 0: keep every tile-list entry in the cell lists (no culling: the bit-identity tests); bit 4: deterministic backward accumulation
+                                   // (two passes, 64-bit fixed point; 3 channels); bit 5: one-pass intersection scatter (intersect.hip). Bits 1-3 were the removed experiments.
 static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom& g) {
     if (tile_size < 8 || tile_size > 64 || (tile_size & 7)) return false;
     g.tw = (cams->image_width + tile_size - 1) / tile_size;
     g.th = (cams->image_height + tile_size - 1) / tile_size;
-    g.ws_wpt = (tile_size / 8) * (tile_size / 8);
-    g.wide = (tile_size & 15) == 0 && (g_debug_flags & 2u) != 0;
-    g.rows = !g.wide && (g_debug_flags & 4u) != 0;
-    g.rows_merged = g.rows && (g_debug_flags & 8u) != 0;
-    g.wpt = g.wide ? (tile_size / 16) * (tile_size / 8) : g.ws_wpt;
+    g.wpt = (tile_size / 8) * (tile_size / 8);
     g.waves_per_block = (g.wpt % 4 == 0) ? 4 : (g.wpt % 2 == 0) ? 2 : 1; // whole workgroups per tile (9, 25, 49 cells: one wave each)
     g.blocks_per_tile = g.wpt / g.waves_per_block;
     g.threads = g.waves_per_block * 64;
     const uint64_t nb = uint64_t(cams->C) * g.tw * g.th * g.blocks_per_tile;
     g.grid = uint32_t(((nb + 7) / 8) * 8);
     g.cells = uint64_t(cams->C) * g.tw * g.th * g.wpt;
-    g.ws_cells = uint64_t(cams->C) * g.tw * g.th * g.ws_wpt;
     return true;
 }
-
 
 } // namespace lfs
 
@@ -1195,7 +819,10 @@ extern "C" size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t
     cams.C = C; cams.image_width = image_width; cams.image_height = image_height;
     RasterGeom g;
     if (!raster_geom(&cams, tile_size, g) || n_isects < 0) return 0;
-    return raster_ws(nullptr, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), (g_debug_flags & 4u) != 0, (g_debug_flags & 16u) != 0).bytes;
+    return raster_ws(nullptr, C, N, g.cells, uint64_t(g.wpt) * uint64_t(n_isects), (g_debug_flags & 16u) != 0).bytes;
+}
+size_t lfs::raster_workspace_bytes_for(uint32_t N, uint32_t image_width, uint32_t image_height, uint32_t tile_size, int64_t capacity) {
+    return lfs_rasterize_workspace_bytes(1, N, 3, image_width, image_height, tile_size, capacity);
 }
 
 static int raster_mode(const lfs_cameras* cams) {
@@ -1212,16 +839,21 @@ static int raster_check(uint32_t N, uint32_t channels, const lfs_cameras* cams, 
     return LFS_OK;
 }
 
+// n_isects >= 0: the host knows the count (operator calls); the workspace holds lists for exactly that many intersections.
+// n_isects < 0 (guarded training step, lfs_step_internal.h): the count is on the device - tile_offsets has T + 1 entries, the kernels read the last one -
+// and the lists are sized for `capacity`.
+struct IsectCount { int64_t n_isects, capacity; int32_t arg() const { return n_isects >= 0 ? int32_t(n_isects) : -1; } int64_t sized() const { return n_isects >= 0 ? n_isects : capacity; } };
+
 // camera state, 64-byte records + culling records, compacted per-cell lists: everything fwd and bwd walk
 static void raster_prepare(const RasterWs& w, const RasterGeom& g, uint32_t N, uint32_t channels, const float* means, const float* quats,
                            const float* scales, const float* colors, const float* opacities, const uint8_t* masks,
                            const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
-                           int64_t n_isects, hipStream_t s, bool prepacked = false) {
+                           const IsectCount ic, hipStream_t s) {
     const uint32_t C = cams->C;
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
-    if (!prepacked) hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
+    hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
     const size_t CN = size_t(C) * N;
-    if (CN > 0 && !prepacked) {
+    if (CN > 0) {
         lfs::ProfScope prof_pack("raster_pack", s);
         const dim3 pg(uint32_t((CN + 255) / 256));
         if (uniform) hipLaunchKernelGGL(raster_pack_kernel<true>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs, w.cull);
@@ -1229,70 +861,46 @@ static void raster_prepare(const RasterWs& w, const RasterGeom& g, uint32_t N, u
     }
     lfs::ProfScope prof_cull("raster_cull", s);
     const uint32_t cull_on = (g_debug_flags & 1u) ? 0u : 1u;
-    if (g.rows_merged) { // quadrant lists in one pass: no cell lists
-        if (uniform) hipLaunchKernelGGL(raster_cull_quads_kernel<true>, dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, tile_size,
-                                        g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, flatten_ids, int32_t(n_isects), w.quad_count, w.quad_list);
-        else hipLaunchKernelGGL(raster_cull_quads_kernel<false>, dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, tile_size,
-                                g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, flatten_ids, int32_t(n_isects), w.quad_count, w.quad_list);
-        return;
-    }
-#define LFS_CULL(U, WD)                                                                                                                       \
-    hipLaunchKernelGGL((raster_cull_kernel<U, WD>), dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, \
-                       tile_size, g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, flatten_ids,              \
-                       int32_t(n_isects), w.cell_count, w.cell_list)
-    if (uniform) { if (g.wide) LFS_CULL(true, true); else LFS_CULL(true, false); }
-    else { if (g.wide) LFS_CULL(false, true); else LFS_CULL(false, false); }
+#define LFS_CULL(U)                                                                                                                     \
+    hipLaunchKernelGGL((raster_cull_kernel<U>), dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, \
+                       tile_size, g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, flatten_ids,        \
+                       ic.arg(), w.cell_count, w.cell_list)
+    if (uniform) LFS_CULL(true); else LFS_CULL(false);
 #undef LFS_CULL
-    if (g.rows) { // split the cell lists into quadrant lists
-        if (uniform) hipLaunchKernelGGL(raster_quad_lists_kernel<true>, dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, tile_size,
-                                        g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, int32_t(n_isects), w.cell_count, w.cell_list,
-                                        w.quad_count, w.quad_list);
-        else hipLaunchKernelGGL(raster_quad_lists_kernel<false>, dim3(g.grid), dim3(g.threads), 0, s, C, g.tw, g.th, cams->image_width, cams->image_height, tile_size,
-                                g.blocks_per_tile, g.waves_per_block, cull_on, w.cams, w.cull, masks, tile_offsets, int32_t(n_isects), w.cell_count, w.cell_list,
-                                w.quad_count, w.quad_list);
-    }
 }
 
 static int raster_fwd_impl(
     uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
     const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
     const lfs_cameras* cams, uint32_t tile_size,
-    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, const IsectCount ic,
     float* render_colors, float* render_alphas, int32_t* last_ids,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream, bool prepacked) {
+    void* workspace, size_t workspace_bytes, hipStream_t s) {
     RasterGeom g;
     int rc = raster_check(N, channels, cams, tile_size, g);
     if (rc) return rc;
     if (!render_colors || !render_alphas || !last_ids || !tile_offsets || !workspace) return LFS_E_INVALID;
-    if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
-    if (uint64_t(n_isects) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
+    const int64_t n_sized = ic.sized();
+    if (n_sized < 0 || n_sized > 0x7FFFFFFFll) return LFS_E_INVALID;
+    if (uint64_t(n_sized) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
     const uint32_t C = cams->C;
-    RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), g.rows, (g_debug_flags & 16u) != 0);
+    RasterWs w = raster_ws(workspace, C, N, g.cells, uint64_t(g.wpt) * uint64_t(n_sized), (g_debug_flags & 16u) != 0);
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N > 0 && (!means || !quats || !scales || !colors || !opacities)) return LFS_E_INVALID;
-    if (n_isects > 0 && !flatten_ids) return LFS_E_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects, s, prepacked);
+    if (n_sized > 0 && !flatten_ids) return LFS_E_INVALID;
+    raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s);
     lfs::ProfScope prof("raster_fwd", s);
-#define LFS_FWD_K(KERNEL, CD, MODE)                                                                              \
-    hipLaunchKernelGGL((KERNEL<CD, MODE>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,                   \
+#define LFS_FWD(CD, MODE)                                                                                        \
+    hipLaunchKernelGGL((raster_fwd_kernel<CD, MODE>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,       \
                        cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
-                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, int32_t(n_isects), \
+                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, ic.arg(), \
                        render_colors, render_alphas, last_ids)
-#define LFS_FWD_ROWS(CD, MODE)                                                                                    \
-    hipLaunchKernelGGL((raster_fwd_rows_kernel<CD, MODE>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,   \
-                       cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
-                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.quad_count, w.quad_list, int32_t(n_isects), \
-                       render_colors, render_alphas, last_ids)
-#define LFS_FWD(CD, MODE) do { if (g.rows) LFS_FWD_ROWS(CD, MODE); else if (g.wide) LFS_FWD_K(raster_fwd_wide_kernel, CD, MODE); else LFS_FWD_K(raster_fwd_kernel, CD, MODE); } while (0)
     switch (channels * 2 + raster_mode(cams)) {
     case 2: LFS_FWD(1, 0); break; case 3: LFS_FWD(1, 1); break;
     case 4: LFS_FWD(2, 0); break; case 5: LFS_FWD(2, 1); break;
     case 6: LFS_FWD(3, 0); break; case 7: LFS_FWD(3, 1); break;
     case 8: LFS_FWD(4, 0); break; default: LFS_FWD(4, 1); break;
     }
-#undef LFS_FWD_K
-#undef LFS_FWD_ROWS
 #undef LFS_FWD
     return (int)hipGetLastError();
 }
@@ -1305,69 +913,45 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
     float* render_colors, float* render_alphas, int32_t* last_ids,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
     (void)ut_params; // carried by the reference signature, unused by its rasterizer as well
-    return raster_fwd_impl(N, channels, means, quats, scales, colors, opacities, backgrounds, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects,
-                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, stream, false);
+    if (n_isects < 0) return LFS_E_INVALID;
+    return raster_fwd_impl(N, channels, means, quats, scales, colors, opacities, backgrounds, masks, cams, tile_size, tile_offsets, flatten_ids, IsectCount{n_isects, 0},
+                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-// Extension (fused training step): the camera state, the 64-byte records and the culling records are ALREADY in the workspace - lfs_gut_prepare_cameras
-// and lfs_sh_model_fwd_pack put them there (offsets: lfs_rasterize_workspace_offsets) - so only the cell lists are built before the forward kernel.
-extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd_prepacked(
-    uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
-    const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
-    const lfs_cameras* cams, uint32_t tile_size,
-    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
-    float* render_colors, float* render_alphas, int32_t* last_ids,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
-    if (!cams || cams->rs_type != LFS_SHUTTER_GLOBAL || cams->C != 1 || channels != 3) return LFS_E_UNSUPPORTED;
-    return raster_fwd_impl(N, channels, means, quats, scales, colors, opacities, backgrounds, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects,
-                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, stream, true);
-}
-
-// byte offsets of the camera state, the records, the accumulator rows and the culling records inside a rasterizer workspace, and the size of that
-// prefix: they do not depend on n_isects, so a workspace can be filled before the intersection count is known (and its prefix copied if it has to grow)
-extern "C" void lfs_rasterize_workspace_offsets(uint32_t C, uint32_t N, size_t* cams, size_t* recs, size_t* acc, size_t* cull, size_t* prefix_bytes) {
-    const RasterWs w = raster_ws(nullptr, C, N, 0, 0, false);
-    const char* z = nullptr;
-    if (cams) *cams = size_t(reinterpret_cast<const char*>(w.cams) - z);
-    if (recs) *recs = size_t(reinterpret_cast<const char*>(w.recs) - z);
-    if (acc) *acc = size_t(reinterpret_cast<const char*>(w.acc) - z);
-    if (cull) *cull = size_t(reinterpret_cast<const char*>(w.cull) - z);
-    if (prefix_bytes) *prefix_bytes = size_t(reinterpret_cast<const char*>(w.cell_count) - z);
-}
-
-extern "C" int lfs_gut_prepare_cameras(const lfs_cameras* cams, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
-    if (!cams || !cams->viewmats0 || !cams->Ks || cams->C == 0 || !workspace) return LFS_E_INVALID;
-    if (workspace_bytes < align256(sizeof(CamDev) * cams->C)) return LFS_E_WORKSPACE;
-    hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *cams, reinterpret_cast<CamDev*>(workspace));
-    return (int)hipGetLastError();
+int lfs::raster_fwd_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
+                            const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+                            int64_t capacity, float* render_colors, float* render_alphas, int32_t* last_ids, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    if (capacity < 0) return LFS_E_INVALID;
+    return raster_fwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, IsectCount{-1, capacity},
+                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, s);
 }
 
 static int raster_bwd_impl(
     uint32_t N, uint32_t channels, const float* means, const float* quats, const float* scales,
     const float* colors, const float* opacities, const float* backgrounds, const uint8_t* masks,
     const lfs_cameras* cams, uint32_t tile_size,
-    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t n_isects,
+    const int32_t* tile_offsets, const int32_t* flatten_ids, const IsectCount ic,
     const float* render_alphas, const int32_t* last_ids,
     const float* v_render_colors, const float* v_render_alphas,
     float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream, bool prepared, const MseFuse* mse = nullptr, bool finish = true) {
+    void* workspace, size_t workspace_bytes, hipStream_t s, bool prepared, const MseFuse* mse = nullptr, bool finish = true) {
     RasterGeom g;
     int rc = raster_check(N, channels, cams, tile_size, g);
     if (rc) return rc;
     if (!workspace || !tile_offsets) return LFS_E_INVALID;
     if (mse && (channels != 3 || cams->C != 1 || masks || v_render_alphas || !mse->render || !mse->target || !mse->loss)) return LFS_E_INVALID;
-    if (n_isects < 0 || n_isects > 0x7FFFFFFFll) return LFS_E_INVALID;
-    if (uint64_t(n_isects) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
+    const int64_t n_sized = ic.sized();
+    if (n_sized < 0 || n_sized > 0x7FFFFFFFll) return LFS_E_INVALID;
+    if (uint64_t(n_sized) >= (1ull << 29)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets inside one cell list
     const uint32_t C = cams->C;
-    const bool det = (g_debug_flags & 16u) != 0 && channels == 3 && !g.rows && !g.wide;
-    RasterWs w = raster_ws(workspace, C, N, g.ws_cells, uint64_t(g.ws_wpt) * uint64_t(n_isects), g.rows, (g_debug_flags & 16u) != 0);
+    const bool det = (g_debug_flags & 16u) != 0 && channels == 3;
+    RasterWs w = raster_ws(workspace, C, N, g.cells, uint64_t(g.wpt) * uint64_t(n_sized), (g_debug_flags & 16u) != 0);
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N == 0) return LFS_OK;
     if (!means || !quats || !scales || !colors || !opacities) return LFS_E_INVALID;
     if (finish && (!v_means || !v_quats || !v_scales || !v_colors || !v_opacities)) return LFS_E_INVALID;
     if (!finish && (channels != 3 || C != 1)) return LFS_E_INVALID; // the accumulator-only forms feed lfs_gut_finish_adam / lfs_gut_finish_grads (one camera, RGB)
-    if (n_isects > 0 && (!flatten_ids || !render_alphas || !last_ids || (!v_render_colors && !mse))) return LFS_E_INVALID; // v_render_alphas == NULL: zeros
-    hipStream_t s = (hipStream_t)stream;
+    if (n_sized > 0 && (!flatten_ids || !render_alphas || !last_ids || (!v_render_colors && !mse))) return LFS_E_INVALID; // v_render_alphas == NULL: zeros
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
     const size_t CN = size_t(C) * N;
     hipError_t e = hipMemsetAsync(w.acc, 0, sizeof(float) * (ACC_STRIDE * CN + (mse ? LOSS_SLOTS : 0)), s);
@@ -1378,40 +962,31 @@ static int raster_bwd_impl(
     if (channels > 3) { e = hipMemsetAsync(v_colors, 0, sizeof(float) * channels * CN, s); if (e != hipSuccess) return (int)e; }
     // self-contained call: camera state, records and cell lists are rebuilt; "prepared" = the caller guarantees
     // the workspace still holds what the forward call with the same inputs left there
-    if (!prepared) raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, n_isects, s);
-    if (n_isects > 0) {
+    if (!prepared) raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s);
+    if (n_sized > 0) {
         lfs::ProfScope prof("raster_bwd", s);
-#define LFS_BWD_K(KERNEL, CD, MODE, ...)                                                                         \
-    hipLaunchKernelGGL((KERNEL<CD, MODE, ##__VA_ARGS__>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,    \
+#define LFS_BWD_K(CD, MODE, ...)                                                                                 \
+    hipLaunchKernelGGL((raster_bwd_kernel<CD, MODE, ##__VA_ARGS__>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th, \
                        cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
-                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, int32_t(n_isects), \
+                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, ic.arg(), \
                        render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors, mse_dev)
-#define LFS_BWD_ROWS(CD, MODE, ...)                                                                              \
-    hipLaunchKernelGGL((raster_bwd_rows_kernel<CD, MODE, ##__VA_ARGS__>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th, \
-                       cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
-                       w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.quad_count, w.quad_list, int32_t(n_isects), \
-                       render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors, mse_dev)
-#define LFS_BWD(CD, MODE) do { if (g.rows) LFS_BWD_ROWS(CD, MODE); else if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, CD, MODE); else LFS_BWD_K(raster_bwd_kernel, CD, MODE); } while (0)
         if (det) { // pass 1: per-slot maxima of |total| (integer atomicMax), pass 2: 64-bit fixed-point sums, then back to float
-#define LFS_BWD_DET(MODE, LOSSV) do { LFS_BWD_K(raster_bwd_kernel, 3, MODE, LOSSV, 1); LFS_BWD_K(raster_bwd_kernel, 3, MODE, LOSSV, 2); } while (0)
+#define LFS_BWD_DET(MODE, LOSSV) do { LFS_BWD_K(3, MODE, LOSSV, 1); LFS_BWD_K(3, MODE, LOSSV, 2); } while (0)
             if (mse) { if (raster_mode(cams) == 0) LFS_BWD_DET(0, true); else LFS_BWD_DET(1, true); }
             else { if (raster_mode(cams) == 0) LFS_BWD_DET(0, false); else LFS_BWD_DET(1, false); }
 #undef LFS_BWD_DET
             const size_t n_acc = ACC_STRIDE * CN;
             hipLaunchKernelGGL(raster_det_resolve_kernel, dim3(uint32_t((n_acc + 255) / 256)), dim3(256), 0, s, n_acc, w.acc, w.det64);
         } else if (mse) {
-            if (raster_mode(cams) == 0) { if (g.rows) LFS_BWD_ROWS(3, 0, true); else if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, 3, 0, true); else LFS_BWD_K(raster_bwd_kernel, 3, 0, true); }
-            else { if (g.rows) LFS_BWD_ROWS(3, 1, true); else if (g.wide) LFS_BWD_K(raster_bwd_wide_kernel, 3, 1, true); else LFS_BWD_K(raster_bwd_kernel, 3, 1, true); }
+            if (raster_mode(cams) == 0) LFS_BWD_K(3, 0, true); else LFS_BWD_K(3, 1, true);
         } else
         switch (channels * 2 + raster_mode(cams)) {
-        case 2: LFS_BWD(1, 0); break; case 3: LFS_BWD(1, 1); break;
-        case 4: LFS_BWD(2, 0); break; case 5: LFS_BWD(2, 1); break;
-        case 6: LFS_BWD(3, 0); break; case 7: LFS_BWD(3, 1); break;
-        case 8: LFS_BWD(4, 0); break; default: LFS_BWD(4, 1); break;
+        case 2: LFS_BWD_K(1, 0); break; case 3: LFS_BWD_K(1, 1); break;
+        case 4: LFS_BWD_K(2, 0); break; case 5: LFS_BWD_K(2, 1); break;
+        case 6: LFS_BWD_K(3, 0); break; case 7: LFS_BWD_K(3, 1); break;
+        case 8: LFS_BWD_K(4, 0); break; default: LFS_BWD_K(4, 1); break;
         }
 #undef LFS_BWD_K
-#undef LFS_BWD_ROWS
-#undef LFS_BWD
     }
     if (!finish) return (int)hipGetLastError();
     const dim3 fg((N + 255) / 256);
@@ -1433,9 +1008,10 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd(
     float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
     (void)ut_params;
+    if (n_isects < 0) return LFS_E_INVALID;
     return raster_bwd_impl(N, channels, means, quats, scales, colors, opacities, backgrounds, masks, cams, tile_size, tile_offsets, flatten_ids,
-                           n_isects, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
-                           v_opacities, workspace, workspace_bytes, stream, false);
+                           IsectCount{n_isects, 0}, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
+                           v_opacities, workspace, workspace_bytes, (hipStream_t)stream, false);
 }
 
 extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared(
@@ -1448,9 +1024,10 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared(
     float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
     (void)ut_params;
+    if (n_isects < 0) return LFS_E_INVALID;
     return raster_bwd_impl(N, channels, means, quats, scales, colors, opacities, backgrounds, masks, cams, tile_size, tile_offsets, flatten_ids,
-                           n_isects, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
-                           v_opacities, workspace, workspace_bytes, stream, true);
+                           IsectCount{n_isects, 0}, render_alphas, last_ids, v_render_colors, v_render_alphas, v_means, v_quats, v_scales, v_colors,
+                           v_opacities, workspace, workspace_bytes, (hipStream_t)stream, true);
 }
 
 // "prepared" backward with the clamped MSE loss of lfs_mse_loss_fwd_bwd folded in (extension): render_colors [H,W,3] = the forward
@@ -1461,12 +1038,12 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse(
     int64_t n_isects, const float* render_colors, const float* render_alphas, const int32_t* last_ids, const float* target_chw, float weight,
     float* loss, float* v_means, float* v_quats, float* v_scales, float* v_colors, float* v_opacities, void* workspace, size_t workspace_bytes,
     lfs_stream_t stream) {
-    if (!cams || !render_colors || !target_chw || !loss) return LFS_E_INVALID;
+    if (!cams || !render_colors || !target_chw || !loss || n_isects < 0) return LFS_E_INVALID;
     const MseFuse mse{render_colors, target_chw, weight / float(3u * cams->image_width * cams->image_height), loss, nullptr};
     if (n_isects == 0) return LFS_E_UNSUPPORTED; // nothing rendered: use lfs_mse_loss_fwd_bwd (the loss of the background image)
-    return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, n_isects,
+    return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, IsectCount{n_isects, 0},
                            render_alphas, last_ids, nullptr, nullptr, v_means, v_quats, v_scales, v_colors, v_opacities, workspace, workspace_bytes,
-                           stream, true, &mse);
+                           (hipStream_t)stream, true, &mse);
 }
 
 
@@ -1475,8 +1052,19 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse(
 // lfs_rasterize_workspace_acc_offset) together with the loss partial sums; lfs_sh_model_bwd_adam_all reads dL/dcolour from the rows and writes
 // dL/d(dirs) into them, lfs_gut_finish_adam turns them into the parameter updates.
 extern "C" size_t lfs_rasterize_workspace_acc_offset(uint32_t C, uint32_t N) {
-    const RasterWs w = raster_ws(nullptr, C, N, 0, 0, false);
+    const RasterWs w = raster_ws(nullptr, C, N, 0, 0);
     return size_t(reinterpret_cast<const char*>(w.acc) - static_cast<const char*>(nullptr));
+}
+
+static int raster_bwd_mse_acc(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
+                              const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+                              const IsectCount ic, const float* render_colors, const float* render_alphas, const int32_t* last_ids, const float* target_chw,
+                              float weight, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    if (!cams || !render_colors || !target_chw) return LFS_E_INVALID;
+    float dummy_loss;
+    const MseFuse mse{render_colors, target_chw, weight / float(3u * cams->image_width * cams->image_height), &dummy_loss, nullptr}; // (.loss is redirected to the slots)
+    return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, ic,
+                           render_alphas, last_ids, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, s, true, &mse, false);
 }
 
 extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc(
@@ -1484,12 +1072,19 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc(
     const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
     int64_t n_isects, const float* render_colors, const float* render_alphas, const int32_t* last_ids, const float* target_chw, float weight,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
-    if (!cams || !render_colors || !target_chw) return LFS_E_INVALID;
-    float dummy_loss;
-    const MseFuse mse{render_colors, target_chw, weight / float(3u * cams->image_width * cams->image_height), &dummy_loss, nullptr}; // (.loss is redirected to the slots)
+    if (n_isects < 0) return LFS_E_INVALID;
     if (n_isects == 0) return LFS_E_UNSUPPORTED;
-    return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, n_isects,
-                           render_alphas, last_ids, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream, true, &mse, false);
+    return raster_bwd_mse_acc(N, means, quats, scales, colors, opacities, backgrounds, cams, tile_size, tile_offsets, flatten_ids, IsectCount{n_isects, 0}, render_colors,
+                              render_alphas, last_ids, target_chw, weight, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int lfs::raster_bwd_mse_acc_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
+                                    const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                    int64_t capacity, const float* render_colors, const float* render_alphas, const int32_t* last_ids, const float* target_chw,
+                                    float weight, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    if (capacity <= 0) return LFS_E_INVALID;
+    return raster_bwd_mse_acc(N, means, quats, scales, colors, opacities, backgrounds, cams, tile_size, tile_offsets, flatten_ids, IsectCount{-1, capacity}, render_colors,
+                              render_alphas, last_ids, target_chw, weight, workspace, workspace_bytes, s);
 }
 
 // the same for a caller-provided dL/d(render) (any loss): lfs_..._bwd_prepared without its last kernel
@@ -1498,10 +1093,19 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_acc(
     const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
     int64_t n_isects, const float* render_alphas, const int32_t* last_ids, const float* v_render_colors, const float* v_render_alphas,
     void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
-    if (!cams || !v_render_colors) return LFS_E_INVALID;
-    return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, n_isects,
-                           render_alphas, last_ids, v_render_colors, v_render_alphas, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream,
-                           true, nullptr, false);
+    if (!cams || !v_render_colors || n_isects < 0) return LFS_E_INVALID;
+    return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, IsectCount{n_isects, 0},
+                           render_alphas, last_ids, v_render_colors, v_render_alphas, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                           (hipStream_t)stream, true, nullptr, false);
+}
+
+int lfs::raster_bwd_acc_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
+                                const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                int64_t capacity, const float* render_alphas, const int32_t* last_ids, const float* v_render_colors, void* workspace,
+                                size_t workspace_bytes, hipStream_t s) {
+    if (!cams || !v_render_colors || capacity <= 0) return LFS_E_INVALID;
+    return raster_bwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, IsectCount{-1, capacity},
+                           render_alphas, last_ids, v_render_colors, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, s, true, nullptr, false);
 }
 
 // The accumulator rows -> gradient TENSORS of the raw parameters in one pass (raster_finish + lfs_activations_bwd + the copy of dL/dmeans): for steps
@@ -1513,7 +1117,7 @@ extern "C" int lfs_gut_finish_grads(
     void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
     if (N == 0) return LFS_OK;
     if (!means || !raw_quats || !quats || !scales || !opacities || !g_means || !g_raw_scales || !g_raw_quats || !g_raw_opacities || !v_colors || !workspace) return LFS_E_INVALID;
-    const RasterWs w = raster_ws(workspace, 1, N, 0, 0, false);
+    const RasterWs w = raster_ws(workspace, 1, N, 0, 0);
     if (workspace_bytes < size_t(reinterpret_cast<const char*>(w.cull) - static_cast<const char*>(workspace))) return LFS_E_WORKSPACE;
     FinishAdam ad{};
     // regularisers of trainer.cpp:132-158 (as lfs_activations_bwd): scale_reg * mean(scales) over 3N values, opacity_reg * mean(opacities)
@@ -1522,19 +1126,19 @@ extern "C" int lfs_gut_finish_grads(
     hipStream_t s = (hipStream_t)stream;
     lfs::ProfScope prof("finish_grads", s);
     hipLaunchKernelGGL(raster_finish_adam_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, s, N, const_cast<float*>(means), (float*)nullptr, const_cast<float*>(raw_quats),
-                       (float*)nullptr, quats, scales, opacities, w.cams, w.acc, (const float*)nullptr, ad, gr, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss);
+                       (float*)nullptr, quats, scales, opacities, w.cams, w.acc, (const float*)nullptr, ad, gr, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss, (const int32_t*)nullptr);
     return (int)hipGetLastError();
 }
 
 // scalars[k] = {lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp} for k = means, raw_scales, raw_quats, raw_opacities; *loss = the fused MSE of the backward (stored, not added)
-extern "C" int lfs_gut_finish_adam(
+int lfs::gut_finish_adam_impl(
     uint32_t N, float* means, float* raw_scales, float* raw_quats, float* raw_opacities, const float* quats, const float* scales, const float* opacities,
     const float* v_dirs, float* const* exp_avg /* [4] host */, float* const* exp_avg_sq /* [4] host */, const float* scalars /* [4][6] host */, float scale_reg,
-    float opacity_reg, float* loss, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    float opacity_reg, float* loss, void* workspace, size_t workspace_bytes, hipStream_t s, const int32_t* abort_flag) {
     if (N == 0) return LFS_OK;
     if (!v_dirs) return LFS_E_INVALID;
     if (!means || !raw_scales || !raw_quats || !raw_opacities || !quats || !scales || !opacities || !exp_avg || !exp_avg_sq || !scalars || !workspace) return LFS_E_INVALID;
-    const RasterWs w = raster_ws(workspace, 1, N, 0, 0, false);
+    const RasterWs w = raster_ws(workspace, 1, N, 0, 0);
     if (workspace_bytes < size_t(reinterpret_cast<const char*>(w.cull) - static_cast<const char*>(workspace))) return LFS_E_WORKSPACE;
     FinishAdam ad;
     for (int k = 0; k < 4; ++k) {
@@ -1544,9 +1148,16 @@ extern "C" int lfs_gut_finish_adam(
     }
     // regularisers of trainer.cpp:132-158 (as lfs_activations_bwd): scale_reg * mean(scales) over 3N values, opacity_reg * mean(opacities)
     ad.scale_reg = scale_reg / (3.f * float(N)); ad.opacity_reg = opacity_reg / float(N);
-    hipStream_t s = (hipStream_t)stream;
     lfs::ProfScope prof("finish_adam", s);
     hipLaunchKernelGGL(raster_finish_adam_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, s, N, means, raw_scales, raw_quats, raw_opacities, quats, scales, opacities,
-                       w.cams, w.acc, v_dirs, ad, FinishGrads{}, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss);
+                       w.cams, w.acc, v_dirs, ad, FinishGrads{}, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss, abort_flag);
     return (int)hipGetLastError();
+}
+
+extern "C" int lfs_gut_finish_adam(
+    uint32_t N, float* means, float* raw_scales, float* raw_quats, float* raw_opacities, const float* quats, const float* scales, const float* opacities,
+    const float* v_dirs, float* const* exp_avg /* [4] host */, float* const* exp_avg_sq /* [4] host */, const float* scalars /* [4][6] host */, float scale_reg,
+    float opacity_reg, float* loss, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    return lfs::gut_finish_adam_impl(N, means, raw_scales, raw_quats, raw_opacities, quats, scales, opacities, v_dirs, exp_avg, exp_avg_sq, scalars, scale_reg, opacity_reg,
+                                     loss, workspace, workspace_bytes, (hipStream_t)stream, nullptr);
 }

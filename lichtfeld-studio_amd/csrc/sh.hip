@@ -12,7 +12,7 @@
 #include "lfs_math.cuh"
 #include "lfs_prof.h"
 #include "lfs_adam.cuh"
-#include "lfs_raster_pack.cuh"
+#include "lfs_step_internal.h"
 #include "../../include/lfs_gsplat.h"
 
 namespace lfs {
@@ -136,6 +136,7 @@ struct ShArgs {
     uint32_t cs, vs;          // element stride of colors / v_colors rows (0 = 3)
     uint32_t ds;              // model bwd: element stride of the v_dirs rows (0 = 3)
     bool dirs_store;          // model bwd: v_dirs rows are WRITTEN (0 for invisible Gaussians) instead of added to
+    const int32_t* abort_flag; // (nullable) speculative training step: != 0 on the device -> the kernel must not touch the parameters (lfs_step_internal.h)
 };
 template <bool MODEL> LFS_DI bool sh_on(const ShArgs& a, uint32_t g) {
     if (MODEL) return a.mask_u32 ? a.mask_u32[g] != 0u : (a.radii[2 * g] > 0 && a.radii[2 * g + 1] > 0);
@@ -159,15 +160,9 @@ template <bool MODEL, class T> LFS_DI T* sh_coef(T* coeffs, T* sh0, T* shN, uint
 //   3. (bwd) lane = Gaussian : dL/d(dir) = sum_k s_k grad b_k, evaluated once per Gaussian.
 // The previous layout evaluated the polynomial in every one of the LPG lanes of a Gaussian and was VALU-bound
 // (rocprof: 8.1e7 VALU instructions = 0.13 ms of the 0.20 ms backward at 1M Gaussians, K = 16).
-// PACK (fused training step, model form, one global-shutter camera): the lane that owns a Gaussian in phase 1 also stages it for the world-space
-// rasterizer once its colour is known - the 64-byte record and the 32-byte culling record of raster_pack_kernel (lfs_raster_pack.cuh), written
-// straight into the rasterizer workspace. The pack kernel, its re-read of means / quats / scales / opacities / colours and one launch disappear.
-struct ShPack { const float* quats; const float* scales; const float* opacities; const CamDev* cam; GaussRec* recs; CullRec* cull; };
-
-template <int LPG, bool MODEL, bool PACK = false>
-__global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors, const ShPack pk = ShPack{}) {
+template <int LPG, bool MODEL>
+__global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors) {
     __shared__ float lds[64 * (LPG + 1)];
-    __shared__ float ldc[PACK ? 64 * 3 : 1];
     const uint32_t lane = threadIdx.x;
     const uint32_t g0 = blockIdx.x * 64u;
     const int degree = a.degree;
@@ -212,22 +207,6 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
             if (MODEL) { r0 = fmaxf(r0 + 0.5f, 0.f); r1 = fmaxf(r1 + 0.5f, 0.f); r2 = fmaxf(r2 + 0.5f, 0.f); }
             const size_t cs = (MODEL && a.cs) ? a.cs : 3;
             colors[cs * g] = r0; colors[cs * g + 1] = r1; colors[cs * g + 2] = r2;
-            if (PACK) { ldc[gl * 3] = r0; ldc[gl * 3 + 1] = r1; ldc[gl * 3 + 2] = r2; }
-        }
-    }
-    if (PACK) {
-        __syncthreads();
-        const uint32_t g = g0 + lane;
-        if (g < a.n && sh_on<MODEL>(a, g)) { // only Gaussians that reach a tile list are ever looked up
-            const f3 mu = ld3(a.means, g);
-            const float4 q = reinterpret_cast<const float4*>(pk.quats)[g];
-            const f3 s3 = ld3(pk.scales, g);
-            const float sc[3] = {s3.x, s3.y, s3.z};
-            GaussRec rec;
-            CullRec cr;
-            pack_gaussian<true>(*pk.cam, mu, q, sc, pk.opacities[g], ldc[lane * 3], ldc[lane * 3 + 1], ldc[lane * 3 + 2], rec, cr);
-            pk.recs[g] = rec;
-            pk.cull[g] = cr;
         }
     }
 }
@@ -247,6 +226,7 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
                                                     float* __restrict__ v_dirs, const ShAdam adam = ShAdam{}) {
     __shared__ float lds[64 * (LPG + 1)];
     __shared__ float ldv[64 * 3];
+    if (ADAM && a.abort_flag != nullptr && *a.abort_flag != 0) return; // (uniform) the step is being re-run with larger buffers: no update from this attempt
     const uint32_t lane = threadIdx.x;
     const uint32_t g0 = blockIdx.x * 64u;
     const int degree = a.degree;
@@ -351,18 +331,6 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
 }
 
 static inline int lanes_for(uint32_t k) { return k <= 1 ? 1 : k <= 4 ? 4 : k <= 16 ? 16 : 32; }
-
-static int sh_launch_fwd_pack(const ShArgs& a, uint32_t Kcover, float* colors, const ShPack& pk, hipStream_t s) {
-    const dim3 grid((a.n + 63) / 64), block(64);
-    lfs::ProfScope prof("sh_fwd_pack", s);
-    switch (lanes_for(Kcover)) {
-    case 1: hipLaunchKernelGGL((sh_fwd_kernel<1, true, true>), grid, block, 0, s, a, colors, pk); break;
-    case 4: hipLaunchKernelGGL((sh_fwd_kernel<4, true, true>), grid, block, 0, s, a, colors, pk); break;
-    case 16: hipLaunchKernelGGL((sh_fwd_kernel<16, true, true>), grid, block, 0, s, a, colors, pk); break;
-    default: hipLaunchKernelGGL((sh_fwd_kernel<32, true, true>), grid, block, 0, s, a, colors, pk); break;
-    }
-    return (int)hipGetLastError();
-}
 
 template <bool MODEL>
 static int sh_launch_fwd(const ShArgs& a, uint32_t Kcover, float* colors, hipStream_t s) {
@@ -620,29 +588,6 @@ extern "C" int lfs_sh_model_fwd(
     return lfs::sh_launch_fwd<true>(a, Kd, colors, (hipStream_t)stream);
 }
 
-#ifndef LFS_EMULATE // (the host build of tests/emul links sh.hip alone)
-// lfs_sh_model_fwd that also stages every visible Gaussian for the rasterizer (see ShPack): quats / scales / opacities are the ACTIVATED values,
-// `workspace` a rasterizer workspace whose camera state lfs_gut_prepare_cameras has filled (one camera, global shutter).
-extern "C" int lfs_sh_model_fwd_pack(
-    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
-    const int32_t* radii, const float* quats, const float* scales, const float* opacities, float* colors,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
-    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
-    if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
-    if (n == 0) return LFS_OK;
-    if (!means || !viewmat || !sh0 || (K > 1 && !shN) || !radii || !colors || !quats || !scales || !opacities || !workspace) return LFS_E_INVALID;
-    size_t o_cams, o_recs, o_cull, prefix;
-    lfs_rasterize_workspace_offsets(1, n, &o_cams, &o_recs, nullptr, &o_cull, &prefix);
-    if (workspace_bytes < prefix) return LFS_E_WORKSPACE;
-    lfs::ShArgs a{};
-    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii;
-    char* ws = static_cast<char*>(workspace);
-    const lfs::ShPack pk{quats, scales, opacities, reinterpret_cast<const lfs::CamDev*>(ws + o_cams), reinterpret_cast<lfs::GaussRec*>(ws + o_recs),
-                         reinterpret_cast<lfs::CullRec*>(ws + o_cull)};
-    return lfs::sh_launch_fwd_pack(a, Kd, colors, pk, (hipStream_t)stream);
-}
-#endif
-
 extern "C" int lfs_sh_model_bwd(
     uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
     const int32_t* radii, const float* colors, const float* v_colors, int accumulate,
@@ -675,11 +620,11 @@ extern "C" int lfs_sh_model_bwd_adam(
 // The all-inline training step (one view, one rank): dL/dcolour is read from the rasterizer's accumulator rows (acc_rows + 13, stride 16 floats),
 // dL/d(dirs) is WRITTEN to v_dirs [n,3] (raster_finish_adam_kernel adds it to the means gradient), and BOTH coefficient tensors
 // are updated in place by their Adam steps: no gradient tensor of the spherical harmonics exists.
-extern "C" int lfs_sh_model_bwd_adam_all(
+int lfs::sh_model_bwd_adam_all_impl(
     uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, float* sh0, float* shN,
     const int32_t* radii, const float* colors, const float* acc_rows, float* v_dirs,
     float* sh0_exp_avg, float* sh0_exp_avg_sq, const float* sh0_scalars /* lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp */,
-    float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, lfs_stream_t stream) {
+    float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, hipStream_t stream, const int32_t* abort_flag) {
     const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
     if (degrees_to_use > 4 || Kd > K || K > 32 || K < 2) return LFS_E_INVALID;
     if (n == 0) return LFS_OK;
@@ -687,11 +632,21 @@ extern "C" int lfs_sh_model_bwd_adam_all(
         !shN_exp_avg_sq || !shN_scalars) return LFS_E_INVALID;
     lfs::ShArgs a{};
     a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
+    a.abort_flag = abort_flag;
     a.vs = 16; a.dirs_store = true; // dL/dcolour: slots 13..15 of the 16-float rows; dL/d(dirs): its own contiguous [n,3] (partial-row writes into the rows cost more than they save)
     lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{shN_scalars[0], shN_scalars[1], shN_scalars[2], shN_scalars[3], shN_scalars[4], shN_scalars[5]}};
     adam.m0 = sh0_exp_avg; adam.v0 = sh0_exp_avg_sq;
     adam.s0 = lfs::AdamScalars{sh0_scalars[0], sh0_scalars[1], sh0_scalars[2], sh0_scalars[3], sh0_scalars[4], sh0_scalars[5]};
-    return lfs::sh_launch_bwd_adam(a, acc_rows + 13, nullptr, v_dirs, adam, (hipStream_t)stream);
+    return lfs::sh_launch_bwd_adam(a, acc_rows + 13, nullptr, v_dirs, adam, stream);
+}
+
+extern "C" int lfs_sh_model_bwd_adam_all(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, float* sh0, float* shN,
+    const int32_t* radii, const float* colors, const float* acc_rows, float* v_dirs,
+    float* sh0_exp_avg, float* sh0_exp_avg_sq, const float* sh0_scalars /* lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp */,
+    float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, lfs_stream_t stream) {
+    return lfs::sh_model_bwd_adam_all_impl(n, K, degrees_to_use, means, viewmat, sh0, shN, radii, colors, acc_rows, v_dirs, sh0_exp_avg, sh0_exp_avg_sq, sh0_scalars,
+                                           shN_exp_avg, shN_exp_avg_sq, shN_scalars, (hipStream_t)stream, nullptr);
 }
 
 static bool sh_views_ok(uint32_t n, uint32_t K, uint32_t degree, uint32_t V, uint32_t stride) {

@@ -69,38 +69,7 @@ def sh_model_bwd_adam(sh_degree: int, means, viewmat, sh0, shN, radii, colors, v
                                                C.c_float(adam["bc1_rcp"]), C.c_float(adam["bc2_sqrt_rcp"]), stream()), "sh_model_bwd_adam")
 
 
-# ---- the front half of the fused step: activations + projection in one kernel, SH colours + rasterizer records in one kernel --------------------
-_FRONT_WS: dict = {}   # device index -> (workspace tensor, last n_isects): filled BEFORE the intersection count is known, so it is sized from the last step
-
-
-def front_workspace(N: int, W: int, H: int, tile: int, dev) -> torch.Tensor:
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    ws, last = _FRONT_WS.get(key, (None, 0))
-    need = load_library().lfs_rasterize_workspace_bytes(C.c_uint32(1), C.c_uint32(N), C.c_uint32(3), C.c_uint32(W), C.c_uint32(H), C.c_uint32(tile),
-                                                        C.c_int64(max(int(last * 1.25), 1 << 20)))
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
-        _FRONT_WS[key] = (ws, last)
-    return ws
-
-
-def front_workspace_fit(ws: torch.Tensor, N: int, W: int, H: int, tile: int, n_isects: int) -> torch.Tensor:
-    """the workspace for the real n_isects: the same tensor, or a larger one that received the records already written (they live in a prefix whose
-    layout does not depend on n_isects)"""
-    lib = load_library()
-    dev = ws.device
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    need = lib.lfs_rasterize_workspace_bytes(C.c_uint32(1), C.c_uint32(N), C.c_uint32(3), C.c_uint32(W), C.c_uint32(H), C.c_uint32(tile), C.c_int64(n_isects))
-    if need > ws.numel():
-        prefix = C.c_size_t(0)
-        lib.lfs_rasterize_workspace_offsets(C.c_uint32(1), C.c_uint32(N), None, None, None, None, C.byref(prefix))
-        new = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
-        new[:prefix.value].copy_(ws[:prefix.value])
-        ws = new
-    _FRONT_WS[key] = (ws, n_isects)
-    return ws
-
-
+# ---- the front half of the fused step: activations + projection in one kernel -------------------------------------------------------------------
 def activations_project(means, raw_quats, raw_scales, raw_opacities, viewmat, Kmat, W: int, H: int, ut, camera_model=CameraModelType.PINHOLE, radii_out=None):
     """activations_fwd + ops.projection_ut_3dgs_fused (trainer constants of rasterizer.cpp:176-181) in one kernel -> (quats, scales, opacities, radii, means2d, depths)"""
     require_gpu(means, raw_quats, raw_scales, raw_opacities, viewmat, Kmat)
@@ -118,35 +87,7 @@ def activations_project(means, raw_quats, raw_scales, raw_opacities, viewmat, Km
     return quats, scales, opac, radii, means2d, depths
 
 
-def sh_model_fwd_pack(sh_degree: int, means, viewmat, sh0, shN, radii, quats, scales, opac, ws):
-    """sh_model_fwd that also writes the rasterizer's records / culling records of the visible Gaussians into the workspace `ws`"""
-    N, K = means.shape[0], 1 + shN.shape[1]
-    colors = torch.empty((N, 3), dtype=means.dtype, device=means.device)
-    check(load_library().lfs_sh_model_fwd_pack(C.c_uint32(N), C.c_uint32(K), C.c_uint32(sh_degree), ptr(means), ptr(viewmat), ptr(sh0), ptr(shN), ptr(radii), ptr(quats),
-                                               ptr(scales), ptr(opac), ptr(colors), ptr(ws), C.c_size_t(ws.numel()), stream()), "sh_model_fwd_pack")
-    return colors
-
-
-def rasterize_fwd_prepacked(means, quats, scales, colors, opac, bg, W: int, H: int, tile: int, viewmat, Kmat, offsets, flatten_ids, ws):
-    N, dev = means.shape[0], means.device
-    renders = torch.empty((1, H, W, 3), dtype=means.dtype, device=dev)
-    alphas = torch.empty((1, H, W, 1), dtype=means.dtype, device=dev)
-    last_ids = torch.empty((1, H, W), dtype=torch.int32, device=dev)
-    cams = cameras_struct(viewmat, None, Kmat, W, H, CameraModelType.PINHOLE, ShutterType.GLOBAL, None, None, None)
-    check(load_library().lfs_rasterize_to_pixels_from_world_3dgs_fwd_prepacked(
-        C.c_uint32(N), C.c_uint32(3), ptr(means), ptr(quats), ptr(scales), ptr(colors), ptr(opac), ptr(bg), None, C.byref(cams), C.c_uint32(tile),
-        ptr(offsets), ptr(flatten_ids), C.c_int64(flatten_ids.shape[0]), ptr(renders), ptr(alphas), ptr(last_ids), ptr(ws), C.c_size_t(ws.numel()), stream()),
-        "rasterize_fwd_prepacked")
-    return renders, alphas, last_ids
-
-
 FUSE_ACT_PROJ = True   # activations + projection in one kernel (bit-identical outputs; saves one launch and the re-read of the activated values)
-# SH colours + rasterizer records in one kernel. Measured on MI355X (SYN-B, same-box A/B, profiles/r02/fuse_front_ab.txt): sh_fwd_pack 0.098 ms against
-# sh_fwd 0.067 + raster_pack 0.043, but raster_cull + raster_fwd lose 0.012 ms - the separate pack kernel runs right before them and leaves the records
-# hot in L2 / Infinity Cache, the fused one writes them a sort and a host round trip earlier - and the step time does not move (1.707 vs 1.702 ms).
-# Off by default; kept, tested (tests/test_gpu_fused.py), as the measured answer to "fuse raster_pack into the streaming pass before it".
-FUSE_SH_PACK = False
-
 
 def _adam_scalars(a: dict):
     return (C.c_float * 6)(a["lr"], a["beta1"], a["beta2"], a["eps"], a["bc1_rcp"], a["bc2_sqrt_rcp"])
@@ -254,22 +195,9 @@ def mse_loss_fwd_bwd(render_hwc, target_chw, weight: float, loss_acc):
 
 FUSE_MSE_INTO_BACKWARD = True   # False: separate lfs_mse_loss_fwd_bwd launch (tests compare the two)
 OVERLAP_SH_EXCHANGE = True       # SH-sharded: the radii / colour all-to-alls run next to the intersection kernels (False: blocking, A/B and debugging)
-SIDE_STREAM_SH = False           # True: SH colours on a second stream next to the intersection kernels. Measured (bench.py --side-stream, same box, 3 pairs):
-                                 # 1.680 - 1.707 ms against 1.690 - 1.694 ms on one stream - no gain, the two sets of kernels do not overlap usefully
 FUSE_FINISH_GRADS = True         # accumulator rows -> raw-parameter gradient tensors in one pass (False: raster_finish + activations_bwd + copy; tests compare)
 BEGIN_ALL_INTERSECTIONS = True   # multi-view steps: the count kernels of all views up front, one host wait per step (False: one per view)
 OVERLAP_SH_WITH_READBACK = True  # False: SH colours first, then the blocking n_isects read-back (A/B timing)
-
-
-_SIDE = {}
-
-
-def _side_stream(device) -> "torch.cuda.Stream":
-    st = _SIDE.get(device.index)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _SIDE[device.index] = st
-    return st
 
 
 @dataclass
@@ -315,16 +243,11 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
     tw, th = (W + tile - 1) // tile, (H + tile - 1) // tile
     with torch.no_grad():
         bg = None if bg_color is None else bg_color.view(1, -1).contiguous()
-        front = FUSE_SH_PACK and sh_exchange is None and given is None   # (SH-sharded: the colours come back from the owners, the pack kernel stays separate)
-        if front:
-            ws = front_workspace(means.shape[0], W, H, tile, means.device)
-            cams_c = cameras_struct(viewmat, None, Kmat, W, H, CameraModelType.PINHOLE, ShutterType.GLOBAL, None, None, None)
-            check(load_library().lfs_gut_prepare_cameras(C.byref(cams_c), ptr(ws), C.c_size_t(ws.numel()), stream()), "gut_prepare_cameras")
         isect_state = None
         if given is not None:
             quats, scales, opac, radii, means2d, depths, given_colors = given[:7]
             isect_state = given[7] if len(given) > 7 else None      # ops.intersect_tile_begin of this view, issued by the caller
-        elif front or FUSE_ACT_PROJ:
+        elif FUSE_ACT_PROJ:
             quats, scales, opac, radii, means2d, depths = activations_project(means, raw_quats, raw_scales, raw_opac, viewmat, Kmat, W, H, ut)
         else:
             quats, scales, opac = activations_fwd(raw_quats, raw_scales, raw_opac)
@@ -338,28 +261,12 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         def sh_stage():
             if given is not None:
                 return given_colors, None
-            if front:
-                return sh_model_fwd_pack(deg, means, viewmat, sh0, shN, radii, quats, scales, opac, ws), None
             if sh_exchange is None:
                 return sh_model_fwd(deg, means, viewmat, sh0, shN, radii), None
             return sh_exchange.forward(deg, means, sh0, shN, radii[0], viewmats_all, sh_model_fwd_views, radii_pending=radii_pending, defer=OVERLAP_SH_EXCHANGE)
-        side_done = None
         if isect_state is not None:
             (colors, sh_ctx) = sh_stage()
             _, _, flatten_ids, offsets = ops.intersect_tile_finish(isect_state)
-        elif SIDE_STREAM_SH and sh_exchange is None and given is None and means.is_cuda:
-            # the SH colours (HBM-bound) on a second stream, next to the intersection kernels (latency / LDS-bound) of this one: they need the
-            # projection's radii only, and nothing before the rasterizer's pack kernel needs them
-            side = _side_stream(means.device)
-            ready = torch.cuda.Event()
-            ready.record()
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                colors, sh_ctx = sh_stage()
-                side_done = torch.cuda.Event()
-                side_done.record()
-            _, _, flatten_ids, offsets = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True, overlap=lambda: None)[:4]
-            torch.cuda.current_stream().wait_event(side_done)
         elif OVERLAP_SH_WITH_READBACK:
             _, _, flatten_ids, offsets, (colors, sh_ctx) = ops.intersect_tile(means2d, radii, depths, None, None, 1, tile, tw, th, True, return_offsets=True,
                                                                                overlap=sh_stage)
@@ -370,12 +277,7 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
             sh_exchange.finish_forward(sh_ctx)
         fwd_args = (means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, None, W, H, tile, viewmat, None, Kmat,
                     CameraModelType.PINHOLE, ut, ShutterType.GLOBAL, None, None, None, offsets, flatten_ids)
-        if front:
-            ws = front_workspace_fit(ws, means.shape[0], W, H, tile, int(flatten_ids.shape[0]))
-            render, alpha, last_ids = rasterize_fwd_prepacked(means, quats, scales, colors.unsqueeze(0), opac.unsqueeze(0), bg, W, H, tile, viewmat, Kmat, offsets,
-                                                              flatten_ids, ws)
-        else:
-            render, alpha, last_ids, ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(*fwd_args, own_workspace=True)
+        render, alpha, last_ids, ws = ops.rasterize_to_pixels_from_world_3dgs_fwd(*fwd_args, own_workspace=True)
         fuse_mse = loss == "mse" and FUSE_MSE_INTO_BACKWARD and flatten_ids.shape[0] > 0 and bilateral is None
         if bilateral is not None:    # clamp (rasterizer.cpp:399 / bilateral_grid.cpp:115) -> slice -> loss on the un-clamped result -> slice backward
             from .losses import loss_fwd_bwd
@@ -441,6 +343,15 @@ def render_and_backward(camera: Camera, model: SplatModel, bg_color: Optional[to
         if sh_exchange is not None:  # owners: SH backward of every rank's view for their rows (dL/d(dirs) straight into g_means)
             sh_exchange.backward(sh_ctx, deg, means, sh0, shN, viewmats_all, v_colors.squeeze(0), g_sh0, g_shN, g_means, accumulate, sh_model_bwd_views,
                                  adam=adam_shard)
+        if adam_fallback is not None:
+            # the all-inline step saw a view without a single intersection: the separate kernels above wrote the (regulariser-only) gradients, and the Adam
+            # updates FusedAdam.prepare_inline() promised - step counts are already advanced, optimizer.step() will skip all six - are applied here with
+            # the prepared scalars: moments decay and the momentum moves the parameters, as in the reference's FusedAdam::step on such a step
+            names = ("means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities")
+            params6 = (means, sh0, shN, raw_scales, raw_quats, raw_opac)
+            ops.adam_step_multi([(p_, adam_fallback[n_]["exp_avg"], adam_fallback[n_]["exp_avg_sq"], g_.contiguous(), adam_fallback[n_]["lr"], adam_fallback[n_]["beta1"],
+                                  adam_fallback[n_]["beta2"], adam_fallback[n_]["eps"], adam_fallback[n_]["bc1_rcp"], adam_fallback[n_]["bc2_sqrt_rcp"])
+                                 for n_, p_, g_ in zip(names, params6, grads) if p_.numel()])
     return FusedStepOutput(render, alpha, radii, int(flatten_ids.shape[0]))
 
 

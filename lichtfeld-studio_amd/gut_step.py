@@ -1,0 +1,177 @@
+"""Host side of csrc/gut_step.hip: the --gut training step as ONE C call (lfs_gut_train_step) and its split form for gradient tensors
+(lfs_gut_view_forward / lfs_gut_view_backward). Mirrors what Trainer::train_step does around rasterize() on the --gut path
+(/root/reference/src/training/trainer.cpp:579-770, rasterization/rasterizer.cpp:200-344) - minus the host synchronisation of
+gsplat/Intersect.cpp:75-76: the intersection lists live in a workspace sized for a CAPACITY, the count stays on the device, and this class
+looks at the (pinned) counts only after the whole step has been enqueued. An attempt that did not fit (count above capacity, or a tile list longer
+than the sort classes launched) updated nothing - the kernels check a device flag - and is simply run again with a larger workspace.
+
+torch is the allocator here (one uint8 tensor per workspace, one pinned int64[3] for the counts) and owns the stream; nothing else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .capi import LfsError, check, load_library, stream
+
+GROUPS = ("means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities")   # FusedAdam group order (strategy_utils.cpp:35-40)
+
+
+class StepArgs(C.Structure):  # lfs_gut_step_args
+    _fields_ = [("N", C.c_uint32), ("K", C.c_uint32), ("sh_degree", C.c_uint32), ("image_width", C.c_uint32), ("image_height", C.c_uint32), ("tile_size", C.c_uint32),
+                ("means", C.c_void_p), ("sh0", C.c_void_p), ("shN", C.c_void_p), ("raw_scales", C.c_void_p), ("raw_quats", C.c_void_p), ("raw_opacities", C.c_void_p),
+                ("exp_avg", C.c_void_p * 6), ("exp_avg_sq", C.c_void_p * 6), ("adam", (C.c_float * 6) * 6),
+                ("viewmat", C.c_void_p), ("Kmat", C.c_void_p), ("background", C.c_void_p), ("target_chw", C.c_void_p),
+                ("loss_weight", C.c_float), ("scale_reg", C.c_float), ("opacity_reg", C.c_float), ("loss", C.c_void_p)]
+
+
+class StepLayout(C.Structure):  # lfs_gut_step_layout
+    _fields_ = [(k, C.c_size_t) for k in ("bytes", "render", "alpha", "last_ids", "radii", "means2d", "depths", "colors", "quats", "scales", "opacities",
+                                          "tile_offsets", "flatten_ids", "isect_ids", "counts", "abort_flag")]
+
+
+class GutStep:
+    """One workspace + the capacity bookkeeping for steps of one (N, W, H, tile) shape on one device."""
+
+    def __init__(self, device, tile: int = 16, initial_capacity: Optional[int] = None, margin: float = 1.25):
+        self.device = torch.device(device)
+        self.tile = tile
+        self.margin = margin
+        self.capacity = int(initial_capacity) if initial_capacity else 0
+        self.assumed_longest = 1024
+        self.ws: Optional[torch.Tensor] = None
+        self.layout: Optional[StepLayout] = None
+        self.shape = None
+        self.counts = torch.zeros(3, dtype=torch.int64).pin_memory()
+        self._stamp = 0
+        self.n_isects = 0
+        self.longest = 0
+        self.retries = 0          # attempts that did not fit (each one is re-run): a few right after start-up or a densification, none in steady state
+
+    # ---- workspace --------------------------------------------------------------------------------------------------------------------------
+    def _ensure(self, N: int, W: int, H: int) -> None:
+        lib = load_library()
+        if self.capacity <= 0:
+            self.capacity = max(4 * N, 1 << 16)       # first guess: ~4 tile entries per Gaussian (SYN-B: 4.4); the first step corrects it
+        shape = (N, W, H, self.capacity, int(lib.lfs_get_debug_flags()))   # (debug bit 4, the deterministic backward, adds a 64-bit accumulator to the workspace)
+        if self.shape == shape and self.ws is not None:
+            return
+        lay = StepLayout()
+        check(lib.lfs_gut_step_layout_for(C.c_uint32(N), C.c_uint32(W), C.c_uint32(H), C.c_uint32(self.tile), C.c_int64(self.capacity), C.byref(lay)), "gut_step_layout_for")
+        if self.ws is None or self.ws.numel() < lay.bytes:
+            self.ws = None                            # (release the old block before the larger one is requested)
+            self.ws = torch.empty(int(lay.bytes), dtype=torch.uint8, device=self.device)
+        self.layout, self.shape = lay, shape
+
+    def _grow(self, n_isects: int, longest: int) -> None:
+        self.capacity = max(int(n_isects * self.margin) + 1024, self.capacity)
+        self.assumed_longest = max(int(longest * self.margin), self.assumed_longest)
+        self.shape = None
+
+    def view(self, name: str, dtype, shape: Sequence[int]) -> torch.Tensor:
+        """A tensor view of one workspace region (render [H,W,3] f32, alpha [H,W] f32, radii [N,2] i32, ...): valid until the next step."""
+        off = getattr(self.layout, name)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        return self.ws[off:off + nbytes].view(dtype).view(*shape)
+
+    # ---- argument block -----------------------------------------------------------------------------------------------------------------------
+    def _args(self, params: Sequence[torch.Tensor], sh_degree: int, W: int, H: int, viewmat: torch.Tensor, Kmat: torch.Tensor, bg: Optional[torch.Tensor],
+              target_chw: Optional[torch.Tensor], weight: float, scale_reg: float, opacity_reg: float, loss_acc: Optional[torch.Tensor],
+              adam: Optional[Dict[str, dict]]) -> StepArgs:
+        means, sh0, shN, raw_scales, raw_quats, raw_opac = params
+        for t in (*params, viewmat, Kmat, bg, target_chw, loss_acc):
+            if t is not None and (not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32):
+                raise LfsError("gut_step: every tensor must be a contiguous float32 CUDA (HIP) tensor")
+        a = StepArgs()
+        a.N, a.K, a.sh_degree = means.shape[0], 1 + shN.shape[1], sh_degree
+        a.image_width, a.image_height, a.tile_size = W, H, self.tile
+        a.means, a.sh0, a.shN = means.data_ptr(), sh0.data_ptr(), (shN.data_ptr() if shN.numel() else None)
+        a.raw_scales, a.raw_quats, a.raw_opacities = raw_scales.data_ptr(), raw_quats.data_ptr(), raw_opac.data_ptr()
+        if adam is not None:
+            for k, name in enumerate(GROUPS):
+                d = adam[name]
+                a.exp_avg[k], a.exp_avg_sq[k] = d["exp_avg"].data_ptr(), d["exp_avg_sq"].data_ptr()
+                for j, key in enumerate(("lr", "beta1", "beta2", "eps", "bc1_rcp", "bc2_sqrt_rcp")):
+                    a.adam[k][j] = d[key]
+        a.viewmat, a.Kmat = viewmat.data_ptr(), Kmat.data_ptr()
+        a.background = bg.data_ptr() if bg is not None else None
+        a.target_chw = target_chw.data_ptr() if target_chw is not None else None
+        a.loss_weight, a.scale_reg, a.opacity_reg = weight, scale_reg, opacity_reg
+        a.loss = loss_acc.data_ptr() if loss_acc is not None else None
+        return a
+
+    def _wait(self) -> bool:
+        """-> did the attempt fit? (the counts were written by the scan kernel long before the host got here)"""
+        lib = load_library()
+        n, lg = C.c_int64(0), C.c_int64(0)
+        rc = lib.lfs_gut_step_wait(C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), C.c_double(30.0), C.byref(n), C.byref(lg))
+        if rc != 0:
+            raise LfsError("gut_step: the intersection counts of this step never arrived in pinned host memory")
+        self.n_isects, self.longest = int(n.value), int(lg.value)
+        return bool(lib.lfs_gut_step_fits(n, lg, C.c_int64(self.capacity), C.c_int64(self.assumed_longest)))
+
+    def _after_fit(self) -> None:
+        # stay ahead of a slowly growing scene: enlarge BEFORE the next step would overflow (a re-run costs a whole step, a reallocation nothing)
+        if self.n_isects > 0.92 * self.capacity or self.longest > 0.92 * self._class_limit():
+            self._grow(self.n_isects, self.longest)
+
+    def _class_limit(self) -> int:
+        a = self.assumed_longest
+        return 1024 if a <= 1024 else 4096 if a <= 4096 else 16384 if a <= 16384 else 1 << 62
+
+    # ---- the step -------------------------------------------------------------------------------------------------------------------------------
+    def train_step(self, params: Sequence[torch.Tensor], adam: Dict[str, dict], sh_degree: int, W: int, H: int, viewmat: torch.Tensor, Kmat: torch.Tensor,
+                   bg: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float, loss_acc: torch.Tensor, scale_reg: float = 0.0,
+                   opacity_reg: float = 0.0) -> int:
+        """Forward + backward + Adam on all six parameter tensors, in place; *loss_acc = weight * mse. `adam[name]` = FusedAdam.prepare_inline(param) for
+        the six names of GROUPS. Returns n_isects."""
+        lib = load_library()
+        N = params[0].shape[0]
+        for attempt in range(4):
+            self._ensure(N, W, H)
+            a = self._args(params, sh_degree, W, H, viewmat, Kmat, bg, target_chw, weight, scale_reg, opacity_reg, loss_acc, adam)
+            self._stamp += 1
+            check(lib.lfs_gut_train_step(C.byref(a), C.c_int64(self.capacity), C.c_int64(self.assumed_longest), C.c_void_p(self.ws.data_ptr()),
+                                         C.c_size_t(self.ws.numel()), C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), stream()), "gut_train_step")
+            if self._wait():
+                self._after_fit()
+                return self.n_isects
+            self.retries += 1
+            self._grow(self.n_isects, self.longest)
+        raise LfsError("gut_step: the step did not fit its workspace after 4 attempts")
+
+    def view_forward(self, params: Sequence[torch.Tensor], sh_degree: int, W: int, H: int, viewmat, Kmat, bg) -> int:
+        """Forward of one view into the workspace (render / alpha / radii via .view()); re-run on overflow. Returns n_isects."""
+        lib = load_library()
+        N = params[0].shape[0]
+        for attempt in range(4):
+            self._ensure(N, W, H)
+            a = self._args(params, sh_degree, W, H, viewmat, Kmat, bg, None, 0.0, 0.0, 0.0, None, None)
+            self._stamp += 1
+            check(lib.lfs_gut_view_forward(C.byref(a), C.c_int64(self.capacity), C.c_int64(self.assumed_longest), C.c_void_p(self.ws.data_ptr()),
+                                           C.c_size_t(self.ws.numel()), C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), stream()), "gut_view_forward")
+            if self._wait():
+                return self.n_isects
+            self.retries += 1
+            self._grow(self.n_isects, self.longest)
+        raise LfsError("gut_step: the view did not fit its workspace after 4 attempts")
+
+    def view_backward(self, params: Sequence[torch.Tensor], sh_degree: int, W: int, H: int, viewmat, Kmat, bg, grads: List[torch.Tensor], accumulate: bool, *,
+                      target_chw: Optional[torch.Tensor] = None, weight: float = 0.0, loss_acc: Optional[torch.Tensor] = None,
+                      v_render: Optional[torch.Tensor] = None, scale_reg: float = 0.0, opacity_reg: float = 0.0) -> None:
+        """Backward of the view view_forward() left in the workspace, into the six gradient tensors (group order)."""
+        lib = load_library()
+        a = self._args(params, sh_degree, W, H, viewmat, Kmat, bg, target_chw, weight, scale_reg, opacity_reg, loss_acc, None)
+        for g in grads:
+            if not g.is_cuda or not g.is_contiguous():
+                raise LfsError("gut_step: gradient tensors must be contiguous CUDA (HIP) tensors")
+        gp = (C.c_void_p * 6)(*[g.data_ptr() if g.numel() else None for g in grads])
+        if v_render is not None:
+            v_render = v_render.contiguous()
+        check(lib.lfs_gut_view_backward(C.byref(a), C.c_int64(self.capacity), C.c_void_p(v_render.data_ptr()) if v_render is not None else None, gp,
+                                        C.c_int(int(accumulate)), C.c_void_p(self.ws.data_ptr()), C.c_size_t(self.ws.numel()), stream()), "gut_view_backward")

@@ -85,6 +85,8 @@ class GutTrainer:
         self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2]) if (world > 1 or fused_l2) else None  # 2 = shN
         self.loss_acc = torch.zeros(1, device=device)
         self.inline_all_adam = True   # one view / one rank / MSE: all six parameters are updated inside the backward kernels (fused.backward_adam_all)
+        self.cxx_step = True          # ... and that step is ONE C++ call without a host read on the critical path (gut_step.GutStep -> csrc/gut_step.hip);
+        self._gut_step = None         #     False: the same kernels enqueued call by call from Python (fused.py; tests compare the two)
         self.inline_shN_adam = True   # see train_step; False keeps the SH backward and the optimizer separate (tests compare the two)
         self.iteration = 0
         self.last_n_isects = 0
@@ -284,7 +286,18 @@ class GutTrainer:
             if (self.inline_shN_adam and self.sh_exchange is not None and len(views) == 1 and self.iteration > 1000 and self.sh_exchange.n   # no update then
                     and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False) and not refining):
                 inline_shard = self.optimizer.prepare_inline(self.model.shN)
-            if self.batch_views and self.world == 1 and self.sh_exchange is None and len(views) > 1:
+            if inline_all is not None and self.cxx_step:
+                from .gut_step import GutStep
+                if self._gut_step is None:
+                    self._gut_step = GutStep(self.device)
+                v, sc = views[0], self.scene
+                N = self.model.means.shape[0]
+                self.last_n_isects = self._gut_step.train_step([p.detach() for p in params], inline_all, self.model.get_active_sh_degree(), sc.width, sc.height,
+                                                               sc.viewmats[v], sc.Ks[v], self.bg, targets[0], 1.0 / total_views, self.loss_acc,
+                                                               self.scale_reg, self.opacity_reg)
+                self._last_radii = self._gut_step.view("radii", torch.int32, (1, N, 2))
+                views_loop = []
+            elif self.batch_views and self.world == 1 and self.sh_exchange is None and len(views) > 1:
                 # several views per step on one rank: the SH stages run ONCE over all views (fused.render_views_and_backward), and shN's Adam update
                 # moves into that one SH backward when the optimizer would read the gradient anyway
                 from .fused import render_views_and_backward

@@ -21,16 +21,6 @@ from gpu_util import make_gaussians, n, pinhole_K, rel_l2, rows_check, small_rot
 pytestmark = pytest.mark.gpu
 
 
-def _wide(lfs, fn):
-    """fn() with the experimental wide (16x8 cell, two pixels per lane) kernels switched on"""
-    lib = lfs.load_library()
-    try:
-        lib.lfs_set_debug_flags(2)
-        return fn()
-    finally:
-        lib.lfs_set_debug_flags(0)
-
-
 def _lists(oracle, means, quats, scales, opac, vm0, vm1, K, W, H, ts, model, shutter, rad, tan, thin):
     C = K.shape[0]
     radii, m2, d, _, _ = oracle.projection_ut_3dgs_fused(means, quats, scales, opac, vm0, vm1, K, W, H, camera_model=int(model),
@@ -57,10 +47,6 @@ def _run(oracle, lfs, ops, rng, N, W, H, ts=16, C=1, cdim=3, bg=True, masks=None
     args_g = (t(means), t(quats), t(scales), t(colors), t(opacs), t(bgc), t(masks, torch.bool), W, H, ts, t(vm0), t(vm1), t(K), model, None, shutter,
               t(rad), t(tan), t(thin), t(offs, torch.int32), t(flat, torch.int32))
     g_rc, g_ra, g_li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args_g)
-    # the opt-in two-pixels-per-lane kernels (tile sizes that are multiples of 16) against the default one-pixel-per-lane kernels: same
-    # fma chains per pixel, so the forward has to be BIT-identical (for the other tile sizes both runs take the same kernels)
-    p_rc, p_ra, p_li = _wide(lfs, lambda: ops.rasterize_to_pixels_from_world_3dgs_fwd(*args_g))
-    assert torch.equal(g_rc, p_rc) and torch.equal(g_ra, p_ra) and torch.equal(g_li, p_li)
     assert g_rc.shape == (C, H, W, cdim) and g_ra.shape == (C, H, W, 1) and g_li.shape == (C, H, W) and g_li.dtype == torch.int32
     d = np.abs(n(g_rc) - o_rc)
     assert d.mean() < 2e-6, d.mean()
@@ -76,9 +62,6 @@ def _run(oracle, lfs, ops, rng, N, W, H, ts=16, C=1, cdim=3, bg=True, masks=None
     og = oracle.rasterize_bwd(*args_o, o_ra, o_li, v_rc, v_ra)
     og64 = oracle.rasterize_bwd(*args_o, o_ra, o_li, v_rc, v_ra, dtype=np.float64)
     gg = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args_g, t(o_ra), t(o_li, torch.int32), t(v_rc), t(v_ra))
-    pg = _wide(lfs, lambda: ops.rasterize_to_pixels_from_world_3dgs_bwd(*args_g, t(o_ra), t(o_li, torch.int32), t(v_rc), t(v_ra)))
-    for name, a, b in zip(["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"], gg, pg):
-        assert rel_l2(n(a), n(b)) < 1e-4, ("wide vs narrow", name, rel_l2(n(a), n(b)))   # identical alphas: only the summation order differs
     for name, a, b, c in zip(["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"], gg, og, og64):
         assert a.shape == tuple(b.shape), name
         assert np.isfinite(n(a)).all(), name
@@ -286,9 +269,7 @@ def test_cell_culling_full_size_bit_identical(lfs):
     cam = Camera(sc.viewmats[1:2].contiguous(), sc.Ks[1:2].contiguous(), sc.width, sc.height)
     with torch.no_grad():
         a, b = _cull_on_off(lfs, lambda: rasterize(cam, model, torch.zeros(3, device=dev)))
-        c = _wide(lfs, lambda: rasterize(cam, model, torch.zeros(3, device=dev)))
     assert torch.equal(a.image, b.image) and torch.equal(a.alpha, b.alpha)
-    assert torch.equal(c.image, b.image) and torch.equal(c.alpha, b.alpha)     # one pixel per lane vs two
 
 
 def test_prepared_backward_equals_self_contained_backward(lfs, oracle_mod):
