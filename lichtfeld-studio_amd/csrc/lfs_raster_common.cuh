@@ -224,6 +224,52 @@ LFS_DI void wave_sum16_atomic_pk(const v2f (&V)[8], float* __restrict__ dst, con
     }
 }
 
+// The same 16 sums through LDS (round 3; LFS_BWD_LDS_REDUCE): every lane parks its 16 values in its own row of a [64][17] scratch block of the wavefront
+// (ds_write2_b32 x 8; the odd row stride spreads the lanes over all banks), lane L then sums column L & 15 over the 16 rows of its quarter L >> 4
+// (ds_read2_b32 x 8 + a 4-level tree), and two swaps fold the four quarters. 12 VALU instructions + 16 LDS instructions instead of the ~45 issue slots of the
+// register transpose above (12 half-rate swaps, 6 selects, 5 DPP adds and the wait states both need): the backward is VALU-issue bound, its LDS pipe idle.
+// A wavefront's LDS operations execute in order, so the write -> read -> (next entry's) write sequence needs no barrier.
+constexpr int RED_STRIDE = 17;
+template <int ACC = 0>
+LFS_DI void wave_sum16_atomic_lds(const v2f (&V)[8], float* __restrict__ dst, const uint32_t lane, float* __restrict__ scratch /* this wavefront's [64 * RED_STRIDE] */,
+                                  unsigned long long* __restrict__ det64 = nullptr) {
+    float* wr = scratch + lane * RED_STRIDE;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wr[2 * j] = V[j].x; wr[2 * j + 1] = V[j].y; }
+    LFS_WAVE_LOCKSTEP();
+#ifndef LFS_EMULATE
+    __builtin_amdgcn_wave_barrier(); // (no instruction: keeps the compiler from moving the reads across the writes of OTHER lanes it cannot see)
+#endif
+    const float* rd = scratch + (lane >> 4) * (16 * RED_STRIDE) + (lane & 15);
+    float c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = rd[i * RED_STRIDE];
+    LFS_WAVE_LOCKSTEP();
+#ifndef LFS_EMULATE
+    __builtin_amdgcn_wave_barrier();
+#endif
+    v2f p0 = v2f{c[0], c[1]} + v2f{c[2], c[3]}, p1 = v2f{c[4], c[5]} + v2f{c[6], c[7]}, p2 = v2f{c[8], c[9]} + v2f{c[10], c[11]}, p3 = v2f{c[12], c[13]} + v2f{c[14], c[15]};
+    p0 += p1; p2 += p3; p0 += p2;
+    float t = p0.x + p0.y;
+    auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    t = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    if (lane < 16) { // lane L holds the total of v[L]
+        if (ACC == 0) unsafeAtomicAdd(dst + lane, t);
+#ifndef LFS_EMULATE
+        else if (ACC == 1) atomicMax(reinterpret_cast<uint32_t*>(dst) + lane, __float_as_uint(t) & 0x7fffffffu);
+        else {
+            const uint32_t mbits = reinterpret_cast<const uint32_t*>(dst)[lane];
+            if (mbits != 0u && t != 0.f) {
+                const int e = max(int((mbits >> 23) & 0xffu), 1) - 127;
+                atomicAdd(det64 + lane, (unsigned long long)__float2ll_rn(ldexpf(t, 40 - e)));
+            }
+        }
+#endif
+    }
+}
+
 // 8 per-lane values -> 8 totals with one 8-lane atomic instruction (same halving scheme as wave_sum16_atomic: 18 VALU), and a
 // single value -> its total by a row butterfly + two cross-row folds (7 VALU). Used by the EWA blend backward (9 sums).
 LFS_DI void wave_sum8_atomic(const float (&v)[8], float* __restrict__ dst, const uint32_t lane) {

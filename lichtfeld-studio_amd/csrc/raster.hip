@@ -364,6 +364,9 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 // pass over the image disappears.
 struct MseFuse { const float* render; const float* target; float scale; float* loss; unsigned long long* det64; };
 
+#ifndef LFS_BWD_LDS_REDUCE
+#define LFS_BWD_LDS_REDUCE 1   // the 16-value wave reduction through an LDS transpose instead of register swaps (lfs_raster_common.cuh). Measured on SYN-B, same box,
+#endif                         // 3 pairs (profiles/r03/raster_bwd_lds_reduce_ab.txt): raster_bwd 0.621 - 0.624 -> 0.534 - 0.541 ms; 0 = the register transpose of rounds 1 - 2
 #ifndef LFS_BWD_PK
 #define LFS_BWD_PK 1   // the backward's gradient products and the first two levels of its 16-value reduction on register pairs (v_pk_mul_f32 / v_pk_add_f32): 47 fewer
 #endif                 // VALU instructions in the kernel (-12 per evaluation), bit-identical sums; measured 0.621 - 0.631 -> 0.611 - 0.617 ms (same box, 3 pairs)
@@ -378,6 +381,10 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ acc, float* __restrict__ v_colors_extra, const MseFuse mse = MseFuse{}) {
     const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
+#if LFS_BWD_LDS_REDUCE
+    __shared__ float s_red[4 * 64 * RED_STRIDE]; // one [64][17] transpose block per wavefront (wave_sum16_atomic_lds)
+    float* const red_scratch = s_red + (threadIdx.x >> 6) * (64 * RED_STRIDE);
+#endif
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
     if (!cc.in_grid) return;
     const uint32_t cid = cc.cid;
@@ -511,7 +518,11 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
             V[5] = ayz;
             V[6] = v2f{v_op, fac * vc[0]};
             V[7] = v2f{vc[1], vc[2]} * fac;
+#if LFS_BWD_LDS_REDUCE
+            wave_sum16_atomic_lds<ACC>(V, acc + size_t(e.x) * ACC_STRIDE, lane, red_scratch, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
+#else
             wave_sum16_atomic_pk<ACC>(V, acc + size_t(e.x) * ACC_STRIDE, lane, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
+#endif
             return;
         }
 #endif
