@@ -9,8 +9,9 @@ Workload = BASELINE.json configs[1] (SYN-B of SURVEY.md §8d): 1 000 000 synthet
 1920x1080, SH degree 3, 16x16 tiles, 64 orbit cameras, lrs of default_optimization_params.json,
 MSE loss against a fixed random target (rasterizer-only metric). One "step" = every rank renders
 one view, backpropagates, the parameter gradients are summed over ranks (one RCCL all-reduce of
-the flat 59*N-float bucket) and every rank applies the fused Adam step: weak scaling, value =
-world * K / max-over-ranks(time).  Inputs are resident in HBM before the timed region.
+the flat 59*N-float bucket: the north-star layout, the headline for N > 1; the SH-sharded layout
+is timed right after it and reported under "sh_sharded") and every rank applies the fused Adam
+step: weak scaling, value = world * K / max-over-ranks(time).  Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0, with
   roofline     : the dominant kernel (by HIP-event time inside the timed region) against the
@@ -136,16 +137,71 @@ def cpu_baseline(scene, view: int, target, threads: int, hip_step: dict | None =
 
 
 def hip_reference_step(trainer, view: int, target_dev) -> dict:
-    """One fused forward + backward of the HIP path at `view` from the trainer's CURRENT parameters, results on the host (for parity_vs_oracle)."""
-    from lichtfeld_studio_amd.fused import render_and_backward
-    grads = [torch.zeros_like(p) for p in trainer.model.parameters()]
+    """One forward + backward of the HIP path at `view` from the trainer's CURRENT parameters, results on the host (for parity_vs_oracle): through the same
+    C++ entry points the timed steps use (gut_step.GutStep -> lfs_gut_view_forward / lfs_gut_view_backward; the Adam-inline step enqueues the same kernels)."""
+    from lichtfeld_studio_amd.gut_step import GutStep
+    gs = GutStep(trainer.device)
+    sc = trainer.scene
+    params = [p.detach() for p in trainer.model.parameters()]
+    grads = [torch.zeros_like(p) for p in params]
     loss = torch.zeros(1, device=target_dev.device)
-    out = render_and_backward(trainer.camera(view), trainer.model, trainer.bg, target_dev, 1.0, grads, loss, accumulate=False)
+    deg, N = trainer.model.get_active_sh_degree(), params[0].shape[0]
+    n_isects = gs.view_forward(params, deg, sc.width, sc.height, sc.viewmats[view], sc.Ks[view], trainer.bg)
+    gs.view_backward(params, deg, sc.width, sc.height, sc.viewmats[view], sc.Ks[view], trainer.bg, grads, False, target_chw=target_dev, weight=1.0, loss_acc=loss)
+    torch.cuda.synchronize()
     names = ["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"]
-    res = {"render": out.image_hwc.cpu().numpy(), "alpha": out.alpha.cpu().numpy(), "radii": out.radii.cpu().numpy(), "loss": float(loss),
-           "grads": {k: g.cpu().numpy() for k, g in zip(names, grads)}}
-    res["n_isects"] = out.n_isects
+    res = {"render": gs.view("render", torch.float32, (1, sc.height, sc.width, 3)).cpu().numpy(), "alpha": gs.view("alpha", torch.float32, (1, sc.height, sc.width, 1)).cpu().numpy(),
+           "radii": gs.view("radii", torch.int32, (1, N, 2)).cpu().numpy(), "loss": float(loss), "grads": {k: g.cpu().numpy() for k, g in zip(names, grads)}}
+    res["n_isects"] = n_isects
     return res
+
+
+def measure(trainer, targets, args, world: int, device, profile: bool) -> dict:
+    """W warm-up steps (the last up to 3 with every kernel scope timed: the per-kernel table, which names the dominant kernel), then exactly K timed steps
+    bracketed by barrier + synchronize, max over ranks. Inside the timed region only the dominant kernel is bracketed with events (two hipEventRecord per
+    step), so the event overhead of the other scopes stays out of the measured throughput."""
+    from lichtfeld_studio_amd import capi
+    from lichtfeld_studio_amd import dist as lfs_dist
+    table_steps = min(3, args.warmup) if profile else 0
+    for _ in range(args.warmup - table_steps):
+        trainer.train_step(targets)
+    table, coll_ms = {}, {}
+    if table_steps:
+        torch.cuda.synchronize()
+        capi.profile_collect()
+        capi.profile_filter(None)
+        capi.profile_enable(True)
+        # the collectives' device time is measured here as well (two timing events per collective), NOT inside the timed region
+        lfs_dist.stats_enable(timing=world > 1 or bool(os.environ.get("LFS_DIST_FORCE_COLLECTIVES")))
+        for _ in range(table_steps):
+            trainer.train_step(targets)
+        capi.profile_enable(False)
+        table = capi.profile_collect()
+        coll_ms = {k: v["ms"] / table_steps for k, v in lfs_dist.stats_collect().items()}
+    dom = max(table.items(), key=lambda kv: kv[1][0])[0] if table else None
+    lfs_dist.barrier()
+    torch.cuda.synchronize()
+    seen = lfs_dist.ranks_seen(device)
+    if seen != world:
+        raise SystemExit(f"the process group reaches {seen} ranks, --gpus says {world}")
+    lfs_dist.stats_enable(timing=False)   # calls and payload bytes of the timed steps only (no events)
+    if dom:
+        capi.profile_filter(dom)
+        capi.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(targets)
+    lfs_dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernels = {}
+    if dom:
+        capi.profile_enable(False)
+        kernels = capi.profile_collect()
+        capi.profile_filter(None)
+    elapsed = lfs_dist.max_over_ranks(elapsed, device)
+    coll = lfs_dist.stats_collect()   # this rank's collectives inside the timed steps: calls, payload bytes (device ms: from the profiled warm-up steps above)
+    return dict(elapsed=elapsed, table=table, table_steps=table_steps, kernels=kernels, dom=dom, coll=coll, coll_ms=coll_ms, seen=seen)
 
 
 def main() -> None:
@@ -165,8 +221,8 @@ def main() -> None:
                     help="mcmc = BASELINE.json configs[4]: strategies.MCMC (mcmc_optimization_params.json: SGLD noise every step, relocation of dead Gaussians "
                          "every 100 iterations with the Relocation kernel, scale / opacity regularisers), max_cap = the scene's Gaussian count")
     ap.add_argument("--bilateral-grid", action="store_true", help="BASELINE.json configs[4]: per-image 16x16x8 bilateral grid between render and loss (+ its TV loss and Adam)")
-    ap.add_argument("--replicated", action="store_true", help="multi-GPU: keep shN replicated (59 floats / Gaussian all-reduced) instead of SH-sharded")
-    ap.add_argument("--sh-sharded", action="store_true", help="force the SH-sharded layout (the default for more than one rank) - with LFS_DIST_FORCE_COLLECTIVES=1 this runs its collectives on ONE GPU")
+    ap.add_argument("--replicated", action="store_true", help="multi-GPU: only the headline layout (replicated Gaussians, one all-reduce of the 59-float bucket); skips the SH-sharded side line")
+    ap.add_argument("--sh-sharded", action="store_true", help="measure ONLY the SH-sharded layout, as the headline - with LFS_DIST_FORCE_COLLECTIVES=1 this runs its collectives on ONE GPU")
     ap.add_argument("--path", default="step", choices=["step", "ops"],
                     help="step (default) = the C++ training step (csrc/gut_step.hip, one host call per step); ops = the DROP-IN route: the sequence "
                          "rasterizer.cpp:224-344 makes through the reference-signature C++ wrappers of _lfs_torch_ops.so, op by op under torch autograd, then six "
@@ -205,7 +261,11 @@ def main() -> None:
     def make_trainer(sh_sharded):
         return GutTrainer(scene, device, iterations=30000 if args.strategy == "mcmc" else 7000, world=world, rank=rank, views_per_rank=args.views_per_rank,
                           loss=args.loss, rasterizer=args.rasterizer, sh_sharded=sh_sharded, use_bilateral_grid=args.bilateral_grid, **extra)
-    trainer = make_trainer(False if args.replicated else (True if args.sh_sharded else None))
+    # N > 1: the HEADLINE is the north-star layout - replicated Gaussians, per-rank forward / backward, one all-reduce of the flat gradient bucket before the
+    # fused Adam step ("dpN-replicated"). The SH-sharded layout (dist.ShExchange: shN and its Adam state owned by one rank each, 14 instead of 59 floats per
+    # Gaussian in the all-reduce) is measured right after it and reported beside it under "sh_sharded"; --sh-sharded / --replicated restrict the run to one.
+    headline_sharded = bool(args.sh_sharded) and not args.replicated
+    trainer = make_trainer(headline_sharded)
     if args.strategy == "mcmc" and args.start_iteration == 3000:
         # the warm-up must contain one refinement step (iteration 3000: relocation + its torch index kernels, whose first use loads ~20 code
         # objects at 20 - 200 ms each); the timed window then holds warm steps only, one of them (every 100th) a refinement step
@@ -213,69 +273,38 @@ def main() -> None:
     trainer.iteration = args.start_iteration
     from lichtfeld_studio_amd import fused as _fused
     targets = [scenes.target_image(scene.height, scene.width, seed=43).to(device)]
-    parallelism_fallback = None
-    if world > 1 and trainer.sh_exchange is not None:
-        # one trial step of the SH-sharded layout (all_to_all + all_gather + all_reduce); if the collective library refuses any of them on this node,
-        # every rank falls back to the replicated layout (one all_reduce per step) together and the JSON line says so
-        ok = 1
-        try:
-            trainer.train_step(targets)
-            torch.cuda.synchronize()
-        except RuntimeError as e:
-            ok, parallelism_fallback = 0, str(e).splitlines()[0][:200]
-        flag = torch.tensor([float(ok)], device=device)
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        if float(flag) == 0.0:
-            parallelism_fallback = parallelism_fallback or "another rank failed its SH-sharded trial step"
-            trainer = make_trainer(False)
-        trainer.iteration = args.start_iteration
     hip_step = None
-    if world == 1 and not args.no_cpu_baseline and args.rasterizer == "gut" and trainer.sh_exchange is None:
+    if world == 1 and not args.no_cpu_baseline and args.rasterizer == "gut" and args.path == "step":
         hip_step = hip_reference_step(trainer, 0, targets[0])   # before any update: the oracle starts from the same parameters
 
-    # Warm-up. Its last (up to 3) steps run with every kernel scope timed (HIP events on the launch stream): that gives the
-    # per-kernel table and names the dominant kernel. Inside the timed region only that kernel is bracketed with events
-    # (two hipEventRecord per step), so the event overhead of the ~30 other scopes stays out of the measured throughput.
     profile = not args.no_profile
-    table_steps = min(3, args.warmup) if profile else 0
-    for _ in range(args.warmup - table_steps):
-        trainer.train_step(targets)
-    table = {}
-    coll_ms = {}
-    if table_steps:
-        torch.cuda.synchronize()
-        capi.profile_collect()
-        capi.profile_filter(None)
-        capi.profile_enable(True)
-        # the collectives' device time is measured here as well (two timing events per collective), NOT inside the timed region: in the SH-sharded
-        # step the event pairs of four collectives cost ~0.3 ms of host time per step (measured at world 1: 2.05 ms with them, 1.68 ms without)
-        lfs_dist.stats_enable(timing=world > 1 or bool(os.environ.get("LFS_DIST_FORCE_COLLECTIVES")))
-        for _ in range(table_steps):
-            trainer.train_step(targets)
-        capi.profile_enable(False)
-        table = capi.profile_collect()
-        coll_ms = {k: v["ms"] / table_steps for k, v in lfs_dist.stats_collect().items()}
-    dom = max(table.items(), key=lambda kv: kv[1][0])[0] if table else None
-    lfs_dist.barrier()
-    torch.cuda.synchronize()
-    seen = lfs_dist.ranks_seen(device)
-    lfs_dist.stats_enable(timing=False)   # calls and payload bytes of the timed steps only (no events)
-    if dom:
-        capi.profile_filter(dom)
-        capi.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.train_step(targets)
-    lfs_dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernels = {}
-    if dom:
-        capi.profile_enable(False)
-        kernels = capi.profile_collect()
-        capi.profile_filter(None)
-    elapsed = lfs_dist.max_over_ranks(elapsed, device)
-    coll = lfs_dist.stats_collect()   # this rank's collectives inside the timed steps: calls, payload bytes (device ms: from the profiled warm-up steps above)
+    m = measure(trainer, targets, args, world, device, profile)
+    elapsed, table, table_steps, kernels, dom, coll, coll_ms, seen = (m[k] for k in ("elapsed", "table", "table_steps", "kernels", "dom", "coll", "coll_ms", "seen"))
+
+    sharded_line = None
+    if world > 1 and not args.replicated and not args.sh_sharded and args.rasterizer == "gut" and args.strategy == "none":
+        # one trial step of the SH-sharded layout (all_to_all + all_gather + all_reduce); if the collective library refuses any of them on this node the
+        # side line says so instead of failing the run
+        ok, why = 1, None
+        tr2 = None
+        try:
+            tr2 = make_trainer(True)
+            tr2.iteration = args.start_iteration
+            tr2.train_step(targets)
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            ok, why = 0, str(e).splitlines()[0][:200]
+        flag = torch.tensor([float(ok)], device=device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if float(flag) == 1.0:
+            tr2.iteration = args.start_iteration
+            m2 = measure(tr2, targets, args, world, device, False)
+            sharded_line = {"parallelism": f"dp{world}-sh-sharded", "value": round(world * args.views_per_rank * args.steps / m2["elapsed"], 3),
+                            "ms_per_step": round(m2["elapsed"] / args.steps * 1e3, 4),
+                            "collectives_per_step": {k: {"calls": v["calls"] / args.steps, "MB": round(v["bytes"] / args.steps / 1e6, 3)} for k, v in m2["coll"].items()}}
+        else:
+            sharded_line = {"parallelism": f"dp{world}-sh-sharded", "value": None, "failed": why or "another rank failed its SH-sharded trial step"}
+        del tr2
 
     refine_ms = None
     if args.strategy == "mcmc" and world == 1:   # one refinement step on its own (relocation of the dead Gaussians + the step around it)
@@ -365,13 +394,14 @@ def main() -> None:
         "config": {"rasterizer": args.rasterizer, "workload": f"{scene.name}: {N} Gaussians, {scene.width}x{scene.height}, SH degree {scene.sh_degree}, "
                                f"16x16 tiles, {n_views} orbit cameras, {'MSE' if args.loss == 'mse' else 'L1 + 0.2 D-SSIM'} loss, default_optimization_params lrs",
                    "global_batch": world * args.views_per_rank, "views_per_rank": args.views_per_rank,
-                   "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ""), "start_iteration": args.start_iteration,
-                   **({"parallelism_fallback": parallelism_fallback} if parallelism_fallback else {}),
+                   "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ("-replicated" if world > 1 else "")),
+                   "path": args.path, "start_iteration": args.start_iteration,
                    "strategy": args.strategy, "bilateral_grid": bool(args.bilateral_grid), "refine_step_ms": None if refine_ms is None else round(refine_ms, 3),
                    "visible_gaussians": V, **({"visible_gaussians_source": v_source} if v_source else {}), "n_isects": I},
         "collectives": {"backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None), "ranks_seen": seen,
                         "per_step": {k: {"calls": v["calls"] / args.steps, "MB": round(v["bytes"] / args.steps / 1e6, 3), "ms": round(coll_ms.get(k, 0.0), 4)} for k, v in coll.items()}},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
+        **({"sh_sharded": sharded_line} if sharded_line is not None else {}),
     }
     # C-level stdout first (RCCL prints its version banner through stdio; on a pipe that buffer would otherwise be flushed at exit, after our line):
     # the JSON line is the last thing rank 0 prints

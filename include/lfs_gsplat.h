@@ -415,6 +415,12 @@ LFS_API int lfs_gut_view_forward(const lfs_gut_step_args* args, int64_t capacity
                                  int64_t* host_counts, int64_t stamp, lfs_stream_t stream);
 LFS_API int lfs_gut_view_backward(const lfs_gut_step_args* args, int64_t capacity, const float* v_render /* [H,W,3], used when args->target_chw == NULL */,
                                   float* const* grads /* [6] host */, int accumulate, void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+/*   = lfs_gut_view_backward_sh (rasterizer backward + SH backward: grads[1], grads[2] final) then lfs_gut_view_backward_finish (grads[0], grads[3..5]); a
+ *   data-parallel caller starts the all-reduce of the SH gradients between the two (dist.GradBucket.all_reduce_early). */
+LFS_API int lfs_gut_view_backward_sh(const lfs_gut_step_args* args, int64_t capacity, const float* v_render, float* const* grads, int accumulate,
+                                     void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+LFS_API int lfs_gut_view_backward_finish(const lfs_gut_step_args* args, int64_t capacity, float* const* grads, int accumulate,
+                                         void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 LFS_API int lfs_gut_step_wait(const int64_t* host_counts, int64_t stamp, double timeout_s, int64_t* n_isects, int64_t* longest);
 
 /* Extension: the all-inline training step of the fused 3DGUT path (one camera, global shutter, 3 channels, ONE view per step on one rank - the

@@ -149,38 +149,59 @@ extern "C" int lfs_gut_train_step(const lfs_gut_step_args* a, int64_t capacity, 
                                 a->opacity_reg, a->loss, w.raster_ws, w.raster_ws_bytes, s, w.abort_flag);
 }
 
-// Forward + backward of one view into GRADIENT TENSORS (data-parallel ranks, several views per step): the same speculative front half, then the
-// accumulator-only backward, lfs_gut_finish_grads and the SH backward. grads: means, sh0, shN, raw_scales, raw_quats, raw_opacities - written
-// (accumulate == 0) or added to. With target_chw the clamped MSE is folded into the backward and *loss += it; otherwise v_render [H,W,3] is the caller's
-// dL/d(render) (any loss: the caller ran it on the forward image of lfs_gut_view_forward). An attempt that did not fit its buffers writes gradients of an
-// EMPTY render (all lists were emptied): the caller checks the counts before it uses them, and runs the view again.
-extern "C" int lfs_gut_view_backward(const lfs_gut_step_args* a, int64_t capacity, const float* v_render, float* const* grads /* [6] host */, int accumulate,
-                                     void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+// Backward of the view lfs_gut_view_forward left in the workspace, into GRADIENT TENSORS (data-parallel ranks, several views per step, iterations <= 1000):
+// grads = means, sh0, shN, raw_scales, raw_quats, raw_opacities - written (accumulate == 0) or added to. Two halves, so that a data-parallel caller can put
+// the all-reduce of the SH gradients (45 of 59 floats per Gaussian at degree 3) on the wire between them:
+//   lfs_gut_view_backward_sh     : accumulator-only rasterizer backward (with target_chw the clamped MSE is folded in, otherwise v_render [H,W,3] is the
+//                                  caller's dL/d(render)), then the SH backward straight from the accumulator rows -> grads[1], grads[2] final for this view
+//   lfs_gut_view_backward_finish : rows + dL/d(dirs) -> grads[0], grads[3..5] (raster_finish + activation backward + regularisers); *loss += the fused MSE
+// An attempt that did not fit its buffers (lfs_gut_step_fits) rendered EMPTY lists: the caller checks the counts of the forward before it calls these.
+static int view_setup(const lfs_gut_step_args* a, int64_t capacity, void* workspace, size_t workspace_bytes, StepWs& w, lfs_cameras& cams, const int32_t*& offsets) {
     int rc = check_args(a, false);
     if (rc) return rc;
-    if (!workspace || !grads || (!a->target_chw && !v_render) || (a->target_chw && !a->loss)) return LFS_E_INVALID;
-    for (int k = 0; k < 6; ++k) if (!grads[k] && !(k == 2 && a->K == 1)) return LFS_E_INVALID;
-    StepWs w;
+    if (!workspace) return LFS_E_INVALID;
     if (!step_ws(workspace, a->N, a->image_width, a->image_height, a->tile_size, capacity, w, nullptr)) return LFS_E_INVALID;
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
     const uint32_t tile = a->tile_size, tw = (a->image_width + tile - 1) / tile, th = (a->image_height + tile - 1) / tile;
-    lfs_cameras cams{};
+    cams = lfs_cameras{};
     cams.C = 1; cams.image_width = a->image_width; cams.image_height = a->image_height; cams.camera_model = LFS_CAMERA_PINHOLE; cams.rs_type = LFS_SHUTTER_GLOBAL;
     cams.viewmats0 = a->viewmat; cams.Ks = a->Kmat;
-    const int32_t* offsets = isect_workspace_offsets(w.isect_ws, 1, a->N, tw, th);
+    offsets = isect_workspace_offsets(w.isect_ws, 1, a->N, tw, th);
+    return LFS_OK;
+}
+
+extern "C" int lfs_gut_view_backward_sh(const lfs_gut_step_args* a, int64_t capacity, const float* v_render, float* const* grads /* [6] host */, int accumulate,
+                                        void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    StepWs w; lfs_cameras cams; const int32_t* offsets;
+    int rc = view_setup(a, capacity, workspace, workspace_bytes, w, cams, offsets);
+    if (rc) return rc;
+    if (!grads || !grads[1] || (a->K > 1 && !grads[2]) || (!a->target_chw && !v_render)) return LFS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
     if (a->target_chw)
-        rc = raster_bwd_mse_acc_guarded(a->N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, tile, offsets, w.flatten_ids, capacity, w.render,
-                                        w.alpha, w.last_ids, a->target_chw, a->loss_weight, w.raster_ws, w.raster_ws_bytes, s);
+        rc = raster_bwd_mse_acc_guarded(a->N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, a->tile_size, offsets, w.flatten_ids, capacity,
+                                        w.render, w.alpha, w.last_ids, a->target_chw, a->loss_weight, w.raster_ws, w.raster_ws_bytes, s);
     else
-        rc = raster_bwd_acc_guarded(a->N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, tile, offsets, w.flatten_ids, capacity, w.alpha,
+        rc = raster_bwd_acc_guarded(a->N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, a->tile_size, offsets, w.flatten_ids, capacity, w.alpha,
                                     w.last_ids, v_render, w.raster_ws, w.raster_ws_bytes, s);
     if (rc) return rc;
-    // dL/dcolour lands in v_dirs' slot ([N,3]; the SH backward reads it and adds dL/d(dirs) onto the means gradient)
-    rc = lfs_gut_finish_grads(a->N, a->means, a->raw_quats, w.quats, w.scales, w.opacities, a->scale_reg, a->opacity_reg, accumulate, grads[0], grads[3], grads[4], grads[5],
-                              w.v_dirs, a->target_chw ? a->loss : nullptr, w.raster_ws, w.raster_ws_bytes, stream);
+    const float* acc_rows = reinterpret_cast<const float*>(static_cast<const char*>(w.raster_ws) + lfs_rasterize_workspace_acc_offset(1, a->N));
+    return sh_model_bwd_rows_impl(a->N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, acc_rows, accumulate, grads[1], grads[2], w.v_dirs, s);
+}
+
+extern "C" int lfs_gut_view_backward_finish(const lfs_gut_step_args* a, int64_t capacity, float* const* grads /* [6] host */, int accumulate,
+                                            void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    StepWs w; lfs_cameras cams; const int32_t* offsets;
+    int rc = view_setup(a, capacity, workspace, workspace_bytes, w, cams, offsets);
     if (rc) return rc;
-    return lfs_sh_model_bwd(a->N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, w.v_dirs, accumulate, grads[1], grads[2], grads[0], stream);
+    if (!grads || !grads[0] || !grads[3] || !grads[4] || !grads[5] || (a->target_chw && !a->loss)) return LFS_E_INVALID;
+    return gut_finish_grads_impl(a->N, a->means, a->raw_quats, w.quats, w.scales, w.opacities, a->scale_reg, a->opacity_reg, accumulate, grads[0], grads[3], grads[4],
+                                 grads[5], nullptr, w.v_dirs, a->target_chw ? a->loss : nullptr, w.raster_ws, w.raster_ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int lfs_gut_view_backward(const lfs_gut_step_args* a, int64_t capacity, const float* v_render, float* const* grads /* [6] host */, int accumulate,
+                                     void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    const int rc = lfs_gut_view_backward_sh(a, capacity, v_render, grads, accumulate, workspace, workspace_bytes, stream);
+    return rc ? rc : lfs_gut_view_backward_finish(a, capacity, grads, accumulate, workspace, workspace_bytes, stream);
 }
 
 extern "C" int lfs_gut_view_forward(const lfs_gut_step_args* a, int64_t capacity, int64_t assumed_longest, void* workspace, size_t workspace_bytes,

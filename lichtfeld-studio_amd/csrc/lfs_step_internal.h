@@ -49,4 +49,11 @@ int sh_model_bwd_adam_all_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, 
                                const float* sh0_scalars, float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, hipStream_t s,
                                const int32_t* abort_flag);
 
+int sh_model_bwd_rows_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+                           const int32_t* radii, const float* colors, const float* acc_rows, int accumulate, float* v_sh0, float* v_shN, float* v_dirs, hipStream_t s);
+// lfs_gut_finish_grads with dL/d(dirs) [N,3] (nullable) added to the means gradient and no dL/dcolour output (the SH backward has run already)
+int gut_finish_grads_impl(uint32_t N, const float* means, const float* raw_quats, const float* quats, const float* scales, const float* opacities, float scale_reg,
+                          float opacity_reg, int accumulate, float* g_means, float* g_raw_scales, float* g_raw_quats, float* g_raw_opacities, float* v_colors,
+                          const float* v_dirs, float* loss, void* workspace, size_t workspace_bytes, hipStream_t s);
+
 } // namespace lfs

@@ -682,9 +682,22 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
     float sc[3], vd[3] = {0.f, 0.f, 0.f};
     const f3 mu = ld3(means, gid);
     ld3a(scales, sc);
-    if (ADAM) ld3a(v_dirs, vd);
-    if (any) { // exactly raster_finish_kernel<true> for C == 1
-        const float4 q = reinterpret_cast<const float4*>(quats)[gid];
+    if (ADAM || v_dirs != nullptr) ld3a(v_dirs, vd);   // (gradient-tensor form: nullable - the SH backward then adds dL/d(dirs) onto g_means afterwards)
+    // Every operand of the pass is requested HERE, before any arithmetic (round 3): the kernel used to fetch in three dependent phases (rows -> quaternion
+    // inside `if (any)` -> moments), which left each wavefront with 3 - 7 loads in flight and the kernel at 3.5 TB/s. The geometry vjp below now runs for
+    // every Gaussian and is SELECTED by `any` (un-touched Gaussians keep exact zeros; their 1/scale may be inf), so no load hides behind a branch.
+    const float4 q = reinterpret_cast<const float4*>(quats)[gid];
+    const float4 rq = reinterpret_cast<const float4*>(raw_quats)[gid];
+    const float o = opacities[gid];
+    float m0[3] = {0.f, 0.f, 0.f}, v0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f}, m1[3] = {0.f, 0.f, 0.f}, v1[3] = {0.f, 0.f, 0.f};
+    float4 mq = make_float4(0.f, 0.f, 0.f, 0.f), vq4 = mq;
+    float po = 0.f, mo = 0.f, vo = 0.f;
+    if (ADAM) {
+        ld3a(ad.m[0], m0); ld3a(ad.v[0], v0); ld3a(raw_scales, p1); ld3a(ad.m[1], m1); ld3a(ad.v[1], v1);
+        mq = reinterpret_cast<const float4*>(ad.m[2])[gid]; vq4 = reinterpret_cast<const float4*>(ad.v[2])[gid];
+        po = raw_opacities[gid]; mo = ad.m[3][gid]; vo = ad.v[3][gid];
+    }
+    { // exactly raster_finish_kernel<true> for C == 1 (selected by `any` at the end)
         const m3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
         const float is[3] = {1.f / sc[0], 1.f / sc[1], 1.f / sc[2]};
         m3 M;
@@ -715,13 +728,16 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             vs[c] += -is[c] * is[c] * (R.m[0][c] * vM.m[c][0] + R.m[1][c] * vM.m[c][1] + R.m[2][c] * vM.m[c][2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { vm[k] = any ? vm[k] : 0.f; vs[k] = any ? vs[k] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vq[k] = any ? vq[k] : 0.f;
     }
     {
 #pragma clang fp contract(off)
         // + dL/d(dirs) of the SH backward (sh.hip adds it onto the rasterizer's dL/dmeans in the separate path)
         float gm[3] = {vm[0] + vd[0], vm[1] + vd[1], vm[2] + vd[2]};
         // activations_bwd_kernel<false> (l2_fused.hip)
-        const float4 rq = reinterpret_cast<const float4*>(raw_quats)[gid];
         const float nrm = sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
         float gq[4];
         if (nrm > 1e-12f) {
@@ -737,11 +753,10 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
         float gs[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) gs[k] = (vs[k] + ad.scale_reg) * sc[k];
-        const float o = opacities[gid];
         const float go = (v_opac + ad.opacity_reg) * o * (1.f - o);
         if (!ADAM) { // gradient tensors out (activations_bwd_kernel's stores; dL/dmeans = the rasterizer's part, the SH backward adds the rest)
             const float v_col[3] = {a3.y, a3.z, a3.w};
-            st3a(gr.v_colors, v_col);
+            if (gr.v_colors != nullptr) st3a(gr.v_colors, v_col);
             float4* gqo = reinterpret_cast<float4*>(gr.g_quats) + gid;
             if (gr.accumulate) {
                 float om[3], os[3];
@@ -763,10 +778,6 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
         // Adam (adam_multi_kernel's per-element update). Every moment is loaded before the first store (the moment arrays hang off a struct: no
         // __restrict__, a load could not move above an earlier store) and three-float rows move as 12-byte accesses (lfs_math.cuh). Measured on
         // one box against the element-by-element version: no difference (0.094 - 0.104 ms either way; the kernel walks 29 streams)
-        float m0[3], v0[3], p1[3], m1[3], v1[3];
-        ld3a(ad.m[0], m0); ld3a(ad.v[0], v0); ld3a(raw_scales, p1); ld3a(ad.m[1], m1); ld3a(ad.v[1], v1);
-        float4 mq = reinterpret_cast<const float4*>(ad.m[2])[gid], vq4 = reinterpret_cast<const float4*>(ad.v[2])[gid];
-        float po = raw_opacities[gid], mo = ad.m[3][gid], vo = ad.v[3][gid];
         float p[3] = {mu.x, mu.y, mu.z};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1122,23 +1133,31 @@ int lfs::raster_bwd_acc_guarded(uint32_t N, const float* means, const float* qua
 // The accumulator rows -> gradient TENSORS of the raw parameters in one pass (raster_finish + lfs_activations_bwd + the copy of dL/dmeans): for steps
 // that need the gradients themselves (multi-GPU all-reduce, several views per step, non-MSE losses). g_* are written or, accumulate != 0, added to;
 // v_colors [N,3] is written (the SH backward consumes it and adds dL/d(dirs) onto g_means). loss (nullable): += the fused MSE partial sums.
-extern "C" int lfs_gut_finish_grads(
+int lfs::gut_finish_grads_impl(
     uint32_t N, const float* means, const float* raw_quats, const float* quats, const float* scales, const float* opacities, float scale_reg, float opacity_reg,
-    int accumulate, float* g_means, float* g_raw_scales, float* g_raw_quats, float* g_raw_opacities, float* v_colors, float* loss,
-    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    int accumulate, float* g_means, float* g_raw_scales, float* g_raw_quats, float* g_raw_opacities, float* v_colors, const float* v_dirs, float* loss,
+    void* workspace, size_t workspace_bytes, hipStream_t s) {
     if (N == 0) return LFS_OK;
-    if (!means || !raw_quats || !quats || !scales || !opacities || !g_means || !g_raw_scales || !g_raw_quats || !g_raw_opacities || !v_colors || !workspace) return LFS_E_INVALID;
+    if (!means || !raw_quats || !quats || !scales || !opacities || !g_means || !g_raw_scales || !g_raw_quats || !g_raw_opacities || (!v_colors && !v_dirs) || !workspace) return LFS_E_INVALID;
     const RasterWs w = raster_ws(workspace, 1, N, 0, 0);
     if (workspace_bytes < size_t(reinterpret_cast<const char*>(w.cull) - static_cast<const char*>(workspace))) return LFS_E_WORKSPACE;
     FinishAdam ad{};
     // regularisers of trainer.cpp:132-158 (as lfs_activations_bwd): scale_reg * mean(scales) over 3N values, opacity_reg * mean(opacities)
     ad.scale_reg = scale_reg / (3.f * float(N)); ad.opacity_reg = opacity_reg / float(N);
     const FinishGrads gr{g_means, g_raw_scales, g_raw_quats, g_raw_opacities, v_colors, accumulate};
-    hipStream_t s = (hipStream_t)stream;
     lfs::ProfScope prof("finish_grads", s);
     hipLaunchKernelGGL(raster_finish_adam_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, s, N, const_cast<float*>(means), (float*)nullptr, const_cast<float*>(raw_quats),
-                       (float*)nullptr, quats, scales, opacities, w.cams, w.acc, (const float*)nullptr, ad, gr, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss, (const int32_t*)nullptr);
+                       (float*)nullptr, quats, scales, opacities, w.cams, w.acc, v_dirs, ad, gr, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss, (const int32_t*)nullptr);
     return (int)hipGetLastError();
+}
+
+extern "C" int lfs_gut_finish_grads(
+    uint32_t N, const float* means, const float* raw_quats, const float* quats, const float* scales, const float* opacities, float scale_reg, float opacity_reg,
+    int accumulate, float* g_means, float* g_raw_scales, float* g_raw_quats, float* g_raw_opacities, float* v_colors, float* loss,
+    void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    if (N != 0 && !v_colors) return LFS_E_INVALID;
+    return lfs::gut_finish_grads_impl(N, means, raw_quats, quats, scales, opacities, scale_reg, opacity_reg, accumulate, g_means, g_raw_scales, g_raw_quats, g_raw_opacities,
+                                      v_colors, nullptr, loss, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // scalars[k] = {lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp} for k = means, raw_scales, raw_quats, raw_opacities; *loss = the fused MSE of the backward (stored, not added)

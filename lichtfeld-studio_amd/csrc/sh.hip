@@ -602,6 +602,23 @@ extern "C" int lfs_sh_model_bwd(
     return lfs::sh_launch_bwd<true, false>(a, v_colors, nullptr, v_sh0, v_shN, v_means, (hipStream_t)stream);
 }
 
+// lfs_sh_model_bwd with dL/dcolour read from the rasterizer's accumulator rows (slots 13..15 of 16 floats) and dL/d(dirs) WRITTEN to its own [n,3] array:
+// the data-parallel step runs the SH backward BEFORE the finish pass, so that the shN gradient - 45 of a Gaussian's 59 floats - is final (and its
+// all-reduce on the wire) while lfs_gut_finish_grads still runs (csrc/gut_step.hip).
+int lfs::sh_model_bwd_rows_impl(
+    uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+    const int32_t* radii, const float* colors, const float* acc_rows, int accumulate, float* v_sh0, float* v_shN, float* v_dirs, hipStream_t stream) {
+    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
+    if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
+    if (n == 0) return LFS_OK;
+    if (!means || !viewmat || !sh0 || (K > 1 && (!shN || !v_shN)) || !radii || !colors || !acc_rows || !v_sh0 || !v_dirs) return LFS_E_INVALID;
+    lfs::ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
+    a.vs = 16; a.dirs_store = true;
+    if (accumulate) return lfs::sh_launch_bwd<true, true>(a, acc_rows + 13, nullptr, v_sh0, v_shN, v_dirs, stream);
+    return lfs::sh_launch_bwd<true, false>(a, acc_rows + 13, nullptr, v_sh0, v_shN, v_dirs, stream);
+}
+
 extern "C" int lfs_sh_model_bwd_adam(
     uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, float* shN,
     const int32_t* radii, const float* colors, const float* v_colors, float* v_sh0, float* v_means,

@@ -140,33 +140,40 @@ class GradBucket:
         """Sum over ranks of the whole bucket (or its non-deferred prefix), minus whatever `all_reduce_early` already has in flight."""
         if _active():
             hi = self.active_numel if skip_deferred else self.flat.numel()
-            if self._early is not None:       # [lo_e, hi_e) is being reduced on RCCL's stream: reduce the two pieces around it, then wait
-                lo_e, hi_e, work, end = self._early
+            if self._early is not None:       # [lo_e, hi_e) is being reduced on RCCL's stream: reduce the pieces around it, then wait
+                lo_e, hi_e, works = self._early
                 self._early = None
                 if lo_e > 0:
-                    self._reduce(self.flat[:lo_e], "all_reduce")
+                    self._reduce(self.flat[:min(lo_e, hi)], "all_reduce")
                 if hi > hi_e:
                     self._reduce(self.flat[hi_e:hi], "all_reduce")
-                if work is not None:
-                    work.wait()               # the current stream waits for the collective's stream
-                if end is not None:
-                    end.record()
+                for work, end in works:
+                    if work is not None:
+                        work.wait()           # the current stream waits for the collective's stream
+                    if end is not None:
+                        end.record()
             else:
                 self._reduce(self.flat[:hi], "all_reduce")
             if average:
                 self.flat[:hi].div_(dist.get_world_size())
 
-    def all_reduce_early(self, indices: List[int]) -> None:
-        """Start the all-reduce of the parameters `indices` (contiguous in the flat buffer) NOW, asynchronously: RCCL runs it on its own
-        stream, ordered after what the current stream has enqueued so far, while the caller keeps launching kernels that do not touch those
-        gradients (the SH backward). `all_reduce()` later reduces the rest and waits. No-op at world 1."""
+    def all_reduce_early(self, indices: List[int], chunks: int = 1) -> None:
+        """Start the all-reduce of the parameters `indices` (contiguous in the flat buffer) NOW, asynchronously, in `chunks` collectives of equal size:
+        RCCL runs them on its own stream, ordered after what the current stream has enqueued so far, while the caller keeps launching kernels that do
+        not touch those gradients. `all_reduce()` later reduces the rest and waits. The replicated data-parallel step sends the SH gradients this way
+        (45 of 59 floats per Gaussian, final before the finish pass runs; several chunks so that the first bytes move while the last are still being
+        summed up by the ring). No-op at world 1."""
         if not _active() or self._early is not None:
             return
         lo = min(self.offsets[i] for i in indices)
         hi = max(self.offsets[i] + self.sizes[i] for i in indices)
         assert sum(self.sizes[i] for i in indices) == hi - lo, "early segment must be contiguous in the bucket"
-        work, end = self._reduce(self.flat[lo:hi], "all_reduce_early", async_op=True)
-        self._early = (lo, hi, work, end)
+        chunks = max(1, min(int(chunks), hi - lo))
+        step = -(-(hi - lo) // chunks)
+        works = []
+        for a in range(lo, hi, step):
+            works.append(self._reduce(self.flat[a:min(a + step, hi)], "all_reduce_early", async_op=True))
+        self._early = (lo, hi, works)
 
 
 def _staged(t: torch.Tensor) -> bool:

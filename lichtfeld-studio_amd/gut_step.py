@@ -161,17 +161,36 @@ class GutStep:
             self._grow(self.n_isects, self.longest)
         raise LfsError("gut_step: the view did not fit its workspace after 4 attempts")
 
-    def view_backward(self, params: Sequence[torch.Tensor], sh_degree: int, W: int, H: int, viewmat, Kmat, bg, grads: List[torch.Tensor], accumulate: bool, *,
-                      target_chw: Optional[torch.Tensor] = None, weight: float = 0.0, loss_acc: Optional[torch.Tensor] = None,
-                      v_render: Optional[torch.Tensor] = None, scale_reg: float = 0.0, opacity_reg: float = 0.0) -> None:
-        """Backward of the view view_forward() left in the workspace, into the six gradient tensors (group order)."""
+    def _backward_call(self, fn_name: str, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, v_render, scale_reg, opacity_reg):
         lib = load_library()
         a = self._args(params, sh_degree, W, H, viewmat, Kmat, bg, target_chw, weight, scale_reg, opacity_reg, loss_acc, None)
         for g in grads:
             if not g.is_cuda or not g.is_contiguous():
                 raise LfsError("gut_step: gradient tensors must be contiguous CUDA (HIP) tensors")
         gp = (C.c_void_p * 6)(*[g.data_ptr() if g.numel() else None for g in grads])
+        ws, nb = C.c_void_p(self.ws.data_ptr()), C.c_size_t(self.ws.numel())
+        if fn_name == "lfs_gut_view_backward_finish":
+            check(lib.lfs_gut_view_backward_finish(C.byref(a), C.c_int64(self.capacity), gp, C.c_int(int(accumulate)), ws, nb, stream()), fn_name)
+            return
         if v_render is not None:
             v_render = v_render.contiguous()
-        check(lib.lfs_gut_view_backward(C.byref(a), C.c_int64(self.capacity), C.c_void_p(v_render.data_ptr()) if v_render is not None else None, gp,
-                                        C.c_int(int(accumulate)), C.c_void_p(self.ws.data_ptr()), C.c_size_t(self.ws.numel()), stream()), "gut_view_backward")
+        check(getattr(lib, fn_name)(C.byref(a), C.c_int64(self.capacity), C.c_void_p(v_render.data_ptr()) if v_render is not None else None, gp,
+                                    C.c_int(int(accumulate)), ws, nb, stream()), fn_name)
+
+    def view_backward(self, params: Sequence[torch.Tensor], sh_degree: int, W: int, H: int, viewmat, Kmat, bg, grads: List[torch.Tensor], accumulate: bool, *,
+                      target_chw: Optional[torch.Tensor] = None, weight: float = 0.0, loss_acc: Optional[torch.Tensor] = None,
+                      v_render: Optional[torch.Tensor] = None, scale_reg: float = 0.0, opacity_reg: float = 0.0) -> None:
+        """Backward of the view view_forward() left in the workspace, into the six gradient tensors (group order): written, or added to with `accumulate`.
+        With target_chw the clamped MSE (weight) is folded into the backward and loss_acc += it; otherwise v_render [H,W,3] is dL/d(render)."""
+        self._backward_call("lfs_gut_view_backward", params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, v_render,
+                            scale_reg, opacity_reg)
+
+    def view_backward_sh(self, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, *, target_chw=None, weight=0.0, loss_acc=None, v_render=None) -> None:
+        """First half of view_backward: rasterizer backward + SH backward. grads[1] (sh0) and grads[2] (shN) are final for this view when it has run."""
+        self._backward_call("lfs_gut_view_backward_sh", params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, v_render, 0.0, 0.0)
+
+    def view_backward_finish(self, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, *, target_chw=None, weight=0.0, loss_acc=None,
+                             scale_reg: float = 0.0, opacity_reg: float = 0.0) -> None:
+        """Second half: accumulator rows + dL/d(dirs) -> grads[0], grads[3..5]; loss_acc += the fused MSE of the first half (when target_chw was given)."""
+        self._backward_call("lfs_gut_view_backward_finish", params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, None,
+                            scale_reg, opacity_reg)

@@ -297,6 +297,30 @@ class GutTrainer:
                                                                self.scale_reg, self.opacity_reg)
                 self._last_radii = self._gut_step.view("radii", torch.int32, (1, N, 2))
                 views_loop = []
+            elif (self.cxx_step and inline is None and self.sh_exchange is None and self.loss_kind == "mse" and self.bilateral is None and self.strategy is None
+                  and (self.world > 1 or len(views) == 1)):
+                # gradient-tensor form of the C++ step (data-parallel ranks with the north-star layout - replicated Gaussians, one all-reduce of the flat
+                # bucket - and single-rank steps while iteration <= 1000): per view one speculative forward + two backward calls, no host read in between.
+                # The SH backward runs BEFORE the finish pass, so on the last view the shN segment (45 of 59 floats per Gaussian at degree 3) is on the wire,
+                # in 4 chunks, while the finish kernel still runs; the remaining 14 floats follow in all_reduce() below.
+                from .gut_step import GutStep
+                if self._gut_step is None:
+                    self._gut_step = GutStep(self.device)
+                gs, sc = self._gut_step, self.scene
+                ps = [p.detach() for p in params]
+                deg, N = self.model.get_active_sh_degree(), self.model.means.shape[0]
+                for k, v in enumerate(views):
+                    vm, Km, tgt = sc.viewmats[v], sc.Ks[v], targets[k % len(targets)]
+                    self.last_n_isects = gs.view_forward(ps, deg, sc.width, sc.height, vm, Km, self.bg)
+                    gs.view_backward_sh(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=tgt, weight=1.0 / total_views,
+                                        loss_acc=self.loss_acc)
+                    if self.world > 1 and k == len(views) - 1 and self.iteration > 1000 and ps[2].numel():
+                        self.bucket.all_reduce_early([2], chunks=4)
+                    gs.view_backward_finish(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=tgt, weight=1.0 / total_views,
+                                            loss_acc=self.loss_acc, scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
+                                            opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0)
+                self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
+                views_loop = []
             elif self.batch_views and self.world == 1 and self.sh_exchange is None and len(views) > 1:
                 # several views per step on one rank: the SH stages run ONCE over all views (fused.render_views_and_backward), and shN's Adam update
                 # moves into that one SH backward when the optimizer would read the gradient anyway

@@ -278,6 +278,11 @@ def _worker_early(rank, world, port, q):
         b.all_reduce_early([3, 4, 5])          # scales, quats, opacities: contiguous [6N, 14N) of the flat buffer
         b.all_reduce(skip_deferred=skip)
         out[skip] = ([v.clone().numpy() for v in a.views], [v.clone().numpy() for v in b.views])
+    # the replicated data-parallel step of round 3: the shN segment [14N, 59N) first, in 4 chunks (45 N = 495 floats -> 124 + 124 + 124 + 123), then the rest
+    c = ld.GradBucket(params, deferred=[2]); c.gather(grads)
+    c.all_reduce_early([2], chunks=4)
+    c.all_reduce(skip_deferred=False)
+    out["shN_first"] = [v.clone().numpy() for v in c.views]
     st = ld.stats_collect()
     q.put((rank, out, st, ld.ranks_seen(torch.device("cpu"))))
     dist.destroy_process_group()
@@ -302,7 +307,9 @@ def test_early_segment_all_reduce_equals_the_single_collective():
             single, split = out[skip]
             for x, y in zip(single, split):
                 assert np.array_equal(x, y)
-        assert st["all_reduce_early"]["calls"] == 2 and st["all_reduce_early"]["bytes"] == 2 * 4 * 11 * 8
-        assert st["all_reduce"]["calls"] == 2 + 1 + 2   # two single collectives; the split ones: [0,6N) (+ [14N, 59N) when not skipped)
+        for x, y in zip(out[False][0], out["shN_first"]):
+            assert np.array_equal(x, y)
+        assert st["all_reduce_early"]["calls"] == 2 + 4 and st["all_reduce_early"]["bytes"] == 2 * 4 * 11 * 8 + 4 * 11 * 45
+        assert st["all_reduce"]["calls"] == 2 + 1 + 2 + 1   # two single collectives; the split ones: [0,6N) (+ [14N, 59N) when not skipped); [0,14N) behind the shN chunks
     assert np.array_equal(res[0][1][False][1][2], res[1][1][False][1][2])            # shN summed over both ranks
     assert not np.array_equal(res[0][1][True][1][2], res[1][1][True][1][2])          # ... and left local when deferred

@@ -22,14 +22,17 @@ def _scene():
     return sc
 
 
-def _worker(rank, world, port, sharded, q):
+def _worker(rank, world, port, sharded, q, backend="gloo"):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    rccl = backend == "nccl"       # one GPU per rank over RCCL (needs >= world devices); gloo: all ranks share cuda:0, collectives staged through the host
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if rccl else 0))
     import lichtfeld_studio_amd  # noqa: F401
     from lichtfeld_studio_amd import dist as ld, scenes
     from lichtfeld_studio_amd.trainer import GutTrainer
-    ld.init_distributed(backend="gloo")
-    dev = torch.device("cuda:0")
+    if rccl:
+        torch.cuda.set_device(rank)
+    ld.init_distributed(backend=backend)
+    dev = torch.device("cuda", rank if rccl else 0)
     sc = _scene()
     tr = GutTrainer(sc, dev, iterations=100, world=world, rank=rank, sh_sharded=sharded)
     tr.iteration = 1000           # past the shN warm-up: Adam updates shN, the replicated layout all-reduces it
@@ -43,14 +46,18 @@ def _worker(rank, world, port, sharded, q):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("sharded,world", [(True, 2), (False, 2), (True, 4)])
-def test_multi_rank_step_matches_single_process(lfs, sharded, world):
+@pytest.mark.parametrize("sharded,world,backend", [(True, 2, "gloo"), (False, 2, "gloo"), (True, 4, "gloo"), (False, 2, "nccl"), (True, 2, "nccl")])
+def test_multi_rank_step_matches_single_process(lfs, sharded, world, backend):
+    """backend "nccl" = RCCL with one GPU per rank: self-skips on a box with fewer GPUs than ranks (every box so far), so that the first multi-GPU box
+    that runs this suite exercises the real collectives of both layouts - the replicated one with its chunked early all-reduce of the SH gradients."""
     from lichtfeld_studio_amd import scenes
     from lichtfeld_studio_amd.trainer import GutTrainer
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        pytest.skip(f"RCCL needs one GPU per rank: {torch.cuda.device_count()} device(s) here, {world} ranks")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + int(sharded) + 3 * world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, sharded, q)) for r in range(world)]
+    port = 33500 + (os.getpid() % 2000) + int(sharded) + 3 * world + (11 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, sharded, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
