@@ -258,9 +258,17 @@ def main() -> None:
     if args.strategy == "mcmc":
         from lichtfeld_studio_amd import strategies
         extra = dict(strategy="mcmc", opt_params=strategies.OptimizationParameters(iterations=30000, max_cap=scene.N))
+    if args.path == "ops":
+        if world != 1 or args.rasterizer != "gut" or args.strategy != "none" or args.bilateral_grid:
+            raise SystemExit("--path ops measures the single-GPU 3DGUT drop-in route (no strategy, no bilateral grid)")
+        from lichtfeld_studio_amd import torch_ops_route
+        torch_ops_route.install()   # rasterizer.py / fused_adam.py now call the compiled reference-signature wrappers of _lfs_torch_ops.so
+
     def make_trainer(sh_sharded):
+        ops_route = args.path == "ops"   # op by op under torch autograd + six adam_step_wrapper launches: what the reference's own trainer would execute
         return GutTrainer(scene, device, iterations=30000 if args.strategy == "mcmc" else 7000, world=world, rank=rank, views_per_rank=args.views_per_rank,
-                          loss=args.loss, rasterizer=args.rasterizer, sh_sharded=sh_sharded, use_bilateral_grid=args.bilateral_grid, **extra)
+                          loss=args.loss, rasterizer=args.rasterizer, sh_sharded=sh_sharded, use_bilateral_grid=args.bilateral_grid,
+                          fused_l2=not ops_route, fused_adam=not ops_route, **extra)
     # N > 1: the HEADLINE is the north-star layout - replicated Gaussians, per-rank forward / backward, one all-reduce of the flat gradient bucket before the
     # fused Adam step ("dpN-replicated"). The SH-sharded layout (dist.ShExchange: shN and its Adam state owned by one rank each, 14 instead of 59 floats per
     # Gaussian in the all-reduce) is measured right after it and reported beside it under "sh_sharded"; --sh-sharded / --replicated restrict the run to one.
@@ -356,12 +364,19 @@ def main() -> None:
         # PMC-measured HBM traffic (separate rocprofv3 --pmc passes, see profiles/): filled when a
         # measurement for this exact workload has been committed.
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        lib_version = capi.load_library().lfs_version().decode()
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
+                measured_on = tj.get(f"{args.workload}:{N}", {}).get("_library")
+                if measured_on != lib_version:
+                    # counters of another build say nothing about this one: no number rather than a stale one
+                    roofline["traffic_note"] = f"profiles/traffic.json was measured on '{measured_on}', this run is '{lib_version}': traffic withheld (tools/profile.sh + tools/update_traffic.py refresh it)"
+                    tj = {}
                 ent = tj.get(f"{args.workload}:{N}", {}).get(dom)
                 if ent is not None:
                     roofline["traffic"] = ent
+                    roofline["traffic_measured_on"] = measured_on
                 # the rasterizer kernels are VALU-issue bound, not HBM bound: next to the HBM fraction, the share of the launch during which the
                 # vector ALUs were issuing, from the PMC pass (SQ_INSTS_VALU wave-instructions x 4 cycles on a SIMD16, 1024 SIMDs, 2.4 GHz)
                 valu = tj.get(f"{args.workload}:{N}", {}).get("_valu_insts", {}).get(dom)
@@ -400,7 +415,7 @@ def main() -> None:
                    "visible_gaussians": V, **({"visible_gaussians_source": v_source} if v_source else {}), "n_isects": I},
         "collectives": {"backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None), "ranks_seen": seen,
                         "per_step": {k: {"calls": v["calls"] / args.steps, "MB": round(v["bytes"] / args.steps / 1e6, 3), "ms": round(coll_ms.get(k, 0.0), 4)} for k, v in coll.items()}},
-        "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel, "library": capi.load_library().lfs_version().decode(),
         **({"sh_sharded": sharded_line} if sharded_line is not None else {}),
     }
     # C-level stdout first (RCCL prints its version banner through stdio; on a pipe that buffer would otherwise be flushed at exit, after our line):

@@ -41,8 +41,21 @@ SOURCES = {
     # load and defeats the software prefetch (measured on the ISA); plain v_fma with SGPR operands
     "raster.hip": ["-fno-slp-vectorize"],
     "gut_step.hip": [],   # host code only: the C++ training-step driver
+    "version.hip": [],    # lfs_version(): carries the hash of the sources (recompiled whenever any of them changed)
 }
 HEADERS = ["lfs_math.cuh", "lfs_adam.cuh", "lfs_camera.cuh", "lfs_prof.h", "lfs_raster_common.cuh", "lfs_cull_conic.cuh", "lfs_raster_pack.cuh", "lfs_tilelists.cuh", "lfs_fastgs.cuh", "lfs_step_internal.h", os.path.join("..", "..", "include", "lfs_gsplat.h")]
+
+
+def source_hash() -> str:
+    """sha1 (12 hex digits) over every file of csrc/ (version.hip excluded: it only carries the hash) and include/lfs_gsplat.h, in name order."""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh", ".h", ".cpp")) and f != "version.hip")
+    for f in files + [os.path.join("..", "..", "include", "lfs_gsplat.h")]:
+        h.update(os.path.basename(f).encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
 
 
 def _stale(obj: str, src: str) -> bool:
@@ -56,13 +69,22 @@ def _stale(obj: str, src: str) -> bool:
 def _compile(name: str, extra: list[str]) -> str:
     src = os.path.join(CSRC, name)
     obj = os.path.join(BUILD, name + ".o")
-    if _stale(obj, src):
+    stale = _stale(obj, src)
+    if name == "version.hip":
+        h = source_hash()
+        stamp = os.path.join(BUILD, "version.hash")
+        stale = stale or not os.path.exists(stamp) or open(stamp).read() != h
+        extra = [*extra, f'-DLFS_SRC_HASH="{h}"']
+    if stale:
         cmd = [HIPCC, *COMMON, *extra, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {name}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
         if r.stderr.strip():
             sys.stderr.write(r.stderr)
+        if name == "version.hip":
+            with open(os.path.join(BUILD, "version.hash"), "w") as fh:
+                fh.write(source_hash())
     return obj
 
 

@@ -112,4 +112,3 @@ extern "C" int lfs_adam_step_multi(const lfs_adam_tensor* tensors, int32_t n_ten
     return (int)hipGetLastError();
 }
 
-extern "C" const char* lfs_version(void) { return "lfs_gsplat gfx950 abi-1"; }
