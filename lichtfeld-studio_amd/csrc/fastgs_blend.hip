@@ -145,12 +145,19 @@ __global__ void __launch_bounds__(256) fg_blend_fwd_kernel(
     }
 }
 
+#ifndef LFS_FG_LDS_REDUCE
+#define LFS_FG_LDS_REDUCE 0   // the nine wave sums through an LDS transpose (lfs_raster_common.cuh), as the 3DGUT backward does with its sixteen
+#endif
 __global__ void __launch_bounds__(256) fg_blend_bwd_kernel(
     const uint32_t gw, const uint32_t gh, const uint32_t width, const uint32_t height,
     const GaussRec* __restrict__ recs, const int32_t* __restrict__ offsets, const int32_t* __restrict__ cell_count, const int2* __restrict__ cell_list,
     const float* __restrict__ alpha_map, const int32_t* __restrict__ n_contrib, const float* __restrict__ g_image, const float* __restrict__ g_alpha,
     float* __restrict__ acc) {
     const uint32_t total_tiles = gw * gh;
+#if LFS_FG_LDS_REDUCE
+    __shared__ float s_red[4 * 64 * RED9_STRIDE]; // one [64][9] transpose block per wavefront (wave_sum9_atomic_lds)
+    float* const red_scratch = s_red + (threadIdx.x >> 6) * (64 * RED9_STRIDE);
+#endif
     const CellCtx cc = cell_ctx(total_tiles, total_tiles, gw, TILE, 1, 4);
     if (!cc.in_grid) return;
     const uint32_t lane = threadIdx.x & 63;
@@ -194,11 +201,16 @@ __global__ void __launch_bounds__(256) fg_blend_bwd_kernel(
         const float hx = -aD * f.dx, hy = -aD * f.dy;
         // accumulator row: {sum hx, sum hy, sum hx dx, sum hx dy | sum hy dy, dc.r, dc.g, dc.b | sum alpha dL/dalpha}
         //   dL/dmean2d = conic . (sum hx, sum hy), dL/dconic = 0.5 (sum hx dx, sum hx dy, sum hy dy)   (fastgs_prep.hip)
-        const float v[8] = {hx, hy, hx * f.dx, hx * f.dy, hy * f.dy, w * gc0, w * gc1, w * gc2};
         float* row = acc + size_t(e.x) * ACC_STRIDE;
+#if LFS_FG_LDS_REDUCE
+        const float v[9] = {hx, hy, hx * f.dx, hx * f.dy, hy * f.dy, w * gc0, w * gc1, w * gc2, aD};
+        wave_sum9_atomic_lds(v, row, lane, red_scratch);
+#else
+        const float v[8] = {hx, hy, hx * f.dx, hx * f.dy, hy * f.dy, w * gc0, w * gc1, w * gc2};
         wave_sum8_atomic(v, row, lane);
         const float tot = wave_sum1(aD);
         if (lane == 0) unsafeAtomicAdd(row + 8, tot);
+#endif
     };
     walk_cell_list<-1>(cl, recs, lo - 1, lo, eval, []() { return true; });
 }

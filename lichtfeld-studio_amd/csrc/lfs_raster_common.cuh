@@ -270,6 +270,36 @@ LFS_DI void wave_sum16_atomic_lds(const v2f (&V)[8], float* __restrict__ dst, co
     }
 }
 
+// The EWA blend backward's NINE sums the same way (a [64][9] block: the odd stride is conflict-free for the row writes and for the column reads alike);
+// lanes 9..15 of every quarter read a duplicate column and are dropped at the atomic. Replaces wave_sum8_atomic + wave_sum1 + two atomics.
+constexpr int RED9_STRIDE = 9;
+LFS_DI void wave_sum9_atomic_lds(const float (&v)[9], float* __restrict__ dst, const uint32_t lane, float* __restrict__ scratch /* this wavefront's [64 * 9] */) {
+    float* wr = scratch + lane * RED9_STRIDE;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[k] = v[k];
+    LFS_WAVE_LOCKSTEP();
+#ifndef LFS_EMULATE
+    __builtin_amdgcn_wave_barrier();
+#endif
+    const uint32_t r = min(lane & 15u, 8u);
+    const float* rd = scratch + (lane >> 4) * (16 * RED9_STRIDE) + r;
+    float c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = rd[i * RED9_STRIDE];
+    LFS_WAVE_LOCKSTEP();
+#ifndef LFS_EMULATE
+    __builtin_amdgcn_wave_barrier();
+#endif
+    v2f p0 = v2f{c[0], c[1]} + v2f{c[2], c[3]}, p1 = v2f{c[4], c[5]} + v2f{c[6], c[7]}, p2 = v2f{c[8], c[9]} + v2f{c[10], c[11]}, p3 = v2f{c[12], c[13]} + v2f{c[14], c[15]};
+    p0 += p1; p2 += p3; p0 += p2;
+    float t = p0.x + p0.y;
+    auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    t = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+    auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    t = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+    if (lane < 9) unsafeAtomicAdd(dst + lane, t);
+}
+
 // 8 per-lane values -> 8 totals with one 8-lane atomic instruction (same halving scheme as wave_sum16_atomic: 18 VALU), and a
 // single value -> its total by a row butterfly + two cross-row folds (7 VALU). Used by the EWA blend backward (9 sums).
 LFS_DI void wave_sum8_atomic(const float (&v)[8], float* __restrict__ dst, const uint32_t lane) {

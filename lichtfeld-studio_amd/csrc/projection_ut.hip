@@ -15,7 +15,12 @@ namespace lfs {
 // ACT (fused training step): quats / scales / opacities are the RAW parameters; the kernel applies gs::SplatData's activations first (the arithmetic of
 // activations_fwd_kernel, l2_fused.hip: x / max(|x|, 1e-12), exp, sigmoid), stores the activated values (act_*) and projects those - bit for bit what the
 // two separate kernels compute. conics are not needed by the world-space rasterizer and not written then.
-template <bool ACT>
+// SIMPLE (round 3): the camera block is KNOWN to be an undistorted pinhole with a global shutter - what the trainer renders (rasterizer.cpp:176-181 with the
+// COLMAP PINHOLE / SIMPLE_PINHOLE models and every synthetic scene). The camera-model, distortion and shutter branches of lfs_camera.cuh - all wave-uniform,
+// but all compiled into the generic kernel: 125 VGPRs and ~70 000 lines of ISA for the worst case, a fisheye camera under a rolling shutter - become
+// compile-time constants and fold away; the arithmetic on the path that remains is untouched (same functions, no contraction: bit-identical outputs,
+// tests/test_gpu_projection_sh.py).
+template <bool ACT, bool SIMPLE = false>
 __global__ void __launch_bounds__(256) projection_ut_kernel(
     const uint32_t N,
     const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
@@ -31,7 +36,12 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
     const size_t idx = size_t(cid) * N + gid;
 
     CamDev cam;
-    cam_init(cam, cams, cid);
+    lfs_cameras cs = cams;
+    if (SIMPLE) {
+        cs.camera_model = LFS_CAMERA_PINHOLE; cs.rs_type = LFS_SHUTTER_GLOBAL; cs.viewmats1 = nullptr;
+        cs.radial_coeffs = nullptr; cs.tangential_coeffs = nullptr; cs.thin_prism_coeffs = nullptr; cs.n_radial = 0; cs.n_thin_prism = 0;
+    }
+    cam_init(cam, cs, cid);
 
     int32_t out_rx = 0, out_ry = 0;
     float o_m2x = 0.f, o_m2y = 0.f, o_depth = 0.f, o_c0 = 0.f, o_c1 = 0.f, o_c2 = 0.f, o_comp = 0.f;
@@ -138,6 +148,10 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
 
 } // namespace lfs
 
+static bool simple_camera(const lfs_cameras* c) {
+    return c->camera_model == LFS_CAMERA_PINHOLE && c->rs_type == LFS_SHUTTER_GLOBAL && !c->viewmats1 && !c->radial_coeffs && !c->tangential_coeffs && !c->thin_prism_coeffs;
+}
+
 extern "C" int lfs_projection_ut_3dgs_fused(
     uint32_t N, const float* means, const float* quats, const float* scales, const float* opacities,
     const lfs_cameras* cams, float eps2d, float near_plane, float far_plane, float radius_clip,
@@ -152,9 +166,14 @@ extern "C" int lfs_projection_ut_3dgs_fused(
     if (ut_params) ut = *ut_params;
     dim3 grid((N + 255) / 256, cams->C);
     lfs::ProfScope prof("projection_ut", (hipStream_t)stream);
-    hipLaunchKernelGGL(lfs::projection_ut_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
-                       N, means, quats, scales, opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
-                       radii, means2d, depths, conics, compensations, nullptr, nullptr, nullptr);
+    if (simple_camera(cams))
+        hipLaunchKernelGGL((lfs::projection_ut_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                           N, means, quats, scales, opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
+                           radii, means2d, depths, conics, compensations, nullptr, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((lfs::projection_ut_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream,
+                           N, means, quats, scales, opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
+                           radii, means2d, depths, conics, compensations, nullptr, nullptr, nullptr);
     return (int)hipGetLastError();
 }
 
@@ -170,8 +189,13 @@ extern "C" int lfs_activations_project_ut(
     if (ut_params) ut = *ut_params;
     dim3 grid((N + 255) / 256, cams->C);
     lfs::ProfScope prof("activations_projection_ut", (hipStream_t)stream);
-    hipLaunchKernelGGL(lfs::projection_ut_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
-                       N, means, raw_quats, raw_scales, raw_opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
-                       radii, means2d, depths, nullptr, nullptr, quats, scales, opacities);
+    if (simple_camera(cams))
+        hipLaunchKernelGGL((lfs::projection_ut_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                           N, means, raw_quats, raw_scales, raw_opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
+                           radii, means2d, depths, nullptr, nullptr, quats, scales, opacities);
+    else
+        hipLaunchKernelGGL((lfs::projection_ut_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream,
+                           N, means, raw_quats, raw_scales, raw_opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
+                           radii, means2d, depths, nullptr, nullptr, quats, scales, opacities);
     return (int)hipGetLastError();
 }

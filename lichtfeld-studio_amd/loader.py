@@ -321,11 +321,12 @@ def read_ply(path: str) -> Tuple[List[str], np.ndarray]:
         lib.lfs_ply_close(h)
 
 
-def load_ply(path: str, device="cuda:0", active_sh_degree: Optional[int] = 0):
+def load_ply(path: str, device="cuda:0", active_sh_degree: Optional[int] = None):
     """load_ply (src/loader/formats/ply.cpp:497-640) -> SplatModel, held to the reference's reader run on the CPU (tests/test_loader_reference.py).
     Columns that the file lacks get the reference's defaults (:531-600): sh0 zeros [N,1,3]; shN zeros [N,15,3] (degree 3); opacity 0; log-scale -5 when there
-    is no scale_0; the identity quaternion (1,0,0,0) when there is no rot_0. SH degree from the shN width; the model starts at active degree 0, as the SplatData
-    the reference constructs does (splat_data.cpp:211; its viewer sets the degree per request) - pass active_sh_degree=None for the maximum."""
+    is no scale_0; the identity quaternion (1,0,0,0) when there is no rot_0. SH degree from the shN width. A LOADED model evaluates every degree it holds
+    (active_sh_degree=None: evaluation / rendering of a trained file is what a caller expects; the SplatData the reference constructs starts at 0,
+    splat_data.cpp:211, and its viewer / trainer set the degree per request - a resume path that wants that passes active_sh_degree=0)."""
     from .rasterizer import SplatModel
     names, data = read_ply(path)
     col = {n: i for i, n in enumerate(names)}

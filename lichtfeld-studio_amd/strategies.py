@@ -305,10 +305,6 @@ class DefaultStrategy(_StrategyBase):
         scales = torch.exp(raw_scales)
         is_small = scales.max(-1).values <= p.grow_scale3d * self.scene_scale
         is_dup, is_split = is_grad_high & is_small, is_grad_high & ~is_small
-        # what the children of every row would be (used where the row is split)
-        rotmats = ops.quats_to_rotmats(torch.nn.functional.normalize(raw_quats, dim=-1).contiguous())
-        rnd = rnd_full if rnd_full is not None else torch.randn((2, N, 3), device=self.device, dtype=scales.dtype, generator=self.generator)
-        child_means = means.unsqueeze(0) + _split_samples(rotmats, scales, rnd)
         child_raw_scales = torch.log(scales / 1.6)
         child_raw_opac = torch.logit(1.0 - torch.sqrt(1.0 - torch.sigmoid(raw_opac))) if p.revised_opacity else raw_opac
 
@@ -317,19 +313,35 @@ class DefaultStrategy(_StrategyBase):
             if it > p.reset_every:
                 out = out | (torch.exp(rs).max(-1).values > p.prune_scale3d * self.scene_scale)
             return out
+        if N == 0:
+            return
         keep_parent, keep_child = ~pruned(raw_opac, raw_scales), ~pruned(child_raw_opac, child_raw_scales)
         flags = torch.stack([~is_split & keep_parent, is_dup & keep_parent, is_split & keep_child, is_split & keep_child]).reshape(-1)
         inc = torch.cumsum(flags.to(torch.int64), 0)
-        total = int(inc[-1])                                  # the one host read of the refinement step
+        split_inc = torch.cumsum(is_split.to(torch.int64), 0)
+        total, n_split = (int(x) for x in torch.stack([inc[-1], split_inc[-1]]).tolist())   # the ONE host read of the refinement step: new count + split count
+        if total == 0:
+            self._remove(torch.ones(N, dtype=torch.bool, device=self.device))
+            return
+        # the children of the split rows only: the normal deviates are drawn for exactly those rows, [2, n_split, 3] in row order - the draw of the
+        # reference's split() (default_strategy.cpp:100-104) and of grow_gs above, so the generator stream is the same on both paths for the same seed.
+        # rnd_full (tests): deviates per ORIGINAL row. nonzero_static: the size is known from the read above, no second synchronisation.
+        sidx = torch.nonzero_static(is_split, size=n_split).reshape(-1)
+        if rnd_full is not None:
+            rnd = rnd_full.index_select(1, sidx)
+        else:
+            rnd = torch.randn((2, n_split, 3), device=self.device, dtype=scales.dtype, generator=self.generator)
+        rotmats = ops.quats_to_rotmats(torch.nn.functional.normalize(raw_quats.index_select(0, sidx), dim=-1).contiguous()) if n_split else means.new_zeros((0, 3, 3))
+        child_means = means.index_select(0, sidx).unsqueeze(0) + _split_samples(rotmats, scales.index_select(0, sidx), rnd)      # [2, n_split, 3]
         k = torch.searchsorted(inc, torch.arange(total, device=self.device), right=True)   # output slot -> flat (category, row)
         cat, row = torch.div(k, N, rounding_mode="floor"), k % N
         is_child, is_old = cat >= 2, cat == 0
-        child_slot = (cat - 2).clamp_min(0) * N + row
+        child_slot = ((cat - 2).clamp_min(0) * n_split + (split_inc.index_select(0, row) - 1).clamp_min(0)).clamp_max(max(2 * n_split - 1, 0))
 
         def param_fn(i, t):
             new = t.index_select(0, row)
-            if i == 0:
-                new = torch.where(is_child.unsqueeze(-1), child_means.reshape(2 * N, 3).index_select(0, child_slot), new)
+            if i == 0 and n_split:
+                new = torch.where(is_child.unsqueeze(-1), child_means.reshape(2 * n_split, 3).index_select(0, child_slot), new)
             elif i == 3:
                 new = torch.where(is_child.unsqueeze(-1), child_raw_scales.index_select(0, row), new)
             elif i == 5:

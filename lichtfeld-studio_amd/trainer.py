@@ -232,7 +232,8 @@ class GutTrainer:
     def export_model(self) -> SplatModel:
         """The complete model on this rank (SH-sharded: shN all-gathered; every rank must call it): what loader.save_ply / evaluate.evaluate take."""
         m = self.model
-        out = SplatModel(m.means.detach(), m.sh0.detach(), self.full_shN(), m.raw_scales.detach(), m.raw_quats.detach(), m.raw_opacities.detach(), m.active_sh_degree)
+        out = SplatModel(m.means.detach(), m.sh0.detach(), self.full_shN(), m.raw_scales.detach(), m.raw_quats.detach(), m.raw_opacities.detach(), m.max_sh_degree,
+                         active_sh_degree=m.active_sh_degree)
         return out
 
     def camera(self, view: int) -> Camera:
@@ -240,11 +241,17 @@ class GutTrainer:
         return Camera(sc.viewmats[view:view + 1].contiguous(), sc.Ks[view:view + 1].contiguous(), sc.width, sc.height)
 
     def train_step(self, targets: List[torch.Tensor], views: Optional[List[int]] = None, views_all: Optional[List[List[int]]] = None) -> float:
+        out = self._train_step(targets, views, views_all)
+        # the SH schedule, AFTER the backward / optimizer step of the iteration, where the strategies keep it (post_backward: mcmc.cpp:366-368,
+        # default_strategy.cpp) - iteration 1000, 2000, ... still renders with the old degree, as the reference does; without a strategy the trainer does it
+        if self.strategy is None and self.iteration % self.sh_degree_interval == 0 and self.model.active_sh_degree < self.model.max_sh_degree:
+            self.model.active_sh_degree += 1
+        return out
+
+    def _train_step(self, targets: List[torch.Tensor], views: Optional[List[int]] = None, views_all: Optional[List[List[int]]] = None) -> float:
         """One optimisation step on this rank's share of the global view batch. `views` overrides this rank's views of the round-robin
         schedule; SH-sharded, the owners must know every rank's views: pass `views_all` (one list per rank) with an explicit schedule."""
         self.iteration += 1
-        if self.strategy is None and self.iteration % self.sh_degree_interval == 0 and self.model.active_sh_degree < self.model.max_sh_degree:
-            self.model.active_sh_degree += 1   # the strategies do this in post_backward (mcmc.cpp:366-368); without one the trainer keeps the schedule
         if views_all is not None:
             views = views_all[self.rank]
         elif views is not None and self.sh_exchange is not None and self.world > 1:

@@ -186,8 +186,8 @@ def test_ply_write_matches_reference_layout_and_reads_back(ld, tmp_path):
     for name, x, y in zip(["means", "sh0", "shN", "scales", "quats", "opac"], back.parameters(), [t["means"], t["sh0"], t["shN"], t["scales"],
                                                                                                  torch.nn.functional.normalize(t["quats"], dim=-1), t["opac"]]):
         assert x.shape == y.shape and torch.allclose(x.detach(), y, atol=1e-7), name
-    assert back.get_active_sh_degree() == 0 and back.max_sh_degree == 2          # a loaded model starts at degree 0, like the reference's SplatData
-    assert ld.load_ply(path, device="cpu", active_sh_degree=None).get_active_sh_degree() == 2
+    assert back.get_active_sh_degree() == 2 and back.max_sh_degree == 2          # a LOADED model evaluates every degree it holds (evaluation / rendering of a trained file)
+    assert ld.load_ply(path, device="cpu", active_sh_degree=0).get_active_sh_degree() == 0     # ... a resume path asks for the reference's SplatData start (splat_data.cpp:211)
     # generic reader: ascii, mixed types, an element after the vertices, doubles
     p2 = str(tmp_path / "mixed.ply")
     open(p2, "w").write("ply\nformat ascii 1.0\ncomment hi\nelement vertex 2\nproperty double x\nproperty float y\nproperty uchar red\nelement face 1\n"

@@ -288,8 +288,11 @@ def test_product_ply_reader_equals_the_reference_reader(ld, tmp_path, name):
         assert got.reshape(-1).shape == ref.reshape(-1).shape and np.array_equal(got.reshape(-1), ref.reshape(-1)), (name, key, got.shape, ref.shape)
         if key != "opacity":                                     # (SplatModel holds opacity as [N], SplatData as [N,1])
             assert got.shape == ref.shape, (name, key)
-    assert m.get_active_sh_degree() == int(g("sh_degree")) == 0
     assert m.max_sh_degree == int(np.sqrt(g("shN").shape[1] + 1)) - 1
+    # the degree a model starts at: the SplatData the reference constructs from the file starts at 0 (splat_data.cpp:211) - what a resume path asks for with
+    # active_sh_degree=0; the product's default for a LOADED file is every degree it holds (evaluation / rendering; round-2 advisor finding)
+    assert ld.load_ply(path, device="cpu", active_sh_degree=0).get_active_sh_degree() == int(g("sh_degree")) == 0
+    assert m.get_active_sh_degree() == m.max_sh_degree
 
 
 @pytest.mark.skipif(not oracle.have_ref("libref_ply.so"), reason="oracle/_ref/libref_ply.so not built (needs /root/reference)")

@@ -26,7 +26,7 @@ def _model(N, seed=0):
     return SplatModel(mk(sc.means), mk(sc.sh0), mk(sc.shN), mk(raw_s), mk(raw_q), mk(raw_o), 1)
 
 
-def _run(fused, it, n_high, monkeypatch):
+def _run(fused, it, n_high, monkeypatch, inject=True):
     from lichtfeld_studio_amd import strategies
     monkeypatch.setattr(strategies.ops, "quats_to_rotmats", _q2r)
     N = 3000
@@ -39,7 +39,7 @@ def _run(fused, it, n_high, monkeypatch):
     info = torch.zeros(2, N)
     info[0] = 4.0
     info[1, :n_high] = 4e-3                                   # a high average screen-space gradient: duplicated (small) or split (large)
-    rnd = torch.randn(2, N, 3, generator=torch.Generator().manual_seed(9))
+    rnd = torch.randn(2, N, 3, generator=torch.Generator().manual_seed(9)) if inject else None   # None: each path draws from the strategy's own generator
     if fused:
         st.grow_and_prune_fused(it, info, rnd)
     else:
@@ -56,3 +56,12 @@ def test_fused_refinement_equals_the_reference_sequence(monkeypatch):
         assert a[0].shape[0] != 3000 or n_high == 0
         for x, y in zip(a, b):
             assert x.shape == y.shape and torch.equal(x, y), (it, n_high, x.shape, y.shape)
+
+
+def test_fused_refinement_consumes_the_generator_like_the_reference_sequence(monkeypatch):
+    """Without injected deviates both paths draw [2, n_split, 3] from the strategy's generator - the draw of the reference's split()
+    (default_strategy.cpp:100-104): the same seed gives the same model on both paths (round-2 advisor finding: the fused path drew [2, N, 3])."""
+    for it, n_high in ((700, 900), (700, 3000)):
+        a, b = _run(False, it, n_high, monkeypatch, inject=False), _run(True, it, n_high, monkeypatch, inject=False)
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.equal(x, y), (it, n_high)

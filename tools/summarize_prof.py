@@ -25,7 +25,7 @@ for f in find("trace/**/*kernel_trace.csv"):
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:40]:
         print(f"{k:60s} calls {len(v):5d} avg {sum(v)/len(v):10.2f} total {sum(v):12.1f} {100*sum(v)/tot:5.1f}%")
 
-for tag in ["pmc_fetch", "pmc_write", "pmc_sq"]:
+for tag in ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"]:
     for f in find(f"{tag}/**/*counter_collection.csv"):
         acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
         seen = set()
