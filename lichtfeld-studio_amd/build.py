@@ -26,7 +26,10 @@ SOURCES = {
     "projection_ut.hip": ["-ffp-contract=off"],
     # LFS_SH_DPP_SUM: the 16-lane sums as DPP row operations instead of ds_bpermute - bit-identical sums (tests/test_emulated_sh.py),
     # GPU-verified in round 2 (tests/test_gpu_projection_sh.py + test_gpu_fused.py green on the variant build; sh_fwd 0.0755 -> 0.0704 ms)
-    "sh.hip": ["-ffp-contract=off", "-DLFS_SH_DPP_SUM"],
+    # -fno-slp-vectorize (round 3): the SLP vectorizer pairs the three colour channels' group sums into v_pk_add_f32, which keeps the DPP moves from folding into the
+    # adds and, in the operator form of the forward kernel (sh_fwd_kernel<16, false>), blew the allocation up to 508 VGPRs + AGPR spills: 0.23 ms per launch at 1M
+    # Gaussians against 0.04 for the model form (tools/bench_sh_ops.py). Without it: 71 VGPRs; every other kernel of the file needs fewer registers as well.
+    "sh.hip": ["-ffp-contract=off", "-DLFS_SH_DPP_SUM", "-fno-slp-vectorize"],
     "intersect.hip": ["-ffp-contract=off"],
     "mcmc.hip": ["-ffp-contract=off"],
     "adam.hip": ["-ffp-contract=off"],

@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(256) fg_blend_fwd_kernel(
 }
 
 #ifndef LFS_FG_LDS_REDUCE
-#define LFS_FG_LDS_REDUCE 0   // the nine wave sums through an LDS transpose (lfs_raster_common.cuh), as the 3DGUT backward does with its sixteen
+#define LFS_FG_LDS_REDUCE 1   // the nine wave sums through an LDS transpose (lfs_raster_common.cuh), as the 3DGUT backward does with its sixteen. Same-box A/B x2
+                              // (profiles/r03/fastgs_blend_bwd_lds_reduce_ab.txt): fastgs_blend_bwd 0.452 - 0.457 -> 0.391 - 0.395 ms; 0 = register swaps + DPP
 #endif
 __global__ void __launch_bounds__(256) fg_blend_bwd_kernel(
     const uint32_t gw, const uint32_t gh, const uint32_t width, const uint32_t height,
