@@ -257,6 +257,85 @@ void adam_step_wrapper(torch::Tensor& param, torch::Tensor& exp_avg, torch::Tens
 } // namespace fast_gs::optimizer
 
 // ---------------------------------------------------------------------------------------------------------
+// lfs::GutTrainStep: the C++ training step (csrc/gut_step.hip) for a libtorch caller
+// ---------------------------------------------------------------------------------------------------------
+namespace lfs {
+GutTrainStep::GutTrainStep(uint32_t tile_size, int64_t initial_capacity) : tile_(tile_size), capacity_(initial_capacity) {}
+
+void GutTrainStep::ensure(uint32_t N, uint32_t W, uint32_t H, const torch::Tensor& like) {
+    if (capacity_ <= 0) capacity_ = std::max<int64_t>(4 * int64_t(N), 1 << 16);   // first guess; the first step corrects it
+    const uint32_t flags = lfs_get_debug_flags();
+    if (ws_.defined() && N == N_ && W == W_ && H == H_ && cap_built_ == capacity_ && flags == flags_) return;
+    lfs_gut_step_layout lay{};
+    check_rc(lfs_gut_step_layout_for(N, W, H, tile_, capacity_, &lay), "gut_step_layout_for");
+    if (!ws_.defined() || (size_t)ws_.numel() < lay.bytes || ws_.device() != like.device()) {
+        ws_ = at::Tensor();   // release the old block before the larger one is requested
+        ws_ = at::empty({(int64_t)lay.bytes}, like.options().dtype(at::kByte));
+    }
+    if (!counts_.defined()) counts_ = at::zeros({3}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    N_ = N; W_ = W; H_ = H; cap_built_ = capacity_; flags_ = flags;
+    off_render_ = lay.render; off_alpha_ = lay.alpha; off_radii_ = lay.radii; ws_bytes_ = lay.bytes;
+}
+
+int64_t GutTrainStep::step(torch::Tensor& means, torch::Tensor& sh0, torch::Tensor& shN, torch::Tensor& raw_scales, torch::Tensor& raw_quats,
+                           torch::Tensor& raw_opacities, const std::array<AdamGroupState, 6>& adam, uint32_t sh_degree, const torch::Tensor& viewmat,
+                           const torch::Tensor& K, uint32_t image_width, uint32_t image_height, const at::optional<torch::Tensor>& background,
+                           const torch::Tensor& target_chw, float loss_weight, torch::Tensor& loss, float scale_reg, float opacity_reg) {
+    LFS_DEVICE_GUARD(means);
+    LFS_CHECK_INPUT(means); LFS_CHECK_INPUT(sh0); LFS_CHECK_INPUT(shN); LFS_CHECK_INPUT(raw_scales); LFS_CHECK_INPUT(raw_quats); LFS_CHECK_INPUT(raw_opacities);
+    LFS_CHECK_INPUT(viewmat); LFS_CHECK_INPUT(K); LFS_CHECK_INPUT(target_chw); LFS_CHECK_INPUT(loss);
+    TORCH_CHECK(shN.dim() == 3 && shN.size(1) > 0, "GutTrainStep needs higher-degree SH coefficients (shN [N,K-1,3], K > 1)");
+    TORCH_CHECK(target_chw.numel() == 3 * int64_t(image_width) * image_height, "target must be [3,H,W]");
+    const uint32_t N = (uint32_t)means.size(0);
+    lfs_gut_step_args a{};
+    a.N = N; a.K = 1 + (uint32_t)shN.size(1); a.sh_degree = sh_degree; a.image_width = image_width; a.image_height = image_height; a.tile_size = tile_;
+    a.means = means.data_ptr<float>(); a.sh0 = sh0.data_ptr<float>(); a.shN = shN.data_ptr<float>();
+    a.raw_scales = raw_scales.data_ptr<float>(); a.raw_quats = raw_quats.data_ptr<float>(); a.raw_opacities = raw_opacities.data_ptr<float>();
+    for (int k = 0; k < 6; ++k) {
+        LFS_CHECK_INPUT(adam[k].exp_avg); LFS_CHECK_INPUT(adam[k].exp_avg_sq);
+        a.exp_avg[k] = adam[k].exp_avg.data_ptr<float>(); a.exp_avg_sq[k] = adam[k].exp_avg_sq.data_ptr<float>();
+        const float sc[6] = {adam[k].lr, adam[k].beta1, adam[k].beta2, adam[k].eps, adam[k].bias_correction1_rcp, adam[k].bias_correction2_sqrt_rcp};
+        for (int j = 0; j < 6; ++j) a.adam[k][j] = sc[j];
+    }
+    a.viewmat = viewmat.data_ptr<float>(); a.Kmat = K.data_ptr<float>();
+    a.background = opt_ptr<float>(background); a.target_chw = target_chw.data_ptr<float>();
+    a.loss_weight = loss_weight; a.scale_reg = scale_reg; a.opacity_reg = opacity_reg; a.loss = loss.data_ptr<float>();
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        ensure(N, image_width, image_height, means);
+        ++stamp_;
+        int64_t* counts = counts_.data_ptr<int64_t>();
+        check_rc(lfs_gut_train_step(&a, capacity_, assumed_longest_, ws_.data_ptr(), (size_t)ws_.numel(), counts, stamp_, cur_stream()), "gut_train_step");
+        // the counts were written by the scan kernel early in the step: by now they have long arrived (no GPU idle time behind this wait)
+        check_rc(lfs_gut_step_wait(counts, stamp_, 30.0, &n_isects_, &longest_), "gut_step_wait");
+        if (lfs_gut_step_fits(n_isects_, longest_, capacity_, assumed_longest_)) {
+            if (double(n_isects_) > 0.92 * double(capacity_)) capacity_ = int64_t(double(n_isects_) * 1.25) + 1024;   // stay ahead of a growing scene
+            const int64_t limit = assumed_longest_ <= 1024 ? 1024 : assumed_longest_ <= 4096 ? 4096 : assumed_longest_ <= 16384 ? 16384 : (int64_t(1) << 62);
+            if (double(longest_) > 0.92 * double(limit)) assumed_longest_ = std::max<int64_t>(assumed_longest_, int64_t(double(longest_) * 1.25));
+            return n_isects_;
+        }
+        ++retries_;
+        capacity_ = std::max<int64_t>(capacity_, int64_t(double(n_isects_) * 1.25) + 1024);
+        assumed_longest_ = std::max<int64_t>(assumed_longest_, int64_t(double(longest_) * 1.25));
+    }
+    TORCH_CHECK(false, "GutTrainStep: the step did not fit its workspace after 4 attempts");
+    return -1;
+}
+
+torch::Tensor GutTrainStep::render() const {
+    TORCH_CHECK(ws_.defined(), "no step has run");
+    return ws_.narrow(0, (int64_t)off_render_, int64_t(12) * W_ * H_).view(at::kFloat).view({(int64_t)H_, (int64_t)W_, 3});
+}
+torch::Tensor GutTrainStep::alpha() const {
+    TORCH_CHECK(ws_.defined(), "no step has run");
+    return ws_.narrow(0, (int64_t)off_alpha_, int64_t(4) * W_ * H_).view(at::kFloat).view({(int64_t)H_, (int64_t)W_});
+}
+torch::Tensor GutTrainStep::radii() const {
+    TORCH_CHECK(ws_.defined(), "no step has run");
+    return ws_.narrow(0, (int64_t)off_radii_, int64_t(8) * N_).view(at::kInt).view({(int64_t)N_, 2});
+}
+} // namespace lfs
+
+// ---------------------------------------------------------------------------------------------------------
 // fast_gs::rasterization (rasterization_api.h:27-75, src/rasterization_api.cu) and fusedssim (ssim.cuh:11-30)
 // ---------------------------------------------------------------------------------------------------------
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, int, int, int, int, int>

@@ -62,6 +62,23 @@ PYBIND11_MODULE(_lfs_torch_ops, m) {
                                                               sh_rest, prim, tile, inst, bucket, w2c, cam_position, active_sh_bases, width, height, fx, fy,
                                                               cx, cy, near_plane, far_plane, n_visible, n_instances, n_buckets, sel0, sel1);
           });
+    // lfs::GutTrainStep: params / exp_avg / exp_avg_sq as lists of six tensors (FusedAdam group order), scalars [6][6] = lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp
+    py::class_<lfs::GutTrainStep>(m, "GutTrainStep")
+        .def(py::init<uint32_t, int64_t>(), py::arg("tile_size") = 16, py::arg("initial_capacity") = 0)
+        .def("step", [](lfs::GutTrainStep& self, std::vector<at::Tensor> params, std::vector<at::Tensor> exp_avg, std::vector<at::Tensor> exp_avg_sq,
+                        std::vector<std::vector<float>> scalars, uint32_t sh_degree, at::Tensor viewmat, at::Tensor K, uint32_t W, uint32_t H, OptT background,
+                        at::Tensor target, float weight, at::Tensor loss, float scale_reg, float opacity_reg) {
+            TORCH_CHECK(params.size() == 6 && exp_avg.size() == 6 && exp_avg_sq.size() == 6 && scalars.size() == 6, "six parameter groups");
+            std::array<lfs::AdamGroupState, 6> ad;
+            for (int k = 0; k < 6; ++k) {
+                TORCH_CHECK(scalars[k].size() == 6, "six Adam scalars per group");
+                ad[k] = lfs::AdamGroupState{exp_avg[k], exp_avg_sq[k], scalars[k][0], scalars[k][1], scalars[k][2], scalars[k][3], scalars[k][4], scalars[k][5]};
+            }
+            return self.step(params[0], params[1], params[2], params[3], params[4], params[5], ad, sh_degree, viewmat, K, W, H, background, target, weight, loss,
+                             scale_reg, opacity_reg);
+        })
+        .def("render", &lfs::GutTrainStep::render).def("alpha", &lfs::GutTrainStep::alpha).def("radii", &lfs::GutTrainStep::radii)
+        .def("retries", &lfs::GutTrainStep::retries).def("capacity", &lfs::GutTrainStep::capacity);
     m.def("fusedssim", [](float C1, float C2, at::Tensor a, at::Tensor b, bool train) { return fusedssim(C1, C2, a, b, train); });
     m.def("fusedssim_backward", [](float C1, float C2, at::Tensor a, at::Tensor b, at::Tensor g, at::Tensor d1, at::Tensor d2, at::Tensor d3) {
         return fusedssim_backward(C1, C2, a, b, g, d1, d2, d3);

@@ -183,3 +183,45 @@ def test_drop_in_route_training_step_equals_the_python_mirror(lfs):
         tol = 2e-3 * float(upd) + 1e-7   # (elements whose gradient is pure rounding noise may step the other way: allow 0.1 % of them, as tests/test_gpu_dp2.py does)
         assert float(((pa - pc).abs() > tol).float().mean()) < 1e-3, (name, float((pa - pc).abs().max()), tol)
     assert abs(la[-1] - lc[-1]) <= 1e-5 * abs(la[-1])
+
+
+@pytest.mark.gpu
+def test_cxx_gut_train_step_class_equals_the_python_driver(lfs):
+    """lfs::GutTrainStep (include/lfs_gsplat_torch.hpp: the training step as one call for a libtorch C++ caller - what INTEGRATION.md patches into
+    Trainer::train_step) against gut_step.GutStep.train_step: both enqueue lfs_gut_train_step, so with the deterministic rasterizer sums parameters, moments and
+    loss agree BIT FOR BIT over several steps - including a first attempt that overflows its deliberately small workspace and is re-run."""
+    m = _mod()
+    from lichtfeld_studio_amd import scenes
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    dev = "cuda:0"
+    sc = scenes.syn_a(n=5000, sh_degree=2)
+    target = torch.rand(3, sc.height, sc.width, generator=torch.Generator().manual_seed(13)).to(dev) * 0.7
+    lib = lfs.load_library()
+    names = ["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"]
+    try:
+        lib.lfs_set_debug_flags(16)
+        a = GutTrainer(sc, dev, iterations=7000)      # Python driver (ctypes -> lfs_gut_train_step)
+        b = GutTrainer(sc, dev, iterations=7000)      # same optimizer bookkeeping, the step itself through the C++ class
+        a.iteration = b.iteration = 1500
+        step = m.GutTrainStep(16, 1000)                # 1000 entries: the first attempt cannot fit
+        loss_b = torch.zeros(1, device=dev)
+        for _ in range(3):
+            la = a.train_step([target], views=[0])
+            b.iteration += 1
+            ad = [b.optimizer.prepare_inline(getattr(b.model, k)) for k in names]
+            params = [p.detach() for p in b.model.parameters()]
+            n_isects = step.step(params, [d["exp_avg"] for d in ad], [d["exp_avg_sq"] for d in ad],
+                                 [[d["lr"], d["beta1"], d["beta2"], d["eps"], d["bc1_rcp"], d["bc2_sqrt_rcp"]] for d in ad], b.model.get_active_sh_degree(),
+                                 b.scene.viewmats[0], b.scene.Ks[0], sc.width, sc.height, b.bg, target, 1.0, loss_b, 0.0, 0.0)
+            b.optimizer.step(b.iteration)      # (every group was updated inline: nothing left to do but the bookkeeping)
+            b.scheduler.step()
+        torch.cuda.synchronize()
+    finally:
+        lib.lfs_set_debug_flags(0)
+    assert step.retries() >= 1 and n_isects == a.last_n_isects > 0
+    assert float(la) == float(loss_b)
+    assert tuple(step.render().shape) == (sc.height, sc.width, 3) and tuple(step.radii().shape) == (5000, 2)
+    for name, pa, pb in zip(names, a.model.parameters(), b.model.parameters()):
+        assert torch.equal(pa, pb), (name, float((pa - pb).abs().max()))
+        sa, sb = a.optimizer.state[id(pa)], b.optimizer.state[id(pb)]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), name
