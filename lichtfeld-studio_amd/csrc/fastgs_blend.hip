@@ -106,12 +106,13 @@ LFS_DI Frag frag_eval(const GaussRec& rec, const float px, const float py) {
     return f;
 }
 
-__global__ void __launch_bounds__(256) fg_blend_fwd_kernel(
+// fwd / bwd: ONE wavefront per workgroup (the cells of a tile never cooperate here; a finished cell frees its slot at once - as raster.hip's wave_geom)
+__global__ void __launch_bounds__(64) fg_blend_fwd_kernel(
     const uint32_t gw, const uint32_t gh, const uint32_t width, const uint32_t height,
     const GaussRec* __restrict__ recs, const int32_t* __restrict__ offsets, const int32_t* __restrict__ cell_count, const int2* __restrict__ cell_list,
     float* __restrict__ image, float* __restrict__ alpha_map, int32_t* __restrict__ n_contrib) {
     const uint32_t total_tiles = gw * gh;
-    const CellCtx cc = cell_ctx(total_tiles, total_tiles, gw, TILE, 1, 4);
+    const CellCtx cc = cell_ctx(total_tiles, total_tiles, gw, TILE, WPT, 1);
     if (!cc.in_grid) return;
     const bool inside = cc.i < height && cc.j < width;
     const float px = float(cc.j) + 0.5f, py = float(cc.i) + 0.5f;
@@ -149,17 +150,17 @@ __global__ void __launch_bounds__(256) fg_blend_fwd_kernel(
 #define LFS_FG_LDS_REDUCE 1   // the nine wave sums through an LDS transpose (lfs_raster_common.cuh), as the 3DGUT backward does with its sixteen. Same-box A/B x2
                               // (profiles/r03/fastgs_blend_bwd_lds_reduce_ab.txt): fastgs_blend_bwd 0.452 - 0.457 -> 0.391 - 0.395 ms; 0 = register swaps + DPP
 #endif
-__global__ void __launch_bounds__(256) fg_blend_bwd_kernel(
+__global__ void __launch_bounds__(64) fg_blend_bwd_kernel(
     const uint32_t gw, const uint32_t gh, const uint32_t width, const uint32_t height,
     const GaussRec* __restrict__ recs, const int32_t* __restrict__ offsets, const int32_t* __restrict__ cell_count, const int2* __restrict__ cell_list,
     const float* __restrict__ alpha_map, const int32_t* __restrict__ n_contrib, const float* __restrict__ g_image, const float* __restrict__ g_alpha,
     float* __restrict__ acc) {
     const uint32_t total_tiles = gw * gh;
 #if LFS_FG_LDS_REDUCE
-    __shared__ float s_red[4 * 64 * RED9_STRIDE]; // one [64][9] transpose block per wavefront (wave_sum9_atomic_lds)
-    float* const red_scratch = s_red + (threadIdx.x >> 6) * (64 * RED9_STRIDE);
+    __shared__ float s_red[64 * RED9_STRIDE]; // this wavefront's [64][9] transpose block (wave_sum9_atomic_lds)
+    float* const red_scratch = s_red;
 #endif
-    const CellCtx cc = cell_ctx(total_tiles, total_tiles, gw, TILE, 1, 4);
+    const CellCtx cc = cell_ctx(total_tiles, total_tiles, gw, TILE, WPT, 1);
     if (!cc.in_grid) return;
     const uint32_t lane = threadIdx.x & 63;
     const bool inside = cc.i < height && cc.j < width;
@@ -267,7 +268,8 @@ extern "C" int lfs_fastgs_render(
                            w.rec, w.offsets, iw.ids, iw.cell_count, iw.cell_list);
     }
     lfs::ProfScope prof("fastgs_blend_fwd", s);
-    hipLaunchKernelGGL(fgs::fg_blend_fwd_kernel, dim3(grid), dim3(256), 0, s, f.gw, f.gh, width, height, w.rec, w.offsets, iw.cell_count, iw.cell_list,
+    const uint32_t wgrid = ((T * fgs::WPT + 7) / 8) * 8;
+    hipLaunchKernelGGL(fgs::fg_blend_fwd_kernel, dim3(wgrid), dim3(64), 0, s, f.gw, f.gh, width, height, w.rec, w.offsets, iw.cell_count, iw.cell_list,
                        image, alpha, w.n_contrib);
     return (int)hipGetLastError();
 }
@@ -291,10 +293,11 @@ static int fastgs_backward_impl(
     const fgs::Frame f = make_frame(w2c, cam_position, active_sh_bases, total_bases_sh_rest, width, height, fx, fy, cx, cy, near_plane, far_plane);
     hipError_t e = hipMemsetAsync(w.acc, 0, sizeof(float) * ACC_STRIDE * size_t(N), s);
     if (e != hipSuccess) return (int)e;
-    const uint32_t T = f.gw * f.gh, grid = ((T + 7) / 8) * 8;
+    const uint32_t T = f.gw * f.gh;
     if (n_instances > 0) {
         lfs::ProfScope prof("fastgs_blend_bwd", s);
-        hipLaunchKernelGGL(fgs::fg_blend_bwd_kernel, dim3(grid), dim3(256), 0, s, f.gw, f.gh, width, height, w.rec, w.offsets, iw.cell_count, iw.cell_list,
+        const uint32_t wgrid = ((T * fgs::WPT + 7) / 8) * 8;
+        hipLaunchKernelGGL(fgs::fg_blend_bwd_kernel, dim3(wgrid), dim3(64), 0, s, f.gw, f.gh, width, height, w.rec, w.offsets, iw.cell_count, iw.cell_list,
                            alpha, w.n_contrib, grad_image, grad_alpha, w.acc);
     }
     return fgs::launch_preprocess_bwd(N, means, scales_raw, rotations_raw, sh_coefficients_0, sh_coefficients_rest, f, w, grad_means, grad_scales_raw, grad_rotations_raw,

@@ -364,6 +364,10 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 // pass over the image disappears.
 struct MseFuse { const float* render; const float* target; float scale; float* loss; unsigned long long* det64; };
 
+#ifndef LFS_RASTER_WAVE_BLOCKS
+#define LFS_RASTER_WAVE_BLOCKS 1   // fwd / bwd launched with ONE wavefront per workgroup (wave_geom below). Same-box A/B x3 (profiles/r03/raster_wave_blocks_ab.txt):
+                                   // raster_bwd 0.532 - 0.537 -> 0.514 - 0.526 ms, raster_fwd 0.241 - 0.247 -> 0.237 - 0.241 ms; 0 = the tile's four cells as one workgroup
+#endif
 #ifndef LFS_BWD_LDS_REDUCE
 #define LFS_BWD_LDS_REDUCE 1   // the 16-value wave reduction through an LDS transpose instead of register swaps (lfs_raster_common.cuh). Measured on SYN-B, same box,
 #endif                         // 3 pairs (profiles/r03/raster_bwd_lds_reduce_ab.txt): raster_bwd 0.621 - 0.624 -> 0.534 - 0.541 ms; 0 = the register transpose of rounds 1 - 2
@@ -382,7 +386,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     float* __restrict__ acc, float* __restrict__ v_colors_extra, const MseFuse mse = MseFuse{}) {
     const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
 #if LFS_BWD_LDS_REDUCE
-    __shared__ float s_red[4 * 64 * RED_STRIDE]; // one [64][17] transpose block per wavefront (wave_sum16_atomic_lds)
+    __shared__ float s_red[(LFS_RASTER_WAVE_BLOCKS ? 1 : 4) * 64 * RED_STRIDE]; // one [64][17] transpose block per wavefront (wave_sum16_atomic_lds)
     float* const red_scratch = s_red + (threadIdx.x >> 6) * (64 * RED_STRIDE);
 #endif
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
@@ -826,6 +830,19 @@ static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom&
     g.cells = uint64_t(cams->C) * g.tw * g.th * g.wpt;
     return true;
 }
+// fwd / bwd never cooperate across the wavefronts of a workgroup (only the cull kernel shares its gathers through LDS): with one wavefront per workgroup a
+// finished cell frees its slot at once instead of waiting for the slowest of its tile's four
+static RasterGeom wave_geom(const lfs_cameras* cams, const RasterGeom& g) {
+    RasterGeom w = g;
+#if LFS_RASTER_WAVE_BLOCKS
+    w.waves_per_block = 1; w.blocks_per_tile = g.wpt; w.threads = 64;
+    const uint64_t nb = uint64_t(cams->C) * g.tw * g.th * w.blocks_per_tile;
+    w.grid = uint32_t(((nb + 7) / 8) * 8);
+#else
+    (void)cams;
+#endif
+    return w;
+}
 
 } // namespace lfs
 
@@ -912,9 +929,10 @@ static int raster_fwd_impl(
     if (n_sized > 0 && !flatten_ids) return LFS_E_INVALID;
     raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s);
     lfs::ProfScope prof("raster_fwd", s);
+    const RasterGeom gw = wave_geom(cams, g);
 #define LFS_FWD(CD, MODE)                                                                                        \
-    hipLaunchKernelGGL((raster_fwd_kernel<CD, MODE>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th,       \
-                       cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
+    hipLaunchKernelGGL((raster_fwd_kernel<CD, MODE>), dim3(gw.grid), dim3(gw.threads), 0, s, C, N, g.tw, g.th,     \
+                       cams->image_width, cams->image_height, tile_size, gw.blocks_per_tile, gw.waves_per_block, \
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, ic.arg(), \
                        render_colors, render_alphas, last_ids)
     switch (channels * 2 + raster_mode(cams)) {
@@ -987,9 +1005,10 @@ static int raster_bwd_impl(
     if (!prepared) raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s);
     if (n_sized > 0) {
         lfs::ProfScope prof("raster_bwd", s);
+        const RasterGeom gw = wave_geom(cams, g);
 #define LFS_BWD_K(CD, MODE, ...)                                                                                 \
-    hipLaunchKernelGGL((raster_bwd_kernel<CD, MODE, ##__VA_ARGS__>), dim3(g.grid), dim3(g.threads), 0, s, C, N, g.tw, g.th, \
-                       cams->image_width, cams->image_height, tile_size, g.blocks_per_tile, g.waves_per_block,   \
+    hipLaunchKernelGGL((raster_bwd_kernel<CD, MODE, ##__VA_ARGS__>), dim3(gw.grid), dim3(gw.threads), 0, s, C, N, g.tw, g.th, \
+                       cams->image_width, cams->image_height, tile_size, gw.blocks_per_tile, gw.waves_per_block, \
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, ic.arg(), \
                        render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors, mse_dev)
         if (det) { // pass 1: per-slot maxima of |total| (integer atomicMax), pass 2: 64-bit fixed-point sums, then back to float
