@@ -75,12 +75,15 @@ int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacit
     cams.viewmats0 = a->viewmat; cams.Ks = a->Kmat;
     const lfs_ut_params ut{0.1f, 2.f, 0.f, 0.1f, 1};   // Cameras.h:27-61 defaults, as the trainer passes them (rasterizer_autograd.cpp:223-234)
     // trainer constants of rasterizer.cpp:176-181: eps2d 0.3, near 0.01, far 1e4, radius_clip 0
-    int rc = lfs_activations_project_ut(N, a->means, a->raw_quats, a->raw_scales, a->raw_opacities, &cams, 0.3f, 0.01f, 10000.f, 0.f, &ut, w.quats, w.scales,
-                                        w.opacities, w.radii, w.means2d, w.depths, s);
+    // the projection kernel also clears the intersection stage's per-tile totals and writes the rasterizer's camera state (first block of the raster workspace):
+    // two launches of a few microseconds each that a step does not need (the 32 KB memset and cam_prep_kernel)
+    int rc = activations_project_ut_impl(N, a->means, a->raw_quats, a->raw_scales, a->raw_opacities, &cams, 0.3f, 0.01f, 10000.f, 0.f, &ut, w.quats, w.scales,
+                                         w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th, w.raster_ws, s);
     if (rc) return rc;
     const IsectGuard guard{capacity, assumed_longest, w.abort_flag};
     int64_t* counts = host_counts ? host_counts : w.dev_counts;   // [n_isects, longest tile list, stamp]
-    rc = isect_count_impl(1, N, w.means2d, w.radii, tile, tw, th, w.tiles_per_gauss, counts, counts + 1, nullptr, 0u, counts + 2, stamp, w.isect_ws, w.isect_ws_bytes, s, &guard);
+    rc = isect_count_impl(1, N, w.means2d, w.radii, tile, tw, th, w.tiles_per_gauss, counts, counts + 1, nullptr, LFS_ISECT_COUNTERS_ZERO, counts + 2, stamp, w.isect_ws,
+                          w.isect_ws_bytes, s, &guard);
     if (rc) return rc;
     // the SH colours need the projection's radii only: enqueued between the count and the binning passes, as the Python step did with its `overlap` hook
     rc = lfs_sh_model_fwd(N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, s);
@@ -90,7 +93,7 @@ int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacit
     if (rc) return rc;
     f.offsets = isect_workspace_offsets(w.isect_ws, 1, N, tw, th);
     return raster_fwd_guarded(N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, tile, f.offsets, w.flatten_ids, capacity, w.render, w.alpha,
-                              w.last_ids, w.raster_ws, w.raster_ws_bytes, s);
+                              w.last_ids, w.raster_ws, w.raster_ws_bytes, s, /*cams_ready=*/true);
 }
 
 int check_args(const lfs_gut_step_args* a, bool need_adam) {

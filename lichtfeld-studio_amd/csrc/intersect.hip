@@ -484,6 +484,9 @@ int lfs::isect_count_impl(
     return (int)hipGetLastError();
 }
 
+uint32_t* lfs::isect_workspace_totals(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height) {
+    return isect_ws(workspace, C, N, tile_width, tile_height).totals;
+}
 const int32_t* lfs::isect_workspace_offsets(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height) {
     return isect_ws(workspace, C, N, tile_width, tile_height).offsets;
 }

@@ -31,7 +31,8 @@ const int32_t* isect_workspace_offsets(void* workspace, uint32_t C, uint32_t N, 
 // rasterizer, guarded: n_isects = -1 (the kernels read offsets[T]; tile_offsets must be the [T + 1] array above), cell lists sized for `capacity`
 int raster_fwd_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
                        const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
-                       int64_t capacity, float* render_colors, float* render_alphas, int32_t* last_ids, void* workspace, size_t workspace_bytes, hipStream_t s);
+                       int64_t capacity, float* render_colors, float* render_alphas, int32_t* last_ids, void* workspace, size_t workspace_bytes, hipStream_t s,
+                       bool cams_ready = false);
 int raster_bwd_mse_acc_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
                                const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
                                int64_t capacity, const float* render_colors, const float* render_alphas, const int32_t* last_ids, const float* target_chw,
@@ -49,6 +50,13 @@ int sh_model_bwd_adam_all_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, 
                                const float* sh0_scalars, float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, hipStream_t s,
                                const int32_t* abort_flag);
 
+// lfs_activations_project_ut with two riders for the training step (both save a launch of a few microseconds each): `zero_words` [zero_n] is cleared (the
+// intersection stage's per-tile totals - the count kernel then runs with LFS_ISECT_COUNTERS_ZERO, no memset), and the device-side camera state the rasterizer
+// kernels read is written to `cams_out` (what cam_prep_kernel computes; raster_fwd_guarded(..., cams_ready = true) then skips that kernel)
+int activations_project_ut_impl(uint32_t N, const float* means, const float* raw_quats, const float* raw_scales, const float* raw_opacities, const lfs_cameras* cams,
+                                float eps2d, float near_plane, float far_plane, float radius_clip, const lfs_ut_params* ut_params, float* quats, float* scales,
+                                float* opacities, int32_t* radii, float* means2d, float* depths, uint32_t* zero_words, uint32_t zero_n, void* cams_out, hipStream_t s);
+uint32_t* isect_workspace_totals(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height);
 int sh_model_bwd_rows_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
                            const int32_t* radii, const float* colors, const float* acc_rows, int accumulate, float* v_sh0, float* v_shN, float* v_dirs, hipStream_t s);
 // lfs_gut_finish_grads with dL/d(dirs) [N,3] (nullable) added to the means gradient and no dL/dcolour output (the SH backward has run already)

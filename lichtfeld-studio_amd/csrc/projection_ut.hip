@@ -9,6 +9,7 @@
 // same rounding path as the oracle.
 #include "lfs_camera.cuh"
 #include "lfs_prof.h"
+#include "lfs_step_internal.h"
 
 namespace lfs {
 
@@ -29,9 +30,12 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
     const lfs_ut_params ut,
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
     float* __restrict__ conics, float* __restrict__ compensations,
-    float* __restrict__ act_quats = nullptr, float* __restrict__ act_scales = nullptr, float* __restrict__ act_opacities = nullptr) {
+    float* __restrict__ act_quats = nullptr, float* __restrict__ act_scales = nullptr, float* __restrict__ act_opacities = nullptr,
+    uint32_t* __restrict__ zero_words = nullptr, const uint32_t zero_n = 0, CamDev* __restrict__ cams_out = nullptr) {
     const uint32_t cid = blockIdx.y;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_words != nullptr && cid == 0) // rider of the training step: clear the intersection stage's per-tile totals (saves its memset launch)
+        for (uint32_t i = gid; i < zero_n; i += gridDim.x * blockDim.x) zero_words[i] = 0u;
     if (gid >= N) return;
     const size_t idx = size_t(cid) * N + gid;
 
@@ -42,6 +46,7 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
         cs.radial_coeffs = nullptr; cs.tangential_coeffs = nullptr; cs.thin_prism_coeffs = nullptr; cs.n_radial = 0; cs.n_thin_prism = 0;
     }
     cam_init(cam, cs, cid);
+    if (cams_out != nullptr && gid == 0) cams_out[cid] = cam; // rider of the training step: the rasterizer's camera state (what cam_prep_kernel computes)
 
     int32_t out_rx = 0, out_ry = 0;
     float o_m2x = 0.f, o_m2y = 0.f, o_depth = 0.f, o_c0 = 0.f, o_c1 = 0.f, o_c2 = 0.f, o_comp = 0.f;
@@ -177,10 +182,10 @@ extern "C" int lfs_projection_ut_3dgs_fused(
     return (int)hipGetLastError();
 }
 
-extern "C" int lfs_activations_project_ut(
+int lfs::activations_project_ut_impl(
     uint32_t N, const float* means, const float* raw_quats, const float* raw_scales, const float* raw_opacities, const lfs_cameras* cams,
     float eps2d, float near_plane, float far_plane, float radius_clip, const lfs_ut_params* ut_params,
-    float* quats, float* scales, float* opacities, int32_t* radii, float* means2d, float* depths, lfs_stream_t stream) {
+    float* quats, float* scales, float* opacities, int32_t* radii, float* means2d, float* depths, uint32_t* zero_words, uint32_t zero_n, void* cams_out, hipStream_t stream) {
     if (!cams || !cams->viewmats0 || !cams->Ks) return LFS_E_INVALID;
     if (cams->camera_model != LFS_CAMERA_PINHOLE && cams->camera_model != LFS_CAMERA_FISHEYE) return LFS_E_UNSUPPORTED;
     if (N == 0 || cams->C == 0) return LFS_OK;
@@ -192,10 +197,18 @@ extern "C" int lfs_activations_project_ut(
     if (simple_camera(cams))
         hipLaunchKernelGGL((lfs::projection_ut_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream,
                            N, means, raw_quats, raw_scales, raw_opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
-                           radii, means2d, depths, nullptr, nullptr, quats, scales, opacities);
+                           radii, means2d, depths, nullptr, nullptr, quats, scales, opacities, zero_words, zero_n, static_cast<lfs::CamDev*>(cams_out));
     else
         hipLaunchKernelGGL((lfs::projection_ut_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream,
                            N, means, raw_quats, raw_scales, raw_opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
-                           radii, means2d, depths, nullptr, nullptr, quats, scales, opacities);
+                           radii, means2d, depths, nullptr, nullptr, quats, scales, opacities, zero_words, zero_n, static_cast<lfs::CamDev*>(cams_out));
     return (int)hipGetLastError();
+}
+
+extern "C" int lfs_activations_project_ut(
+    uint32_t N, const float* means, const float* raw_quats, const float* raw_scales, const float* raw_opacities, const lfs_cameras* cams,
+    float eps2d, float near_plane, float far_plane, float radius_clip, const lfs_ut_params* ut_params,
+    float* quats, float* scales, float* opacities, int32_t* radii, float* means2d, float* depths, lfs_stream_t stream) {
+    return lfs::activations_project_ut_impl(N, means, raw_quats, raw_scales, raw_opacities, cams, eps2d, near_plane, far_plane, radius_clip, ut_params, quats, scales,
+                                            opacities, radii, means2d, depths, nullptr, 0, nullptr, (hipStream_t)stream);
 }

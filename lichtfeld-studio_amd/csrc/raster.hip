@@ -887,10 +887,10 @@ struct IsectCount { int64_t n_isects, capacity; int32_t arg() const { return n_i
 static void raster_prepare(const RasterWs& w, const RasterGeom& g, uint32_t N, uint32_t channels, const float* means, const float* quats,
                            const float* scales, const float* colors, const float* opacities, const uint8_t* masks,
                            const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
-                           const IsectCount ic, hipStream_t s) {
+                           const IsectCount ic, hipStream_t s, bool cams_ready = false) {
     const uint32_t C = cams->C;
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
-    hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams);
+    if (!cams_ready) hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams); // (training step: written by the projection kernel already)
     const size_t CN = size_t(C) * N;
     if (CN > 0) {
         lfs::ProfScope prof_pack("raster_pack", s);
@@ -914,7 +914,7 @@ static int raster_fwd_impl(
     const lfs_cameras* cams, uint32_t tile_size,
     const int32_t* tile_offsets, const int32_t* flatten_ids, const IsectCount ic,
     float* render_colors, float* render_alphas, int32_t* last_ids,
-    void* workspace, size_t workspace_bytes, hipStream_t s) {
+    void* workspace, size_t workspace_bytes, hipStream_t s, bool cams_ready = false) {
     RasterGeom g;
     int rc = raster_check(N, channels, cams, tile_size, g);
     if (rc) return rc;
@@ -927,7 +927,7 @@ static int raster_fwd_impl(
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N > 0 && (!means || !quats || !scales || !colors || !opacities)) return LFS_E_INVALID;
     if (n_sized > 0 && !flatten_ids) return LFS_E_INVALID;
-    raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s);
+    raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s, cams_ready);
     lfs::ProfScope prof("raster_fwd", s);
     const RasterGeom gw = wave_geom(cams, g);
 #define LFS_FWD(CD, MODE)                                                                                        \
@@ -960,10 +960,11 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
 
 int lfs::raster_fwd_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
                             const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
-                            int64_t capacity, float* render_colors, float* render_alphas, int32_t* last_ids, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                            int64_t capacity, float* render_colors, float* render_alphas, int32_t* last_ids, void* workspace, size_t workspace_bytes, hipStream_t s,
+                            bool cams_ready) {
     if (capacity < 0) return LFS_E_INVALID;
     return raster_fwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, IsectCount{-1, capacity},
-                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, s);
+                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, s, cams_ready);
 }
 
 static int raster_bwd_impl(

@@ -276,7 +276,10 @@ class GutTrainer:
             refining = self.strategy is not None and self.strategy.is_refining(self.iteration)   # parameters are replaced before the optimizer step
             strat_ok = self.strategy is None or (self.strategy_kind == "mcmc" and not refining)
             inline = None
-            if (self.inline_shN_adam and self.world == 1 and self.sh_exchange is None and len(views) == 1 and strat_ok and self.iteration > 1000
+            # LFS_DIST_FORCE_COLLECTIVES=1 (one GPU, RCCL with world size 1): take the MULTI-rank code path - gradient tensors, early + final all-reduce - so that
+            # what a rank of an N-GPU job executes can be run and timed on a single device (bench.py --replicated / --sh-sharded with that variable set)
+            multi = self.world > 1 or lfs_dist._FORCE
+            if (self.inline_shN_adam and not multi and self.sh_exchange is None and len(views) == 1 and strat_ok and self.iteration > 1000
                     and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False)):
                 inline = self.optimizer.prepare_inline(self.model.shN)
             # ... and when the MSE is folded into the rasterizer backward as well, EVERY parameter is updated by the backward kernels (fused.backward_adam_all):
@@ -305,7 +308,7 @@ class GutTrainer:
                 self._last_radii = self._gut_step.view("radii", torch.int32, (1, N, 2))
                 views_loop = []
             elif (self.cxx_step and inline is None and self.sh_exchange is None and self.loss_kind == "mse" and self.bilateral is None and self.strategy is None
-                  and (self.world > 1 or len(views) == 1)):
+                  and (multi or len(views) == 1)):
                 # gradient-tensor form of the C++ step (data-parallel ranks with the north-star layout - replicated Gaussians, one all-reduce of the flat
                 # bucket - and single-rank steps while iteration <= 1000): per view one speculative forward + two backward calls, no host read in between.
                 # The SH backward runs BEFORE the finish pass, so on the last view the shN segment (45 of 59 floats per Gaussian at degree 3) is on the wire,
@@ -321,14 +324,14 @@ class GutTrainer:
                     self.last_n_isects = gs.view_forward(ps, deg, sc.width, sc.height, vm, Km, self.bg)
                     gs.view_backward_sh(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=tgt, weight=1.0 / total_views,
                                         loss_acc=self.loss_acc)
-                    if self.world > 1 and k == len(views) - 1 and self.iteration > 1000 and ps[2].numel():
+                    if multi and k == len(views) - 1 and self.iteration > 1000 and ps[2].numel():
                         self.bucket.all_reduce_early([2], chunks=4)
                     gs.view_backward_finish(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=tgt, weight=1.0 / total_views,
                                             loss_acc=self.loss_acc, scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
                                             opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0)
                 self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
                 views_loop = []
-            elif self.batch_views and self.world == 1 and self.sh_exchange is None and len(views) > 1:
+            elif self.batch_views and not multi and self.sh_exchange is None and len(views) > 1:
                 # several views per step on one rank: the SH stages run ONCE over all views (fused.render_views_and_backward), and shN's Adam update
                 # moves into that one SH backward when the optimizer would read the gradient anyway
                 from .fused import render_views_and_backward

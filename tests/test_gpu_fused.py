@@ -276,7 +276,7 @@ def test_all_inline_adam_step_is_bit_identical_to_the_separate_kernels(lfs):
         torch.cuda.synchronize()
     finally:
         lib.lfs_set_debug_flags(0)
-    assert float(la) == float(lb) and float(la) > 0
+    assert abs(float(la) - float(lb)) <= 2e-6 * float(lb) and float(la) > 0   # (the loss value is a float-atomic sum: last-bit order dependence)
     for name, pa, pb in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], a.model.parameters(), b.model.parameters()):
         assert torch.equal(pa, pb), (name, float((pa - pb).abs().max()))
         sa, sb = a.optimizer.state[id(pa)], b.optimizer.state[id(pb)]

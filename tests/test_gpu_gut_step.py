@@ -43,7 +43,9 @@ def test_cxx_step_is_bit_identical_to_the_python_enqueued_step(lfs):
     finally:
         lib.lfs_set_debug_flags(0)
     assert a._gut_step is not None and b._gut_step is None
-    assert float(la) == float(lb) and float(la) > 0
+    # (the loss VALUE is a float-atomic sum of per-wavefront partials over 256 slots - its last bit depends on arrival order even in the deterministic mode, which
+    #  covers the gradient accumulators; the parameters below do not depend on it)
+    assert abs(float(la) - float(lb)) <= 2e-6 * float(lb) and float(la) > 0
     assert a.last_n_isects == b.last_n_isects > 0
     assert torch.equal(a.last_visible, b.last_visible)
     _same_state(a, b, 4)
@@ -73,7 +75,7 @@ def test_overflowing_attempt_updates_nothing_and_is_run_again(lfs, capacity, lon
     assert gs.n_isects == b.last_n_isects and gs.capacity >= gs.n_isects
     if longest == 8:
         assert gs.longest > 1024, gs.longest   # (otherwise this case does not test the sort-class guard)
-    assert float(la) == float(lb)
+    assert abs(float(la) - float(lb)) <= 2e-6 * float(lb)
     _same_state(a, b, 2)
 
 

@@ -219,7 +219,7 @@ def test_cxx_gut_train_step_class_equals_the_python_driver(lfs):
     finally:
         lib.lfs_set_debug_flags(0)
     assert step.retries() >= 1 and n_isects == a.last_n_isects > 0
-    assert float(la) == float(loss_b)
+    assert abs(float(la) - float(loss_b)) <= 2e-6 * float(la)   # (float-atomic partial sums of the loss value: last-bit order dependence; parameters are exact)
     assert tuple(step.render().shape) == (sc.height, sc.width, 3) and tuple(step.radii().shape) == (5000, 2)
     for name, pa, pb in zip(names, a.model.parameters(), b.model.parameters()):
         assert torch.equal(pa, pb), (name, float((pa - pb).abs().max()))
