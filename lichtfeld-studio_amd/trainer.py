@@ -28,10 +28,11 @@ class GutTrainer:
         sc = scene.to(device)
         self.scene = sc
         mk = lambda t: t.clone().contiguous().requires_grad_(True)
-        # SH-sharded data parallelism (dist.ShExchange): shN and its Adam state live on one rank each. Default for the fused 3DGUT step
-        # on more than one rank; the strategies index all parameters by Gaussian and keep the replicated layout.
+        # Data-parallel layout. Default (round 3): the north-star one - Gaussians REPLICATED, per-rank forward / backward, one all-reduce of the flat gradient
+        # bucket before the fused Adam step. sh_sharded=True opts into dist.ShExchange (shN and its Adam state owned by one rank each: 14 instead of 59 floats per
+        # Gaussian in the all-reduce; fused 3DGUT step, no strategy or MCMC). bench.py --gpus N times both.
         if sh_sharded is None:
-            sh_sharded = world > 1 and fused_l2 and rasterizer == "gut" and strategy in (None, "mcmc")
+            sh_sharded = False
         if sh_sharded and not (fused_l2 and rasterizer == "gut" and strategy in (None, "mcmc")):
             raise ValueError("sh_sharded needs the fused 3DGUT step (no strategy, or MCMC: its refinement steps run on the gathered tensors)")
         self.sh_exchange = lfs_dist.ShExchange(sc.means.shape[0], world, rank) if sh_sharded else None

@@ -101,8 +101,8 @@ def _mcmc_worker(rank, world, port, q):
     dev = torch.device("cuda:0")
     sc = _scene()
     op = strategies.OptimizationParameters(iterations=400, start_refine=1002, refine_every=4, stop_refine=2000, max_cap=7000)
-    tr = GutTrainer(sc, dev, iterations=400, world=world, rank=rank, strategy="mcmc", opt_params=op)
-    assert tr.sh_exchange is not None, "MCMC keeps the SH-sharded layout"
+    tr = GutTrainer(sc, dev, iterations=400, world=world, rank=rank, strategy="mcmc", opt_params=op, sh_sharded=True)
+    assert tr.sh_exchange is not None, "MCMC supports the SH-sharded layout"
     tr.iteration = 1000
     target = scenes.target_image(sc.height, sc.width).to(dev) * 0.6
     n_seen, losses = [], []
