@@ -81,3 +81,36 @@ def test_io_library_exports_every_symbol_of_its_header():
     import subprocess
     needed = subprocess.run(["readelf", "-d", loader.io_library_path()], capture_output=True, text=True).stdout
     assert "amdhip" not in needed and "torch" not in needed and "libz" in needed
+
+
+def test_step_driver_host_functions(lfs):
+    """csrc/gut_step.hip, host side only (no launch): the workspace layout of the speculative training step grows with the capacity and keeps every region
+    256-byte aligned and disjoint; lfs_gut_step_fits = "count within capacity AND longest tile list within the sort classes launched for the assumption";
+    argument validation happens before anything is enqueued; lfs_gut_step_wait reads the stamp protocol from plain host memory."""
+    from lichtfeld_studio_amd.gut_step import StepArgs, StepLayout
+    lib = lfs.load_library()
+    lay = {}
+    for cap in (1 << 16, 5_000_000, 20_000_000):
+        l = StepLayout()
+        assert lib.lfs_gut_step_layout_for(ctypes.c_uint32(1_000_000), ctypes.c_uint32(1920), ctypes.c_uint32(1080), ctypes.c_uint32(16), ctypes.c_int64(cap), ctypes.byref(l)) == 0
+        lay[cap] = l
+        offs = sorted((getattr(l, k), k) for k, _ in StepLayout._fields_ if k not in ("bytes", "tile_offsets"))
+        assert all(o % 256 == 0 for o, _ in offs) and len({o for o, _ in offs}) == len(offs), offs
+        assert offs[-1][0] < l.bytes and l.tile_offsets < l.bytes
+    assert lay[1 << 16].bytes < lay[5_000_000].bytes < lay[20_000_000].bytes
+    # per intersection: 8 (keys) + 4 (ids) + 8 (binning scratch) + 4 cells x 8 (cell lists) = 52 bytes
+    per = (lay[20_000_000].bytes - lay[5_000_000].bytes) / 15_000_000
+    assert 51.9 < per < 52.1, per
+    assert lib.lfs_gut_step_layout_for(ctypes.c_uint32(1000), ctypes.c_uint32(64), ctypes.c_uint32(64), ctypes.c_uint32(16), ctypes.c_int64(0), ctypes.byref(StepLayout())) != 0
+    fits = lambda n, lg, cap, assumed: lib.lfs_gut_step_fits(ctypes.c_int64(n), ctypes.c_int64(lg), ctypes.c_int64(cap), ctypes.c_int64(assumed))
+    assert fits(100, 10, 100, 1024) == 1 and fits(101, 10, 100, 1024) == 0
+    assert fits(100, 1024, 1000, 1024) == 1 and fits(100, 1025, 1000, 1024) == 0      # first sort class: lists of <= 1024 entries
+    assert fits(100, 4096, 1000, 1025) == 1 and fits(100, 4097, 1000, 4096) == 0
+    assert fits(100, 16384, 1000, 5000) == 1 and fits(100, 16385, 1000, 16384) == 0
+    assert fits(100, 10 ** 9, 1000, 16385) == 1                                          # the global-memory class sorts any length
+    a = StepArgs()                                                                         # all-null arguments: refused before any launch
+    assert lib.lfs_gut_train_step(ctypes.byref(a), ctypes.c_int64(1000), ctypes.c_int64(1024), None, ctypes.c_size_t(0), None, ctypes.c_int64(1), None) != 0
+    counts = (ctypes.c_int64 * 3)(123, 45, 7)
+    n, lg = ctypes.c_int64(0), ctypes.c_int64(0)
+    assert lib.lfs_gut_step_wait(counts, ctypes.c_int64(7), ctypes.c_double(0.1), ctypes.byref(n), ctypes.byref(lg)) == 0 and (n.value, lg.value) == (123, 45)
+    assert lib.lfs_gut_step_wait(counts, ctypes.c_int64(8), ctypes.c_double(0.05), ctypes.byref(n), ctypes.byref(lg)) != 0     # a stamp that never arrives: time-out, not a hang
