@@ -416,7 +416,10 @@ LFS_API int lfs_gut_view_forward(const lfs_gut_step_args* args, int64_t capacity
 LFS_API int lfs_gut_view_backward(const lfs_gut_step_args* args, int64_t capacity, const float* v_render /* [H,W,3], used when args->target_chw == NULL */,
                                   float* const* grads /* [6] host */, int accumulate, void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 /*   = lfs_gut_view_backward_sh (rasterizer backward + SH backward: grads[1], grads[2] final) then lfs_gut_view_backward_finish (grads[0], grads[3..5]); a
- *   data-parallel caller starts the all-reduce of the SH gradients between the two (dist.GradBucket.all_reduce_early). */
+ *   data-parallel caller starts the all-reduce of the SH gradients between the two (dist.GradBucket.all_reduce_early). With args->exp_avg[2] /
+ *   exp_avg_sq[2] / adam[2] set (one view per step, accumulate == 0) lfs_gut_view_backward_sh applies shN's Adam update itself, as lfs_sh_model_bwd_adam
+ *   does, and grads[2] is neither read nor written: the steps whose loss is not the folded MSE (L1 + D-SSIM, bilateral grid, MCMC) keep the 45-of-59-float
+ *   tensor out of the optimizer launch that way. */
 LFS_API int lfs_gut_view_backward_sh(const lfs_gut_step_args* args, int64_t capacity, const float* v_render, float* const* grads, int accumulate,
                                      void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 LFS_API int lfs_gut_view_backward_finish(const lfs_gut_step_args* args, int64_t capacity, float* const* grads, int accumulate,

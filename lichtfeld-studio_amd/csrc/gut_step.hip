@@ -178,7 +178,11 @@ extern "C" int lfs_gut_view_backward_sh(const lfs_gut_step_args* a, int64_t capa
     StepWs w; lfs_cameras cams; const int32_t* offsets;
     int rc = view_setup(a, capacity, workspace, workspace_bytes, w, cams, offsets);
     if (rc) return rc;
-    if (!grads || !grads[1] || (a->K > 1 && !grads[2]) || (!a->target_chw && !v_render)) return LFS_E_INVALID;
+    // args->exp_avg[2] given: shN's Adam step runs inside the SH backward (one view per step, one rank - the reference's MCMC / L1+D-SSIM / bilateral-grid
+    // steps, whose other five tensors go through gradient tensors and FusedAdam); grads[2] is then neither read nor written
+    const bool inline_shN = a->K > 1 && a->exp_avg[2] != nullptr;
+    if (inline_shN && (accumulate || !a->exp_avg_sq[2])) return LFS_E_INVALID;
+    if (!grads || !grads[1] || (a->K > 1 && !grads[2] && !inline_shN) || (!a->target_chw && !v_render)) return LFS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     if (a->target_chw)
         rc = raster_bwd_mse_acc_guarded(a->N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, a->tile_size, offsets, w.flatten_ids, capacity,
@@ -188,7 +192,8 @@ extern "C" int lfs_gut_view_backward_sh(const lfs_gut_step_args* a, int64_t capa
                                     w.last_ids, v_render, w.raster_ws, w.raster_ws_bytes, s);
     if (rc) return rc;
     const float* acc_rows = reinterpret_cast<const float*>(static_cast<const char*>(w.raster_ws) + lfs_rasterize_workspace_acc_offset(1, a->N));
-    return sh_model_bwd_rows_impl(a->N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, acc_rows, accumulate, grads[1], grads[2], w.v_dirs, s);
+    return sh_model_bwd_rows_impl(a->N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, acc_rows, accumulate, grads[1], grads[2], w.v_dirs, s,
+                                  inline_shN ? a->exp_avg[2] : nullptr, inline_shN ? a->exp_avg_sq[2] : nullptr, inline_shN ? a->adam[2] : nullptr);
 }
 
 extern "C" int lfs_gut_view_backward_finish(const lfs_gut_step_args* a, int64_t capacity, float* const* grads /* [6] host */, int accumulate,

@@ -58,7 +58,8 @@ int activations_project_ut_impl(uint32_t N, const float* means, const float* raw
                                 float* opacities, int32_t* radii, float* means2d, float* depths, uint32_t* zero_words, uint32_t zero_n, void* cams_out, hipStream_t s);
 uint32_t* isect_workspace_totals(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height);
 int sh_model_bwd_rows_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
-                           const int32_t* radii, const float* colors, const float* acc_rows, int accumulate, float* v_sh0, float* v_shN, float* v_dirs, hipStream_t s);
+                           const int32_t* radii, const float* colors, const float* acc_rows, int accumulate, float* v_sh0, float* v_shN, float* v_dirs, hipStream_t s,
+                           float* shN_exp_avg = nullptr, float* shN_exp_avg_sq = nullptr, const float* shN_scalars = nullptr); // given: shN's Adam step inline, v_shN unused
 // lfs_gut_finish_grads with dL/d(dirs) [N,3] (nullable) added to the means gradient and no dL/dcolour output (the SH backward has run already)
 int gut_finish_grads_impl(uint32_t N, const float* means, const float* raw_quats, const float* quats, const float* scales, const float* opacities, float scale_reg,
                           float opacity_reg, int accumulate, float* g_means, float* g_raw_scales, float* g_raw_quats, float* g_raw_opacities, float* v_colors,

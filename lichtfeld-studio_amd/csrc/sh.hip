@@ -607,14 +607,22 @@ extern "C" int lfs_sh_model_bwd(
 // all-reduce on the wire) while lfs_gut_finish_grads still runs (csrc/gut_step.hip).
 int lfs::sh_model_bwd_rows_impl(
     uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
-    const int32_t* radii, const float* colors, const float* acc_rows, int accumulate, float* v_sh0, float* v_shN, float* v_dirs, hipStream_t stream) {
+    const int32_t* radii, const float* colors, const float* acc_rows, int accumulate, float* v_sh0, float* v_shN, float* v_dirs, hipStream_t stream,
+    float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars) {
     const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
     if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
     if (n == 0) return LFS_OK;
-    if (!means || !viewmat || !sh0 || (K > 1 && (!shN || !v_shN)) || !radii || !colors || !acc_rows || !v_sh0 || !v_dirs) return LFS_E_INVALID;
+    const bool inline_adam = shN_exp_avg != nullptr;   // shN updated in place by this launch (one view per step): no shN gradient is written
+    if (inline_adam && (accumulate || K < 2 || !shN_exp_avg_sq || !shN_scalars)) return LFS_E_INVALID;
+    if (!means || !viewmat || !sh0 || (K > 1 && (!shN || (!v_shN && !inline_adam))) || !radii || !colors || !acc_rows || !v_sh0 || !v_dirs) return LFS_E_INVALID;
     lfs::ShArgs a{};
     a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
     a.vs = 16; a.dirs_store = true;
+    if (inline_adam) {
+        const float* t = shN_scalars;
+        const lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{t[0], t[1], t[2], t[3], t[4], t[5]}};
+        return lfs::sh_launch_bwd_adam(a, acc_rows + 13, v_sh0, v_dirs, adam, stream);
+    }
     if (accumulate) return lfs::sh_launch_bwd<true, true>(a, acc_rows + 13, nullptr, v_sh0, v_shN, v_dirs, stream);
     return lfs::sh_launch_bwd<true, false>(a, acc_rows + 13, nullptr, v_sh0, v_shN, v_dirs, stream);
 }

@@ -94,7 +94,9 @@ class GutStep:
         a.raw_scales, a.raw_quats, a.raw_opacities = raw_scales.data_ptr(), raw_quats.data_ptr(), raw_opac.data_ptr()
         if adam is not None:
             for k, name in enumerate(GROUPS):
-                d = adam[name]
+                d = adam.get(name)
+                if d is None:   # (view_backward_sh takes shN's state alone)
+                    continue
                 a.exp_avg[k], a.exp_avg_sq[k] = d["exp_avg"].data_ptr(), d["exp_avg_sq"].data_ptr()
                 for j, key in enumerate(("lr", "beta1", "beta2", "eps", "bc1_rcp", "bc2_sqrt_rcp")):
                     a.adam[k][j] = d[key]
@@ -161,9 +163,10 @@ class GutStep:
             self._grow(self.n_isects, self.longest)
         raise LfsError("gut_step: the view did not fit its workspace after 4 attempts")
 
-    def _backward_call(self, fn_name: str, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, v_render, scale_reg, opacity_reg):
+    def _backward_call(self, fn_name: str, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, v_render, scale_reg, opacity_reg,
+                       adam=None):
         lib = load_library()
-        a = self._args(params, sh_degree, W, H, viewmat, Kmat, bg, target_chw, weight, scale_reg, opacity_reg, loss_acc, None)
+        a = self._args(params, sh_degree, W, H, viewmat, Kmat, bg, target_chw, weight, scale_reg, opacity_reg, loss_acc, adam)
         for g in grads:
             if not g.is_cuda or not g.is_contiguous():
                 raise LfsError("gut_step: gradient tensors must be contiguous CUDA (HIP) tensors")
@@ -185,9 +188,12 @@ class GutStep:
         self._backward_call("lfs_gut_view_backward", params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, v_render,
                             scale_reg, opacity_reg)
 
-    def view_backward_sh(self, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, *, target_chw=None, weight=0.0, loss_acc=None, v_render=None) -> None:
-        """First half of view_backward: rasterizer backward + SH backward. grads[1] (sh0) and grads[2] (shN) are final for this view when it has run."""
-        self._backward_call("lfs_gut_view_backward_sh", params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, v_render, 0.0, 0.0)
+    def view_backward_sh(self, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, *, target_chw=None, weight=0.0, loss_acc=None, v_render=None,
+                         adam_shN: Optional[dict] = None) -> None:
+        """First half of view_backward: rasterizer backward + SH backward. grads[1] (sh0) and grads[2] (shN) are final for this view when it has run.
+        adam_shN (FusedAdam.prepare_inline(shN); one view per step): shN is updated in place by the SH backward instead and grads[2] is left alone."""
+        self._backward_call("lfs_gut_view_backward_sh", params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, v_render, 0.0, 0.0,
+                            adam=None if adam_shN is None else {"shN": adam_shN})
 
     def view_backward_finish(self, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, *, target_chw=None, weight=0.0, loss_acc=None,
                              scale_reg: float = 0.0, opacity_reg: float = 0.0) -> None:

@@ -308,26 +308,40 @@ class GutTrainer:
                                                                self.scale_reg, self.opacity_reg)
                 self._last_radii = self._gut_step.view("radii", torch.int32, (1, N, 2))
                 views_loop = []
-            elif (self.cxx_step and inline is None and self.sh_exchange is None and self.loss_kind == "mse" and self.bilateral is None and self.strategy is None
-                  and (multi or len(views) == 1)):
+            elif self.cxx_step and self.sh_exchange is None and (multi or len(views) == 1):
                 # gradient-tensor form of the C++ step (data-parallel ranks with the north-star layout - replicated Gaussians, one all-reduce of the flat
-                # bucket - and single-rank steps while iteration <= 1000): per view one speculative forward + two backward calls, no host read in between.
-                # The SH backward runs BEFORE the finish pass, so on the last view the shN segment (45 of 59 floats per Gaussian at degree 3) is on the wire,
-                # in 4 chunks, while the finish kernel still runs; the remaining 14 floats follow in all_reduce() below.
+                # bucket -, single-rank steps while iteration <= 1000, and every step whose loss is not the folded MSE: L1 + D-SSIM, bilateral grid, MCMC):
+                # per view one speculative forward + two backward calls, no host read in between; the loss kernels run between forward and backward on the
+                # image the forward left in the step workspace. The SH backward runs BEFORE the finish pass, so on the last view of a rank the shN segment
+                # (45 of 59 floats per Gaussian at degree 3) is on the wire, in 4 chunks, while the finish kernel still runs; the remaining 14 floats follow
+                # in all_reduce() below. One view on one rank with Adam reading shN (`inline`): the SH backward applies shN's update itself.
                 from .gut_step import GutStep
                 if self._gut_step is None:
                     self._gut_step = GutStep(self.device)
                 gs, sc = self._gut_step, self.scene
                 ps = [p.detach() for p in params]
                 deg, N = self.model.get_active_sh_degree(), self.model.means.shape[0]
+                weight = 1.0 / total_views
                 for k, v in enumerate(views):
                     vm, Km, tgt = sc.viewmats[v], sc.Ks[v], targets[k % len(targets)]
                     self.last_n_isects = gs.view_forward(ps, deg, sc.width, sc.height, vm, Km, self.bg)
-                    gs.view_backward_sh(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=tgt, weight=1.0 / total_views,
-                                        loss_acc=self.loss_acc)
+                    v_render, fold = None, None
+                    if self.bilateral is not None:   # clamp -> slice -> loss on the un-clamped result -> slice backward (fused.render_and_backward does the same)
+                        from .losses import loss_fwd_bwd
+                        render = gs.view("render", torch.float32, (sc.height, sc.width, 3))
+                        shown = self.bilateral.apply_fused(render, v, chw=False)
+                        v_shown = loss_fwd_bwd(self.loss_kind, shown, tgt, weight, self.loss_acc, chw=False, clamp=False, lambda_dssim=self.lambda_dssim)
+                        v_render = self.bilateral.apply_fused_backward(render, v, v_shown, chw=False)
+                    elif self.loss_kind == "l1_ssim":
+                        from .losses import photometric_loss_fwd_bwd
+                        v_render = photometric_loss_fwd_bwd(gs.view("render", torch.float32, (1, sc.height, sc.width, 3)), tgt, self.lambda_dssim, weight, self.loss_acc)
+                    else:
+                        fold = tgt                   # the clamped MSE is derived inside the rasterizer backward
+                    gs.view_backward_sh(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=fold, weight=weight,
+                                        loss_acc=self.loss_acc, v_render=v_render, adam_shN=inline)
                     if multi and k == len(views) - 1 and self.iteration > 1000 and ps[2].numel():
                         self.bucket.all_reduce_early([2], chunks=4)
-                    gs.view_backward_finish(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=tgt, weight=1.0 / total_views,
+                    gs.view_backward_finish(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=fold, weight=weight,
                                             loss_acc=self.loss_acc, scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
                                             opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0)
                 self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
