@@ -261,14 +261,14 @@ extern "C" int lfs_fastgs_render(
         hipLaunchKernelGGL(tile_sort_lds_kernel<1024>, dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, T, 0u, w.offsets, iw.keys, iw.ids);
         hipLaunchKernelGGL(tile_sort_global_kernel, dim3(T), dim3(1024), 0, s, 16385u, T, 0u, w.offsets, iw.keys, iw.ids);
     }
-    const uint32_t grid = ((T + 7) / 8) * 8;
+    const uint32_t grid = cell_grid_blocks(T, 1);
     {
         lfs::ProfScope prof("fastgs_cull", s);
         hipLaunchKernelGGL(fgs::fg_cull_kernel, dim3(grid), dim3(256), 0, s, f.gw, f.gh, width, height, (fgs::g_fastgs_debug & 1u) ? 0u : 1u,
                            w.rec, w.offsets, iw.ids, iw.cell_count, iw.cell_list);
     }
     lfs::ProfScope prof("fastgs_blend_fwd", s);
-    const uint32_t wgrid = ((T * fgs::WPT + 7) / 8) * 8;
+    const uint32_t wgrid = cell_grid_blocks(uint64_t(T) * fgs::WPT, fgs::WPT);
     hipLaunchKernelGGL(fgs::fg_blend_fwd_kernel, dim3(wgrid), dim3(64), 0, s, f.gw, f.gh, width, height, w.rec, w.offsets, iw.cell_count, iw.cell_list,
                        image, alpha, w.n_contrib);
     return (int)hipGetLastError();
@@ -296,7 +296,7 @@ static int fastgs_backward_impl(
     const uint32_t T = f.gw * f.gh;
     if (n_instances > 0) {
         lfs::ProfScope prof("fastgs_blend_bwd", s);
-        const uint32_t wgrid = ((T * fgs::WPT + 7) / 8) * 8;
+        const uint32_t wgrid = cell_grid_blocks(uint64_t(T) * fgs::WPT, fgs::WPT);
         hipLaunchKernelGGL(fgs::fg_blend_bwd_kernel, dim3(wgrid), dim3(64), 0, s, f.gw, f.gh, width, height, w.rec, w.offsets, iw.cell_count, iw.cell_list,
                            alpha, w.n_contrib, grad_image, grad_alpha, w.acc);
     }

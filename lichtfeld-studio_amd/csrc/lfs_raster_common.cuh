@@ -18,15 +18,32 @@ struct CellCtx {
     uint32_t cid, tile_global, wl, i, j; // wl = 8x8 cell index inside the tile (wave-uniform)
     bool in_grid;
 };
-// Workgroup -> (tile, cell). Consecutive workgroup ids go round-robin over the
-// 8 XCDs; remap so that each XCD works on one contiguous band of tiles and the
-// records of neighbouring tiles meet in the same L2.
+// Workgroup -> (tile, cell). Consecutive workgroup ids go round-robin over the 8 XCDs, and a workgroup cannot move to another XCD: remap so that each XCD
+// works on contiguous chunks of tiles (the records of neighbouring tiles meet in the same L2) AND every XCD gets the same share of the image's work.
+// One chunk per XCD (rounds 1-2) gave the XCDs with the top and bottom eighth of a view half the work of the others - on SYN-B the busiest XCD had 1.16 - 1.17 x
+// the mean (tools/band_balance.py), so the kernels ran 16 % longer than their work. LFS_XCD_BANDS chunks per XCD, dealt round-robin (chunk c -> XCD c % 8):
+// 8 of them (a chunk = about one tile row of a 1080p view) bring that to 1.01 - 1.02.
+#ifndef LFS_XCD_BANDS
+#define LFS_XCD_BANDS 8
+#endif
+// workgroups per chunk: whole tiles
+__host__ __device__ inline uint32_t cell_chunk_blocks(uint32_t nb, uint32_t blocks_per_tile) {
+    const uint32_t chunks = 8u * LFS_XCD_BANDS;
+    const uint32_t cs = (nb + chunks - 1) / chunks;
+    return cs ? ((cs + blocks_per_tile - 1) / blocks_per_tile) * blocks_per_tile : blocks_per_tile;
+}
+// the grid that covers nb workgroups under this mapping (what the host launches)
+__host__ __device__ inline uint32_t cell_grid_blocks(uint64_t nb, uint32_t blocks_per_tile) {
+    return 8u * LFS_XCD_BANDS * cell_chunk_blocks(uint32_t(nb), blocks_per_tile);
+}
 LFS_DI CellCtx cell_ctx(uint32_t n_tiles, uint32_t total_tiles, uint32_t tw, uint32_t tile_size, uint32_t blocks_per_tile, uint32_t waves_per_block) {
     CellCtx c;
     const uint32_t nb = total_tiles * blocks_per_tile;
-    const uint32_t per_xcd = (nb + 7) / 8;
-    const uint32_t b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    c.in_grid = b < nb && (blockIdx.x >> 3) < per_xcd;
+    const uint32_t cs = cell_chunk_blocks(nb, blocks_per_tile);
+    const uint32_t k = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const uint32_t band = k / cs;
+    const uint32_t b = (band * 8u + xcd) * cs + (k - band * cs);
+    c.in_grid = b < nb && band < LFS_XCD_BANDS;
     const uint32_t tg = b / blocks_per_tile, bt = b % blocks_per_tile;
     c.tile_global = tg;
     c.cid = tg / n_tiles;

@@ -37,11 +37,19 @@
 #include "lfs_step_internal.h"
 
 // Host build on the wavefront emulator (tests/emul) only: wave-evaluation counters [fwd, fwd that composited, bwd, bwd that accumulated]
+#ifndef LFS_FINISH_LDS_ROWS
+#define LFS_FINISH_LDS_ROWS 1 // (round 3, same box: finish_adam 0.106 / 0.102 -> 0.102 / 0.097 ms; 0 = four 16-byte loads per lane at a 64-byte stride)
+#endif
 #ifdef LFS_EMULATE
-extern "C" { __attribute__((visibility("default"))) unsigned long long lfs_emul_counters[4] = {0, 0, 0, 0}; }
+extern "C" { __attribute__((visibility("default"))) unsigned long long lfs_emul_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0}; }
 #define LFS_EMUL_COUNT(i) do { if ((threadIdx.x & 63) == 0) ++lfs_emul_counters[i]; } while (0)
+// lane utilisation of an accumulated backward evaluation: [4] += live lanes, [5] += 8x4 half cells (rows 0-3 / 4-7) with a live lane, [6] += 4x4 quarters with one
+#define LFS_EMUL_LANES(m) do { const unsigned long long m_ = (m); if ((threadIdx.x & 63) == 0) { lfs_emul_counters[4] += __builtin_popcountll(m_); \
+    lfs_emul_counters[5] += ((m_ & 0xffffffffull) != 0) + ((m_ >> 32) != 0); \
+    for (int q_ = 0; q_ < 4; ++q_) { const unsigned long long qm_ = (0x0f0f0f0full << ((q_ & 1) * 4)) << ((q_ >> 1) * 32); lfs_emul_counters[6] += (m_ & qm_) != 0; } } } while (0)
 #else
 #define LFS_EMUL_COUNT(i) do { } while (0)
+#define LFS_EMUL_LANES(m) do { } while (0)
 #endif
 
 namespace lfs {
@@ -475,6 +483,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         LFS_EMUL_COUNT(2);
         if (__ballot(valid) == 0ull) return;
         LFS_EMUL_COUNT(3);
+        LFS_EMUL_LANES(__ballot(valid));
 
         // Invalid lanes are masked by zeroing three scalars (fac, v_op, and through it s): every reduced value below is
         // a product with one of them. (All factors are finite for an inactive lane: its direction is 0, so w = gro, t = 0.)
@@ -670,10 +679,31 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
         }
     }
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+#if LFS_FINISH_LDS_ROWS
+    // the 64 accumulator rows of a wavefront (4 KB contiguous) as four fully coalesced 1-KB loads, handed to their lanes through a wave-private LDS block
+    // (row stride 20 floats: 16-byte aligned, conflict-free on the read side) instead of four 16-byte loads per lane at a 64-byte stride
+    __shared__ float4 s_rows[4][64 * 5];
+    float4* const rows = s_rows[threadIdx.x >> 6];
+    {
+        const uint32_t lane = threadIdx.x & 63, g0 = gid - lane;
+        const float4* src = reinterpret_cast<const float4*>(acc + size_t(g0) * ACC_STRIDE);
+        float4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const uint32_t idx = i * 64 + lane; t[i] = (g0 + (idx >> 2) < N) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const uint32_t idx = i * 64 + lane; rows[(idx >> 2) * 5 + (idx & 3)] = t[i]; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (gid >= N) return;
+    float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+    const float4* a4 = rows + (threadIdx.x & 63) * 5;
+    const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
+#else
     if (gid >= N) return;
     float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
     const float4* a4 = reinterpret_cast<const float4*>(acc + size_t(gid) * ACC_STRIDE);
     const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
+#endif
     const float v_opac = a3.x;
     const float A[9] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x};
     const f3 G{-a2.y, -a2.z, -a2.w};
@@ -826,7 +856,7 @@ static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom&
     g.blocks_per_tile = g.wpt / g.waves_per_block;
     g.threads = g.waves_per_block * 64;
     const uint64_t nb = uint64_t(cams->C) * g.tw * g.th * g.blocks_per_tile;
-    g.grid = uint32_t(((nb + 7) / 8) * 8);
+    g.grid = cell_grid_blocks(nb, g.blocks_per_tile);
     g.cells = uint64_t(cams->C) * g.tw * g.th * g.wpt;
     return true;
 }
@@ -837,7 +867,7 @@ static RasterGeom wave_geom(const lfs_cameras* cams, const RasterGeom& g) {
 #if LFS_RASTER_WAVE_BLOCKS
     w.waves_per_block = 1; w.blocks_per_tile = g.wpt; w.threads = 64;
     const uint64_t nb = uint64_t(cams->C) * g.tw * g.th * w.blocks_per_tile;
-    w.grid = uint32_t(((nb + 7) / 8) * 8);
+    w.grid = cell_grid_blocks(nb, w.blocks_per_tile);
 #else
     (void)cams;
 #endif

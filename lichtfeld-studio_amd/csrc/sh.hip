@@ -167,13 +167,39 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
     const uint32_t g0 = blockIdx.x * 64u;
     const int degree = a.degree;
     const int Kd = (degree + 1) * (degree + 1);
+    // Memory round trips of a wavefront, in series: (1) the visibility word and the direction of its 64 Gaussians, issued together; (2) the coefficient rows of
+    // the visible ones - issued as soon as the visibility BALLOT is known, before the basis polynomial is evaluated, so the direction's latency and the
+    // polynomial hide under them. (Until round 3 the chain was radii.x -> radii.y -> means -> basis -> LDS -> coefficients: four round trips, 0.073 ms for
+    // 224 MB at 1M Gaussians = 3.1 TB/s.)
+    const uint32_t gmine = g0 + lane;
+    bool on = false;
+    f3 d{0.f, 0.f, 1.f};
+    if (gmine < a.n) {
+        d = sh_dir<MODEL>(a, gmine);   // (read for masked-out rows too: 12 B, no dependent wait)
+        if (MODEL && a.mask_u32 == nullptr) { const int2 r = *reinterpret_cast<const int2*>(a.radii + 2 * size_t(gmine)); on = r.x > 0 && r.y > 0; }
+        else on = sh_on<MODEL>(a, gmine);
+    }
+    const unsigned long long vis = __ballot(on);
+    constexpr int GPI = 64 / LPG; // Gaussians per iteration
+    const int k = lane % LPG;
+    // all coefficient loads of the wavefront are issued before the first use (LPG independent 12-byte loads per lane in flight);
+    // masked-out Gaussians get colour 0 and their coefficients are not fetched
+    float c0[LPG], c1[LPG], c2[LPG];
+#pragma unroll
+    for (int it = 0; it < LPG; ++it) {
+        const uint32_t gl = it * GPI + lane / LPG;
+        const uint32_t g = g0 + gl;
+        c0[it] = c1[it] = c2[it] = 0.f;
+        if (k < Kd && ((vis >> gl) & 1ull)) {
+            const float* cf = sh_coef<MODEL>(a.coeffs, a.sh0, a.shN, a.K, g, k);
+            c0[it] = cf[0]; c1[it] = cf[1]; c2[it] = cf[2];
+        }
+    }
     {   // phase 1
-        const uint32_t g = g0 + lane;
         float b[25];
 #pragma unroll
         for (int k = 0; k < 25; ++k) b[k] = 0.f;
-        if (g < a.n && sh_on<MODEL>(a, g)) {
-            f3 d = sh_dir<MODEL>(a, g);
+        if (on) {
             if (degree >= 1) { const float inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
             sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
         } // masked-out rows: b = 0 -> colour 0
@@ -181,21 +207,6 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
         for (int k = 0; k < LPG; ++k) lds[lane * (LPG + 1) + k] = (k < 25) ? b[k] : 0.f;
     }
     __syncthreads();
-    constexpr int GPI = 64 / LPG; // Gaussians per iteration
-    const int k = lane % LPG;
-    // all coefficient loads of the wavefront are issued before the first use (LPG independent 12-byte loads per lane in flight);
-    // b_0 != 0 marks the rows that are evaluated at all (masked-out Gaussians have b = 0 and their coefficients are not fetched)
-    float c0[LPG], c1[LPG], c2[LPG];
-#pragma unroll
-    for (int it = 0; it < LPG; ++it) {
-        const uint32_t gl = it * GPI + lane / LPG;
-        const uint32_t g = g0 + gl;
-        c0[it] = c1[it] = c2[it] = 0.f;
-        if (g < a.n && k < Kd && lds[gl * (LPG + 1)] != 0.f) {
-            const float* cf = sh_coef<MODEL>(a.coeffs, a.sh0, a.shN, a.K, g, k);
-            c0[it] = cf[0]; c1[it] = cf[1]; c2[it] = cf[2];
-        }
-    }
 #pragma unroll
     for (int it = 0; it < LPG; ++it) {
         const uint32_t gl = it * GPI + lane / LPG;
@@ -234,7 +245,9 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
     const bool want_dirs = (v_dirs != nullptr) && degree >= 1;
     // phase 1 (lane = Gaussian)
     const uint32_t gmine = g0 + lane;
-    const bool on = gmine < a.n && sh_on<MODEL>(a, gmine);
+    // every operand of phase 1 is requested at once - visibility, direction, dL/dcolour, the stored colour - and masked afterwards: one memory round trip
+    // instead of three in series (radii.x -> radii.y -> the rest); the rows of a masked-out Gaussian are read and ignored
+    bool on = false;
     f3 d{0.f, 0.f, 0.f};
     float inorm = 1.f;
     {
@@ -242,19 +255,22 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
 #pragma unroll
         for (int k = 0; k < 25; ++k) b[k] = 0.f;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-        if (on) {
-            d = sh_dir<MODEL>(a, gmine);
-            if (degree >= 1) { inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
-            sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
+        if (gmine < a.n) {
+            f3 dr = sh_dir<MODEL>(a, gmine);
             const size_t vs = (MODEL && a.vs) ? a.vs : 3, cs = (MODEL && a.cs) ? a.cs : 3;
+            float w0, w1, w2, k0 = 1.f, k1 = 1.f, k2 = 1.f;
             if (MODEL && a.vs == 16 && ((reinterpret_cast<uintptr_t>(v_colors) - 4) & 15) == 0) { // rows of a rasterizer accumulator (3DGUT: slots 13..15, fastgs: 5..7): ONE aligned 16-byte load instead of three strided dwords
                 const float4 r = *reinterpret_cast<const float4*>(v_colors + 16 * size_t(gmine) - 1);
-                v0 = r.y; v1 = r.z; v2 = r.w;
-            } else { v0 = v_colors[vs * gmine]; v1 = v_colors[vs * gmine + 1]; v2 = v_colors[vs * gmine + 2]; }
-            if (MODEL) {
-                if (!(a.colors[cs * gmine] > 0.f)) v0 = 0.f;
-                if (!(a.colors[cs * gmine + 1] > 0.f)) v1 = 0.f;
-                if (!(a.colors[cs * gmine + 2] > 0.f)) v2 = 0.f;
+                w0 = r.y; w1 = r.z; w2 = r.w;
+            } else { w0 = v_colors[vs * gmine]; w1 = v_colors[vs * gmine + 1]; w2 = v_colors[vs * gmine + 2]; }
+            if (MODEL) { k0 = a.colors[cs * gmine]; k1 = a.colors[cs * gmine + 1]; k2 = a.colors[cs * gmine + 2]; }
+            if (MODEL && a.mask_u32 == nullptr) { const int2 r = *reinterpret_cast<const int2*>(a.radii + 2 * size_t(gmine)); on = r.x > 0 && r.y > 0; }
+            else on = sh_on<MODEL>(a, gmine);
+            if (on) {
+                d = dr;
+                if (degree >= 1) { inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
+                sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
+                v0 = (k0 > 0.f) ? w0 : 0.f; v1 = (k1 > 0.f) ? w1 : 0.f; v2 = (k2 > 0.f) ? w2 : 0.f;
             }
         }
 #pragma unroll

@@ -304,7 +304,8 @@ def test_fused_front_half_matches_the_separate_kernels(lfs):
     finally:
         fused.FUSE_ACT_PROJ = True
     (c, gc, lc), (b, gb, lb) = res[True], res[False]
-    assert c.n_isects == b.n_isects and torch.equal(c.radii, b.radii) and torch.equal(c.image_hwc, b.image_hwc) and lc == lb
+    # (the loss value is a float-atomic sum of per-wavefront partials: its last bit depends on their arrival order)
+    assert c.n_isects == b.n_isects and torch.equal(c.radii, b.radii) and torch.equal(c.image_hwc, b.image_hwc) and abs(lc - lb) <= 2e-6 * abs(lb)
 
 
 def test_batched_views_step_matches_the_view_by_view_step(lfs):

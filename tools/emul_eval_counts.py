@@ -1,4 +1,4 @@
-"""Developer script (CPU only): wave-evaluation counts of the rasterizer's default and quadrant-row kernels on a WINDOW of SYN-B (same
+"""Developer script (CPU only): wave-evaluation counts and lane utilisation of the rasterizer's kernels on a WINDOW of SYN-B (same
 Gaussian statistics as the benchmark: the full scene, a 160x96-pixel crop of the 1080p view), run on the wavefront emulator of tests/emul.
     python tools/emul_eval_counts.py [width height]"""
 import ctypes as C
@@ -28,7 +28,7 @@ ops.load_library = lambda: lib
 ops.require_gpu = lambda *a: None
 ops.stream = lambda: None
 ops.workspace = lambda nbytes, dev, tag: torch.zeros(max(int(nbytes), 256), dtype=torch.uint8)
-counters = (C.c_ulonglong * 4).in_dll(lib, "lfs_emul_counters")
+counters = (C.c_ulonglong * 8).in_dll(lib, "lfs_emul_counters")
 
 sc = scenes.syn_b(n=1_000_000, n_views=4)
 quats = torch.nn.functional.normalize(sc.raw_quats, dim=-1).numpy(); scales = sc.raw_scales.exp().numpy(); opac = torch.sigmoid(sc.raw_opacities).numpy()
@@ -51,15 +51,11 @@ t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt)
 colors = rng.random((1, N, 3)).astype(np.float32)
 args = (t(means), t(quats), t(scales), t(colors), t(opac[None]), None, None, W, H, 16, t(vm), None, t(K), lfs.CameraModelType.PINHOLE, None,
         lfs.ShutterType.GLOBAL, None, None, None, t(offs, torch.int32), t(flat, torch.int32))
-res = {}
-for flag, name in ((0, "default 8x8 cells"), (4, "quadrant rows")):
-    lib.lfs_set_debug_flags(flag)
-    for i in range(4): counters[i] = 0
-    rc, ra, li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
-    ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, torch.randn_like(rc), torch.randn_like(ra))
-    res[name] = list(counters)
-    print(f"{name:22s} fwd evaluations {counters[0]:8d} (composited {counters[1]:8d})   bwd evaluations {counters[2]:8d} (accumulated {counters[3]:8d})")
 lib.lfs_set_debug_flags(0)
-b = res["default 8x8 cells"]
-for name, c in res.items():
-    print(f"{name:22s} vs default: fwd {b[0] / c[0]:.2f}x fewer, bwd {b[2] / c[2]:.2f}x fewer")
+for i in range(8): counters[i] = 0
+rc, ra, li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
+ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, torch.randn_like(rc), torch.randn_like(ra))
+c = list(counters)
+print(f"8x8 cells: fwd evaluations {c[0]} (composited {c[1]}), bwd evaluations {c[2]} (accumulated {c[3]}) = {c[2] / len(flat):.3f} per tile entry")
+print(f"accumulated bwd evaluations: {c[4] / c[3]:.1f} of 64 lanes live ({100 * c[4] / (64 * c[3]):.0f} %); 8x4 half cells with a live lane: {c[5] / c[3]:.2f} of 2; "
+      f"4x4 quarters: {c[6] / c[3]:.2f} of 4")
