@@ -10,6 +10,17 @@ struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2, r3; };
 
 constexpr int ACC_STRIDE = 16; // A(9) | G(3) | opacity | rgb(3)
 
+// LFS_REC_LOG2 (round 3, the 3DGUT rasterizer): records carry M' = c M, g' = c g with c = sqrt(0.5 log2 e), and log2(opacity) in place of the opacity, so that
+//   alpha_raw = opac * exp(-0.5 |w|^2) = exp2(log2(opac) - |w'|^2),   w' = g' - t q' = c w  (t is scale-free)
+// costs the evaluation 3 fma + 1 exp instead of 3 fma + 2 mul + 1 exp, and the backward works on s = alpha_raw * dL/dalpha directly (it never needs vis or
+// the opacity on their own). What the backward accumulates is then  A' = c A,  G' = c G  and  O' = opac * dL/dopac: the finish kernels undo the two
+// per-Gaussian constants when they read the row (REC_UNSCALE, 1 / opac). 0 = the round-1/2 records (un-scaled, plain opacity).
+#ifndef LFS_REC_LOG2
+#define LFS_REC_LOG2 1
+#endif
+constexpr float REC_SCALE = 0.84932180028801904f;   // sqrt(0.5 * log2(e))
+constexpr float REC_UNSCALE = 1.17741002251547469f; // 1 / REC_SCALE = sqrt(2 ln 2)
+
 
 // ---------------------------------------------------------------------------
 // tile / cell bookkeeping shared by cull, fwd and bwd

@@ -33,10 +33,22 @@ LFS_DI void pack_gaussian(const CamDev& cam, const f3 mu, const float4 q, const 
 #pragma unroll
             for (int c = 0; c < 3; ++c) Mr.m[r][c] = M.m[r][0] * Ri.m[0][c] + M.m[r][1] * Ri.m[1][c] + M.m[r][2] * Ri.m[2][c];
     }
+#if LFS_REC_LOG2
+    // The record in the form the per-pixel evaluation wants (lfs_raster_common.cuh, REC_SCALE): matrix (and, global shutter, g) times sqrt(0.5 log2 e), and
+    // log2(opacity) - alpha = exp2(log2(opac) - |w'|^2) is then three fused multiply-adds and one v_exp_f32 (opacity 0: -inf -> alpha 0, never composited)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Mr.m[r][c] *= REC_SCALE;
+    if (UNIFORM_ORIGIN) g = g * REC_SCALE;
+    const float opac_field = __builtin_amdgcn_logf(opac);   // v_log_f32 = log2
+#else
+    const float opac_field = opac;
+#endif
     rec.r0 = make_float4(Mr.m[0][0], Mr.m[0][1], Mr.m[0][2], g.x);
     rec.r1 = make_float4(Mr.m[1][0], Mr.m[1][1], Mr.m[1][2], g.y);
     rec.r2 = make_float4(Mr.m[2][0], Mr.m[2][1], Mr.m[2][2], g.z);
-    rec.r3 = make_float4(opac, c0, c1, c2);
+    rec.r3 = make_float4(opac_field, c0, c1, c2);
     ConicRec k = conic_never();
     if (UNIFORM_ORIGIN) {
         const m3& Ri = cam.Rinv;                      // camera -> world, so world -> camera is its transpose

@@ -240,7 +240,7 @@ constexpr int RAY_ROLLING = 0, RAY_GLOBAL = 1;
 // Distance of the Gaussian centre to the ray line in the Gaussian's normalised frame. With q = M d (un-normalised),
 // t = (gro . q) / |q|^2 and the foot vector w = gro - t q:  |w| equals the reference's |normalize(q) x gro|, and the
 // backward collapses to dL/dgro = -s w, dL/dq = t s w (s = vis * dL/dvis): no normalisation, no cross products.
-struct RayEval { f3 om, w; float t, vis; };
+struct RayEval { f3 om, w; float t, vis; }; // LFS_REC_LOG2: w = c w_true and `vis` is alpha_raw = opac * vis_true (see lfs_raster_common.cuh)
 template <int MODE>
 LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& d, RayEval& e) {
     e.om = {0.f, 0.f, 0.f};
@@ -256,11 +256,19 @@ LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& d, RayEval& e)
                fma3(rec.r1.x, d.x, rec.r1.y, d.y, rec.r1.z, d.z),
                fma3(rec.r2.x, d.x, rec.r2.y, d.y, rec.r2.z, d.z)};
     const float l = fma3(q.x, q.x, q.y, q.y, q.z, q.z);
+#if LFS_REC_LOG2
+    // l == 0 (inactive lane: d = 0; degenerate record: M = 0): q = 0 as well, so t = 0 * FLT_MAX = 0 and w = gro - one v_min instead of compare + select
+    const float rl = fminf(fast_rcp(l), 3.402823466e38f);
+    e.t = fma3(gro.x, q.x, gro.y, q.y, gro.z, q.z) * rl;
+    e.w = {__builtin_fmaf(-e.t, q.x, gro.x), __builtin_fmaf(-e.t, q.y, gro.y), __builtin_fmaf(-e.t, q.z, gro.z)};
+    e.vis = __builtin_amdgcn_exp2f(__builtin_fmaf(-e.w.z, e.w.z, __builtin_fmaf(-e.w.y, e.w.y, __builtin_fmaf(-e.w.x, e.w.x, rec.r3.x))));
+#else
     const float rl = l > 0.f ? fast_rcp(l) : 0.f; // l == 0: no direction (inactive lane / degenerate record), w = gro
     e.t = fma3(gro.x, q.x, gro.y, q.y, gro.z, q.z) * rl;
     e.w = {__builtin_fmaf(-e.t, q.x, gro.x), __builtin_fmaf(-e.t, q.y, gro.y), __builtin_fmaf(-e.t, q.z, gro.z)};
     // exp(-0.5 |w|^2) as one exp2: -0.5 * log2(e) = -0.72134752
     e.vis = __builtin_amdgcn_exp2f(-0.72134752044448170f * fma3(e.w.x, e.w.x, e.w.y, e.w.y, e.w.z, e.w.z));
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -329,7 +337,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     auto eval = [&](const GaussRec& rec, const int2 e) {
         RayEval re;
         ray_eval<MODE>(rec, ro, rd, re);
-        const float alpha = fminf(0.999f, rec.r3.x * re.vis);
+        const float alpha = fminf(0.999f, LFS_REC_LOG2 ? re.vis : rec.r3.x * re.vis);
         const bool pass = !(alpha < thr); // live pixel and alpha >= 1/255 (a NaN alpha passes, as in the reference's `if (alpha < 1/255) continue`)
         LFS_EMUL_COUNT(0);
         if (__ballot(pass) == 0ull) return;
@@ -476,8 +484,12 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     auto eval = [&](const GaussRec& rec, const int2 e) {
         RayEval re;
         ray_eval<MODE>(rec, ro, rd, re);
+#if LFS_REC_LOG2
+        const float araw = re.vis;
+#else
         const float vis = re.vis, opac = rec.r3.x;
         const float araw = opac * vis;
+#endif
         const float alpha = fminf(0.999f, araw);
         const bool valid = e.y <= bin_final && !(alpha < (1.f / 255.f)); // (inactive lanes carry bin_final = -1; vis > 1 cannot happen)
         LFS_EMUL_COUNT(2);
@@ -513,9 +525,15 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 #pragma unroll
         for (int k = CDIM; k < 3; ++k) v[13 + k] = 0.f;
         // through alpha = min(0.999, opac * vis): no gradient on the clamped side
+#if LFS_REC_LOG2
+        const float sgeo = (valid && araw <= 0.999f) ? araw * v_alpha : 0.f; // s = alpha_raw * dL/dalpha = opac * dL/dopacity = vis * dL/dvis
+        const float v_op = sgeo;                                            // (slot 12 holds opac * dL/dopacity: the finish kernels divide)
+        v[12] = v_op;
+#else
         const float v_op = (valid && araw <= 0.999f) ? vis * v_alpha : 0.f; // dL/dopacity
         v[12] = v_op;
         const float sgeo = opac * v_op;                                     // s = vis * dL/dvis
+#endif
 #if LFS_BWD_PK
         if (CDIM == 3 && MODE == RAY_GLOBAL) { // the 18 products and the first two reduction levels on register PAIRS (v_pk_mul_f32 / v_pk_add_f32)
             v2f V[8];
@@ -571,7 +589,8 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
     const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
     const CamDev* __restrict__ cams, const float* __restrict__ acc,
     float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
-    float* __restrict__ v_colors, float* __restrict__ v_opacities, const float* __restrict__ loss_slots, float* __restrict__ loss) {
+    float* __restrict__ v_colors, float* __restrict__ v_opacities, const float* __restrict__ loss_slots, float* __restrict__ loss,
+    const float* __restrict__ opacities) {
     if (loss_slots != nullptr && blockIdx.x == 0) { // fused MSE: fold the backward kernel's partial sums into the caller's accumulator
         float v = threadIdx.x < LOSS_SLOTS ? loss_slots[threadIdx.x] : 0.f;
 #pragma unroll
@@ -586,7 +605,15 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
     for (uint32_t cid = 0; cid < C; ++cid) {
         const size_t idx = size_t(cid) * N + gid;
         const float4* a4 = reinterpret_cast<const float4*>(acc + idx * ACC_STRIDE);
-        const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
+        float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
+#if LFS_REC_LOG2
+        { // the row was accumulated against the scaled record (lfs_raster_common.cuh): A' = c A, G' = c G, slot 12 = opac * dL/dopac
+            a0.x *= REC_UNSCALE; a0.y *= REC_UNSCALE; a0.z *= REC_UNSCALE; a0.w *= REC_UNSCALE; a1.x *= REC_UNSCALE; a1.y *= REC_UNSCALE; a1.z *= REC_UNSCALE;
+            a1.w *= REC_UNSCALE; a2.x *= REC_UNSCALE; a2.y *= REC_UNSCALE; a2.z *= REC_UNSCALE; a2.w *= REC_UNSCALE;
+            const float op = opacities[idx];
+            a3.x = a3.x != 0.f ? a3.x / op : 0.f;
+        }
+#endif
         v_opacities[idx] = a3.x;
         float* vcol = v_colors + idx * channels;
         vcol[0] = a3.y;
@@ -679,7 +706,7 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
         }
     }
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-#if LFS_FINISH_LDS_ROWS
+#if LFS_FINISH_LDS_ROWS && !defined(LFS_EMULATE)   // (the emulator switches lanes only at cross-lane operations: no wave-private LDS hand-over there)
     // the 64 accumulator rows of a wavefront (4 KB contiguous) as four fully coalesced 1-KB loads, handed to their lanes through a wave-private LDS block
     // (row stride 20 floats: 16-byte aligned, conflict-free on the read side) instead of four 16-byte loads per lane at a 64-byte stride
     __shared__ float4 s_rows[4][64 * 5];
@@ -704,9 +731,15 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
     const float4* a4 = reinterpret_cast<const float4*>(acc + size_t(gid) * ACC_STRIDE);
     const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
 #endif
-    const float v_opac = a3.x;
+#if LFS_REC_LOG2
+    // the row was accumulated against the scaled record (lfs_raster_common.cuh): A' = c A, G' = c G, slot 12 = opac * dL/dopac (divided where `o` is loaded)
+    const float A[9] = {a0.x * REC_UNSCALE, a0.y * REC_UNSCALE, a0.z * REC_UNSCALE, a0.w * REC_UNSCALE, a1.x * REC_UNSCALE, a1.y * REC_UNSCALE, a1.z * REC_UNSCALE,
+                        a1.w * REC_UNSCALE, a2.x * REC_UNSCALE};
+    const f3 G{-a2.y * REC_UNSCALE, -a2.z * REC_UNSCALE, -a2.w * REC_UNSCALE};
+#else
     const float A[9] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x};
     const f3 G{-a2.y, -a2.z, -a2.w};
+#endif
     bool any = G.x != 0.f || G.y != 0.f || G.z != 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) any |= A[k] != 0.f;
@@ -723,6 +756,7 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
     const float4 q = reinterpret_cast<const float4*>(quats)[gid];
     const float4 rq = reinterpret_cast<const float4*>(raw_quats)[gid];
     const float o = opacities[gid];
+    const float v_opac = LFS_REC_LOG2 ? (a3.x != 0.f ? a3.x / o : 0.f) : a3.x;
     float m0[3] = {0.f, 0.f, 0.f}, v0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f}, m1[3] = {0.f, 0.f, 0.f}, v1[3] = {0.f, 0.f, 0.f};
     float4 mq = make_float4(0.f, 0.f, 0.f, 0.f), vq4 = mq;
     float po = 0.f, mo = 0.f, vo = 0.f;
@@ -1065,8 +1099,8 @@ static int raster_bwd_impl(
     lfs::ProfScope prof_fin("raster_finish", s);
     const float* slots = mse ? w.acc + ACC_STRIDE * CN : nullptr;
     float* loss_out = mse ? mse->loss : nullptr;
-    if (uniform) hipLaunchKernelGGL(raster_finish_kernel<true>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities, slots, loss_out);
-    else hipLaunchKernelGGL(raster_finish_kernel<false>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities, slots, loss_out);
+    if (uniform) hipLaunchKernelGGL(raster_finish_kernel<true>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities, slots, loss_out, opacities);
+    else hipLaunchKernelGGL(raster_finish_kernel<false>, fg, dim3(256), 0, s, C, N, channels, means, quats, scales, w.cams, w.acc, v_means, v_quats, v_scales, v_colors, v_opacities, slots, loss_out, opacities);
     return (int)hipGetLastError();
 }
 

@@ -203,6 +203,7 @@ static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
+#define __builtin_amdgcn_logf(x) log2f(x)
 #define __builtin_amdgcn_readfirstlane(x) emu::readfirstlane_u32(uint32_t(x))
 #define __builtin_amdgcn_readlane(x, l) emu::xlane_u32(uint32_t(x), (l))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu::update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
