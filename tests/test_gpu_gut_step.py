@@ -51,6 +51,28 @@ def test_cxx_step_is_bit_identical_to_the_python_enqueued_step(lfs):
     _same_state(a, b, 4)
 
 
+@pytest.mark.parametrize("n", [1, 63, 65, 129])
+def test_cxx_step_on_ragged_gaussian_counts(lfs, n):
+    """N = 1 / 63 / 65 / 129: partial last wavefronts in every per-Gaussian kernel (the finish pass hands its accumulator rows over through wave-private
+    LDS in blocks of 64 rows; the SH kernels work on 64 Gaussians per workgroup) and an image of mostly empty tiles - the C++ step against the
+    Python-enqueued one, bit for bit."""
+    from lichtfeld_studio_amd import scenes
+    sc = scenes.syn_a(n=n, sh_degree=1)
+    target = torch.rand(3, sc.height, sc.width, generator=torch.Generator().manual_seed(9)).to(DEV) * 0.7
+    lib = lfs.load_library()
+    try:
+        lib.lfs_set_debug_flags(16)
+        a, b = _pair(lfs, sc)
+        for _ in range(3):
+            la, lb = a.train_step([target], views=[0]), b.train_step([target], views=[0])
+        torch.cuda.synchronize()
+    finally:
+        lib.lfs_set_debug_flags(0)
+    assert abs(float(la) - float(lb)) <= 2e-6 * float(lb) and float(la) > 0
+    assert a.last_n_isects == b.last_n_isects
+    _same_state(a, b, 3)
+
+
 @pytest.mark.parametrize("kind", ["l1_ssim", "bilateral", "mcmc", "mse_early"])
 def test_cxx_split_step_is_bit_identical_for_the_other_losses_and_mcmc(lfs, kind):
     """The steps that keep gradient tensors - L1 + D-SSIM, bilateral grid (+ its TV loss and Adam), MCMC (noise every step, regularisers; relocation on the
