@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(64) fg_blend_bwd_kernel(
     float* __restrict__ acc) {
     const uint32_t total_tiles = gw * gh;
 #if LFS_FG_LDS_REDUCE
-    __shared__ float s_red[64 * RED9_STRIDE]; // this wavefront's [64][9] transpose block (wave_sum9_atomic_lds)
+    __shared__ __attribute__((aligned(16))) float s_red[RED9_SCRATCH_FLOATS]; // this wavefront's transpose block (wave_sum9_atomic_lds)
     float* const red_scratch = s_red;
 #endif
     const CellCtx cc = cell_ctx(total_tiles, total_tiles, gw, TILE, WPT, 1);

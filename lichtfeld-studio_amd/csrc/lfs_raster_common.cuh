@@ -258,9 +258,37 @@ LFS_DI void wave_sum16_atomic_pk(const v2f (&V)[8], float* __restrict__ dst, con
 // register transpose above (12 half-rate swaps, 6 selects, 5 DPP adds and the wait states both need): the backward is VALU-issue bound, its LDS pipe idle.
 // A wavefront's LDS operations execute in order, so the write -> read -> (next entry's) write sequence needs no barrier.
 constexpr int RED_STRIDE = 17;
+// LFS_RED_ADDTID (round 3, second form): the block is stored VALUE-major, [16][72] floats - value k of lane l at k * 72 + l - with ds_write_addtid_b32
+// (address = M0 + offset + 4 * lane: no address VGPR, 2 LDS cycles per instruction instead of 6 for ds_write2_b32: MI355X_MICROARCH.md, LDS), and lane L
+// (k = L & 15, q = L >> 4) reads the four 16-byte pieces {16 j + 4 q .. + 3}, j = 0..3, of row k with ds_read_b128 (row stride 72: the 16 lanes of every
+// b128 service group hit 16 disjoint 4-bank ranges). 16 x 2 + 4 x 4 = 48 LDS cycles per evaluation instead of 8 x 6 + 8 x 4 = 80.
+#ifndef LFS_RED_ADDTID
+#define LFS_RED_ADDTID 1
+#endif
+constexpr int RED_ROW = 72;
+constexpr int RED_SCRATCH_FLOATS = (LFS_RED_ADDTID ? 16 * RED_ROW : 64 * RED_STRIDE); // per wavefront
 template <int ACC = 0>
-LFS_DI void wave_sum16_atomic_lds(const v2f (&V)[8], float* __restrict__ dst, const uint32_t lane, float* __restrict__ scratch /* this wavefront's [64 * RED_STRIDE] */,
+LFS_DI void wave_sum16_atomic_lds(const v2f (&V)[8], float* __restrict__ dst, const uint32_t lane, float* __restrict__ scratch /* this wavefront's [RED_SCRATCH_FLOATS] */,
                                   unsigned long long* __restrict__ det64 = nullptr) {
+    float c[16];
+#if LFS_RED_ADDTID && !defined(LFS_EMULATE)
+    {
+        const uint32_t base = __builtin_amdgcn_readfirstlane(uint32_t(reinterpret_cast<uintptr_t>(scratch))); // LDS byte address (low half of the flat address)
+        // (s_nop: one wait state between the SALU write of M0 and an add-TID LDS instruction)
+        asm volatile("s_mov_b32 m0, %16\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:288\n\tds_write_addtid_b32 %2 offset:576\n\tds_write_addtid_b32 %3 offset:864\n\t"
+                     "ds_write_addtid_b32 %4 offset:1152\n\tds_write_addtid_b32 %5 offset:1440\n\tds_write_addtid_b32 %6 offset:1728\n\tds_write_addtid_b32 %7 offset:2016\n\t"
+                     "ds_write_addtid_b32 %8 offset:2304\n\tds_write_addtid_b32 %9 offset:2592\n\tds_write_addtid_b32 %10 offset:2880\n\tds_write_addtid_b32 %11 offset:3168\n\t"
+                     "ds_write_addtid_b32 %12 offset:3456\n\tds_write_addtid_b32 %13 offset:3744\n\tds_write_addtid_b32 %14 offset:4032\n\tds_write_addtid_b32 %15 offset:4320"
+                     :: "v"(V[0].x), "v"(V[0].y), "v"(V[1].x), "v"(V[1].y), "v"(V[2].x), "v"(V[2].y), "v"(V[3].x), "v"(V[3].y), "v"(V[4].x), "v"(V[4].y), "v"(V[5].x),
+                        "v"(V[5].y), "v"(V[6].x), "v"(V[6].y), "v"(V[7].x), "v"(V[7].y), "s"(base) : "memory", "m0");
+        __builtin_amdgcn_wave_barrier();
+        const float4* rd = reinterpret_cast<const float4*>(scratch + (lane & 15) * RED_ROW + 4 * (lane >> 4));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float4 r = rd[4 * j]; c[4 * j] = r.x; c[4 * j + 1] = r.y; c[4 * j + 2] = r.z; c[4 * j + 3] = r.w; }
+        __builtin_amdgcn_wave_barrier();
+    }
+#else
     float* wr = scratch + lane * RED_STRIDE;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { wr[2 * j] = V[j].x; wr[2 * j + 1] = V[j].y; }
@@ -269,12 +297,12 @@ LFS_DI void wave_sum16_atomic_lds(const v2f (&V)[8], float* __restrict__ dst, co
     __builtin_amdgcn_wave_barrier(); // (no instruction: keeps the compiler from moving the reads across the writes of OTHER lanes it cannot see)
 #endif
     const float* rd = scratch + (lane >> 4) * (16 * RED_STRIDE) + (lane & 15);
-    float c[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) c[i] = rd[i * RED_STRIDE];
     LFS_WAVE_LOCKSTEP();
 #ifndef LFS_EMULATE
     __builtin_amdgcn_wave_barrier();
+#endif
 #endif
     v2f p0 = v2f{c[0], c[1]} + v2f{c[2], c[3]}, p1 = v2f{c[4], c[5]} + v2f{c[6], c[7]}, p2 = v2f{c[8], c[9]} + v2f{c[10], c[11]}, p3 = v2f{c[12], c[13]} + v2f{c[14], c[15]};
     p0 += p1; p2 += p3; p0 += p2;
@@ -301,7 +329,24 @@ LFS_DI void wave_sum16_atomic_lds(const v2f (&V)[8], float* __restrict__ dst, co
 // The EWA blend backward's NINE sums the same way (a [64][9] block: the odd stride is conflict-free for the row writes and for the column reads alike);
 // lanes 9..15 of every quarter read a duplicate column and are dropped at the atomic. Replaces wave_sum8_atomic + wave_sum1 + two atomics.
 constexpr int RED9_STRIDE = 9;
-LFS_DI void wave_sum9_atomic_lds(const float (&v)[9], float* __restrict__ dst, const uint32_t lane, float* __restrict__ scratch /* this wavefront's [64 * 9] */) {
+constexpr int RED9_SCRATCH_FLOATS = (LFS_RED_ADDTID ? 16 * RED_ROW : 64 * RED9_STRIDE); // per wavefront (value-major form: rows 9..15 are read by the dropped lanes, never written)
+LFS_DI void wave_sum9_atomic_lds(const float (&v)[9], float* __restrict__ dst, const uint32_t lane, float* __restrict__ scratch /* this wavefront's [RED9_SCRATCH_FLOATS] */) {
+    float c[16];
+#if LFS_RED_ADDTID && !defined(LFS_EMULATE)
+    {   // value-major block through ds_write_addtid_b32 / ds_read_b128, as wave_sum16_atomic_lds
+        const uint32_t base = __builtin_amdgcn_readfirstlane(uint32_t(reinterpret_cast<uintptr_t>(scratch)));
+        asm volatile("s_mov_b32 m0, %9\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:288\n\tds_write_addtid_b32 %2 offset:576\n\tds_write_addtid_b32 %3 offset:864\n\t"
+                     "ds_write_addtid_b32 %4 offset:1152\n\tds_write_addtid_b32 %5 offset:1440\n\tds_write_addtid_b32 %6 offset:1728\n\tds_write_addtid_b32 %7 offset:2016\n\t"
+                     "ds_write_addtid_b32 %8 offset:2304"
+                     :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "s"(base) : "memory", "m0");
+        __builtin_amdgcn_wave_barrier();
+        const float4* rd = reinterpret_cast<const float4*>(scratch + (lane & 15) * RED_ROW + 4 * (lane >> 4));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float4 r = rd[4 * j]; c[4 * j] = r.x; c[4 * j + 1] = r.y; c[4 * j + 2] = r.z; c[4 * j + 3] = r.w; }
+        __builtin_amdgcn_wave_barrier();
+    }
+#else
     float* wr = scratch + lane * RED9_STRIDE;
 #pragma unroll
     for (int k = 0; k < 9; ++k) wr[k] = v[k];
@@ -311,12 +356,12 @@ LFS_DI void wave_sum9_atomic_lds(const float (&v)[9], float* __restrict__ dst, c
 #endif
     const uint32_t r = min(lane & 15u, 8u);
     const float* rd = scratch + (lane >> 4) * (16 * RED9_STRIDE) + r;
-    float c[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) c[i] = rd[i * RED9_STRIDE];
     LFS_WAVE_LOCKSTEP();
 #ifndef LFS_EMULATE
     __builtin_amdgcn_wave_barrier();
+#endif
 #endif
     v2f p0 = v2f{c[0], c[1]} + v2f{c[2], c[3]}, p1 = v2f{c[4], c[5]} + v2f{c[6], c[7]}, p2 = v2f{c[8], c[9]} + v2f{c[10], c[11]}, p3 = v2f{c[12], c[13]} + v2f{c[14], c[15]};
     p0 += p1; p2 += p3; p0 += p2;

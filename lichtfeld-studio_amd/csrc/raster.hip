@@ -402,8 +402,8 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     float* __restrict__ acc, float* __restrict__ v_colors_extra, const MseFuse mse = MseFuse{}) {
     const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
 #if LFS_BWD_LDS_REDUCE
-    __shared__ float s_red[(LFS_RASTER_WAVE_BLOCKS ? 1 : 4) * 64 * RED_STRIDE]; // one [64][17] transpose block per wavefront (wave_sum16_atomic_lds)
-    float* const red_scratch = s_red + (threadIdx.x >> 6) * (64 * RED_STRIDE);
+    __shared__ __attribute__((aligned(16))) float s_red[(LFS_RASTER_WAVE_BLOCKS ? 1 : 4) * RED_SCRATCH_FLOATS]; // one transpose block per wavefront (wave_sum16_atomic_lds)
+    float* const red_scratch = s_red + (threadIdx.x >> 6) * RED_SCRATCH_FLOATS;
 #endif
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
     if (!cc.in_grid) return;
