@@ -122,31 +122,58 @@ def build_io(force: bool = False) -> str:
     return IO_OUT
 
 
+TORCH_BACKEND_OUT = os.path.join(HERE, "liblfs_gsplat_torch.so")
 TORCH_OPS_OUT = os.path.join(HERE, "_lfs_torch_ops.so")
 
 
-def build_torch_ops(force: bool = False) -> str:
-    """libtorch wrappers (csrc/torch_ops.cpp = the reference's gsplat::/fast_gs:: C++ signatures) + a pybind
-    module for the tests -> lichtfeld-studio_amd/_lfs_torch_ops.so, linked against liblfs_gsplat.so."""
-    import sysconfig
-
+def _torch_flags():
     import torch
+    tdir = os.path.dirname(torch.__file__)
+    cflags = ["-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-D_GLIBCXX_USE_CXX11_ABI=1",
+              f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include", "-I/opt/rocm/include"]
+    ldflags = [f"-L{tdir}/lib", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", f"-L{HERE}", "-llfs_gsplat", "-llfs_io", "-L/opt/rocm/lib", "-lamdhip64",
+               f"-Wl,-rpath,{tdir}/lib", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    return cflags, ldflags
+
+
+def _fresh(out: str, deps: list[str]) -> bool:
+    return os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps)
+
+
+def build_torch_backend(force: bool = False) -> str:
+    """The drop-in backend library: csrc/torch_ops.cpp (the reference's gsplat:: / fast_gs:: / fusedssim / gs::bilateral_grid C++ signatures on libtorch tensors, over
+    the C ABI of liblfs_gsplat.so) -> lichtfeld-studio_amd/liblfs_gsplat_torch.so. This is what replaces the reference's `gsplat_backend` + `fastgs_backend` static
+    libraries (gsplat/CMakeLists.txt:42, fastgs/CMakeLists.txt:26) at link time; oracle/Makefile `reflink` links the reference's own rasterizer.cpp /
+    rasterizer_autograd.cpp / fused_adam.cpp against it (tests/test_gpu_reference_links.py)."""
     build()
     build_io()
-    srcs = [os.path.join(CSRC, "torch_ops.cpp"), os.path.join(CSRC, "torch_ops_pybind.cpp")]
-    deps = srcs + [os.path.join(HERE, "..", "include", "lfs_gsplat_torch.hpp"), os.path.join(HERE, "..", "include", "lfs_gsplat.h"),
-                   os.path.join(HERE, "..", "include", "lfs_io.h"), OUT, IO_OUT]
-    if not force and os.path.exists(TORCH_OPS_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(TORCH_OPS_OUT) for d in deps):
-        return TORCH_OPS_OUT
-    tdir = os.path.dirname(torch.__file__)
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "lfs_gsplat_torch.hpp"), os.path.join(HERE, "..", "include", "lfs_gut_train_step.hpp"), os.path.join(HERE, "..", "include", "lfs_gsplat.h"),
+            os.path.join(HERE, "..", "include", "lfs_io.h"), OUT, IO_OUT]
+    if not force and _fresh(TORCH_BACKEND_OUT, deps):
+        return TORCH_BACKEND_OUT
+    cflags, ldflags = _torch_flags()
+    cmd = ["g++", *cflags, src, *ldflags, "-o", TORCH_BACKEND_OUT]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"torch backend build failed:\n{' '.join(cmd)}\n{r.stdout[-3000:]}\n{r.stderr[-6000:]}")
+    return TORCH_BACKEND_OUT
+
+
+def build_torch_ops(force: bool = False) -> str:
+    """pybind module over the backend library for the tests (csrc/torch_ops_pybind.cpp) -> lichtfeld-studio_amd/_lfs_torch_ops.so, linked against
+    liblfs_gsplat_torch.so (the wrappers are compiled once, into the library a reference build links)."""
+    import sysconfig
+
     import pybind11
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-D_GLIBCXX_USE_CXX11_ABI=1",
-           "-DTORCH_EXTENSION_NAME=_lfs_torch_ops", "-DTORCH_API_INCLUDE_EXTENSION_H",
-           f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include", "-I/opt/rocm/include", f"-I{pybind11.get_include()}",
-           f"-I{sysconfig.get_paths()['include']}", *srcs,
-           f"-L{tdir}/lib", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python",
-           f"-L{HERE}", "-llfs_gsplat", "-llfs_io", "-L/opt/rocm/lib", "-lamdhip64",
-           f"-Wl,-rpath,{tdir}/lib", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-o", TORCH_OPS_OUT]
+    backend = build_torch_backend(force)
+    src = os.path.join(CSRC, "torch_ops_pybind.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "lfs_gsplat_torch.hpp"), backend]
+    if not force and _fresh(TORCH_OPS_OUT, deps):
+        return TORCH_OPS_OUT
+    cflags, ldflags = _torch_flags()
+    cmd = ["g++", *cflags, "-DTORCH_EXTENSION_NAME=_lfs_torch_ops", "-DTORCH_API_INCLUDE_EXTENSION_H", f"-I{pybind11.get_include()}",
+           f"-I{sysconfig.get_paths()['include']}", src, "-llfs_gsplat_torch", *ldflags, "-ltorch_python", "-o", TORCH_OPS_OUT]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"torch ops build failed:\n{' '.join(cmd)}\n{r.stdout[-3000:]}\n{r.stderr[-6000:]}")

@@ -33,7 +33,7 @@ def build(ref: bool = True) -> None:
         # targets cost a minute or two of header parsing each when built from scratch. The four the core parity tests use must build; the others only serve the
         # *_reference tests, which skip without them, so their failure does not fail build().
         core = ["ref", "refk", "refk_fastgs", "refk_loss"]
-        more = ["refcolmap", "refsplatio", "refstrategy", "refraster", "reflosshost", "refply", "refgsplat", "reffast"]
+        more = ["refcolmap", "refsplatio", "refstrategy", "refraster", "reflosshost", "refply", "refgsplat", "reffast", "reflink"]
         subprocess.run(["make", "-C", _HERE, "-k", "-j8", *core, *more], check=False, capture_output=True)
         subprocess.run(["make", "-C", _HERE, *core], check=True, capture_output=True)     # (up to date unless the parallel run failed: then this reports it)
 
@@ -872,8 +872,58 @@ def ref_raster_lib(full=False):
 _REF_RASTER_FULL = {}
 
 
+def ref_links_gpu_lib():
+    """oracle/_ref/libref_links_gpu.so (`make -C oracle reflink`): the reference's own L2 code (rasterizer.cpp, rasterizer_autograd.cpp, camera.cpp, bilateral_grid.cpp,
+    fused_adam.cpp, compiled unmodified against its own gsplat/Ops.h + ROCm libtorch) LINKED to the product backend lichtfeld-studio_amd/liblfs_gsplat_torch.so. Same C
+    entry points as libref_raster_full.so, tensors on cuda:0; the link-level drop-in proof of tests/test_gpu_reference_links.py. None if not built."""
+    if "gpu" not in _REF_RASTER_FULL:
+        path = os.path.join(_HERE, "_ref", "libref_links_gpu.so")
+        if not os.path.exists(path):
+            return None
+        import torch  # noqa: F401  (libtorch / libtorch_hip must be in the process before the library's dependencies resolve)
+        _REF_RASTER_FULL["gpu"] = C.CDLL(path)
+    return _REF_RASTER_FULL["gpu"]
+
+
+def ref_links_fused_adam_steps(params, grads, lrs, iteration0, n_steps):
+    """gs::training::FusedAdam (built as strategy_utils.cpp:20-48 builds it) stepping `n_steps` times from `iteration0` over the linked backend's adam_step_wrapper:
+    six float arrays each for params / grads -> (params, exp_avg, exp_avg_sq, step_counts)."""
+    lib = ref_links_gpu_lib()
+    p = [_f32(x).reshape(-1).copy() for x in params]
+    g = [_f32(x).reshape(-1) for x in grads]
+    m, v = [np.zeros_like(x) for x in p], [np.zeros_like(x) for x in p]
+    sizes = (C.c_int64 * 6)(*[x.size for x in p])
+    ptrs = lambda arrs: (C.c_void_p * 6)(*[a.ctypes.data for a in arrs])
+    counts = (C.c_int64 * 6)()
+    rc = lib.reflink_fused_adam_steps(sizes, ptrs(p), ptrs(g), ptrs(m), ptrs(v), (C.c_double * 6)(*[float(x) for x in lrs]), C.c_int(iteration0), C.c_int(n_steps), counts)
+    if rc:
+        raise RuntimeError("reflink_fused_adam_steps failed")
+    return p, m, v, list(counts)
+
+
+def ref_links_mse_train_steps(mode, means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, gt_image, lrs,
+                              iteration0, n_steps):
+    """`n_steps` MSE training steps on the reference's own SplatData / Camera / FusedAdam objects in libref_links_gpu.so: mode 0 = the reference's sequence (rasterize()
+    -> mse_loss -> backward -> FusedAdam::step -> zero_grad), mode 1 = INTEGRATION.md §1b's patch (optimizer state read with FusedAdam's real members, the step as one
+    lfs::GutTrainStep::step call) -> dict(params [6], exp_avg [6], exp_avg_sq [6], losses [n_steps], n_isects)"""
+    lib = ref_links_gpu_lib()
+    p = [_f32(x).copy() for x in (means, sh0, shN, scaling, rotation, opacity)]
+    N, K1 = p[0].shape[0], p[2].shape[1]
+    m, v = [np.zeros_like(x) for x in p], [np.zeros_like(x) for x in p]
+    R, T, gt = _f32(R), _f32(T), _f32(gt_image)
+    bg = None if bg is None else _f32(bg)
+    ptrs = lambda arrs: (C.c_void_p * 6)(*[a.ctypes.data for a in arrs])
+    losses, n_isects = np.zeros(n_steps, np.float32), C.c_int64(-1)
+    rc = lib.reflink_mse_train_steps(C.c_int(mode), C.c_int64(N), C.c_int64(K1), C.c_int(sh_degree), C.c_int(active_sh_degree), ptrs(p), _p(R), _p(T), C.c_float(fx),
+                                     C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_int(width), C.c_int(height), None if bg is None else _p(bg), _p(gt),
+                                     (C.c_double * 6)(*[float(x) for x in lrs]), C.c_int(iteration0), C.c_int(n_steps), _p(losses), ptrs(m), ptrs(v), C.byref(n_isects))
+    if rc:
+        raise RuntimeError("reflink_mse_train_steps failed")
+    return dict(params=p, exp_avg=m, exp_avg_sq=v, losses=losses, n_isects=n_isects.value)
+
+
 def ref_render_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, v_image, v_alpha=None,
-                        full=False):
+                        full=False, lib=None):
     """gs::training::rasterize() of the reference for one pinhole camera + backward of sum(image * v_image) [+ sum(alpha * v_alpha)] through its autograd
     Functions: raw parameters as SplatData holds them (sh0 [N,1,3], shN [N,K,3], opacity [N]) -> dict(image [3,H,W], alpha [1,H,W], radii [N], viewmat [4,4],
     K [3,3], g_means, g_sh0, g_shN, g_scaling, g_rotation, g_opacity)"""
@@ -885,7 +935,7 @@ def ref_render_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, 
     out = dict(image=np.empty((3, height, width), np.float32), alpha=np.empty((1, height, width), np.float32), radii=np.empty(N, np.int32),
                g_means=np.empty((N, 3), np.float32), g_sh0=np.empty((N, 1, 3), np.float32), g_shN=np.empty((N, K1, 3), np.float32), g_scaling=np.empty((N, 3), np.float32),
                g_rotation=np.empty((N, 4), np.float32), g_opacity=np.empty(N, np.float32), viewmat=np.empty((4, 4), np.float32), K=np.empty((3, 3), np.float32))
-    rc = ref_raster_lib(full).refraster_render_backward(
+    rc = (lib or ref_raster_lib(full)).refraster_render_backward(
         C.c_int64(N), C.c_int64(K1), C.c_int(sh_degree), C.c_int(active_sh_degree), *[_p(a) for a in arrs], _p(R), _p(T), C.c_float(fx), C.c_float(fy), C.c_float(cx),
         C.c_float(cy), C.c_int(width), C.c_int(height), C.c_int(width), C.c_int(height), None if bg is None else _p(bg), _p(v_image),
         None if v_alpha is None else _p(v_alpha), _p(out["image"]), _p(out["alpha"]), out["radii"].ctypes.data_as(C.c_void_p),
@@ -1032,7 +1082,7 @@ def ref_load_ply(path):
 
 
 def ref_train_loss_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, gt_image, lambda_dssim,
-                            scale_reg, opacity_reg, bilateral=None):
+                            scale_reg, opacity_reg, bilateral=None, lib=None):
     """The loss of one training step as Trainer::train_step composes it - rasterize() [-> BilateralGrid::apply] -> L1 + D-SSIM (fused_ssim "valid") -> + scale /
     opacity regularisers [+ tv_weight * tv_loss()] - and its gradients w.r.t. the six raw tensors [and the grids], over the reference's whole gsplat library, its own
     ssim.cu and bilateral-grid code (libref_raster_full.so) -> dict(loss, image, g_* [, g_grids]). bilateral = dict(n_images, gW, gH, gL, image_idx, delta
@@ -1048,7 +1098,7 @@ def ref_train_loss_backward(means, sh0, shN, scaling, rotation, opacity, sh_degr
     if delta is not None:
         out["g_grids"] = np.empty_like(delta)
     loss = C.c_float()
-    rc = ref_raster_lib(full=True).refraster_train_loss_backward(
+    rc = (lib or ref_raster_lib(full=True)).refraster_train_loss_backward(
         C.c_int64(N), C.c_int64(K1), C.c_int(sh_degree), C.c_int(active_sh_degree), *[_p(a) for a in arrs], _p(R), _p(T), C.c_float(fx), C.c_float(fy), C.c_float(cx),
         C.c_float(cy), C.c_int(width), C.c_int(height), None if bg is None else _p(bg), _p(gt), C.c_float(lambda_dssim), C.c_float(scale_reg), C.c_float(opacity_reg),
         C.byref(loss), _p(out["image"]), *[_p(out[k]) for k in ("g_means", "g_sh0", "g_shN", "g_scaling", "g_rotation", "g_opacity")],

@@ -189,10 +189,14 @@ std::tuple<int, int, int> get_image_info(std::filesystem::path) { throw std::run
 #endif
 
 // ---- C API --------------------------------------------------------------------------------------------------------------------------------------------------
+#ifdef REF_LINK_GPU // (make reflink: the same entry points with the tensors on the GPU - the reference's L2 code unmodified, LINKED to the product's backend library)
+static torch::Tensor f32(const float* p, std::vector<int64_t> shape) { return torch::from_blob(const_cast<float*>(p), shape, torch::kFloat32).clone().to(torch::kCUDA); }
+#else
 static torch::Tensor f32(const float* p, std::vector<int64_t> shape) { return torch::from_blob(const_cast<float*>(p), shape, torch::kFloat32).clone(); }
+#endif
 static void put(const torch::Tensor& t, float* dst) {
     if (!dst) return;
-    auto c = t.detach().to(torch::kFloat32).contiguous();
+    auto c = t.detach().to(torch::kFloat32).cpu().contiguous();
     std::memcpy(dst, c.data_ptr<float>(), sizeof(float) * c.numel());
 }
 
@@ -220,7 +224,7 @@ REF_API int refraster_render_backward(int64_t N, int64_t K1, int sh_degree, int 
         auto out = gs::training::rasterize(cam, model, bgc, 1.0f, false, false, gs::training::RenderMode::RGB, nullptr);
         put(out.image, image), put(out.alpha, alpha);
         if (radii) {
-            auto r = out.radii.to(torch::kInt).contiguous();
+            auto r = out.radii.to(torch::kInt).cpu().contiguous();
             std::memcpy(radii, r.data_ptr<int32_t>(), sizeof(int32_t) * r.numel());
         }
         put(cam.world_view_transform(), viewmat_out), put(cam.K(), K_out);
@@ -296,6 +300,128 @@ REF_API int refraster_train_loss_backward(int64_t N, int64_t K1, int sh_degree, 
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "refraster_train_loss_backward: %s\n", e.what());
+        return 1;
+    }
+}
+#endif
+
+#ifdef REF_LINK_GPU
+#include "fused_adam.hpp"
+// The reference's optimizer over the product's fast_gs::optimizer::adam_step_wrapper: FusedAdam built exactly as create_optimizer builds it
+// (strategy_utils.cpp:20-48: six single-tensor groups in the order means, sh0, shN, scaling, rotation, opacity, each Options(lr).eps(1e-15).betas(0.9, 0.999), global
+// Options(0).eps(1e-15)), `n_steps` calls of FusedAdam::step(iteration0 + k) (fused_adam.cpp:22-95) with the given gradients -> parameters, both moments.
+// Sizes: sizes[g] floats for group g; buffers are updated in place.
+REF_API int reflink_fused_adam_steps(const int64_t* sizes, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                     const double* lrs, int iteration0, int n_steps, int64_t* step_counts) {
+    try {
+        using Options = gs::training::FusedAdam::Options;
+        std::vector<torch::Tensor> p;
+        std::vector<torch::optim::OptimizerParamGroup> groups;
+        for (int g = 0; g < 6; ++g) {
+            p.push_back(f32(params[g], {sizes[g]}).set_requires_grad(true));
+            p.back().mutable_grad() = f32(grads[g], {sizes[g]});
+            auto options = std::make_unique<Options>(lrs[g]);
+            options->eps(1e-15).betas(std::make_tuple(0.9, 0.999));
+            groups.emplace_back(std::vector<torch::Tensor>{p.back()}, std::unique_ptr<torch::optim::OptimizerOptions>(std::move(options)));
+        }
+        auto global_options = std::make_unique<Options>(0.f);
+        global_options->eps(1e-15);
+        gs::training::FusedAdam opt(std::move(groups), std::move(global_options));
+        for (int k = 0; k < n_steps; ++k) opt.step(iteration0 + k);
+        for (int g = 0; g < 6; ++g) {
+            put(p[g], params[g]);
+            auto it = opt.state().find(p[g].unsafeGetTensorImpl());
+            TORCH_CHECK(it != opt.state().end(), "no optimizer state for group ", g);
+            auto& st = static_cast<gs::training::FusedAdam::AdamParamState&>(*it->second);
+            put(st.exp_avg, exp_avg[g]), put(st.exp_avg_sq, exp_avg_sq[g]);
+            step_counts[g] = st.step_count;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "reflink_fused_adam_steps: %s\n", e.what());
+        return 1;
+    }
+}
+
+// INTEGRATION.md §1b, COMPILED: `n_steps` training steps with the MSE loss on the reference's own SplatData / Camera / FusedAdam objects,
+//   mode 0: as the reference's trainer runs them - gs::training::rasterize() -> mse_loss -> backward() -> FusedAdam::step(iter) -> zero_grad (trainer.cpp:640-760 with
+//           the loss of SURVEY.md §8d), every operator through the linked backend one by one;
+//   mode 1: the patch - the optimizer state is taken from FusedAdam with the members it really has (torch::optim::Optimizer::param_groups() / state(), the group's
+//           FusedAdam::Options, FusedAdam::AdamParamState; lazy initialisation and ++step_count as fused_adam.cpp:44-66 do them) and the whole step is ONE call of
+//           lfs::GutTrainStep::step (include/lfs_gut_train_step.hpp).
+// Both leave parameters and moments in the same FusedAdam / SplatData objects, which are read back: tests/test_gpu_reference_links.py holds mode 1 to mode 0.
+#include "lfs_gut_train_step.hpp"
+REF_API int reflink_mse_train_steps(int mode, int64_t N, int64_t K1, int sh_degree, int active_sh_degree, float* const* params, const float* R, const float* T, float fx,
+                                    float fy, float cx, float cy, int width, int height, const float* bg, const float* gt_image, const double* lrs, int iteration0,
+                                    int n_steps, float* losses, float* const* exp_avg, float* const* exp_avg_sq, int64_t* n_isects_out) {
+    try {
+        using FusedAdam = gs::training::FusedAdam;
+        auto req = [](torch::Tensor t) { return t.set_requires_grad(true); };
+        gs::SplatData model(sh_degree, req(f32(params[0], {N, 3})), req(f32(params[1], {N, 1, 3})), req(f32(params[2], {N, K1, 3})), req(f32(params[3], {N, 3})),
+                            req(f32(params[4], {N, 4})), req(f32(params[5], {N, 1})), 1.0f);
+        model.set_active_sh_degree(active_sh_degree);
+        gs::Camera cam(f32(R, {3, 3}), f32(T, {3}), fx, fy, cx, cy, torch::empty({0}, torch::kFloat32), torch::empty({0}, torch::kFloat32), gsplat::CameraModelType::PINHOLE,
+                       "view", "", width, height, 0);
+        torch::Tensor bgc = bg ? f32(bg, {3}) : torch::Tensor(), gt = f32(gt_image, {3, height, width});
+        std::vector<torch::Tensor*> tensors = {&model.means(), &model.sh0(), &model.shN(), &model.scaling_raw(), &model.rotation_raw(), &model.opacity_raw()};
+        std::vector<torch::optim::OptimizerParamGroup> groups; // strategy_utils.cpp:20-48 (create_optimizer)
+        for (int g = 0; g < 6; ++g) {
+            auto options = std::make_unique<FusedAdam::Options>(lrs[g]);
+            options->eps(1e-15).betas(std::make_tuple(0.9, 0.999));
+            groups.emplace_back(std::vector<torch::Tensor>{*tensors[g]}, std::unique_ptr<torch::optim::OptimizerOptions>(std::move(options)));
+        }
+        auto global_options = std::make_unique<FusedAdam::Options>(0.f);
+        global_options->eps(1e-15);
+        FusedAdam optimizer(std::move(groups), std::move(global_options));
+        lfs::GutTrainStep gut_step;
+        torch::Tensor loss_scalar = torch::zeros({1}, gt.options());
+        for (int k = 0; k < n_steps; ++k) {
+            const int iter = iteration0 + k;
+            if (mode == 0) {
+                auto out = gs::training::rasterize(cam, model, bgc, 1.0f, false, false, gs::training::RenderMode::RGB, nullptr);
+                auto loss = torch::mse_loss(out.image, gt);
+                loss.backward();
+                optimizer.step(iter);
+                optimizer.zero_grad(true, iter);
+                losses[k] = loss.item<float>();
+            } else {
+                TORCH_CHECK(iter > 1000, "the one-call step updates all six groups: FusedAdam skips shN up to iteration 1000 (fused_adam.cpp:68-70) - use the split form there");
+                std::array<lfs::AdamGroupState, 6> adam;
+                auto& pg = optimizer.param_groups();
+                for (int g = 0; g < 6; ++g) {
+                    auto& param = pg[g].params()[0];
+                    auto& slot = optimizer.state()[param.unsafeGetTensorImpl()];
+                    if (!slot) { // fused_adam.cpp:44-57
+                        auto fresh = std::make_unique<FusedAdam::AdamParamState>();
+                        fresh->exp_avg = torch::zeros_like(param, torch::MemoryFormat::Preserve);
+                        fresh->exp_avg_sq = torch::zeros_like(param, torch::MemoryFormat::Preserve);
+                        slot = std::move(fresh);
+                    }
+                    auto& st = static_cast<FusedAdam::AdamParamState&>(*slot);
+                    ++st.step_count; // :66
+                    const auto& o = static_cast<const FusedAdam::Options&>(pg[g].options());
+                    const auto [b1, b2] = o.betas();
+                    adam[g] = {st.exp_avg, st.exp_avg_sq, (float)o.lr(), (float)b1, (float)b2, (float)o.eps(), (float)(1.0 / (1.0 - std::pow(b1, st.step_count))),
+                               (float)(1.0 / std::sqrt(1.0 - std::pow(b2, st.step_count)))}; // :78-79
+                }
+                loss_scalar.zero_();
+                auto viewmat = cam.world_view_transform().contiguous(), Kmat = cam.K().contiguous();
+                *n_isects_out = gut_step.step(model.means(), model.sh0(), model.shN(), model.scaling_raw(), model.rotation_raw(), model.opacity_raw(), adam,
+                                              (uint32_t)model.get_active_sh_degree(), viewmat, Kmat, (uint32_t)width, (uint32_t)height,
+                                              bgc.defined() ? at::optional<torch::Tensor>(bgc) : at::nullopt, gt, 1.f, loss_scalar);
+                losses[k] = loss_scalar.item<float>();
+            }
+        }
+        for (int g = 0; g < 6; ++g) {
+            put(*tensors[g], params[g]);
+            auto it = optimizer.state().find(tensors[g]->unsafeGetTensorImpl());
+            TORCH_CHECK(it != optimizer.state().end(), "no optimizer state for group ", g);
+            auto& st = static_cast<FusedAdam::AdamParamState&>(*it->second);
+            put(st.exp_avg, exp_avg[g]), put(st.exp_avg_sq, exp_avg_sq[g]);
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "reflink_mse_train_steps: %s\n", e.what());
         return 1;
     }
 }

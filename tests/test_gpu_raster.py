@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import make_gaussians, n, pinhole_K, rel_l2, rows_check, small_rotation_viewmat, t
+from gpu_util import atomic_noise_bar, make_gaussians, n, noise_check, pinhole_K, rel_l2, rows_check, small_rotation_viewmat, t
 
 pytestmark = pytest.mark.gpu
 
@@ -252,11 +252,10 @@ def test_cell_culling_is_conservative(lfs, oracle_mod, kind):
     v_rc, v_ra = t(rng.standard_normal(tuple(r1.shape)).astype(np.float32)), t(rng.standard_normal(tuple(a1.shape)).astype(np.float32))
     bwd = lambda: ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, a1, l1, v_rc, v_ra)
     g0, g1 = _cull_on_off(lfs, bwd)
-    g2 = bwd()  # run-to-run noise of the float atomics (large for ill-conditioned needles)
-    for x0, x1, x2 in zip(g0, g1, g2):
+    g2, g3 = bwd(), bwd()  # run-to-run noise of the float atomics (large and heavy-tailed for ill-conditioned needles: three draws)
+    for i, (x0, x1, x2, x3) in enumerate(zip(g0, g1, g2, g3)):
         assert torch.isfinite(x1).all()
-        noise = float((x2 - x1).norm() / (x1.norm() + 1e-30))
-        assert float((x0 - x1).norm() / (x0.norm() + 1e-30)) < max(1e-5, 5 * noise)
+        noise_check(f"cull on/off bwd[{i}] {kind}", rel_l2(n(x0), n(x1)), atomic_noise_bar(x1, x2, x3))
 
 
 def test_cell_culling_full_size_bit_identical(lfs):
@@ -290,8 +289,9 @@ def test_prepared_backward_equals_self_contained_backward(lfs, oracle_mod):
     v_rc, v_ra = torch.randn_like(rc), torch.randn_like(ra)
     ga = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra, prepared_workspace=ws)
     gb = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra)
-    for a, b in zip(ga, gb):
-        assert float((a - b).norm() / (b.norm() + 1e-30)) < 1e-5
+    gc = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra)   # a second draw of the float-atomic sums: the bar is relative to their own noise
+    for i, (a, b, c) in enumerate(zip(ga, gb, gc)):
+        noise_check(f"prepared vs self-contained bwd[{i}]", rel_l2(n(a), n(b)), atomic_noise_bar(c, b))
 
 
 def test_deterministic_backward_mode_is_bit_reproducible(lfs, oracle_mod):
@@ -313,6 +313,7 @@ def test_deterministic_backward_mode_is_bit_reproducible(lfs, oracle_mod):
     rc, ra, li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
     v_rc, v_ra = torch.randn_like(rc), torch.randn_like(ra)
     ref = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra)
+    ref2 = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra)  # second draw of the float-atomic mode: its own run-to-run noise
     lib = lfs.load_library()
     try:
         lib.lfs_set_debug_flags(16)
@@ -328,8 +329,11 @@ def test_deterministic_backward_mode_is_bit_reproducible(lfs, oracle_mod):
             fused.append([g.clone() for g in grads])
     finally:
         lib.lfs_set_debug_flags(0)
-    for name, a, b, c, r in zip(["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"], *runs, ref):
+    for name, a, b, c, r, r2 in zip(["v_means", "v_quats", "v_scales", "v_colors", "v_opacities"], *runs, ref, ref2):
         assert torch.equal(a, b) and torch.equal(a, c), name
-        assert torch.isfinite(a).all() and rel_l2(n(a), n(r)) < 1e-5, (name, rel_l2(n(a), n(r)))
+        assert torch.isfinite(a).all()
+        # the float-atomic operand is ONE draw of an order-dependent sum (run-to-run ~1e-5 on v_quats): the bar is max(2e-5, 5 x that noise), never a
+        # constant on the noise floor (round 3's 1e-5 bar failed at 1.000015e-05 on the driver's box)
+        noise_check(f"deterministic vs float-atomic {name}", rel_l2(n(a), n(r)), atomic_noise_bar(r2, r))
     for a, b in zip(*fused):
         assert torch.equal(a, b) and float(a.abs().max()) > 0

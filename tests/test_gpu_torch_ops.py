@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from gpu_util import atomic_noise_bar, n, noise_allclose, noise_check, rel_l2
+
 
 def _mod():
     import lichtfeld_studio_amd  # noqa: F401
@@ -72,8 +74,10 @@ def test_torch_ops_equal_python_mirror(lfs):
                                                    None, None, None, offs, t1[2], f1[1], f1[2], vr, va)
     b2 = ops.rasterize_to_pixels_from_world_3dgs_bwd(means, quats, scales, colors, opac[None].contiguous(), None, None, W, H, 16, vm, None, K,
                                                      lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, offs, t1[2], f1[1], f1[2], vr, va)
-    for x, y in zip(b1, b2):     # float atomics: same math, order-dependent rounding
-        assert float((x - y).norm() / (y.norm() + 1e-20)) < 1e-5
+    b3 = ops.rasterize_to_pixels_from_world_3dgs_bwd(means, quats, scales, colors, opac[None].contiguous(), None, None, W, H, 16, vm, None, K,
+                                                     lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, offs, t1[2], f1[1], f1[2], vr, va)
+    for i, (x, y, z) in enumerate(zip(b1, b2, b3)):     # float atomics: same math, order-dependent rounding -> bar relative to two draws of the same entry
+        noise_check(f"libtorch wrapper vs ctypes bwd[{i}]", rel_l2(n(x), n(y)), atomic_noise_bar(z, y))
     assert torch.equal(m.quats_to_rotmats(quats), ops.quats_to_rotmats(quats))
     p = torch.randn(10007, device=dev); e1, e2, g = torch.zeros_like(p), torch.zeros_like(p), torch.randn_like(p)
     p2, f1_, f2_ = p.clone(), e1.clone(), e2.clone()
@@ -111,14 +115,15 @@ def test_torch_fastgs_and_ssim_wrappers_equal_python_mirror(lfs):
                                    n_buckets, s0, s1)
     g2 = fastgs.backward_wrapper(dens2, gi, ga, image2, alpha2, a[0], a[1], a[2], a[4], a[5], pws, iws, a[6], s, n_inst2)
     assert len(g1) == 7 and g1[6] is None     # grad_w2c undefined: w2c does not require grad (rasterization_api.cu backward)
-    for x, y in zip(g1[:6], g2[:6]):
+    for i, (x, y) in enumerate(zip(g1[:6], g2[:6])):
         assert x.shape == y.shape or x.numel() == y.numel()
-        assert torch.allclose(x.reshape(-1), y.reshape(-1), rtol=1e-4, atol=1e-6 + 1e-5 * float(y.abs().max()))
-    assert torch.equal(dens1[0], dens2[0]) and torch.allclose(dens1[1], dens2[1], rtol=1e-4, atol=1e-7)
+        noise_allclose(f"fastgs wrapper bwd[{i}]", x, y, rtol=1e-4, atol=1e-6 + 1e-5 * float(y.abs().max()))
+    assert torch.equal(dens1[0], dens2[0])
+    noise_allclose("fastgs wrapper densification_info[1]", dens1[1], dens2[1], rtol=1e-4, atol=1e-7)
     # no densification info requested: empty tensor, as the reference's `densification_info.size(0) > 0` test
     g3 = m.fastgs_backward_wrapper(torch.empty(0, device="cuda:0"), gi, ga, image, alpha, a[0], a[1], a[2], a[5], prim, tile, inst, bucket, a[6], cam,
                                    *fr, n_vis, n_inst, n_buckets, s0, s1)
-    assert torch.allclose(g3[0], g1[0], rtol=1e-4, atol=1e-6 + 1e-5 * float(g1[0].abs().max()))
+    noise_allclose("fastgs wrapper bwd no-dens", g3[0], g1[0], rtol=1e-4, atol=1e-6 + 1e-5 * float(g1[0].abs().max()))
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         m.fastgs_forward_wrapper(*[x.cpu() for x in a], cam.cpu(), *fr)
 
@@ -135,7 +140,8 @@ def test_torch_fastgs_and_ssim_wrappers_equal_python_mirror(lfs):
     grid, rgb, go = torch.randn(12, 8, 16, 16, device="cuda:0"), torch.rand(120, 200, 3, device="cuda:0"), torch.randn(120, 200, 3, device="cuda:0")
     assert torch.equal(m.bilateral_slice_forward(grid, rgb), bg.slice_forward(grid, rgb))
     b1, b2 = m.bilateral_slice_backward(grid, rgb, go), bg.slice_backward(grid, rgb, go)
-    assert torch.equal(b1[1], b2[1]) and torch.allclose(b1[0], b2[0], rtol=1e-4, atol=1e-5 * float(b2[0].abs().max()))
+    assert torch.equal(b1[1], b2[1])
+    noise_allclose("bilateral wrapper grid grad", b1[0], b2[0], rtol=1e-4, atol=1e-5 * float(b2[0].abs().max()))
     grids = torch.randn(3, 12, 8, 16, 16, device="cuda:0")
     assert torch.allclose(m.bilateral_tv_loss_forward(grids), bg.tv_loss_forward(grids), rtol=1e-5)
     assert torch.equal(m.bilateral_tv_loss_backward(grids, torch.tensor(0.5)), bg.tv_loss_backward(grids, 0.5))
@@ -219,7 +225,7 @@ def test_cxx_gut_train_step_class_equals_the_python_driver(lfs):
     finally:
         lib.lfs_set_debug_flags(0)
     assert step.retries() >= 1 and n_isects == a.last_n_isects > 0
-    assert abs(float(la) - float(loss_b)) <= 2e-6 * float(la)   # (float-atomic partial sums of the loss value: last-bit order dependence; parameters are exact)
+    noise_check("lfs::GutTrainStep loss value", abs(float(la) - float(loss_b)), 1e-5 * float(la))   # (float-atomic partial sums of the loss value: last-bit order dependence; parameters are exact)
     assert tuple(step.render().shape) == (sc.height, sc.width, 3) and tuple(step.radii().shape) == (5000, 2)
     for name, pa, pb in zip(names, a.model.parameters(), b.model.parameters()):
         assert torch.equal(pa, pb), (name, float((pa - pb).abs().max()))
