@@ -16,7 +16,20 @@ struct __attribute__((aligned(16))) CullRec { float4 a, b; };
 template <bool UNIFORM_ORIGIN>
 LFS_DI void pack_gaussian(const CamDev& cam, const f3 mu, const float4 q, const float sc[3], const float opac, const float c0, const float c1, const float c2,
                           GaussRec& rec, CullRec& cr) {
-    const m3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
+    // No contraction anywhere in this function (and in conic_record): the records are built by raster_pack_kernel (raster.hip, compiled with contraction) AND by the
+    // training step's projection kernel (projection_ut.hip, compiled without) - the two must produce the same bits (the C++ step is held bit for bit to the
+    // op-by-op path, tests/test_gpu_gut_step.py). The helpers of lfs_math.cuh take the including file's default, so their bodies are repeated here.
+#pragma clang fp contract(off)
+    m3 R;
+    {   // quat_to_rotmat (lfs_math.cuh; Utils.cuh:80-102)
+        float w = q.x, x = q.y, y = q.z, z = q.w;
+        const float inv = 1.f / sqrtf(x * x + y * y + z * z + w * w);
+        x *= inv; y *= inv; z *= inv; w *= inv;
+        const float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+        R.m[0][0] = 1.f - 2.f * (y2 + z2); R.m[1][0] = 2.f * (xy + wz); R.m[2][0] = 2.f * (xz - wy);
+        R.m[0][1] = 2.f * (xy - wz); R.m[1][1] = 1.f - 2.f * (x2 + z2); R.m[2][1] = 2.f * (yz + wx);
+        R.m[0][2] = 2.f * (xz + wy); R.m[1][2] = 2.f * (yz - wx); R.m[2][2] = 1.f - 2.f * (x2 + y2);
+    }
     const float is[3] = {1.f / sc[0], 1.f / sc[1], 1.f / sc[2]};
     m3 M;
 #pragma unroll
@@ -26,7 +39,8 @@ LFS_DI void pack_gaussian(const CamDev& cam, const f3 mu, const float4 q, const 
     f3 g = mu;
     m3 Mr = M;
     if (UNIFORM_ORIGIN) {
-        g = mul(M, cam.origin - mu);
+        const float omx = cam.origin.x - mu.x, omy = cam.origin.y - mu.y, omz = cam.origin.z - mu.z;
+        g = {M.m[0][0] * omx + M.m[0][1] * omy + M.m[0][2] * omz, M.m[1][0] * omx + M.m[1][1] * omy + M.m[1][2] * omz, M.m[2][0] * omx + M.m[2][1] * omy + M.m[2][2] * omz};
         const m3& Ri = cam.Rinv; // camera -> world: the kernels then work on CAMERA-space ray directions
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -40,7 +54,7 @@ LFS_DI void pack_gaussian(const CamDev& cam, const f3 mu, const float4 q, const 
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) Mr.m[r][c] *= REC_SCALE;
-    if (UNIFORM_ORIGIN) g = g * REC_SCALE;
+    if (UNIFORM_ORIGIN) g = {g.x * REC_SCALE, g.y * REC_SCALE, g.z * REC_SCALE};
     const float opac_field = __builtin_amdgcn_logf(opac);   // v_log_f32 = log2
 #else
     const float opac_field = opac;
@@ -52,8 +66,9 @@ LFS_DI void pack_gaussian(const CamDev& cam, const f3 mu, const float4 q, const 
     ConicRec k = conic_never();
     if (UNIFORM_ORIGIN) {
         const m3& Ri = cam.Rinv;                      // camera -> world, so world -> camera is its transpose
-        const f3 pcv = mul_t(Ri, mu - cam.origin);
-        const float pc[3] = {pcv.x, pcv.y, pcv.z};
+        const float dx = mu.x - cam.origin.x, dy = mu.y - cam.origin.y, dz = mu.z - cam.origin.z;
+        const float pc[3] = {Ri.m[0][0] * dx + Ri.m[1][0] * dy + Ri.m[2][0] * dz, Ri.m[0][1] * dx + Ri.m[1][1] * dy + Ri.m[2][1] * dz,
+                             Ri.m[0][2] * dx + Ri.m[1][2] * dy + Ri.m[2][2] * dz};
         float A[3][3];                                // A = Rc R S  (Sigma_cam = A A^T)
 #pragma unroll
         for (int r = 0; r < 3; ++r)

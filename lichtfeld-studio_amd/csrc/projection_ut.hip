@@ -9,6 +9,7 @@
 // same rounding path as the oracle.
 #include "lfs_camera.cuh"
 #include "lfs_prof.h"
+#include "lfs_raster_pack.cuh"
 #include "lfs_step_internal.h"
 
 namespace lfs {
@@ -21,7 +22,12 @@ namespace lfs {
 // but all compiled into the generic kernel: 125 VGPRs and ~70 000 lines of ISA for the worst case, a fisheye camera under a rolling shutter - become
 // compile-time constants and fold away; the arithmetic on the path that remains is untouched (same functions, no contraction: bit-identical outputs,
 // tests/test_gpu_projection_sh.py).
-template <bool ACT, bool SIMPLE = false>
+// PACK (round 4, the training step): the kernel also writes what raster_pack_kernel (raster.hip) would compute from the activated values in a second pass over the
+// Gaussians - the rasterizer's 64-byte record (colour slots zero: the SH colour kernel writes them into the record afterwards) and the 32-byte culling record - for
+// every Gaussian that has a footprint. Same function (pack_gaussian, contraction-free), same operands: same bits; saves re-reading 44 B per Gaussian and a launch.
+// pack_colors [N,3]: the SH colours (the step evaluates them BEFORE this kernel, for every Gaussian - a record is then one full 64-byte store; a first version had
+// the SH kernel write its three floats into the finished records afterwards: partial-sector writes, sh_fwd 0.064 -> 0.083 ms).
+template <bool ACT, bool SIMPLE = false, bool PACK = false>
 __global__ void __launch_bounds__(256) projection_ut_kernel(
     const uint32_t N,
     const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
@@ -31,7 +37,8 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
     float* __restrict__ conics, float* __restrict__ compensations,
     float* __restrict__ act_quats = nullptr, float* __restrict__ act_scales = nullptr, float* __restrict__ act_opacities = nullptr,
-    uint32_t* __restrict__ zero_words = nullptr, const uint32_t zero_n = 0, CamDev* __restrict__ cams_out = nullptr) {
+    uint32_t* __restrict__ zero_words = nullptr, const uint32_t zero_n = 0, CamDev* __restrict__ cams_out = nullptr,
+    GaussRec* __restrict__ recs = nullptr, CullRec* __restrict__ cull = nullptr, const float* __restrict__ pack_colors = nullptr) {
     const uint32_t cid = blockIdx.y;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (zero_words != nullptr && cid == 0) // rider of the training step: clear the intersection stage's per-tile totals (saves its memset launch)
@@ -50,6 +57,7 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
 
     int32_t out_rx = 0, out_ry = 0;
     float o_m2x = 0.f, o_m2y = 0.f, o_depth = 0.f, o_c0 = 0.f, o_c1 = 0.f, o_c2 = 0.f, o_comp = 0.f;
+    f3 p_mean{0.f, 0.f, 0.f}; float4 p_q = make_float4(1.f, 0.f, 0.f, 0.f); float p_sc[3] = {1.f, 1.f, 1.f}, p_op = 0.f; // PACK: the activated operands
 
     do {
         const f3 mean = ld3(means, gid);
@@ -67,6 +75,7 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
                 act_opacities[gid] = opac_in;
             }
         }
+        if (PACK) { p_mean = mean; p_q = qin; p_sc[0] = scale.x; p_sc[1] = scale.y; p_sc[2] = scale.z; p_op = opac_in; }
         const quat rot = qnormalize(quat{qin.x, qin.y, qin.z, qin.w});
 
         // depth test at the centre-of-exposure pose
@@ -149,6 +158,13 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
     depths[idx] = o_depth;
     if (conics != nullptr) { conics[3 * idx] = o_c0; conics[3 * idx + 1] = o_c1; conics[3 * idx + 2] = o_c2; }
     if (compensations != nullptr) compensations[idx] = o_comp;
+    if (PACK && out_rx > 0 && out_ry > 0) {
+        GaussRec rec; CullRec cr;
+        const f3 col = ld3(pack_colors, gid);
+        pack_gaussian<true>(cam, p_mean, p_q, p_sc, p_op, col.x, col.y, col.z, rec, cr);
+        recs[idx] = rec;
+        cull[idx] = cr;
+    }
 }
 
 } // namespace lfs
@@ -185,7 +201,8 @@ extern "C" int lfs_projection_ut_3dgs_fused(
 int lfs::activations_project_ut_impl(
     uint32_t N, const float* means, const float* raw_quats, const float* raw_scales, const float* raw_opacities, const lfs_cameras* cams,
     float eps2d, float near_plane, float far_plane, float radius_clip, const lfs_ut_params* ut_params,
-    float* quats, float* scales, float* opacities, int32_t* radii, float* means2d, float* depths, uint32_t* zero_words, uint32_t zero_n, void* cams_out, hipStream_t stream) {
+    float* quats, float* scales, float* opacities, int32_t* radii, float* means2d, float* depths, uint32_t* zero_words, uint32_t zero_n, void* cams_out, hipStream_t stream,
+    void* recs_out, void* cull_out, const float* pack_colors) {
     if (!cams || !cams->viewmats0 || !cams->Ks) return LFS_E_INVALID;
     if (cams->camera_model != LFS_CAMERA_PINHOLE && cams->camera_model != LFS_CAMERA_FISHEYE) return LFS_E_UNSUPPORTED;
     if (N == 0 || cams->C == 0) return LFS_OK;
@@ -194,6 +211,14 @@ int lfs::activations_project_ut_impl(
     if (ut_params) ut = *ut_params;
     dim3 grid((N + 255) / 256, cams->C);
     lfs::ProfScope prof("activations_projection_ut", (hipStream_t)stream);
+    if (recs_out != nullptr) { // the training step: records + culling records from the same pass (one camera, undistorted pinhole, global shutter)
+        if (!simple_camera(cams) || cams->C != 1 || !cull_out || !pack_colors) return LFS_E_INVALID;
+        hipLaunchKernelGGL((lfs::projection_ut_kernel<true, true, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                           N, means, raw_quats, raw_scales, raw_opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
+                           radii, means2d, depths, nullptr, nullptr, quats, scales, opacities, zero_words, zero_n, static_cast<lfs::CamDev*>(cams_out),
+                           static_cast<lfs::GaussRec*>(recs_out), static_cast<lfs::CullRec*>(cull_out), pack_colors);
+        return (int)hipGetLastError();
+    }
     if (simple_camera(cams))
         hipLaunchKernelGGL((lfs::projection_ut_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream,
                            N, means, raw_quats, raw_scales, raw_opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
@@ -210,5 +235,5 @@ extern "C" int lfs_activations_project_ut(
     float eps2d, float near_plane, float far_plane, float radius_clip, const lfs_ut_params* ut_params,
     float* quats, float* scales, float* opacities, int32_t* radii, float* means2d, float* depths, lfs_stream_t stream) {
     return lfs::activations_project_ut_impl(N, means, raw_quats, raw_scales, raw_opacities, cams, eps2d, near_plane, far_plane, radius_clip, ut_params, quats, scales,
-                                            opacities, radii, means2d, depths, nullptr, 0, nullptr, (hipStream_t)stream);
+                                            opacities, radii, means2d, depths, nullptr, 0, nullptr, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }

@@ -179,6 +179,12 @@ static inline void __syncthreads() { emu::block_barrier(); }
 static inline float __shfl_xor(float v, int m, int = 64) { return __uint_as_float(emu::xlane_u32(__float_as_uint(v), int(emu::lane_id()) ^ m)); }
 static inline int __shfl_xor(int v, int m, int = 64) { return int(emu::xlane_u32(uint32_t(v), int(emu::lane_id()) ^ m)); }
 static inline uint32_t __shfl_xor(uint32_t v, int m, int = 64) { return emu::xlane_u32(v, int(emu::lane_id()) ^ m); }
+// __shfl: every lane reads the lane it names (ds_bpermute)
+static inline int __shfl(int v, int src, int = 64) { uint64_t o[2][64]; emu::wave_exchange(uint64_t(uint32_t(v)), 0, o); return int(uint32_t(o[0][src & 63])); }
+static inline uint32_t __shfl(uint32_t v, int src, int = 64) { uint64_t o[2][64]; emu::wave_exchange(uint64_t(v), 0, o); return uint32_t(o[0][src & 63]); }
+static inline float __shfl(float v, int src, int = 64) { uint64_t o[2][64]; emu::wave_exchange(uint64_t(__float_as_uint(v)), 0, o); return __uint_as_float(uint32_t(o[0][src & 63])); }
+static inline unsigned long long __shfl_xor(unsigned long long v, int m, int = 64) { uint64_t o[2][64]; emu::wave_exchange(uint64_t(v), 0, o); return o[0][(int(emu::lane_id()) ^ m) & 63]; }
+#define __builtin_amdgcn_wave_barrier() do { } while (0)
 // __shfl_up: lane i reads lane i - d; lanes below d keep their own value
 static inline uint64_t emu_shfl_up64(uint64_t v, int d) { uint64_t o[2][64]; emu::wave_exchange(v, 0, o); const int l = int(emu::lane_id()); return l >= d ? o[0][l - d] : v; }
 static inline uint64_t __shfl_up(uint64_t v, int d, int = 64) { return emu_shfl_up64(v, d); }

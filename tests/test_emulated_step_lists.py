@@ -1,0 +1,133 @@
+"""The training step's front end with MASKED tile lists (round 4: csrc/intersect.hip isect_count_masked_kernel / isect_rows_kernel<true> / the payload-only sort,
+csrc/raster.hip cells_from_masks_kernel, records packed by the projection kernel, SH colours written into the records) compiled as HOST code on the wavefront
+emulator (tests/emul) and driven through lfs_gut_view_forward, against the SAME entry point with debug bit 6 set - the reference's lists (every tile of the
+radii's bounding rectangle) + raster_pack_kernel + raster_cull_kernel, i.e. the path rounds 1-3 measured and the one gsplat::intersect_tile keeps:
+  * render, alpha, radii BIT-identical (the masks only drop (Gaussian, cell) pairs that cannot reach alpha >= 1/255: conservative, lfs_cull_conic.cuh);
+  * the per-cell lists the rasterizer walks hold the same Gaussians in the same order;
+  * counts: [3] (the reference's n_isects) equals the unmasked path's count, [0] (listed) is smaller;
+  * culling off (debug bit 0): every tile of the rectangle is listed again, all four cells.
+Cases: SYN-A-like, a dense scene with tile lists beyond 1024 entries (the second sort class), large Gaussians (rectangles of more than 16 tiles: masks re-derived by
+the binning kernel), tile size 8, ragged image sizes, a capacity that is too small (the guarded attempt aborts and reports the counts)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+CSRC = os.path.join(ROOT, "lichtfeld-studio_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++ to build the emulated kernels")
+    out = str(tmp_path_factory.mktemp("emul") / "liblfs_step_emul.so")
+    srcs = [os.path.join(CSRC, f) for f in ("intersect.hip", "raster.hip", "projection_ut.hip", "sh.hip", "gut_step.hip")]
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-DLFS_EMULATE", "-fPIC", "-shared", "-ffp-contract=on", "-I" + os.path.join(HERE, "emul"), "-Wno-unused-value",
+           "-Wno-unknown-attributes", *srcs, os.path.join(HERE, "emul", "emul_stubs.cpp"), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lib = C.CDLL(out)
+    lib.lfs_rasterize_workspace_bytes.restype = C.c_size_t
+    lib.lfs_intersect_tile_workspace_bytes.restype = C.c_size_t
+    lib.lfs_gut_step_reference_count.restype = C.c_int64
+    return lib
+
+
+def _scene(seed, N, W, H, smin, smax, spread=1.0, K=4, degree=1):
+    sys.path.insert(0, HERE)
+    from gpu_util import make_gaussians, pinhole_K, small_rotation_viewmat
+    rng = np.random.default_rng(seed)
+    means, quats, scales, opac = make_gaussians(rng, N, spread=spread, smin=smin, smax=smax)
+    raw_scales = np.log(scales).astype(np.float32)
+    raw_opac = np.log(opac / (1 - opac)).astype(np.float32)
+    opac_low = rng.random(N) < 0.1
+    raw_opac[opac_low] = -6.0                                    # some below 1/255: never listed by the projection
+    sh0 = (rng.standard_normal((N, 1, 3)) * 0.5).astype(np.float32)
+    shN = (rng.standard_normal((N, K - 1, 3)) * 0.2).astype(np.float32)
+    vm = small_rotation_viewmat(rng, 0.08, 0.15)
+    Kmat = pinhole_K(0.8 * W, W, H, 1)[0]
+    return dict(means=means, raw_quats=quats, raw_scales=raw_scales, raw_opac=raw_opac, sh0=sh0, shN=shN, vm=vm, K=Kmat, bg=rng.random(3).astype(np.float32), Kn=K, degree=degree)
+
+
+def _forward(lib, sc, W, H, tile, capacity, flags, assumed_longest=1024):
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lfs_gut_step_defs", os.path.join(ROOT, "lichtfeld-studio_amd", "gut_step.py"))
+    src = open(spec.origin).read()
+    ns = {}
+    # only the two ctypes structures are needed (the module itself imports the GPU library loader)
+    start, end = src.index("class StepArgs"), src.index("class GutStep")
+    exec("import ctypes as C\n" + src[start:end], ns)
+    StepArgs, StepLayout = ns["StepArgs"], ns["StepLayout"]
+    N = sc["means"].shape[0]
+    lib.lfs_set_debug_flags(C.c_uint32(flags))
+    try:
+        lay = StepLayout()
+        assert lib.lfs_gut_step_layout_for(C.c_uint32(N), C.c_uint32(W), C.c_uint32(H), C.c_uint32(tile), C.c_int64(capacity), C.byref(lay)) == 0
+        ws = np.full(int(lay.bytes) + 64, 0xA5, np.uint8)             # garbage: the step must not rely on a clean workspace
+        keep = [np.ascontiguousarray(sc[k], np.float32) for k in ("means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opac", "vm", "K", "bg")]
+        a = StepArgs()
+        a.N, a.K, a.sh_degree, a.image_width, a.image_height, a.tile_size = N, sc["Kn"], sc["degree"], W, H, tile
+        a.means, a.sh0, a.shN, a.raw_scales, a.raw_quats, a.raw_opacities, a.viewmat, a.Kmat, a.background = [x.ctypes.data for x in keep]
+        counts = np.zeros(4, np.int64)
+        rc = lib.lfs_gut_view_forward(C.byref(a), C.c_int64(capacity), C.c_int64(assumed_longest), C.c_void_p(ws.ctypes.data), C.c_size_t(int(lay.bytes)),
+                                      C.c_void_p(counts.ctypes.data), C.c_int64(7), None)
+        assert rc == 0, rc
+        assert counts[2] == 7
+        view = lambda name, dtype, shape: ws[getattr(lay, name):getattr(lay, name) + int(np.prod(shape)) * np.dtype(dtype).itemsize].view(dtype).reshape(shape).copy()
+        tw, th = (W + tile - 1) // tile, (H + tile - 1) // tile
+        out = dict(render=view("render", np.float32, (H, W, 3)), alpha=view("alpha", np.float32, (H, W)), radii=view("radii", np.int32, (N, 2)),
+                   last_ids=view("last_ids", np.int32, (H, W)), offsets=view("tile_offsets", np.int32, (tw * th + 1,)), counts=counts.copy(),
+                   abort=int(view("abort_flag", np.int32, (1,))[0]), ws=ws, lay=lay)
+        return out
+    finally:
+        lib.lfs_set_debug_flags(C.c_uint32(0))
+
+
+CASES = {
+    # name: (N, W, H, tile, smin, smax, spread)
+    "syn_a_like": (1500, 160, 112, 16, 0.01, 0.06, 1.0),
+    "dense_long_lists": (5000, 48, 48, 16, 0.03, 0.12, 0.25),
+    "large_gaussians": (300, 208, 144, 16, 0.2, 0.9, 1.0),
+    "tile_8_ragged": (900, 91, 67, 8, 0.01, 0.08, 1.0),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_masked_lists_render_bit_identically_to_the_reference_lists(emu, case):
+    N, W, H, tile, smin, smax, spread = CASES[case]
+    sc = _scene(sum(map(ord, case)), N, W, H, smin, smax, spread)
+    cap = 64 * N
+    ref = _forward(emu, sc, W, H, tile, cap, flags=64, assumed_longest=1 << 20)     # the reference's lists + pack + cull kernels
+    new = _forward(emu, sc, W, H, tile, cap, flags=0, assumed_longest=1 << 20)      # masked lists
+    assert ref["abort"] == 0 and new["abort"] == 0
+    n_ref, n_listed = int(ref["counts"][0]), int(new["counts"][0])
+    print(f"{case}: reference n_isects {n_ref}, listed {n_listed} ({n_listed / max(n_ref, 1):.2f}), longest {int(ref['counts'][1])} -> {int(new['counts'][1])}")
+    assert int(ref["counts"][3]) == n_ref and int(new["counts"][3]) == n_ref          # both report the reference's count
+    assert 0 < n_listed <= n_ref and int(new["counts"][1]) <= int(ref["counts"][1])
+    assert np.array_equal(ref["radii"], new["radii"])
+    assert (ref["alpha"] > 0.05).mean() > 0.02, "degenerate scene"
+    assert np.array_equal(ref["render"], new["render"]) and np.array_equal(ref["alpha"], new["alpha"])
+    if case == "dense_long_lists":
+        assert int(new["counts"][1]) > 1024, "the second sort class is not exercised"
+    # culling off: the masked path lists every tile of every rectangle again
+    off = _forward(emu, sc, W, H, tile, cap, flags=1, assumed_longest=1 << 20)
+    assert int(off["counts"][0]) == n_ref and np.array_equal(off["offsets"], ref["offsets"])
+    assert np.array_equal(off["render"], ref["render"]) and np.array_equal(off["alpha"], ref["alpha"]) and np.array_equal(off["last_ids"], ref["last_ids"])
+
+
+def test_guarded_attempt_that_does_not_fit_reports_counts_and_renders_nothing(emu):
+    N, W, H, tile, smin, smax, spread = CASES["syn_a_like"]
+    sc = _scene(5, N, W, H, smin, smax, spread)
+    ok = _forward(emu, sc, W, H, tile, 64 * N, flags=0)
+    small = _forward(emu, sc, W, H, tile, max(int(ok["counts"][0]) // 3, 1), flags=0)
+    assert small["abort"] == 1 and np.array_equal(small["counts"][[0, 1, 3]], ok["counts"][[0, 1, 3]])
+    assert small["offsets"].max() == 0 and float(small["alpha"].max()) == 0.0
+    short = _forward(emu, sc, W, H, tile, 64 * N, flags=0, assumed_longest=4)       # sort classes launched for lists of <= 1024 entries only: fits here
+    assert short["abort"] == 0 and np.array_equal(short["render"], ok["render"])
