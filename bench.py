@@ -412,10 +412,7 @@ def main() -> None:
                    "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ("-replicated" if world > 1 else "")),
                    "path": args.path, "start_iteration": args.start_iteration,
                    "strategy": args.strategy, "bilateral_grid": bool(args.bilateral_grid), "refine_step_ms": None if refine_ms is None else round(refine_ms, 3),
-                   "visible_gaussians": V, **({"visible_gaussians_source": v_source} if v_source else {}), "n_isects": I,
-                   # what the step's own tile lists hold (round 4: tiles of a Gaussian's bounding rectangle that its alpha >= 1/255 ellipse cannot reach are not listed);
-                   # n_isects above - the reference's count, gsplat::intersect_tile's - is what the algorithmic bytes of SURVEY.md 8(d) are computed from
-                   "n_listed": (int(trainer._gut_step.n_listed) if getattr(trainer, "_gut_step", None) is not None and hasattr(trainer._gut_step, "n_listed") else None)},
+                   "visible_gaussians": V, **({"visible_gaussians_source": v_source} if v_source else {}), "n_isects": I},
         "collectives": {"backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None), "ranks_seen": seen,
                         "per_step": {k: {"calls": v["calls"] / args.steps, "MB": round(v["bytes"] / args.steps / 1e6, 3), "ms": round(coll_ms.get(k, 0.0), 4)} for k, v in coll.items()}},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel, "library": capi.load_library().lfs_version().decode(),

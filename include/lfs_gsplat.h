@@ -386,11 +386,8 @@ LFS_API int lfs_activations_project_ut(
  *      No host read on the critical path: the intersection lists are sized for `capacity` entries and sorted by the size classes that cover
  *      `assumed_longest` entries per tile; the true count stays on the device. When it exceeds either assumption the kernels raise a device flag,
  *      empty all lists and the Adam kernels return without updating anything: the caller learns it from the counts - written to PINNED host memory
- *      host_counts[4] = {intersections LISTED, longest tile list, stamp, the reference's n_isects} early in the step - after it has enqueued everything
- *      (lfs_gut_step_wait, lfs_gut_step_fits), enlarges the workspace and calls again with the same arguments. "Listed" is what `capacity` has to hold: the step's
- *      own tile lists leave out the tiles of a Gaussian's bounding rectangle that its alpha >= 1/255 ellipse cannot reach (masked lists, csrc/intersect.hip;
- *      conservative - the image and the gradients are those of the full lists); lfs_gut_step_reference_count returns the rectangle count of
- *      gsplat/IntersectTile.cu:24-114, what gsplat::intersect_tile reports as n_isects.
+ *      host_counts[3] = {n_isects, longest tile list, stamp} early in the step - after it has enqueued everything (lfs_gut_step_wait, lfs_gut_step_fits),
+ *      enlarges the workspace and calls again with the same arguments.
  *   lfs_gut_step_args: parameters are updated in place; exp_avg / exp_avg_sq / adam[k] in FusedAdam's group order (fused_adam.cpp:22-95, strategy_utils.cpp:35-40)
  *      means, sh0, shN, raw_scales, raw_quats, raw_opacities; adam[k] = {lr, beta1, beta2, eps, 1/(1-beta1^t), 1/sqrt(1-beta2^t)} (fused_adam.cpp:78-92).
  *      viewmat [4,4], Kmat [3,3], background [3] (nullable), target_chw [3,H,W] on the device; *loss = loss_weight * mse(clamp(render,0,1), target) (stored).
@@ -409,12 +406,11 @@ typedef struct lfs_gut_step_args {
 } lfs_gut_step_args;
 typedef struct lfs_gut_step_layout {
     size_t bytes, render, alpha, last_ids, radii, means2d, depths, colors, quats, scales, opacities, tile_offsets, flatten_ids, isect_ids, counts, abort_flag;
-    size_t colors_stride; /* floats between the colour rows at `colors`: 3, or 16 when the step keeps the colours inside the rasterizer's 64-byte records (masked lists) */
 } lfs_gut_step_layout;
 LFS_API int lfs_gut_step_layout_for(uint32_t N, uint32_t image_width, uint32_t image_height, uint32_t tile_size, int64_t capacity, lfs_gut_step_layout* out);
 LFS_API int lfs_gut_step_fits(int64_t n_isects, int64_t longest, int64_t capacity, int64_t assumed_longest); /* 1: the attempt with these assumptions was valid */
 LFS_API int lfs_gut_train_step(const lfs_gut_step_args* args, int64_t capacity, int64_t assumed_longest, void* workspace, size_t workspace_bytes,
-                               int64_t* host_counts /* pinned [4], or NULL: counts stay in the workspace */, int64_t stamp, lfs_stream_t stream);
+                               int64_t* host_counts /* pinned [3], or NULL: counts stay in the workspace */, int64_t stamp, lfs_stream_t stream);
 LFS_API int lfs_gut_view_forward(const lfs_gut_step_args* args, int64_t capacity, int64_t assumed_longest, void* workspace, size_t workspace_bytes,
                                  int64_t* host_counts, int64_t stamp, lfs_stream_t stream);
 LFS_API int lfs_gut_view_backward(const lfs_gut_step_args* args, int64_t capacity, const float* v_render /* [H,W,3], used when args->target_chw == NULL */,
@@ -428,8 +424,7 @@ LFS_API int lfs_gut_view_backward_sh(const lfs_gut_step_args* args, int64_t capa
                                      void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 LFS_API int lfs_gut_view_backward_finish(const lfs_gut_step_args* args, int64_t capacity, float* const* grads, int accumulate,
                                          void* workspace, size_t workspace_bytes, lfs_stream_t stream);
-LFS_API int lfs_gut_step_wait(const int64_t* host_counts, int64_t stamp, double timeout_s, int64_t* n_listed, int64_t* longest);
-LFS_API int64_t lfs_gut_step_reference_count(const int64_t* host_counts); /* after lfs_gut_step_wait returned 0: the reference's n_isects of that step */
+LFS_API int lfs_gut_step_wait(const int64_t* host_counts, int64_t stamp, double timeout_s, int64_t* n_isects, int64_t* longest);
 
 /* Extension: the all-inline training step of the fused 3DGUT path (one camera, global shutter, 3 channels, ONE view per step on one rank - the
  * reference's training configuration). No parameter gradient is materialised:

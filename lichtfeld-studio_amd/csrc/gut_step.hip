@@ -25,8 +25,6 @@ namespace {
 inline size_t a256(size_t v) { return (v + 255) & ~size_t(255); }
 
 struct StepWs {
-    bool masked;            // round 4: masked tile lists (intersect.hip) + records packed by the projection kernel; false = the reference's lists + pack + cull kernels
-    uint32_t colors_stride; // element stride of the colour rows: 3 (own array), or 16 when the SH kernel writes them into the rasterizer's records (masked)
     float *quats, *scales, *opacities, *means2d, *depths, *colors, *v_dirs, *render, *alpha;
     int32_t *radii, *tiles_per_gauss, *flatten_ids, *last_ids, *abort_flag;
     int64_t *isect_ids, *binned, *dev_counts;
@@ -56,12 +54,9 @@ bool step_ws(void* base, uint32_t N, uint32_t W, uint32_t H, uint32_t tile, int6
     w.v_dirs = (float*)(p + o_vdirs); w.isect_ws = p + o_iws; w.isect_ids = (int64_t*)(p + o_ids); w.flatten_ids = (int32_t*)(p + o_flat);
     w.binned = (int64_t*)(p + o_binned); w.raster_ws = p + o_rws; w.render = (float*)(p + o_render); w.alpha = (float*)(p + o_alpha);
     w.last_ids = (int32_t*)(p + o_last); w.abort_flag = (int32_t*)(p + o_flag); w.dev_counts = (int64_t*)(p + o_counts);
-    w.masked = isect_masked_supported(N, tile, tw, th);
-    w.colors_stride = 3;
-    const size_t o_colors_eff = o_colors;
     if (lay) {
         lay->bytes = o; lay->quats = o_quats; lay->scales = o_scales; lay->opacities = o_opac; lay->radii = o_radii; lay->means2d = o_m2d; lay->depths = o_depths;
-        lay->colors = o_colors_eff; lay->colors_stride = w.colors_stride; lay->isect_ids = o_ids; lay->flatten_ids = o_flat; lay->render = o_render; lay->alpha = o_alpha; lay->last_ids = o_last;
+        lay->colors = o_colors; lay->isect_ids = o_ids; lay->flatten_ids = o_flat; lay->render = o_render; lay->alpha = o_alpha; lay->last_ids = o_last;
         lay->abort_flag = o_flag; lay->counts = o_counts;
         lay->tile_offsets = o_iws + size_t(reinterpret_cast<const char*>(isect_workspace_offsets(nullptr, 1, N, tw, th)) - static_cast<const char*>(nullptr));
     }
@@ -82,43 +77,36 @@ int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacit
     // trainer constants of rasterizer.cpp:176-181: eps2d 0.3, near 0.01, far 1e4, radius_clip 0
     // the projection kernel also clears the intersection stage's per-tile totals and writes the rasterizer's camera state (first block of the raster workspace):
     // two launches of a few microseconds each that a step does not need (the 32 KB memset and cam_prep_kernel)
-    uint32_t zero_n = 0;
-    uint32_t* zero_words = isect_workspace_totals(w.isect_ws, 1, N, tw, th, &zero_n);
-    void *cams_dev = nullptr, *recs = nullptr, *cull = nullptr;
-    raster_workspace_parts(w.raster_ws, N, &cams_dev, &recs, &cull);
+    // Round 4: the SH colours are evaluated FIRST (for every Gaussian - visibility is not known yet, 6 % more coefficient rows on SYN-B) so that the projection
+    // kernel, which has the activated quaternion / scale / opacity in registers, can write the rasterizer's 64-byte record and the 32-byte culling record of every
+    // visible Gaussian itself: raster_pack_kernel's second pass over the Gaussians (0.040 ms, 152 MB re-read) is gone. Debug bit 6: the round-3 order (A/B, tests).
+    const bool pack_here = !(lfs_get_debug_flags() & 64u);
+    void *recs = nullptr, *cull = nullptr;
+    raster_workspace_parts(w.raster_ws, N, nullptr, &recs, &cull);
     int rc = LFS_OK;
-    if (w.masked) { // the SH colours first (for every Gaussian: visibility is not known yet) - the projection kernel then writes each record as one 64-byte store
-        rc = sh_model_fwd_impl(N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, nullptr, w.colors, 0, s);
+    if (pack_here) {
+        rc = sh_model_fwd_impl(N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, nullptr, w.colors, s);
         if (rc) return rc;
     }
     rc = activations_project_ut_impl(N, a->means, a->raw_quats, a->raw_scales, a->raw_opacities, &cams, 0.3f, 0.01f, 10000.f, 0.f, &ut, w.quats, w.scales,
-                                     w.opacities, w.radii, w.means2d, w.depths, zero_words, zero_n, w.raster_ws, s, w.masked ? recs : nullptr, w.masked ? cull : nullptr,
-                                     w.masked ? w.colors : nullptr);
+                                     w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th, w.raster_ws, s,
+                                     pack_here ? recs : nullptr, pack_here ? cull : nullptr, pack_here ? w.colors : nullptr);
     if (rc) return rc;
-    int64_t* counts = host_counts ? host_counts : w.dev_counts;   // [listed intersections, longest tile list, stamp, the reference's n_isects]
-    const IsectGuard guard{capacity, assumed_longest, w.abort_flag, counts + 3};
-    if (w.masked) {
-        // Round 4: the projection kernel has written the rasterizer's records and culling records; the lists hold only the (Gaussian, tile) pairs whose alpha >= 1/255
-        // ellipse reaches the tile, each with the 4-bit mask of the tile's cells it reaches. No pack kernel, no cull kernel.
-        rc = isect_masked_lists_impl(N, w.means2d, w.radii, w.depths, cull, cams_dev, tile, tw, th, w.isect_ids, w.flatten_ids, w.binned, counts, stamp, w.isect_ws,
-                                     w.isect_ws_bytes, s, &guard);
-        if (rc) return rc;
-        f.offsets = isect_workspace_offsets(w.isect_ws, 1, N, tw, th);
-        return raster_fwd_guarded(N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, tile, f.offsets, w.flatten_ids, capacity, w.render, w.alpha,
-                                  w.last_ids, w.raster_ws, w.raster_ws_bytes, s, /*cams_ready=*/true, /*masked_lists=*/true);
-    }
+    const IsectGuard guard{capacity, assumed_longest, w.abort_flag};
+    int64_t* counts = host_counts ? host_counts : w.dev_counts;   // [n_isects, longest tile list, stamp]
     rc = isect_count_impl(1, N, w.means2d, w.radii, tile, tw, th, w.tiles_per_gauss, counts, counts + 1, nullptr, LFS_ISECT_COUNTERS_ZERO, counts + 2, stamp, w.isect_ws,
                           w.isect_ws_bytes, s, &guard);
     if (rc) return rc;
-    // the SH colours need the projection's radii only: enqueued between the count and the binning passes, as the Python step did with its `overlap` hook
-    rc = lfs_sh_model_fwd(N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, s);
-    if (rc) return rc;
+    if (!pack_here) { // the SH colours need the projection's radii only: enqueued between the count and the binning passes, as the Python step did with its `overlap` hook
+        rc = lfs_sh_model_fwd(N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, s);
+        if (rc) return rc;
+    }
     rc = isect_emit_impl(1, N, w.means2d, w.radii, w.depths, tile, tw, th, 1, -1, w.tiles_per_gauss, w.isect_ids, w.flatten_ids, nullptr, w.binned, -1, w.isect_ws,
                          w.isect_ws_bytes, s, &guard);
     if (rc) return rc;
     f.offsets = isect_workspace_offsets(w.isect_ws, 1, N, tw, th);
     return raster_fwd_guarded(N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, tile, f.offsets, w.flatten_ids, capacity, w.render, w.alpha,
-                              w.last_ids, w.raster_ws, w.raster_ws_bytes, s, /*cams_ready=*/true);
+                              w.last_ids, w.raster_ws, w.raster_ws_bytes, s, /*cams_ready=*/true, /*records_ready=*/pack_here);
 }
 
 int check_args(const lfs_gut_step_args* a, bool need_adam) {
@@ -144,8 +132,6 @@ extern "C" int lfs_gut_step_layout_for(uint32_t N, uint32_t image_width, uint32_
     return LFS_OK;
 }
 
-extern "C" int64_t lfs_gut_step_reference_count(const int64_t* host_counts) { return host_counts ? reinterpret_cast<const volatile int64_t*>(host_counts)[3] : -1; }
-
 extern "C" int lfs_gut_step_fits(int64_t n_isects, int64_t longest, int64_t capacity, int64_t assumed_longest) {
     return (n_isects <= capacity && uint64_t(longest) <= uint64_t(sort_class_limit(assumed_longest))) ? 1 : 0;
 }
@@ -167,7 +153,7 @@ extern "C" int lfs_gut_train_step(const lfs_gut_step_args* a, int64_t capacity, 
     if (rc) return rc;
     const float* acc_rows = reinterpret_cast<const float*>(static_cast<const char*>(w.raster_ws) + lfs_rasterize_workspace_acc_offset(1, a->N));
     rc = sh_model_bwd_adam_all_impl(a->N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, acc_rows, w.v_dirs, a->exp_avg[1], a->exp_avg_sq[1],
-                                    a->adam[1], a->exp_avg[2], a->exp_avg_sq[2], a->adam[2], s, w.abort_flag, w.colors_stride == 16 ? 16u : 0u);
+                                    a->adam[1], a->exp_avg[2], a->exp_avg_sq[2], a->adam[2], s, w.abort_flag);
     if (rc) return rc;
     // lfs_gut_finish_adam's order: means, raw_scales, raw_quats, raw_opacities = FusedAdam groups 0, 3, 4, 5
     float* const m[4] = {a->exp_avg[0], a->exp_avg[3], a->exp_avg[4], a->exp_avg[5]};
@@ -220,8 +206,7 @@ extern "C" int lfs_gut_view_backward_sh(const lfs_gut_step_args* a, int64_t capa
     if (rc) return rc;
     const float* acc_rows = reinterpret_cast<const float*>(static_cast<const char*>(w.raster_ws) + lfs_rasterize_workspace_acc_offset(1, a->N));
     return sh_model_bwd_rows_impl(a->N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, acc_rows, accumulate, grads[1], grads[2], w.v_dirs, s,
-                                  inline_shN ? a->exp_avg[2] : nullptr, inline_shN ? a->exp_avg_sq[2] : nullptr, inline_shN ? a->adam[2] : nullptr,
-                                  w.colors_stride == 16 ? 16u : 0u);
+                                  inline_shN ? a->exp_avg[2] : nullptr, inline_shN ? a->exp_avg_sq[2] : nullptr, inline_shN ? a->adam[2] : nullptr);
 }
 
 extern "C" int lfs_gut_view_backward_finish(const lfs_gut_step_args* a, int64_t capacity, float* const* grads /* [6] host */, int accumulate,

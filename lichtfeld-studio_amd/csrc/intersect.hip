@@ -19,11 +19,9 @@
 // "sort by (tile, depth, flatten id)" are the same total order: the result does
 // not depend on the (atomic, unordered) bucket fill. tile_offsets falls out of
 // the scan, so intersect_offset is free on this path.
-#include <algorithm>
 #include "lfs_math.cuh"
 #include "lfs_prof.h"
 #include "lfs_tilelists.cuh"
-#include "lfs_raster_pack.cuh"
 #include "lfs_step_internal.h"
 #include "../../include/lfs_gsplat.h"
 
@@ -154,131 +152,6 @@ __global__ void __launch_bounds__(1024) isect_scatter_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// MASKED lists (round 4; the training step only - never behind gsplat::intersect_tile, whose outputs stay bit-exact with the reference).
-// The reference lists a Gaussian in every tile of the bounding rectangle of its radii; for the small Gaussians of a trained scene most of those tiles are
-// never touched by the alpha >= 1/255 ellipse (SYN-B: the per-cell conic test of raster_cull_kernel removed 86 % of the 4 cells x entries), yet every
-// entry was scattered, sorted and then gathered again (a 32-byte culling record per entry, 1.36 x the algorithmic bytes of that kernel) only to be dropped.
-// Here the conic test runs where the Gaussian's culling record is read ONCE, coalesced: per (Gaussian, tile) a 4-bit mask says which of the tile's 8x8
-// cells can reach the alpha threshold (lfs_cull_conic.cuh: conservative, so the image and the gradients are exactly those of the full lists); tiles with an
-// empty mask are not listed at all, the others carry the mask through binning and sort in the four bits below the Gaussian index, and the per-cell lists
-// fall out of a gather-free compaction (raster.hip: cells_from_masks_kernel). What stays defined as in the reference: tiles_per_gauss / n_isects are still
-// the rectangle counts (reported to the caller), the order inside a tile is (depth, Gaussian index).
-//   isect_count_masked_kernel : lanes = (Gaussian, tile) PAIRS of the wavefront's 64 Gaussians (prefix sum + search: converged evaluation of the 4 conic tests,
-//                               where a per-Gaussian loop over its rectangle would run every wavefront at the pace of its largest Gaussian); masks of
-//                               rectangles of <= 16 tiles are stored (64 bits per Gaussian), larger ones are re-derived by the binning kernel.
-// ---------------------------------------------------------------------------
-struct CellFrame { float ax, bx, ay, by, mx, my; uint32_t cull_on; }; // u(j) = ax * j + bx at pixel column j's left edge + 0.5 (normalised camera x); margins mx, my
-LFS_DI CellFrame cell_frame(const CamDev& cam, uint32_t cull_on) {
-    CellFrame f;
-    f.ax = 1.f / cam.fx; f.bx = (0.5f - cam.cx) / cam.fx; f.ay = 1.f / cam.fy; f.by = (0.5f - cam.cy) / cam.fy;
-    f.mx = 0.25f / cam.fx; f.my = 0.25f / cam.fy; f.cull_on = cull_on;   // a quarter pixel of numerical margin, as raster_cull_kernel
-    return f;
-}
-constexpr uint32_t NREF_SLOTS = 64; // the rectangle count (the reference's n_isects) is accumulated over this many addresses
-
-// The cells of one ROW of 8x8 cells (cell row `crow` of the image) the Gaussian can reach: the global cell columns [clo, chi] (empty: clo > chi), from ONE
-// interval computation (lfs_cull_conic.cuh: conic_strip_interval) - a Gaussian costs (cell rows of its rectangle) x ~50 operations, its tiles only integer
-// compares. History of this stage on SYN-B (profiles/r04): per-(Gaussian, tile) 4-cell conic tests in a per-Gaussian loop 0.168 + 0.241 ms (count + binning:
-// the few Gaussians with 20 - 60 tile rectangles hold their wavefronts), the same tests with lanes = (Gaussian, tile) pairs and stored masks 0.077 + 0.049 ms,
-// this form (nothing stored, both kernels re-derive the row ranges) see DESIGN.md. `per_cell`: the strip form is degenerate for this record (a needle whose leading
-// coefficient is within the tolerance of zero): the caller tests the row's cells one by one with conic_culled.
-struct CellRowRange { int32_t clo, chi; bool per_cell; };
-LFS_DI CellRowRange cell_row_range(const CellFrame& f, const ConicRec& k, const uint32_t crow) {
-    CellRowRange r{-(1 << 28), 1 << 28, false};
-    if (!f.cull_on) return r;
-    const float i0 = float(crow * 8u);
-    const float v0 = f.ay * i0 + f.by - f.my, v1 = f.ay * (i0 + 7.f) + f.by + f.my;
-    float lo, hi;
-    if (!conic_strip_interval(k, v0, v1, lo, hi)) { r.clo = 1; r.chi = 0; return r; }
-    if (!(lo > -INFINITY) || !(hi < INFINITY)) { r.per_cell = k.g < INFINITY; return r; } // (a "never cull" record: every cell)
-    // cell column c spans u in [ax 8c + bx - mx, ax (8c + 7) + bx + mx]; it meets [lo + px, hi + px] iff tl <= c <= th (a thousandth of a cell of slack for the rounding here)
-    const float inv = 1.f / (8.f * f.ax);
-    const float tl = (lo + k.px - f.bx - f.mx - 7.f * f.ax) * inv - 1e-3f, th = (hi + k.px - f.bx + f.mx) * inv + 1e-3f;
-    r.clo = int32_t(ceilf(fminf(fmaxf(tl, -1e6f), 1e6f)));
-    r.chi = int32_t(floorf(fminf(fmaxf(th, -1e6f), 1e6f)));
-    return r;
-}
-// the 4-bit (WPS = 2) / 1-bit (WPS = 1) cell mask of tile column x from the ranges of the tile's cell rows; bit (cr * WPS + cc)
-template <int WPS>
-LFS_DI uint32_t tile_mask_from_rows(const CellFrame& f, const ConicRec& k, const CellRowRange (&rr)[WPS], const uint32_t x, const uint32_t y) {
-    uint32_t mask = 0;
-#pragma unroll
-    for (int cr = 0; cr < WPS; ++cr)
-#pragma unroll
-        for (int cc = 0; cc < WPS; ++cc) {
-            const int32_t col = int32_t(x * WPS + cc);
-            bool on = col >= rr[cr].clo && col <= rr[cr].chi;
-            if (rr[cr].per_cell) {
-                const float j0 = float(col * 8), i0 = float((y * WPS + cr) * 8u);
-                on = !conic_culled(k, f.ax * j0 + f.bx - f.mx, f.ax * (j0 + 7.f) + f.bx + f.mx, f.ay * i0 + f.by - f.my, f.ay * (i0 + 7.f) + f.by + f.my);
-            }
-            mask |= on ? 1u << (cr * WPS + cc) : 0u;
-        }
-    return mask;
-}
-// the tile columns [jlo, jhi) of the rectangle [x0, x1) a tile row can list at all (saves the empty iterations of wide rectangles)
-template <int WPS>
-LFS_DI void tile_cols_of_rows(const CellRowRange (&rr)[WPS], const uint32_t x0, const uint32_t x1, uint32_t& jlo, uint32_t& jhi) {
-    int32_t lo = 1 << 28, hi = -(1 << 28);
-    bool any_per_cell = false;
-#pragma unroll
-    for (int cr = 0; cr < WPS; ++cr) { any_per_cell |= rr[cr].per_cell; if (rr[cr].clo <= rr[cr].chi) { lo = min(lo, rr[cr].clo); hi = max(hi, rr[cr].chi); } }
-    if (any_per_cell) { jlo = x0; jhi = x1; return; }
-    if (lo > hi) { jlo = x0; jhi = x0; return; }
-    const int32_t tlo = lo >= 0 ? lo / WPS : 0, thi = hi >= 0 ? hi / WPS : -1;
-    jlo = uint32_t(min(max(tlo, int32_t(x0)), int32_t(x1)));
-    jhi = uint32_t(min(max(thi + 1, int32_t(jlo)), int32_t(x1)));
-}
-
-template <int WPS, bool LDS_HIST>
-__global__ void __launch_bounds__(1024) isect_count_masked_kernel(
-    const uint32_t N, const uint32_t per_block, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const CullRec* __restrict__ cull,
-    const CamDev* __restrict__ cams, const float tile_size_f, const uint32_t tw, const uint32_t th, const uint32_t cull_on,
-    uint32_t* __restrict__ totals, unsigned long long* __restrict__ n_ref_slots) {
-    LFS_DYN_LDS(uint32_t, hist); // [T] (LDS_HIST)
-    __shared__ unsigned long long s_ref[16];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t T = tw * th;
-    if (LDS_HIST) {
-        for (uint32_t t = threadIdx.x; t < T; t += 1024) hist[t] = 0u;
-        __syncthreads();
-    }
-    const CellFrame fr = cell_frame(cams[0], cull_on);
-    unsigned long long ref_sum = 0;
-    const uint32_t begin = blockIdx.x * per_block, end = min(begin + per_block, N);
-    for (uint32_t idx = begin + threadIdx.x; idx < end; idx += 1024) {
-        TileRect rc;
-        if (!tile_rect(means2d, radii, idx, tile_size_f, tw, th, rc) || rc.x1 <= rc.x0 || rc.y1 <= rc.y0) continue;
-        ref_sum += (unsigned long long)(rc.x1 - rc.x0) * (rc.y1 - rc.y0);
-        const CullRec cr = cull[idx];
-        const ConicRec kr{cr.a.x, cr.a.y, cr.a.z, cr.a.w, cr.b.x, cr.b.y, cr.b.z, cr.b.w};
-        for (uint32_t i = rc.y0; i < rc.y1; ++i) {
-            CellRowRange rr[WPS];
-#pragma unroll
-            for (int c = 0; c < WPS; ++c) rr[c] = cell_row_range(fr, kr, i * WPS + c);
-            uint32_t jlo, jhi;
-            tile_cols_of_rows<WPS>(rr, rc.x0, rc.x1, jlo, jhi);
-            for (uint32_t x = jlo; x < jhi; ++x)
-                if (tile_mask_from_rows<WPS>(fr, kr, rr, x, i)) { if (LDS_HIST) atomicAdd(&hist[i * tw + x], 1u); else atomicAdd(&totals[i * tw + x], 1u); }
-        }
-    }
-    if (LDS_HIST) {
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < T; t += 1024) { const uint32_t c = hist[t]; if (c) atomicAdd(&totals[t], c); }
-    }
-    // the reference's intersection count (rectangle areas) of this workgroup -> one of NREF_SLOTS addresses
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) ref_sum += __shfl_xor(ref_sum, m, 64);
-    if (lane == 0) s_ref[wave] = ref_sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int w = 0; w < 16; ++w) t += s_ref[w];
-        if (t) atomicAdd(&n_ref_slots[blockIdx.x & (NREF_SLOTS - 1)], t);
-    }
-}
-
-// ---------------------------------------------------------------------------
 // Two-pass scatter (the default when the caller provides a scratch array): the one-pass kernel above writes every intersection as an isolated
 // 8-byte store (a workgroup's ~9 000 intersections fall into ~8 000 different tile buckets), and HBM writes in 32-byte sectors: 158 MB written for
 // 36 MB of payload (PMC, SYN-B). Binning in two steps keeps every store part of a run of hundreds of bytes:
@@ -325,17 +198,10 @@ LFS_DI void block_scan_1024(const uint32_t* a, uint32_t* out, uint32_t L, uint32
     __syncthreads();
 }
 
-// Entry layout of the two passes (64 bits):  depth bits << dshift | tile_x << xshift | Gaussian index << pshift | cell mask.
-//   reference lists (gsplat::intersect_tile): dshift 32, xshift = bits(C N - 1), pshift 0, no mask
-//   masked lists (training step)            : pshift 4, xshift = bits(N - 1) + 4, dshift = max(32, xshift + bits(tile_w - 1)) <= 33 - a depth behind the near
-//                                             plane is positive, its sign bit is free: one more bit for the payload (3 M Gaussians at 100 tile columns need 33)
-struct EntryFmt { uint32_t dshift, xshift, pshift; };
-template <bool MASKED, int WPS>
 __global__ void __launch_bounds__(1024) isect_rows_kernel(
     const uint32_t C, const uint32_t N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths,
-    const float tile_size_f, const uint32_t tw, const uint32_t th, const EntryFmt fmt,
-    const int32_t* __restrict__ offsets, uint32_t* __restrict__ row_cursor, uint64_t* __restrict__ scratch, const int32_t* __restrict__ abort_flag = nullptr,
-    const CullRec* __restrict__ cull = nullptr, const CamDev* __restrict__ cams = nullptr, const uint32_t cull_on = 1) {
+    const float tile_size_f, const uint32_t tw, const uint32_t th, const uint32_t idx_bits,
+    const int32_t* __restrict__ offsets, uint32_t* __restrict__ row_cursor, uint64_t* __restrict__ scratch, const int32_t* __restrict__ abort_flag = nullptr) {
     LFS_DYN_LDS(uint64_t, stage); // [ROWS_STAGE]
     if (abort_flag != nullptr && *abort_flag != 0) return; // speculative step: the lists do not fit the caller's buffers (tile_scan_kernel) - this kernel derives its
                                                            // write positions from the Gaussians, not from the (zeroed) offsets, so it has to stop itself
@@ -348,24 +214,7 @@ __global__ void __launch_bounds__(1024) isect_rows_kernel(
     TileRect rc{0, 0, 0, 0};
     const bool have = begin < total && tile_rect(means2d, radii, begin, tile_size_f, tw, th, rc) && rc.x1 > rc.x0 && rc.y1 > rc.y0;
     const uint32_t nx = rc.x1 - rc.x0, rb = uint32_t(begin / N) * th;
-    // MASKED: the cell ranges of a tile row are re-derived here from the culling record (cell_row_range: one interval per row of cells) - twice, for the count
-    // and for the placement: cheaper than storing them between the two kernels and between the two phases
-    ConicRec kr{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    CellFrame fr{};
-    if (MASKED && have) { const CullRec cr = cull[begin]; kr = ConicRec{cr.a.x, cr.a.y, cr.a.z, cr.a.w, cr.b.x, cr.b.y, cr.b.z, cr.b.w}; fr = cell_frame(cams[0], cull_on); }
-    if (have) for (uint32_t i = rc.y0; i < rc.y1; ++i) {
-        uint32_t c = nx;
-        if (MASKED) {
-            CellRowRange rr[WPS];
-#pragma unroll
-            for (int q = 0; q < WPS; ++q) rr[q] = cell_row_range(fr, kr, i * WPS + q);
-            uint32_t jlo, jhi;
-            tile_cols_of_rows<WPS>(rr, rc.x0, rc.x1, jlo, jhi);
-            c = 0;
-            for (uint32_t x = jlo; x < jhi; ++x) c += tile_mask_from_rows<WPS>(fr, kr, rr, x, i) != 0u;
-        }
-        if (c) atomicAdd(&cnt[rb + i], c);
-    }
+    if (have) for (uint32_t i = rc.y0; i < rc.y1; ++i) atomicAdd(&cnt[rb + i], nx);
     __syncthreads();
     for (uint32_t r = threadIdx.x; r < R; r += 1024) { const uint32_t c = cnt[r]; gbase[r] = c ? atomicAdd(&row_cursor[r], c) : 0u; }
     block_scan_1024(cnt, lbase, R, tmp);
@@ -374,29 +223,16 @@ __global__ void __launch_bounds__(1024) isect_rows_kernel(
     for (uint32_t r = threadIdx.x; r < R; r += 1024) cnt[r] = 0u; // now the running rank inside the row
     __syncthreads();
     if (have) {
-        const uint64_t hi = uint64_t(__float_as_uint(depths[begin])) << fmt.dshift | uint64_t(uint32_t(begin)) << fmt.pshift;
+        const uint64_t hi = uint64_t(__float_as_uint(depths[begin])) << 32 | uint64_t(uint32_t(begin));
         for (uint32_t i = rc.y0; i < rc.y1; ++i) {
             const uint32_t row = rb + i;
-            if (!MASKED) {
-                const uint32_t k = atomicAdd(&cnt[row], nx);
-                uint64_t* dst = staged ? stage + lbase[row] + k : scratch + size_t(offsets[size_t(row) * tw]) + gbase[row] + k;
-                for (uint32_t j = 0; j < nx; ++j) dst[j] = hi | (uint64_t(rc.x0 + j) << fmt.xshift);
+            const uint32_t k = atomicAdd(&cnt[row], nx);
+            if (staged) {
+                uint64_t* dst = stage + lbase[row] + k;
+                for (uint32_t j = 0; j < nx; ++j) dst[j] = hi | (uint64_t(rc.x0 + j) << idx_bits);
             } else {
-                CellRowRange rr[WPS];
-#pragma unroll
-                for (int q = 0; q < WPS; ++q) rr[q] = cell_row_range(fr, kr, i * WPS + q);
-                uint32_t jlo, jhi;
-                tile_cols_of_rows<WPS>(rr, rc.x0, rc.x1, jlo, jhi);
-                uint32_t c = 0, masks = 0; // (up to 8 tiles' masks are kept from the counting pass of this row; longer rows re-derive them)
-                for (uint32_t x = jlo; x < jhi; ++x) { const uint32_t m = tile_mask_from_rows<WPS>(fr, kr, rr, x, i); c += m != 0u; if (x - jlo < 8u) masks |= m << ((x - jlo) * 4u); }
-                if (c == 0) continue;
-                const uint32_t k = atomicAdd(&cnt[row], c);
-                uint64_t* dst = staged ? stage + lbase[row] + k : scratch + size_t(offsets[size_t(row) * tw]) + gbase[row] + k;
-                uint32_t w = 0;
-                for (uint32_t x = jlo; x < jhi; ++x) {
-                    const uint32_t m = (x - jlo < 8u) ? (masks >> ((x - jlo) * 4u)) & 15u : tile_mask_from_rows<WPS>(fr, kr, rr, x, i);
-                    if (m) dst[w++] = hi | (uint64_t(x) << fmt.xshift) | uint64_t(m);
-                }
+                uint64_t* dst = scratch + size_t(offsets[size_t(row) * tw]) + gbase[row] + k;
+                for (uint32_t j = 0; j < nx; ++j) dst[j] = hi | (uint64_t(rc.x0 + j) << idx_bits);
             }
         }
     }
@@ -412,7 +248,7 @@ __global__ void __launch_bounds__(1024) isect_rows_kernel(
 }
 
 __global__ void __launch_bounds__(1024) isect_tiles_kernel(
-    const uint32_t R, const uint32_t tw, const EntryFmt fmt, const int64_t n_isects_arg,
+    const uint32_t R, const uint32_t tw, const uint32_t idx_bits, const int64_t n_isects_arg,
     const int32_t* __restrict__ offsets, uint32_t* __restrict__ cursor, const uint64_t* __restrict__ scratch, int64_t* __restrict__ isect_ids) {
     LFS_DYN_LDS(uint64_t, stage); // [TILES_CHUNK]
     __shared__ uint32_t cnt[TILES_SPAN], lpre[TILES_SPAN + 1], gb[TILES_SPAN], tmp[17];
@@ -430,16 +266,15 @@ __global__ void __launch_bounds__(1024) isect_tiles_kernel(
     __syncthreads();
     const uint32_t r_lo = rows_s[0], r_hi = rows_s[1];
     const uint32_t t_lo = r_lo * tw, span = (r_hi - r_lo + 1) * tw;
-    // out: depth bits << dshift | payload (everything below the tile column: Gaussian index [<< 4 | cell mask])
-    const uint64_t low_mask = (uint64_t(1) << fmt.dshift) - 1, pay_mask = (uint64_t(1) << fmt.xshift) - 1;
+    const uint64_t idx_mask = (uint64_t(1) << idx_bits) - 1;
     if (span > TILES_SPAN) { // a chunk across many (mostly empty) rows: plain scatter
         for (int64_t p = p0 + threadIdx.x; p < p1; p += 1024) {
             const uint64_t e = scratch[p];
             uint32_t r = r_lo;
             while (r < r_hi && int64_t(offsets[size_t(r + 1) * tw]) <= p) ++r;
-            const uint32_t t = r * tw + uint32_t((e & low_mask) >> fmt.xshift);
+            const uint32_t t = r * tw + uint32_t((e & 0xFFFFFFFFull) >> idx_bits);
             const uint32_t slot = atomicAdd(&cursor[t], 1u);
-            isect_ids[size_t(offsets[t]) + slot] = int64_t((e & ~low_mask) | (e & pay_mask));
+            isect_ids[size_t(offsets[t]) + slot] = int64_t((e & 0xFFFFFFFF00000000ull) | (e & idx_mask));
         }
         return;
     }
@@ -454,8 +289,8 @@ __global__ void __launch_bounds__(1024) isect_tiles_kernel(
             const uint64_t e = scratch[p];
             uint32_t r = r_lo;
             while (r < r_hi && int64_t(offsets[size_t(r + 1) * tw]) <= p) ++r;
-            const uint32_t tl = (r - r_lo) * tw + uint32_t((e & low_mask) >> fmt.xshift);
-            ent[k] = (e & ~low_mask) | (e & pay_mask);
+            const uint32_t tl = (r - r_lo) * tw + uint32_t((e & 0xFFFFFFFFull) >> idx_bits);
+            ent[k] = (e & 0xFFFFFFFF00000000ull) | (e & idx_mask);
             where[k] = tl << 16 | atomicAdd(&cnt[tl], 1u);
         }
     }
@@ -575,7 +410,6 @@ __global__ void __launch_bounds__(256) isect_offset_kernel(
 // ---- workspace layout ------------------------------------------------------
 struct IsectWs {
     uint32_t* totals;   // [T]
-    unsigned long long* nref; // [NREF_SLOTS] partial sums of the rectangle counts (masked lists); directly behind totals: one clear covers both
     uint32_t* cursor;   // [T]
     uint32_t* row_cursor; // [C * tile_h]   (two-pass scatter)
     int32_t* offsets;   // [T+1]
@@ -588,7 +422,6 @@ static IsectWs isect_ws(void* base, uint32_t C, uint32_t N, uint32_t tw, uint32_
     const size_t nb = (size_t(C) * N + SCAN_ITEMS - 1) / SCAN_ITEMS + 1;
     IsectWs w; char* p = (char*)base; size_t o = 0;
     w.totals = (uint32_t*)(p + o); o += align256(T * 4);
-    w.nref = (unsigned long long*)(p + o); o += align256(NREF_SLOTS * 8);
     w.cursor = (uint32_t*)(p + o); o += align256(T * 4);
     w.row_cursor = (uint32_t*)(p + o); o += align256(size_t(C) * th * 4);
     w.offsets = (int32_t*)(p + o); o += align256((T + 1) * 4);
@@ -644,19 +477,15 @@ int lfs::isect_count_impl(
     if (guard != nullptr) {
         if (guard->capacity < 0 || !guard->abort_flag) return LFS_E_INVALID;
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets,
-                           max_tile_isects, stamp_out, stamp, guard->capacity, sort_class_limit(guard->assumed_longest), guard->abort_flag,
-                           (unsigned long long*)nullptr, 0u, guard->n_ref_out);
+                           max_tile_isects, stamp_out, stamp, guard->capacity, sort_class_limit(guard->assumed_longest), guard->abort_flag);
     } else
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets,
                            max_tile_isects, stamp_out, stamp);
     return (int)hipGetLastError();
 }
 
-uint32_t* lfs::isect_workspace_totals(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height, uint32_t* n_words) {
-    const IsectWs w = isect_ws(workspace, C, N, tile_width, tile_height);
-    // the per-tile totals and, directly behind them, the rectangle-count slots of the masked lists: what a step's first kernel clears
-    if (n_words) *n_words = uint32_t((reinterpret_cast<const char*>(w.nref + NREF_SLOTS) - reinterpret_cast<const char*>(w.totals)) / 4);
-    return w.totals;
+uint32_t* lfs::isect_workspace_totals(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height) {
+    return isect_ws(workspace, C, N, tile_width, tile_height).totals;
 }
 const int32_t* lfs::isect_workspace_offsets(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height) {
     return isect_ws(workspace, C, N, tile_width, tile_height).offsets;
@@ -677,103 +506,6 @@ extern "C" int lfs_intersect_tile_count(
     int32_t* tiles_per_gauss, int64_t* n_isects, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
     return lfs_intersect_tile_count_ex(C, N, means2d, radii, tile_size, tile_width, tile_height, tiles_per_gauss, n_isects, nullptr, nullptr, 0u, nullptr, 0, workspace,
                                        workspace_bytes, stream);
-}
-
-static int enable_big_lds() { // > 64 KiB of dynamic LDS has to be opted into once per process
-    static bool big_lds_enabled = false;
-    if (big_lds_enabled) return LFS_OK;
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_lds_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-    if (ae != hipSuccess) return (int)ae;
-    ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_bins_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4096 * 8);
-    if (ae != hipSuccess) return (int)ae;
-    ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_bins_kernel<1024, 1024, false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-    if (ae != hipSuccess) return (int)ae;
-    ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&isect_rows_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_STAGE * 8);
-    if (ae != hipSuccess) return (int)ae;
-    ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&isect_rows_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_STAGE * 8);
-    if (ae != hipSuccess) return (int)ae;
-    ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&isect_rows_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_STAGE * 8);
-    if (ae != hipSuccess) return (int)ae;
-    ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&isect_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TILES_CHUNK * 8);
-    if (ae != hipSuccess) return (int)ae;
-    big_lds_enabled = true;
-    return LFS_OK;
-}
-
-// The per-tile sort, by size class (LDS sized to the class so that small tiles do not cap the occupancy): <= 1024 entries with the counting kernel on 256 bins
-// (256 threads, keys staged in LDS), <= 4096 on 512 bins with 512 threads and only the binned copy in LDS (32 KiB; measured against the staged
-// 256-thread form: 0.277 -> 0.127 ms per view at 12 M intersections, 0.058 -> 0.042 at 4.4 M; 1024 threads or the same change for the first class:
-// no further gain), <= 16384 on 1024 bins (1024 threads, 128 KiB LDS; a bin of more than 64 keys falls back to the bitonic network inside the
-// kernel), larger -> bitonic on global memory. `longest` (the longest tile list when known): classes no tile falls into are not launched (~9 us each at T = 8160).
-static void launch_tile_sorts(uint32_t T, uint32_t n_tiles, uint32_t tile_n_bits, int64_t longest, const int32_t* offsets, int64_t* isect_ids, int32_t* flatten_ids,
-                              uint32_t dshift, uint32_t payload_only, hipStream_t s) {
-    hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 1024 * 8, s, 1u, 1024u, n_tiles, tile_n_bits, offsets, isect_ids, flatten_ids, dshift, payload_only);
-    if (longest > 1024)
-        hipLaunchKernelGGL((tile_sort_bins_kernel<512, 512, false, 32>), dim3(T), dim3(512), 4096 * 8, s, 1025u, 4096u, n_tiles, tile_n_bits, offsets, isect_ids, flatten_ids, dshift, payload_only);
-    if (longest > 4096)
-        hipLaunchKernelGGL((tile_sort_bins_kernel<1024, 1024, false, 64>), dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, n_tiles, tile_n_bits, offsets, isect_ids, flatten_ids, dshift, payload_only);
-    if (longest > 16384)
-        hipLaunchKernelGGL(tile_sort_global_kernel, dim3(T), dim3(1024), 0, s, 16385u, n_tiles, tile_n_bits, offsets, isect_ids, flatten_ids, dshift, payload_only);
-}
-
-// ---- masked lists of the training step (see isect_count_masked_kernel) ------------------------------------------------------------------------------
-// One camera, pinhole, tile size 8 or 16 (at most 4 cells per tile: the 4 mask bits), bits(N - 1) + 4 + bits(tile_w - 1) <= 33.
-bool lfs::isect_masked_supported(uint32_t N, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height) {
-    if (tile_size != 16 && tile_size != 8) return false;
-    if (N == 0 || tile_height > ROWS_MAX) return false;
-    const uint32_t idx_bits = bit_width_u32(N - 1) ? bit_width_u32(N - 1) : 1u;
-    return idx_bits + 4 + bit_width_u32(tile_width - 1) <= 33 && !(lfs_get_debug_flags() & (32u | 64u)); // debug bit 6: the reference lists + cull kernel (A/B, tests)
-}
-
-// counts: [0] intersections LISTED (what `capacity` has to hold), [1] the longest tile list, [2] stamp, [3] the reference's n_isects (rectangle areas)
-int lfs::isect_masked_lists_impl(uint32_t N, const float* means2d, const int32_t* radii, const float* depths, const void* cull_recs, const void* cams_dev,
-                                 uint32_t tile_size, uint32_t tile_width, uint32_t tile_height, int64_t* bucket /* [capacity] 8-byte entries */,
-                                 int32_t* payload_out /* [capacity]: sorted (Gaussian index << 4 | cell mask) */, int64_t* scratch /* [capacity] */, int64_t* counts,
-                                 int64_t stamp, void* workspace, size_t workspace_bytes, hipStream_t s, const IsectGuard* guard) {
-    if (!guard || !guard->abort_flag || guard->capacity <= 0 || !counts || !workspace || !bucket || !payload_out || !scratch || !cull_recs || !cams_dev) return LFS_E_INVALID;
-    if (!isect_masked_supported(N, tile_size, tile_width, tile_height)) return LFS_E_UNSUPPORTED;
-    if (guard->capacity > 0x7FFFFFFFll) return LFS_E_UNSUPPORTED;
-    IsectWs w = isect_ws(workspace, 1, N, tile_width, tile_height);
-    if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
-    int rc = enable_big_lds();
-    if (rc) return rc;
-    const uint32_t T = tile_width * tile_height, R = tile_height;
-    const uint32_t idx_bits = bit_width_u32(N - 1) ? bit_width_u32(N - 1) : 1u;
-    EntryFmt fmt; fmt.pshift = 4; fmt.xshift = idx_bits + 4; fmt.dshift = fmt.xshift + bit_width_u32(tile_width - 1) > 32 ? 33u : 32u;
-    const uint32_t cull_on = (lfs_get_debug_flags() & 1u) ? 0u : 1u;
-    const CullRec* cull = static_cast<const CullRec*>(cull_recs);
-    const CamDev* cams = static_cast<const CamDev*>(cams_dev);
-    {
-        lfs::ProfScope prof("isect_count_scan", s);
-        const uint32_t pb = isect_per_block(N);
-        const dim3 grid((N + pb - 1) / pb);
-        const bool lds_hist = size_t(T) * 4 <= LDS_HIST_LIMIT;
-#define LFS_COUNT_MASKED(WPS, LH)                                                                                                                         \
-    hipLaunchKernelGGL((isect_count_masked_kernel<WPS, LH>), grid, dim3(1024), (LH) ? size_t(T) * 4 : 0, s, N, pb, means2d, radii, cull, cams, float(tile_size), \
-                       tile_width, tile_height, cull_on, w.totals, w.nref)
-        if (tile_size == 16) { if (lds_hist) LFS_COUNT_MASKED(2, true); else LFS_COUNT_MASKED(2, false); }
-        else { if (lds_hist) LFS_COUNT_MASKED(1, true); else LFS_COUNT_MASKED(1, false); }
-#undef LFS_COUNT_MASKED
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, counts, true, w.cursor, w.row_cursor, R, (int32_t*)nullptr,
-                           counts + 1, counts + 2, stamp, guard->capacity, sort_class_limit(guard->assumed_longest), guard->abort_flag, w.nref, NREF_SLOTS, counts + 3);
-    }
-    {
-        lfs::ProfScope prof("isect_scatter", s);
-        const dim3 rgrid(uint32_t((size_t(N) + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-        if (tile_size == 16)
-            hipLaunchKernelGGL((isect_rows_kernel<true, 2>), rgrid, dim3(1024), ROWS_STAGE * 8, s, 1u, N, means2d, radii, depths, float(tile_size), tile_width, tile_height, fmt,
-                               w.offsets, w.row_cursor, reinterpret_cast<uint64_t*>(scratch), guard->abort_flag, cull, cams, cull_on);
-        else
-            hipLaunchKernelGGL((isect_rows_kernel<true, 1>), rgrid, dim3(1024), ROWS_STAGE * 8, s, 1u, N, means2d, radii, depths, float(tile_size), tile_width, tile_height, fmt,
-                               w.offsets, w.row_cursor, reinterpret_cast<uint64_t*>(scratch), guard->abort_flag, cull, cams, cull_on);
-        hipLaunchKernelGGL(isect_tiles_kernel, dim3(uint32_t((guard->capacity + TILES_CHUNK - 1) / TILES_CHUNK)), dim3(1024), TILES_CHUNK * 8, s, R, tile_width, fmt,
-                           int64_t(-1), w.offsets, w.cursor, reinterpret_cast<const uint64_t*>(scratch), bucket);
-    }
-    lfs::ProfScope prof_sort("isect_tile_sort", s);
-    int64_t longest = int64_t(sort_class_limit(guard->assumed_longest));
-    if (longest == int64_t(0xFFFFFFFFu)) longest = INT64_MAX;
-    launch_tile_sorts(T, T, bit_width_u32(T), longest, w.offsets, bucket, payload_out, fmt.dshift, 1u, s);
-    return (int)hipGetLastError();
 }
 
 int lfs::isect_emit_impl(
@@ -806,7 +538,23 @@ int lfs::isect_emit_impl(
     const uint32_t tile_n_bits = bit_width_u32(tile_width * tile_height);
     const size_t total = size_t(C) * N;
     if (sort) {
-        { const int lrc = enable_big_lds(); if (lrc) return lrc; }
+        static bool big_lds_enabled = false; // > 64 KiB of dynamic LDS has to be opted into once per process
+        if (!big_lds_enabled) {
+            hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_lds_kernel<1024>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            if (ae != hipSuccess) return (int)ae;
+            ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_bins_kernel<256>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4096 * 8);
+            if (ae != hipSuccess) return (int)ae;
+            ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_bins_kernel<1024, 1024, false, 64>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            if (ae != hipSuccess) return (int)ae;
+            ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&isect_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_STAGE * 8);
+            if (ae != hipSuccess) return (int)ae;
+            ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&isect_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TILES_CHUNK * 8);
+            if (ae != hipSuccess) return (int)ae;
+            big_lds_enabled = true;
+        }
         const uint32_t pb = isect_per_block(total);
         const uint32_t blocks = uint32_t((total + pb - 1) / pb);
         int tok = lfs::prof_begin("isect_scatter", s);
@@ -815,11 +563,10 @@ int lfs::isect_emit_impl(
         const bool two_pass = scratch != nullptr && R <= ROWS_MAX && total <= 0xFFFFFFFFull && idx_bits + bit_width_u32(tile_width - 1) <= 32 &&
                               !(lfs_get_debug_flags() & 32u);
         if (two_pass) {
-            const EntryFmt fmt{32u, idx_bits, 0u};
-            hipLaunchKernelGGL((isect_rows_kernel<false, 2>), dim3(uint32_t((total + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(1024), ROWS_STAGE * 8, s, C, N, means2d, radii,
-                               depths, float(tile_size), tile_width, tile_height, fmt, w.offsets, w.row_cursor, reinterpret_cast<uint64_t*>(scratch),
+            hipLaunchKernelGGL(isect_rows_kernel, dim3(uint32_t((total + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(1024), ROWS_STAGE * 8, s, C, N, means2d, radii,
+                               depths, float(tile_size), tile_width, tile_height, idx_bits, w.offsets, w.row_cursor, reinterpret_cast<uint64_t*>(scratch),
                                guarded ? guard->abort_flag : nullptr);
-            hipLaunchKernelGGL(isect_tiles_kernel, dim3(uint32_t((n_grid + TILES_CHUNK - 1) / TILES_CHUNK)), dim3(1024), TILES_CHUNK * 8, s, R, tile_width, fmt,
+            hipLaunchKernelGGL(isect_tiles_kernel, dim3(uint32_t((n_grid + TILES_CHUNK - 1) / TILES_CHUNK)), dim3(1024), TILES_CHUNK * 8, s, R, tile_width, idx_bits,
                                n_arg, w.offsets, w.cursor, reinterpret_cast<const uint64_t*>(scratch), isect_ids);
         } else if (guarded) { lfs::prof_end(tok, s); return LFS_E_UNSUPPORTED; } // (the one-pass scatter does not watch the abort flag)
         else if (size_t(T) * 8 <= LDS_HIST_LIMIT)
@@ -831,8 +578,20 @@ int lfs::isect_emit_impl(
         lfs::prof_end(tok, s);
         lfs::ProfScope prof_sort("isect_tile_sort", s);
         const uint32_t n_tiles_ = tile_width * tile_height;
-        // (max_tile_isects >= 0: the longest tile list, from lfs_intersect_tile_count_ex)
-        launch_tile_sorts(T, n_tiles_, tile_n_bits, max_tile_isects >= 0 ? max_tile_isects : INT64_MAX, w.offsets, isect_ids, flatten_ids, 32u, 0u, s);
+        // size classes (LDS sized to the class so that small tiles do not cap the occupancy): <= 1024 entries with the counting kernel on 256 bins
+        // (256 threads, keys staged in LDS), <= 4096 on 512 bins with 512 threads and only the binned copy in LDS (32 KiB; measured against the staged
+        // 256-thread form: 0.277 -> 0.127 ms per view at 12 M intersections, 0.058 -> 0.042 at 4.4 M; 1024 threads or the same change for the first class:
+        // no further gain), <= 16384 on 1024 bins (1024 threads, 128 KiB LDS; a bin of more than 64 keys falls back to the bitonic network inside the
+        // kernel), larger -> bitonic on global memory
+        // (max_tile_isects >= 0: the longest tile list, from lfs_intersect_tile_count_ex - classes no tile falls into are not launched: ~9 us each at T = 8160)
+        const int64_t longest = max_tile_isects >= 0 ? max_tile_isects : INT64_MAX;
+        hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 1024 * 8, s, 1u, 1024u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
+        if (longest > 1024)
+            hipLaunchKernelGGL((tile_sort_bins_kernel<512, 512, false, 32>), dim3(T), dim3(512), 4096 * 8, s, 1025u, 4096u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
+        if (longest > 4096)
+            hipLaunchKernelGGL((tile_sort_bins_kernel<1024, 1024, false, 64>), dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
+        if (longest > 16384)
+            hipLaunchKernelGGL(tile_sort_global_kernel, dim3(T), dim3(1024), 0, s, 16385u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
     } else {
         if (!tiles_per_gauss) return LFS_E_INVALID;
         const uint32_t nb = uint32_t((total + SCAN_ITEMS - 1) / SCAN_ITEMS);

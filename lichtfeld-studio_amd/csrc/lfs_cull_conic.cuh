@@ -95,57 +95,4 @@ LFS_CONIC_FN bool conic_culled(const ConicRec& k, const float u0, const float u1
     return !centre_in && best <= -tol; // (a NaN - inf - inf for rays within 1e-19 rad of the camera plane - compares false: not culled)
 }
 
-// The same question for a whole STRIP of rays v in [v0, v1] at once (round 4: the training step's masked tile lists, intersect.hip): the interval [lo, hi] of
-// du = u - px for which SOME ray of the strip can composite the Gaussian; false when there is none. {f' >= 0} is convex, so its intersection with the strip is,
-// and the projection of that onto u is an interval: a cell [u0, u1] x [v0, v1] can be culled exactly when [u0 - px, u1 - px] misses it. For a fixed du the
-// maximum over dv is attained at the vertex dv = b du + e when it lies in the strip, else on the nearer edge, so the set is the hull of three pieces:
-//   f'(du, V0) >= 0,   f'(du, V1) >= 0,   and   max_dv f' = (a + b^2) du^2 + 2 (d + b e) du + (g + e^2) >= 0  where V0 <= b du + e <= V1
-// - three concave quadratics, one square root each, instead of four clamped edge evaluations PER CELL: a Gaussian costs (cell rows of its rectangle) x ~45
-// operations rather than (cells) x ~45. Same tolerance as conic_culled - 8e-6 (|a| + 2 |b| + 1) (du^2 + dv^2) of slack on f' - folded into the coefficients: the
-// du^2 part goes to the leading coefficient (which has to stay negative: otherwise the whole line), the dv^2 part, at the strip's larger |dv|, to the constant.
-// "never cull" records give the whole line, anything not finite gives the whole line as well (never culls).
-LFS_CONIC_FN bool conic_strip_interval(const ConicRec& k, const float v0, const float v1, float& lo, float& hi) {
-    lo = -INFINITY; hi = INFINITY;
-    const float tau = 8e-6f * (fabsf(k.a) + 2.f * fabsf(k.b) + 1.f);
-    const float Am = k.a + k.b * k.b + tau, Aq = k.a + tau;
-    if (!(k.g < INFINITY) || !(Aq < 0.f) || !(Am < 0.f)) return true;
-    const float V0 = v0 - k.py, V1 = v1 - k.py;
-    const float tol = tau * fmaxf(V0 * V0, V1 * V1);
-    float l = INFINITY, h = -INFINITY;
-    bool bad = false;
-    // A x^2 + 2 B x + C >= -tol for x in [xlo, xhi], A < 0
-#define LFS_STRIP_PIECE(A, B, C, xlo, xhi)                                  \
-    do {                                                                    \
-        const float A_ = (A), B_ = (B), C_ = (C);                           \
-        const float disc = B_ * B_ - A_ * (C_ + tol);                       \
-        if (!(disc - disc == 0.f)) bad = true;                              \
-        else if (disc >= 0.f) {                                             \
-            const float s_ = sqrtf(disc), i_ = 1.f / A_;                    \
-            const float r0 = fmaxf((-B_ + s_) * i_, (xlo));                 \
-            const float r1 = fminf((-B_ - s_) * i_, (xhi));                 \
-            if (!(r0 - r0 == 0.f) && !(r0 == -INFINITY)) bad = true;        \
-            if (!(r1 - r1 == 0.f) && !(r1 == INFINITY)) bad = true;         \
-            if (r0 <= r1) { l = fminf(l, r0); h = fmaxf(h, r1); }           \
-        }                                                                   \
-    } while (0)
-    LFS_STRIP_PIECE(Aq, k.b * V0 + k.d, (2.f * k.e - V0) * V0 + k.g, -INFINITY, INFINITY);
-    LFS_STRIP_PIECE(Aq, k.b * V1 + k.d, (2.f * k.e - V1) * V1 + k.g, -INFINITY, INFINITY);
-    {   // the vertex piece, where V0 <= b du + e <= V1 (widened by the rounding of the two quotients)
-        float xlo = -INFINITY, xhi = INFINITY;
-        bool any = true;
-        if (k.b != 0.f) {
-            const float ib = 1.f / k.b, q0 = (V0 - k.e) * ib, q1 = (V1 - k.e) * ib;
-            xlo = fminf(q0, q1); xhi = fmaxf(q0, q1);
-            const float m = 4e-6f * (fabsf(xlo) + fabsf(xhi)) + 1e-30f;
-            xlo -= m; xhi += m;
-            if (!(xlo - xlo == 0.f) || !(xhi - xhi == 0.f)) { xlo = -INFINITY; xhi = INFINITY; }
-        } else any = V0 <= k.e && k.e <= V1;
-        if (any) LFS_STRIP_PIECE(Am, k.d + k.b * k.e, k.g + k.e * k.e, xlo, xhi);
-    }
-#undef LFS_STRIP_PIECE
-    if (bad) return true; // (lo, hi) = the whole line
-    lo = l; hi = h;
-    return l <= h;
-}
-
 } // namespace lfs

@@ -8,7 +8,7 @@
 
 namespace lfs {
 
-struct IsectGuard { int64_t capacity; int64_t assumed_longest; int32_t* abort_flag; int64_t* n_ref_out = nullptr; }; // n_ref_out: receives the reference's n_isects (counts[3] of a step)
+struct IsectGuard { int64_t capacity; int64_t assumed_longest; int32_t* abort_flag; };
 
 // the longest tile list the sort classes launched for `assumed_longest` can order (intersect.hip: <= 1024, <= 4096, <= 16384, global)
 inline uint32_t sort_class_limit(int64_t assumed_longest) {
@@ -32,8 +32,10 @@ const int32_t* isect_workspace_offsets(void* workspace, uint32_t C, uint32_t N, 
 int raster_fwd_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
                        const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
                        int64_t capacity, float* render_colors, float* render_alphas, int32_t* last_ids, void* workspace, size_t workspace_bytes, hipStream_t s,
-                       bool cams_ready = false, bool masked_lists = false); // masked_lists: records are in the workspace, flatten_ids = the masked lists' payload words
+                       bool cams_ready = false, bool records_ready = false); // records_ready: the projection kernel wrote the records + culling records (no raster_pack launch)
 void raster_workspace_parts(void* workspace, uint32_t N, void** cams_dev, void** recs, void** cull);
+int sh_model_fwd_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+                      const int32_t* radii /* NULL: every Gaussian */, float* colors, hipStream_t s);
 int raster_bwd_mse_acc_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
                                const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
                                int64_t capacity, const float* render_colors, const float* render_alphas, const int32_t* last_ids, const float* target_chw,
@@ -49,9 +51,7 @@ int gut_finish_adam_impl(uint32_t N, float* means, float* raw_scales, float* raw
 int sh_model_bwd_adam_all_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, float* sh0, float* shN,
                                const int32_t* radii, const float* colors, const float* acc_rows, float* v_dirs, float* sh0_exp_avg, float* sh0_exp_avg_sq,
                                const float* sh0_scalars, float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, hipStream_t s,
-                               const int32_t* abort_flag, uint32_t colors_stride = 0); // colors_stride (0 = 3): the step keeps the colours inside the rasterizer's records (16)
-int sh_model_fwd_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
-                      const int32_t* radii, float* colors, uint32_t colors_stride, hipStream_t s);
+                               const int32_t* abort_flag);
 
 // lfs_activations_project_ut with two riders for the training step (both save a launch of a few microseconds each): `zero_words` [zero_n] is cleared (the
 // intersection stage's per-tile totals - the count kernel then runs with LFS_ISECT_COUNTERS_ZERO, no memset), and the device-side camera state the rasterizer
@@ -60,17 +60,10 @@ int activations_project_ut_impl(uint32_t N, const float* means, const float* raw
                                 float eps2d, float near_plane, float far_plane, float radius_clip, const lfs_ut_params* ut_params, float* quats, float* scales,
                                 float* opacities, int32_t* radii, float* means2d, float* depths, uint32_t* zero_words, uint32_t zero_n, void* cams_out, hipStream_t s,
                                 void* recs_out = nullptr, void* cull_out = nullptr, const float* pack_colors = nullptr); // (given: the rasterizer's records - with these colours [N,3] - and culling records from the same pass, lfs_raster_pack.cuh)
-uint32_t* isect_workspace_totals(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height, uint32_t* n_words = nullptr);
-// masked lists of the training step (intersect.hip: isect_count_masked_kernel): tiles a Gaussian's alpha >= 1/255 ellipse cannot reach are not listed, the others carry
-// a 4-bit cell mask; payload_out = the sorted (Gaussian index << 4 | mask) words per tile. counts [4]: listed, longest list, stamp, the reference's n_isects.
-bool isect_masked_supported(uint32_t N, uint32_t tile_size, uint32_t tile_width, uint32_t tile_height);
-int isect_masked_lists_impl(uint32_t N, const float* means2d, const int32_t* radii, const float* depths, const void* cull_recs, const void* cams_dev, uint32_t tile_size,
-                            uint32_t tile_width, uint32_t tile_height, int64_t* bucket, int32_t* payload_out, int64_t* scratch, int64_t* counts, int64_t stamp,
-                            void* workspace, size_t workspace_bytes, hipStream_t s, const IsectGuard* guard);
+uint32_t* isect_workspace_totals(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height);
 int sh_model_bwd_rows_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
                            const int32_t* radii, const float* colors, const float* acc_rows, int accumulate, float* v_sh0, float* v_shN, float* v_dirs, hipStream_t s,
-                           float* shN_exp_avg = nullptr, float* shN_exp_avg_sq = nullptr, const float* shN_scalars = nullptr, // given: shN's Adam step inline, v_shN unused
-                           uint32_t colors_stride = 0);
+                           float* shN_exp_avg = nullptr, float* shN_exp_avg_sq = nullptr, const float* shN_scalars = nullptr); // given: shN's Adam step inline, v_shN unused
 // lfs_gut_finish_grads with dL/d(dirs) [N,3] (nullable) added to the means gradient and no dL/dcolour output (the SH backward has run already)
 int gut_finish_grads_impl(uint32_t N, const float* means, const float* raw_quats, const float* quats, const float* scales, const float* opacities, float scale_reg,
                           float opacity_reg, int accumulate, float* g_means, float* g_raw_scales, float* g_raw_quats, float* g_raw_opacities, float* v_colors,

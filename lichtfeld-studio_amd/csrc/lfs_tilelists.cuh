@@ -17,10 +17,7 @@ static __global__ void __launch_bounds__(1024) tile_scan_kernel(
     const uint32_t T, uint32_t* __restrict__ totals, int32_t* __restrict__ offsets, int64_t* __restrict__ n_isects,
     const bool zero_totals = false, uint32_t* __restrict__ cursor = nullptr, uint32_t* __restrict__ aux = nullptr, const uint32_t n_aux = 0,
     int32_t* __restrict__ offsets_out = nullptr, int64_t* __restrict__ max_total = nullptr, int64_t* __restrict__ stamp_out = nullptr, const int64_t stamp = 0,
-    const int64_t capacity = -1, const uint32_t max_list = 0xFFFFFFFFu, int32_t* __restrict__ abort_flag = nullptr,
-    unsigned long long* __restrict__ n_ref_slots = nullptr, const uint32_t n_ref_n = 0, int64_t* __restrict__ n_ref_out = nullptr) {
-    // n_ref_slots (masked lists, intersect.hip): partial sums of the REFERENCE's intersection count (rectangle areas); their total goes to *n_ref_out next to
-    // the counts of the lists actually built, and the slots are left zero for the next call
+    const int64_t capacity = -1, const uint32_t max_list = 0xFFFFFFFFu, int32_t* __restrict__ abort_flag = nullptr) {
     // capacity >= 0 (the speculative training step, csrc/gut_step.hip): the caller sized its list buffers for `capacity` intersections and launched the
     // per-tile sort classes up to `max_list` entries BEFORE these counts existed. When either assumption fails, *abort_flag = 1, every offset is
     // rewritten to 0 (all lists empty: nothing downstream indexes past its buffers) and the true counts are still reported - the host sees them after
@@ -81,11 +78,6 @@ static __global__ void __launch_bounds__(1024) tile_scan_kernel(
         for (uint32_t i = threadIdx.x; i < T; i += 1024) { offsets[i] = 0; if (offsets_out != nullptr) offsets_out[i] = 0; }
     }
     if (threadIdx.x == 0) {
-        if (n_ref_slots != nullptr) {
-            unsigned long long r = 0;
-            for (uint32_t i = 0; i < n_ref_n; ++i) { r += n_ref_slots[i]; n_ref_slots[i] = 0ull; }
-            if (n_ref_out != nullptr) *n_ref_out = int64_t(r);
-        } else if (n_ref_out != nullptr) *n_ref_out = int64_t(carry); // the reference's lists: what is listed IS the reference's count
         offsets[T] = over ? 0 : int32_t(carry); *n_isects = int64_t(carry);
         if (abort_flag != nullptr) *abort_flag = over ? 1 : 0;
         if (max_total != nullptr) *max_total = int64_t(longest);
@@ -139,9 +131,7 @@ LFS_DI void bitonic_sort_lds(uint64_t* __restrict__ keys, const uint32_t n_pad) 
 template <int THREADS, int NBINS = 256, bool COPY = true, uint32_t BIN_LIMIT = 32>
 __global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
     const uint32_t n_min, const uint32_t n_max, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets,
-    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, const uint32_t dshift = 32, const uint32_t payload_only = 0) {
-    // dshift: the keys are (depth bits << dshift | payload); payload_only (the training step's masked lists, intersect.hip): the sorted PAYLOADS go to
-    // flatten_ids (Gaussian index << 4 | cell mask) and the reference's (camera | tile | depth) keys are not written - nobody reads them there
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
     LFS_DYN_LDS(uint64_t, lds64);
     __shared__ uint32_t s_hist[NBINS], s_off[NBINS + 1], s_minmax[2], s_big;
     static_assert(NBINS % 64 == 0, "one wave scans the bin counts");
@@ -162,7 +152,7 @@ __global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
     for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
         const uint64_t k = uint64_t(isect_ids[start + i]);
         if (COPY) A[i] = k;
-        const uint32_t d = uint32_t(k >> dshift);
+        const uint32_t d = uint32_t(k >> 32);
         lo = min(lo, d); hi = max(hi, d);
     }
 #pragma unroll
@@ -171,12 +161,7 @@ __global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
     __syncthreads();
     const uint32_t dmin = s_minmax[0];
     const float scale = float(NBINS) / (float(s_minmax[1] - dmin) + 1.f); // monotone map of the unsigned depth bits onto [0, NBINS)
-    auto bin_of = [&](uint64_t k) { return min(uint32_t(NBINS - 1), uint32_t(float(uint32_t(k >> dshift) - dmin) * scale)); };
-    const uint64_t pay_mask = (uint64_t(1) << dshift) - 1;
-    auto emit = [&](uint32_t pos, uint64_t k) {
-        if (payload_only) flatten_ids[start + pos] = int32_t(uint32_t(k & pay_mask));
-        else { isect_ids[start + pos] = int64_t(hi_bits | (k >> 32)); flatten_ids[start + pos] = int32_t(uint32_t(k)); }
-    };
+    auto bin_of = [&](uint64_t k) { return min(uint32_t(NBINS - 1), uint32_t(float(uint32_t(k >> 32) - dmin) * scale)); };
     for (uint32_t i = threadIdx.x; i < n; i += THREADS) atomicAdd(&s_hist[bin_of(key_at(i))], 1u);
     __syncthreads();
     if (threadIdx.x < 64) { // exclusive scan of the NBINS counts by one wave (PER per lane)
@@ -203,7 +188,11 @@ __global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
     __syncthreads();
     if (s_big) {
         bitonic_sort_lds<THREADS>(B, n_pad);
-        for (uint32_t i = threadIdx.x; i < n; i += THREADS) emit(i, B[i]);
+        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+            const uint64_t k = B[i];
+            isect_ids[start + i] = int64_t(hi_bits | (k >> 32));
+            flatten_ids[start + i] = int32_t(uint32_t(k));
+        }
         return;
     }
     // rank inside the bin = number of smaller keys in it (keys are unique: a flatten id occurs once per tile); every key
@@ -214,7 +203,8 @@ __global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
         const uint32_t o = s_off[b], m = s_off[b + 1] - o;
         uint32_t rank = 0;
         for (uint32_t j = 0; j < m; ++j) rank += B[o + j] < k ? 1u : 0u;
-        emit(o + rank, k);
+        isect_ids[start + o + rank] = int64_t(hi_bits | (k >> 32));
+        flatten_ids[start + o + rank] = int32_t(uint32_t(k));
     }
 }
 
@@ -247,8 +237,7 @@ __global__ void __launch_bounds__(THREADS) tile_sort_lds_kernel(
 
 // buckets too large for LDS: same network directly on the combined keys in global memory, then the same conversion
 static __global__ void __launch_bounds__(1024) tile_sort_global_kernel(
-    const uint32_t n_min, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets, int64_t* isect_ids, int32_t* flatten_ids,
-    const uint32_t dshift = 32, const uint32_t payload_only = 0) {
+    const uint32_t n_min, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets, int64_t* isect_ids, int32_t* flatten_ids) {
     const uint32_t t = blockIdx.x;
     const uint32_t start = uint32_t(offsets[t]);
     const uint32_t n = uint32_t(offsets[t + 1]) - start;
@@ -275,11 +264,10 @@ static __global__ void __launch_bounds__(1024) tile_sort_global_kernel(
         }
     }
     const uint64_t hi_bits = ((uint64_t(t / n_tiles) << tile_n_bits) | uint64_t(t % n_tiles)) << 32;
-    const uint64_t pay_mask = (uint64_t(1) << dshift) - 1;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         const uint64_t k = K[i];
-        if (payload_only) flatten_ids[start + i] = int32_t(uint32_t(k & pay_mask));
-        else { flatten_ids[start + i] = int32_t(uint32_t(k)); K[i] = hi_bits | (k >> 32); }
+        flatten_ids[start + i] = int32_t(uint32_t(k));
+        K[i] = hi_bits | (k >> 32);
     }
 }
 

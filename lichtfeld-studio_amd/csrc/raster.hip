@@ -230,31 +230,6 @@ __global__ void __launch_bounds__(256) raster_cull_kernel(
     if (lane == 0) cell_count[cell] = count;
 }
 
-// The training step's masked lists (intersect.hip, isect_count_masked_kernel): the per-tile sort leaves (Gaussian index << 4 | cell mask) words in list order; a
-// cell's list is the compaction of the entries whose mask has the cell's bit. No record is gathered (raster_cull_kernel fetched a 32-byte culling record per
-// entry and evaluated the conic per cell: that test ran once per (Gaussian, tile) where the record was read coalesced). Same output as raster_cull_kernel:
-// cell_count + (Gaussian, list position) pairs in list order.
-template <int WPT>
-__global__ void __launch_bounds__(64 * WPT) cells_from_masks_kernel(const int32_t* __restrict__ offsets, const int32_t* __restrict__ payload,
-                                                                     int32_t* __restrict__ cell_count, int2* __restrict__ cell_list) {
-    const uint32_t t = blockIdx.x, c = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int32_t start = offsets[t], end = offsets[t + 1];
-    int2* __restrict__ out = cell_list + (size_t(WPT) * size_t(start) + size_t(c) * size_t(end - start));
-    int32_t count = 0;
-    for (int32_t base = start; base < end; base += 64) {
-        const int32_t i = base + int32_t(lane);
-        const uint32_t pl = i < end ? uint32_t(payload[i]) : 0u;
-        const bool hit = i < end && ((pl >> c) & 1u);
-        const uint64_t m = __ballot(hit);
-        if (hit) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            out[count + int32_t(rank)] = make_int2(int32_t(pl >> 4), i);
-        }
-        count += __popcll(m);
-    }
-    if (lane == 0) cell_count[size_t(t) * WPT + c] = count;
-}
-
 // Ray modes (template parameter of fwd / bwd):
 //   0 rolling shutter : world-space ray (ro, rd) per pixel, record = {M, mu}
 //   1 global shutter  : camera-space direction d (any camera model), record = {M Rinv, M (o - mu)}
@@ -976,12 +951,12 @@ struct IsectCount { int64_t n_isects, capacity; int32_t arg() const { return n_i
 static void raster_prepare(const RasterWs& w, const RasterGeom& g, uint32_t N, uint32_t channels, const float* means, const float* quats,
                            const float* scales, const float* colors, const float* opacities, const uint8_t* masks,
                            const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
-                           const IsectCount ic, hipStream_t s, bool cams_ready = false) {
+                           const IsectCount ic, hipStream_t s, bool cams_ready = false, bool records_ready = false) {
     const uint32_t C = cams->C;
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
     if (!cams_ready) hipLaunchKernelGGL(cam_prep_kernel, dim3(1), dim3(64), 0, s, *cams, w.cams); // (training step: written by the projection kernel already)
     const size_t CN = size_t(C) * N;
-    if (CN > 0) {
+    if (CN > 0 && !records_ready) { // (training step, round 4: records + culling records written by the projection kernel - projection_ut.hip, PACK)
         lfs::ProfScope prof_pack("raster_pack", s);
         const dim3 pg(uint32_t((CN + 255) / 256));
         if (uniform) hipLaunchKernelGGL(raster_pack_kernel<true>, pg, dim3(256), 0, s, C, N, channels, means, quats, scales, colors, opacities, w.cams, w.recs, w.cull);
@@ -1003,9 +978,7 @@ static int raster_fwd_impl(
     const lfs_cameras* cams, uint32_t tile_size,
     const int32_t* tile_offsets, const int32_t* flatten_ids, const IsectCount ic,
     float* render_colors, float* render_alphas, int32_t* last_ids,
-    void* workspace, size_t workspace_bytes, hipStream_t s, bool cams_ready = false, bool masked_lists = false) {
-    // masked_lists (the training step, round 4): camera state and records are in the workspace already (the projection kernel wrote them, the SH colour kernel
-    // filled in the colours) and `flatten_ids` holds the sorted (Gaussian index << 4 | cell mask) words of intersect.hip's masked lists: no pack, no cull
+    void* workspace, size_t workspace_bytes, hipStream_t s, bool cams_ready = false, bool records_ready = false) {
     RasterGeom g;
     int rc = raster_check(N, channels, cams, tile_size, g);
     if (rc) return rc;
@@ -1018,14 +991,7 @@ static int raster_fwd_impl(
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     if (N > 0 && (!means || !quats || !scales || !colors || !opacities)) return LFS_E_INVALID;
     if (n_sized > 0 && !flatten_ids) return LFS_E_INVALID;
-    if (masked_lists) {
-        if (g.wpt != 4 && g.wpt != 1) return LFS_E_UNSUPPORTED;
-        lfs::ProfScope prof_cells("raster_cull", s);
-        const uint32_t T = C * g.tw * g.th;
-        if (g.wpt == 4) hipLaunchKernelGGL(cells_from_masks_kernel<4>, dim3(T), dim3(256), 0, s, tile_offsets, flatten_ids, w.cell_count, w.cell_list);
-        else hipLaunchKernelGGL(cells_from_masks_kernel<1>, dim3(T), dim3(64), 0, s, tile_offsets, flatten_ids, w.cell_count, w.cell_list);
-    } else
-        raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s, cams_ready);
+    raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s, cams_ready, records_ready);
     lfs::ProfScope prof("raster_fwd", s);
     const RasterGeom gw = wave_geom(cams, g);
 #define LFS_FWD(CD, MODE)                                                                                        \
@@ -1059,13 +1025,13 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
 int lfs::raster_fwd_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
                             const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
                             int64_t capacity, float* render_colors, float* render_alphas, int32_t* last_ids, void* workspace, size_t workspace_bytes, hipStream_t s,
-                            bool cams_ready, bool masked_lists) {
+                            bool cams_ready, bool records_ready) {
     if (capacity < 0) return LFS_E_INVALID;
     return raster_fwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, IsectCount{-1, capacity},
-                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, s, cams_ready, masked_lists);
+                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, s, cams_ready, records_ready);
 }
 
-// where the records / culling records / camera state of a (one-camera) rasterizer workspace live: the training step's projection kernel writes them there
+// where the camera state / records / culling records of a (one-camera) rasterizer workspace live: the training step's projection kernel writes them there
 void lfs::raster_workspace_parts(void* workspace, uint32_t N, void** cams_dev, void** recs, void** cull) {
     const RasterWs w = raster_ws(workspace, 1, N, 0, 0);
     if (cams_dev) *cams_dev = w.cams;

@@ -592,16 +592,16 @@ extern "C" int lfs_spherical_harmonics_bwd(
     return lfs::sh_launch_bwd<false, false>(a, v_colors, v_coeffs, nullptr, nullptr, v_dirs, (hipStream_t)stream);
 }
 
-// colors_stride (0 = 3): element stride of the colour rows - the training step writes the colours straight into the rasterizer's 64-byte records (16)
+// radii == NULL (the training step: the colours are evaluated BEFORE the projection, which writes them into the rasterizer's records): every Gaussian
 int lfs::sh_model_fwd_impl(
     uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
-    const int32_t* radii, float* colors, uint32_t colors_stride, hipStream_t stream) {
+    const int32_t* radii, float* colors, hipStream_t stream) {
     const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
     if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
     if (n == 0) return LFS_OK;
-    if (!means || !viewmat || !sh0 || (K > 1 && !shN) || !colors) return LFS_E_INVALID;   // radii == NULL (internal callers): colours for every Gaussian
+    if (!means || !viewmat || !sh0 || (K > 1 && !shN) || !colors) return LFS_E_INVALID;
     lfs::ShArgs a{};
-    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.cs = colors_stride;
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii;
     return lfs::sh_launch_fwd<true>(a, Kd, colors, stream);
 }
 
@@ -609,7 +609,7 @@ extern "C" int lfs_sh_model_fwd(
     uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
     const int32_t* radii, float* colors, lfs_stream_t stream) {
     if (!radii) return LFS_E_INVALID;
-    return lfs::sh_model_fwd_impl(n, K, degrees_to_use, means, viewmat, sh0, shN, radii, colors, 0, (hipStream_t)stream);
+    return lfs::sh_model_fwd_impl(n, K, degrees_to_use, means, viewmat, sh0, shN, radii, colors, (hipStream_t)stream);
 }
 
 extern "C" int lfs_sh_model_bwd(
@@ -632,7 +632,7 @@ extern "C" int lfs_sh_model_bwd(
 int lfs::sh_model_bwd_rows_impl(
     uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
     const int32_t* radii, const float* colors, const float* acc_rows, int accumulate, float* v_sh0, float* v_shN, float* v_dirs, hipStream_t stream,
-    float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, uint32_t colors_stride) {
+    float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars) {
     const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
     if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
     if (n == 0) return LFS_OK;
@@ -641,7 +641,7 @@ int lfs::sh_model_bwd_rows_impl(
     if (!means || !viewmat || !sh0 || (K > 1 && (!shN || (!v_shN && !inline_adam))) || !radii || !colors || !acc_rows || !v_sh0 || !v_dirs) return LFS_E_INVALID;
     lfs::ShArgs a{};
     a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
-    a.vs = 16; a.dirs_store = true; a.cs = colors_stride;
+    a.vs = 16; a.dirs_store = true;
     if (inline_adam) {
         const float* t = shN_scalars;
         const lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{t[0], t[1], t[2], t[3], t[4], t[5]}};
@@ -673,7 +673,7 @@ int lfs::sh_model_bwd_adam_all_impl(
     uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, float* sh0, float* shN,
     const int32_t* radii, const float* colors, const float* acc_rows, float* v_dirs,
     float* sh0_exp_avg, float* sh0_exp_avg_sq, const float* sh0_scalars /* lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp */,
-    float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, hipStream_t stream, const int32_t* abort_flag, uint32_t colors_stride) {
+    float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, hipStream_t stream, const int32_t* abort_flag) {
     const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
     if (degrees_to_use > 4 || Kd > K || K > 32 || K < 2) return LFS_E_INVALID;
     if (n == 0) return LFS_OK;
@@ -681,7 +681,7 @@ int lfs::sh_model_bwd_adam_all_impl(
         !shN_exp_avg_sq || !shN_scalars) return LFS_E_INVALID;
     lfs::ShArgs a{};
     a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii; a.colors = colors;
-    a.abort_flag = abort_flag; a.cs = colors_stride;
+    a.abort_flag = abort_flag;
     a.vs = 16; a.dirs_store = true; // dL/dcolour: slots 13..15 of the 16-float rows; dL/d(dirs): its own contiguous [n,3] (partial-row writes into the rows cost more than they save)
     lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{shN_scalars[0], shN_scalars[1], shN_scalars[2], shN_scalars[3], shN_scalars[4], shN_scalars[5]}};
     adam.m0 = sh0_exp_avg; adam.v0 = sh0_exp_avg_sq;
@@ -695,7 +695,7 @@ extern "C" int lfs_sh_model_bwd_adam_all(
     float* sh0_exp_avg, float* sh0_exp_avg_sq, const float* sh0_scalars /* lr, beta1, beta2, eps, bc1_rcp, bc2_sqrt_rcp */,
     float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, lfs_stream_t stream) {
     return lfs::sh_model_bwd_adam_all_impl(n, K, degrees_to_use, means, viewmat, sh0, shN, radii, colors, acc_rows, v_dirs, sh0_exp_avg, sh0_exp_avg_sq, sh0_scalars,
-                                           shN_exp_avg, shN_exp_avg_sq, shN_scalars, (hipStream_t)stream, nullptr, 0);
+                                           shN_exp_avg, shN_exp_avg_sq, shN_scalars, (hipStream_t)stream, nullptr);
 }
 
 static bool sh_views_ok(uint32_t n, uint32_t K, uint32_t degree, uint32_t V, uint32_t stride) {

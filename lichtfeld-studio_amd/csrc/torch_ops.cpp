@@ -272,7 +272,7 @@ void GutTrainStep::ensure(uint32_t N, uint32_t W, uint32_t H, const torch::Tenso
         ws_ = at::Tensor();   // release the old block before the larger one is requested
         ws_ = at::empty({(int64_t)lay.bytes}, like.options().dtype(at::kByte));
     }
-    if (!counts_.defined()) counts_ = at::zeros({4}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    if (!counts_.defined()) counts_ = at::zeros({3}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
     N_ = N; W_ = W; H_ = H; cap_built_ = capacity_; flags_ = flags;
     off_render_ = lay.render; off_alpha_ = lay.alpha; off_radii_ = lay.radii; ws_bytes_ = lay.bytes;
 }
@@ -311,7 +311,7 @@ int64_t GutTrainStep::step(torch::Tensor& means, torch::Tensor& sh0, torch::Tens
             if (double(n_isects_) > 0.92 * double(capacity_)) capacity_ = int64_t(double(n_isects_) * 1.25) + 1024;   // stay ahead of a growing scene
             const int64_t limit = assumed_longest_ <= 1024 ? 1024 : assumed_longest_ <= 4096 ? 4096 : assumed_longest_ <= 16384 ? 16384 : (int64_t(1) << 62);
             if (double(longest_) > 0.92 * double(limit)) assumed_longest_ = std::max<int64_t>(assumed_longest_, int64_t(double(longest_) * 1.25));
-            return lfs_gut_step_reference_count(counts);   // (n_isects_ = what the step's lists hold: the capacity bookkeeping; the caller gets the reference's count)
+            return n_isects_;
         }
         ++retries_;
         capacity_ = std::max<int64_t>(capacity_, int64_t(double(n_isects_) * 1.25) + 1024);

@@ -5,7 +5,7 @@ gsplat/Intersect.cpp:75-76: the intersection lists live in a workspace sized for
 looks at the (pinned) counts only after the whole step has been enqueued. An attempt that did not fit (count above capacity, or a tile list longer
 than the sort classes launched) updated nothing - the kernels check a device flag - and is simply run again with a larger workspace.
 
-torch is the allocator here (one uint8 tensor per workspace, one pinned int64[4] for the counts) and owns the stream; nothing else.
+torch is the allocator here (one uint8 tensor per workspace, one pinned int64[3] for the counts) and owns the stream; nothing else.
 """
 from __future__ import annotations
 
@@ -29,7 +29,7 @@ class StepArgs(C.Structure):  # lfs_gut_step_args
 
 class StepLayout(C.Structure):  # lfs_gut_step_layout
     _fields_ = [(k, C.c_size_t) for k in ("bytes", "render", "alpha", "last_ids", "radii", "means2d", "depths", "colors", "quats", "scales", "opacities",
-                                          "tile_offsets", "flatten_ids", "isect_ids", "counts", "abort_flag", "colors_stride")]
+                                          "tile_offsets", "flatten_ids", "isect_ids", "counts", "abort_flag")]
 
 
 class GutStep:
@@ -44,7 +44,7 @@ class GutStep:
         self.ws: Optional[torch.Tensor] = None
         self.layout: Optional[StepLayout] = None
         self.shape = None
-        self.counts = torch.zeros(4, dtype=torch.int64).pin_memory()   # listed intersections, longest tile list, stamp, the reference's n_isects
+        self.counts = torch.zeros(3, dtype=torch.int64).pin_memory()
         self._stamp = 0
         self.n_isects = 0
         self.longest = 0
@@ -114,16 +114,13 @@ class GutStep:
         rc = lib.lfs_gut_step_wait(C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), C.c_double(30.0), C.byref(n), C.byref(lg))
         if rc != 0:
             raise LfsError("gut_step: the intersection counts of this step never arrived in pinned host memory")
-        # n_listed: what the lists of this step hold (the masked lists of round 4 drop the tiles a Gaussian's alpha >= 1/255 ellipse cannot reach) - what capacity
-        # has to cover; n_isects: the reference's count (bounding rectangles of the radii, gsplat/IntersectTile.cu:24-114), reported to the caller
-        self.n_listed, self.longest = int(n.value), int(lg.value)
-        self.n_isects = int(lib.lfs_gut_step_reference_count(C.c_void_p(self.counts.data_ptr())))
+        self.n_isects, self.longest = int(n.value), int(lg.value)
         return bool(lib.lfs_gut_step_fits(n, lg, C.c_int64(self.capacity), C.c_int64(self.assumed_longest)))
 
     def _after_fit(self) -> None:
         # stay ahead of a slowly growing scene: enlarge BEFORE the next step would overflow (a re-run costs a whole step, a reallocation nothing)
-        if self.n_listed > 0.92 * self.capacity or self.longest > 0.92 * self._class_limit():
-            self._grow(self.n_listed, self.longest)
+        if self.n_isects > 0.92 * self.capacity or self.longest > 0.92 * self._class_limit():
+            self._grow(self.n_isects, self.longest)
 
     def _class_limit(self) -> int:
         a = self.assumed_longest
@@ -147,7 +144,7 @@ class GutStep:
                 self._after_fit()
                 return self.n_isects
             self.retries += 1
-            self._grow(self.n_listed, self.longest)
+            self._grow(self.n_isects, self.longest)
         raise LfsError("gut_step: the step did not fit its workspace after 4 attempts")
 
     def view_forward(self, params: Sequence[torch.Tensor], sh_degree: int, W: int, H: int, viewmat, Kmat, bg) -> int:
@@ -163,7 +160,7 @@ class GutStep:
             if self._wait():
                 return self.n_isects
             self.retries += 1
-            self._grow(self.n_listed, self.longest)
+            self._grow(self.n_isects, self.longest)
         raise LfsError("gut_step: the view did not fit its workspace after 4 attempts")
 
     def _backward_call(self, fn_name: str, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, v_render, scale_reg, opacity_reg,

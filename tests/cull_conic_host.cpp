@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     auto logu = [&](double lo, double hi) { return std::exp(std::log(lo) + U(rng) * (std::log(hi) - std::log(lo))); };
     const double fx = 1200.0;
     const double opacs[] = {0.003, 0.0045, 0.01, 0.05, 0.3, 0.9, 0.999};
-    long cells = 0, vis = 0, cullable = 0, culled = 0, false_culls = 0, never = 0, culled_strip = 0, false_culls_strip = 0, whole_line = 0;
+    long cells = 0, vis = 0, cullable = 0, culled = 0, false_culls = 0, never = 0;
     for (long it = 0; it < N; ++it) {
         const int kind = int(it % 8); // 0,6 normal  1,7 needles  2 huge  3 tiny  4 far  5 near
         double z = 0.3 + U(rng) * 19.7;
@@ -89,17 +89,6 @@ int main(int argc, char** argv) {
             const float v0 = (float)((y0 + 0.5) / fx - 0.25 / fx), v1 = (float)((y0 + ny - 0.5) / fx + 0.25 / fx);
             const bool cul = lfs::conic_culled(rec, u0, u1, v0, v1);
             const bool v = visible(pd, Ad, (double)(float)opac, x0, y0, nx, ny, fx);
-            // the strip form (round 4): the cell is culled when its u-range misses the interval of its strip of rays
-            float slo, shi;
-            const bool some = lfs::conic_strip_interval(rec, v0, v1, slo, shi);
-            const bool whole = some && std::isinf(slo) && std::isinf(shi); // degenerate for the strip form (leading coefficient within the tolerance of 0): the kernels fall back to the per-cell test
-            whole_line += whole && !std::isinf(rec.g);
-            const bool cul2 = whole ? cul : (!some || (u1 - rec.px) < slo || (u0 - rec.px) > shi);
-            culled_strip += cul2;
-            if (cul2 && v) {
-                ++false_culls_strip;
-                if (false_culls_strip <= 5) printf("FALSE STRIP CULL kind %d p %.6g %.6g %.6g s %.3g %.3g %.3g opac %.4g cell %ld %ld wide %d\n", kind, p[0], p[1], p[2], s[0], s[1], s[2], opac, ox, oy, wide);
-            }
             ++cells; vis += v; cullable += !v; culled += cul;
             if (cul && v) {
                 ++false_culls;
@@ -107,7 +96,6 @@ int main(int argc, char** argv) {
             }
         }
     }
-    printf("{\"cells\": %ld, \"visible\": %ld, \"cullable\": %ld, \"culled\": %ld, \"false_culls\": %ld, \"never_cull_records\": %ld, \"culled_strip\": %ld, \"false_culls_strip\": %ld, \"strip_whole_line\": %ld}\n",
-           cells, vis, cullable, culled, false_culls, never, culled_strip, false_culls_strip, whole_line);
-    return (false_culls || false_culls_strip) ? 1 : 0;
+    printf("{\"cells\": %ld, \"visible\": %ld, \"cullable\": %ld, \"culled\": %ld, \"false_culls\": %ld, \"never_cull_records\": %ld}\n", cells, vis, cullable, culled, false_culls, never);
+    return false_culls ? 1 : 0;
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r4_front.sh <tag>: the masked tile lists of round 4 against the round-3 front end (LFS_DEBUG_FLAGS=64) on ONE box:
+# tools/r4_front.sh <tag>: the step with the records packed by the projection kernel (round 4) against the round-3 order (LFS_DEBUG_FLAGS=64: separate pack kernel) on ONE box:
 # the step-level parity tests, three alternating bench pairs, one kernel trace of each -> gpurun_out/front_<tag>/
 set -u
 TAG=${1:-a}
@@ -11,20 +11,20 @@ echo "pytest rc $?: $(tail -1 $OUT/pytest.log)" | tee $OUT/summary.txt
 [ "$(grep -c passed $OUT/pytest.log)" = "0" ] && tail -60 $OUT/pytest.log
 B="python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
 for i in 1 2 3; do
-  $B > $OUT/bench_masked_$i.json 2>> $OUT/bench.err
-  LFS_DEBUG_FLAGS=64 $B > $OUT/bench_reference_lists_$i.json 2>> $OUT/bench.err
+  $B > $OUT/bench_packed_$i.json 2>> $OUT/bench.err
+  LFS_DEBUG_FLAGS=64 $B > $OUT/bench_round3_order_$i.json 2>> $OUT/bench.err
   python - <<PY | tee -a $OUT/summary.txt
 import json
-a=json.load(open("$OUT/bench_masked_$i.json")); b=json.load(open("$OUT/bench_reference_lists_$i.json"))
-print("pair $i: masked", a["ms_per_step"], "ms", a["value"], "img/s | reference lists", b["ms_per_step"], "ms", b["value"], "img/s")
+a=json.load(open("$OUT/bench_packed_$i.json")); b=json.load(open("$OUT/bench_round3_order_$i.json"))
+print("pair $i: packed by projection", a["ms_per_step"], "ms", a["value"], "img/s | round-3 order", b["ms_per_step"], "ms", b["value"], "img/s")
 PY
 done
 cd /tmp && export TMPDIR=/tmp
 P="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_masked -o trace -- $P > $OUT/trace_masked.log 2>&1
-LFS_DEBUG_FLAGS=64 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_reference -o trace -- $P > $OUT/trace_reference.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_packed -o trace -- $P > $OUT/trace_packed.log 2>&1
+LFS_DEBUG_FLAGS=64 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_round3 -o trace -- $P > $OUT/trace_round3.log 2>&1
 cd $REPO
-for k in masked reference; do
+for k in packed round3; do
   f=$(find $OUT/trace_$k -name "*kernel_stats.csv" | head -1)
   echo "== $k" >> $OUT/summary.txt; head -22 "$f" | cut -d, -f1-4 | cut -c1-120 >> $OUT/summary.txt
 done
