@@ -77,10 +77,14 @@ def algorithmic_bytes(N: int, V: int, I: int, P: int, T: int, K: int, adam_elems
 
 
 def reference_torch_impl_baseline(threads: int):
-    """The reference's OWN CPU code (tests/torch_impl.cpp, compiled in place into oracle/_ref by oracle/Makefile - no reference source is
-    copied) on the host cores, at the size it is written for (config 1 / SYN-A: 10k Gaussians, 256x256, SH degree 0): EWA projection +
-    SH colours + tile intersection, forward only (torch_impl has no compositing and no unscented transform; its isect loop does one
-    `.item()` per Gaussian and is impractical at 1M). Median of 5. Returns None when the prebuilt library is absent."""
+    """SURVEY.md 8(d) "CPU baseline timing": the reference's OWN CPU code (tests/torch_impl.cpp:38,147,296,324, compiled in place into oracle/_ref by
+    oracle/Makefile - no reference source is copied) on the host cores:
+      * config 1 / SYN-A (10k Gaussians, 256x256, SH degree 0): quat_scale_to_covar_preci + fully_fused_projection + spherical_harmonics + isect_tiles,
+        forward + autograd backward, median of 10;
+      * projection + SH only (forward + backward) at 1 M Gaussians / 1080p / SH degree 3 - the per-element `.item()` loop of isect_tiles
+        (torch_impl.cpp:370-397) makes the intersection impractical there; median of 3 (seconds each).
+    torch_impl has no compositing and no unscented transform: this times what the reference can run on a CPU, it is not the benchmarked path.
+    Returns None when the prebuilt library is absent."""
     import numpy as np
 
     import oracle
@@ -89,21 +93,23 @@ def reference_torch_impl_baseline(threads: int):
         oracle.ref_lib()
     except Exception:
         return None
+    med = lambda x: float(np.sort(x)[len(x) // 2])
     sc = scenes.syn_a()
-    means, quats = sc.means.numpy(), sc.raw_quats.numpy()
-    scales = np.exp(sc.raw_scales.numpy())
-    vm, Kmat = sc.viewmats[0].numpy(), sc.Ks[0].numpy()
-    sh = sc.sh0.numpy()
-    ts = []
-    for _ in range(5):
-        t0 = time.perf_counter()
-        radii, m2, d, _ = oracle.ref_fully_fused_projection(means, quats, scales, vm, Kmat, sc.width, sc.height)
-        oracle.ref_spherical_harmonics(0, means - np.linalg.inv(vm)[:3, 3].astype(np.float32), sh)
-        oracle.ref_isect_tiles(m2[None], radii[None], d[None], 16, sc.width // 16, sc.height // 16, True)
-        ts.append(time.perf_counter() - t0)
-    ms = sorted(ts)[len(ts) // 2] * 1e3
-    return {"value": round(ms, 2), "unit": "ms", "cores": threads, "kind": "reference",
-            "sample": "tests/torch_impl.cpp: fully_fused_projection + spherical_harmonics + isect_tiles, forward, SYN-A (10000 Gaussians, 256x256, SH deg 0), median of 5"}
+    sec, n_isects = oracle.ref_cpu_stage_fwd_bwd(sc.means.numpy(), sc.raw_quats.numpy(), np.exp(sc.raw_scales.numpy()), sc.sh0.numpy(), 0, sc.viewmats[0].numpy(),
+                                                 sc.Ks[0].numpy(), sc.width, sc.height, True, threads, 10)
+    out = {"value": round(med(sec) * 1e3, 2), "unit": "ms", "cores": threads, "kind": "reference",
+           "sample": f"tests/torch_impl.cpp: quat_scale_to_covar_preci + fully_fused_projection + spherical_harmonics + isect_tiles, forward + autograd backward, "
+                     f"SYN-A (10000 Gaussians, 256x256, SH deg 0, {n_isects} intersections), median of 10, libtorch x{threads} threads"}
+    try:
+        sb = scenes.syn_b(n=1_000_000, n_views=1)
+        coeffs = np.concatenate([sb.sh0.numpy(), sb.shN.numpy()], 1)
+        sec1, _ = oracle.ref_cpu_stage_fwd_bwd(sb.means.numpy(), sb.raw_quats.numpy(), np.exp(sb.raw_scales.numpy()), coeffs, 3, sb.viewmats[0].numpy(), sb.Ks[0].numpy(),
+                                               sb.width, sb.height, False, threads, 3)
+        out["projection_sh_1M"] = {"value": round(med(sec1), 3), "unit": "s", "cores": threads,
+                                   "sample": "the same without isect_tiles at 1 000 000 Gaussians, 1920x1080, SH deg 3 (SYN-B view 0), forward + autograd backward, median of 3"}
+    except Exception as e:
+        out["projection_sh_1M"] = {"value": None, "sample": f"failed: {e}"}
+    return out
 
 
 def cpu_baseline(scene, view: int, target, threads: int, hip_step: dict | None = None) -> dict:

@@ -311,6 +311,19 @@ def ref_fully_fused_projection(means, quats, scales, viewmat, K, width, height, 
     return radii, m2, d, c
 
 
+def ref_cpu_stage_fwd_bwd(means, quats, scales, coeffs, degree, viewmat, K, width, height, with_isect, threads, repeats, tile_size=16):
+    """the reference's tests/torch_impl.cpp covariance + EWA projection + SH (+ tile intersection), forward + autograd backward, `repeats`
+    times on `threads` libtorch threads -> (seconds per repeat [repeats], n_isects)"""
+    m, q, s, c = _c(means, np.float32), _c(quats, np.float32), _c(scales, np.float32), _c(coeffs, np.float32)
+    v, K = _c(viewmat, np.float32), _c(K, np.float32)
+    sec = np.zeros(repeats, np.float64)
+    lib_ = ref_lib()
+    lib_.ref_cpu_stage_fwd_bwd.restype = C.c_int64
+    n = lib_.ref_cpu_stage_fwd_bwd(C.c_int64(m.shape[0]), C.c_int(c.shape[1]), C.c_int(degree), _p(m), _p(q), _p(s), _p(c), _p(v), _p(K), C.c_int(width), C.c_int(height),
+                                   C.c_int(tile_size), C.c_int(1 if with_isect else 0), C.c_int(threads), C.c_int(repeats), sec.ctypes.data_as(C.c_void_p))
+    return sec, int(n)
+
+
 # ---- fastgs (EWA) rasterizer (oracle_fastgs.hpp) --------------------------------
 def _fg_args(dt, means, scales_raw, rot_raw, opac_raw, sh0, sh_rest, w2c, cam_pos, active_sh_bases, W, H, fx, fy, cx, cy, near, far):
     cf = C.c_float if dt == np.float32 else C.c_double

@@ -79,3 +79,38 @@ REF_API int64_t ref_cpu_stage_pipeline(int64_t N, int K, int degree, const float
     }
     return n + (colors.numel() > 0 ? 0 : 0);
 }
+
+// SURVEY.md 8(d) "CPU baseline timing": quat_scale_to_covar_preci + fully_fused_projection + spherical_harmonics (+ isect_tiles) of the reference's
+// tests/torch_impl.cpp (:38, :147, :296, :324), FORWARD + AUTOGRAD BACKWARD (the gradient of a fixed linear functional of means2d, depths, conics and colours
+// with respect to means, quats, scales and the SH coefficients), `repeats` times on `threads` libtorch intra-op threads; seconds[r] = wall time of repeat r.
+// Returns the number of intersections (0 without isect). The per-element `.item()` loop of isect_tiles (torch_impl.cpp:370-397) makes it impractical at 1 M.
+#include <chrono>
+REF_API int64_t ref_cpu_stage_fwd_bwd(int64_t N, int K, int degree, const float* means, const float* quats, const float* scales, const float* coeffs,
+                                      const float* viewmat, const float* Kmat, int width, int height, int tile_size, int with_isect, int threads, int repeats,
+                                      double* seconds) {
+    at::set_num_threads(threads);
+    auto req = [](torch::Tensor t) { return t.set_requires_grad(true); };
+    auto m = req(f32(means, {N, 3})), q = req(f32(quats, {N, 4})), s = req(f32(scales, {N, 3})), c = req(f32(coeffs, {N, K, 3}));
+    auto vm = f32(viewmat, {1, 4, 4}), Kt = f32(Kmat, {1, 3, 3});
+    torch::manual_seed(1);
+    auto w2 = torch::randn({1, N, 2}), wd = torch::randn({1, N}), wc = torch::randn({1, N, 3}), wcol = torch::randn({N, 3});
+    int64_t n = 0;
+    for (int r = 0; r < repeats; ++r) {
+        for (auto* t : {&m, &q, &s, &c}) if (t->grad().defined()) t->mutable_grad().reset();
+        const auto t0 = std::chrono::steady_clock::now();
+        auto [covars, precis] = reference::quat_scale_to_covar_preci(q, s, true, false, false);
+        auto [radii, means2d, depths, conics, comp] = reference::fully_fused_projection(m, covars, vm, Kt, width, height);
+        auto campos = torch::inverse(vm).index({torch::indexing::Slice(), torch::indexing::Slice(0, 3), 3});
+        auto colors = reference::spherical_harmonics(degree, m - campos, c);
+        if (with_isect) {
+            torch::NoGradGuard ng;
+            int tw = (width + tile_size - 1) / tile_size, th = (height + tile_size - 1) / tile_size;
+            auto [tpg, ids, flat] = reference::isect_tiles(means2d.detach(), radii.to(torch::kInt32), depths.detach(), tile_size, tw, th, true);
+            n = ids.numel();
+        }
+        auto loss = (means2d * w2).sum() + (depths * wd).sum() + (conics * wc).sum() + (colors * wcol).sum();
+        loss.backward();
+        seconds[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return n;
+}
