@@ -161,11 +161,11 @@ LFS_API int lfs_intersect_offset(
  *      worst case). Returns 0 for an unsupported tile_size. */
 LFS_API size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t channels, uint32_t image_width,
                                              uint32_t image_height, uint32_t tile_size, int64_t n_isects);
-/*      developer switch, not part of the reference API: bit 0 = build the per-cell lists without culling
- *      (fwd output must be bit-identical either way; tests/test_gpu_raster.py); bit 1 = the experimental kernels with
- *      16x8 cells and two pixels per lane (bit-identical forward, slower on the benchmark scene: csrc/raster.hip); bit 2 = the
- *      experimental quadrant-row kernels (csrc/lfs_raster_rows.cuh; lfs_rasterize_workspace_bytes grows while the bit is set); bit 3 with bit 2 = their quadrant lists built in one pass;
- *      bit 4 = deterministic backward accumulation; bit 5 = the one-pass intersection scatter even when a scratch array is given. */
+/*      developer switch, not part of the reference API: bit 0 = build the per-cell lists without culling (fwd output must be bit-identical either way;
+ *      tests/test_gpu_raster.py); bits 1 - 3: unused (the experimental kernels they selected were measured and removed);
+ *      bit 4 = deterministic backward accumulation (two passes, 64-bit fixed point: run-to-run bit-identical gradients; lfs_rasterize_workspace_bytes grows while it is set);
+ *      bit 5 = the one-pass intersection scatter even when a scratch array is given; bit 6 = the training step packs the rasterizer's records with the separate
+ *      raster_pack pass of rounds 1 - 3 instead of inside the projection kernel (A/B, tests/test_emulated_step_pack.py). */
 LFS_API void lfs_set_debug_flags(uint32_t flags);
 LFS_API uint32_t lfs_get_debug_flags(void);
 LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
@@ -409,6 +409,8 @@ typedef struct lfs_gut_step_layout {
 } lfs_gut_step_layout;
 LFS_API int lfs_gut_step_layout_for(uint32_t N, uint32_t image_width, uint32_t image_height, uint32_t tile_size, int64_t capacity, lfs_gut_step_layout* out);
 LFS_API int lfs_gut_step_fits(int64_t n_isects, int64_t longest, int64_t capacity, int64_t assumed_longest); /* 1: the attempt with these assumptions was valid */
+LFS_API int lfs_gut_step_supported(uint32_t N, uint32_t image_width, uint32_t image_height, uint32_t tile_size); /* 0: this shape is outside the speculative step (more than
+    512 tile rows, index-bit limit, debug bit 5): lfs_gut_* return LFS_E_UNSUPPORTED - enqueue the operators one by one instead (trainer.py does) */
 LFS_API int lfs_gut_train_step(const lfs_gut_step_args* args, int64_t capacity, int64_t assumed_longest, void* workspace, size_t workspace_bytes,
                                int64_t* host_counts /* pinned [3], or NULL: counts stay in the workspace */, int64_t stamp, lfs_stream_t stream);
 LFS_API int lfs_gut_view_forward(const lfs_gut_step_args* args, int64_t capacity, int64_t assumed_longest, void* workspace, size_t workspace_bytes,

@@ -38,11 +38,11 @@ SOURCES = {
     "bilateral_grid.hip": ["-ffp-contract=off"],
     "dataprep.hip": ["-ffp-contract=off"],
     "fastgs_prep.hip": ["-ffp-contract=off"],
-    "fastgs_blend.hip": ["-fno-slp-vectorize", "-Wno-inline-asm"],
+    "fastgs_blend.hip": ["-fno-slp-vectorize"],
     "prof.hip": [],
     # no SLP packing: v_pk_* operand pairing forces SGPR shuffles right after the scalar record
     # load and defeats the software prefetch (measured on the ISA); plain v_fma with SGPR operands
-    "raster.hip": ["-fno-slp-vectorize", "-Wno-inline-asm"],   # (-Wno-inline-asm: wave_sum16_atomic_lds names m0 as clobbered on purpose)
+    "raster.hip": ["-fno-slp-vectorize"],
     "gut_step.hip": [],   # host code only: the C++ training-step driver
     "version.hip": [],    # lfs_version(): carries the hash of the sources (recompiled whenever any of them changed)
 }
@@ -104,6 +104,32 @@ def build(force: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     return OUT
+
+
+VARIANT_DS_WRITE2 = os.path.join(HERE, "liblfs_gsplat_red_ds_write2.so")
+
+
+def build_variants(force: bool = False) -> str:
+    """The test-suite's second build of the two rasterizer files: -DLFS_RED_ADDTID=0 - the backward's 16-value wave reduction through plain ds_write2_b32 stores
+    instead of the inline-asm ds_write_addtid_b32 block (lfs_raster_common.cuh) -> liblfs_gsplat_red_ds_write2.so. tests/test_gpu_raster.py runs both
+    libraries on the same inputs: the asm path is checked against compiler-generated code on every suite run, not only when somebody remembers to."""
+    build()
+    vsrc = ["raster.hip", "fastgs_blend.hip"]
+    vobjs = []
+    for name in vsrc:
+        src, obj = os.path.join(CSRC, name), os.path.join(BUILD, name + ".red_ds_write2.o")
+        if force or _stale(obj, src):
+            cmd = [HIPCC, *COMMON, *SOURCES[name], "-DLFS_RED_ADDTID=0", "-c", src, "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for the variant of {name}:\n{r.stdout}\n{r.stderr}")
+        vobjs.append(obj)
+    objs = [os.path.join(BUILD, n + ".o") for n in SOURCES if n not in vsrc] + vobjs
+    if force or not os.path.exists(VARIANT_DS_WRITE2) or any(os.path.getmtime(o) > os.path.getmtime(VARIANT_DS_WRITE2) for o in objs):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", VARIANT_DS_WRITE2], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"variant link failed:\n{r.stdout}\n{r.stderr}")
+    return VARIANT_DS_WRITE2
 
 
 IO_OUT = os.path.join(HERE, "liblfs_io.so")

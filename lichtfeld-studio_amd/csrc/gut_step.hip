@@ -132,6 +132,14 @@ extern "C" int lfs_gut_step_layout_for(uint32_t N, uint32_t image_width, uint32_
     return LFS_OK;
 }
 
+// 1: the speculative step takes this problem shape (its binning needs the two-pass scatter: at most 512 tile rows, Gaussian index + tile column in 32 bits, debug
+// bit 5 off; tile sizes the rasterizer has cell kernels for). 0: lfs_gut_* would return LFS_E_UNSUPPORTED - the caller enqueues the operators one by one instead.
+extern "C" int lfs_gut_step_supported(uint32_t N, uint32_t image_width, uint32_t image_height, uint32_t tile_size) {
+    if (N == 0 || tile_size < 8 || tile_size > 64 || (tile_size & 7) || image_width == 0 || image_height == 0) return 0;
+    const uint32_t tw = (image_width + tile_size - 1) / tile_size, th = (image_height + tile_size - 1) / tile_size;
+    return isect_two_pass_supported(1, N, tw, th) ? 1 : 0;
+}
+
 extern "C" int lfs_gut_step_fits(int64_t n_isects, int64_t longest, int64_t capacity, int64_t assumed_longest) {
     return (n_isects <= capacity && uint64_t(longest) <= uint64_t(sort_class_limit(assumed_longest))) ? 1 : 0;
 }

@@ -484,6 +484,14 @@ int lfs::isect_count_impl(
     return (int)hipGetLastError();
 }
 
+// what the guarded (speculative) emit needs: the two-pass binned scatter (the one-pass kernels do not watch the abort flag)
+bool lfs::isect_two_pass_supported(uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height) {
+    const size_t total = size_t(C) * N;
+    if (total == 0 || tile_width == 0 || tile_height == 0) return false;
+    const uint32_t idx_bits = bit_width_u32(uint32_t(total - 1)) ? bit_width_u32(uint32_t(total - 1)) : 1u;
+    return C * tile_height <= ROWS_MAX && total <= 0xFFFFFFFFull && idx_bits + bit_width_u32(tile_width - 1) <= 32 && !(lfs_get_debug_flags() & 32u);
+}
+
 uint32_t* lfs::isect_workspace_totals(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height) {
     return isect_ws(workspace, C, N, tile_width, tile_height).totals;
 }
@@ -560,8 +568,7 @@ int lfs::isect_emit_impl(
         int tok = lfs::prof_begin("isect_scatter", s);
         const uint32_t R = C * tile_height;
         const uint32_t idx_bits = bit_width_u32(uint32_t(total - 1)) ? bit_width_u32(uint32_t(total - 1)) : 1u;
-        const bool two_pass = scratch != nullptr && R <= ROWS_MAX && total <= 0xFFFFFFFFull && idx_bits + bit_width_u32(tile_width - 1) <= 32 &&
-                              !(lfs_get_debug_flags() & 32u);
+        const bool two_pass = scratch != nullptr && isect_two_pass_supported(C, N, tile_width, tile_height);
         if (two_pass) {
             hipLaunchKernelGGL(isect_rows_kernel, dim3(uint32_t((total + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(1024), ROWS_STAGE * 8, s, C, N, means2d, radii,
                                depths, float(tile_size), tile_width, tile_height, idx_bits, w.offsets, w.row_cursor, reinterpret_cast<uint64_t*>(scratch),

@@ -274,14 +274,20 @@ LFS_DI void wave_sum16_atomic_lds(const v2f (&V)[8], float* __restrict__ dst, co
 #if LFS_RED_ADDTID && !defined(LFS_EMULATE)
     {
         const uint32_t base = __builtin_amdgcn_readfirstlane(uint32_t(reinterpret_cast<uintptr_t>(scratch))); // LDS byte address (low half of the flat address)
-        // (s_nop: one wait state between the SALU write of M0 and an add-TID LDS instruction)
-        asm volatile("s_mov_b32 m0, %16\n\ts_nop 0\n\t"
-                     "ds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:288\n\tds_write_addtid_b32 %2 offset:576\n\tds_write_addtid_b32 %3 offset:864\n\t"
-                     "ds_write_addtid_b32 %4 offset:1152\n\tds_write_addtid_b32 %5 offset:1440\n\tds_write_addtid_b32 %6 offset:1728\n\tds_write_addtid_b32 %7 offset:2016\n\t"
-                     "ds_write_addtid_b32 %8 offset:2304\n\tds_write_addtid_b32 %9 offset:2592\n\tds_write_addtid_b32 %10 offset:2880\n\tds_write_addtid_b32 %11 offset:3168\n\t"
-                     "ds_write_addtid_b32 %12 offset:3456\n\tds_write_addtid_b32 %13 offset:3744\n\tds_write_addtid_b32 %14 offset:4032\n\tds_write_addtid_b32 %15 offset:4320"
-                     :: "v"(V[0].x), "v"(V[0].y), "v"(V[1].x), "v"(V[1].y), "v"(V[2].x), "v"(V[2].y), "v"(V[3].x), "v"(V[3].y), "v"(V[4].x), "v"(V[4].y), "v"(V[5].x),
-                        "v"(V[5].y), "v"(V[6].x), "v"(V[6].y), "v"(V[7].x), "v"(V[7].y), "s"(base) : "memory", "m0");
+        // M0 is a register the compiler manages itself (LLVM does not promise to honour an "m0" clobber): the block saves it, sets it, and puts it back - it leaves no
+        // trace in M0, so nothing depends on how the compiler places its own M0 initialisations around the asm. (s_nop: one wait state between the SALU write
+        // of M0 and an add-TID LDS instruction; the stores have read M0 when they issue, so the restore needs none.)
+        uint32_t m0_saved;
+        asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[base]\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %[a0] offset:0\n\tds_write_addtid_b32 %[a1] offset:288\n\tds_write_addtid_b32 %[a2] offset:576\n\tds_write_addtid_b32 %[a3] offset:864\n\t"
+                     "ds_write_addtid_b32 %[a4] offset:1152\n\tds_write_addtid_b32 %[a5] offset:1440\n\tds_write_addtid_b32 %[a6] offset:1728\n\tds_write_addtid_b32 %[a7] offset:2016\n\t"
+                     "ds_write_addtid_b32 %[a8] offset:2304\n\tds_write_addtid_b32 %[a9] offset:2592\n\tds_write_addtid_b32 %[a10] offset:2880\n\tds_write_addtid_b32 %[a11] offset:3168\n\t"
+                     "ds_write_addtid_b32 %[a12] offset:3456\n\tds_write_addtid_b32 %[a13] offset:3744\n\tds_write_addtid_b32 %[a14] offset:4032\n\tds_write_addtid_b32 %[a15] offset:4320\n\t"
+                     "s_mov_b32 m0, %[sv]"
+                     : [sv] "=&s"(m0_saved)
+                     : [a0] "v"(V[0].x), [a1] "v"(V[0].y), [a2] "v"(V[1].x), [a3] "v"(V[1].y), [a4] "v"(V[2].x), [a5] "v"(V[2].y), [a6] "v"(V[3].x), [a7] "v"(V[3].y),
+                       [a8] "v"(V[4].x), [a9] "v"(V[4].y), [a10] "v"(V[5].x), [a11] "v"(V[5].y), [a12] "v"(V[6].x), [a13] "v"(V[6].y), [a14] "v"(V[7].x), [a15] "v"(V[7].y),
+                       [base] "s"(base) : "memory");
         __builtin_amdgcn_wave_barrier();
         const float4* rd = reinterpret_cast<const float4*>(scratch + (lane & 15) * RED_ROW + 4 * (lane >> 4));
 #pragma unroll
@@ -335,11 +341,15 @@ LFS_DI void wave_sum9_atomic_lds(const float (&v)[9], float* __restrict__ dst, c
 #if LFS_RED_ADDTID && !defined(LFS_EMULATE)
     {   // value-major block through ds_write_addtid_b32 / ds_read_b128, as wave_sum16_atomic_lds
         const uint32_t base = __builtin_amdgcn_readfirstlane(uint32_t(reinterpret_cast<uintptr_t>(scratch)));
-        asm volatile("s_mov_b32 m0, %9\n\ts_nop 0\n\t"
-                     "ds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:288\n\tds_write_addtid_b32 %2 offset:576\n\tds_write_addtid_b32 %3 offset:864\n\t"
-                     "ds_write_addtid_b32 %4 offset:1152\n\tds_write_addtid_b32 %5 offset:1440\n\tds_write_addtid_b32 %6 offset:1728\n\tds_write_addtid_b32 %7 offset:2016\n\t"
-                     "ds_write_addtid_b32 %8 offset:2304"
-                     :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "s"(base) : "memory", "m0");
+        uint32_t m0_saved; // (M0 saved and put back inside the block: see wave_sum16_atomic_lds)
+        asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[base]\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %[a0] offset:0\n\tds_write_addtid_b32 %[a1] offset:288\n\tds_write_addtid_b32 %[a2] offset:576\n\tds_write_addtid_b32 %[a3] offset:864\n\t"
+                     "ds_write_addtid_b32 %[a4] offset:1152\n\tds_write_addtid_b32 %[a5] offset:1440\n\tds_write_addtid_b32 %[a6] offset:1728\n\tds_write_addtid_b32 %[a7] offset:2016\n\t"
+                     "ds_write_addtid_b32 %[a8] offset:2304\n\t"
+                     "s_mov_b32 m0, %[sv]"
+                     : [sv] "=&s"(m0_saved)
+                     : [a0] "v"(v[0]), [a1] "v"(v[1]), [a2] "v"(v[2]), [a3] "v"(v[3]), [a4] "v"(v[4]), [a5] "v"(v[5]), [a6] "v"(v[6]), [a7] "v"(v[7]), [a8] "v"(v[8]),
+                       [base] "s"(base) : "memory");
         __builtin_amdgcn_wave_barrier();
         const float4* rd = reinterpret_cast<const float4*>(scratch + (lane & 15) * RED_ROW + 4 * (lane >> 4));
 #pragma unroll

@@ -1,5 +1,5 @@
 // The per-(camera, Gaussian) staging of the world-space rasterizer, shared by raster_pack_kernel (raster.hip: the Ops.h entry points) and by the
-// fused training step, where the SH colour kernel writes the finished records itself (sh.hip, lfs_sh_model_fwd_pack): the 64-byte record the
+// training step, whose projection kernel writes the finished records itself (projection_ut.hip, PACK): the 64-byte record the
 // fwd / bwd kernels walk and the 32-byte culling record (silhouette conic of the alpha >= 1/255 ellipsoid, lfs_cull_conic.cuh).
 #pragma once
 #include "lfs_camera.cuh"

@@ -25,6 +25,7 @@ int isect_count_impl(uint32_t C, uint32_t N, const float* means2d, const int32_t
 int isect_emit_impl(uint32_t C, uint32_t N, const float* means2d, const int32_t* radii, const float* depths, uint32_t tile_size, uint32_t tile_width,
                     uint32_t tile_height, int sort, int64_t n_isects, const int32_t* tiles_per_gauss, int64_t* isect_ids, int32_t* flatten_ids,
                     int32_t* tile_offsets, int64_t* scratch, int64_t max_tile_isects, void* workspace, size_t workspace_bytes, hipStream_t s, const IsectGuard* guard);
+bool isect_two_pass_supported(uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height);
 // the [T + 1] offsets inside an intersection workspace (offsets[T] = n_isects): what the guarded rasterizer calls take as tile_offsets
 const int32_t* isect_workspace_offsets(void* workspace, uint32_t C, uint32_t N, uint32_t tile_width, uint32_t tile_height);
 

@@ -48,6 +48,7 @@ class GutStep:
         self._stamp = 0
         self.n_isects = 0
         self.longest = 0
+        self.wait_poll_s = 5.0    # how long _wait spins on the pinned counts before it falls back to a stream synchronisation
         self.retries = 0          # attempts that did not fit (each one is re-run): a few right after start-up or a densification, none in steady state
 
     # ---- workspace --------------------------------------------------------------------------------------------------------------------------
@@ -111,9 +112,15 @@ class GutStep:
         """-> did the attempt fit? (the counts were written by the scan kernel long before the host got here)"""
         lib = load_library()
         n, lg = C.c_int64(0), C.c_int64(0)
-        rc = lib.lfs_gut_step_wait(C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), C.c_double(30.0), C.byref(n), C.byref(lg))
+        # the stamp usually is there already; when the step sits behind other work on the stream (the previous step's all-reduce, a first-collective RCCL
+        # initialisation that can take longer than any fixed timeout) the host simply waits for the stream and looks again - it only gives up when the stream
+        # has DRAINED and the stamp of this step is still missing
+        rc = lib.lfs_gut_step_wait(C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), C.c_double(self.wait_poll_s), C.byref(n), C.byref(lg))
         if rc != 0:
-            raise LfsError("gut_step: the intersection counts of this step never arrived in pinned host memory")
+            torch.cuda.current_stream(self.device).synchronize()
+            rc = lib.lfs_gut_step_wait(C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), C.c_double(1.0), C.byref(n), C.byref(lg))
+        if rc != 0:
+            raise LfsError("gut_step: the stream has drained and the intersection counts of this step never arrived in pinned host memory")
         self.n_isects, self.longest = int(n.value), int(lg.value)
         return bool(lib.lfs_gut_step_fits(n, lg, C.c_int64(self.capacity), C.c_int64(self.assumed_longest)))
 

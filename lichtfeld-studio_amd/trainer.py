@@ -5,6 +5,7 @@ scope; the loss here is the rasterizer-only MSE of SURVEY.md §8
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import List, Optional
 
 import torch
@@ -13,6 +14,52 @@ from . import dist as lfs_dist
 from .fused_adam import ExponentialLR, FusedAdam, default_param_groups
 from .rasterizer import Camera, RenderMode, SplatModel, rasterize
 from .scenes import Scene
+
+
+@dataclass(frozen=True)
+class StepPlan:
+    """Which form of the training step runs, and with which fusions (GutTrainer._train_step dispatches on it)."""
+    path: str            # "fastgs" | "autograd" | "cxx_all" | "cxx_views" | "batch_views" | "py_views"
+    inline_shN: bool     # shN's Adam update happens inside the SH backward (no shN gradient tensor)
+    inline_all: bool     # every parameter is updated by the backward kernels (no gradient tensors at all)
+    inline_shard: bool   # SH-sharded: the owners' multi-view SH backward applies the shard's Adam update
+    multi: bool          # the multi-rank code path (world > 1, or LFS_DIST_FORCE_COLLECTIVES on one GPU)
+    skip_deferred: bool  # the shN segment stays out of the flat all-reduce
+
+
+def plan_step(*, rasterizer: str, fused_l2: bool, world: int, force_collectives: bool, sh_sharded: bool, shard_rows: int, n_views: int, loss: str,
+              strategy: Optional[str], refining: bool, iteration: int, has_shN: bool, optimizer_fused: bool, bilateral: bool, inline_shN_adam: bool = True,
+              inline_all_adam: bool = True, cxx_step: bool = True, batch_views: bool = True) -> StepPlan:
+    """Pure function of the configuration -> the step form. The rules, in the order they are applied:
+      * fastgs rasterizer -> its own step; fused_l2 off -> torch autograd over the op-by-op mirror.
+      * shN's Adam update moves into the SH backward (inline_shN) when Adam reads shN anyway (iteration > 1000, fused_adam.cpp:68-70), there IS an shN, the
+        optimizer is the fused one, and the strategy does not touch shN before the optimizer step: no strategy, or MCMC between refinements (post_backward then
+        only adds noise to the means, mcmc.cpp:362-384) - never on refining iterations (relocation rewrites shN rows and moments first).
+        - replicated layout: additionally one view on one rank (gradient of a single view, no all-reduce: nothing else needs the tensor)
+        - several views on one rank (batch_views): inside the ONE multi-view SH backward
+        - SH-sharded, one view per rank: the owners' multi-view backward updates the shard (inline_shard)
+      * inline_all (no gradient tensor at all) = inline_shN on one view / one rank + MSE + no strategy + no bilateral grid.
+      * C++ step driver (cxx_step): inline_all -> ONE call (cxx_all); otherwise its per-view form whenever the layout is replicated and the rank has one view
+        or runs the multi-rank path (cxx_views). Several views on one rank without collectives -> batch_views. Everything else - SH-sharded ranks, cxx_step
+        off - -> the kernels enqueued from Python view by view (py_views)."""
+    multi = world > 1 or force_collectives
+    if rasterizer == "fastgs":
+        return StepPlan("fastgs", False, False, False, multi, iteration <= 1000)
+    if not fused_l2:
+        return StepPlan("autograd", False, False, False, multi, iteration <= 1000)
+    strat_ok = strategy is None or (strategy == "mcmc" and not refining)
+    adam_reads_shN = iteration > 1000 and has_shN and optimizer_fused
+    inline_one = inline_shN_adam and not multi and not sh_sharded and n_views == 1 and strat_ok and adam_reads_shN
+    inline_all = inline_one and inline_all_adam and strategy is None and loss == "mse" and not bilateral
+    inline_shard = inline_shN_adam and sh_sharded and n_views == 1 and adam_reads_shN and shard_rows > 0 and not refining
+    skip_deferred = iteration <= 1000 or sh_sharded
+    if inline_all and cxx_step:
+        return StepPlan("cxx_all", True, True, False, multi, skip_deferred)
+    if cxx_step and not sh_sharded and (multi or n_views == 1):
+        return StepPlan("cxx_views", inline_one, False, False, multi, skip_deferred)
+    if batch_views and not multi and not sh_sharded and n_views > 1:
+        return StepPlan("batch_views", inline_shN_adam and strat_ok and adam_reads_shN, False, False, multi, skip_deferred)
+    return StepPlan("py_views", inline_one, inline_all, inline_shard, multi, skip_deferred)
 
 
 class GutTrainer:
@@ -251,7 +298,9 @@ class GutTrainer:
 
     def _train_step(self, targets: List[torch.Tensor], views: Optional[List[int]] = None, views_all: Optional[List[List[int]]] = None) -> float:
         """One optimisation step on this rank's share of the global view batch. `views` overrides this rank's views of the round-robin
-        schedule; SH-sharded, the owners must know every rank's views: pass `views_all` (one list per rank) with an explicit schedule."""
+        schedule; SH-sharded, the owners must know every rank's views: pass `views_all` (one list per rank) with an explicit schedule.
+        WHICH of the step forms runs is decided by plan_step (a pure function of the configuration, table-tested in tests/test_host_logic.py);
+        each form is one method below."""
         self.iteration += 1
         if views_all is not None:
             views = views_all[self.rank]
@@ -261,134 +310,148 @@ class GutTrainer:
             views = lfs_dist.views_for_step(self.iteration - 1, self.rank, self.world, self.scene.viewmats.shape[0], self.views_per_rank)
         self._views_all = views_all
         total_views = self.world * len(views)
-        loss_value = None
-        if self.rasterizer == "fastgs":
+        plan = self._plan(len(views))
+        if plan.path == "fastgs":
             return self._train_step_fastgs(targets, views, total_views)
-        if self.fused_l2:
-            from .fused import render_and_backward
-            params = self.model.parameters()
-            every = None
-            if self.sh_exchange is not None:  # what every rank renders at sub-step k (the owners evaluate SH for all of them)
-                every = self._views_all or [lfs_dist.views_for_step(self.iteration - 1, j, self.world, self.scene.viewmats.shape[0], len(views))
-                                            for j in range(self.world)]
-            # one view, one rank, Adam reading shN (iteration > 1000): the SH backward applies shN's Adam update itself (no shN gradient tensor)
-            # (with MCMC too, between refinements: post_backward then only adds noise to the means - mcmc.cpp:362-384 - and shN reaches optimizer.step() as the
-            # backward left it; on refining iterations relocation rewrites shN rows and moments first, so the update stays in the optimizer launch)
-            refining = self.strategy is not None and self.strategy.is_refining(self.iteration)   # parameters are replaced before the optimizer step
-            strat_ok = self.strategy is None or (self.strategy_kind == "mcmc" and not refining)
-            inline = None
-            # LFS_DIST_FORCE_COLLECTIVES=1 (one GPU, RCCL with world size 1): take the MULTI-rank code path - gradient tensors, early + final all-reduce - so that
-            # what a rank of an N-GPU job executes can be run and timed on a single device (bench.py --replicated / --sh-sharded with that variable set)
-            multi = self.world > 1 or lfs_dist._FORCE
-            if (self.inline_shN_adam and not multi and self.sh_exchange is None and len(views) == 1 and strat_ok and self.iteration > 1000
-                    and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False)):
-                inline = self.optimizer.prepare_inline(self.model.shN)
-            # ... and when the MSE is folded into the rasterizer backward as well, EVERY parameter is updated by the backward kernels (fused.backward_adam_all):
-            # no gradient tensor, no separate activation-backward / optimizer launches
-            inline_all = None
-            if inline is not None and self.inline_all_adam and self.strategy is None and self.loss_kind == "mse" and self.bilateral is None:
-                inline_all = {"shN": inline}
-                for name in ("means", "sh0", "raw_scales", "raw_quats", "raw_opacities"):
-                    inline_all[name] = self.optimizer.prepare_inline(getattr(self.model, name))
-                inline = None
-            if inline_all is None:
-                self.loss_acc.zero_()   # (the all-inline step stores the loss: no fill launch)
-            inline_shard = None   # SH-sharded, one view per rank: the owners' multi-view SH backward applies the shard's Adam update
-            if (self.inline_shN_adam and self.sh_exchange is not None and len(views) == 1 and self.iteration > 1000 and self.sh_exchange.n   # no update then
-                    and self.model.shN.shape[1] > 0 and getattr(self.optimizer, "fused", False) and not refining):
-                inline_shard = self.optimizer.prepare_inline(self.model.shN)
-            if inline_all is not None and self.cxx_step:
-                from .gut_step import GutStep
-                if self._gut_step is None:
-                    self._gut_step = GutStep(self.device)
-                v, sc = views[0], self.scene
-                N = self.model.means.shape[0]
-                self.last_n_isects = self._gut_step.train_step([p.detach() for p in params], inline_all, self.model.get_active_sh_degree(), sc.width, sc.height,
-                                                               sc.viewmats[v], sc.Ks[v], self.bg, targets[0], 1.0 / total_views, self.loss_acc,
-                                                               self.scale_reg, self.opacity_reg)
-                self._last_radii = self._gut_step.view("radii", torch.int32, (1, N, 2))
-                views_loop = []
-            elif self.cxx_step and self.sh_exchange is None and (multi or len(views) == 1):
-                # gradient-tensor form of the C++ step (data-parallel ranks with the north-star layout - replicated Gaussians, one all-reduce of the flat
-                # bucket -, single-rank steps while iteration <= 1000, and every step whose loss is not the folded MSE: L1 + D-SSIM, bilateral grid, MCMC):
-                # per view one speculative forward + two backward calls, no host read in between; the loss kernels run between forward and backward on the
-                # image the forward left in the step workspace. The SH backward runs BEFORE the finish pass, so on the last view of a rank the shN segment
-                # (45 of 59 floats per Gaussian at degree 3) is on the wire, in 4 chunks, while the finish kernel still runs; the remaining 14 floats follow
-                # in all_reduce() below. One view on one rank with Adam reading shN (`inline`): the SH backward applies shN's update itself.
-                from .gut_step import GutStep
-                if self._gut_step is None:
-                    self._gut_step = GutStep(self.device)
-                gs, sc = self._gut_step, self.scene
-                ps = [p.detach() for p in params]
-                deg, N = self.model.get_active_sh_degree(), self.model.means.shape[0]
-                weight = 1.0 / total_views
-                for k, v in enumerate(views):
-                    vm, Km, tgt = sc.viewmats[v], sc.Ks[v], targets[k % len(targets)]
-                    self.last_n_isects = gs.view_forward(ps, deg, sc.width, sc.height, vm, Km, self.bg)
-                    v_render, fold = None, None
-                    if self.bilateral is not None:   # clamp -> slice -> loss on the un-clamped result -> slice backward (fused.render_and_backward does the same)
-                        from .losses import loss_fwd_bwd
-                        render = gs.view("render", torch.float32, (sc.height, sc.width, 3))
-                        shown = self.bilateral.apply_fused(render, v, chw=False)
-                        v_shown = loss_fwd_bwd(self.loss_kind, shown, tgt, weight, self.loss_acc, chw=False, clamp=False, lambda_dssim=self.lambda_dssim)
-                        v_render = self.bilateral.apply_fused_backward(render, v, v_shown, chw=False)
-                    elif self.loss_kind == "l1_ssim":
-                        from .losses import photometric_loss_fwd_bwd
-                        v_render = photometric_loss_fwd_bwd(gs.view("render", torch.float32, (1, sc.height, sc.width, 3)), tgt, self.lambda_dssim, weight, self.loss_acc)
-                    else:
-                        fold = tgt                   # the clamped MSE is derived inside the rasterizer backward
-                    gs.view_backward_sh(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=fold, weight=weight,
-                                        loss_acc=self.loss_acc, v_render=v_render, adam_shN=inline)
-                    if multi and k == len(views) - 1 and self.iteration > 1000 and ps[2].numel():
-                        self.bucket.all_reduce_early([2], chunks=4)
-                    gs.view_backward_finish(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=fold, weight=weight,
-                                            loss_acc=self.loss_acc, scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
-                                            opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0)
-                self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
-                views_loop = []
-            elif self.batch_views and not multi and self.sh_exchange is None and len(views) > 1:
-                # several views per step on one rank: the SH stages run ONCE over all views (fused.render_views_and_backward), and shN's Adam update
-                # moves into that one SH backward when the optimizer would read the gradient anyway
-                from .fused import render_views_and_backward
-                inline_v = None
-                if (self.inline_shN_adam and strat_ok and self.iteration > 1000 and self.model.shN.shape[1] > 0
-                        and getattr(self.optimizer, "fused", False)):
-                    inline_v = self.optimizer.prepare_inline(self.model.shN)
-                outs = render_views_and_backward([self.camera(v) for v in views], self.model, self.bg, [targets[k % len(targets)] for k in range(len(views))],
-                                                 1.0 / total_views, self.bucket.views, self.loss_acc, loss=self.loss_kind, lambda_dssim=self.lambda_dssim,
-                                                 scale_reg=self.scale_reg, opacity_reg=self.opacity_reg, adam_shN=inline_v, bilateral=self.bilateral,
-                                                 image_idxs=list(views))
-                self.last_n_isects, self._last_radii = outs[-1].n_isects, outs[-1].radii
-                views_loop = []
+        if plan.path == "autograd":
+            return self._step_autograd(targets, views, total_views)
+        if not plan.inline_all:
+            self.loss_acc.zero_()   # (the all-inline step stores the loss: no fill launch)
+        if plan.path == "cxx_all":
+            self._step_cxx_all(plan, targets, views, total_views)
+        elif plan.path == "cxx_views":
+            self._step_cxx_views(plan, targets, views, total_views)
+        elif plan.path == "batch_views":
+            self._step_batch_views(plan, targets, views, total_views)
+        else:
+            self._step_py_views(plan, targets, views, total_views)
+        return self._finish_fused_step(plan)
+
+    def _cxx_supported(self) -> bool:
+        """Shapes the speculative C++ step does not take (more than 512 tile rows, the index-bit limit, debug bit 5: csrc/intersect.hip would return
+        LFS_E_UNSUPPORTED) run the same kernels enqueued call by call from Python (the py_views form) instead of failing."""
+        from .capi import load_library
+        sc = self.scene
+        return bool(load_library().lfs_gut_step_supported(int(self.model.means.shape[0]), int(sc.width), int(sc.height), 16))
+
+    def _plan(self, n_views: int) -> "StepPlan":
+        st = self.strategy
+        return plan_step(rasterizer=self.rasterizer, fused_l2=self.fused_l2, world=self.world, force_collectives=bool(lfs_dist._FORCE),
+                         sh_sharded=self.sh_exchange is not None, shard_rows=(self.sh_exchange.n if self.sh_exchange is not None else 0), n_views=n_views,
+                         loss=self.loss_kind, strategy=(None if st is None else self.strategy_kind), refining=bool(st is not None and st.is_refining(self.iteration)),
+                         iteration=self.iteration, has_shN=self.model.shN.shape[1] > 0, optimizer_fused=bool(getattr(self.optimizer, "fused", False)),
+                         bilateral=self.bilateral is not None, inline_shN_adam=self.inline_shN_adam, inline_all_adam=self.inline_all_adam,
+                         cxx_step=self.cxx_step and self.rasterizer != "fastgs" and self.fused_l2 and self._cxx_supported(), batch_views=self.batch_views)
+
+    def _gut(self):
+        from .gut_step import GutStep
+        if self._gut_step is None:
+            self._gut_step = GutStep(self.device)
+        return self._gut_step
+
+    def _step_cxx_all(self, plan, targets, views, total_views) -> None:
+        """One view, one rank, MSE, iteration > 1000: forward + backward + Adam on all six tensors as ONE C++ call (csrc/gut_step.hip), no gradient tensors."""
+        inline_all = {name: self.optimizer.prepare_inline(getattr(self.model, name)) for name in ("shN", "means", "sh0", "raw_scales", "raw_quats", "raw_opacities")}
+        gs, sc, v = self._gut(), self.scene, views[0]
+        N = self.model.means.shape[0]
+        self.last_n_isects = gs.train_step([p.detach() for p in self.model.parameters()], inline_all, self.model.get_active_sh_degree(), sc.width, sc.height,
+                                           sc.viewmats[v], sc.Ks[v], self.bg, targets[0], 1.0 / total_views, self.loss_acc, self.scale_reg, self.opacity_reg)
+        self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
+
+    def _step_cxx_views(self, plan, targets, views, total_views) -> None:
+        """Gradient-tensor form of the C++ step (data-parallel ranks with the north-star layout - replicated Gaussians, one all-reduce of the flat bucket -,
+        single-rank steps while iteration <= 1000, and every step whose loss is not the folded MSE: L1 + D-SSIM, bilateral grid, MCMC): per view one speculative
+        forward + two backward calls; the host looks at the forward's (pinned) counts once per view, after it has enqueued the forward. The loss kernels run
+        between forward and backward on the image the forward left in the step workspace. The SH backward runs BEFORE the finish pass, so on the last view of a
+        rank the shN segment (45 of 59 floats per Gaussian at degree 3) is on the wire, in 4 chunks, while the finish kernel still runs; the remaining 14 floats
+        follow in all_reduce(). One view on one rank with Adam reading shN (plan.inline_shN): the SH backward applies shN's update itself."""
+        inline = self.optimizer.prepare_inline(self.model.shN) if plan.inline_shN else None
+        gs, sc = self._gut(), self.scene
+        ps = [p.detach() for p in self.model.parameters()]
+        deg, N = self.model.get_active_sh_degree(), self.model.means.shape[0]
+        weight = 1.0 / total_views
+        for k, v in enumerate(views):
+            vm, Km, tgt = sc.viewmats[v], sc.Ks[v], targets[k % len(targets)]
+            self.last_n_isects = gs.view_forward(ps, deg, sc.width, sc.height, vm, Km, self.bg)
+            v_render, fold = None, None
+            if self.bilateral is not None:   # clamp -> slice -> loss on the un-clamped result -> slice backward (fused.render_and_backward does the same)
+                from .losses import loss_fwd_bwd
+                render = gs.view("render", torch.float32, (sc.height, sc.width, 3))
+                shown = self.bilateral.apply_fused(render, v, chw=False)
+                v_shown = loss_fwd_bwd(self.loss_kind, shown, tgt, weight, self.loss_acc, chw=False, clamp=False, lambda_dssim=self.lambda_dssim)
+                v_render = self.bilateral.apply_fused_backward(render, v, v_shown, chw=False)
+            elif self.loss_kind == "l1_ssim":
+                from .losses import photometric_loss_fwd_bwd
+                v_render = photometric_loss_fwd_bwd(gs.view("render", torch.float32, (1, sc.height, sc.width, 3)), tgt, self.lambda_dssim, weight, self.loss_acc)
             else:
-                views_loop = list(enumerate(views))
-            for k, v in views_loop:
-                vm_all = None if every is None else [self.scene.viewmats[e[k]:e[k] + 1].contiguous() for e in every]
-                out = render_and_backward(self.camera(v), self.model, self.bg, targets[k % len(targets)], 1.0 / total_views,
-                                          self.bucket.views, self.loss_acc, accumulate=k > 0, loss=self.loss_kind, lambda_dssim=self.lambda_dssim,
-                                          # regularisers: once per step, and 1/world of them per rank (the all-reduce sums the ranks)
-                                          scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
-                                          opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0,
-                                          sh_exchange=self.sh_exchange, viewmats_all=vm_all, adam_shN=inline, adam_shard=inline_shard, adam_all=inline_all,
-                                          bilateral=self.bilateral, image_idx=v,
-                                          # last view: scales / quats / opacities gradients are final before the SH backward starts - their all-reduce overlaps with it
-                                          on_geometry_grads=(lambda: self.bucket.all_reduce_early([3, 4, 5])) if (self.world > 1 and k == len(views) - 1) else None)
-                self.last_n_isects, self._last_radii = out.n_isects, out.radii
-            # the deferred segment (shN) stays out of the all-reduce while Adam does not read it (iteration <= 1000) and, SH-sharded, always
-            self.bucket.all_reduce(skip_deferred=self.iteration <= 1000 or self.sh_exchange is not None)
-            self._bilateral_step()
-            for p, gv in zip(params, self.bucket.views):
-                p.grad = gv
-            if self.strategy is not None:  # trainer.cpp:741-760: post_backward (may replace the parameter tensors) then step
-                if self.sh_exchange is not None and self.strategy.is_refining(self.iteration):
-                    self._refine_with_full_shN(lambda: self.strategy.post_backward(self.iteration))
-                else:
-                    self.strategy.post_backward(self.iteration)
-                self.strategy.step(self.iteration)  # FusedAdam skips tensors without a gradient, as the reference's does after add_new_gs
+                fold = tgt                   # the clamped MSE is derived inside the rasterizer backward
+            gs.view_backward_sh(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=fold, weight=weight,
+                                loss_acc=self.loss_acc, v_render=v_render, adam_shN=inline)
+            if plan.multi and k == len(views) - 1 and self.iteration > 1000 and ps[2].numel():
+                self.bucket.all_reduce_early([2], chunks=4)
+            gs.view_backward_finish(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, target_chw=fold, weight=weight,
+                                    loss_acc=self.loss_acc, scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
+                                    opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0)
+        self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
+
+    def _step_batch_views(self, plan, targets, views, total_views) -> None:
+        """Several views per step on one rank: the SH stages run ONCE over all views (fused.render_views_and_backward), and shN's Adam update moves into
+        that one SH backward when the optimizer would read the gradient anyway."""
+        from .fused import render_views_and_backward
+        inline_v = self.optimizer.prepare_inline(self.model.shN) if plan.inline_shN else None
+        outs = render_views_and_backward([self.camera(v) for v in views], self.model, self.bg, [targets[k % len(targets)] for k in range(len(views))],
+                                         1.0 / total_views, self.bucket.views, self.loss_acc, loss=self.loss_kind, lambda_dssim=self.lambda_dssim,
+                                         scale_reg=self.scale_reg, opacity_reg=self.opacity_reg, adam_shN=inline_v, bilateral=self.bilateral,
+                                         image_idxs=list(views))
+        self.last_n_isects, self._last_radii = outs[-1].n_isects, outs[-1].radii
+
+    def _step_py_views(self, plan, targets, views, total_views) -> None:
+        """The fused kernels enqueued call by call from Python (fused.render_and_backward), view by view: the SH-sharded layout, cxx_step = False (the tests hold
+        the C++ step to this path bit for bit), and the fallback of the C++ step."""
+        from .fused import render_and_backward
+        inline = self.optimizer.prepare_inline(self.model.shN) if (plan.inline_shN and not plan.inline_all) else None
+        inline_shard = self.optimizer.prepare_inline(self.model.shN) if plan.inline_shard else None
+        inline_all = None
+        if plan.inline_all:
+            inline_all = {name: self.optimizer.prepare_inline(getattr(self.model, name)) for name in ("shN", "means", "sh0", "raw_scales", "raw_quats", "raw_opacities")}
+        every = None
+        if self.sh_exchange is not None:  # what every rank renders at sub-step k (the owners evaluate SH for all of them)
+            every = self._views_all or [lfs_dist.views_for_step(self.iteration - 1, j, self.world, self.scene.viewmats.shape[0], len(views)) for j in range(self.world)]
+        for k, v in enumerate(views):
+            vm_all = None if every is None else [self.scene.viewmats[e[k]:e[k] + 1].contiguous() for e in every]
+            out = render_and_backward(self.camera(v), self.model, self.bg, targets[k % len(targets)], 1.0 / total_views,
+                                      self.bucket.views, self.loss_acc, accumulate=k > 0, loss=self.loss_kind, lambda_dssim=self.lambda_dssim,
+                                      # regularisers: once per step, and 1/world of them per rank (the all-reduce sums the ranks)
+                                      scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
+                                      opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0,
+                                      sh_exchange=self.sh_exchange, viewmats_all=vm_all, adam_shN=inline, adam_shard=inline_shard, adam_all=inline_all,
+                                      bilateral=self.bilateral, image_idx=v,
+                                      # last view: scales / quats / opacities gradients are final before the SH backward starts - their all-reduce overlaps with it
+                                      on_geometry_grads=(lambda: self.bucket.all_reduce_early([3, 4, 5])) if (self.world > 1 and k == len(views) - 1) else None)
+            self.last_n_isects, self._last_radii = out.n_isects, out.radii
+
+    def _finish_fused_step(self, plan):
+        """What follows the backward of every fused step form: all-reduce of the flat bucket, the bilateral grid's own optimizer, strategy / optimizer step."""
+        params = self.model.parameters()
+        # the deferred segment (shN) stays out of the all-reduce while Adam does not read it (iteration <= 1000) and, SH-sharded, always
+        self.bucket.all_reduce(skip_deferred=plan.skip_deferred)
+        self._bilateral_step()
+        for p, gv in zip(params, self.bucket.views):
+            p.grad = gv
+        if self.strategy is not None:  # trainer.cpp:741-760: post_backward (may replace the parameter tensors) then step
+            if self.sh_exchange is not None and self.strategy.is_refining(self.iteration):
+                self._refine_with_full_shN(lambda: self.strategy.post_backward(self.iteration))
             else:
-                self.optimizer.step(self.iteration)
-                self.scheduler.step()
-            return self.loss_acc  # this rank's share of the loss (a 1-element tensor, read it after a sync)
+                self.strategy.post_backward(self.iteration)
+            self.strategy.step(self.iteration)  # FusedAdam skips tensors without a gradient, as the reference's does after add_new_gs
+        else:
+            self.optimizer.step(self.iteration)
+            self.scheduler.step()
+        return self.loss_acc  # this rank's share of the loss (a 1-element tensor, read it after a sync)
+
+    def _step_autograd(self, targets, views, total_views):
+        """torch autograd over the op-by-op mirror of gs::training::rasterize (rasterizer.py): the reference's own structure, kept as the comparison path."""
+        loss_value = None
         for k, v in enumerate(views):
             out = rasterize(self.camera(v), self.model, self.bg, 1.0, False, False, RenderMode.RGB)
             if self.loss_kind == "l1_ssim":

@@ -12,6 +12,8 @@ its own runs):
             ~1e-3 of the tensor norm), same vs the fp32 oracle up to its own distance from fp64; the
             oracle's forward outputs are fed to both sides. At the full 1M / 3M sizes: test_gpu_headline_parity.py.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -337,3 +339,36 @@ def test_deterministic_backward_mode_is_bit_reproducible(lfs, oracle_mod):
         noise_check(f"deterministic vs float-atomic {name}", rel_l2(n(a), n(r)), atomic_noise_bar(r2, r))
     for a, b in zip(*fused):
         assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
+def test_lds_reduction_asm_block_agrees_with_the_compiler_generated_stores(lfs, tmp_path):
+    """The backward's 16-value (3DGUT) / 9-value (EWA) wave reduction stores its values with ds_write_addtid_b32 from an inline-asm block that sets M0 (saved and
+    restored inside the block, lfs_raster_common.cuh). The second library of the build (build.build_variants: -DLFS_RED_ADDTID=0, plain ds_write2_b32 stores the
+    compiler schedules itself) runs the same inputs in a subprocess: the per-Gaussian sums may differ in the order of their additions only. 3DGUT gradients in
+    the deterministic accumulation mode (run-to-run bit-identical within a library): 2e-6 relative L2; EWA gradients (float atomics): noise-relative."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    variant = os.path.join(os.path.dirname(here), "lichtfeld-studio_amd", "liblfs_gsplat_red_ds_write2.so")
+    if not os.path.exists(variant):
+        pytest.skip("liblfs_gsplat_red_ds_write2.so not built (__graft_entry__.build())")
+    res = {}
+    for tag, libpath in (("default", None), ("ds_write2", variant)):
+        env = dict(os.environ)
+        env.pop("LFS_GSPLAT_LIB", None)
+        if libpath:
+            env["LFS_GSPLAT_LIB"] = libpath
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(here, "lds_reduction_probe.py"), out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[tag] = dict(np.load(out))
+    a, b = res["default"], res["ds_write2"]
+    for k in [k for k in a if k.startswith("gut_")]:
+        assert np.isfinite(a[k]).all() and np.abs(a[k]).max() > 0
+        noise_check(f"LDS reduction asm vs ds_write2 {k}", rel_l2(a[k], b[k]), 2e-6)
+    for name in ["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"]:
+        x0, x1, y0 = a[f"fastgs0_{name}"], a[f"fastgs1_{name}"], b[f"fastgs0_{name}"]
+        if np.abs(x0).max() == 0:
+            assert np.abs(y0).max() == 0
+            continue
+        noise_check(f"EWA LDS reduction asm vs ds_write2 {name}", rel_l2(y0, x0), atomic_noise_bar(x0, x1, b[f"fastgs1_{name}"]))

@@ -127,3 +127,70 @@ def test_warmup_exponential_lr_follows_reference_schedule():
     s2 = WarmupExponentialLR(o2, gamma=0.5, param_group_index=1)
     s2.step()
     assert o2.param_groups[0]["lr"] == 1.0 and o2.param_groups[1]["lr"] == 0.5
+
+
+def test_step_plan_table():
+    """trainer.plan_step - the pure function that picks the training-step form - over EVERY combination of its inputs: the invariants that make a skipped or
+    doubled update impossible, and the rows the documented configurations must land on."""
+    import itertools
+
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd.trainer import plan_step
+    base = dict(rasterizer="gut", fused_l2=True, world=1, force_collectives=False, sh_sharded=False, shard_rows=0, n_views=1, loss="mse", strategy=None, refining=False,
+                iteration=3000, has_shN=True, optimizer_fused=True, bilateral=False)
+    # documented rows
+    assert plan_step(**base).path == "cxx_all"                                                    # the benchmarked step: one C++ call, no gradient tensors
+    assert plan_step(**dict(base, iteration=500)).path == "cxx_views"                             # shN not optimised yet: gradient tensors, shN skipped
+    assert plan_step(**dict(base, iteration=500)).skip_deferred
+    assert plan_step(**dict(base, loss="l1_ssim")) == plan_step(**dict(base, loss="l1_ssim"))    # (frozen dataclass: comparable)
+    p = plan_step(**dict(base, loss="l1_ssim"))
+    assert p.path == "cxx_views" and p.inline_shN and not p.inline_all                            # L1 + D-SSIM: shN's update inline, the rest through the optimizer
+    p = plan_step(**dict(base, strategy="mcmc", loss="l1_ssim", refining=True))
+    assert p.path == "cxx_views" and not p.inline_shN                                             # relocation rewrites shN rows before the optimizer step
+    p = plan_step(**dict(base, world=8))
+    assert p.path == "cxx_views" and p.multi and not p.inline_shN and not p.skip_deferred         # data-parallel, replicated: every gradient through the all-reduce
+    p = plan_step(**dict(base, world=8, n_views=8))
+    assert p.path == "cxx_views"                                                                  # BASELINE config 4: 8 views per rank
+    p = plan_step(**dict(base, n_views=8))
+    assert p.path == "batch_views" and p.inline_shN                                               # several views on one rank: one SH pass over all of them
+    p = plan_step(**dict(base, world=4, sh_sharded=True, shard_rows=1000))
+    assert p.path == "py_views" and p.inline_shard and p.skip_deferred                            # SH-sharded: owners update their shard, shN never all-reduced
+    assert plan_step(**dict(base, cxx_step=False)).path == "py_views" and plan_step(**dict(base, cxx_step=False)).inline_all
+    assert plan_step(**dict(base, rasterizer="fastgs")).path == "fastgs" and plan_step(**dict(base, fused_l2=False)).path == "autograd"
+    assert plan_step(**dict(base, world=1, force_collectives=True)).path == "cxx_views"           # one GPU running the multi-rank code path
+    # invariants over the whole table
+    n = 0
+    for (world, force, sharded, n_views, loss, strategy, refining, iteration, has_shN, fused, bilateral, i_shN, i_all, cxx, batch) in itertools.product(
+            (1, 2, 8), (False, True), (False, True), (1, 8), ("mse", "l1_ssim"), (None, "mcmc", "default"), (False, True), (500, 1000, 1001, 7000), (False, True),
+            (False, True), (False, True), (False, True), (False, True), (False, True), (False, True)):
+        if refining and strategy is None:
+            continue
+        p = plan_step(rasterizer="gut", fused_l2=True, world=world, force_collectives=force, sh_sharded=sharded, shard_rows=1000 if sharded else 0, n_views=n_views,
+                      loss=loss, strategy=strategy, refining=refining, iteration=iteration, has_shN=has_shN, optimizer_fused=fused, bilateral=bilateral,
+                      inline_shN_adam=i_shN, inline_all_adam=i_all, cxx_step=cxx, batch_views=batch)
+        n += 1
+        assert p.path in ("cxx_all", "cxx_views", "batch_views", "py_views")
+        assert p.multi == (world > 1 or force)
+        assert p.skip_deferred == (iteration <= 1000 or sharded)
+        if p.inline_shN or p.inline_all or p.inline_shard:   # an inline update only when Adam would have read the tensor, and never around a refinement
+            assert iteration > 1000 and has_shN and fused and i_shN and not refining
+        if p.inline_shN or p.inline_all:                     # replicated layout: only without a strategy, or MCMC between refinements (post_backward = noise on the means)
+            assert strategy in (None, "mcmc")
+        if p.inline_all:
+            assert p.inline_shN and loss == "mse" and strategy is None and not bilateral and not p.multi and not sharded and n_views == 1 and i_all
+        if p.inline_shN and p.path != "batch_views":
+            assert not p.multi and not sharded and n_views == 1        # a single view's gradient, no all-reduce: nobody else needs the shN gradient tensor
+        if p.inline_shN and p.path == "batch_views":
+            assert not p.multi and not sharded
+        if p.inline_shard:
+            assert sharded and n_views == 1 and p.path == "py_views"
+        assert not (p.inline_shard and p.inline_shN)
+        if p.path == "cxx_all":
+            assert cxx and p.inline_all
+        if p.path == "cxx_views":
+            assert cxx and not sharded and (p.multi or n_views == 1) and not p.inline_all
+        if p.path == "batch_views":
+            assert n_views > 1 and not p.multi and not sharded and batch
+        if sharded:
+            assert p.path == "py_views"
+    assert n > 20000
