@@ -426,6 +426,11 @@ LFS_API int lfs_gut_view_backward_sh(const lfs_gut_step_args* args, int64_t capa
                                      void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 LFS_API int lfs_gut_view_backward_finish(const lfs_gut_step_args* args, int64_t capacity, float* const* grads, int accumulate,
                                          void* workspace, size_t workspace_bytes, lfs_stream_t stream);
+/*   lfs_gut_view_backward_rows: the view's backward WITHOUT the SH backward - grads[0] (means, no SH direction term), grads[3..5] and dL/dcolour rows [N,3] ->
+ *   v_colors_out: the factored gradient exchange of the replicated data-parallel layout (dist.ColorGradExchange) gathers the rows of all ranks and runs
+ *   lfs_sh_model_bwd_views over all views on every rank (radii = colors = NULL there: rows pre-masked with colour > 0 by the rank that rendered the view). */
+LFS_API int lfs_gut_view_backward_rows(const lfs_gut_step_args* args, int64_t capacity, const float* v_render, float* const* grads /* [6] host */, int accumulate,
+                                       float* v_colors_out, void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 LFS_API int lfs_gut_step_wait(const int64_t* host_counts, int64_t stamp, double timeout_s, int64_t* n_isects, int64_t* longest);
 
 /* Extension: the all-inline training step of the fused 3DGUT path (one camera, global shutter, 3 channels, ONE view per step on one rank - the

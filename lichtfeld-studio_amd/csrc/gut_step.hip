@@ -227,6 +227,28 @@ extern "C" int lfs_gut_view_backward_finish(const lfs_gut_step_args* a, int64_t 
                                  grads[5], nullptr, w.v_dirs, a->target_chw ? a->loss : nullptr, w.raster_ws, w.raster_ws_bytes, (hipStream_t)stream);
 }
 
+// The view's backward for the FACTORED gradient exchange of the replicated data-parallel layout (dist.ColorGradExchange): rasterizer backward, then the finish pass -
+// grads[0], grads[3..5] (means WITHOUT the SH direction term, scales, quaternions, opacities), written or added to - and dL/dcolour [N,3] -> v_colors_out. No SH
+// backward here: per view the gradient of the SH coefficients is the outer product basis(direction) x dL/dcolour, every rank knows every rank's camera, so the ranks
+// exchange the 3-float rows and each evaluates the multi-view SH backward (lfs_sh_model_bwd_views) over ALL views itself.
+extern "C" int lfs_gut_view_backward_rows(const lfs_gut_step_args* a, int64_t capacity, const float* v_render, float* const* grads /* [6] host */, int accumulate,
+                                          float* v_colors_out, void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
+    StepWs w; lfs_cameras cams; const int32_t* offsets;
+    int rc = view_setup(a, capacity, workspace, workspace_bytes, w, cams, offsets);
+    if (rc) return rc;
+    if (!grads || !grads[0] || !grads[3] || !grads[4] || !grads[5] || !v_colors_out || (!a->target_chw && !v_render) || (a->target_chw && !a->loss)) return LFS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->target_chw)
+        rc = raster_bwd_mse_acc_guarded(a->N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, a->tile_size, offsets, w.flatten_ids, capacity,
+                                        w.render, w.alpha, w.last_ids, a->target_chw, a->loss_weight, w.raster_ws, w.raster_ws_bytes, s);
+    else
+        rc = raster_bwd_acc_guarded(a->N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, a->tile_size, offsets, w.flatten_ids, capacity, w.alpha,
+                                    w.last_ids, v_render, w.raster_ws, w.raster_ws_bytes, s);
+    if (rc) return rc;
+    return gut_finish_grads_impl(a->N, a->means, a->raw_quats, w.quats, w.scales, w.opacities, a->scale_reg, a->opacity_reg, accumulate, grads[0], grads[3], grads[4],
+                                 grads[5], v_colors_out, nullptr, a->target_chw ? a->loss : nullptr, w.raster_ws, w.raster_ws_bytes, s);
+}
+
 extern "C" int lfs_gut_view_backward(const lfs_gut_step_args* a, int64_t capacity, const float* v_render, float* const* grads /* [6] host */, int accumulate,
                                      void* workspace, size_t workspace_bytes, lfs_stream_t stream) {
     const int rc = lfs_gut_view_backward_sh(a, capacity, v_render, grads, accumulate, workspace, workspace_bytes, stream);

@@ -474,16 +474,23 @@ __global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const
             for (int kk = 0; kk < 25; ++kk) b[kk] = 0.f;
             float v0 = 0.f, v1 = 0.f, v2 = 0.f;
             const size_t row = size_t(v) * a.view_stride + gmine;
-            if (gmine < a.n) { const int32_t* rr = a.radii + row * 2; on = rr[0] > 0 && rr[1] > 0; }
+            if (gmine < a.n) {
+                if (a.radii != nullptr) { const int32_t* rr = a.radii + row * 2; on = rr[0] > 0 && rr[1] > 0; }
+                // radii == NULL (the factored gradient exchange, dist.ColorGradExchange): the rows arrive already masked by visibility and by the clamp of the
+                // rank that rendered the view - a Gaussian takes part in a view exactly when its row is not zero
+                else on = v_colors[row * 3] != 0.f || v_colors[row * 3 + 1] != 0.f || v_colors[row * 3 + 2] != 0.f;
+            }
             if (on) {
                 const f3 cp = campos_of(a.viewmats + 16 * v);
                 d = {m.x - cp.x, m.y - cp.y, m.z - cp.z};
                 if (degree >= 1) { inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
                 sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
                 v0 = v_colors[row * 3]; v1 = v_colors[row * 3 + 1]; v2 = v_colors[row * 3 + 2];
-                if (!(a.colors[row * 3] > 0.f)) v0 = 0.f;       // clamp_min backward
-                if (!(a.colors[row * 3 + 1] > 0.f)) v1 = 0.f;
-                if (!(a.colors[row * 3 + 2] > 0.f)) v2 = 0.f;
+                if (a.colors != nullptr) {                        // clamp_min backward
+                    if (!(a.colors[row * 3] > 0.f)) v0 = 0.f;
+                    if (!(a.colors[row * 3 + 1] > 0.f)) v1 = 0.f;
+                    if (!(a.colors[row * 3 + 2] > 0.f)) v2 = 0.f;
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < LPG; ++kk) lds[lane * (LPG + 1) + kk] = (kk < 25) ? b[kk] : 0.f;
@@ -538,6 +545,7 @@ __global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const
             adam_elem(q0, m0, s0, a0[it], adam.s); adam_elem(q1, m1, s1, a1[it], adam.s); adam_elem(q2, m2, s2, a2[it], adam.s);
             pp[0] = q0; pp[1] = q1; pp[2] = q2;
             adam.m[e] = m0; adam.m[e + 1] = m1; adam.m[e + 2] = m2; adam.v[e] = s0; adam.v[e + 1] = s1; adam.v[e + 2] = s2;
+        } else if (v_shN == nullptr) { // (nobody reads the higher-degree gradient: iteration <= 1000, fused_adam.cpp:68-70)
         } else if (accumulate) { v_shN[e] += a0[it]; v_shN[e + 1] += a1[it]; v_shN[e + 2] += a2[it]; }
         else { v_shN[e] = a0[it]; v_shN[e + 1] = a1[it]; v_shN[e + 2] = a2[it]; }
     }
@@ -730,8 +738,9 @@ extern "C" int lfs_sh_model_bwd_views(
     if (n == 0 || n_views == 0) return LFS_OK;
     if (!sh_views_ok(n, K, degrees_to_use, n_views, view_stride)) return LFS_E_INVALID;
     const bool inline_adam = shN_exp_avg != nullptr;
-    if (!means || !viewmats || !sh0 || (K > 1 && !shN) || !radii || !colors || !v_colors || !v_sh0 || !v_means) return LFS_E_INVALID;
-    if (inline_adam ? (accumulate || !shN_exp_avg_sq || K < 2) : (K > 1 && !v_shN)) return LFS_E_INVALID;
+    // radii / colors may BOTH be NULL: v_colors rows pre-masked by their producer (see the kernel); v_shN may be NULL without inline Adam: gradient not wanted
+    if (!means || !viewmats || !sh0 || (K > 1 && !shN) || ((radii == nullptr) != (colors == nullptr)) || !v_colors || !v_sh0 || !v_means) return LFS_E_INVALID;
+    if (inline_adam && (accumulate || !shN_exp_avg_sq || K < 2)) return LFS_E_INVALID;
     const lfs::ShViews a{n, K, int(degrees_to_use), n_views, view_stride, means, viewmats, sh0, shN, radii, colors};
     const lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp}};
     hipStream_t s = (hipStream_t)stream;

@@ -170,14 +170,18 @@ def sh_model_fwd_views(sh_degree: int, means, viewmats, sh0, shN, radii_views):
 def sh_model_bwd_views(sh_degree: int, means, viewmats, sh0, shN, radii_views, colors_views, v_colors_views, v_sh0, v_shN, v_means, accumulate: bool,
                        adam: Optional[dict] = None):
     """The backward of sh_model_fwd_views summed over the views: v_sh0 / v_shN (the owner's rows) written or added to, v_means += dL/d(dirs);
-    with `adam` (FusedAdam.prepare_inline; accumulate False) v_shN is not touched and shN is updated in place."""
-    require_gpu(means, viewmats, sh0, shN, radii_views, colors_views, v_colors_views, v_sh0, v_means)
-    n, K, V, S = means.shape[0], 1 + shN.shape[1], radii_views.shape[0], radii_views.shape[1]
+    with `adam` (FusedAdam.prepare_inline; accumulate False) v_shN is not touched and shN is updated in place. radii_views = colors_views = None: the rows of
+    v_colors_views [V,S,3] come PRE-MASKED (visibility and colour > 0 applied by the rank that rendered the view - the factored gradient exchange,
+    dist.ColorGradExchange); v_shN = None without adam: the higher-degree gradient is not wanted (iteration <= 1000)."""
+    require_gpu(means, viewmats, sh0, shN, v_colors_views, v_sh0, v_means)
+    if radii_views is not None:
+        require_gpu(radii_views, colors_views)
+    n, K, V, S = means.shape[0], 1 + shN.shape[1], v_colors_views.shape[0], v_colors_views.shape[1]
     z = C.c_float(0.0)
     sc = [C.c_float(adam[k]) for k in ("lr", "beta1", "beta2", "eps", "bc1_rcp", "bc2_sqrt_rcp")] if adam else [z] * 6
     check(load_library().lfs_sh_model_bwd_views(C.c_uint32(n), C.c_uint32(K), C.c_uint32(sh_degree), C.c_uint32(V), C.c_uint32(S), ptr(means), ptr(viewmats),
                                                 ptr(sh0), ptr(shN), ptr(radii_views), ptr(colors_views), ptr(v_colors_views), C.c_int(int(accumulate)),
-                                                ptr(v_sh0), None if adam else ptr(v_shN), ptr(v_means), ptr(adam["exp_avg"]) if adam else None,
+                                                ptr(v_sh0), None if (adam or v_shN is None) else ptr(v_shN), ptr(v_means), ptr(adam["exp_avg"]) if adam else None,
                                                 ptr(adam["exp_avg_sq"]) if adam else None, *sc, stream()), "sh_model_bwd_views")
 
 

@@ -202,6 +202,23 @@ class GutStep:
         self._backward_call("lfs_gut_view_backward_sh", params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, target_chw, weight, loss_acc, v_render, 0.0, 0.0,
                             adam=None if adam_shN is None else {"shN": adam_shN})
 
+    def view_backward_rows(self, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, rows_out: torch.Tensor, *, target_chw=None, weight=0.0, loss_acc=None,
+                           v_render=None, scale_reg: float = 0.0, opacity_reg: float = 0.0) -> None:
+        """The view's backward for the factored gradient exchange (dist.ColorGradExchange): grads[0] (means, without the SH direction term), grads[3..5] written / added
+        to, dL/dcolour -> rows_out [N,3], masked with the clamp of the SH colours (colour > 0) - what the multi-view SH backward of every rank takes as it is."""
+        lib = load_library()
+        a = self._args(params, sh_degree, W, H, viewmat, Kmat, bg, target_chw, weight, scale_reg, opacity_reg, loss_acc, None)
+        if not rows_out.is_cuda or not rows_out.is_contiguous() or rows_out.numel() != 3 * params[0].shape[0]:
+            raise LfsError("gut_step: rows_out must be a contiguous CUDA (HIP) tensor [N,3]")
+        gp = (C.c_void_p * 6)(*[g.data_ptr() if g.numel() else None for g in grads])
+        if v_render is not None:
+            v_render = v_render.contiguous()
+        check(lib.lfs_gut_view_backward_rows(C.byref(a), C.c_int64(self.capacity), C.c_void_p(v_render.data_ptr()) if v_render is not None else None, gp,
+                                             C.c_int(int(accumulate)), C.c_void_p(rows_out.data_ptr()), C.c_void_p(self.ws.data_ptr()), C.c_size_t(self.ws.numel()),
+                                             stream()), "gut_view_backward_rows")
+        N = params[0].shape[0]
+        rows_out.view(N, 3).mul_(self.view("colors", torch.float32, (N, 3)) > 0)   # clamp_min backward of rasterizer.cpp:262 (colours of invisible Gaussians: rows are 0 anyway)
+
     def view_backward_finish(self, params, sh_degree, W, H, viewmat, Kmat, bg, grads, accumulate, *, target_chw=None, weight=0.0, loss_acc=None,
                              scale_reg: float = 0.0, opacity_reg: float = 0.0) -> None:
         """Second half: accumulator rows + dL/d(dirs) -> grads[0], grads[3..5]; loss_acc += the fused MSE of the first half (when target_chw was given)."""

@@ -29,7 +29,7 @@ class StepPlan:
 
 def plan_step(*, rasterizer: str, fused_l2: bool, world: int, force_collectives: bool, sh_sharded: bool, shard_rows: int, n_views: int, loss: str,
               strategy: Optional[str], refining: bool, iteration: int, has_shN: bool, optimizer_fused: bool, bilateral: bool, inline_shN_adam: bool = True,
-              inline_all_adam: bool = True, cxx_step: bool = True, batch_views: bool = True) -> StepPlan:
+              inline_all_adam: bool = True, cxx_step: bool = True, batch_views: bool = True, factored_sh: bool = False) -> StepPlan:
     """Pure function of the configuration -> the step form. The rules, in the order they are applied:
       * fastgs rasterizer -> its own step; fused_l2 off -> torch autograd over the op-by-op mirror.
       * shN's Adam update moves into the SH backward (inline_shN) when Adam reads shN anyway (iteration > 1000, fused_adam.cpp:68-70), there IS an shN, the
@@ -53,6 +53,12 @@ def plan_step(*, rasterizer: str, fused_l2: bool, world: int, force_collectives:
     inline_all = inline_one and inline_all_adam and strategy is None and loss == "mse" and not bilateral
     inline_shard = inline_shN_adam and sh_sharded and n_views == 1 and adam_reads_shN and shard_rows > 0 and not refining
     skip_deferred = iteration <= 1000 or sh_sharded
+    if factored_sh and multi and not sh_sharded:
+        # replicated layout with the factored SH exchange (dist.ColorGradExchange): per view rasterizer backward + finish, rows gathered, ONE multi-view SH backward
+        # over every rank's views with shN's Adam update inside whenever Adam reads shN and no refinement rewrites it first; sh0 / shN never enter the all-reduce
+        if not cxx_step:
+            raise ValueError("the factored SH exchange runs through the C++ step driver (cxx_step)")
+        return StepPlan("cxx_factored", inline_shN_adam and strat_ok and adam_reads_shN, False, False, multi, True)
     if inline_all and cxx_step:
         return StepPlan("cxx_all", True, True, False, multi, skip_deferred)
     if cxx_step and not sh_sharded and (multi or n_views == 1):
@@ -67,7 +73,7 @@ class GutTrainer:
                  views_per_rank: int = 1, fused_adam: bool = True, fused_l2: bool = True, loss: str = "mse", lambda_dssim: float = 0.2,
                  strategy: Optional[str] = None, opt_params=None, scene_scale: float = 1.0, seed: int = 0, rasterizer: str = "gut",
                  use_bilateral_grid: bool = False, bilateral_grid_dims=(16, 16, 8), bilateral_grid_lr: float = 2e-3, tv_loss_weight: float = 10.0,
-                 sh_sharded: Optional[bool] = None):
+                 sh_sharded: Optional[bool] = None, factored_sh: bool = False):
         """strategy: None (fixed set of Gaussians: the benchmark), "mcmc" (strategies.MCMC: relocation + growth + SGLD noise, with
         the scale / opacity regularisers of trainer.cpp:132-158) or "default" (ADC; needs densification_info, see strategies.py).
         `seed` seeds the strategy's generator: the same on every rank, so replicas densify identically."""
@@ -78,8 +84,14 @@ class GutTrainer:
         # Data-parallel layout. Default (round 3): the north-star one - Gaussians REPLICATED, per-rank forward / backward, one all-reduce of the flat gradient
         # bucket before the fused Adam step. sh_sharded=True opts into dist.ShExchange (shN and its Adam state owned by one rank each: 14 instead of 59 floats per
         # Gaussian in the all-reduce; fused 3DGUT step, no strategy or MCMC). bench.py --gpus N times both.
+        # factored_sh=True (round 4) keeps the replicated layout and shrinks its collective: the SH gradients are exchanged as dL/dcolour rows (all-gather, 12 B per
+        # Gaussian and view) and assembled by every rank itself (dist.ColorGradExchange); only 11 of 59 floats per Gaussian remain in the all-reduce.
         if sh_sharded is None:
             sh_sharded = False
+        if factored_sh and (sh_sharded or not (fused_l2 and rasterizer == "gut")):
+            raise ValueError("factored_sh is a variant of the replicated layout of the fused 3DGUT step")
+        self.factored_sh = bool(factored_sh)
+        self.color_exchange = None
         if sh_sharded and not (fused_l2 and rasterizer == "gut" and strategy in (None, "mcmc")):
             raise ValueError("sh_sharded needs the fused 3DGUT step (no strategy, or MCMC: its refinement steps run on the gathered tensors)")
         self.sh_exchange = lfs_dist.ShExchange(sc.means.shape[0], world, rank) if sh_sharded else None
@@ -130,7 +142,7 @@ class GutTrainer:
         # the op-by-op mirror (rasterizer.py); gradients land directly in the flat bucket the all-reduce works on.
         self.fused_l2 = fused_l2
         self.loss_kind, self.lambda_dssim = loss, lambda_dssim  # "mse" | "l1_ssim" (trainer.cpp:115-128)
-        self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2]) if (world > 1 or fused_l2) else None  # 2 = shN
+        self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=self._deferred()) if (world > 1 or fused_l2) else None  # 2 = shN
         self.loss_acc = torch.zeros(1, device=device)
         self.inline_all_adam = True   # one view / one rank / MSE: all six parameters are updated inside the backward kernels (fused.backward_adam_all)
         self.cxx_step = True          # ... and that step is ONE C++ call without a host read on the critical path (gut_step.GutStep -> csrc/gut_step.hip);
@@ -141,13 +153,17 @@ class GutTrainer:
         self._last_radii = None
         self._last_visible = None
 
+    def _deferred(self):
+        """bucket segments that stay out of the flat all-reduce: shN (2) while Adam does not read it; with the factored exchange sh0 (1) and shN always"""
+        return [1, 2] if getattr(self, "factored_sh", False) else [2]
+
     def _on_resize(self) -> None:
         """The strategy replaced parameter tensors (densification): the flat gradient bucket has to follow."""
         if self._resize_suspended:      # (_refine_with_full_shN: shN is gathered right now - one rebuild when the shard is back)
             self._resize_pending = True
             return
         if self.bucket is not None:
-            self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2])
+            self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=self._deferred())
 
     @property
     def last_visible(self):
@@ -177,7 +193,7 @@ class GutTrainer:
         densification_info, or MCMC) -> fused Adam. Black background."""
         from .fastgs import render_and_backward as fg_step
         if self.bucket is None:
-            self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=[2])
+            self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=self._deferred())
         params = self.model.parameters()
         N = params[0].shape[0]
         self.loss_acc.zero_()
@@ -321,6 +337,8 @@ class GutTrainer:
             self._step_cxx_all(plan, targets, views, total_views)
         elif plan.path == "cxx_views":
             self._step_cxx_views(plan, targets, views, total_views)
+        elif plan.path == "cxx_factored":
+            self._step_cxx_factored(plan, targets, views, total_views)
         elif plan.path == "batch_views":
             self._step_batch_views(plan, targets, views, total_views)
         else:
@@ -341,7 +359,8 @@ class GutTrainer:
                          loss=self.loss_kind, strategy=(None if st is None else self.strategy_kind), refining=bool(st is not None and st.is_refining(self.iteration)),
                          iteration=self.iteration, has_shN=self.model.shN.shape[1] > 0, optimizer_fused=bool(getattr(self.optimizer, "fused", False)),
                          bilateral=self.bilateral is not None, inline_shN_adam=self.inline_shN_adam, inline_all_adam=self.inline_all_adam,
-                         cxx_step=self.cxx_step and self.rasterizer != "fastgs" and self.fused_l2 and self._cxx_supported(), batch_views=self.batch_views)
+                         cxx_step=self.cxx_step and self.rasterizer != "fastgs" and self.fused_l2 and self._cxx_supported(), batch_views=self.batch_views,
+                         factored_sh=self.factored_sh)
 
     def _gut(self):
         from .gut_step import GutStep
@@ -394,6 +413,52 @@ class GutTrainer:
                                     opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0)
         self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
 
+    def _step_cxx_factored(self, plan, targets, views, total_views) -> None:
+        """Replicated layout, factored SH exchange. Per view of this rank: speculative forward, loss, rasterizer backward + finish (means / scales / quaternions /
+        opacities gradients into the bucket, dL/dcolour rows - clamp-masked - into the send buffer). Then: the all-reduce of the 11 remaining floats per Gaussian
+        starts (asynchronously, on RCCL's stream), the rows of all ranks are all-gathered, and the multi-view SH backward runs over the views of ALL ranks in
+        rank-major order: sh0's gradient -> bucket, shN's Adam update inside (or its gradient -> bucket on refining iterations, or nothing while iteration <= 1000),
+        the direction term of the means gradient -> added after the all-reduce has landed. Every rank executes the same sums in the same order."""
+        from . import fused
+        gs, sc = self._gut(), self.scene
+        ps = [p.detach() for p in self.model.parameters()]
+        deg, N = self.model.get_active_sh_degree(), self.model.means.shape[0]
+        ex = self.color_exchange
+        if ex is None or ex.n != N or ex.vpr != len(views):
+            ex = self.color_exchange = lfs_dist.ColorGradExchange(N, self.world, self.rank, len(views), self.device)
+        weight = 1.0 / total_views
+        for k, v in enumerate(views):
+            vm, Km, tgt = sc.viewmats[v], sc.Ks[v], targets[k % len(targets)]
+            self.last_n_isects = gs.view_forward(ps, deg, sc.width, sc.height, vm, Km, self.bg)
+            v_render, fold = None, None
+            if self.bilateral is not None:
+                from .losses import loss_fwd_bwd
+                render = gs.view("render", torch.float32, (sc.height, sc.width, 3))
+                shown = self.bilateral.apply_fused(render, v, chw=False)
+                v_shown = loss_fwd_bwd(self.loss_kind, shown, tgt, weight, self.loss_acc, chw=False, clamp=False, lambda_dssim=self.lambda_dssim)
+                v_render = self.bilateral.apply_fused_backward(render, v, v_shown, chw=False)
+            elif self.loss_kind == "l1_ssim":
+                from .losses import photometric_loss_fwd_bwd
+                v_render = photometric_loss_fwd_bwd(gs.view("render", torch.float32, (1, sc.height, sc.width, 3)), tgt, self.lambda_dssim, weight, self.loss_acc)
+            else:
+                fold = tgt
+            gs.view_backward_rows(ps, deg, sc.width, sc.height, vm, Km, self.bg, self.bucket.views, k > 0, ex.send[k], target_chw=fold, weight=weight,
+                                  loss_acc=self.loss_acc, v_render=v_render, scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
+                                  opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0)
+        self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
+        self.bucket.all_reduce_early([0, 3, 4, 5], chunks=1)          # 11 floats per Gaussian, on RCCL's stream while the rows travel and the SH backward runs
+        rows = ex.gather()                                            # [world * views, N, 3], rank-major
+        every = self._views_all or [lfs_dist.views_for_step(self.iteration - 1, j, self.world, sc.viewmats.shape[0], len(views)) for j in range(self.world)]
+        if rows.shape[0] != len(every) * len(views):                  # (one GPU forced through the collectives: the gathered rows are this rank's own)
+            every = [list(views)]
+        vms = torch.stack([sc.viewmats[v] for e in every for v in e]).contiguous()
+        adam = self.optimizer.prepare_inline(self.model.shN) if plan.inline_shN else None
+        want_shN_grad = adam is None and self.iteration > 1000 and self.model.shN.shape[1] > 0     # a refining iteration: relocation first, then the optimizer
+        ex.v_dirs.zero_()
+        fused.sh_model_bwd_views(deg, ps[0], vms, ps[1], ps[2], None, None, rows, self.bucket.views[1], self.bucket.views[2] if want_shN_grad else None, ex.v_dirs,
+                                 False, adam=adam)
+        self._pending_v_dirs = ex.v_dirs
+
     def _step_batch_views(self, plan, targets, views, total_views) -> None:
         """Several views per step on one rank: the SH stages run ONCE over all views (fused.render_views_and_backward), and shN's Adam update moves into
         that one SH backward when the optimizer would read the gradient anyway."""
@@ -435,6 +500,8 @@ class GutTrainer:
         params = self.model.parameters()
         # the deferred segment (shN) stays out of the all-reduce while Adam does not read it (iteration <= 1000) and, SH-sharded, always
         self.bucket.all_reduce(skip_deferred=plan.skip_deferred)
+        if plan.path == "cxx_factored":   # the SH direction term of dL/dmeans, summed over every rank's views by the multi-view SH backward: identical on all ranks
+            self.bucket.views[0].add_(self._pending_v_dirs)
         self._bilateral_step()
         for p, gv in zip(params, self.bucket.views):
             p.grad = gv

@@ -313,3 +313,75 @@ def test_early_segment_all_reduce_equals_the_single_collective():
         assert st["all_reduce"]["calls"] == 2 + 1 + 2 + 1   # two single collectives; the split ones: [0,6N) (+ [14N, 59N) when not skipped); [0,14N) behind the shN chunks
     assert np.array_equal(res[0][1][False][1][2], res[1][1][False][1][2])            # shN summed over both ranks
     assert not np.array_equal(res[0][1][True][1][2], res[1][1][True][1][2])          # ... and left local when deferred
+
+
+# ---- the factored exchange of the replicated layout (dist.ColorGradExchange, round 4) ------------------------------------------------------------------------
+def _factored_worker(rank, world, port, q, N, vpr):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import oracle
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import dist as ld
+    ld.init_distributed(backend="gloo")
+    fwd, bwd, _, bwd_views = _sh_standins(oracle)
+    N, K, deg, means, sh0, shN, viewmats, radii, v_colors = _sh_problem(world * vpr, N)
+    ex = ld.ColorGradExchange(N, world, rank, vpr, "cpu")
+    # what trainer._step_cxx_factored does per view: the rendering rank masks its dL/dcolour rows with visibility (rows of invisible Gaussians are zero: the
+    # rasterizer never touched them) and with the clamp of ITS colours; the rasterizer's own dL/dmeans goes into the bucket
+    g_means, g_other = torch.zeros(N, 3), torch.zeros(N, 8)
+    for k in range(vpr):
+        my = rank * vpr + k
+        c = fwd(deg, means, viewmats[my], sh0, shN, radii[my])
+        vis = (radii[my] > 0).all(-1, keepdim=True)
+        ex.send[k] = v_colors[my] * vis * (c > 0)
+        g_means += 1.0 + rank          # stands for the rasterizer part of dL/dmeans of this view
+        g_other += float(my + 1)       # ... and for scales / quaternions / opacities
+    bucket = ld.GradBucket([g_means, torch.zeros(N, 1, 3), torch.zeros(N, K - 1, 3), g_other], deferred=[1, 2])
+    bucket.gather([g_means, None, None, g_other])
+    rows = ex.gather()
+    bucket.all_reduce_early([0, 3])
+    vms = torch.cat([viewmats[j] for j in range(world * vpr)])            # rank-major: view k of rank r at r * vpr + k
+    ones = torch.ones(world * vpr, N, 2, dtype=torch.int32)              # the pre-masked form needs neither radii nor colours: all-visible, all-positive stand-ins
+    ex.v_dirs.zero_()
+    bwd_views(deg, means, vms, sh0, shN, ones, torch.ones(world * vpr, N, 3), rows, bucket.views[1], bucket.views[2], ex.v_dirs, False)
+    bucket.all_reduce(skip_deferred=True)
+    bucket.views[0].add_(ex.v_dirs)
+    q.put((rank, [v.numpy().copy() for v in bucket.views]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,vpr", [(2, 203, 1), (3, 57, 2), (4, 31, 1)])
+def test_factored_color_gradient_exchange_matches_replicated_computation(world, N, vpr):
+    """Replicated layout, two ways to get the SH gradients onto every rank: (reference) each rank runs the SH backward of its own views and the [N,K,3] gradients
+    are summed over the ranks - what the flat all-reduce does; (factored) the ranks all-gather clamp-masked dL/dcolour rows and each runs the multi-view backward
+    over ALL views. Same sh0 / shN gradients and the same dL/dmeans (rasterizer part through the all-reduce + direction term from the multi-view pass) up to
+    summation order, and BIT-identical across the ranks."""
+    import oracle
+    oracle.lib()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32100 + (os.getpid() % 2000) + 13 * world + vpr
+    procs = [ctx.Process(target=_factored_worker, args=(r, world, port, q, N, vpr)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fwd, bwd, _, _ = _sh_standins(oracle)
+    N, K, deg, means, sh0, shN, viewmats, radii, v_colors = _sh_problem(world * vpr, N)
+    ref_sh0, ref_shN, ref_means, ref_other = torch.zeros(N, 1, 3), torch.zeros(N, K - 1, 3), torch.zeros(N, 3), torch.zeros(N, 8)
+    for rank in range(world):
+        for k in range(vpr):
+            my = rank * vpr + k
+            c = fwd(deg, means, viewmats[my], sh0, shN, radii[my])
+            bwd(deg, means, viewmats[my], sh0, shN, radii[my], c, v_colors[my], ref_sh0, ref_shN, ref_means, True)
+            ref_means += 1.0 + rank
+            ref_other += float(my + 1)
+    for rank in range(world):
+        g_means, g_sh0, g_shN, g_other = results[rank][1]
+        assert np.allclose(g_means, ref_means.numpy(), atol=2e-5) and np.allclose(g_sh0, ref_sh0.numpy(), atol=2e-5) and np.allclose(g_shN, ref_shN.numpy(), atol=2e-5)
+        assert np.array_equal(g_other, ref_other.numpy())
+        for a, b in zip(results[0][1], results[rank][1]):
+            assert np.array_equal(a, b), "replicas must stay bit-identical"
+    assert float(np.abs(ref_shN.numpy()).max()) > 0

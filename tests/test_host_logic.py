@@ -158,6 +158,13 @@ def test_step_plan_table():
     assert plan_step(**dict(base, cxx_step=False)).path == "py_views" and plan_step(**dict(base, cxx_step=False)).inline_all
     assert plan_step(**dict(base, rasterizer="fastgs")).path == "fastgs" and plan_step(**dict(base, fused_l2=False)).path == "autograd"
     assert plan_step(**dict(base, world=1, force_collectives=True)).path == "cxx_views"           # one GPU running the multi-rank code path
+    # the factored SH exchange (round 4): a variant of the replicated multi-rank layout only
+    p = plan_step(**dict(base, world=8, factored_sh=True))
+    assert p.path == "cxx_factored" and p.inline_shN and p.skip_deferred and p.multi               # shN updated inside the multi-view SH backward, never all-reduced
+    assert plan_step(**dict(base, world=8, factored_sh=True, iteration=500)).inline_shN is False    # Adam does not read shN yet
+    assert plan_step(**dict(base, world=8, factored_sh=True, strategy="mcmc", loss="l1_ssim", refining=True)).inline_shN is False
+    assert plan_step(**dict(base, world=1, factored_sh=True)).path == "cxx_all"                     # one rank: nothing to exchange
+    assert plan_step(**dict(base, world=1, force_collectives=True, factored_sh=True)).path == "cxx_factored"
     # invariants over the whole table
     n = 0
     for (world, force, sharded, n_views, loss, strategy, refining, iteration, has_shN, fused, bilateral, i_shN, i_all, cxx, batch) in itertools.product(
