@@ -283,9 +283,29 @@ def main() -> None:
     # Gaussian in the all-reduce) is measured right after it and reported beside it under "sh_sharded"; --sh-sharded / --replicated restrict the run to one.
     # Round 4: a third layout, "factored" - replicated Gaussians as the north star says, but the SH gradients travel as dL/dcolour rows (all-gather) and are assembled
     # by every rank (dist.ColorGradExchange): 11 instead of 59 floats per Gaussian in the all-reduce. It is measured beside the other two; --factored makes it the headline.
+    # Which of the two exchanges of the replicated layout is the HEADLINE at N > 1: the factored one moves world x views_per_rank x 12 bytes per Gaussian, the flat
+    # all-reduce ~2 x 236 whatever the number of views - factored while world x views_per_rank <= 16 (8 GPUs x 1 view: 96 + 44 MB per rank instead of 236 MB through the
+    # ring), flat beyond (BASELINE configs[3]: 64 views per step). --replicated / --factored force one of them; the other is reported beside the headline.
     headline_sharded = bool(args.sh_sharded) and not args.replicated
-    headline_factored = bool(args.factored) and not args.replicated and not headline_sharded and (world > 1 or bool(os.environ.get("LFS_DIST_FORCE_COLLECTIVES")))
+    forced = bool(os.environ.get("LFS_DIST_FORCE_COLLECTIVES"))
+    auto_factored = lambda vpr: world > 1 and world * vpr <= 16
+    headline_factored = (not args.replicated and not headline_sharded and args.rasterizer == "gut" and args.path == "step"
+                         and ((bool(args.factored) and (world > 1 or forced)) or (not args.factored and auto_factored(args.views_per_rank))))
     trainer = make_trainer(headline_sharded, headline_factored)
+    if headline_factored and not args.factored:
+        # the factored exchange has never run between two GPUs (no multi-GPU box was ever available to this repository): one guarded trial step, on EVERY rank, before
+        # anything is timed; if any rank's collective library refuses it the headline falls back to the flat all-reduce and says so
+        ok = 1
+        try:
+            trainer.iteration = args.start_iteration
+            trainer.train_step([scenes.target_image(scene.height, scene.width, seed=43).to(device)])
+            torch.cuda.synchronize()
+        except RuntimeError:
+            ok = 0
+        flag = torch.tensor([float(ok)], device=device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        trainer = make_trainer(False, float(flag) == 1.0)   # (a fresh model either way: the trial step updated the parameters)
+        headline_factored = float(flag) == 1.0
     if args.strategy == "mcmc" and args.start_iteration == 3000:
         # the warm-up must contain one refinement step (iteration 3000: relocation + its torch index kernels, whose first use loads ~20 code
         # objects at 20 - 200 ms each); the timed window then holds warm steps only, one of them (every 100th) a refinement step
@@ -328,19 +348,21 @@ def main() -> None:
         return line
 
     sharded_line = factored_line = config4_line = None
-    multi_default = world > 1 and not args.replicated and not args.sh_sharded and not args.factored and args.rasterizer == "gut" and args.strategy == "none"
+    multi_default = world > 1 and not args.replicated and not args.sh_sharded and not args.factored and args.rasterizer == "gut" and args.strategy == "none" and args.path == "step"
     if multi_default:
-        factored_line = side_line(f"dp{world}-replicated-factored-sh", False, True)
+        # the OTHER exchange of the replicated layout, then the SH-sharded layout
+        factored_line = side_line(f"dp{world}-replicated-flat-all-reduce", False, False) if headline_factored else side_line(f"dp{world}-replicated-factored-sh", False, True)
         sharded_line = side_line(f"dp{world}-sh-sharded", True, False)
         if not args.no_config4 and args.workload == "syn-b":
-            # BASELINE.json configs[3]: replicated 3 M Gaussians, 1600x1200, 8 views per rank and step (64 at 8 GPUs), factored exchange - the configuration the
-            # ">= 6x at 8 GPUs" target is stated for: 8 views of compute per collective instead of 1
+            # BASELINE.json configs[3]: replicated 3 M Gaussians, 1600x1200, 8 views per rank and step (64 at 8 GPUs) - the configuration the ">= 6x at 8 GPUs"
+            # target is stated for: 8 views of compute per collective instead of 1 (64 views: the flat all-reduce, see above)
             try:
                 sc4 = scenes.syn_c()
-                config4_line = side_line(f"dp{world}-replicated-factored-sh", False, True, sc=sc4, vpr=8)
+                f4 = auto_factored(8)
+                config4_line = side_line(f"dp{world}-replicated-" + ("factored-sh" if f4 else "flat-all-reduce"), False, f4, sc=sc4, vpr=8)
                 del sc4
             except Exception as e:   # (memory on a small box, ...): reported, not fatal
-                config4_line = {"parallelism": f"dp{world}-replicated-factored-sh", "value": None, "failed": str(e).splitlines()[0][:200]}
+                config4_line = {"parallelism": f"dp{world}-replicated", "value": None, "failed": str(e).splitlines()[0][:200]}
 
     refine_ms = None
     if args.strategy == "mcmc" and world == 1:   # one refinement step on its own (relocation of the dead Gaussians + the step around it)
@@ -437,7 +459,7 @@ def main() -> None:
         "config": {"rasterizer": args.rasterizer, "workload": f"{scene.name}: {N} Gaussians, {scene.width}x{scene.height}, SH degree {scene.sh_degree}, "
                                f"16x16 tiles, {n_views} orbit cameras, {'MSE' if args.loss == 'mse' else 'L1 + 0.2 D-SSIM'} loss, default_optimization_params lrs",
                    "global_batch": world * args.views_per_rank, "views_per_rank": args.views_per_rank,
-                   "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ("-replicated-factored-sh" if trainer.factored_sh and (world > 1 or os.environ.get("LFS_DIST_FORCE_COLLECTIVES")) else ("-replicated" if world > 1 else ""))),
+                   "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ("-replicated-factored-sh" if trainer.factored_sh and (world > 1 or os.environ.get("LFS_DIST_FORCE_COLLECTIVES")) else ("-replicated-flat-all-reduce" if world > 1 else ""))),
                    "path": args.path, "start_iteration": args.start_iteration,
                    "strategy": args.strategy, "bilateral_grid": bool(args.bilateral_grid), "refine_step_ms": None if refine_ms is None else round(refine_ms, 3),
                    "visible_gaussians": V, **({"visible_gaussians_source": v_source} if v_source else {}), "n_isects": I},
@@ -445,7 +467,7 @@ def main() -> None:
                         "per_step": {k: {"calls": v["calls"] / args.steps, "MB": round(v["bytes"] / args.steps / 1e6, 3), "ms": round(coll_ms.get(k, 0.0), 4)} for k, v in coll.items()}},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel, "library": capi.load_library().lfs_version().decode(),
         **({"sh_sharded": sharded_line} if sharded_line is not None else {}),
-        **({"factored_sh": factored_line} if factored_line is not None else {}),
+        **({"replicated_other_exchange": factored_line} if factored_line is not None else {}),
         **({"config4": config4_line} if config4_line is not None else {}),
     }
     # C-level stdout first (RCCL prints its version banner through stdio; on a pipe that buffer would otherwise be flushed at exit, after our line):
