@@ -915,7 +915,7 @@ def ref_links_fused_adam_steps(params, grads, lrs, iteration0, n_steps):
 
 
 def ref_links_mse_train_steps(mode, means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, gt_image, lrs,
-                              iteration0, n_steps):
+                              iteration0, n_steps, timed_from=-1):
     """`n_steps` MSE training steps on the reference's own SplatData / Camera / FusedAdam objects in libref_links_gpu.so: mode 0 = the reference's sequence (rasterize()
     -> mse_loss -> backward -> FusedAdam::step -> zero_grad), mode 1 = INTEGRATION.md §1b's patch (optimizer state read with FusedAdam's real members, the step as one
     lfs::GutTrainStep::step call) -> dict(params [6], exp_avg [6], exp_avg_sq [6], losses [n_steps], n_isects)"""
@@ -926,13 +926,14 @@ def ref_links_mse_train_steps(mode, means, sh0, shN, scaling, rotation, opacity,
     R, T, gt = _f32(R), _f32(T), _f32(gt_image)
     bg = None if bg is None else _f32(bg)
     ptrs = lambda arrs: (C.c_void_p * 6)(*[a.ctypes.data for a in arrs])
-    losses, n_isects = np.zeros(n_steps, np.float32), C.c_int64(-1)
+    losses, n_isects, ms = np.zeros(n_steps, np.float32), C.c_int64(-1), C.c_double(0.0)
     rc = lib.reflink_mse_train_steps(C.c_int(mode), C.c_int64(N), C.c_int64(K1), C.c_int(sh_degree), C.c_int(active_sh_degree), ptrs(p), _p(R), _p(T), C.c_float(fx),
                                      C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_int(width), C.c_int(height), None if bg is None else _p(bg), _p(gt),
-                                     (C.c_double * 6)(*[float(x) for x in lrs]), C.c_int(iteration0), C.c_int(n_steps), _p(losses), ptrs(m), ptrs(v), C.byref(n_isects))
+                                     (C.c_double * 6)(*[float(x) for x in lrs]), C.c_int(iteration0), C.c_int(n_steps), _p(losses), ptrs(m), ptrs(v), C.byref(n_isects),
+                                     C.c_int(timed_from), C.byref(ms))
     if rc:
         raise RuntimeError("reflink_mse_train_steps failed")
-    return dict(params=p, exp_avg=m, exp_avg_sq=v, losses=losses, n_isects=n_isects.value)
+    return dict(params=p, exp_avg=m, exp_avg_sq=v, losses=losses, n_isects=n_isects.value, ms_per_step=(ms.value if timed_from >= 0 else None))
 
 
 def ref_render_backward(means, sh0, shN, scaling, rotation, opacity, sh_degree, active_sh_degree, R, T, fx, fy, cx, cy, width, height, bg, v_image, v_alpha=None,

@@ -351,9 +351,13 @@ REF_API int reflink_fused_adam_steps(const int64_t* sizes, float* const* params,
 //           lfs::GutTrainStep::step (include/lfs_gut_train_step.hpp).
 // Both leave parameters and moments in the same FusedAdam / SplatData objects, which are read back: tests/test_gpu_reference_links.py holds mode 1 to mode 0.
 #include "lfs_gut_train_step.hpp"
+#include <chrono>
+#include <torch/cuda.h>
 REF_API int reflink_mse_train_steps(int mode, int64_t N, int64_t K1, int sh_degree, int active_sh_degree, float* const* params, const float* R, const float* T, float fx,
                                     float fy, float cx, float cy, int width, int height, const float* bg, const float* gt_image, const double* lrs, int iteration0,
-                                    int n_steps, float* losses, float* const* exp_avg, float* const* exp_avg_sq, int64_t* n_isects_out) {
+                                    int n_steps, float* losses, float* const* exp_avg, float* const* exp_avg_sq, int64_t* n_isects_out, int timed_from, double* ms_per_step) {
+    // timed_from >= 0 / ms_per_step: wall time per step of steps [timed_from, n_steps), device-synchronised at both ends (the loss value is then NOT read back per step -
+    // the reference's trainer reads it only for its progress bar)
     try {
         using FusedAdam = gs::training::FusedAdam;
         auto req = [](torch::Tensor t) { return t.set_requires_grad(true); };
@@ -375,15 +379,18 @@ REF_API int reflink_mse_train_steps(int mode, int64_t N, int64_t K1, int sh_degr
         FusedAdam optimizer(std::move(groups), std::move(global_options));
         lfs::GutTrainStep gut_step;
         torch::Tensor loss_scalar = torch::zeros({1}, gt.options());
+        std::chrono::steady_clock::time_point t0;
+        const bool timing = ms_per_step != nullptr && timed_from >= 0 && timed_from < n_steps;
         for (int k = 0; k < n_steps; ++k) {
             const int iter = iteration0 + k;
+            if (timing && k == timed_from) { torch::cuda::synchronize(); t0 = std::chrono::steady_clock::now(); }
             if (mode == 0) {
                 auto out = gs::training::rasterize(cam, model, bgc, 1.0f, false, false, gs::training::RenderMode::RGB, nullptr);
                 auto loss = torch::mse_loss(out.image, gt);
                 loss.backward();
                 optimizer.step(iter);
                 optimizer.zero_grad(true, iter);
-                losses[k] = loss.item<float>();
+                if (!timing) losses[k] = loss.item<float>();
             } else {
                 TORCH_CHECK(iter > 1000, "the one-call step updates all six groups: FusedAdam skips shN up to iteration 1000 (fused_adam.cpp:68-70) - use the split form there");
                 std::array<lfs::AdamGroupState, 6> adam;
@@ -409,8 +416,12 @@ REF_API int reflink_mse_train_steps(int mode, int64_t N, int64_t K1, int sh_degr
                 *n_isects_out = gut_step.step(model.means(), model.sh0(), model.shN(), model.scaling_raw(), model.rotation_raw(), model.opacity_raw(), adam,
                                               (uint32_t)model.get_active_sh_degree(), viewmat, Kmat, (uint32_t)width, (uint32_t)height,
                                               bgc.defined() ? at::optional<torch::Tensor>(bgc) : at::nullopt, gt, 1.f, loss_scalar);
-                losses[k] = loss_scalar.item<float>();
+                if (!timing) losses[k] = loss_scalar.item<float>();
             }
+        }
+        if (timing) {
+            torch::cuda::synchronize();
+            *ms_per_step = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / double(n_steps - timed_from);
         }
         for (int g = 0; g < 6; ++g) {
             put(*tensors[g], params[g]);

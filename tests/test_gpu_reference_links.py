@@ -182,3 +182,34 @@ def test_integration_patch_with_fused_adams_real_members_equals_the_references_o
         frac = float((np.abs(pa - pb) > tol).mean())
         print(f"patched vs reference sequence {key}: largest update {upd:.3e}, max diff {np.abs(pa - pb).max():.3e}, beyond tolerance {frac:.2e}")
         assert frac < 1e-3, (key, frac)
+
+
+@have
+@pytest.mark.gpu
+def test_reference_trainer_sequence_at_the_benchmark_size_timed(lfs, oracle_mod):
+    """The drop-in route MEASURED on the reference's own code: gs::training::rasterize() + mse_loss + backward() + FusedAdam::step() + zero_grad of the linked library
+    (C++ host code, libtorch autograd, every operator through liblfs_gsplat_torch.so) on SYN-B - 1 M Gaussians, 1920x1080, SH degree 3, iteration 3000 - and the
+    one-call patch of INTEGRATION.md 1b beside it. Writes gpurun_out/reference_links_synb_timing.json (copied to profiles/ by the round's scripts); asserts only
+    that both run and agree on the first loss. What the two numbers mean is in INTEGRATION.md."""
+    import json
+    from lichtfeld_studio_amd import scenes
+    sc = scenes.syn_b(n=1_000_000, n_views=1)
+    vm = sc.viewmats[0].numpy()
+    R, T = vm[:3, :3].copy(), vm[:3, 3].copy()
+    K = sc.Ks[0].numpy()
+    target = scenes.target_image(sc.height, sc.width, seed=43).numpy()
+    lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 5e-3, 1e-3, 5e-2]
+    args = (sc.means.numpy(), sc.sh0.numpy(), sc.shN.numpy(), sc.raw_scales.numpy(), sc.raw_quats.numpy(), sc.raw_opacities.numpy(), 3, 3, R, T, float(K[0, 0]), float(K[1, 1]),
+            float(K[0, 2]), float(K[1, 2]), sc.width, sc.height, (0.0, 0.0, 0.0), target, lrs, 3000)
+    first = [oracle_mod.ref_links_mse_train_steps(mode, *args, 1)["losses"][0] for mode in (0, 1)]
+    assert first[0] > 0 and abs(first[0] - first[1]) <= 2e-6 * first[0], first
+    out = {"workload": "SYN-B view 0: 1000000 Gaussians, 1920x1080, SH degree 3, MSE, iteration 3000 (all six groups in Adam)", "steps_timed": 20, "warmup": 5}
+    for mode, name in ((0, "reference_sequence_ms_per_step"), (1, "one_call_patch_ms_per_step")):
+        out[name] = round(oracle_mod.ref_links_mse_train_steps(mode, *args, 25, timed_from=5)["ms_per_step"], 4)
+    out["reference_sequence_img_per_s"] = round(1e3 / out["reference_sequence_ms_per_step"], 1)
+    out["one_call_patch_img_per_s"] = round(1e3 / out["one_call_patch_ms_per_step"], 1)
+    print("linked reference on SYN-B:", out)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "reference_links_synb_timing.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    assert out["one_call_patch_ms_per_step"] < out["reference_sequence_ms_per_step"]
