@@ -431,9 +431,12 @@ def main() -> None:
                 # vector ALUs were issuing, from the PMC pass (SQ_INSTS_VALU wave-instructions x 4 cycles on a SIMD16, 1024 SIMDs, 2.4 GHz)
                 valu = tj.get(f"{args.workload}:{N}", {}).get("_valu_insts", {}).get(dom)
                 if valu is not None:
-                    roofline["valu"] = {"wave_insts_per_launch": valu, "issue_ms": round(valu * 4 / 1024 / 2.4e9 * 1e3, 4),
-                                        "issue_frac_of_launch": round(valu * 4 / 1024 / 2.4e9 / avg_s, 4),
-                                        "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/), 4 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz"}
+                    # the clock the rasterizer kernels actually run at: 2.0 - 2.2 GHz (profiles/r03/clock_pass_grbm.txt: GRBM_GUI_ACTIVE / SQ_BUSY_CYCLES per launch against the
+                    # launch durations), not the 2.4 GHz peak - priced at the 2.4 GHz of rounds 1 - 3 this line understated how close to the issue limit the kernel is
+                    ghz = 2.1e9
+                    roofline["valu"] = {"wave_insts_per_launch": valu, "issue_ms": round(valu * 4 / 1024 / ghz * 1e3, 4),
+                                        "issue_frac_of_launch": round(valu * 4 / 1024 / ghz / avg_s, 4),
+                                        "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/), 4 cycles per wave64 instruction, 1024 SIMDs, 2.1 GHz (measured under this kernel: profiles/r03/clock_pass_grbm.txt)"}
             except Exception:
                 pass
 
