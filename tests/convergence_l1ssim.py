@@ -151,6 +151,11 @@ def main():
             r["oracle"] = round(eval_psnr(scene_of(init, o), targets), 4)
             r["oracle_psnr_oracle_renderer"] = ores["seeds"][str(seed)]["oracle_psnr_oracle_renderer"]
             r["gap_deterministic_db"] = round(r["hip_deterministic"] - r["oracle"], 4)
+        elif str(seed) in ores.get("seeds", {}):
+            # no stored model for this seed: the oracle's final PSNR as its OWN renderer measured it (the two renderers differ by ~1e-7 in the image: where both
+            # numbers exist they agree to the fourth decimal - seeds 0 - 4 of profiles/r04/convergence_mse_hip_5seeds.json)
+            r["oracle"] = r["oracle_psnr_oracle_renderer"] = ores["seeds"][str(seed)]["oracle_psnr_oracle_renderer"]
+            r["gap_deterministic_db"] = round(r["hip_deterministic"] - r["oracle"], 4)
         out["seeds"][str(seed)] = r
         print(seed, r, flush=True)
     hd = [v["hip_deterministic"] for v in out["seeds"].values()]
@@ -164,8 +169,8 @@ def main():
         # trajectory is a sample - the HIP runs of ONE seed scatter by sigma 0.02 - 0.16 dB between float-atomic orders, and so would two builds of the reference
         ga = [x - v["oracle"] for v in out["seeds"].values() if "oracle" in v for x in v["hip_atomic"]]
         per_seed_atomic = [float(np.mean(v["hip_atomic"])) - v["oracle"] for v in out["seeds"].values() if "oracle" in v]
-        tq = {2: 12.71, 3: 4.303, 4: 3.182, 5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365, 9: 2.306, 10: 2.262}
-        ci = lambda xs: round(float(tq.get(len(xs), 2.0) * np.std(xs, ddof=1) / math.sqrt(len(xs))), 4) if len(xs) > 1 else None
+        from scipy.stats import t as student_t
+        ci = lambda xs: round(float(student_t.ppf(0.975, len(xs) - 1) * np.std(xs, ddof=1) / math.sqrt(len(xs))), 4) if len(xs) > 1 else None
         out["summary"].update(oracle_mean=round(float(np.mean(oo)), 4), oracle_std=round(float(np.std(oo)), 4), mean_gap_db=round(float(np.mean(gaps)), 4),
                               mean_abs_gap_db=round(float(np.mean(np.abs(gaps))), 4), n_seeds_with_oracle=len(oo), mean_gap_ci95_db=ci(gaps),
                               mean_gap_atomic_db=round(float(np.mean(per_seed_atomic)), 4), mean_gap_atomic_ci95_db=ci(per_seed_atomic),

@@ -19,3 +19,48 @@ def test_hip_and_oracle_training_reach_the_same_psnr(lfs, oracle_mod):
     p_hip, p_ora = hip[iters], ora[iters]
     assert p_hip > start + 0.5, (start, p_hip)            # training works
     assert abs(p_hip - p_ora) < 0.05, (p_hip, p_ora)      # and lands where the reference algorithm lands
+
+
+def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs):
+    """BASELINE.json north star: "PSNR within 0.05 dB of reference after 7k iters", on the BENCHMARKED step - clamped MSE through the C++ step driver
+    (lfs_gut_train_step) - against the CPU oracle (the restatement of the reference kernels, pinned to them by tests/golden/refk_*) trained with the same recipe
+    from the same perturbed start for the same 7 000 iterations: tests/golden/convergence_mse_oracle.json holds the oracle's final PSNR per task seed (generated
+    by `tests/convergence_l1ssim.py --oracle --loss mse`, ~6 CPU-minutes per seed). The HIP side runs here in the DETERMINISTIC accumulation mode (debug bit 4:
+    bit-identical run to run, so this assertion is not a coin flip). One trajectory is a sample - float-atomic runs of ONE seed scatter by sigma ~0.1 dB, single
+    seeds land on both sides of the oracle by up to 0.3 dB - so the criterion is evaluated on the mean over the seeds; the 95 % interval is printed."""
+    import json
+    import math
+    import os
+    import convergence_check as cc
+    from lichtfeld_studio_amd import scenes
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    here = os.path.dirname(os.path.abspath(__file__))
+    ores = json.load(open(os.path.join(here, "golden", "convergence_mse_oracle.json")))["seeds"]
+    seeds = sorted(int(k) for k in ores)[:int(os.environ.get("LFS_PSNR_SEEDS", "10"))]
+    dev = torch.device("cuda:0")
+    lib = lfs.load_library()
+    gaps = []
+    try:
+        lib.lfs_set_debug_flags(16)
+        for seed in seeds:
+            gt, init = cc.make_task(seed=100 + seed)
+            targets = cc.render_views_hip(gt, dev)
+            tr = GutTrainer(init, dev, iterations=7000)
+            V = init.viewmats.shape[0]
+            for it in range(7000):
+                tr.train_step([targets[it % V]], views=[it % V])
+            assert tr._gut_step is not None, "the run did not go through the C++ step"
+            m = tr.model
+            fin = scenes.Scene("fin", init.width, init.height, init.sh_degree, m.means.detach(), m.raw_quats.detach(), m.raw_scales.detach(), m.raw_opacities.detach(),
+                               m.sh0.detach(), m.shN.detach(), tr.scene.viewmats, tr.scene.Ks)
+            p = float(np.mean([cc.psnr(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(cc.render_views_hip(fin, dev), targets)]))
+            gaps.append(p - ores[str(seed)]["oracle_psnr_oracle_renderer"])
+            print(f"seed {seed}: HIP {p:.4f} dB, oracle {ores[str(seed)]['oracle_psnr_oracle_renderer']:.4f} dB, gap {gaps[-1]:+.4f}")
+    finally:
+        lib.lfs_set_debug_flags(0)
+    mean = float(np.mean(gaps))
+    from scipy.stats import t as student_t
+    ci = float(student_t.ppf(0.975, len(gaps) - 1)) * float(np.std(gaps, ddof=1)) / math.sqrt(len(gaps))
+    print(f"PSNR after 7000 iterations, {len(gaps)} seeds: mean gap {mean:+.4f} dB (95 % interval +- {ci:.3f}), single seeds {min(gaps):+.3f} .. {max(gaps):+.3f}")
+    assert min(gaps) > -1.0 and all(np.isfinite(gaps))
+    assert abs(mean) <= 0.05, (mean, ci, gaps)
