@@ -326,7 +326,7 @@ class GutTrainer:
             views = lfs_dist.views_for_step(self.iteration - 1, self.rank, self.world, self.scene.viewmats.shape[0], self.views_per_rank)
         self._views_all = views_all
         total_views = self.world * len(views)
-        plan = self._plan(len(views))
+        plan = self.last_plan = self._plan(len(views))   # (kept for tests and tools: which form the step took)
         if plan.path == "fastgs":
             return self._train_step_fastgs(targets, views, total_views)
         if plan.path == "autograd":
