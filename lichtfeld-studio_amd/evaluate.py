@@ -39,14 +39,22 @@ class EvalMetrics:
 
 
 @torch.no_grad()
-def evaluate(model, cameras: List, images: List[torch.Tensor], iteration: int = 0, background: Optional[torch.Tensor] = None) -> EvalMetrics:
-    """cameras: rasterizer.Camera per validation view; images: the ground truth [3,H,W] in [0,1]."""
+def evaluate(model, cameras: List, images: List[torch.Tensor], iteration: int = 0, background: Optional[torch.Tensor] = None,
+             rasterizer: str = "fastgs") -> EvalMetrics:
+    """cameras: rasterizer.Camera per validation view; images: the ground truth [3,H,W] in [0,1]. rasterizer="fastgs" is the reference's protocol
+    (metrics.cpp:430 renders with fast_rasterize whatever was trained with); "gut" renders with the 3DGUT rasterizer instead - what a model trained with
+    --gut was optimised for: 3DGUT has no screen-space dilation, the EWA renderer adds its 0.3-pixel low-pass to Gaussians the training shrank below a
+    pixel (profiles/r04/scale_train_*: up to 13 dB between the two numbers on an MCMC model with noise injection)."""
     from .fastgs import fast_rasterize
+    from .rasterizer import rasterize
+    if rasterizer not in ("fastgs", "gut"):
+        raise ValueError("rasterizer must be 'fastgs' or 'gut'")
+    render = fast_rasterize if rasterizer == "fastgs" else rasterize
     dev = model.means.device
     bg = background if background is not None else torch.zeros(3, device=dev)
     ps, ss = [], []
     for cam, gt in zip(cameras, images):
-        img = torch.clamp(fast_rasterize(cam, model, bg).image, 0.0, 1.0)
+        img = torch.clamp(render(cam, model, bg).image, 0.0, 1.0)
         ps.append(psnr(img, gt.to(dev)))
         ss.append(ssim(img, gt.to(dev)))
     n = max(len(ps), 1)

@@ -80,6 +80,9 @@ def main():
             images.append(img)
         m = evaluate.evaluate(tr.model, cameras, images, args.iterations)
         out.update(psnr=round(m.psnr, 4), ssim=round(m.ssim, 5), val_images=m.n_images)
+        if args.gut:   # the reference's protocol above renders with the EWA rasterizer; this is the renderer the model was trained with
+            mg = evaluate.evaluate(tr.model, cameras, images, args.iterations, rasterizer="gut")
+            out.update(psnr_gut=round(mg.psnr, 4), ssim_gut=round(mg.ssim, 5))
     os.makedirs(args.output_path, exist_ok=True)
     ply = os.path.join(args.output_path, f"splat_{args.iterations}.ply")
     loader.save_ply(tr.model, ply)
