@@ -224,7 +224,7 @@ def _sh_worker(rank, world, port, q, N=203):
 import pytest
 
 
-@pytest.mark.parametrize("world,N", [(2, 203), (3, 5), (4, 3)])      # uneven shards; more ranks than rows per shard; a rank that owns nothing
+@pytest.mark.parametrize("world,N", [(2, 203), (3, 5), (4, 3), (8, 29)])      # uneven shards; more ranks than rows per shard; a rank that owns nothing; 8 ranks
 def test_sh_sharded_exchange_matches_replicated_computation(world, N):
     import oracle
     oracle.lib()
@@ -350,7 +350,7 @@ def _factored_worker(rank, world, port, q, N, vpr):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,N,vpr", [(2, 203, 1), (3, 57, 2), (4, 31, 1)])
+@pytest.mark.parametrize("world,N,vpr", [(2, 203, 1), (3, 57, 2), (4, 31, 1), (8, 41, 1)])   # (8 ranks x 1 view: what `bench.py --gpus 8` runs)
 def test_factored_color_gradient_exchange_matches_replicated_computation(world, N, vpr):
     """Replicated layout, two ways to get the SH gradients onto every rank: (reference) each rank runs the SH backward of its own views and the [N,K,3] gradients
     are summed over the ranks - what the flat all-reduce does; (factored) the ranks all-gather clamp-masked dL/dcolour rows and each runs the multi-view backward
