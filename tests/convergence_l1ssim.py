@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--iters", type=int, default=ITERS)
     ap.add_argument("--loss", choices=["l1_ssim", "mse"], default="l1_ssim", help="mse: the loss of the BENCHMARKED step (SURVEY.md 8d), HIP side through the C++ step driver")
     ap.add_argument("--atomic-runs", type=int, default=3)
+    ap.add_argument("--det-runs", type=int, default=2, choices=[1, 2], help="2: the deterministic mode is run twice and the two results compared bit for bit")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02", "convergence_l1ssim_oracle.json"))
     ap.add_argument("--oracle-json", default=os.path.join(ROOT, "profiles", "r02", "convergence_l1ssim_oracle.json"))
     args = ap.parse_args()
@@ -143,8 +144,10 @@ def main():
         o = dict(np.load(f)) if os.path.exists(f) else None
         targets = render_views_hip(gt, dev)
         r = {"psnr_start": round(eval_psnr(init, targets), 4)}
-        d1, d2 = train(init, targets, True), train(init, targets, True)
-        r["deterministic_runs_bit_identical"] = bool(all(np.array_equal(d1[k], d2[k]) for k in NAMES))
+        d1 = train(init, targets, True)
+        if args.det_runs == 2:
+            d2 = train(init, targets, True)
+            r["deterministic_runs_bit_identical"] = bool(all(np.array_equal(d1[k], d2[k]) for k in NAMES))
         r["hip_deterministic"] = round(eval_psnr(scene_of(init, d1), targets), 4)
         r["hip_atomic"] = [round(eval_psnr(scene_of(init, train(init, targets, False)), targets), 4) for _ in range(args.atomic_runs)]
         if o is not None:
