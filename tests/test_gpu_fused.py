@@ -377,7 +377,8 @@ def test_fused_finish_grads_matches_finish_plus_activation_backward(lfs):
         lib.lfs_set_debug_flags(0)
     for loss in ("mse", "l1_ssim"):
         (a, la), (b, lb) = res[(loss, True)], res[(loss, False)]
-        assert abs(la - lb) <= 1e-6 * abs(lb) and la > 0   # (the 256 partial sums of the loss are folded in a different order: one ulp)
+        assert la > 0
+        noise_check(f"finish-kernel forms, loss value {loss}", abs(la - lb) / abs(lb), 4e-6)   # (the 256 partial sums of the loss are float atomics: ~1e-7)
         for name, x, y in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], a[0], b[0]):
             assert torch.equal(x, y), (loss, name, float((x - y).abs().max()))
         for name, x, y in zip(["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"], a[1], b[1]):

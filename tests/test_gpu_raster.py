@@ -219,8 +219,8 @@ def _cull_on_off(lfs, fn):
 @pytest.mark.parametrize("kind", ["small", "needles", "huge_and_near", "low_opacity"])
 def test_cell_culling_is_conservative(lfs, oracle_mod, kind):
     """The per-8x8-cell culling (raster_cull_kernel) may only drop entries that cannot reach alpha >= 1/255 on any
-    ray of the cell: forward outputs must be BIT-identical with culling on and off, the backward equal up to the
-    float-atomic summation order."""
+    ray of the cell: forward outputs must be BIT-identical with culling on and off; the backward BIT-identical in the deterministic accumulation mode
+    (order-independent integer sums: a culled entry contributes nothing either way), and equal up to the float-atomic summation order in the default mode."""
     from lichtfeld_studio_amd import ops
     rng = np.random.default_rng({"small": 40, "needles": 41, "huge_and_near": 42, "low_opacity": 43}[kind])
     N, W, H, ts = 6000, 200, 136, 16
@@ -253,11 +253,22 @@ def test_cell_culling_is_conservative(lfs, oracle_mod, kind):
     assert float(a1.max()) > 0.05, "degenerate scene"
     v_rc, v_ra = t(rng.standard_normal(tuple(r1.shape)).astype(np.float32)), t(rng.standard_normal(tuple(a1.shape)).astype(np.float32))
     bwd = lambda: ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, a1, l1, v_rc, v_ra)
+    lib = lfs.load_library()
+
+    def with_flags(flags):
+        try:
+            lib.lfs_set_debug_flags(flags)
+            return bwd()
+        finally:
+            lib.lfs_set_debug_flags(0)
+    for i, (x_off, x_on) in enumerate(zip(with_flags(16 | 1), with_flags(16))):   # the exact statement
+        assert torch.isfinite(x_on).all()
+        assert torch.equal(x_off, x_on), f"deterministic mode, culling on vs off: bwd[{i}] differs"
     g0, g1 = _cull_on_off(lfs, bwd)
-    g2, g3 = bwd(), bwd()  # run-to-run noise of the float atomics (large and heavy-tailed for ill-conditioned needles: three draws)
-    for i, (x0, x1, x2, x3) in enumerate(zip(g0, g1, g2, g3)):
+    g2, g3, g4 = bwd(), bwd(), bwd()  # run-to-run noise of the float atomics (large and heavy-tailed for ill-conditioned needles: four draws; the bar is wide -
+    for i, (x0, x1, x2, x3, x4) in enumerate(zip(g0, g1, g2, g3, g4)):   # the sharp check is the deterministic one above)
         assert torch.isfinite(x1).all()
-        noise_check(f"cull on/off bwd[{i}] {kind}", rel_l2(n(x0), n(x1)), atomic_noise_bar(x1, x2, x3, floor=5e-5))
+        noise_check(f"cull on/off bwd[{i}] {kind}", rel_l2(n(x0), n(x1)), atomic_noise_bar(x1, x2, x3, x4, floor=5e-5, k=24.0))
 
 
 def test_cell_culling_full_size_bit_identical(lfs):
