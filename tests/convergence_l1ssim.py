@@ -164,19 +164,19 @@ def main():
     hd = [v["hip_deterministic"] for v in out["seeds"].values()]
     ha = [x for v in out["seeds"].values() for x in v["hip_atomic"]]
     out["summary"] = {"hip_deterministic_mean": round(float(np.mean(hd)), 4), "hip_deterministic_std": round(float(np.std(hd)), 4),
-                      "hip_atomic_mean": round(float(np.mean(ha)), 4), "hip_atomic_std": round(float(np.std(ha)), 4)}
+                      "hip_atomic_mean": round(float(np.mean(ha)), 4) if ha else None, "hip_atomic_std": round(float(np.std(ha)), 4) if ha else None}
     oo = [v["oracle"] for v in out["seeds"].values() if "oracle" in v]
     if oo:
         gaps = [v["gap_deterministic_db"] for v in out["seeds"].values() if "oracle" in v]
         # the criterion (BASELINE.json: "PSNR within 0.05 dB of reference after 7k iters") on the MEAN over the seeds, with its 95 % interval (Student t): one
         # trajectory is a sample - the HIP runs of ONE seed scatter by sigma 0.02 - 0.16 dB between float-atomic orders, and so would two builds of the reference
         ga = [x - v["oracle"] for v in out["seeds"].values() if "oracle" in v for x in v["hip_atomic"]]
-        per_seed_atomic = [float(np.mean(v["hip_atomic"])) - v["oracle"] for v in out["seeds"].values() if "oracle" in v]
+        per_seed_atomic = [float(np.mean(v["hip_atomic"])) - v["oracle"] for v in out["seeds"].values() if "oracle" in v and v["hip_atomic"]]
         from scipy.stats import t as student_t
         ci = lambda xs: round(float(student_t.ppf(0.975, len(xs) - 1) * np.std(xs, ddof=1) / math.sqrt(len(xs))), 4) if len(xs) > 1 else None
         out["summary"].update(oracle_mean=round(float(np.mean(oo)), 4), oracle_std=round(float(np.std(oo)), 4), mean_gap_db=round(float(np.mean(gaps)), 4),
                               mean_abs_gap_db=round(float(np.mean(np.abs(gaps))), 4), n_seeds_with_oracle=len(oo), mean_gap_ci95_db=ci(gaps),
-                              mean_gap_atomic_db=round(float(np.mean(per_seed_atomic)), 4), mean_gap_atomic_ci95_db=ci(per_seed_atomic),
+                              mean_gap_atomic_db=round(float(np.mean(per_seed_atomic)), 4) if per_seed_atomic else None, mean_gap_atomic_ci95_db=ci(per_seed_atomic),
                               atomic_runs_within_0p05=int(sum(abs(x) <= 0.05 for x in ga)), atomic_runs=len(ga))
     print(json.dumps(out))
 
