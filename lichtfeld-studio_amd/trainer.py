@@ -149,6 +149,7 @@ class GutTrainer:
         self._gut_step = None         #     False: the same kernels enqueued call by call from Python (fused.py; tests compare the two)
         self.inline_shN_adam = True   # see train_step; False keeps the SH backward and the optimizer separate (tests compare the two)
         self.iteration = 0
+        self.last_plan: Optional[StepPlan] = None   # the form the last step took (plan_step): tests and tools read it
         self.last_n_isects = 0
         self._last_radii = None
         self._last_visible = None
