@@ -24,6 +24,8 @@ struct alignas(8) int2 { int x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+struct alignas(8) ushort4 { unsigned short x, y, z, w; };
+static inline ushort4 make_ushort4(unsigned short x, unsigned short y, unsigned short z, unsigned short w) { return ushort4{x, y, z, w}; }
 typedef int hipError_t;
 typedef void* hipStream_t;
 enum { hipSuccess = 0 };
@@ -35,6 +37,15 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+// events and pinned host memory (csrc/fastgs_prep.hip's count read-back): everything is synchronous here
+typedef void* hipEvent_t;
+enum { hipHostMallocDefault = 0, hipEventDisableTiming = 2 };
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : 2; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = malloc(1); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 
 #define __global__
 #define __device__
@@ -43,6 +54,7 @@ static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hip
 #define __launch_bounds__(...)
 #define __shared__ static
 #define __restrict__ __restrict
+#define __constant__
 
 namespace emu {
 constexpr int MAX_THREADS = 1024, STACK_BYTES = 512 * 1024;
@@ -173,6 +185,11 @@ inline u32x2 permlane16_swap(uint32_t vdst, uint32_t src, bool, bool) {
 
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float __saturatef(float x) { return fminf(fmaxf(x, 0.f), 1.f); }   // (NaN -> 0, as the clamp modifier)
+static inline int __float2int_rd(float x) { return int(floorf(x)); }
+static inline int __float2int_ru(float x) { return int(ceilf(x)); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline uint64_t __ballot(bool p) { return emu::ballot(p); }
 static inline void __syncthreads() { emu::block_barrier(); }
@@ -184,7 +201,10 @@ static inline int __shfl(int v, int src, int = 64) { uint64_t o[2][64]; emu::wav
 static inline uint32_t __shfl(uint32_t v, int src, int = 64) { uint64_t o[2][64]; emu::wave_exchange(uint64_t(v), 0, o); return uint32_t(o[0][src & 63]); }
 static inline float __shfl(float v, int src, int = 64) { uint64_t o[2][64]; emu::wave_exchange(uint64_t(__float_as_uint(v)), 0, o); return __uint_as_float(uint32_t(o[0][src & 63])); }
 static inline unsigned long long __shfl_xor(unsigned long long v, int m, int = 64) { uint64_t o[2][64]; emu::wave_exchange(uint64_t(v), 0, o); return o[0][(int(emu::lane_id()) ^ m) & 63]; }
-#define __builtin_amdgcn_wave_barrier() do { } while (0)
+// On the GPU the lanes of a wavefront execute in lock-step, so LDS written before a wave barrier by one lane is visible to the others after it. Fibers switch only
+// at cross-lane operations: the barrier is one here (every live lane arrives before any continues). It must sit in wave-converged code - as on the GPU.
+#define __builtin_amdgcn_wave_barrier() ((void)emu::ballot(true))
+#define __builtin_amdgcn_fence(...) do { } while (0)
 // __shfl_up: lane i reads lane i - d; lanes below d keep their own value
 static inline uint64_t emu_shfl_up64(uint64_t v, int d) { uint64_t o[2][64]; emu::wave_exchange(v, 0, o); const int l = int(emu::lane_id()); return l >= d ? o[0][l - d] : v; }
 static inline uint64_t __shfl_up(uint64_t v, int d, int = 64) { return emu_shfl_up64(v, d); }
@@ -207,6 +227,7 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __expf(x) expf(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
 #define __builtin_amdgcn_logf(x) log2f(x)
@@ -217,3 +238,18 @@ static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 #define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) emu::permlane16_swap((a), (b), (fi), (bc))
 #define __builtin_amdgcn_mbcnt_lo(mask, x) (uint32_t(x) + uint32_t(__builtin_popcount(uint32_t(mask) & (emu::lane_id() >= 32 ? 0xffffffffu : ((1u << emu::lane_id()) - 1u)))))
 #define __builtin_amdgcn_mbcnt_hi(mask, x) (uint32_t(x) + uint32_t(emu::lane_id() > 32 ? __builtin_popcount(uint32_t(mask) & ((1u << (emu::lane_id() - 32)) - 1u)) : 0))
+// v_mfma_f32_16x16x4_f32: D[16][16] = A[16][4] B[4][16] + C. Lane l holds A[l % 16][l / 16] and B[l / 16][l % 16]; register r of the accumulator holds
+// D[4 * (l / 16) + r][l % 16] (the layout csrc/bilateral_grid.hip's backward relies on). k summed in ascending order with fused multiply-adds.
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+static inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c) {
+    uint64_t o[2][64]; emu::wave_exchange(__float_as_uint(a), __float_as_uint(b), o);
+    const int l = int(emu::lane_id()), j = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(__uint_as_float(uint32_t(o[0][16 * k + i])), __uint_as_float(uint32_t(o[1][16 * k + j])), acc);
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32((a), (b), (c))
