@@ -6,6 +6,7 @@ GPU run of the same functions stays the parity test proper."""
 import importlib
 import os
 import sys
+import types
 
 import pytest
 
@@ -22,6 +23,18 @@ SELECTION = {
     "test_gpu_loss": {"test_photometric_loss_full_size_properties": "1080p images: minutes under emulation",
                       "test_l1_ssim_trainers_agree_and_train": "trainer on a HIP stream"},
     "test_gpu_bilateral": {"test_gut_trainer_with_bilateral_grid_matches_autograd_composition": "trainer on a HIP stream"},
+    "test_gpu_fastgs": {"test_fast_rasterize_autograd_and_full_size": "1 M primitives at 1080p",
+                        "test_fastgs_trainer_step_matches_autograd": "whole training steps: more than a minute each under emulation",
+                        "test_fastgs_trainer_reference_default_configuration": "whole training steps", "test_fastgs_inline_shN_adam_matches_separate_optimizer": "whole training steps"},
+    "test_gpu_dataprep": {"test_colmap_directory_to_training_and_ply": "trainer on a HIP stream", "test_train_colmap_tool_end_to_end": "a subprocess that needs the GPU",
+                          "test_mean_neighbor_distances_large_against_kdtree": "a minute under emulation (the small sizes of the same kernel are taken)"},
+    # every HIP-vs-reference-kernel golden comparison (tests/golden/refk_*.npz, ref_*.npz: outputs of the reference's own kernels / host code run on the CPU)
+    "test_gpu_refk_golden": {"test_hip_rasterization_matches_reference_kernel[syn_a]": "10 000 Gaussians at 256 x 256: half a minute under emulation (nine other cases are taken)"},
+    "test_gpu_strategy_reference": {},
+    "test_gpu_strategies": {"test_default_strategy_fused_refinement_one_host_read_same_result": "counts host synchronisations of a HIP stream",
+                            "test_mcmc_refinement_step_needs_no_host_sync": "counts host synchronisations of a HIP stream",
+                            "test_mcmc_inline_shN_adam_between_refinements_is_bit_identical": "trainer on a HIP stream",
+                            "test_mcmc_training_grows_the_model_and_fits_the_views": "trainer on a HIP stream"},
 }
 if os.environ.get("LFS_EMUL_SUITE_TRY"):   # development: LFS_EMUL_SUITE_TRY=test_gpu_loss,test_gpu_fastgs runs whole modules to see what the emulator can take
     SELECTION = {m: {} for m in os.environ["LFS_EMUL_SUITE_TRY"].split(",")}
@@ -35,6 +48,19 @@ def _emulated_library_and_cpu_tensors():
         yield
 
 
+def _without_cases(fn, dropped):
+    """a copy of the test function whose parametrize marks lack the values in `dropped` (exclusions written as name[case])"""
+    new = types.FunctionType(fn.__code__, fn.__globals__, fn.__name__, fn.__defaults__, fn.__closure__)
+    new.__dict__.update(fn.__dict__)
+    marks = []
+    for m in getattr(fn, "pytestmark", []):
+        if m.name == "parametrize" and isinstance(m.args[0], str) and "," not in m.args[0]:
+            m = pytest.mark.parametrize(m.args[0], [v for v in m.args[1] if str(v) not in dropped], **m.kwargs).mark
+        marks.append(m)
+    new.pytestmark = marks
+    return new
+
+
 _MODULES = []
 for _modname, _excluded in SELECTION.items():
     _mod = importlib.import_module(_modname)
@@ -42,6 +68,7 @@ for _modname, _excluded in SELECTION.items():
     for _n in dir(_mod):
         _obj = getattr(_mod, _n)
         if _n.startswith("test_") and callable(_obj) and _n not in _excluded:
-            globals()[f"test_emulated__{_modname[9:]}__{_n[5:]}"] = _obj
+            _drop = {k[len(_n) + 1:-1] for k in _excluded if k.startswith(_n + "[")}
+            globals()[f"test_emulated__{_modname[9:]}__{_n[5:]}"] = _without_cases(_obj, _drop) if _drop else _obj
         elif hasattr(_obj, "_pytestfixturefunction") or type(_obj).__name__ == "FixtureFunctionDefinition":
             globals().setdefault(_n, _obj)   # the module's own fixtures
