@@ -174,9 +174,29 @@ def cuda_requests_served_by_the_cpu():
     class generator(real_generator):   # (a class, not a function: `torch.Generator | None` annotations are evaluated while it is in place)
         def __new__(cls, device="cpu"):
             return real_generator.__new__(real_generator, "cpu" if _is_cuda(device) else device)
+    class stream:   # what torch.cuda.current_stream() hands out: the emulated kernels have finished when their launch returns
+        cuda_stream = 0
+        def synchronize(self): pass
+        def wait_stream(self, other): pass
+        def wait_event(self, event): pass
+        def record_event(self, event=None): return event
+    class event:    # torch.cuda.Event
+        def __init__(self, *a, **k): pass
+        def record(self, stream=None): pass
+        def synchronize(self): pass
+        def wait(self, stream=None): pass
+        def query(self): return True
+        def elapsed_time(self, other): return 0.0
+    saved = {k: getattr(torch.cuda, k) for k in ("current_stream", "current_device", "set_device", "Event")}
+    torch.cuda.Event = event
     torch.Generator, torch.cuda.synchronize = generator, (lambda *a, **k: None)
+    torch.cuda.current_stream, torch.cuda.current_device, torch.cuda.set_device = (lambda *a, **k: stream()), (lambda: 0), (lambda *a, **k: None)
+    torch.Tensor.is_cuda = property(lambda self: True)   # the host layer's "must be a device tensor" checks (torch.Tensor is a Python class: removed again below)
     try:
         with _CudaToCpu():
             yield
     finally:
+        del torch.Tensor.is_cuda
         torch.Generator, torch.cuda.synchronize = real_generator, real_sync
+        for k, v in saved.items():
+            setattr(torch.cuda, k, v)

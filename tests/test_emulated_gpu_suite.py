@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import emul_util  # noqa: E402
 
-# module -> the tests of it that are NOT taken, each with the reason
+# module -> the tests of it that are NOT taken, each with the reason (dict), or the list of the tests that are
 SELECTION = {
     "test_gpu_small_ops": {},
     "test_gpu_projection_sh": {},
@@ -31,6 +31,11 @@ SELECTION = {
     # every HIP-vs-reference-kernel golden comparison (tests/golden/refk_*.npz, ref_*.npz: outputs of the reference's own kernels / host code run on the CPU)
     "test_gpu_refk_golden": {"test_hip_rasterization_matches_reference_kernel[syn_a]": "10 000 Gaussians at 256 x 256: half a minute under emulation (nine other cases are taken)"},
     "test_gpu_strategy_reference": {},
+    # the Python mirrors of rasterize() / fast_rasterize() and the fused training steps against what the reference's own rasterize() + backward() + train step produced
+    "test_gpu_raster_reference": {},
+    # the rasterizer against the oracle: tests/test_emulated_raster.py and the golden cases above already walk the emulated rasterizer through pinhole / rolling shutter /
+    # channel counts / dense scenes; from the GPU file the cases those do not have (its other tests take 10 - 200 s each under emulation)
+    "test_gpu_raster": ["test_raster_other_tile_sizes", "test_raster_fisheye", "test_raster_opencv_distortion", "test_raster_tile_masks", "test_raster_empty_intersections"],
     "test_gpu_strategies": {"test_default_strategy_fused_refinement_one_host_read_same_result": "counts host synchronisations of a HIP stream",
                             "test_mcmc_refinement_step_needs_no_host_sync": "counts host synchronisations of a HIP stream",
                             "test_mcmc_inline_shN_adam_between_refinements_is_bit_identical": "trainer on a HIP stream",
@@ -67,7 +72,7 @@ for _modname, _excluded in SELECTION.items():
     _MODULES.append(_modname)
     for _n in dir(_mod):
         _obj = getattr(_mod, _n)
-        if _n.startswith("test_") and callable(_obj) and _n not in _excluded:
+        if _n.startswith("test_") and callable(_obj) and (_n in _excluded if isinstance(_excluded, list) else _n not in _excluded):
             _drop = {k[len(_n) + 1:-1] for k in _excluded if k.startswith(_n + "[")}
             globals()[f"test_emulated__{_modname[9:]}__{_n[5:]}"] = _without_cases(_obj, _drop) if _drop else _obj
         elif hasattr(_obj, "_pytestfixturefunction") or type(_obj).__name__ == "FixtureFunctionDefinition":
