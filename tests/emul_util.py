@@ -114,7 +114,7 @@ def installed():
     lib = library()
     pkg = sys.modules["lichtfeld_studio_amd"].__name__
     import importlib
-    mods = [importlib.import_module(f"{pkg}.{m}") for m in ("capi", "ops", "losses", "fastgs", "bilateral_grid", "fused", "fused_adam", "rasterizer", "strategies")]
+    mods = [sys.modules[pkg]] + [importlib.import_module(f"{pkg}.{m}") for m in ("capi", "ops", "losses", "fastgs", "bilateral_grid", "fused", "fused_adam", "rasterizer", "strategies")]
     repl = {
         "load_library": lambda: lib,
         "require_gpu": _require_cpu_contiguous,
