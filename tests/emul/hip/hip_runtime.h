@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <setjmp.h>
 #include <ucontext.h>
 #include <vector>
 
@@ -59,13 +60,24 @@ static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSucc
 namespace emu {
 constexpr int MAX_THREADS = 1024, STACK_BYTES = 512 * 1024;
 struct Wave { uint64_t slot[2][64]; uint64_t live = 0; int nlive = 0, arrived = 0, departed = 0; unsigned gen = 0; };
-struct Fiber { ucontext_t ctx; uint3_emu tid; int flat, lane, wave; bool done; char* stack; };
+// Fiber switches: swapcontext() saves and restores the signal mask with a system call on every switch (~1 us; a rasterizer evaluation makes a dozen cross-lane
+// operations per lane). Each fiber is therefore only ENTERED through its ucontext; every later switch is _setjmp / _longjmp (no signal mask). Under AddressSanitizer
+// (LFS_EMUL_SANITIZE) the plain swapcontext path is kept - ASan follows stack switches through its swapcontext interceptor only.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define LFS_EMU_UCONTEXT_ONLY 1
+#endif
+#endif
+#ifndef LFS_EMU_UCONTEXT_ONLY
+#define LFS_EMU_UCONTEXT_ONLY 0
+#endif
+struct Fiber { ucontext_t ctx; jmp_buf jb; uint3_emu tid; int flat, lane, wave; bool done, started; char* stack; };
 struct Block {
     uint3_emu bid, bdim, gdim;
     Fiber fib[MAX_THREADS];
     Wave waves[MAX_THREADS / 64];
     int nthreads = 0, nlive = 0, bar_arrived = 0, bar_departed = 0; unsigned bar_gen = 0;
-    ucontext_t main_ctx;
+    ucontext_t main_ctx; jmp_buf main_jb;
     uint64_t progress = 0;
     void (*body)(void*) = nullptr; void* body_arg = nullptr;
 };
@@ -73,14 +85,25 @@ inline Block*& blk() { static Block* b = nullptr; return b; }
 inline std::vector<uint64_t>& dyn_store() { static std::vector<uint64_t> v; return v; }
 inline void* dyn_lds() { return dyn_store().data(); }   // the workgroup's dynamic LDS block (LFS_DYN_LDS in csrc/lfs_math.cuh)
 inline Fiber*& cur() { static Fiber* f = nullptr; return f; }
-inline void yield() { Fiber* f = cur(); swapcontext(&f->ctx, &blk()->main_ctx); }
+inline void yield() {
+    Fiber* f = cur();
+#if LFS_EMU_UCONTEXT_ONLY
+    swapcontext(&f->ctx, &blk()->main_ctx);
+#else
+    if (_setjmp(f->jb) == 0) _longjmp(blk()->main_jb, 1);
+#endif
+}
 inline void fiber_entry() {
     Block* b = blk(); Fiber* f = cur();
     b->body(b->body_arg);
     f->done = true;
     Wave& w = b->waves[f->wave];
     w.live &= ~(1ull << f->lane); w.nlive--; b->nlive--; b->progress++;
+#if LFS_EMU_UCONTEXT_ONLY
     swapcontext(&f->ctx, &b->main_ctx);
+#else
+    _longjmp(b->main_jb, 1);
+#endif
 }
 // all live lanes of the wavefront exchange up to two 64-bit payloads; out[k][l] is meaningful where live has bit l
 inline uint64_t wave_exchange(uint64_t a, uint64_t b2, uint64_t (&out)[2][64]) {
@@ -125,7 +148,7 @@ void launch(dim3 grid, dim3 block, size_t shm, F&& f) {
         for (int w = 0; w < (nt + 63) / 64; ++w) { Wave& wv = b->waves[w]; wv.live = 0; wv.nlive = 0; wv.arrived = wv.departed = 0; }
         for (int t = 0; t < nt; ++t) {
             Fiber& fb = b->fib[t];
-            fb.flat = t; fb.lane = t & 63; fb.wave = t >> 6; fb.done = false;
+            fb.flat = t; fb.lane = t & 63; fb.wave = t >> 6; fb.done = false; fb.started = false;
             fb.tid = {unsigned(t) % block.x, (unsigned(t) / block.x) % block.y, unsigned(t) / (block.x * block.y)};
             b->waves[fb.wave].live |= 1ull << fb.lane; b->waves[fb.wave].nlive++;
             getcontext(&fb.ctx);
@@ -140,7 +163,14 @@ void launch(dim3 grid, dim3 block, size_t shm, F&& f) {
                 Fiber& fb = b->fib[t];
                 if (fb.done) continue;
                 cur() = &fb;
+#if LFS_EMU_UCONTEXT_ONLY
                 swapcontext(&b->main_ctx, &fb.ctx);
+#else
+                if (_setjmp(b->main_jb) == 0) {
+                    if (!fb.started) { fb.started = true; setcontext(&fb.ctx); }
+                    _longjmp(fb.jb, 1);
+                }
+#endif
                 if (!fb.done) ++remaining;
             }
             if (remaining > 0 && b->progress == before) {
