@@ -93,6 +93,22 @@ def build() -> str:
     return out
 
 
+class _EmulatedLib:
+    """ctypes library + one adjustment: debug bit 4 (the DETERMINISTIC accumulation mode: integer atomics, compiled out of the emulated build - there is nothing to
+    make deterministic, the emulator executes the wavefronts one after the other) is dropped on its way in, so a test that asks for that mode gets the plain
+    float accumulation - reproducible here - instead of kernels that accumulate nothing."""
+
+    def __init__(self, lib):
+        self.__dict__["_lib"] = lib
+
+    def __getattr__(self, name):
+        return getattr(self._lib, name)
+
+    def lfs_set_debug_flags(self, flags):
+        v = int(getattr(flags, "value", flags))
+        return self._lib.lfs_set_debug_flags(C.c_uint32(v & ~16))
+
+
 def library():
     """the emulated library behind ctypes, with the restypes capi.load_library sets"""
     global _LIB
@@ -102,7 +118,7 @@ def library():
                      "lfs_fastgs_instance_workspace_bytes", "lfs_mcmc_relocate_workspace_bytes", "lfs_rasterize_workspace_acc_offset"):
             getattr(lib, name).restype = C.c_size_t
         lib.lfs_version.restype = C.c_char_p
-        _LIB = lib
+        _LIB = _EmulatedLib(lib)
     return _LIB
 
 

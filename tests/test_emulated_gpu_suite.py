@@ -31,11 +31,23 @@ SELECTION = {
     # every HIP-vs-reference-kernel golden comparison (tests/golden/refk_*.npz, ref_*.npz: outputs of the reference's own kernels / host code run on the CPU)
     "test_gpu_refk_golden": {"test_hip_rasterization_matches_reference_kernel[syn_a]": "10 000 Gaussians at 256 x 256: half a minute under emulation (nine other cases are taken)"},
     "test_gpu_strategy_reference": {},
+    # the benchmarked path: the whole training step as ONE C++ call (csrc/gut_step.hip: lfs_gut_train_step, speculative workspace, pinned counts) against the
+    # Python-enqueued op sequence, bit for bit; its split forms against render_and_backward
+    "test_gpu_gut_step": {"test_cxx_split_step_is_bit_identical_for_the_other_losses_and_mcmc": "40 s per variant (trainer steps with SSIM / bilateral grid / MCMC around the C++ calls)",
+                          "test_overflowing_attempt_updates_nothing_and_is_run_again": "20 - 130 s (the guarded attempt is covered by tests/test_emulated_step_pack.py)"},
+    # one whole training image through the Python mirror (projection -> SH -> intersection -> rasterize -> loss -> backward) against the oracle's pipeline
+    "test_gpu_pipeline": ["test_train_step_gradients_match_oracle", "test_render_modes_and_background_gradient"],
+    # the fused front half / backward / finish / inline-Adam entry points against the op-by-op path, torch autograd and the oracle
+    "test_gpu_fused": {"test_batched_views_step_matches_the_view_by_view_step": "two minutes under emulation", "test_inline_shN_adam_trainer_path_trains": "100 s: dozens of training steps",
+                       "test_all_inline_adam_step_is_bit_identical_to_the_separate_kernels": "a minute", "test_fused_finish_grads_matches_finish_plus_activation_backward": "half a minute",
+                       "test_fused_and_autograd_trainers_take_the_same_steps": "25 s of training steps"},
     # the Python mirrors of rasterize() / fast_rasterize() and the fused training steps against what the reference's own rasterize() + backward() + train step produced
     "test_gpu_raster_reference": {},
-    # the rasterizer against the oracle: tests/test_emulated_raster.py and the golden cases above already walk the emulated rasterizer through pinhole / rolling shutter /
-    # channel counts / dense scenes; from the GPU file the cases those do not have (its other tests take 10 - 200 s each under emulation)
-    "test_gpu_raster": ["test_raster_other_tile_sizes", "test_raster_fisheye", "test_raster_opencv_distortion", "test_raster_tile_masks", "test_raster_empty_intersections"],
+    "test_gpu_raster": {"test_cell_culling_full_size_bit_identical": "1 M Gaussians at 1080p", "test_raster_bwd_is_linear_in_output_gradients_full_size": "1 M Gaussians at 1080p",
+                        "test_deterministic_backward_mode_is_bit_reproducible": "the integer-atomic accumulation mode is compiled out of the emulated build (no 64-bit atomics to model)",
+                        "test_lds_reduction_asm_block_agrees_with_the_compiler_generated_stores": "compares two GPU builds in a subprocess (ISA-level by definition)",
+                        "test_cell_culling_is_conservative[huge_and_near]": "half a minute (culling-off walks of every tile list); [small] and [low_opacity] are taken",
+                        "test_cell_culling_is_conservative[needles]": "as above"},
     "test_gpu_strategies": {"test_default_strategy_fused_refinement_one_host_read_same_result": "counts host synchronisations of a HIP stream",
                             "test_mcmc_refinement_step_needs_no_host_sync": "counts host synchronisations of a HIP stream",
                             "test_mcmc_inline_shN_adam_between_refinements_is_bit_identical": "trainer on a HIP stream",
