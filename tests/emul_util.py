@@ -130,7 +130,9 @@ def installed():
     lib = library()
     pkg = sys.modules["lichtfeld_studio_amd"].__name__
     import importlib
-    mods = [sys.modules[pkg]] + [importlib.import_module(f"{pkg}.{m}") for m in ("capi", "ops", "losses", "fastgs", "bilateral_grid", "fused", "fused_adam", "rasterizer", "strategies")]
+    for m in ("capi", "ops", "losses", "fastgs", "bilateral_grid", "fused", "fused_adam", "rasterizer", "strategies", "gut_step", "trainer"):
+        importlib.import_module(f"{pkg}.{m}")
+    mods = [m for name, m in list(sys.modules.items()) if m is not None and (name == pkg or name.startswith(pkg + "."))]   # every module of the package that holds a loader reference
     repl = {
         "load_library": lambda: lib,
         "require_gpu": _require_cpu_contiguous,

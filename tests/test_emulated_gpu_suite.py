@@ -89,3 +89,23 @@ for _modname, _excluded in SELECTION.items():
             globals()[f"test_emulated__{_modname[9:]}__{_n[5:]}"] = _without_cases(_obj, _drop) if _drop else _obj
         elif hasattr(_obj, "_pytestfixturefunction") or type(_obj).__name__ == "FixtureFunctionDefinition":
             globals().setdefault(_n, _obj)   # the module's own fixtures
+
+
+def test_every_module_of_the_package_talks_to_the_emulated_library():
+    """guards the runs above against being vacuous: a module that kept its reference to the real loader would call the gfx950 library (which fails without a
+    device, or - worse - would not be what these tests claim to exercise)"""
+    import lichtfeld_studio_amd as lfs
+    pkg = lfs.__name__
+    lib = emul_util.library()
+    seen = 0
+    for name, mod in list(sys.modules.items()):
+        if mod is not None and (name == pkg or name.startswith(pkg + ".")) and hasattr(mod, "load_library"):
+            assert mod.load_library() is lib, name
+            seen += 1
+    assert seen >= 8, seen
+    assert lib.lfs_version().decode().endswith("src-unknown")      # the host build (csrc/version.hip without the build's hash), not liblfs_gsplat.so
+    lib.lfs_set_debug_flags(16 | 1)
+    try:
+        assert int(lib.lfs_get_debug_flags()) == 1                  # the integer-atomic mode is not part of an emulated build: its bit never arrives
+    finally:
+        lib.lfs_set_debug_flags(0)
