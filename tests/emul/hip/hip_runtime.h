@@ -19,13 +19,17 @@
 // ---- HIP types ------------------------------------------------------------------------------------------------------
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint3_emu { unsigned x, y, z; };
+// Vector types carry DWORD alignment here: gfx950 serves a global_load / store_dwordx2 / x4 at any 4-byte-aligned address, and the product relies on it in one place -
+// the data-parallel path hands the kernels gradient rows that are views into the flat all-reduce bucket (dist.GradBucket), whose segment offsets are multiples of 4 bytes
+// only when the Gaussian count is odd (found by tests/test_emulated_dp.py: with 16-byte float4 the host compiler emitted an aligned store and the row write of
+// raster_finish_adam_kernel faulted). A host build must therefore not assume more than the GPU guarantees.
 struct float2 { float x, y; };
-struct alignas(16) float4 { float x, y, z, w; };
-struct alignas(8) int2 { int x, y; };
+struct alignas(4) float4 { float x, y, z, w; };
+struct alignas(4) int2 { int x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
-struct alignas(8) ushort4 { unsigned short x, y, z, w; };
+struct alignas(4) ushort4 { unsigned short x, y, z, w; };
 static inline ushort4 make_ushort4(unsigned short x, unsigned short y, unsigned short z, unsigned short w) { return ushort4{x, y, z, w}; }
 typedef int hipError_t;
 typedef void* hipStream_t;
