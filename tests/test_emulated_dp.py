@@ -42,9 +42,9 @@ def _emulated():
         dp2._worker, dp2._mcmc_worker = saved
 
 
-# default: the north-star layout (replicated, flat all-reduce) and the factored exchange bench.py picks up to 16 views per step; LFS_EMUL_DP_ALL=1 adds the SH-sharded
-# layout and three ranks (all four: 3.5 minutes, green at the commit that added this file)
-_CASES = [(False, 2), ("factored", 2)] + ([(True, 2), ("factored", 3)] if os.environ.get("LFS_EMUL_DP_ALL") else [])
+# default: the north-star layout (replicated Gaussians, flat all-reduce with the early SH chunks) on two ranks - 50 s; LFS_EMUL_DP_ALL=1 adds the factored exchange on two
+# and three ranks and the SH-sharded layout (all four: 3.5 minutes, green at the commit that added this file and at the one that set this default)
+_CASES = [(False, 2)] + ([("factored", 2), (True, 2), ("factored", 3)] if os.environ.get("LFS_EMUL_DP_ALL") else [])
 
 
 @pytest.mark.parametrize("sharded,world", _CASES)
