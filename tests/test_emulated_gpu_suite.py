@@ -17,6 +17,7 @@ import emul_util  # noqa: E402
 # module -> the tests of it that are NOT taken, each with the reason (dict), or the list of the tests that are
 SELECTION = {
     "test_gpu_small_ops": {},
+    "test_gpu_zz_edge_sizes": {},
     "test_gpu_projection_sh": {},
     "test_gpu_intersect": {"test_intersect_full_size_properties": "1 M Gaussians: minutes under emulation",
                            "test_two_pass_scatter_equals_one_pass_over_random_shapes": "40 random shapes up to 150 k Gaussians: half a minute; the two-pass scatter is covered by tests/test_emulated_intersect.py"},
