@@ -165,3 +165,58 @@ def test_fastgs_single_primitive_matches_oracle(lfs, oracle_mod):
             print(f"fastgs single primitive, {name}: rel-L2 {e:.2e}")
             assert e < 5e-4, (name, e)
     assert np.array_equal(n(dens)[0], og[6][0].astype(np.float32))
+
+
+def test_mcmc_relocation_without_dead_gaussians_and_growth_at_the_cap_touch_nothing(lfs):
+    """mcmc.cpp:113-194 with an empty dead set (`dead_indices.numel() == 0`: return) and mcmc.cpp:196-340 at `max_cap` (n_new == 0: return): every parameter and
+    every Adam moment keeps its bits; the noise injection that follows still moves the means"""
+    from lichtfeld_studio_amd import strategies
+    from test_gpu_strategies import _model, _prime_optimizer
+    model, dead = _model(N=1500, dead_frac=0.0)
+    assert int(dead.sum()) == 0
+    st = strategies.MCMC(model, strategies.OptimizationParameters(max_cap=1500), generator=torch.Generator(device=model.means.device).manual_seed(3))
+    _prime_optimizer(st)
+    before = {k: n(getattr(model, k)).copy() for k in strategies._PARAM_NAMES}
+    moments = {k: (n(st.optimizer.state[id(getattr(model, k))]["exp_avg"]).copy(), n(st.optimizer.state[id(getattr(model, k))]["exp_avg_sq"]).copy())
+               for k in strategies._PARAM_NAMES}
+    assert int(st.relocate_gs()) == 0
+    assert st.add_new_gs() == 0 and model.means.shape[0] == 1500
+    for k in strategies._PARAM_NAMES:
+        assert np.array_equal(n(getattr(model, k)), before[k]), k
+        s = st.optimizer.state[id(getattr(model, k))]
+        assert np.array_equal(n(s["exp_avg"]), moments[k][0]) and np.array_equal(n(s["exp_avg_sq"]), moments[k][1]), k
+    st.inject_noise()
+    assert not np.array_equal(n(model.means), before["means"])
+    for k in strategies._PARAM_NAMES:
+        if k != "means":
+            assert np.array_equal(n(getattr(model, k)), before[k]), k
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_adc_refinement_with_nothing_to_grow_or_prune_touches_nothing(lfs, fused):
+    """default_strategy.cpp:162-195 / :229-249 when no Gaussian passes the gradient threshold and none is below the pruning opacity (empty duplicate / split / prune
+    sets): the model, the Adam moments and the Gaussian count keep their bits - in the reference's sequence (grow_gs + prune_gs) and in the fused device-side form"""
+    from lichtfeld_studio_amd import strategies
+    from test_gpu_strategies import _model, _prime_optimizer
+    N = 1200
+    model, _ = _model(N=N, dead_frac=0.0)
+    dev = model.means.device
+    p = strategies.OptimizationParameters(grow_scale3d=0.035, prune_opacity=0.005, reset_every=300)
+    st = strategies.DefaultStrategy(model, p, generator=torch.Generator(device=dev).manual_seed(2))
+    _prime_optimizer(st)
+    assert float(model.get_opacity().detach().min()) > 0.005
+    before = {k: n(getattr(model, k)).copy() for k in strategies._PARAM_NAMES}
+    moments = {k: n(st.optimizer.state[id(getattr(model, k))]["exp_avg"]).copy() for k in strategies._PARAM_NAMES}
+    info = torch.zeros(2, N, device=dev)
+    info[0] = 4.0
+    info[1] = 4.0 * 1e-5                                   # average gradient 1e-5 < grad_threshold 2e-4 everywhere
+    rnd = torch.randn(2, N, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    if fused:
+        st.grow_and_prune_fused(700, info, rnd)
+    else:
+        st.grow_gs(700, info, rnd)
+        st.prune_gs(700)
+    assert model.means.shape[0] == N
+    for k in strategies._PARAM_NAMES:
+        assert np.array_equal(n(getattr(model, k)), before[k]), k
+        assert np.array_equal(n(st.optimizer.state[id(getattr(model, k))]["exp_avg"]), moments[k]), k
