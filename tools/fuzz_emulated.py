@@ -24,7 +24,16 @@ import emul_util  # noqa: E402
 from gpu_util import small_rotation_viewmat  # noqa: E402
 
 
-def one_case(rng, lfs, ops, lib, idx):
+STATS = {}
+
+
+def _stat(name, value):
+    a = STATS.setdefault(name, [0, 0.0])
+    a[0] += 1
+    a[1] = max(a[1], float(value))
+
+
+def one_case(rng, lfs, ops, lib, idx, orc=None):
     N = int(rng.choice([0, 1, 2, 63, 64, 65, int(rng.integers(3, 400))]))
     W, H = int(rng.integers(1, 121)), int(rng.integers(1, 121))
     ts = int(rng.choice([8, 16, 24, 32, 48]))
@@ -57,13 +66,33 @@ def one_case(rng, lfs, ops, lib, idx):
                                                            False, cm, None, st, None if rad is None else t(rad), None if tan is None else t(tan), None if thin is None else t(thin))
     for x in (m2, d, conics):
         assert torch.isfinite(x).all(), (desc, "projection")
+    if orc is not None and N:
+        # --oracle: the differential mode - every stage against the CPU restatement of the reference's kernels (oracle/), at the bars of the GPU parity tests
+        o_radii, o_m2, o_d, o_conics, _ = orc.projection_ut_3dgs_fused(means, quats, scales, opac, vm0, vm1, K, W, H, 0.3, 0.01, 1e4, 0.0, False, model, None, shutter, rad, tan, thin)
+        r_n = radii.numpy()
+        both = (r_n > 0).all(-1) & (o_radii > 0).all(-1)
+        vis_diff = int(((r_n > 0).all(-1) != (o_radii > 0).all(-1)).sum())      # a Gaussian on the culling boundary may land on either side (radii +-1)
+        _stat("projection: visibility differs (Gaussians per case)", vis_diff)
+        assert vis_diff <= max(1, (Cn * N) // 100), (desc, "projection visibility", vis_diff)
+        if both.any():
+            assert int(np.abs(r_n[both] - o_radii[both]).max()) <= 1, (desc, "radii")
+            for nm, a, b in (("means2d", m2.numpy()[both], o_m2[both]), ("depths", d.numpy()[both], o_d[both]), ("conics", conics.numpy()[both], o_conics[both])):
+                err = float(np.max(np.abs(a - b) / (1e-4 + 1e-4 * np.abs(b))))
+                _stat(f"projection: {nm} |diff| / (atol 1e-4 + rtol 1e-4)", err)
+                assert err <= 1.0, (desc, nm, err)
     deg = int(rng.integers(0, 5))
     Kc = int(rng.choice([k for k in (1, 4, 9, 16, 25) if k >= (deg + 1) ** 2]))
     coeffs = (rng.standard_normal((N, Kc, 3)) * 0.3).astype(np.float32)
     dirs = rng.standard_normal((N, 3)).astype(np.float32)
     smask = (rng.random(N) < 0.8)
-    col3 = ops.spherical_harmonics_fwd(deg, t(dirs), t(coeffs), t(smask, torch.bool) if rng.random() < 0.7 else None)
+    use_smask = rng.random() < 0.7
+    col3 = ops.spherical_harmonics_fwd(deg, t(dirs), t(coeffs), t(smask, torch.bool) if use_smask else None)
     assert torch.isfinite(col3).all(), (desc, "sh_fwd")
+    if orc is not None and N:
+        want = orc.spherical_harmonics_fwd(deg, dirs, coeffs, smask if use_smask else None)
+        err = float(np.max(np.abs(col3.numpy() - want) / (1e-5 + 1e-5 * np.abs(want))))
+        _stat("sh_fwd: |diff| / (atol 1e-5 + rtol 1e-5)", err)
+        assert err <= 1.0, (desc, "sh_fwd vs oracle", err)
     tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
     tpg, ids, flat, offs = ops.intersect_tile(m2, radii, d, None, None, Cn, ts, tw, th, True, return_offsets=True)
     ids_n, flat_n, offs_n = ids.numpy(), flat.numpy(), offs.numpy().reshape(-1)
@@ -71,6 +100,11 @@ def one_case(rng, lfs, ops, lib, idx):
     assert np.all(np.diff(ids_n) >= 0), (desc, "isect order")                      # (camera | tile | depth bits) ascending
     assert np.all(np.diff(offs_n) >= 0) and (len(offs_n) == 0 or offs_n[-1] <= len(ids_n)), (desc, "offsets")
     assert np.all((flat_n >= 0) & (flat_n < max(Cn * N, 1))), (desc, "flatten ids")
+    if orc is not None and N:
+        o_tpg, o_ids, o_flat = orc.intersect_tile(m2.numpy(), radii.numpy(), d.numpy(), Cn, ts, tw, th, True)     # integer stage: bit-exact on identical inputs
+        assert np.array_equal(tpg.numpy().reshape(o_tpg.shape), o_tpg) and np.array_equal(ids_n, o_ids) and np.array_equal(flat_n, o_flat), (desc, "isect vs oracle")
+        assert np.array_equal(offs_n, orc.intersect_offset(o_ids, Cn, tw, th).reshape(-1)), (desc, "offsets vs oracle")
+        _stat("intersect_tile / intersect_offset: bit-exact cases", 0)
     colors = rng.random((Cn, N, cdim)).astype(np.float32)
     opacs = np.tile(opac[None], (Cn, 1)).astype(np.float32)
     bg = rng.random((Cn, cdim)).astype(np.float32) if rng.random() < 0.6 else None
@@ -79,6 +113,18 @@ def one_case(rng, lfs, ops, lib, idx):
             None if vm1 is None else t(vm1), t(K), cm, None, st, None if rad is None else t(rad), None if tan is None else t(tan), None if thin is None else t(thin), offs, flat)
     rc, ra, li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
     assert torch.isfinite(rc).all() and float(ra.min()) >= 0.0 and float(ra.max()) <= 1.0 + 1e-6, (desc, "raster fwd")
+    if orc is not None and N:
+        oargs = (means, quats, scales, colors, opacs, bg, masks, W, H, ts, vm0, vm1, K, model, shutter, rad, tan, thin, offs.numpy(), flat_n)
+        o_rc, o_ra, o_li = orc.rasterize_fwd(*oargs)
+        dimg, dalp = np.abs(rc.numpy() - o_rc), np.abs(ra.numpy() - o_ra)
+        _stat("raster fwd: mean |colour diff| (bar 1e-5)", dimg.mean() if dimg.size else 0.0)
+        beyond = int((dimg.reshape(-1, cdim).max(-1) > 1 / 255 + 1e-4).sum())
+        _stat("raster fwd: pixels beyond 1/255 + 1e-4", beyond)
+        assert (dimg.mean() if dimg.size else 0.0) <= 1e-5 and dalp.mean() <= 1e-5, (desc, "raster fwd vs oracle", float(dimg.mean()), float(dalp.mean()))
+        assert beyond <= max(1, int(1e-3 * Cn * W * H)), (desc, "raster fwd flips", beyond)
+        li_diff = int((li.numpy() != o_li).sum())
+        _stat("raster fwd: last_ids differing pixels", li_diff)
+        assert li_diff <= max(1, int(1e-3 * Cn * W * H)), (desc, "last_ids", li_diff)
     lib.lfs_set_debug_flags(1)       # culling off: the cell lists are the tile lists - the same image, bit for bit
     try:
         rc2, ra2, li2 = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
@@ -89,12 +135,42 @@ def one_case(rng, lfs, ops, lib, idx):
     grads = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra)
     for g in grads:
         assert torch.isfinite(g).all(), (desc, "raster bwd")
-    v_coeffs, v_dirs = ops.spherical_harmonics_bwd(Kc, deg, t(dirs), t(coeffs), None, t(rng.standard_normal((N, 3)).astype(np.float32)), True)
+    if orc is not None and N and len(flat_n):
+        # both sides continue from THIS forward's alphas / last ids; the oracle in fp64 is the truth (tests/test_gpu_raster.py: <= 2e-4 with counted flip rows)
+        og = orc.rasterize_bwd(*oargs, ra.numpy(), li.numpy(), v_rc.numpy(), v_ra.numpy(), dtype=np.float64)
+        from gpu_util import rows_check
+        for nm, a, b in zip(("v_means", "v_quats", "v_scales", "v_colors", "v_opacities"), grads, og):
+            a, b = a.numpy().astype(np.float64), np.asarray(b, np.float64)
+            if nm in ("v_colors", "v_opacities"):
+                a, b = a.reshape(Cn * N, -1), b.reshape(Cn * N, -1)
+            else:
+                a, b = a.reshape(N, -1), b.reshape(N, -1)
+            if np.sqrt((b ** 2).sum()) < 1e-12:
+                assert np.abs(a).max() < 1e-9, (desc, nm, "oracle gradient is zero")
+                continue
+            e, flips, rest = rows_check(a, b, bar=2e-4, max_flips=4)
+            _stat(f"raster bwd: {nm} rel-L2 vs fp64 oracle without <= 4 flip rows (bar 2e-4)", rest)
+            _stat(f"raster bwd: {nm} flip rows", flips)
+            assert rest <= 2e-4, (desc, nm, e, flips, rest)
+    v_col = rng.standard_normal((N, 3)).astype(np.float32)
+    v_coeffs, v_dirs = ops.spherical_harmonics_bwd(Kc, deg, t(dirs), t(coeffs), None, t(v_col), True)
     assert torch.isfinite(v_coeffs).all() and torch.isfinite(v_dirs).all(), (desc, "sh_bwd")
+    if orc is not None and N:
+        o_vc, o_vd = orc.spherical_harmonics_bwd(deg, dirs, coeffs, None, v_col, True)
+        e1 = float(np.max(np.abs(v_coeffs.numpy() - o_vc) / (1e-5 + 1e-5 * np.abs(o_vc))))
+        e2 = float(np.max(np.abs(v_dirs.numpy() - o_vd) / (1e-5 * max(1.0, float(np.abs(o_vd).max())) + 1e-4 * np.abs(o_vd))))
+        _stat("sh_bwd: v_coeffs |diff| / (atol 1e-5 + rtol 1e-5)", e1)
+        _stat("sh_bwd: v_dirs |diff| / (atol 1e-5 max|v_dirs| + rtol 1e-4)", e2)
+        assert e1 <= 1.0 and e2 <= 1.0, (desc, "sh_bwd vs oracle", e1, e2)
     if N:
         p, m, v = t(means).clone(), torch.zeros(N, 3), torch.zeros(N, 3)
         ops.adam_step_wrapper(p, m, v, grads[0].reshape(-1, 3)[:N].contiguous(), 1e-3, 0.9, 0.999, 1e-15, 10.0, 31.6)
         assert torch.isfinite(p).all(), (desc, "adam")
+        if orc is not None:
+            g0 = grads[0].reshape(-1, 3)[:N].contiguous().numpy()
+            wp, wm, wv = orc.adam_step(means.reshape(-1), np.zeros(3 * N, np.float32), np.zeros(3 * N, np.float32), g0.reshape(-1), 1e-3, 0.9, 0.999, 1e-15, 10.0, 31.6)
+            assert np.array_equal(p.numpy().reshape(-1), wp) and np.array_equal(m.numpy().reshape(-1), wm) and np.array_equal(v.numpy().reshape(-1), wv), (desc, "adam bit-exact")
+            _stat("adam_step: bit-exact cases", 0)
     return desc, len(ids_n)
 
 
@@ -102,19 +178,39 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--replay", default=None, help="a JSON file written by a failed run (the generator state before the failing case): run that one case again")
+    ap.add_argument("--oracle", action="store_true", help="differential mode: every stage is compared with the CPU oracle (tests-only code, as in tests/)")
     a = ap.parse_args()
+    orc = None
+    if a.oracle:
+        import oracle as orc
+        orc.build(ref=False)
     rng = np.random.default_rng(a.seed)
     with emul_util.installed() as lib:
         import lichtfeld_studio_amd as lfs
         from lichtfeld_studio_amd import ops
+        import json
+        if a.replay:
+            rng.bit_generator.state = json.load(open(a.replay))["state"]
+            print("replayed:", one_case(rng, lfs, ops, lib, -1, orc))
+            return
         t0, n, isects, biggest = time.time(), 0, 0, 0
         while time.time() - t0 < a.seconds:
-            desc, k = one_case(rng, lfs, ops, lib, n)
+            state = rng.bit_generator.state
+            try:
+                desc, k = one_case(rng, lfs, ops, lib, n, orc)
+            except AssertionError as e:
+                path = f"/tmp/fuzz_emulated_seed{a.seed}_case{n}.json"
+                json.dump({"state": state, "error": str(e)}, open(path, "w"))
+                print(f"case {n} failed; generator state before it written to {path} (--replay {path}{' --oracle' if orc is not None else ''})")
+                raise
             n += 1
             isects += k
             biggest = max(biggest, k)
         print(f"fuzz_emulated: {n} cases in {time.time() - t0:.0f} s (seed {a.seed}), {isects} tile intersections walked in total, largest case {biggest}; "
-              f"sanitizer {'ON' if os.environ.get('LFS_EMUL_SANITIZE') else 'off'}; no assertion failed")
+              f"sanitizer {'ON' if os.environ.get('LFS_EMUL_SANITIZE') else 'off'}; oracle comparison {'ON' if orc is not None else 'off'}; no assertion failed")
+        for k, (cnt, worst) in sorted(STATS.items()):
+            print(f"  {k}: {cnt} comparisons, worst {worst:.3g}")
 
 
 if __name__ == "__main__":
