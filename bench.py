@@ -430,7 +430,12 @@ def main() -> None:
             try:
                 tj = json.load(open(tpath))
                 measured_on = tj.get(f"{args.workload}:{N}", {}).get("_library")
-                if measured_on != lib_version:
+                # a later build whose gfx950 code objects are byte for byte those of the measured one (a source edit that is compiled out by default changes the source
+                # hash, not the machine code: tools/code_object_identity.py, its output committed under profiles/) is the measured library as far as counters go
+                same_code = tj.get(f"{args.workload}:{N}", {}).get("_byte_identical_builds", {})
+                if measured_on != lib_version and lib_version in same_code:
+                    roofline["traffic_note"] = f"measured on '{measured_on}'; this build's code objects are byte-identical to it ({same_code[lib_version]})"
+                elif measured_on != lib_version:
                     # counters of another build say nothing about this one: no number rather than a stale one
                     roofline["traffic_note"] = f"profiles/traffic.json was measured on '{measured_on}', this run is '{lib_version}': traffic withheld (tools/profile.sh + tools/update_traffic.py refresh it)"
                     tj = {}

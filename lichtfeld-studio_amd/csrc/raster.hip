@@ -38,6 +38,11 @@
 
 // Host build on the wavefront emulator (tests/emul) only: wave-evaluation counters [fwd, fwd that composited, bwd, bwd that accumulated]
 #ifndef LFS_FINISH_LDS_ROWS
+// LFS_BWD_REORTH (default 0 until it has been timed and the PSNR comparison re-run on an MI355X; tools/build_variant.py reorth raster.hip -DLFS_BWD_REORTH=1): the backward
+// re-orthogonalises the foot vector against the ray direction before it is used in a gradient - K8's gradients for FLAT Gaussians (tools/aniso_probe.py).
+#ifndef LFS_BWD_REORTH
+#define LFS_BWD_REORTH 0
+#endif
 #define LFS_FINISH_LDS_ROWS 1 // (round 3, same box: finish_adam 0.106 / 0.102 -> 0.102 / 0.097 ms; 0 = four 16-byte loads per lane at a 64-byte stride)
 #endif
 #ifdef LFS_EMULATE
@@ -240,7 +245,7 @@ constexpr int RAY_ROLLING = 0, RAY_GLOBAL = 1;
 // Distance of the Gaussian centre to the ray line in the Gaussian's normalised frame. With q = M d (un-normalised),
 // t = (gro . q) / |q|^2 and the foot vector w = gro - t q:  |w| equals the reference's |normalize(q) x gro|, and the
 // backward collapses to dL/dgro = -s w, dL/dq = t s w (s = vis * dL/dvis): no normalisation, no cross products.
-struct RayEval { f3 om, w; float t, vis; }; // LFS_REC_LOG2: w = c w_true and `vis` is alpha_raw = opac * vis_true (see lfs_raster_common.cuh)
+struct RayEval { f3 om, w, q; float t, vis, rl; }; // LFS_REC_LOG2: w = c w_true and `vis` is alpha_raw = opac * vis_true (see lfs_raster_common.cuh)
 template <int MODE>
 LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& d, RayEval& e) {
     e.om = {0.f, 0.f, 0.f};
@@ -260,11 +265,13 @@ LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& d, RayEval& e)
     // l == 0 (inactive lane: d = 0; degenerate record: M = 0): q = 0 as well, so t = 0 * FLT_MAX = 0 and w = gro - one v_min instead of compare + select
     const float rl = fminf(fast_rcp(l), 3.402823466e38f);
     e.t = fma3(gro.x, q.x, gro.y, q.y, gro.z, q.z) * rl;
+    e.q = q; e.rl = rl;
     e.w = {__builtin_fmaf(-e.t, q.x, gro.x), __builtin_fmaf(-e.t, q.y, gro.y), __builtin_fmaf(-e.t, q.z, gro.z)};
     e.vis = __builtin_amdgcn_exp2f(__builtin_fmaf(-e.w.z, e.w.z, __builtin_fmaf(-e.w.y, e.w.y, __builtin_fmaf(-e.w.x, e.w.x, rec.r3.x))));
 #else
     const float rl = l > 0.f ? fast_rcp(l) : 0.f; // l == 0: no direction (inactive lane / degenerate record), w = gro
     e.t = fma3(gro.x, q.x, gro.y, q.y, gro.z, q.z) * rl;
+    e.q = q; e.rl = rl;
     e.w = {__builtin_fmaf(-e.t, q.x, gro.x), __builtin_fmaf(-e.t, q.y, gro.y), __builtin_fmaf(-e.t, q.z, gro.z)};
     // exp(-0.5 |w|^2) as one exp2: -0.5 * log2(e) = -0.72134752
     e.vis = __builtin_amdgcn_exp2f(-0.72134752044448170f * fma3(e.w.x, e.w.x, e.w.y, e.w.y, e.w.z, e.w.z));
@@ -484,6 +491,15 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     auto eval = [&](const GaussRec& rec, const int2 e) {
         RayEval re;
         ray_eval<MODE>(rec, ro, rd, re);
+#if LFS_BWD_REORTH
+        {   // w = gro - t q is the difference of two vectors of length |o - mu| / s_min: for a FLAT Gaussian (one scale 20 - 100 x below the others, 5 units away: 1e4) its
+            // component ALONG q carries an absolute rounding error of ulp(1e4) ~ 1e-3 - harmless in |w|^2 (alpha above is computed from the un-corrected w, bit-identical
+            // to the forward), but dL/dgro = -s w is multiplied by 1 / s_min again in the finish pass. w is orthogonal to q by construction: one Gram-Schmidt step takes
+            // the spurious component out (w . q is a product with the LARGE q, so it is resolved exactly where the error sits). tools/aniso_probe.py.
+            const float c = fma3(re.w.x, re.q.x, re.w.y, re.q.y, re.w.z, re.q.z) * re.rl;
+            re.w = {__builtin_fmaf(-c, re.q.x, re.w.x), __builtin_fmaf(-c, re.q.y, re.w.y), __builtin_fmaf(-c, re.q.z, re.w.z)};
+        }
+#endif
 #if LFS_REC_LOG2
         const float araw = re.vis;
 #else

@@ -49,7 +49,8 @@ def build() -> str:
     """-> path of the emulated library (built once per content hash of sources + emulator under the system temp directory)"""
     srcs = _product_sources()
     sanitize = bool(os.environ.get("LFS_EMUL_SANITIZE"))
-    h = hashlib.sha1(repr(sorted(srcs.items())).encode() + (b"asan" if sanitize else b""))
+    extra_defines = os.environ.get("LFS_EMUL_DEFINES", "").split()   # e.g. "-DLFS_BWD_REORTH=1": an emulated build of a compile-time variant of the product library
+    h = hashlib.sha1(repr(sorted(srcs.items())).encode() + (b"asan" if sanitize else b"") + " ".join(extra_defines).encode())
     deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "emul", "hip", "hip_runtime.h"), os.path.join(HERE, "emul", "emul_stubs.cpp"),
                                                                        os.path.join(ROOT, "include", "lfs_gsplat.h"), __file__]
     for d in deps:
@@ -61,6 +62,7 @@ def build() -> str:
         return out
     os.makedirs(work, exist_ok=True)
     common = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-DLFS_EMULATE", "-fPIC", "-I" + os.path.join(HERE, "emul"), "-I" + CSRC, "-Wno-unused-value", "-Wno-unknown-attributes"]
+    common += extra_defines
     if sanitize:
         common[1:1] = ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g"]
 

@@ -1,0 +1,60 @@
+"""CPU (emulated product library): the backward rasterizer's gradients for FLAT Gaussians - one scale 4 .. 80 x below the other two, the shape most Gaussians of a trained scene
+have. Found by the differential fuzzer (tools/fuzz_emulated.py --oracle, seed 12 case 1106; profiles/r04/fuzz_emulated.txt): the foot-vector form w = gro - t q of K8
+(csrc/raster.hip ray_eval) subtracts two vectors of length |o - mu| / s_min, the component of w along q keeps an absolute rounding error of ulp(|gro|), and the finish pass multiplies
+dL/dgro by 1 / s_min again - dL/dmeans is off by 0.3 % at aspect 10 and by tens of percent at aspect 80, dL/dquats by 2 - 4 % at aspect 40 - 80, where the reference's
+cross-product form evaluated in fp32 (the oracle's float instantiation) stays at 1e-4. The forward image is not affected (|w|^2 is insensitive to the error).
+-DLFS_BWD_REORTH=1 (one Gram-Schmidt step on w, seven FMA-class instructions per evaluation, alpha untouched) removes it; it is compiled out by default until it has
+been timed and the PSNR comparison re-run on an MI355X. Both builds are run here: the default one documents the limitation (strict xfail: the test
+starts failing as 'unexpectedly passing' the day the default changes), the variant must hold the oracle's own fp32 accuracy."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import emul_util  # noqa: E402
+
+
+def _probe(tmp_path, defines):
+    if not emul_util.available():
+        pytest.skip("no clang++ to build the emulated library")
+    out = os.path.join(tmp_path, "aniso.json")
+    env = dict(os.environ, LFS_EMUL_DEFINES=defines)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "aniso_probe.py"), "--json", out], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    print(r.stdout)
+    return json.load(open(out))
+
+
+def _holds_the_oracles_fp32_accuracy(rows, min_aspect=0.0):
+    for r in rows:
+        if r["aspect"] < 2 or r["aspect"] < min_aspect:   # (aspect 1: dL/dquats is zero in exact arithmetic, nothing to be relative to)
+            continue
+        for k in ("v_quats", "v_means", "v_scales"):
+            assert r[k + "_hip"] <= max(4 * r[k + "_o32"], 3e-4), (k, r)
+        assert r["fwd"] < 2e-5, r
+
+
+def test_moderately_flat_gaussians_default_build(tmp_path):
+    rows = _probe(str(tmp_path), "")
+    for r in rows:
+        if 2 <= r["aspect"] <= 4:
+            assert r["v_quats_hip"] < 5e-4 and r["v_means_hip"] < 5e-4 and r["v_scales_hip"] < 5e-4, r
+        assert r["fwd"] < 2e-5, r                                  # the forward holds at every aspect ratio
+    with open(os.path.join(str(tmp_path), "rows.json"), "w") as fh:
+        json.dump(rows, fh)
+    # the limitation itself, as numbers (so a silent change of either sign is noticed): aspect 40 - 80 is off by more than 1 % in dL/dmeans in the default build
+    assert max(r["v_means_hip"] for r in rows if r["aspect"] >= 40) > 1e-2
+
+
+@pytest.mark.xfail(strict=True, reason="K8's foot vector loses the component along the ray for flat Gaussians; -DLFS_BWD_REORTH=1 fixes it, default off until timed on an MI355X")
+def test_flat_gaussians_default_build_holds_fp32_accuracy(tmp_path):
+    _holds_the_oracles_fp32_accuracy(_probe(str(tmp_path), ""), min_aspect=10)
+
+
+def test_flat_gaussians_with_the_reorthogonalised_foot_vector(tmp_path):
+    _holds_the_oracles_fp32_accuracy(_probe(str(tmp_path), "-DLFS_BWD_REORTH=1"))
