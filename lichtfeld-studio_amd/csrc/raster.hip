@@ -36,15 +36,15 @@
 #include "lfs_adam.cuh"
 #include "lfs_step_internal.h"
 
-// Host build on the wavefront emulator (tests/emul) only: wave-evaluation counters [fwd, fwd that composited, bwd, bwd that accumulated]
-#ifndef LFS_FINISH_LDS_ROWS
-// LFS_BWD_REORTH (default 0 until it has been timed and the PSNR comparison re-run on an MI355X; tools/build_variant.py reorth raster.hip -DLFS_BWD_REORTH=1): the backward
+// LFS_BWD_REORTH (default 1 since round 5; -DLFS_BWD_REORTH=0 = the rounds 1 - 4 backward, kept for A/B: tools/build_variant.py noreorth raster.hip -DLFS_BWD_REORTH=0): the backward
 // re-orthogonalises the foot vector against the ray direction before it is used in a gradient - K8's gradients for FLAT Gaussians (tools/aniso_probe.py).
 #ifndef LFS_BWD_REORTH
-#define LFS_BWD_REORTH 0
+#define LFS_BWD_REORTH 1
 #endif
+#ifndef LFS_FINISH_LDS_ROWS
 #define LFS_FINISH_LDS_ROWS 1 // (round 3, same box: finish_adam 0.106 / 0.102 -> 0.102 / 0.097 ms; 0 = four 16-byte loads per lane at a 64-byte stride)
 #endif
+// Host build on the wavefront emulator (tests/emul) only: wave-evaluation counters [fwd, fwd that composited, bwd, bwd that accumulated]
 #ifdef LFS_EMULATE
 extern "C" { __attribute__((visibility("default"))) unsigned long long lfs_emul_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0}; }
 #define LFS_EMUL_COUNT(i) do { if ((threadIdx.x & 63) == 0) ++lfs_emul_counters[i]; } while (0)

@@ -103,6 +103,19 @@ def syn_b(seed: int = 42, n: int = 1_000_000, n_views: int = 64) -> Scene:
     return _syn_box("SYN-B", seed, n, 1920, 1080, 1200.0, n_views)
 
 
+def syn_b_flat(seed: int = 42, n: int = 1_000_000, n_views: int = 64, max_aspect: float = 100.0) -> Scene:
+    """SYN-B with the shape statistics of a TRAINED scene (round 5): every Gaussian is a flat disk - one random axis is `aspect` times thinner than SYN-B's draw, aspect
+    log-uniform in [1, max_aspect]. SYN-B itself draws its three log-scales from one sigma = 0.4 normal (aspect <= 6 for all but a handful): the regime in which the backward's
+    foot-vector form lost the position / rotation gradients before LFS_BWD_REORTH. Same means / colours / opacities / cameras as SYN-B."""
+    sc = _syn_box("SYN-B-flat", seed, n, 1920, 1080, 1200.0, n_views)
+    g = torch.Generator().manual_seed(seed + 1000)
+    thin = torch.randint(0, 3, (n,), generator=g)
+    aspect = torch.exp(torch.rand(n, generator=g) * math.log(max_aspect))
+    sc.raw_scales[torch.arange(n), thin] -= aspect.log()
+    sc.extra["aspect"] = aspect
+    return sc
+
+
 def syn_c(seed: int = 42, n: int = 3_000_000, n_views: int = 64) -> Scene:
     """config 4: 3M Gaussians, 1600x1200, 64 views/step across 8 GPUs."""
     return _syn_box("SYN-C", seed, n, 1600, 1200, 1000.0, n_views)

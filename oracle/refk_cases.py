@@ -8,13 +8,17 @@ import numpy as np
 from . import FISHEYE, GLOBAL, PINHOLE
 
 
-def _gaussians(rng, N, spread=1.0, zmin=3.0, smin=0.01, smax=0.06):
+def _gaussians(rng, N, spread=1.0, zmin=3.0, smin=0.01, smax=0.06, flat=None):
     means = rng.standard_normal((N, 3)).astype(np.float32) * spread
     means[:, 2] = np.abs(means[:, 2]) + zmin
     quats = rng.standard_normal((N, 4)).astype(np.float32)
     quats /= np.linalg.norm(quats, axis=-1, keepdims=True)      # Fwd.cu:314: "quats need to be normalized before passing in"
     scales = (rng.random((N, 3)) * (smax - smin) + smin).astype(np.float32)
     opac = (rng.random(N) * 0.8 + 0.1).astype(np.float32)
+    if flat is not None:   # FLAT Gaussians (round 5): one random axis `flat` times thinner than the largest of the other two - the shape trained scenes are made of
+        thin = rng.integers(0, 3, N)
+        scales[np.arange(N), thin] = 0.0
+        scales[np.arange(N), thin] = scales.max(-1) / np.float32(flat)
     return means, quats.astype(np.float32), scales, opac
 
 
@@ -47,6 +51,14 @@ RASTER_CASES = {
     "fisheye": dict(N=1500, W=96, H=96, seed=9, camera_model=FISHEYE, radial=[0.01, -0.002, 0.0, 0.0]),
     "rolling_top_bottom": dict(N=1500, W=112, H=80, seed=10, rs_type=0, rolling=True),
     "rolling_right_left": dict(N=1500, W=112, H=80, seed=11, rs_type=3, rolling=True),
+    # round 5: flat Gaussians - aspect ratio 10 .. 80 (every case above draws its three scales from one range: aspect <= 6). The regime in which the foot-vector form
+    # of K8 needs its re-orthogonalisation step (csrc/raster.hip LFS_BWD_REORTH); the reference's cross-product form is well conditioned here.
+    "flat10": dict(N=1500, W=112, H=80, seed=12, smin=0.02, flat=10.0),
+    "flat20": dict(N=1500, W=112, H=80, seed=13, smin=0.02, flat=20.0),
+    "flat40": dict(N=1500, W=112, H=80, seed=14, smin=0.02, flat=40.0),
+    "flat80": dict(N=1500, W=112, H=80, seed=15, smin=0.02, flat=80.0),
+    "flat40_fisheye": dict(N=1500, W=96, H=96, seed=16, smin=0.02, flat=40.0, camera_model=FISHEYE, radial=[0.01, -0.002, 0.0, 0.0]),
+    "flat40_rolling": dict(N=1500, W=112, H=80, seed=17, smin=0.02, flat=40.0, rs_type=0, rolling=True),
 }
 
 PROJECTION_CASES = {
@@ -76,7 +88,7 @@ def build_inputs(cfg: dict) -> dict:
         vm0 = np.eye(4, dtype=np.float32)[None]
         K = np.array([[[200.0, 0, 128], [0, 200.0, 128], [0, 0, 1]]], np.float32)
     else:
-        means, quats, scales, opac = _gaussians(rng, N, spread=cfg.get("spread", 1.0), smin=cfg.get("smin", 0.01), smax=cfg.get("smax", 0.06))
+        means, quats, scales, opac = _gaussians(rng, N, spread=cfg.get("spread", 1.0), smin=cfg.get("smin", 0.01), smax=cfg.get("smax", 0.06), flat=cfg.get("flat"))
         vm0 = np.stack([_viewmat(rng, 0.05 + 0.1 * c, 0.1) for c in range(C)])
         K = _K(0.8 * W, W, H, C)
     vm1 = np.stack([_viewmat(rng, 0.12, 0.2) @ vm0[c] for c in range(C)]).astype(np.float32) if cfg.get("rolling") else None

@@ -11,7 +11,8 @@ Bars (written where they are asserted):
   backward       : per-tensor relative L2 <= 1e-3 vs the oracle (tests/test_numerical_gradients.cpp:59-81 uses 1e-3), and the
                    number of "flip rows" (Gaussians with an alpha that crossed 1/255 or the 0.999 cap at one pixel, v_exp_f32 vs exp:
                    gpu_util.rows_check) is counted and bounded explicitly (<= 4 of 1-3 M) instead of being dropped by fraction;
-                   measured: SYN-B 0 flips and 2e-5 .. 8e-5, SYN-C 1 flip (quats: 1.9e-3 with it, 1.9e-4 without), SYN-D 0 flips and <= 1.5e-4
+                   measured: SYN-B 0 flips and 2e-5 .. 8e-5, SYN-C 1 flip (quats: 1.9e-3 with it, 1.9e-4 without), SYN-D 0 flips and <= 1.5e-4;
+                   SYN-B-flat (aspect up to 100): printed by the run - the library before LFS_BWD_REORTH fails this bar on v_means / v_quats there
   raw-parameter gradients of the whole step (activations + SH + clamp + loss): relative L2 <= 1e-3
 """
 import numpy as np
@@ -33,6 +34,9 @@ SCENES = {
     "syn_b": dict(maker="syn_b", view=0),
     "syn_c": dict(maker="syn_c", view=5),
     "syn_d": dict(maker="syn_d", view=9),
+    # round 5: SYN-B made of flat disks (aspect ratio log-uniform in 1 .. 100: scenes.syn_b_flat) - the regime K8's re-orthogonalisation step exists for; no parity
+    # scene of rounds 1 - 4 had a Gaussian flatter than 6 : 1. Same bars as the other three.
+    "syn_b_flat": dict(maker="syn_b_flat", view=0),
 }
 
 

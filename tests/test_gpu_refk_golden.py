@@ -3,7 +3,9 @@
 and fastgs' adam_kernels.cuh run on the CPU by oracle/ref_kernels.cpp; generator: oracle/make_golden_refk.py). No oracle in between: this is
 "HIP vs the reference" for the ops SURVEY.md §8c lists as unpinned, incl. BASELINE.json configs[0]'s shape (10k Gaussians, 256x256: `syn_a`).
 Bars: SURVEY.md §8c - integer radii +-1 on < 0.2 %, means2d 1e-2 px (UT fp32 noise floor), forward mean |diff| <= 2e-6 and last_ids >= 99.9 %,
-backward relative L2 <= 2e-4 with the alpha-threshold flip rows counted (gpu_util.rows_check), Adam bit-exact."""
+backward relative L2 <= 2e-4 with the alpha-threshold flip rows counted (gpu_util.rows_check), Adam bit-exact. Round 5: six cases of FLAT Gaussians (aspect 10 - 80,
+pinhole / fisheye / rolling shutter: `flat*`), same bars - except that a tensor on which the reference kernel itself is further than 1e-4 from the fp64 oracle
+(dL/dscales at aspect >= 40) is held to the fp64 oracle at twice the reference kernel's own distance."""
 import os
 
 import numpy as np
@@ -39,10 +41,26 @@ def test_hip_rasterization_matches_reference_kernel(lfs, name):
     rc, ra, li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
     check_raster_fwd(d, n(rc), n(ra), n(li), mean_bar=2e-6)
     g = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, t(d["alpha"]), t(d["last_ids"], torch.int32), t(d["v_render"]), t(d["v_alpha"]))
-    for nme, a, b in raster_bwd_rows(d, [n(x) for x in g]):
+    o64 = None
+    for k, (nme, a, b) in enumerate(raster_bwd_rows(d, [n(x) for x in g])):
         e, flips, rest = rows_check(a, b, bar=2e-4, max_flips=2)
         print(f"refk {name} {nme}: rel-L2 {e:.2e}, flip rows {flips}, without them {rest:.2e}")
-        assert np.isfinite(a).all() and rest < 2e-4, (nme, e, flips, rest)
+        assert np.isfinite(a).all()
+        if rest < 2e-4:
+            continue
+        # Flat Gaussians (round 5, aspect 40 - 80): dL/dscale of the THIN axis is ill-conditioned in fp32 in the reference's own arithmetic as well - its kernel sits
+        # 2 - 3e-4 away from the fp64 oracle on `flat80` (two fp32 results that far from the truth are up to the sum of both apart). Where the 2e-4 bar against the
+        # reference kernel does not hold, the test is the one that matters: the HIP result must be as close to the TRUTH (fp64 oracle) as the reference kernel is,
+        # up to a factor 2 - and only the flat cases may take this branch.
+        assert name.startswith("flat"), (nme, e, flips, rest)
+        if o64 is None:
+            import oracle
+            o64 = raster_bwd_rows(d, oracle.rasterize_bwd(*ru.oracle_raster_args(d), d["alpha"], d["last_ids"], d["v_render"], d["v_alpha"], dtype=np.float64))
+        truth = o64[k][1]
+        e_ref = rows_check(b, truth, bar=2e-4, max_flips=2)[2]
+        e_hip, flips64, rest64 = rows_check(a, truth, bar=max(2e-4, 2 * e_ref), max_flips=2)
+        print(f"refk {name} {nme}: against the fp64 oracle HIP {rest64:.2e} ({flips64} flip rows), the reference kernel {e_ref:.2e}")
+        assert rest64 < max(2e-4, 2 * e_ref), (nme, e_hip, flips64, rest64, e_ref)
 
 
 def test_hip_small_ops_match_reference_kernels(lfs):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Conditioning probe for the backward rasterizer (K8) on the EMULATED product library (no GPU): ONE flat Gaussian - two scales 0.04, the third from 0.04 down to 5e-4 - in front of a
+"""Conditioning probe for the backward rasterizer (K8) on the EMULATED product library (no GPU; with --gpu: on the MI355X through the shipped library): ONE flat Gaussian - two scales 0.04, the third from 0.04 down to 5e-4 - in front of a
 pinhole camera; dL/d(quaternion), dL/d(scales), dL/d(mean) of the HIP kernels (host IEEE fp32 under emulation) and of the oracle evaluated in fp32, each against the oracle in fp64,
 on a 48 x 48 image, six random orientations each (worst shown); the forward image against the fp64 oracle beside it. Found by tools/fuzz_emulated.py --oracle (seed 12, case 1106):
 profiles/r04/fuzz_emulated.txt.    python tools/aniso_probe.py        LFS_EMUL_DEFINES=-DLFS_BWD_REORTH=1 python tools/aniso_probe.py   (the build with the re-orthogonalised foot vector)"""
@@ -21,9 +21,11 @@ def main():
     rows_out = []
     import oracle as orc
     orc.build(ref=False)
-    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).contiguous()
+    import contextlib
+    on_gpu = "--gpu" in sys.argv
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).contiguous().to("cuda:0" if on_gpu else "cpu")
     rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-300))
-    with emul_util.installed():
+    with (contextlib.nullcontext() if on_gpu else emul_util.installed()):
         import lichtfeld_studio_amd as lfs
         from lichtfeld_studio_amd import ops
         cm, st = lfs.CameraModelType(0), lfs.ShutterType(4)
@@ -51,7 +53,8 @@ def main():
                     args = (t(means), t(quats), t(scales), t(colors), t(opac[None]), None, None, W, H, ts, t(vm), None, t(K), cm, None, st, None, None, None, offs, flat)
                     rc, ra, li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
                     v_rc, v_ra = t(rng.standard_normal(tuple(rc.shape)).astype(np.float32)), t(rng.standard_normal(tuple(ra.shape)).astype(np.float32))
-                    g = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra)
+                    g = [x.cpu() for x in ops.rasterize_to_pixels_from_world_3dgs_bwd(*args, ra, li, v_rc, v_ra)]
+                    rc, ra, li, v_rc, v_ra, offs, flat = [x.cpu() for x in (rc, ra, li, v_rc, v_ra, offs, flat)]
                     oargs = (means, quats, scales, colors, opac[None], None, None, W, H, ts, vm, None, K, 0, 4, None, None, None, offs.numpy(), flat.numpy())
                     o64 = orc.rasterize_bwd(*oargs, ra.numpy(), li.numpy(), v_rc.numpy(), v_ra.numpy(), dtype=np.float64)
                     o32 = orc.rasterize_bwd(*oargs, ra.numpy(), li.numpy(), v_rc.numpy(), v_ra.numpy(), dtype=np.float32)

@@ -25,6 +25,12 @@ from gpu_util import small_rotation_viewmat  # noqa: E402
 
 
 STATS = {}
+DEV = "cpu"          # --gpu: "cuda:0" - the same cases through the SHIPPED gfx950 library on the MI355X (the parity run proper; the emulated run checks the logic)
+FLAT_P = 0.0         # --flat P: with probability P a case's Gaussians are flat disks (one random axis 10 / 30 / 100 x thinner): the regime of K8's re-orthogonalisation
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
 
 
 def _stat(name, value):
@@ -42,13 +48,18 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
     model = int(rng.choice([0, 0, 0, 2]))                 # PINHOLE / FISHEYE
     shutter = int(rng.choice([4, 4, 4, 0, 1, 2, 3]))
     desc = dict(idx=idx, N=N, W=W, H=H, ts=ts, C=Cn, cdim=cdim, model=model, shutter=shutter)
-    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).contiguous()
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).contiguous().to(DEV)
     means = rng.standard_normal((N, 3)).astype(np.float32) * float(rng.choice([0.3, 1.0, 3.0]))
     means[:, 2] = np.abs(means[:, 2]) + float(rng.choice([0.2, 1.5, 3.0]))
     quats = rng.standard_normal((N, 4)).astype(np.float32)
     smax = float(rng.choice([0.05, 0.3, 2.0]))
     scales = (rng.random((N, 3)) * smax + 1e-3).astype(np.float32)
     opac = (rng.random(N) * 0.98 + 0.01).astype(np.float32)
+    if FLAT_P > 0 and rng.random() < FLAT_P and N:
+        aspect = float(rng.choice([10.0, 30.0, 100.0]))
+        thin_axis = rng.integers(0, 3, N)
+        scales[np.arange(N), thin_axis] = np.maximum(scales.max(-1) / np.float32(aspect), np.float32(2e-4))
+        desc["flat"] = aspect
     vm0 = np.stack([small_rotation_viewmat(rng, 0.05 + 0.2 * c, 0.2) for c in range(Cn)]).astype(np.float32)
     vm1 = np.stack([small_rotation_viewmat(rng, 0.1, 0.3) for _ in range(Cn)]).astype(np.float32) if shutter != 4 else None
     f = float(rng.uniform(0.4, 1.5)) * max(W, H)
@@ -69,14 +80,14 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
     if orc is not None and N:
         # --oracle: the differential mode - every stage against the CPU restatement of the reference's kernels (oracle/), at the bars of the GPU parity tests
         o_radii, o_m2, o_d, o_conics, _ = orc.projection_ut_3dgs_fused(means, quats, scales, opac, vm0, vm1, K, W, H, 0.3, 0.01, 1e4, 0.0, False, model, None, shutter, rad, tan, thin)
-        r_n = radii.numpy()
+        r_n = _np(radii)
         both = (r_n > 0).all(-1) & (o_radii > 0).all(-1)
         vis_diff = int(((r_n > 0).all(-1) != (o_radii > 0).all(-1)).sum())      # a Gaussian on the culling boundary may land on either side (radii +-1)
         _stat("projection: visibility differs (Gaussians per case)", vis_diff)
         assert vis_diff <= max(1, (Cn * N) // 100), (desc, "projection visibility", vis_diff)
         if both.any():
             assert int(np.abs(r_n[both] - o_radii[both]).max()) <= 1, (desc, "radii")
-            for nm, a, b in (("means2d", m2.numpy()[both], o_m2[both]), ("depths", d.numpy()[both], o_d[both]), ("conics", conics.numpy()[both], o_conics[both])):
+            for nm, a, b in (("means2d", _np(m2)[both], o_m2[both]), ("depths", _np(d)[both], o_d[both]), ("conics", _np(conics)[both], o_conics[both])):
                 err = float(np.max(np.abs(a - b) / (1e-4 + 1e-4 * np.abs(b))))
                 _stat(f"projection: {nm} |diff| / (atol 1e-4 + rtol 1e-4)", err)
                 assert err <= 1.0, (desc, nm, err)
@@ -90,19 +101,19 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
     assert torch.isfinite(col3).all(), (desc, "sh_fwd")
     if orc is not None and N:
         want = orc.spherical_harmonics_fwd(deg, dirs, coeffs, smask if use_smask else None)
-        err = float(np.max(np.abs(col3.numpy() - want) / (1e-5 + 1e-5 * np.abs(want))))
+        err = float(np.max(np.abs(_np(col3) - want) / (1e-5 + 1e-5 * np.abs(want))))
         _stat("sh_fwd: |diff| / (atol 1e-5 + rtol 1e-5)", err)
         assert err <= 1.0, (desc, "sh_fwd vs oracle", err)
     tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
     tpg, ids, flat, offs = ops.intersect_tile(m2, radii, d, None, None, Cn, ts, tw, th, True, return_offsets=True)
-    ids_n, flat_n, offs_n = ids.numpy(), flat.numpy(), offs.numpy().reshape(-1)
+    ids_n, flat_n, offs_n = _np(ids), _np(flat), _np(offs).reshape(-1)
     assert int(tpg.sum()) == len(ids_n) == len(flat_n), (desc, "isect count")
     assert np.all(np.diff(ids_n) >= 0), (desc, "isect order")                      # (camera | tile | depth bits) ascending
     assert np.all(np.diff(offs_n) >= 0) and (len(offs_n) == 0 or offs_n[-1] <= len(ids_n)), (desc, "offsets")
     assert np.all((flat_n >= 0) & (flat_n < max(Cn * N, 1))), (desc, "flatten ids")
     if orc is not None and N:
-        o_tpg, o_ids, o_flat = orc.intersect_tile(m2.numpy(), radii.numpy(), d.numpy(), Cn, ts, tw, th, True)     # integer stage: bit-exact on identical inputs
-        assert np.array_equal(tpg.numpy().reshape(o_tpg.shape), o_tpg) and np.array_equal(ids_n, o_ids) and np.array_equal(flat_n, o_flat), (desc, "isect vs oracle")
+        o_tpg, o_ids, o_flat = orc.intersect_tile(_np(m2), _np(radii), _np(d), Cn, ts, tw, th, True)     # integer stage: bit-exact on identical inputs
+        assert np.array_equal(_np(tpg).reshape(o_tpg.shape), o_tpg) and np.array_equal(ids_n, o_ids) and np.array_equal(flat_n, o_flat), (desc, "isect vs oracle")
         assert np.array_equal(offs_n, orc.intersect_offset(o_ids, Cn, tw, th).reshape(-1)), (desc, "offsets vs oracle")
         _stat("intersect_tile / intersect_offset: bit-exact cases", 0)
     colors = rng.random((Cn, N, cdim)).astype(np.float32)
@@ -114,15 +125,15 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
     rc, ra, li = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args)
     assert torch.isfinite(rc).all() and float(ra.min()) >= 0.0 and float(ra.max()) <= 1.0 + 1e-6, (desc, "raster fwd")
     if orc is not None and N:
-        oargs = (means, quats, scales, colors, opacs, bg, masks, W, H, ts, vm0, vm1, K, model, shutter, rad, tan, thin, offs.numpy(), flat_n)
+        oargs = (means, quats, scales, colors, opacs, bg, masks, W, H, ts, vm0, vm1, K, model, shutter, rad, tan, thin, _np(offs), flat_n)
         o_rc, o_ra, o_li = orc.rasterize_fwd(*oargs)
-        dimg, dalp = np.abs(rc.numpy() - o_rc), np.abs(ra.numpy() - o_ra)
+        dimg, dalp = np.abs(_np(rc) - o_rc), np.abs(_np(ra) - o_ra)
         _stat("raster fwd: mean |colour diff| (bar 1e-5)", dimg.mean() if dimg.size else 0.0)
         beyond = int((dimg.reshape(-1, cdim).max(-1) > 1 / 255 + 1e-4).sum())
         _stat("raster fwd: pixels beyond 1/255 + 1e-4", beyond)
         assert (dimg.mean() if dimg.size else 0.0) <= 1e-5 and dalp.mean() <= 1e-5, (desc, "raster fwd vs oracle", float(dimg.mean()), float(dalp.mean()))
         assert beyond <= max(1, int(1e-3 * Cn * W * H)), (desc, "raster fwd flips", beyond)
-        li_diff = int((li.numpy() != o_li).sum())
+        li_diff = int((_np(li) != o_li).sum())
         _stat("raster fwd: last_ids differing pixels", li_diff)
         assert li_diff <= max(1, int(1e-3 * Cn * W * H)), (desc, "last_ids", li_diff)
     lib.lfs_set_debug_flags(1)       # culling off: the cell lists are the tile lists - the same image, bit for bit
@@ -137,10 +148,10 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
         assert torch.isfinite(g).all(), (desc, "raster bwd")
     if orc is not None and N and len(flat_n):
         # both sides continue from THIS forward's alphas / last ids; the oracle in fp64 is the truth (tests/test_gpu_raster.py: <= 2e-4 with counted flip rows)
-        og = orc.rasterize_bwd(*oargs, ra.numpy(), li.numpy(), v_rc.numpy(), v_ra.numpy(), dtype=np.float64)
+        og = orc.rasterize_bwd(*oargs, _np(ra), _np(li), _np(v_rc), _np(v_ra), dtype=np.float64)
         from gpu_util import rows_check
         for nm, a, b in zip(("v_means", "v_quats", "v_scales", "v_colors", "v_opacities"), grads, og):
-            a, b = a.numpy().astype(np.float64), np.asarray(b, np.float64)
+            a, b = _np(a).astype(np.float64), np.asarray(b, np.float64)
             if nm in ("v_colors", "v_opacities"):
                 a, b = a.reshape(Cn * N, -1), b.reshape(Cn * N, -1)
             else:
@@ -150,7 +161,7 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
                 continue
             e, flips, rest = rows_check(a, b, bar=2e-4, max_flips=4)
             if idx < 0:   # --replay: where the difference sits, and what the ORACLE's own fp32 evaluation does against its fp64 one on the same case
-                o32 = np.asarray(orc.rasterize_bwd(*oargs, ra.numpy(), li.numpy(), v_rc.numpy(), v_ra.numpy(), dtype=np.float32)[("v_means", "v_quats", "v_scales", "v_colors", "v_opacities").index(nm)], np.float64).reshape(b.shape)
+                o32 = np.asarray(orc.rasterize_bwd(*oargs, _np(ra), _np(li), _np(v_rc), _np(v_ra), dtype=np.float32)[("v_means", "v_quats", "v_scales", "v_colors", "v_opacities").index(nm)], np.float64).reshape(b.shape)
                 rows = np.sqrt(((a - b) ** 2).sum(1)) / np.sqrt((b ** 2).sum())
                 rows32 = np.sqrt(((o32 - b) ** 2).sum(1)) / np.sqrt((b ** 2).sum())
                 top = np.argsort(rows)[::-1][:8]
@@ -160,7 +171,7 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
                     for r in top[:6]:
                         print(f"    row {int(r)}: scales {scales[r]}, opacity {opac[r]:.3f}, mean {means[r]}, |v_quats| HIP {np.linalg.norm(a[r]):.4e} oracle64 {np.linalg.norm(b[r]):.4e}, "
                               f"row-relative error {np.linalg.norm(a[r] - b[r]) / (np.linalg.norm(b[r]) + 1e-30):.2e}, v_scales row-relative error "
-                              f"{np.linalg.norm(grads[2].numpy().reshape(N, -1)[r] - np.asarray(og[2]).reshape(N, -1)[r]) / (np.linalg.norm(np.asarray(og[2]).reshape(N, -1)[r]) + 1e-30):.2e}")
+                              f"{np.linalg.norm(_np(grads[2]).reshape(N, -1)[r] - np.asarray(og[2]).reshape(N, -1)[r]) / (np.linalg.norm(np.asarray(og[2]).reshape(N, -1)[r]) + 1e-30):.2e}")
                     print("    median row-relative error over all rows:", float(np.median(np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-30))), "smax", smax)
                     # threshold flips or a defect? A flip is a discontinuity at ONE (pixel, Gaussian) pair: under a 3e-5 relative change of the opacities the pairs that sit
                     # on a threshold are other pairs, so the rows that stand out change; a defect in the arithmetic of a row stays with the row.
@@ -170,7 +181,7 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
                         rc_p, ra_p, li_p = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args2)
                         g_p = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args2, ra_p, li_p, v_rc, v_ra)[1].numpy().astype(np.float64).reshape(N, -1)
                         oargs2 = oargs[:4] + (op2,) + oargs[5:]
-                        b_p = np.asarray(orc.rasterize_bwd(*oargs2, ra_p.numpy(), li_p.numpy(), v_rc.numpy(), v_ra.numpy(), dtype=np.float64)[1], np.float64).reshape(N, -1)
+                        b_p = np.asarray(orc.rasterize_bwd(*oargs2, _np(ra_p), _np(li_p), _np(v_rc), _np(v_ra), dtype=np.float64)[1], np.float64).reshape(N, -1)
                         rows_p = np.sqrt(((g_p - b_p) ** 2).sum(1)) / np.sqrt((b_p ** 2).sum())
                         top_p = np.argsort(rows_p)[::-1][:6]
                         print(f"    opacities x (1 {eps:+.0e}): {rows_check(g_p, b_p, bar=2e-4, max_flips=4)}; worst rows", [(int(r), float(f"{rows_p[r]:.2e}")) for r in top_p])
@@ -180,28 +191,32 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
                 # the reference computes in fp32: a case that fp32 itself cannot resolve (huge Gaussians next to the camera ...) is a parity failure only if the kernels ALSO differ from
                 # the oracle's fp32 evaluation - the reference's arithmetic in the reference's precision
                 k32 = ("v_means", "v_quats", "v_scales", "v_colors", "v_opacities").index(nm)
-                o32 = np.asarray(orc.rasterize_bwd(*oargs, ra.numpy(), li.numpy(), v_rc.numpy(), v_ra.numpy(), dtype=np.float32)[k32], np.float64).reshape(b.shape)
+                o32 = np.asarray(orc.rasterize_bwd(*oargs, _np(ra), _np(li), _np(v_rc), _np(v_ra), dtype=np.float32)[k32], np.float64).reshape(b.shape)
                 e32, flips32, rest32 = rows_check(a, o32, bar=2e-4, max_flips=4)
                 _stat(f"raster bwd: {nm} cases beyond the bar against fp64 but within it against the oracle in fp32 (fp32-limited)", rest32)
-                assert rest32 <= 2e-4, (desc, nm, "vs fp64", e, flips, rest, "vs oracle fp32", e32, flips32, rest32)
+                # ... or the kernels are as close to the fp64 truth as the reference's arithmetic in fp32 is (twice its distance): flat Gaussians - dL/dscale of the thin axis
+                # is ill-conditioned in fp32 for every implementation, two fp32 evaluations of it are further from each other than either is from the truth
+                e3264, flips3264, rest3264 = rows_check(o32, b, bar=2e-4, max_flips=4)
+                _stat(f"raster bwd: {nm} fp32-limited cases: (HIP vs fp64) / (oracle fp32 vs fp64)", rest / max(rest3264, 1e-30))
+                assert rest32 <= 2e-4 or rest <= 2 * rest3264, (desc, nm, "vs fp64", e, flips, rest, "vs oracle fp32", e32, flips32, rest32, "oracle fp32 vs fp64", rest3264)
     v_col = rng.standard_normal((N, 3)).astype(np.float32)
     v_coeffs, v_dirs = ops.spherical_harmonics_bwd(Kc, deg, t(dirs), t(coeffs), None, t(v_col), True)
     assert torch.isfinite(v_coeffs).all() and torch.isfinite(v_dirs).all(), (desc, "sh_bwd")
     if orc is not None and N:
         o_vc, o_vd = orc.spherical_harmonics_bwd(deg, dirs, coeffs, None, v_col, True)
-        e1 = float(np.max(np.abs(v_coeffs.numpy() - o_vc) / (1e-5 + 1e-5 * np.abs(o_vc))))
-        e2 = float(np.max(np.abs(v_dirs.numpy() - o_vd) / (1e-5 * max(1.0, float(np.abs(o_vd).max())) + 1e-4 * np.abs(o_vd))))
+        e1 = float(np.max(np.abs(_np(v_coeffs) - o_vc) / (1e-5 + 1e-5 * np.abs(o_vc))))
+        e2 = float(np.max(np.abs(_np(v_dirs) - o_vd) / (1e-5 * max(1.0, float(np.abs(o_vd).max())) + 1e-4 * np.abs(o_vd))))
         _stat("sh_bwd: v_coeffs |diff| / (atol 1e-5 + rtol 1e-5)", e1)
         _stat("sh_bwd: v_dirs |diff| / (atol 1e-5 max|v_dirs| + rtol 1e-4)", e2)
         assert e1 <= 1.0 and e2 <= 1.0, (desc, "sh_bwd vs oracle", e1, e2)
     if N:
-        p, m, v = t(means).clone(), torch.zeros(N, 3), torch.zeros(N, 3)
+        p, m, v = t(means).clone(), torch.zeros(N, 3, device=DEV), torch.zeros(N, 3, device=DEV)
         ops.adam_step_wrapper(p, m, v, grads[0].reshape(-1, 3)[:N].contiguous(), 1e-3, 0.9, 0.999, 1e-15, 10.0, 31.6)
         assert torch.isfinite(p).all(), (desc, "adam")
         if orc is not None:
             g0 = grads[0].reshape(-1, 3)[:N].contiguous().numpy()
             wp, wm, wv = orc.adam_step(means.reshape(-1), np.zeros(3 * N, np.float32), np.zeros(3 * N, np.float32), g0.reshape(-1), 1e-3, 0.9, 0.999, 1e-15, 10.0, 31.6)
-            assert np.array_equal(p.numpy().reshape(-1), wp) and np.array_equal(m.numpy().reshape(-1), wm) and np.array_equal(v.numpy().reshape(-1), wv), (desc, "adam bit-exact")
+            assert np.array_equal(_np(p).reshape(-1), wp) and np.array_equal(_np(m).reshape(-1), wm) and np.array_equal(_np(v).reshape(-1), wv), (desc, "adam bit-exact")
             _stat("adam_step: bit-exact cases", 0)
     return desc, len(ids_n)
 
@@ -212,22 +227,34 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--replay", default=None, help="a JSON file written by a failed run (the generator state before the failing case): run that one case again")
     ap.add_argument("--oracle", action="store_true", help="differential mode: every stage is compared with the CPU oracle (tests-only code, as in tests/)")
+    ap.add_argument("--gpu", action="store_true", help="run the cases on cuda:0 through the shipped gfx950 library instead of the emulated host build")
+    ap.add_argument("--flat", type=float, default=0.0, help="probability of a flat-Gaussian case (aspect 10 / 30 / 100); 0 keeps the case stream of the round-4 records")
+    ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0: run for --seconds)")
     a = ap.parse_args()
+    global DEV, FLAT_P
+    FLAT_P = a.flat
+    if a.gpu:
+        DEV = "cuda:0"
     orc = None
     if a.oracle:
         import oracle as orc
         orc.build(ref=False)
     rng = np.random.default_rng(a.seed)
-    with emul_util.installed() as lib:
+    import contextlib
+    with (contextlib.nullcontext() if a.gpu else emul_util.installed()) as lib:
         import lichtfeld_studio_amd as lfs
         from lichtfeld_studio_amd import ops
         import json
+        if a.gpu:
+            from lichtfeld_studio_amd import capi
+            lib = capi.load_library()
+            print("library:", lib.lfs_version().decode())
         if a.replay:
             rng.bit_generator.state = json.load(open(a.replay))["state"]
             print("replayed:", one_case(rng, lfs, ops, lib, -1, orc))
             return
         t0, n, isects, biggest = time.time(), 0, 0, 0
-        while time.time() - t0 < a.seconds:
+        while time.time() - t0 < a.seconds and (a.cases <= 0 or n < a.cases):
             state = rng.bit_generator.state
             try:
                 desc, k = one_case(rng, lfs, ops, lib, n, orc)
@@ -239,7 +266,7 @@ def main():
             n += 1
             isects += k
             biggest = max(biggest, k)
-        print(f"fuzz_emulated: {n} cases in {time.time() - t0:.0f} s (seed {a.seed}), {isects} tile intersections walked in total, largest case {biggest}; "
+        print(f"fuzz_emulated{' --gpu (shipped gfx950 library)' if a.gpu else ''}{f' --flat {a.flat}' if a.flat else ''}: {n} cases in {time.time() - t0:.0f} s (seed {a.seed}), {isects} tile intersections walked in total, largest case {biggest}; "
               f"sanitizer {'ON' if os.environ.get('LFS_EMUL_SANITIZE') else 'off'}; oracle comparison {'ON' if orc is not None else 'off'}; no assertion failed")
         for k, (cnt, worst) in sorted(STATS.items()):
             print(f"  {k}: {cnt} comparisons, worst {worst:.3g}")
