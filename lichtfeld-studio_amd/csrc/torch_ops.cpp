@@ -11,6 +11,9 @@
 #include <c10/hip/HIPStream.h>
 #include <c10/hip/HIPCachingAllocator.h>
 
+#include <mutex>
+#include <vector>
+
 #define LFS_CHECK_INPUT(x)                                        \
     TORCH_CHECK((x).is_cuda(), #x " must be a CUDA tensor");      \
     TORCH_CHECK((x).is_contiguous(), #x " must be contiguous")
@@ -51,6 +54,12 @@ at::Tensor scratch(size_t bytes, const at::Tensor& like) {
 // the identity of every tensor it was built from - storage address AND autograd version counter (an in-place update bumps it; the Adam / add_noise wrappers below
 // bump it for their raw-pointer writes) - and a backward called with exactly those tensors, on the same stream, takes the "prepared" entry point. Anything else:
 // the self-contained path, as before. One slot per process (a backward matches the forward that directly preceded it: the training step).
+// Round 5 (review of round 4): (a) the slot HOLDS the keyed tensors (`held`), so none of their storages can be freed and handed out again at the same address with the
+// same version and size between the forward and the backward (the ABA hit a caller with short-lived same-sized temporaries could otherwise produce); (b) the slot is
+// guarded by a mutex, and a backward MOVES the workspace out under the lock: the reference's viewer thread may render through these wrappers
+// (rendering_pipeline.cpp:79) while the training thread is between its forward and its backward (render_mutex_ only covers post_backward / step, trainer.cpp:741), and
+// libtorch runs a C++ autograd Function's backward on the engine's device thread, not on the thread that ran the forward - which is also why the slot cannot be
+// thread_local. A forward of another thread in between simply replaces the slot: the training backward then misses and rebuilds its staging (correct, 0.1 ms slower).
 struct TensorId {
     const void* ptr = nullptr; uint32_t version = 0; int64_t numel = -1;
     bool operator==(const TensorId& o) const { return ptr == o.ptr && version == o.version && numel == o.numel; }
@@ -64,7 +73,26 @@ struct RasterKey {
         return W == o.W && H == o.H && tile == o.tile && cam == o.cam && shutter == o.shutter && stream == o.stream;
     }
 };
-struct RasterCache { bool valid = false; RasterKey key; at::Tensor ws; } g_raster_cache;
+struct RasterCache {
+    std::mutex mu; bool valid = false; RasterKey key; at::Tensor ws; std::vector<at::Tensor> held;
+    void store(RasterKey k, at::Tensor w, std::vector<at::Tensor> h, bool ok) {
+        std::vector<at::Tensor> old_held; at::Tensor old_ws;   // (released outside the lock)
+        { std::lock_guard<std::mutex> g(mu); old_held.swap(held); old_ws = std::move(ws); valid = ok; key = k; ws = std::move(w); held = std::move(h); }
+    }
+    // -> the forward's workspace if `k` is the stored key (the slot is emptied either way: one backward per forward)
+    at::Tensor take(const RasterKey& k) {
+        std::vector<at::Tensor> old_held; at::Tensor out, old_ws;
+        { std::lock_guard<std::mutex> g(mu); const bool hit = valid && key == k; if (hit) out = std::move(ws); else old_ws = std::move(ws); ws = at::Tensor(); valid = false; old_held.swap(held); }
+        return out;
+    }
+} g_raster_cache;
+std::vector<at::Tensor> raster_held(const at::Tensor& means, const at::Tensor& quats, const at::Tensor& scales, const at::Tensor& colors, const at::Tensor& opacities,
+                                    const gsplat::OptT& backgrounds, const gsplat::OptT& masks, const at::Tensor& viewmats0, const gsplat::OptT& viewmats1, const at::Tensor& Ks,
+                                    const gsplat::OptT& radial, const gsplat::OptT& tangential, const at::Tensor& tile_offsets, const at::Tensor& flatten_ids) {
+    std::vector<at::Tensor> h{means, quats, scales, colors, opacities, viewmats0, Ks, tile_offsets, flatten_ids};
+    for (const gsplat::OptT* o : {&backgrounds, &masks, &viewmats1, &radial, &tangential}) if (o->has_value() && (*o)->defined()) h.push_back(**o);
+    return h;
+}
 RasterKey raster_key(const at::Tensor& means, const at::Tensor& quats, const at::Tensor& scales, const at::Tensor& colors, const at::Tensor& opacities,
                      const gsplat::OptT& backgrounds, const gsplat::OptT& masks, uint32_t W, uint32_t H, uint32_t tile, const at::Tensor& viewmats0,
                      const gsplat::OptT& viewmats1, const at::Tensor& Ks, int cam, int shutter, const gsplat::OptT& radial, const gsplat::OptT& tangential,
@@ -240,10 +268,11 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
         renders.data_ptr<float>(), alphas.data_ptr<float>(), last_ids.data_ptr<int32_t>(), ws.data_ptr(), (size_t)ws.numel(), cur_stream());
     TORCH_CHECK(rc != LFS_E_UNSUPPORTED, "Unsupported number of channels: ", channels); // Rasterization.cpp:127
     check_rc(rc, "rasterize_to_pixels_from_world_3dgs_fwd");
-    g_raster_cache.valid = !present(thin_prism_coeffs);   // what the backward of THIS forward may reuse (see RasterCache)
-    g_raster_cache.key = raster_key(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1, Ks,
-                                    (int)camera_model, (int)rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids);
-    g_raster_cache.ws = ws;
+    // what the backward of THIS forward may reuse (see RasterCache)
+    g_raster_cache.store(raster_key(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1, Ks,
+                                    (int)camera_model, (int)rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids),
+                         ws, raster_held(means, quats, scales, colors, opacities, backgrounds, masks, viewmats0, viewmats1, Ks, radial_coeffs, tangential_coeffs, tile_offsets, flatten_ids),
+                         !present(thin_prism_coeffs));
     return std::make_tuple(renders, alphas, last_ids);
 }
 
@@ -265,12 +294,10 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     at::Tensor v_colors = at::empty_like(colors), v_opacities = at::empty_like(opacities);
     const lfs_cameras cams = make_cams(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs);
     const lfs_ut_params ut = make_ut(ut_params);
-    const bool hit = g_raster_cache.valid && !present(thin_prism_coeffs) &&
-                     g_raster_cache.key == raster_key(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1,
-                                                      Ks, (int)camera_model, (int)rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids);
-    at::Tensor ws = hit ? g_raster_cache.ws
-                        : scratch(lfs_rasterize_workspace_bytes((uint32_t)C, (uint32_t)N, (uint32_t)channels, (uint32_t)image_width, (uint32_t)image_height, (uint32_t)tile_size, flatten_ids.numel()), means);
-    g_raster_cache.valid = false; g_raster_cache.ws = at::Tensor();   // one backward per forward; the staging is released with this call
+    at::Tensor ws = g_raster_cache.take(raster_key(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1,
+                                                   Ks, (int)camera_model, (int)rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids));
+    const bool hit = ws.defined() && !present(thin_prism_coeffs);   // (the slot is empty now: one backward per forward; the staging is released with this call)
+    if (!hit) ws = scratch(lfs_rasterize_workspace_bytes((uint32_t)C, (uint32_t)N, (uint32_t)channels, (uint32_t)image_width, (uint32_t)image_height, (uint32_t)tile_size, flatten_ids.numel()), means);
     const int rc = (hit ? lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared : lfs_rasterize_to_pixels_from_world_3dgs_bwd)(
         (uint32_t)N, (uint32_t)channels, means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(), colors.data_ptr<float>(),
         opacities.data_ptr<float>(), opt_ptr<float>(backgrounds), (const uint8_t*)opt_ptr<bool>(masks), &cams, tile_size, &ut,

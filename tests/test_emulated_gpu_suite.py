@@ -48,7 +48,7 @@ SELECTION = {
                         "test_deterministic_backward_mode_is_bit_reproducible": "the integer-atomic accumulation mode is compiled out of the emulated build (no 64-bit atomics to model)",
                         "test_lds_reduction_asm_block_agrees_with_the_compiler_generated_stores": "compares two GPU builds in a subprocess (ISA-level by definition)",
                         "test_cell_culling_is_conservative[huge_and_near]": "half a minute (culling-off walks of every tile list); [small] and [low_opacity] are taken",
-                        "test_cell_culling_is_conservative[needles]": "as above"},
+                        "test_cell_culling_is_conservative[needles]": "as above", "test_cell_culling_is_conservative[flat_disks]": "as above (tools/fuzz_emulated.py --flat checks culling on / off on flat disks)"},
     "test_gpu_strategies": {"test_default_strategy_fused_refinement_one_host_read_same_result": "counts host synchronisations of a HIP stream",
                             "test_mcmc_refinement_step_needs_no_host_sync": "counts host synchronisations of a HIP stream",
                             "test_mcmc_inline_shN_adam_between_refinements_is_bit_identical": "trainer on a HIP stream",

@@ -216,13 +216,13 @@ def _cull_on_off(lfs, fn):
     return ref, fn()
 
 
-@pytest.mark.parametrize("kind", ["small", "needles", "huge_and_near", "low_opacity"])
+@pytest.mark.parametrize("kind", ["small", "needles", "huge_and_near", "low_opacity", "flat_disks"])
 def test_cell_culling_is_conservative(lfs, oracle_mod, kind):
     """The per-8x8-cell culling (raster_cull_kernel) may only drop entries that cannot reach alpha >= 1/255 on any
     ray of the cell: forward outputs must be BIT-identical with culling on and off; the backward BIT-identical in the deterministic accumulation mode
     (order-independent integer sums: a culled entry contributes nothing either way), and equal up to the float-atomic summation order in the default mode."""
     from lichtfeld_studio_amd import ops
-    rng = np.random.default_rng({"small": 40, "needles": 41, "huge_and_near": 42, "low_opacity": 43}[kind])
+    rng = np.random.default_rng({"small": 40, "needles": 41, "huge_and_near": 42, "low_opacity": 43, "flat_disks": 44}[kind])
     N, W, H, ts = 6000, 200, 136, 16
     means, quats, scales, opac = make_gaussians(rng, N, spread=1.5, smin=0.01, smax=0.05)
     if kind == "needles":
@@ -234,6 +234,10 @@ def test_cell_culling_is_conservative(lfs, oracle_mod, kind):
     elif kind == "low_opacity":
         opac = rng.uniform(0.0, 0.02, N).astype(np.float32)
         opac[::7] = 0.9
+    elif kind == "flat_disks":   # (round 5) the shape of a trained scene: one axis 20 - 100 x thinner than the other two - the silhouette conic (lfs_cull_conic.cuh) of a disk seen edge-on
+        scales = (rng.random((N, 3)) * 0.2 + 0.05).astype(np.float32)
+        thin = rng.integers(0, 3, N)
+        scales[np.arange(N), thin] = scales.max(-1) / rng.uniform(20.0, 100.0, N).astype(np.float32)
     vm0 = small_rotation_viewmat(rng, 0.2, 0.3)[None]
     K = pinhole_K(0.8 * W, W, H, 1)
     colors = rng.random((1, N, 3)).astype(np.float32)

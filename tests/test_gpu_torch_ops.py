@@ -231,3 +231,90 @@ def test_cxx_gut_train_step_class_equals_the_python_driver(lfs):
         assert torch.equal(pa, pb), (name, float((pa - pb).abs().max()))
         sa, sb = a.optimizer.state[id(pa)], b.optimizer.state[id(pb)]
         assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), name
+
+
+def _raster_inputs(lfs, m, seed, n=3000):
+    """one small scene through the libtorch wrappers up to the tile lists -> (positional args of ..._fwd, W, H)"""
+    from lichtfeld_studio_amd import scenes
+    dev = torch.device("cuda:0")
+    sc = scenes.syn_a(seed=seed, n=n, sh_degree=0).to(dev)
+    means, quats = sc.means.contiguous(), torch.nn.functional.normalize(sc.raw_quats, dim=-1).contiguous()
+    scales, opac = sc.raw_scales.exp().contiguous(), torch.sigmoid(sc.raw_opacities).contiguous()
+    W, H = sc.width, sc.height
+    vm, K = sc.viewmats.contiguous(), sc.Ks.contiguous()
+    radii, m2, d, _, _ = m.projection_ut_3dgs_fused(means, quats, scales, opac, vm, None, K, W, H, 0.3, 0.01, 1e4, 0.0, False, 0, None, 4, None, None, None)
+    _, ids, flat = m.intersect_tile(m2, radii, d, None, None, 1, 16, W // 16, H // 16, True)
+    offs = m.intersect_offset(ids, 1, W // 16, H // 16)
+    colors = torch.rand(1, n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+    return [means, quats, scales, colors, opac[None].contiguous(), None, None, W, H, 16, vm, None, K, 0, None, 4, None, None, None, offs, flat]
+
+
+@pytest.mark.gpu
+def test_raster_staging_cache_survives_freed_and_reallocated_inputs(lfs):
+    """Round-4 review: the forward -> backward staging cache of csrc/torch_ops.cpp was keyed on (address, version, numel) without holding the tensors: a caller that frees its
+    inputs after the forward and allocates same-sized tensors (the caching allocator hands the same addresses back) with OTHER contents got a stale hit - the backward
+    walked records packed from the old colours / opacities. The slot now holds its keyed tensors; whatever the allocator does, the backward must equal the
+    self-contained ctypes path on the tensors it is GIVEN."""
+    m = _mod()
+    from lichtfeld_studio_amd import ops
+    a = _raster_inputs(lfs, m, 3)
+    f = m.rasterize_to_pixels_from_world_3dgs_fwd(*a)
+    vr, va = torch.randn_like(f[0]), torch.randn_like(f[1])
+    ptrs = (a[3].data_ptr(), a[4].data_ptr())
+    shape_c, shape_o = a[3].shape, a[4].shape
+    a[3] = a[4] = None                      # the caller's temporaries die ...
+    torch.cuda.synchronize()
+    c2 = torch.rand(shape_c, device="cuda:0") * 0.5 + 0.25     # ... and same-sized ones with other contents are allocated
+    o2 = torch.rand(shape_o, device="cuda:0") * 0.5 + 0.1
+    a[3], a[4] = c2, o2
+    print("addresses reused by the allocator:", (c2.data_ptr(), o2.data_ptr()) == ptrs, "(held by the cache slot: they must NOT be)")
+    f2 = ops.rasterize_to_pixels_from_world_3dgs_fwd(*a[:13], lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, a[19], a[20])   # (ctypes path: does not touch the slot)
+    got = m.rasterize_to_pixels_from_world_3dgs_bwd(*a, f2[1], f2[2], vr, va)
+    want = [ops.rasterize_to_pixels_from_world_3dgs_bwd(*a[:13], lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, a[19], a[20], f2[1], f2[2], vr, va)
+            for _ in range(3)]
+    for i, x in enumerate(got):
+        noise_check(f"backward after re-allocated inputs [{i}]", rel_l2(n(x), n(want[0][i])), atomic_noise_bar(want[0][i], want[1][i], want[2][i]))
+
+
+@pytest.mark.gpu
+def test_raster_staging_cache_two_threads(lfs):
+    """The viewer thread of the reference renders through the same wrappers while the training thread sits between its forward and its backward
+    (rendering_pipeline.cpp:79; render_mutex_ covers post_backward / step only). Thread B hammers forwards of another scene; thread A's forward + backward pairs must
+    keep producing the gradients of A's scene (hit or miss of the slot - both are correct), without a crash."""
+    import threading
+    m = _mod()
+    from lichtfeld_studio_amd import ops
+    a, b = _raster_inputs(lfs, m, 5), _raster_inputs(lfs, m, 6, n=2500)
+    fa = m.rasterize_to_pixels_from_world_3dgs_fwd(*a)
+    vr, va = torch.randn_like(fa[0]), torch.randn_like(fa[1])
+    want = [ops.rasterize_to_pixels_from_world_3dgs_bwd(*a[:13], lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, a[19], a[20], fa[1], fa[2], vr, va)
+            for _ in range(3)]
+    bars = [atomic_noise_bar(want[0][i], want[1][i], want[2][i]) for i in range(5)]
+    stop, errors = threading.Event(), []
+
+    def viewer():
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                while not stop.is_set():
+                    m.rasterize_to_pixels_from_world_3dgs_fwd(*b)
+                s.synchronize()
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    th = threading.Thread(target=viewer)
+    th.start()
+    try:
+        worst = [0.0] * 5
+        for _ in range(60):
+            f = m.rasterize_to_pixels_from_world_3dgs_fwd(*a)
+            g = m.rasterize_to_pixels_from_world_3dgs_bwd(*a, f[1], f[2], vr, va)
+            assert torch.equal(f[0], fa[0])
+            for i, x in enumerate(g):
+                worst[i] = max(worst[i], rel_l2(n(x), n(want[0][i])))
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    for i in range(5):
+        noise_check(f"two-thread fwd/bwd [{i}]", worst[i], bars[i])
