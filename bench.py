@@ -306,12 +306,36 @@ def main() -> None:
     if headline_factored and not args.factored:
         # the factored exchange has never run between two GPUs (no multi-GPU box was ever available to this repository): one guarded trial step, on EVERY rank, before
         # anything is timed; if any rank's collective library refuses it the headline falls back to the flat all-reduce and says so
+        # Round 5 (review of round 4): a rank that fails BEFORE it enters a data collective would leave its peers blocked inside it, and the flag all-reduce below
+        # would never be reached. So the agreement comes first: every rank tries the two collectives of the layout on a few bytes (all_gather_into_tensor, an
+        # asynchronous all_reduce), the ranks agree on the outcome with one MIN all-reduce - the one collective every torch.distributed backend has - and only a
+        # layout that every rank accepted runs its full trial step (whose remaining failure modes - an unsupported problem shape, a kernel error - are functions of
+        # replicated state and hit all ranks alike, outside the collectives).
+        def agree(ok_here: int) -> bool:
+            f = torch.tensor([float(ok_here)], device=device)
+            torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MIN)
+            return float(f) == 1.0
         ok = 1
         try:
-            trainer.iteration = args.start_iteration
-            trainer.train_step([scenes.target_image(scene.height, scene.width, seed=43).to(device)])
+            from lichtfeld_studio_amd import dist as lfs_dist   # (the layout's own collective wrappers: gloo ranks stage through the host, RCCL goes direct)
+            probe = lfs_dist.ColorGradExchange(4, world, rank, 1, device)
+            probe.send.fill_(1.0)
+            rows = probe.gather()
+            one = torch.ones(4, device=device)
+            lfs_dist.all_reduce_sum(one)
             torch.cuda.synchronize()
-        except RuntimeError:
+            ok = int(float(rows.sum()) == 12.0 * world and float(one[0]) == float(world))
+        except Exception:   # noqa: BLE001  (whatever the collective library throws: the answer is "not this layout")
+            ok = 0
+        if agree(ok):
+            ok = 1
+            try:
+                trainer.iteration = args.start_iteration
+                trainer.train_step([scenes.target_image(scene.height, scene.width, seed=43).to(device)])
+                torch.cuda.synchronize()
+            except Exception:   # noqa: BLE001
+                ok = 0
+        else:
             ok = 0
         flag = torch.tensor([float(ok)], device=device)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)

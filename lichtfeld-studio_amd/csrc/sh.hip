@@ -160,9 +160,15 @@ template <bool MODEL, class T> LFS_DI T* sh_coef(T* coeffs, T* sh0, T* shN, uint
 //   3. (bwd) lane = Gaussian : dL/d(dir) = sum_k s_k grad b_k, evaluated once per Gaussian.
 // The previous layout evaluated the polynomial in every one of the LPG lanes of a Gaussian and was VALU-bound
 // (rocprof: 8.1e7 VALU instructions = 0.13 ms of the 0.20 ms backward at 1M Gaussians, K = 16).
+#ifndef LFS_SH_FWD_SPLIT
+#define LFS_SH_FWD_SPLIT 1
+#endif
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"   // (LPG = 32 - SH degree 4 - does not fit 64 registers: the request is a hint there, nothing spills - tests/test_kernel_resources.py)
 template <int LPG, bool MODEL>
-__global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors) {
+__global__ void __launch_bounds__(64) LFS_WAVES_PER_SIMD(8) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors) {
     __shared__ float lds[64 * (LPG + 1)];
+    __shared__ float lds_dc[MODEL ? 64 * 3 : 1];
     const uint32_t lane = threadIdx.x;
     const uint32_t g0 = blockIdx.x * 64u;
     const int degree = a.degree;
@@ -182,19 +188,30 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
     const unsigned long long vis = __ballot(on);
     constexpr int GPI = 64 / LPG; // Gaussians per iteration
     const int k = lane % LPG;
-    // all coefficient loads of the wavefront are issued before the first use (LPG independent 12-byte loads per lane in flight);
-    // masked-out Gaussians get colour 0 and their coefficients are not fetched
+    // Coefficient loads: masked-out Gaussians get colour 0 and their coefficients are not fetched. LFS_SH_FWD_SPLIT (round 5): the LPG row loads of a lane are issued
+    // in TWO halves - the first before the basis polynomial is evaluated (it hides the direction's latency and the polynomial), the second once the basis sits in LDS and
+    // its ~30 temporaries are dead - so that at most LPG/2 x 3 prefetch registers are live next to the polynomial: 100 -> <= 64 VGPRs = 8 instead of 5 wavefronts per SIMD
+    // (round 4 measured the streaming kernels that run 8 at 5.1 - 5.8 TB/s and this one at 3.6). 0 = all LPG loads up front (rounds 3 - 4).
+    constexpr int HALF = (LFS_SH_FWD_SPLIT && LPG >= 8) ? LPG / 2 : LPG;
     float c0[LPG], c1[LPG], c2[LPG];
-#pragma unroll
-    for (int it = 0; it < LPG; ++it) {
+    // Addresses: one wave-uniform 64-bit row base per iteration (SGPRs) + ONE 32-bit per-lane element offset shared by all iterations (global_load with an SGPR base),
+    // instead of a 64-bit VGPR address pair per iteration (32 VGPRs of the 98 the model form needed). The model form's k == 0 lanes take their row from sh0 - another
+    // allocation, so another base: the lane = Gaussian phase loads sh0 (one coalesced 768-byte block per wavefront) and parks it in LDS next to the basis.
+    const uint32_t KK = MODEL ? a.K - 1 : a.K;                         // rows of the coefficient tensor the lanes k >= (MODEL ? 1 : 0) walk
+    const uint32_t lane_el = ((lane / LPG) * KK + (MODEL ? uint32_t(k) - 1u : uint32_t(k))) * 3u;
+    const float* const walk = MODEL ? a.shN : a.coeffs;
+    auto fetch = [&](const int it) {
         const uint32_t gl = it * GPI + lane / LPG;
-        const uint32_t g = g0 + gl;
         c0[it] = c1[it] = c2[it] = 0.f;
-        if (k < Kd && ((vis >> gl) & 1ull)) {
-            const float* cf = sh_coef<MODEL>(a.coeffs, a.sh0, a.shN, a.K, g, k);
-            c0[it] = cf[0]; c1[it] = cf[1]; c2[it] = cf[2];
+        if (k < Kd && (!MODEL || k >= 1) && ((vis >> gl) & 1ull)) {
+            const float* row = walk + size_t(g0 + uint32_t(it) * GPI) * KK * 3u;   // (uniform)
+            c0[it] = row[lane_el]; c1[it] = row[lane_el + 1]; c2[it] = row[lane_el + 2];
         }
-    }
+    };
+    f3 dc{0.f, 0.f, 0.f};
+    if (MODEL && on) dc = ld3(a.sh0, gmine);
+#pragma unroll
+    for (int it = 0; it < HALF; ++it) fetch(it);
     {   // phase 1
         float b[25];
 #pragma unroll
@@ -205,13 +222,17 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
         } // masked-out rows: b = 0 -> colour 0
 #pragma unroll
         for (int k = 0; k < LPG; ++k) lds[lane * (LPG + 1) + k] = (k < 25) ? b[k] : 0.f;
+        if (MODEL) { lds_dc[lane * 3] = dc.x; lds_dc[lane * 3 + 1] = dc.y; lds_dc[lane * 3 + 2] = dc.z; }
     }
     __syncthreads();
+#pragma unroll
+    for (int it = HALF; it < LPG; ++it) fetch(it);
 #pragma unroll
     for (int it = 0; it < LPG; ++it) {
         const uint32_t gl = it * GPI + lane / LPG;
         const uint32_t g = g0 + gl;
         const float bk = lds[gl * (LPG + 1) + k];
+        if (MODEL && k == 0) { c0[it] = lds_dc[gl * 3]; c1[it] = lds_dc[gl * 3 + 1]; c2[it] = lds_dc[gl * 3 + 2]; }   // (0 for masked-out Gaussians: dc was never loaded)
         float r0 = bk * c0[it], r1 = bk * c1[it], r2 = bk * c2[it];
         r0 = group_sum<LPG>(r0); r1 = group_sum<LPG>(r1); r2 = group_sum<LPG>(r2);
         if (k == 0 && g < a.n) {
@@ -221,6 +242,8 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
         }
     }
 }
+
+#pragma clang diagnostic pop
 
 // op   : v_coeffs [n,K,3] fully written, v_dirs [n,3] (or NULL) fully written.
 // model: v_colors = dL/d(clamped colors), the clamp passes where the stored colour is > 0; v_sh0 / v_shN written

@@ -57,7 +57,9 @@ def plan_step(*, rasterizer: str, fused_l2: bool, world: int, force_collectives:
         # replicated layout with the factored SH exchange (dist.ColorGradExchange): per view rasterizer backward + finish, rows gathered, ONE multi-view SH backward
         # over every rank's views with shN's Adam update inside whenever Adam reads shN and no refinement rewrites it first; sh0 / shN never enter the all-reduce
         if not cxx_step:
-            raise ValueError("the factored SH exchange runs through the C++ step driver (cxx_step)")
+            # (a shape the speculative C++ step does not take - GutTrainer.__init__ rejects factored_sh for those up front; densification growing N past the index-bit
+            #  limit mid-run lands here: an error on every rank at the same iteration, N is replicated)
+            raise ValueError("the factored SH exchange runs through the C++ step driver (cxx_step): unsupported problem shape or cxx_step switched off")
         return StepPlan("cxx_factored", inline_shN_adam and strat_ok and adam_reads_shN, False, False, multi, True)
     if inline_all and cxx_step:
         return StepPlan("cxx_all", True, True, False, multi, skip_deferred)
@@ -91,6 +93,10 @@ class GutTrainer:
         if factored_sh and (sh_sharded or not (fused_l2 and rasterizer == "gut")):
             raise ValueError("factored_sh is a variant of the replicated layout of the fused 3DGUT step")
         self.factored_sh = bool(factored_sh)
+        if self.factored_sh:   # fail at construction, on every rank alike, not in the middle of a run (plan_step has no fallback form for this layout)
+            from .capi import load_library
+            if not load_library().lfs_gut_step_supported(int(sc.means.shape[0]), int(sc.width), int(sc.height), 16):
+                raise ValueError("factored_sh needs a problem shape the C++ step driver takes (lfs_gut_step_supported: <= 512 tile rows, Gaussian index + tile column in 32 bits)")
         self.color_exchange = None
         if sh_sharded and not (fused_l2 and rasterizer == "gut" and strategy in (None, "mcmc")):
             raise ValueError("sh_sharded needs the fused 3DGUT step (no strategy, or MCMC: its refinement steps run on the gathered tensors)")
@@ -315,7 +321,8 @@ class GutTrainer:
 
     def _train_step(self, targets: List[torch.Tensor], views: Optional[List[int]] = None, views_all: Optional[List[List[int]]] = None) -> float:
         """One optimisation step on this rank's share of the global view batch. `views` overrides this rank's views of the round-robin
-        schedule; SH-sharded, the owners must know every rank's views: pass `views_all` (one list per rank) with an explicit schedule.
+        schedule; SH-sharded AND with the factored SH exchange every rank must know every rank's views: pass `views_all` (one list per rank) with an explicit
+        schedule (a bare `views` raises there when world > 1).
         WHICH of the step forms runs is decided by plan_step (a pure function of the configuration, table-tested in tests/test_host_logic.py);
         each form is one method below."""
         self.iteration += 1
@@ -323,6 +330,10 @@ class GutTrainer:
             views = views_all[self.rank]
         elif views is not None and self.sh_exchange is not None and self.world > 1:
             raise ValueError("SH-sharded: pass views_all (every rank's views), the SH owners evaluate them")
+        elif views is not None and self.factored_sh and self.world > 1:
+            # the factored exchange evaluates the SH backward over the views of ALL ranks: with only this rank's views overridden the cameras of the round-robin
+            # schedule would be paired with the gathered dL/dcolour rows of other views - sh0 / shN / the direction term of dL/dmeans silently wrong
+            raise ValueError("factored SH exchange: pass views_all (every rank's views), each rank evaluates the SH backward over all of them")
         if views is None:
             views = lfs_dist.views_for_step(self.iteration - 1, self.rank, self.world, self.scene.viewmats.shape[0], self.views_per_rank)
         self._views_all = views_all

@@ -27,13 +27,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def make_task(n=6000, size=192, n_views=8, sh_degree=1, seed=7):
+def make_task(n=6000, size=192, n_views=8, sh_degree=1, seed=7, flat_max_aspect=None):
+    """flat_max_aspect (round 5): the ground truth is made of flat disks - one random axis `aspect` times thinner, aspect log-uniform in [1, flat_max_aspect] - the shape
+    of a trained scene and the regime of K8's re-orthogonalisation; None = the isotropic-ish task of rounds 2 - 4 (the random streams of its seeds are untouched)."""
     from lichtfeld_studio_amd import scenes
     g = torch.Generator().manual_seed(seed)
     K_ = (sh_degree + 1) ** 2
     means = (torch.rand(n, 3, generator=g) * 2 - 1) * 2.0
     quats = torch.randn(n, 4, generator=g)
     raw_scales = math.log(0.07) + 0.3 * torch.randn(n, 3, generator=g)
+    if flat_max_aspect is not None:
+        g2 = torch.Generator().manual_seed(seed + 50_000)
+        thin = torch.randint(0, 3, (n,), generator=g2)
+        raw_scales[torch.arange(n), thin] -= torch.rand(n, generator=g2) * math.log(flat_max_aspect)
     raw_opac = 1.0 + 1.5 * torch.randn(n, generator=g)
     sh0 = 0.6 * torch.randn(n, 1, 3, generator=g)
     shN = 0.15 * torch.randn(n, K_ - 1, 3, generator=g)

@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--seeds", type=int, nargs="+", default=[0, 1, 2, 3, 4])
     ap.add_argument("--iters", type=int, default=ITERS)
     ap.add_argument("--loss", choices=["l1_ssim", "mse"], default="l1_ssim", help="mse: the loss of the BENCHMARKED step (SURVEY.md 8d), HIP side through the C++ step driver")
+    ap.add_argument("--flat", type=float, default=0.0, help="> 1: the ground truth is made of flat disks, aspect ratio log-uniform in [1, FLAT] (convergence_check.make_task)")
     ap.add_argument("--atomic-runs", type=int, default=3)
     ap.add_argument("--det-runs", type=int, default=2, choices=[1, 2], help="2: the deterministic mode is run twice and the two results compared bit for bit")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02", "convergence_l1ssim_oracle.json"))
@@ -91,11 +92,11 @@ def main():
     if args.oracle:
         from oracle import pipeline
         lname = "L1 + 0.2 D-SSIM" if args.loss == "l1_ssim" else "clamped MSE"
-        res = json.load(open(args.out)) if os.path.exists(args.out) else {"task": f"recover 6000 Gaussians from 8 views 192x192, SH degree 1, {lname} loss, {args.iters} iterations", "seeds": {}}
+        res = json.load(open(args.out)) if os.path.exists(args.out) else {"task": f"recover 6000 Gaussians{f' (flat disks, aspect up to {args.flat:g})' if args.flat > 1 else ''} from 8 views 192x192, SH degree 1, {lname} loss, {args.iters} iterations", "seeds": {}}
         for seed in args.seeds:
             if str(seed) in res["seeds"]:
                 continue
-            gt, init = make_task(seed=100 + seed)
+            gt, init = make_task(seed=100 + seed, flat_max_aspect=args.flat if args.flat > 1 else None)
             targets = oracle_targets(gt)
             t0 = time.time()
             P = train_oracle(init, targets, args.iters, args.loss)
@@ -139,7 +140,7 @@ def main():
             lib.lfs_set_debug_flags(0)
 
     for seed in args.seeds:
-        gt, init = make_task(seed=100 + seed)
+        gt, init = make_task(seed=100 + seed, flat_max_aspect=args.flat if args.flat > 1 else None)
         f = args.oracle_json.replace(".json", f"_seed{seed}.npz")
         o = dict(np.load(f)) if os.path.exists(f) else None
         targets = render_views_hip(gt, dev)

@@ -179,7 +179,7 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
                         op2 = (opacs * (1 + eps)).astype(np.float32)
                         args2 = args[:4] + (t(op2),) + args[5:]
                         rc_p, ra_p, li_p = ops.rasterize_to_pixels_from_world_3dgs_fwd(*args2)
-                        g_p = ops.rasterize_to_pixels_from_world_3dgs_bwd(*args2, ra_p, li_p, v_rc, v_ra)[1].numpy().astype(np.float64).reshape(N, -1)
+                        g_p = _np(ops.rasterize_to_pixels_from_world_3dgs_bwd(*args2, ra_p, li_p, v_rc, v_ra)[1]).astype(np.float64).reshape(N, -1)
                         oargs2 = oargs[:4] + (op2,) + oargs[5:]
                         b_p = np.asarray(orc.rasterize_bwd(*oargs2, _np(ra_p), _np(li_p), _np(v_rc), _np(v_ra), dtype=np.float64)[1], np.float64).reshape(N, -1)
                         rows_p = np.sqrt(((g_p - b_p) ** 2).sum(1)) / np.sqrt((b_p ** 2).sum())
@@ -214,7 +214,7 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
         ops.adam_step_wrapper(p, m, v, grads[0].reshape(-1, 3)[:N].contiguous(), 1e-3, 0.9, 0.999, 1e-15, 10.0, 31.6)
         assert torch.isfinite(p).all(), (desc, "adam")
         if orc is not None:
-            g0 = grads[0].reshape(-1, 3)[:N].contiguous().numpy()
+            g0 = _np(grads[0].reshape(-1, 3)[:N].contiguous())
             wp, wm, wv = orc.adam_step(means.reshape(-1), np.zeros(3 * N, np.float32), np.zeros(3 * N, np.float32), g0.reshape(-1), 1e-3, 0.9, 0.999, 1e-15, 10.0, 31.6)
             assert np.array_equal(_np(p).reshape(-1), wp) and np.array_equal(_np(m).reshape(-1), wm) and np.array_equal(_np(v).reshape(-1), wv), (desc, "adam bit-exact")
             _stat("adam_step: bit-exact cases", 0)

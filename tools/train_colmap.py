@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--eval", action="store_true")
     ap.add_argument("-o", "--output-path", default="output")
     ap.add_argument("--text", action="store_true", help="read cameras.txt / images.txt / points3D.txt")
+    ap.add_argument("--eval-every", type=int, default=0, help="with --eval: held-out PSNR (the renderer the model trains with) every N iterations -> 'psnr_curve' (the turbulence of an MCMC run)")
     args = ap.parse_args()
 
     import lichtfeld_studio_amd  # noqa: F401
@@ -57,15 +58,37 @@ def main():
     tr = GutTrainer(scene, dev, iterations=args.iterations, loss="l1_ssim", strategy=None if args.strategy == "none" else args.strategy, opt_params=op,
                     scene_scale=scene_scale, rasterizer=rast, use_bilateral_grid=args.bilateral_grid)
     g = torch.Generator().manual_seed(0)
+    val_set = None
+    if args.eval and args.eval_every > 0:
+        cams_all, _ = (loader.read_colmap_cameras_and_images_text if args.text else loader.read_colmap_cameras_and_images)(args.data_path, args.images)
+        val = loader.CameraDataset(cams_all, "val", args.test_every, args.resize_factor, args.max_width)
+        vc, vi = [], []
+        for k, img in enumerate(loader.preload(val, dev)):
+            cam = val.cameras[val.indices[k]]
+            h, w = img.shape[1:]
+            vc.append(Camera(torch.from_numpy(loader.world_to_view(cam))[None].to(dev), torch.from_numpy(loader.intrinsics(cam, w, h))[None].to(dev), w, h))
+            vi.append(img)
+        val_set = (vc, vi)
+    curve = []
     t0 = time.time()
+    t_eval = 0.0
     order = []
     for it in range(args.iterations):
         if not order:
             order = torch.randperm(len(ds), generator=g).tolist()          # infinite random sampler, one view per step
         v = order.pop()
         tr.train_step([targets[v]], views=[v])
+        if val_set is not None and (it + 1) % args.eval_every == 0:
+            torch.cuda.synchronize(); te = time.time()
+            m = evaluate.evaluate(tr.model, val_set[0], val_set[1], it + 1, rasterizer=rast if args.gut else "fastgs")
+            s3 = tr.model.raw_scales.detach()
+            asp = (s3.max(-1).values - s3.min(-1).values).exp()
+            curve.append({"iteration": it + 1, "psnr": round(m.psnr, 3), "gaussians": int(tr.model.means.shape[0]), "mean_log_scale": round(float(s3.mean()), 3),
+                          "median_aspect": round(float(asp.median()), 2), "frac_aspect_ge_10": round(float((asp >= 10).float().mean()), 4)})
+            print(json.dumps(curve[-1]), file=sys.stderr, flush=True)
+            t_eval += time.time() - te
     torch.cuda.synchronize()
-    t_train = time.time() - t0
+    t_train = time.time() - t0 - t_eval
     out = {"data": args.data_path, "images": len(ds), "size": [scene.width, scene.height], "iterations": args.iterations, "rasterizer": rast,
            "strategy": args.strategy, "gaussians": int(tr.model.means.shape[0]), "load_s": round(t_load, 1), "train_s": round(t_train, 1),
            "iters_per_s": round(args.iterations / max(t_train, 1e-9), 1)}
@@ -83,6 +106,8 @@ def main():
         if args.gut:   # the reference's protocol above renders with the EWA rasterizer; this is the renderer the model was trained with
             mg = evaluate.evaluate(tr.model, cameras, images, args.iterations, rasterizer="gut")
             out.update(psnr_gut=round(mg.psnr, 4), ssim_gut=round(mg.ssim, 5))
+    if curve:
+        out["psnr_curve"] = curve
     os.makedirs(args.output_path, exist_ok=True)
     ply = os.path.join(args.output_path, f"splat_{args.iterations}.ply")
     loader.save_ply(tr.model, ply)
