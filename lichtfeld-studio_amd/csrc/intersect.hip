@@ -173,6 +173,9 @@ __global__ void __launch_bounds__(1024) isect_scatter_kernel(
 #ifndef LFS_TILES_SPAN
 #define LFS_TILES_SPAN 1024
 #endif
+#ifndef LFS_SORT_2CLASS
+#define LFS_SORT_2CLASS 1   // the <= 1024 and <= 4096 classes of the per-tile sort as ONE launch (lfs_tilelists.cuh tile_sort_bins_2class_kernel); 0 = two launches (rounds 2 - 4)
+#endif
 constexpr uint32_t ROWS_MAX = 512;                // pass 1: row buckets per launch (LDS tables)
 constexpr uint32_t ROWS_STAGE = LFS_ROWS_STAGE;   // pass 1: staged entries per workgroup (64 KiB); more than that -> direct stores
 constexpr uint32_t ROWS_PER_BLOCK = 1024;         // pass 1: Gaussians per workgroup (one per thread)
@@ -592,9 +595,17 @@ int lfs::isect_emit_impl(
         // kernel), larger -> bitonic on global memory
         // (max_tile_isects >= 0: the longest tile list, from lfs_intersect_tile_count_ex - classes no tile falls into are not launched: ~9 us each at T = 8160)
         const int64_t longest = max_tile_isects >= 0 ? max_tile_isects : INT64_MAX;
+#if LFS_SORT_2CLASS
+        // (round 5) both classes in one launch whenever the second one is needed at all: its few long lists then run beside the many short ones instead of after them
+        if (longest > 1024)
+            hipLaunchKernelGGL(tile_sort_bins_2class_kernel, dim3(T), dim3(512), 4096 * 8, s, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
+        else
+            hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 1024 * 8, s, 1u, 1024u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
+#else
         hipLaunchKernelGGL(tile_sort_bins_kernel<256>, dim3(T), dim3(256), 2 * 1024 * 8, s, 1u, 1024u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
         if (longest > 1024)
             hipLaunchKernelGGL((tile_sort_bins_kernel<512, 512, false, 32>), dim3(T), dim3(512), 4096 * 8, s, 1025u, 4096u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
+#endif
         if (longest > 4096)
             hipLaunchKernelGGL((tile_sort_bins_kernel<1024, 1024, false, 64>), dim3(T), dim3(1024), 16384 * 8, s, 4097u, 16384u, n_tiles_, tile_n_bits, w.offsets, isect_ids, flatten_ids);
         if (longest > 16384)

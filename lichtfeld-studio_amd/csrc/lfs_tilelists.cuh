@@ -128,18 +128,13 @@ LFS_DI void bitonic_sort_lds(uint64_t* __restrict__ keys, const uint32_t n_pad) 
 // COPY: the tile's keys are staged in LDS (A) next to the binned copy (B); COPY = false (round 2: lists of 4 097 .. 16 384 keys, the
 // common case at 3 M Gaussians / 1600x1200 where this stage was 0.53 ms per view on the bitonic path) re-reads them from global memory
 // in the two passes instead, so only B (128 KB at 16 384 keys) lives in LDS.
-template <int THREADS, int NBINS = 256, bool COPY = true, uint32_t BIN_LIMIT = 32>
-__global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
-    const uint32_t n_min, const uint32_t n_max, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets,
-    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
-    LFS_DYN_LDS(uint64_t, lds64);
+// (the body: one workgroup of THREADS threads sorts the bucket [start, start + n) of tile t; lds64 = the workgroup's dynamic LDS block)
+template <int THREADS, int NBINS, bool COPY, uint32_t BIN_LIMIT>
+LFS_DI void tile_sort_bins_body(const uint32_t t, const uint32_t start, const uint32_t n, const uint32_t n_tiles, const uint32_t tile_n_bits,
+                                int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, uint64_t* __restrict__ lds64) {
     __shared__ uint32_t s_hist[NBINS], s_off[NBINS + 1], s_minmax[2], s_big;
     static_assert(NBINS % 64 == 0, "one wave scans the bin counts");
     constexpr int PER = NBINS / 64;
-    const uint32_t t = blockIdx.x;
-    const uint32_t start = uint32_t(offsets[t]);
-    const uint32_t n = uint32_t(offsets[t + 1]) - start;
-    if (n < n_min || n > n_max) return;
     uint32_t n_pad = 2; while (n_pad < n) n_pad <<= 1;
     uint64_t* A = lds64;                          // [n_pad] input copy (COPY only)
     uint64_t* B = COPY ? lds64 + n_pad : lds64;   // [n_pad] binned / sorted
@@ -206,6 +201,33 @@ __global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
         isect_ids[start + o + rank] = int64_t(hi_bits | (k >> 32));
         flatten_ids[start + o + rank] = int32_t(uint32_t(k));
     }
+}
+
+template <int THREADS, int NBINS = 256, bool COPY = true, uint32_t BIN_LIMIT = 32>
+__global__ void __launch_bounds__(THREADS) tile_sort_bins_kernel(
+    const uint32_t n_min, const uint32_t n_max, const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets,
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
+    LFS_DYN_LDS(uint64_t, lds64);
+    const uint32_t t = blockIdx.x;
+    const uint32_t start = uint32_t(offsets[t]);
+    const uint32_t n = uint32_t(offsets[t + 1]) - start;
+    if (n < n_min || n > n_max) return;
+    tile_sort_bins_body<THREADS, NBINS, COPY, BIN_LIMIT>(t, start, n, n_tiles, tile_n_bits, isect_ids, flatten_ids, lds64);
+}
+
+// The two size classes that hold every tile of a typical view - 1 .. 1024 entries (256 bins, keys staged in LDS) and 1025 .. 4096 (512 bins, only the binned copy in LDS) -
+// in ONE launch of 512-thread workgroups (round 5): as two launches the second class - few, long lists - ran on its own for 23 us on SYN-B behind the 16 us of the first, most of
+// it the tail of its longest tiles on a mostly idle chip; in one launch those tiles overlap with the thousands of short ones. Same bodies, same results (the body does not
+// depend on which other tiles run beside it); 32 KiB of dynamic LDS per workgroup (the larger class) = 5 workgroups per CU.
+static __global__ void __launch_bounds__(512) tile_sort_bins_2class_kernel(
+    const uint32_t n_tiles, const uint32_t tile_n_bits, const int32_t* __restrict__ offsets, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
+    LFS_DYN_LDS(uint64_t, lds64);
+    const uint32_t t = blockIdx.x;
+    const uint32_t start = uint32_t(offsets[t]);
+    const uint32_t n = uint32_t(offsets[t + 1]) - start;
+    if (n < 1u || n > 4096u) return;   // (longer lists: the 1024-thread class / the global-memory network, launched separately when a tile needs them)
+    if (n <= 1024u) tile_sort_bins_body<512, 256, true, 32>(t, start, n, n_tiles, tile_n_bits, isect_ids, flatten_ids, lds64);
+    else tile_sort_bins_body<512, 512, false, 32>(t, start, n, n_tiles, tile_n_bits, isect_ids, flatten_ids, lds64);
 }
 
 // ---------------------------------------------------------------------------

@@ -166,7 +166,7 @@ template <bool MODEL, class T> LFS_DI T* sh_coef(T* coeffs, T* sh0, T* shN, uint
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"   // (LPG = 32 - SH degree 4 - does not fit 64 registers: the request is a hint there, nothing spills - tests/test_kernel_resources.py)
 template <int LPG, bool MODEL>
-__global__ void __launch_bounds__(64) LFS_WAVES_PER_SIMD(8) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors) {
+__global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors) {
     __shared__ float lds[64 * (LPG + 1)];
     __shared__ float lds_dc[MODEL ? 64 * 3 : 1];
     const uint32_t lane = threadIdx.x;
@@ -205,7 +205,8 @@ __global__ void __launch_bounds__(64) LFS_WAVES_PER_SIMD(8) sh_fwd_kernel(const 
         c0[it] = c1[it] = c2[it] = 0.f;
         if (k < Kd && (!MODEL || k >= 1) && ((vis >> gl) & 1ull)) {
             const float* row = walk + size_t(g0 + uint32_t(it) * GPI) * KK * 3u;   // (uniform)
-            c0[it] = row[lane_el]; c1[it] = row[lane_el + 1]; c2[it] = row[lane_el + 2];
+            const V3f t3 = *reinterpret_cast<const V3f*>(row + lane_el);   // ONE 12-byte load (global_load_dwordx3): written element by element the compiler emits three
+            c0[it] = t3.a[0]; c1[it] = t3.a[1]; c2[it] = t3.a[2];          // dword loads at a 12-byte lane stride - 48 instead of 16 trips through the address unit per wavefront
         }
     };
     f3 dc{0.f, 0.f, 0.f};

@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def make_task(n=6000, size=192, n_views=8, sh_degree=1, seed=7, flat_max_aspect=None):
+def make_task(n=6000, size=192, n_views=8, sh_degree=1, seed=7, flat_max_aspect=None, width=None, height=None, scale=0.07):
     """flat_max_aspect (round 5): the ground truth is made of flat disks - one random axis `aspect` times thinner, aspect log-uniform in [1, flat_max_aspect] - the shape
     of a trained scene and the regime of K8's re-orthogonalisation; None = the isotropic-ish task of rounds 2 - 4 (the random streams of its seeds are untouched)."""
     from lichtfeld_studio_amd import scenes
@@ -35,7 +35,7 @@ def make_task(n=6000, size=192, n_views=8, sh_degree=1, seed=7, flat_max_aspect=
     K_ = (sh_degree + 1) ** 2
     means = (torch.rand(n, 3, generator=g) * 2 - 1) * 2.0
     quats = torch.randn(n, 4, generator=g)
-    raw_scales = math.log(0.07) + 0.3 * torch.randn(n, 3, generator=g)
+    raw_scales = math.log(scale) + 0.3 * torch.randn(n, 3, generator=g)
     if flat_max_aspect is not None:
         g2 = torch.Generator().manual_seed(seed + 50_000)
         thin = torch.randint(0, 3, (n,), generator=g2)
@@ -44,10 +44,12 @@ def make_task(n=6000, size=192, n_views=8, sh_degree=1, seed=7, flat_max_aspect=
     sh0 = 0.6 * torch.randn(n, 1, 3, generator=g)
     shN = 0.15 * torch.randn(n, K_ - 1, 3, generator=g)
     viewmats = scenes.orbit_cameras(n_views, radius=7.0)
-    Ks = torch.tensor([[size * 1.1, 0, size / 2], [0, size * 1.1, size / 2], [0, 0, 1]], dtype=torch.float32).repeat(n_views, 1, 1)
-    gt = scenes.Scene("GT", size, size, sh_degree, means, quats, raw_scales, raw_opac, sh0, shN, viewmats, Ks)
+    W, H = (width or size), (height or size)
+    f = 1.1 * (size if width is None else min(W, H))
+    Ks = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], dtype=torch.float32).repeat(n_views, 1, 1)
+    gt = scenes.Scene("GT", W, H, sh_degree, means, quats, raw_scales, raw_opac, sh0, shN, viewmats, Ks)
     # perturbed start
-    init = scenes.Scene("INIT", size, size, sh_degree,
+    init = scenes.Scene("INIT", W, H, sh_degree,
                         means + 0.04 * torch.randn(n, 3, generator=g), quats + 0.3 * torch.randn(n, 4, generator=g),
                         raw_scales + 0.3 * torch.randn(n, 3, generator=g), raw_opac + 1.0 * torch.randn(n, generator=g),
                         sh0 + 0.4 * torch.randn(n, 1, 3, generator=g), torch.zeros_like(shN), viewmats, Ks)

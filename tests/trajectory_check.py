@@ -41,6 +41,16 @@ def main():
     ap.add_argument("--start-iteration", type=int, default=0, help="both sides begin at this iteration with a fresh optimizer (1000: the FIRST step already is the one-call form "
                                                                     "with shN in Adam - the boundary compared from identical states)")
     ap.add_argument("--out", default="")
+    # round 5: the task itself, towards BASELINE's size (defaults = the 6000-Gaussian task of rounds 2 - 4), and a segment that starts from a HIP-trained state
+    ap.add_argument("--n", type=int, default=6000)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--sh-degree", type=int, default=1)
+    ap.add_argument("--scale", type=float, default=0.07, help="median scale of the ground-truth Gaussians")
+    ap.add_argument("--flat", type=float, default=0.0, help="> 1: flat disks, aspect log-uniform in [1, FLAT]")
+    ap.add_argument("--pretrain", type=int, default=0, help="the HIP side trains this many iterations first (float atomics, the benchmarked step); the compared segment then starts from THAT "
+                                                           "state on both sides, at iteration = pretrain, with a fresh optimizer")
     args = ap.parse_args()
     import lichtfeld_studio_amd
     import oracle
@@ -50,9 +60,38 @@ def main():
     dev = torch.device("cuda:0")
     lib = lichtfeld_studio_amd.load_library()
     cps = sorted(c for c in set(args.checkpoints) if c <= args.steps)
-    gt, init = make_task(seed=100 + args.seed)
+    kw = dict(n=args.n, n_views=args.views, sh_degree=args.sh_degree, scale=args.scale, flat_max_aspect=args.flat if args.flat > 1 else None)
+    if args.width and args.height:
+        kw.update(width=args.width, height=args.height)
+    gt, init = make_task(seed=100 + args.seed, **kw)
     targets = render_views_hip(gt, dev)
     nV = init.viewmats.shape[0]
+    from convergence_check import psnr as _psnr
+    from lichtfeld_studio_amd import scenes as _scenes
+
+    def _scene_of(P):
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a))
+        return _scenes.Scene("s", init.width, init.height, init.sh_degree, t(P["means"]), t(P["raw_quats"]), t(P["raw_scales"]), t(P["raw_opacities"]), t(P["sh0"]), t(P["shN"]),
+                             init.viewmats, init.Ks)
+
+    def _eval(P):
+        return float(np.mean([_psnr(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(render_views_hip(_scene_of(P), dev), targets)]))
+
+    pre = {}
+    if args.pretrain > 0:
+        t0 = time.time()
+        trp = GutTrainer(init, dev, iterations=args.total_iters, loss="mse")
+        for it in range(args.pretrain):
+            trp.train_step([targets[it % nV]], views=[it % nV])
+        torch.cuda.synchronize()
+        Pp = {k: getattr(trp.model, k).detach().cpu().numpy().copy() for k in NAMES}
+        s3 = Pp["raw_scales"]
+        pre = {"pretrain_iterations": args.pretrain, "pretrain_seconds": round(time.time() - t0, 1), "psnr_start": round(_eval({k: np.asarray(pipeline.scene_arrays(init)[k]) for k in NAMES}), 3),
+               "psnr_after_pretrain": round(_eval(Pp), 3), "median_aspect_after_pretrain": round(float(np.median(np.exp(s3.max(-1) - s3.min(-1)))), 2)}
+        print(json.dumps(pre), flush=True)
+        init = _scene_of(Pp)
+        args.start_iteration = args.pretrain
+        del trp
 
     # ---- HIP, deterministic accumulation, the trainer exactly as tests/convergence_l1ssim.py --loss mse runs it
     hip, paths = {}, {}
@@ -106,7 +145,9 @@ def main():
                     row["apart_by_half_a_step"][k] = float((np.abs(np.asarray(hip[step][k], np.float64) - P[k]).reshape(-1) > 0.5 * np.median(d[d > 0])).mean())
             rows.append(row)
             print(json.dumps(row), flush=True)
-    res = {"start_iteration": args.start_iteration, "task": f"seed {args.seed}: 6000 Gaussians, 8 views 192x192, SH degree 1, clamped MSE; distance HIP (deterministic mode) - oracle / distance moved from the start, per tensor",
+    fin = {"psnr_hip_after_segment": round(_eval(hip[cps[-1]]), 4), "psnr_oracle_after_segment": round(_eval(P), 4)} if cps and cps[-1] == args.steps else {}
+    print(json.dumps(fin), flush=True)
+    res = {"start_iteration": args.start_iteration, **pre, **fin, "task": f"seed {args.seed}: {args.n} Gaussians{f' (flat disks, aspect up to {args.flat:g})' if args.flat > 1 else ''}, {nV} views {init.width}x{init.height}, SH degree {init.sh_degree}, clamped MSE; distance HIP (deterministic mode) - oracle / distance moved from the start, per tensor",
            "library": lib.lfs_version().decode(), "oracle_seconds": round(time.time() - t0, 1), "rows": rows}
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
