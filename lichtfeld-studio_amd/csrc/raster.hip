@@ -25,6 +25,9 @@
 //             scalar atomics per (warp, Gaussian)).
 //  * finish : one pass maps the accumulator through the quaternion / scale /
 //             mean vjp (done per (pixel, Gaussian) in the reference).
+// Measured and removed in round 5 (commit f684d4b, profiles/r05/lease4/ab_fwdzero_off.txt): the forward kernel clearing the backward's accumulator rows on the side (two or three
+// 16-byte stores per lane at kernel start, instead of the 64 MB hipMemsetAsync in front of the backward: 9 - 10 us): raster_fwd 0.234 -> 0.247 ms, step +0.015 - 0.025 ms - stores
+// issued by a VALU-bound kernel are not free.
 // Measured and removed in round 3 (kernels in git history up to e34272a, numbers under profiles/): 16x8 "wide" cells with two pixels per lane
 // (profiles/r01/raster_wide_cells_ab.json: bwd 0.84 vs 0.69 ms), quadrant-row kernels with DPP-broadcast records (profiles/r02/raster_rows_vs_default_pmc.txt:
 // 1.17x the VALU instructions), SH colours + record packing in one kernel (profiles/r02/fuse_front_ab.txt: no gain).
@@ -35,8 +38,6 @@
 #include "lfs_raster_pack.cuh"
 #include "lfs_adam.cuh"
 #include "lfs_step_internal.h"
-#include <mutex>
-#include <unordered_set>
 
 // LFS_BWD_REORTH (default 1 since round 5; -DLFS_BWD_REORTH=0 = the rounds 1 - 4 backward, kept for A/B: tools/build_variant.py noreorth raster.hip -DLFS_BWD_REORTH=0): the backward
 // re-orthogonalises the foot vector against the ray direction before it is used in a gradient - K8's gradients for FLAT Gaussians (tools/aniso_probe.py).
@@ -302,15 +303,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     const CamDev* __restrict__ cams, const GaussRec* __restrict__ recs, const float* __restrict__ colors,
     const float* __restrict__ backgrounds, const uint8_t* __restrict__ masks,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ cell_count, const int2* __restrict__ cell_list, const int32_t n_isects,
-    float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids,
-    float4* __restrict__ zero_base = nullptr, const uint32_t zero_n = 0) {
-    // Rider of the training step (round 5): this kernel is VALU-bound and leaves the memory pipes idle - its workgroups clear the backward's accumulator rows
-    // (64 bytes per Gaussian: the hipMemsetAsync of raster_bwd_impl, 9 - 10 us of HBM time on SYN-B, every step) on the side: zero_n float4 spread over ALL launched
-    // workgroups, two or three 16-byte stores per lane. Nothing reads the rows before the backward kernel of the same stream.
-    if (zero_base != nullptr) {
-        const uint32_t per = (zero_n + gridDim.x - 1) / gridDim.x, z0 = blockIdx.x * per, z1 = min(z0 + per, zero_n);
-        for (uint32_t z = z0 + threadIdx.x; z < z1; z += blockDim.x) zero_base[z] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
     const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
     if (!cc.in_grid) return;
@@ -712,16 +705,19 @@ struct FinishAdam { float* m[4]; float* v[4]; AdamScalars s[4]; float scale_reg,
 // `accumulate`) to g_* instead of being consumed - raster_finish_kernel + activations_bwd_kernel + the copy of dL/dmeans in one launch; dL/dcolour goes
 // to v_colors for the SH backward, which adds dL/d(dirs) onto g_means afterwards. *loss += the fused MSE (as raster_finish_kernel).
 struct FinishGrads { float* g_means; float* g_scales; float* g_quats; float* g_opac; float* v_colors; int accumulate; };
+#ifndef LFS_FINISH_BLOCK
+#define LFS_FINISH_BLOCK 256   // threads per workgroup of raster_finish_adam_kernel (A/B hook: 512 / 1024 = a larger contiguous chunk per stream and CU for the 29-stream pass)
+#endif
 template <bool ADAM>
-__global__ void __launch_bounds__(256) raster_finish_adam_kernel(
+__global__ void __launch_bounds__(LFS_FINISH_BLOCK) raster_finish_adam_kernel(
     const uint32_t N, float* __restrict__ means, float* __restrict__ raw_scales, float* __restrict__ raw_quats, float* __restrict__ raw_opacities,
     const float* __restrict__ quats, const float* __restrict__ scales, const float* __restrict__ opacities,
     const CamDev* __restrict__ cams, const float* __restrict__ acc, const float* __restrict__ v_dirs, const FinishAdam ad, const FinishGrads gr,
     const float* __restrict__ loss_slots, float* __restrict__ loss, const int32_t* __restrict__ abort_flag = nullptr) {
     if (ADAM && abort_flag != nullptr && *abort_flag != 0) return; // (uniform) speculative step that did not fit its buffers: no update, the host runs it again
     if (loss_slots != nullptr && blockIdx.x == 0) { // *loss = the fused MSE (a store in a fixed order: the step needs no zeroed accumulator)
-        __shared__ float wave_sum[4];
-        float v = threadIdx.x < LOSS_SLOTS ? loss_slots[threadIdx.x] : 0.f;
+        __shared__ float wave_sum[LFS_FINISH_BLOCK / 64];
+        float v = threadIdx.x < LOSS_SLOTS ? loss_slots[threadIdx.x] : 0.f;   // (LOSS_SLOTS = 256: the first four wavefronts carry the slots whatever the block size)
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
         if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = v;
@@ -735,7 +731,7 @@ __global__ void __launch_bounds__(256) raster_finish_adam_kernel(
 #if LFS_FINISH_LDS_ROWS && !defined(LFS_EMULATE)   // (the emulator switches lanes only at cross-lane operations: no wave-private LDS hand-over there)
     // the 64 accumulator rows of a wavefront (4 KB contiguous) as four fully coalesced 1-KB loads, handed to their lanes through a wave-private LDS block
     // (row stride 20 floats: 16-byte aligned, conflict-free on the read side) instead of four 16-byte loads per lane at a 64-byte stride
-    __shared__ float4 s_rows[4][64 * 5];
+    __shared__ float4 s_rows[LFS_FINISH_BLOCK / 64][64 * 5];
     float4* const rows = s_rows[threadIdx.x >> 6];
     {
         const uint32_t lane = threadIdx.x & 63, g0 = gid - lane;
@@ -907,7 +903,6 @@ __global__ void __launch_bounds__(256) raster_det_resolve_kernel(const size_t n,
 struct RasterGeom { uint32_t tw, th, blocks_per_tile, waves_per_block, threads, grid, wpt; uint64_t cells; };
 static uint32_t g_debug_flags = 0; // bit 0: keep every tile-list entry in the cell lists (no culling: the bit-identity tests); bit 4: deterministic backward accumulation
                                    // (two passes, 64-bit fixed point; 3 channels); bit 5: one-pass intersection scatter (intersect.hip). Bits 1-3 were the removed experiments.
-                                   // bit 6: SH colours after the projection (gut_step.hip); bit 7: the accumulator rows cleared by a memset instead of by the forward kernel (A/B)
 static bool raster_geom(const lfs_cameras* cams, uint32_t tile_size, RasterGeom& g) {
     if (tile_size < 8 || tile_size > 64 || (tile_size & 7)) return false;
     g.tw = (cams->image_width + tile_size - 1) / tile_size;
@@ -969,16 +964,6 @@ static int raster_check(uint32_t N, uint32_t channels, const lfs_cameras* cams, 
     return LFS_OK;
 }
 
-// Which rasterizer workspaces hold accumulator rows that the FORWARD kernel already cleared (zero_base above) and no backward has consumed yet: the guarded backward of the
-// training step then skips its memset. Host-side bookkeeping in launch order - forward and backward of a view are enqueued on one stream, and a "prepared" backward is
-// only valid on the workspace its forward just filled (records, cell lists), which is the same contract. One backward consumes the mark: a second one clears the rows itself.
-namespace {
-std::mutex g_acc_clean_mu;
-std::unordered_set<const void*> g_acc_clean;
-void acc_mark_clean(const void* ws) { std::lock_guard<std::mutex> g(g_acc_clean_mu); if (g_acc_clean.size() > 64) g_acc_clean.clear(); g_acc_clean.insert(ws); }
-bool acc_take_clean(const void* ws) { std::lock_guard<std::mutex> g(g_acc_clean_mu); return g_acc_clean.erase(ws) != 0; }
-} // namespace
-
 // n_isects >= 0: the host knows the count (operator calls); the workspace holds lists for exactly that many intersections.
 // n_isects < 0 (guarded training step, lfs_step_internal.h): the count is on the device - tile_offsets has T + 1 entries, the kernels read the last one -
 // and the lists are sized for `capacity`.
@@ -1031,17 +1016,11 @@ static int raster_fwd_impl(
     raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s, cams_ready, records_ready);
     lfs::ProfScope prof("raster_fwd", s);
     const RasterGeom gw = wave_geom(cams, g);
-    // the guarded forward of the training step (count on the device, one camera, RGB): its backward follows on the same stream and workspace - clear its accumulator rows
-    // (+ the fused-loss slots) here, under the VALU-bound kernel, instead of with a memset in front of the backward. Not in the deterministic mode (its two passes reuse
-    // the rows as maxima and clear a second array), not behind debug bit 7 (A/B).
-    const bool zero_acc = ic.n_isects < 0 && C == 1 && channels == 3 && !(g_debug_flags & (16u | 128u)) && N > 0;
-    float4* const zero_base = zero_acc ? reinterpret_cast<float4*>(w.acc) : nullptr;
-    const uint32_t zero_n = zero_acc ? uint32_t((ACC_STRIDE * size_t(C) * N + LOSS_SLOTS) / 4) : 0u;   // (ACC_STRIDE and LOSS_SLOTS are multiples of 4; acc is 256-byte aligned)
 #define LFS_FWD(CD, MODE)                                                                                        \
     hipLaunchKernelGGL((raster_fwd_kernel<CD, MODE>), dim3(gw.grid), dim3(gw.threads), 0, s, C, N, g.tw, g.th,     \
                        cams->image_width, cams->image_height, tile_size, gw.blocks_per_tile, gw.waves_per_block, \
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, ic.arg(), \
-                       render_colors, render_alphas, last_ids, zero_base, zero_n)
+                       render_colors, render_alphas, last_ids)
     switch (channels * 2 + raster_mode(cams)) {
     case 2: LFS_FWD(1, 0); break; case 3: LFS_FWD(1, 1); break;
     case 4: LFS_FWD(2, 0); break; case 5: LFS_FWD(2, 1); break;
@@ -1049,9 +1028,7 @@ static int raster_fwd_impl(
     case 8: LFS_FWD(4, 0); break; default: LFS_FWD(4, 1); break;
     }
 #undef LFS_FWD
-    const int err = (int)hipGetLastError();
-    if (zero_acc && err == 0) acc_mark_clean(workspace);
-    return err;
+    return (int)hipGetLastError();
 }
 
 extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
@@ -1112,9 +1089,7 @@ static int raster_bwd_impl(
     if (n_sized > 0 && (!flatten_ids || !render_alphas || !last_ids || (!v_render_colors && !mse))) return LFS_E_INVALID; // v_render_alphas == NULL: zeros
     const bool uniform = cams->rs_type == LFS_SHUTTER_GLOBAL;
     const size_t CN = size_t(C) * N;
-    // (guarded step: the forward kernel of this view cleared the rows and the loss slots already - raster_fwd_impl; the mark is consumed by the first backward)
-    const bool rows_clean = prepared && ic.n_isects < 0 && !det && acc_take_clean(workspace);
-    hipError_t e = rows_clean ? hipSuccess : hipMemsetAsync(w.acc, 0, sizeof(float) * (ACC_STRIDE * CN + (mse ? LOSS_SLOTS : 0)), s);
+    hipError_t e = hipMemsetAsync(w.acc, 0, sizeof(float) * (ACC_STRIDE * CN + (mse ? LOSS_SLOTS : 0)), s);
     MseFuse mse_dev{};
     if (mse) { mse_dev = *mse; mse_dev.loss = w.acc + ACC_STRIDE * CN; } // the kernel adds into the slots, raster_finish folds them into *loss
     if (e != hipSuccess) return (int)e;
@@ -1285,7 +1260,7 @@ int lfs::gut_finish_grads_impl(
     ad.scale_reg = scale_reg / (3.f * float(N)); ad.opacity_reg = opacity_reg / float(N);
     const FinishGrads gr{g_means, g_raw_scales, g_raw_quats, g_raw_opacities, v_colors, accumulate};
     lfs::ProfScope prof("finish_grads", s);
-    hipLaunchKernelGGL(raster_finish_adam_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, s, N, const_cast<float*>(means), (float*)nullptr, const_cast<float*>(raw_quats),
+    hipLaunchKernelGGL(raster_finish_adam_kernel<false>, dim3((N + LFS_FINISH_BLOCK - 1) / LFS_FINISH_BLOCK), dim3(LFS_FINISH_BLOCK), 0, s, N, const_cast<float*>(means), (float*)nullptr, const_cast<float*>(raw_quats),
                        (float*)nullptr, quats, scales, opacities, w.cams, w.acc, v_dirs, ad, gr, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss, (const int32_t*)nullptr);
     return (int)hipGetLastError();
 }
@@ -1318,7 +1293,7 @@ int lfs::gut_finish_adam_impl(
     // regularisers of trainer.cpp:132-158 (as lfs_activations_bwd): scale_reg * mean(scales) over 3N values, opacity_reg * mean(opacities)
     ad.scale_reg = scale_reg / (3.f * float(N)); ad.opacity_reg = opacity_reg / float(N);
     lfs::ProfScope prof("finish_adam", s);
-    hipLaunchKernelGGL(raster_finish_adam_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, s, N, means, raw_scales, raw_quats, raw_opacities, quats, scales, opacities,
+    hipLaunchKernelGGL(raster_finish_adam_kernel<true>, dim3((N + LFS_FINISH_BLOCK - 1) / LFS_FINISH_BLOCK), dim3(LFS_FINISH_BLOCK), 0, s, N, means, raw_scales, raw_quats, raw_opacities, quats, scales, opacities,
                        w.cams, w.acc, v_dirs, ad, FinishGrads{}, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss, abort_flag);
     return (int)hipGetLastError();
 }
