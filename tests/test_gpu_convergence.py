@@ -36,7 +36,7 @@ def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs):
     from lichtfeld_studio_amd.trainer import GutTrainer
     here = os.path.dirname(os.path.abspath(__file__))
     ores = json.load(open(os.path.join(here, "golden", "convergence_mse_oracle.json")))["seeds"]
-    seeds = sorted(int(k) for k in ores)[:int(os.environ.get("LFS_PSNR_SEEDS", "10"))]
+    seeds = sorted(int(k) for k in ores)[:int(os.environ.get("LFS_PSNR_SEEDS", "26"))]   # (round 5: all 26 stored seeds - 75 s more, and a mean that does not hang on which ten)
     dev = torch.device("cuda:0")
     lib = lfs.load_library()
     gaps = []
