@@ -9,6 +9,8 @@ import sys
 
 import numpy as np
 import torch
+
+from port_util import free_port
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -64,7 +66,7 @@ def test_dp2_matches_single_process_and_ranks_stay_identical():
     oracle.lib()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -120,7 +122,7 @@ def test_deferred_bucket_segment_is_left_out_of_the_collective():
     skipped by all_reduce(skip_deferred=True); everything else is summed over the ranks."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_worker_deferred, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -230,7 +232,7 @@ def test_sh_sharded_exchange_matches_replicated_computation(world, N):
     oracle.lib()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000) + 7 * world
+    port = free_port()
     procs = [ctx.Process(target=_sh_worker, args=(r, world, port, q, N)) for r in range(world)]
     for p in procs:
         p.start()
@@ -294,7 +296,7 @@ def test_early_segment_all_reduce_equals_the_single_collective():
     skipped; the per-collective accounting counts three collectives and the right payload."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_worker_early, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -360,7 +362,7 @@ def test_factored_color_gradient_exchange_matches_replicated_computation(world, 
     oracle.lib()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 32100 + (os.getpid() % 2000) + 13 * world + vpr
+    port = free_port()
     procs = [ctx.Process(target=_factored_worker, args=(r, world, port, q, N, vpr)) for r in range(world)]
     for p in procs:
         p.start()

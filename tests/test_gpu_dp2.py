@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import pytest
 import torch
+
+from port_util import free_port
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
@@ -59,7 +61,7 @@ def test_multi_rank_step_matches_single_process(lfs, sharded, world, backend):
         pytest.skip(f"RCCL needs one GPU per rank: {torch.cuda.device_count()} device(s) here, {world} ranks")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + {True: 1, False: 0, "factored": 2}[sharded] + 3 * world + (11 if backend == "nccl" else 0)
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, sharded, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
@@ -126,7 +128,7 @@ def test_two_rank_mcmc_keeps_sh_sharded_layout(lfs):
     re-shard for the new N. Replicated parameters, the gathered shN and its gathered Adam moments stay bit-identical across ranks; shards follow N."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 35500 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_mcmc_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -81,9 +81,21 @@ def main():
         if val_set is not None and (it + 1) % args.eval_every == 0:
             torch.cuda.synchronize(); te = time.time()
             m = evaluate.evaluate(tr.model, val_set[0], val_set[1], it + 1, rasterizer=rast if args.gut else "fastgs")
+            # the same metric on 12 TRAINING views: a held-out PSNR that falls while this one holds is a generalisation gap (Gaussians fitted to the rays the training views
+            # sample), both falling is an unstable optimisation
+            tsel = list(range(0, len(ds), max(1, len(ds) // 12)))[:12]
+            tcams = [tr.camera(v) for v in tsel]
+            mt = evaluate.evaluate(tr.model, tcams, [targets[v] for v in tsel], it + 1, rasterizer=rast if args.gut else "fastgs")
             s3 = tr.model.raw_scales.detach()
             asp = (s3.max(-1).values - s3.min(-1).values).exp()
-            curve.append({"iteration": it + 1, "psnr": round(m.psnr, 3), "gaussians": int(tr.model.means.shape[0]), "mean_log_scale": round(float(s3.mean()), 3),
+            # projected size of the SMALLEST axis of every Gaussian in pixels at the first training camera (focal length x scale / depth): the share below half a pixel
+            cam0 = tr.camera(0)
+            with torch.no_grad():
+                pc = tr.model.means.detach() @ cam0.world_view_transform[0, :3, :3].T + cam0.world_view_transform[0, :3, 3]
+                px = float(cam0.K[0, 0, 0]) * s3.exp().min(-1).values / pc[:, 2].clamp_min(1e-3)
+                sub = float(((px < 0.5) & (pc[:, 2] > 0.01)).float().mean())
+            curve.append({"iteration": it + 1, "psnr": round(m.psnr, 3), "psnr_train_views": round(mt.psnr, 3), "thin_axis_below_half_pixel": round(sub, 4),
+                          "gaussians": int(tr.model.means.shape[0]), "mean_log_scale": round(float(s3.mean()), 3),
                           "median_aspect": round(float(asp.median()), 2), "frac_aspect_ge_10": round(float((asp >= 10).float().mean()), 4)})
             print(json.dumps(curve[-1]), file=sys.stderr, flush=True)
             t_eval += time.time() - te
