@@ -19,7 +19,7 @@ namespace lfs {
 
 // Sloan's "Efficient Spherical Harmonic Evaluation" (JCGT 2013) basis, degree <= 4.
 // b[25]; when GRAD also the partials w.r.t. the unit direction.
-template <bool GRAD>
+template <bool GRAD, int MAXDEG = 4>   // MAXDEG: what the caller's lane layout can hold (16 lanes per Gaussian = degree <= 3): higher blocks are compiled out
 LFS_DI void sh_basis(const int degree, const float x, const float y, const float z,
                      float* __restrict__ b, float* __restrict__ bx, float* __restrict__ by, float* __restrict__ bz) {
 #pragma unroll
@@ -45,7 +45,7 @@ LFS_DI void sh_basis(const int degree, const float x, const float y, const float
         bx[7] = t0B; bz[7] = -1.092548430592079f * x;
         bx[8] = c2 * fC1_x; by[8] = c2 * fC1_y;
     }
-    if (degree < 3) return;
+    if (MAXDEG < 3 || degree < 3) return;
     const float t0C = -2.285228997322329f * z2 + 0.4570457994644658f;
     const float t1B = 1.445305721320277f * z;
     const float fC2 = x * fC1 - y * fS1, fS2 = x * fS1 + y * fC1;
@@ -66,7 +66,7 @@ LFS_DI void sh_basis(const int degree, const float x, const float y, const float
         bx[14] = t1B * fC1_x; by[14] = t1B * fC1_y; bz[14] = t1B_z * fC1;
         bx[15] = c3 * fC2_x; by[15] = c3 * fC2_y;
     }
-    if (degree < 4) return;
+    if (MAXDEG < 4 || degree < 4) return;
     const float t0D = z * (-4.683325804901025f * z2 + 2.007139630671868f);
     const float t1C = 3.31161143515146f * z2 - 0.47308734787878f;
     const float t2B = -1.770130769779931f * z;
@@ -487,6 +487,23 @@ __global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const
     for (int it = 0; it < LPG; ++it) a0[it] = a1[it] = a2[it] = 0.f;
     f3 m{0.f, 0.f, 0.f};
     if (gmine < a.n) m = ld3(a.means, gmine);
+    // Round 5: the higher-degree coefficient rows of the wavefront's 64 Gaussians are fetched ONCE (coalesced 12-byte loads) into LDS and read from there by every
+    // view's dL/d(dirs) term and by the Adam epilogue - they used to be re-read from global memory per view (48 dword loads per wavefront and view: L2 hits, but
+    // 8 views = 1.4 GB through the address unit at 1 M Gaussians, the multi-view pass of an 8-GPU rank took 0.66 ms against 0.23 for one view). Row stride K - 1
+    // floats x 3 (45 at degree 3: odd, the lanes of a read spread over the banks). Same values, same arithmetic: results are bit-identical.
+    LFS_DYN_LDS(float, s_cof);   // [64][(K - 1) * 3]
+    const uint32_t cof_stride = (a.K - 1u) * 3u;
+    if (want_dirs || ADAM) {
+#pragma unroll
+        for (int it = 0; it < LPG; ++it) {
+            const uint32_t gl = it * GPI + lane / LPG, g = g0 + gl;
+            if (k >= 1 && uint32_t(k) < a.K && g < a.n) {
+                const V3f t3 = *reinterpret_cast<const V3f*>(a.shN + (size_t(g) * (a.K - 1) + (k - 1)) * 3);
+                float* dst = s_cof + gl * cof_stride + (k - 1) * 3;
+                dst[0] = t3.a[0]; dst[1] = t3.a[1]; dst[2] = t3.a[2];
+            }
+        }
+    }
     float ox = 0.f, oy = 0.f, oz = 0.f;
     for (uint32_t v = 0; v < a.V; ++v) {
         f3 d{0.f, 0.f, 0.f};
@@ -508,7 +525,7 @@ __global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const
                 const f3 cp = campos_of(a.viewmats + 16 * v);
                 d = {m.x - cp.x, m.y - cp.y, m.z - cp.z};
                 if (degree >= 1) { inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
-                sh_basis<false>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
+                sh_basis<false, (LPG <= 4 ? 1 : LPG <= 16 ? 3 : 4)>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
                 v0 = v_colors[row * 3]; v1 = v_colors[row * 3 + 1]; v2 = v_colors[row * 3 + 2];
                 if (a.colors != nullptr) {                        // clamp_min backward
                     if (!(a.colors[row * 3] > 0.f)) v0 = 0.f;
@@ -530,7 +547,7 @@ __global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const
             if (want_dirs) {
                 float sk = 0.f;
                 if (k >= 1 && k < Kd && g0 + gl < a.n && (v0 != 0.f || v1 != 0.f || v2 != 0.f)) { // (basis 0 is constant: sh0 is not needed)
-                    const float* cf = a.shN + (size_t(g0 + gl) * (a.K - 1) + (k - 1)) * 3;
+                    const float* cf = s_cof + gl * cof_stride + (k - 1) * 3;   // (written before the first barrier of the view loop)
                     sk = cf[0] * v0 + cf[1] * v1 + cf[2] * v2;
                 }
                 lds[gl * (LPG + 1) + k] = sk;
@@ -539,7 +556,7 @@ __global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const
         __syncthreads();
         if (on && want_dirs) { // phase 3 (lane = Gaussian)
             float b[25], bx[25], by[25], bz[25];
-            sh_basis<true>(degree, d.x, d.y, d.z, b, bx, by, bz);
+            sh_basis<true, (LPG <= 4 ? 1 : LPG <= 16 ? 3 : 4)>(degree, d.x, d.y, d.z, b, bx, by, bz);
             float gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
             for (int kk = 1; kk < LPG && kk < 25; ++kk) {
@@ -564,7 +581,8 @@ __global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const
         const size_t e = (size_t(g) * (a.K - 1) + (k - 1)) * 3;
         if (ADAM) {
             float* pp = const_cast<float*>(a.shN) + e;
-            float q0 = pp[0], q1 = pp[1], q2 = pp[2];
+            const float* cf = s_cof + (it * GPI + lane / LPG) * cof_stride + (k - 1) * 3;   // the row as it was fetched at the top: nothing has written shN since
+            float q0 = cf[0], q1 = cf[1], q2 = cf[2];
             float m0 = adam.m[e], m1 = adam.m[e + 1], m2 = adam.m[e + 2], s0 = adam.v[e], s1 = adam.v[e + 1], s2 = adam.v[e + 2];
             adam_elem(q0, m0, s0, a0[it], adam.s); adam_elem(q1, m1, s1, a1[it], adam.s); adam_elem(q2, m2, s2, a2[it], adam.s);
             pp[0] = q0; pp[1] = q1; pp[2] = q2;
@@ -769,10 +787,11 @@ extern "C" int lfs_sh_model_bwd_views(
     const lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{lr, beta1, beta2, eps, bias_correction1_rcp, bias_correction2_sqrt_rcp}};
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((n + 63) / 64), block(64);
+    const size_t cof_bytes = size_t(64) * (K > 1 ? (K - 1) * 3 : 1) * sizeof(float);   // the wavefront's coefficient rows in LDS (11.5 KB at degree 3)
     lfs::ProfScope prof(inline_adam ? "sh_bwd_adam" : "sh_bwd", s);
 #define LFS_SH_VIEWS_BWD(L)                                                                                                                  \
-    if (inline_adam) hipLaunchKernelGGL((lfs::sh_views_bwd_kernel<L, true>), grid, block, 0, s, a, v_colors, accumulate, v_sh0, v_shN, v_means, adam); \
-    else hipLaunchKernelGGL((lfs::sh_views_bwd_kernel<L, false>), grid, block, 0, s, a, v_colors, accumulate, v_sh0, v_shN, v_means, adam)
+    if (inline_adam) hipLaunchKernelGGL((lfs::sh_views_bwd_kernel<L, true>), grid, block, cof_bytes, s, a, v_colors, accumulate, v_sh0, v_shN, v_means, adam); \
+    else hipLaunchKernelGGL((lfs::sh_views_bwd_kernel<L, false>), grid, block, cof_bytes, s, a, v_colors, accumulate, v_sh0, v_shN, v_means, adam)
     switch (lfs::lanes_for(K)) {
     case 1: LFS_SH_VIEWS_BWD(1); break;
     case 4: LFS_SH_VIEWS_BWD(4); break;
