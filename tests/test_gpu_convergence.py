@@ -21,7 +21,8 @@ def test_hip_and_oracle_training_reach_the_same_psnr(lfs, oracle_mod):
     assert abs(p_hip - p_ora) < 0.05, (p_hip, p_ora)      # and lands where the reference algorithm lands
 
 
-def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs):
+@pytest.mark.parametrize("task", ["isotropic", "flat50"])
+def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs, task):
     """BASELINE.json north star: "PSNR within 0.05 dB of reference after 7k iters", on the BENCHMARKED step - clamped MSE through the C++ step driver
     (lfs_gut_train_step) - against the CPU oracle (the restatement of the reference kernels, pinned to them by tests/golden/refk_*) trained with the same recipe
     from the same perturbed start for the same 7 000 iterations: tests/golden/convergence_mse_oracle.json holds the oracle's final PSNR per task seed (generated
@@ -35,7 +36,10 @@ def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs):
     from lichtfeld_studio_amd import scenes
     from lichtfeld_studio_amd.trainer import GutTrainer
     here = os.path.dirname(os.path.abspath(__file__))
-    ores = json.load(open(os.path.join(here, "golden", "convergence_mse_oracle.json")))["seeds"]
+    # task "flat50" (round 5): the ground truth is made of flat disks, aspect ratio log-uniform in 1 .. 50 (convergence_check.make_task(flat_max_aspect=50)) - the regime of
+    # K8's re-orthogonalisation; 16 oracle seeds (tests/convergence_l1ssim.py --oracle --loss mse --flat 50, 8 CPU-minutes each). Measured on the shipped library: mean gap
+    # +0.0001 dB, 95 % interval +- 0.025 dB (profiles/r05/lease10/psnr_flat_default.json) - this task RESOLVES the 0.05 dB of the north star
+    ores = json.load(open(os.path.join(here, "golden", "convergence_mse_oracle.json" if task == "isotropic" else "convergence_mse_flat50_oracle.json")))["seeds"]
     seeds = sorted(int(k) for k in ores)[:int(os.environ.get("LFS_PSNR_SEEDS", "26"))]   # (round 5: all 26 stored seeds - 75 s more, and a mean that does not hang on which ten)
     dev = torch.device("cuda:0")
     lib = lfs.load_library()
@@ -43,7 +47,7 @@ def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs):
     try:
         lib.lfs_set_debug_flags(16)
         for seed in seeds:
-            gt, init = cc.make_task(seed=100 + seed)
+            gt, init = cc.make_task(seed=100 + seed, flat_max_aspect=None if task == "isotropic" else 50.0)
             targets = cc.render_views_hip(gt, dev)
             tr = GutTrainer(init, dev, iterations=7000)
             V = init.viewmats.shape[0]
@@ -61,6 +65,6 @@ def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs):
     mean = float(np.mean(gaps))
     from scipy.stats import t as student_t
     ci = float(student_t.ppf(0.975, len(gaps) - 1)) * float(np.std(gaps, ddof=1)) / math.sqrt(len(gaps))
-    print(f"PSNR after 7000 iterations, {len(gaps)} seeds: mean gap {mean:+.4f} dB (95 % interval +- {ci:.3f}), single seeds {min(gaps):+.3f} .. {max(gaps):+.3f}")
+    print(f"PSNR after 7000 iterations, task {task}, {len(gaps)} seeds: mean gap {mean:+.4f} dB (95 % interval +- {ci:.3f}), single seeds {min(gaps):+.3f} .. {max(gaps):+.3f}")
     assert min(gaps) > -1.0 and all(np.isfinite(gaps))
     assert abs(mean) <= 0.05, (mean, ci, gaps)
