@@ -80,19 +80,32 @@ def main():
     ap.add_argument("--iters", type=int, default=ITERS)
     ap.add_argument("--loss", choices=["l1_ssim", "mse"], default="l1_ssim", help="mse: the loss of the BENCHMARKED step (SURVEY.md 8d), HIP side through the C++ step driver")
     ap.add_argument("--flat", type=float, default=0.0, help="> 1: the ground truth is made of flat disks, aspect ratio log-uniform in [1, FLAT] (convergence_check.make_task)")
+    # round 5: the task's size, towards BASELINE (defaults: the 6000-Gaussian task every stored result of rounds 2 - 4 refers to)
+    ap.add_argument("--n", type=int, default=6000)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--sh-degree", type=int, default=1)
+    ap.add_argument("--scale", type=float, default=0.07, help="median scale of the ground-truth Gaussians")
     ap.add_argument("--atomic-runs", type=int, default=3)
     ap.add_argument("--det-runs", type=int, default=2, choices=[1, 2], help="2: the deterministic mode is run twice and the two results compared bit for bit")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02", "convergence_l1ssim_oracle.json"))
     ap.add_argument("--oracle-json", default=os.path.join(ROOT, "profiles", "r02", "convergence_l1ssim_oracle.json"))
     args = ap.parse_args()
     import lichtfeld_studio_amd  # noqa: F401
-    from convergence_check import make_task
+    from convergence_check import make_task as _make_task
     from lichtfeld_studio_amd import scenes
+
+    def make_task(seed, flat_max_aspect=None):
+        kw = dict(n=args.n, n_views=args.views, sh_degree=args.sh_degree, scale=args.scale, flat_max_aspect=flat_max_aspect)
+        if args.width and args.height:
+            kw.update(width=args.width, height=args.height)
+        return _make_task(seed=seed, **kw)
 
     if args.oracle:
         from oracle import pipeline
         lname = "L1 + 0.2 D-SSIM" if args.loss == "l1_ssim" else "clamped MSE"
-        res = json.load(open(args.out)) if os.path.exists(args.out) else {"task": f"recover 6000 Gaussians{f' (flat disks, aspect up to {args.flat:g})' if args.flat > 1 else ''} from 8 views 192x192, SH degree 1, {lname} loss, {args.iters} iterations", "seeds": {}}
+        res = json.load(open(args.out)) if os.path.exists(args.out) else {"task": f"recover {args.n} Gaussians{f' (flat disks, aspect up to {args.flat:g})' if args.flat > 1 else ''} from {args.views} views {args.width or 192}x{args.height or 192}, SH degree {args.sh_degree}, {lname} loss, {args.iters} iterations", "seeds": {}}
         for seed in args.seeds:
             if str(seed) in res["seeds"]:
                 continue
