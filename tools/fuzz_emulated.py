@@ -11,6 +11,7 @@ culling on / off bit-identical in the forward, and - with the library built unde
 Results of the runs of record: profiles/r04/fuzz_emulated.txt."""
 import argparse
 import os
+import re
 import sys
 import time
 
@@ -37,6 +38,9 @@ def _stat(name, value):
     a = STATS.setdefault(name, [0, 0.0])
     a[0] += 1
     a[1] = max(a[1], float(value))
+
+
+REPLAY = False
 
 
 def one_case(rng, lfs, ops, lib, idx, orc=None):
@@ -113,7 +117,24 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
             cond = {"means2d": np.abs(p_m2 - o_m2), "depths": np.abs(p_d - o_d), "conics": np.abs(p_conics - o_conics), "radii": np.abs(p_radii - o_radii)}
         if both.any():
             r_bar = 1 if cond is None else 1 + 512 * int(cond["radii"][both].max())
-            assert int(np.abs(r_n[both] - o_radii[both]).max()) <= r_bar, (desc, "radii")
+            if cond is not None:
+                # (round 5, case 2782 of seed 59 on the MI355X: a needle under a rolling shutter, 2-D covariance of condition number ~1e4 - radius 1517 px on a 68 x 106 image,
+                #  the conic moving by 0.9 % under the 1e-6 perturbation and by 8 % between the two libms, the INTEGER radius by 0 and by 2: the perturbation response of an
+                #  integer cannot resolve a sensitivity below one pixel. A radius of more than ten image sizes - clamped to the image by the tile stage whatever its value -
+                #  gets 1 % of itself on top of the bar; counted.)
+                huge = (o_radii > 10.0 * max(W, H)) & both[..., None]
+                _stat("projection: radii beyond ten image sizes (held to the bar + 1 % of the radius; values per case)", int(huge.sum()))
+                r_bar = r_bar + np.where(huge, np.ceil(1e-2 * o_radii), 0).astype(np.int64)
+            else:
+                r_bar = np.full(o_radii.shape, r_bar, np.int64)
+            if (np.abs(r_n - o_radii)[both] > r_bar[both]).any():   # where, and what the three evaluations say there
+                for cg in np.argwhere(both & (np.abs(r_n - o_radii) > r_bar).any(-1)):
+                    c_, g_ = int(cg[0]), int(cg[1])
+                    print(f"  radii beyond the bar {r_bar[c_, g_]} at (camera, Gaussian) = ({c_}, {g_}): HIP {r_n[c_, g_]} oracle {o_radii[c_, g_]} perturbed oracle {None if cond is None else p_radii[c_, g_]}; "
+                          f"means2d HIP {_np(m2)[c_, g_]} oracle {o_m2[c_, g_]}{'' if cond is None else f' perturbed {p_m2[c_, g_]}'}; conics HIP {_np(conics)[c_, g_]} oracle {o_conics[c_, g_]}"
+                          f"{'' if cond is None else f' perturbed {p_conics[c_, g_]}'}; depth HIP {_np(d)[c_, g_]} oracle {o_d[c_, g_]}; scales {scales[g_]} quat {quats[g_]} mean {means[g_]} "
+                          f"opacity {opac[g_]}; K {K[c_].tolist()} distortion {None if rad is None else rad[c_].tolist()}", flush=True)
+            assert (np.abs(r_n - o_radii)[both] <= r_bar[both]).all(), (desc, "radii")
             for nm, a, b in (("means2d", _np(m2)[both], o_m2[both]), ("depths", _np(d)[both], o_d[both]), ("conics", _np(conics)[both], o_conics[both])):
                 allow = 1e-4 + 1e-4 * np.abs(b) + (0.0 if cond is None else 512.0 * cond[nm][both])
                 if cond is not None:   # never tighter than what the -m gpu suite holds the projection to (tests/test_oracle_refk_golden.py::check_projection: the UT's fp32 noise floor)
@@ -239,7 +260,7 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
             # (one threshold flip at a pixel moves the gradient of every Gaussian behind it in that pixel's list: case 1798 of seed 47 has six such rows of 65, every other row at 3e-7)
             MF = max(4, N // 8)
             e, flips, rest = rows_check(a, b, bar=2e-4, max_flips=MF)
-            if idx < 0:   # --replay: where the difference sits, and what the ORACLE's own fp32 evaluation does against its fp64 one on the same case
+            if REPLAY:   # --replay: where the difference sits, and what the ORACLE's own fp32 evaluation does against its fp64 one on the same case
                 o32 = np.asarray(orc.rasterize_bwd(*oargs, _np(ra), _np(li), _np(v_rc), _np(v_ra), dtype=np.float32)[("v_means", "v_quats", "v_scales", "v_colors", "v_opacities").index(nm)], np.float64).reshape(b.shape)
                 rows = np.sqrt(((a - b) ** 2).sum(1)) / np.sqrt((b ** 2).sum())
                 rows32 = np.sqrt(((o32 - b) ** 2).sum(1)) / np.sqrt((b ** 2).sum())
@@ -314,8 +335,10 @@ def main():
     ap.add_argument("--gpu", action="store_true", help="run the cases on cuda:0 through the shipped gfx950 library instead of the emulated host build")
     ap.add_argument("--flat", type=float, default=0.0, help="probability of a flat-Gaussian case (aspect 10 / 30 / 100); 0 keeps the case stream of the round-4 records")
     ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0: run for --seconds)")
+    ap.add_argument("--keep-going", action="store_true", help="record a failed case (state file + message) and continue with the next one; the exit code says whether any failed")
+    ap.add_argument("--state-dir", default="", help="where the generator state of a failed case is written (default /tmp; on a GPU lease: somewhere under gpurun_out/)")
     a = ap.parse_args()
-    global DEV, FLAT_P
+    global DEV, FLAT_P, REPLAY
     FLAT_P = a.flat
     if a.gpu:
         DEV = "cuda:0"
@@ -335,25 +358,41 @@ def main():
             print("library:", lib.lfs_version().decode())
         if a.replay:
             rng.bit_generator.state = json.load(open(a.replay))["state"]
-            print("replayed:", one_case(rng, lfs, ops, lib, -1, orc))
+            # (the case's own index again: the conditioning bars draw their perturbation from a generator seeded with it)
+            rec = json.load(open(a.replay))
+            m = re.search(r"'idx': (\d+)", rec.get("error", ""))
+            REPLAY = True
+            print("replayed:", one_case(rng, lfs, ops, lib, int(rec["idx"]) if "idx" in rec else int(m.group(1)) if m else -1, orc))
             return
-        t0, n, isects, biggest = time.time(), 0, 0, 0
+        t0, n, isects, biggest, failed = time.time(), 0, 0, 0, []
         while time.time() - t0 < a.seconds and (a.cases <= 0 or n < a.cases):
             state = rng.bit_generator.state
             try:
                 desc, k = one_case(rng, lfs, ops, lib, n, orc)
             except AssertionError as e:
-                path = f"/tmp/fuzz_emulated_seed{a.seed}_case{n}.json"
-                json.dump({"state": state, "error": str(e)}, open(path, "w"))
-                print(f"case {n} failed; generator state before it written to {path} (--replay {path}{' --oracle' if orc is not None else ''})")
-                raise
+                sdir = a.state_dir or "/tmp"
+                os.makedirs(sdir, exist_ok=True)
+                path = os.path.join(sdir, f"fuzz_emulated_seed{a.seed}_case{n}.json")
+                json.dump({"state": state, "idx": n, "error": str(e)}, open(path, "w"))
+                print(f"case {n} failed; generator state before it written to {path} (--replay {path}{' --oracle' if orc is not None else ''})", flush=True)
+                if not a.keep_going:
+                    raise
+                # --keep-going: the failure is recorded, the case is run again WITHOUT the comparisons (the main generator's draws do not depend on them), the stream goes on
+                failed.append((n, str(e)[:300]))
+                rng.bit_generator.state = state
+                desc, k = one_case(rng, lfs, ops, lib, n, None)
             n += 1
             isects += k
             biggest = max(biggest, k)
         print(f"fuzz_emulated{' --gpu (shipped gfx950 library)' if a.gpu else ''}{f' --flat {a.flat}' if a.flat else ''}: {n} cases in {time.time() - t0:.0f} s (seed {a.seed}), {isects} tile intersections walked in total, largest case {biggest}; "
-              f"sanitizer {'ON' if os.environ.get('LFS_EMUL_SANITIZE') else 'off'}; oracle comparison {'ON' if orc is not None else 'off'}; no assertion failed")
+              f"sanitizer {'ON' if os.environ.get('LFS_EMUL_SANITIZE') else 'off'}; oracle comparison {'ON' if orc is not None else 'off'}; {'no assertion failed' if not failed else f'{len(failed)} case(s) FAILED'}")
         for k, (cnt, worst) in sorted(STATS.items()):
             print(f"  {k}: {cnt} comparisons, worst {worst:.3g}")
+        if failed:
+            print(f"FAILED cases ({len(failed)}):")
+            for n_, e_ in failed:
+                print(f"  case {n_}: {e_}")
+            sys.exit(1)
 
 
 if __name__ == "__main__":
