@@ -21,7 +21,16 @@ def test_hip_and_oracle_training_reach_the_same_psnr(lfs, oracle_mod):
     assert abs(p_hip - p_ora) < 0.05, (p_hip, p_ora)      # and lands where the reference algorithm lands
 
 
-@pytest.mark.parametrize("task", ["isotropic", "flat50"])
+TASKS = {   # golden file, make_task arguments
+    "isotropic": ("convergence_mse_oracle.json", {}),
+    "flat50": ("convergence_mse_flat50_oracle.json", dict(flat_max_aspect=50.0)),
+    # round 5, towards BASELINE's size: 100 000 flat disks (aspect up to 30), 8 views 960 x 540, SH degree 3 - the oracle's 7 000 iterations take 2.5 h per seed on 8 cores
+    # (tests/convergence_l1ssim.py --oracle --loss mse --flat 30 --n 100000 --width 960 --height 540 --sh-degree 3 --scale 0.025), the HIP side 2.3 s
+    "flat30_100k": ("convergence_mse_100k_oracle.json", dict(flat_max_aspect=30.0, n=100_000, width=960, height=540, n_views=8, sh_degree=3, scale=0.025)),
+}
+
+
+@pytest.mark.parametrize("task", list(TASKS))
 def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs, task):
     """BASELINE.json north star: "PSNR within 0.05 dB of reference after 7k iters", on the BENCHMARKED step - clamped MSE through the C++ step driver
     (lfs_gut_train_step) - against the CPU oracle (the restatement of the reference kernels, pinned to them by tests/golden/refk_*) trained with the same recipe
@@ -39,7 +48,10 @@ def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs, tas
     # task "flat50" (round 5): the ground truth is made of flat disks, aspect ratio log-uniform in 1 .. 50 (convergence_check.make_task(flat_max_aspect=50)) - the regime of
     # K8's re-orthogonalisation; 16 oracle seeds (tests/convergence_l1ssim.py --oracle --loss mse --flat 50, 8 CPU-minutes each). Measured on the shipped library: mean gap
     # +0.0001 dB, 95 % interval +- 0.025 dB (profiles/r05/lease10/psnr_flat_default.json) - this task RESOLVES the 0.05 dB of the north star
-    ores = json.load(open(os.path.join(here, "golden", "convergence_mse_oracle.json" if task == "isotropic" else "convergence_mse_flat50_oracle.json")))["seeds"]
+    golden, task_kw = TASKS[task]
+    if not os.path.exists(os.path.join(here, "golden", golden)):
+        pytest.skip(f"tests/golden/{golden}: the oracle's trajectories for this task are not stored")
+    ores = json.load(open(os.path.join(here, "golden", golden)))["seeds"]
     seeds = sorted(int(k) for k in ores)[:int(os.environ.get("LFS_PSNR_SEEDS", "26"))]   # (round 5: all 26 stored seeds - 75 s more, and a mean that does not hang on which ten)
     dev = torch.device("cuda:0")
     lib = lfs.load_library()
@@ -47,7 +59,7 @@ def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs, tas
     try:
         lib.lfs_set_debug_flags(16)
         for seed in seeds:
-            gt, init = cc.make_task(seed=100 + seed, flat_max_aspect=None if task == "isotropic" else 50.0)
+            gt, init = cc.make_task(seed=100 + seed, **task_kw)
             targets = cc.render_views_hip(gt, dev)
             tr = GutTrainer(init, dev, iterations=7000)
             V = init.viewmats.shape[0]
@@ -64,7 +76,7 @@ def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs, tas
         lib.lfs_set_debug_flags(0)
     mean = float(np.mean(gaps))
     from scipy.stats import t as student_t
-    ci = float(student_t.ppf(0.975, len(gaps) - 1)) * float(np.std(gaps, ddof=1)) / math.sqrt(len(gaps))
+    ci = float(student_t.ppf(0.975, len(gaps) - 1)) * float(np.std(gaps, ddof=1)) / math.sqrt(len(gaps)) if len(gaps) > 1 else float("nan")
     print(f"PSNR after 7000 iterations, task {task}, {len(gaps)} seeds: mean gap {mean:+.4f} dB (95 % interval +- {ci:.3f}), single seeds {min(gaps):+.3f} .. {max(gaps):+.3f}")
     assert min(gaps) > -1.0 and all(np.isfinite(gaps))
     assert abs(mean) <= 0.05, (mean, ci, gaps)
