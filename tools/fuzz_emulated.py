@@ -202,8 +202,19 @@ def one_case(rng, lfs, ops, lib, idx, orc=None):
                 h_rc.reshape(o_li.shape + (cdim,))[flip] = o_rc.reshape(o_li.shape + (cdim,))[flip]
                 h_ra.reshape(o_li.shape)[flip] = o_ra.reshape(o_li.shape)[flip]
         dimg, dalp = np.abs(h_rc - o_rc), np.abs(h_ra - o_ra)
-        _stat("raster fwd: mean |colour diff| (bar 1e-5)", dimg.mean() if dimg.size else 0.0)
+        # a contribution whose alpha sits on the 1/255 threshold is taken on one side only: |d alpha| = T / 255 at that pixel - below the "beyond" bar of the next lines, yet on a
+        # 4 x 84 image ONE such pixel is a mean of 1.17e-5 (case 284 of seed 71, emulated: mean-alpha bar 1e-5 failed on exactly one flip, last_ids differing at that one pixel).
+        # Pixels that moved by more than half a threshold contribution are counted, bounded like the other flips, and left out of the MEANS.
         beyond = int((dimg.reshape(-1, cdim).max(-1) > 1 / 255 + 1e-4).sum())
+        if dimg.size:
+            pix = np.maximum(dimg.reshape(-1, cdim).max(-1), dalp.reshape(-1))
+            tflip = pix > 0.5 / 255
+            _stat("raster fwd: threshold-flip pixels left out of the means (per case)", int(tflip.sum()))
+            assert int(tflip.sum()) <= max(2, int(2e-3 * Cn * W * H)), (desc, "raster fwd threshold flips", int(tflip.sum()))
+            if tflip.any() and not tflip.all():
+                dimg = dimg.reshape(-1, cdim)[~tflip]
+                dalp = dalp.reshape(-1)[~tflip]
+        _stat("raster fwd: mean |colour diff| (bar 1e-5)", dimg.mean() if dimg.size else 0.0)
         _stat("raster fwd: pixels beyond 1/255 + 1e-4", beyond)
         fwd_ok = (dimg.mean() if dimg.size else 0.0) <= 1e-5 and dalp.mean() <= 1e-5
         limited = False
@@ -363,6 +374,8 @@ def main():
             m = re.search(r"'idx': (\d+)", rec.get("error", ""))
             REPLAY = True
             print("replayed:", one_case(rng, lfs, ops, lib, int(rec["idx"]) if "idx" in rec else int(m.group(1)) if m else -1, orc))
+            for k, (cnt, worst) in sorted(STATS.items()):
+                print(f"  {k}: {worst:.3g}")
             return
         t0, n, isects, biggest, failed = time.time(), 0, 0, 0, []
         while time.time() - t0 < a.seconds and (a.cases <= 0 or n < a.cases):
