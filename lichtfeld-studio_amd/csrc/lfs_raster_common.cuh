@@ -72,6 +72,63 @@ LFS_DI CellCtx cell_ctx(uint32_t n_tiles, uint32_t total_tiles, uint32_t tw, uin
 LFS_DI float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 LFS_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// LFS_SEL_E64 (round 6): the per-lane conditions of the inner loops as LANE MASKS in SGPR pairs - v_cmp_*_e64 writes the mask, plain SALU combines masks, the
+// wave-level "nobody" test is s_cmp on the mask, and every select is v_cndmask_b32_e64 on a mask - instead of the compiler's VCC / EXEC forms. tools/valu_rate.hip on
+// the MI355X (profiles/r06/valu_rate.json), ns per wavefront and SIMD at 7 wavefronts per SIMD: v_cndmask_b32_e64 with an SGPR-pair mask 1.8 (the plain VALU rate);
+// v_cmp -> VCC -> v_cndmask_b32_e32 6.1 per pair (3.7 would be the sum of its parts); v_cmp + s_cbranch_vccz 5.1; s_and_saveexec_b64 + s_or_b64 exec 7.3 per pair.
+// Same compares, same selects, same bits. The helpers take the condition twice: as a bool (the emulator build and the switch-off form) and as the mask.
+#ifndef LFS_SEL_E64
+#define LFS_SEL_E64 0
+#endif
+typedef unsigned long long lmask_t;
+#if LFS_SEL_E64 && !defined(LFS_EMULATE)
+#define LFS_MASK_ASM 1
+#else
+#define LFS_MASK_ASM 0
+#endif
+LFS_DI lmask_t lane_mask(const bool c) {
+#ifdef LFS_EMULATE
+    return __ballot(c);
+#else
+    return __builtin_amdgcn_ballot_w64(c);
+#endif
+}
+// a < b is FALSE (NaN passes), a <= b, uniform int k <= per-lane int v
+LFS_DI lmask_t mask_nlt_f32(const float a, const float b) {
+#if LFS_MASK_ASM
+    lmask_t m; asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m;
+#else
+    return lane_mask(!(a < b));
+#endif
+}
+LFS_DI lmask_t mask_le_f32(const float a, const float b) {
+#if LFS_MASK_ASM
+    lmask_t m; asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m;
+#else
+    return lane_mask(a <= b);
+#endif
+}
+LFS_DI lmask_t mask_le_i32_uniform(const int32_t k_uniform, const int32_t v) {
+#if LFS_MASK_ASM
+    lmask_t m; asm("v_cmp_le_i32_e64 %0, %1, %2" : "=s"(m) : "s"(k_uniform), "v"(v)); return m;
+#else
+    return lane_mask(k_uniform <= v);
+#endif
+}
+LFS_DI float sel_mask(const lmask_t m, const float if_set, const float if_clear) {
+#if LFS_MASK_ASM
+    float r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m)); return r;
+#else
+    return ((m >> (threadIdx.x & 63u)) & 1ull) ? if_set : if_clear;
+#endif
+}
+LFS_DI int32_t sel_mask_i32(const lmask_t m, const int32_t if_set, const int32_t if_clear) {
+#if LFS_MASK_ASM
+    int32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m)); return r;
+#else
+    return ((m >> (threadIdx.x & 63u)) & 1ull) ? if_set : if_clear;
+#endif
+}
 LFS_DI float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 LFS_DI float wave_min(float v) {
 #pragma unroll
@@ -105,11 +162,24 @@ LFS_DI f3 cross_fma(const f3& a, const f3& b) {
 #else
 #define LFS_SGPR_PIN2(text, a, b) asm volatile(text ::"s"(a), "s"(b))
 #endif
+// LFS_WALK_PREFETCH (round 6): the scalar record loads above are in flight for two evaluations; a record that misses the XCD's L2 (FETCH_SIZE says most of them do:
+// raster_fwd moves 64 B from the fabric per walked entry) takes longer than that under load. With the switch on, the 64 lanes pull the records of the NEXT 64 entries
+// towards the L2 with one vector load per chunk (lane = entry; the value is never used), so that the scalar load finds the line there. 0 = off.
+#ifndef LFS_WALK_PREFETCH
+#define LFS_WALK_PREFETCH 0
+#endif
 template <int STEP, class Eval, class Alive>
 LFS_DI void walk_cell_list(const int2* __restrict__ cl, const GaussRec* __restrict__ recs, const int32_t first, const int32_t n,
                            Eval&& eval, Alive&& alive) {
     if (n <= 0) return;
     const int32_t last = n - 1;
+#if LFS_WALK_PREFETCH && !defined(LFS_EMULATE)
+    const int32_t pf_lane = int32_t(threadIdx.x & 63u);
+    auto pf_id = [&](int32_t k) { return k < n ? reinterpret_cast<const int2*>(reinterpret_cast<const char*>(cl) + (uint32_t(first + STEP * k) << 3))->x : -1; };
+    auto pf_touch = [&](int32_t g) { return g >= 0 ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(recs) + (uint32_t(g) << 6)) : 0.f; };
+    float pf_val = pf_touch(pf_id(pf_lane));   // entries 0 .. 63 (the first four also arrive through the scalar loads below)
+    int32_t pf_next = pf_id(64 + pf_lane);     // ids of entries 64 .. 127: touched when the walk reaches entry 0 + 32
+#endif
     // unsigned 32-bit BYTE offsets: the scalar load then takes (64-bit base, 32-bit offset register) and the per-entry address
     // arithmetic is one shift instead of a sign extension + 64-bit shift + 64-bit add (the EWA forward, 22 VALU per entry, was
     // limited by its ~19 SALU per entry). Limits: C*N < 2^26 records, cell list < 2^29 entries (checked by the callers).
@@ -120,6 +190,13 @@ LFS_DI void walk_cell_list(const int2* __restrict__ cl, const GaussRec* __restri
     GaussRec A0 = rec_at(eA0.x), A1 = rec_at(eA1.x), B0 = rec_at(eB0.x), B1 = rec_at(eB1.x);
     for (int32_t k = 0; k < n; k += 4) {
         if (!alive()) break;
+#if LFS_WALK_PREFETCH && !defined(LFS_EMULATE)
+        if ((k & 63) == 32 && k + 32 < n) { // (uniform) half a chunk before the walk gets there: the next chunk's records, and the ids of the one after
+            asm volatile("" ::"v"(pf_val));  // the previous touch has long landed; this only keeps its load alive
+            pf_val = pf_touch(pf_next);
+            pf_next = pf_id(k + 96 + pf_lane);
+        }
+#endif
         eval(A0, eA0);
         if (k + 1 < n) eval(A1, eA1);
         LFS_SGPR_PIN2("; group B must have landed before group A is refilled", B0.r0.x, B1.r0.x);
@@ -134,6 +211,9 @@ LFS_DI void walk_cell_list(const int2* __restrict__ cl, const GaussRec* __restri
         B0 = rec_at(eB0.x); B1 = rec_at(eB1.x);
         nA0 = ent(k + 8); nA1 = ent(k + 9);
     }
+#if LFS_WALK_PREFETCH && !defined(LFS_EMULATE)
+    asm volatile("" ::"v"(pf_val), "v"(pf_next)); // (the touches are loads the compiler would otherwise drop)
+#endif
 }
 
 template <int CTRL>

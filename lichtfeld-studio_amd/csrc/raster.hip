@@ -44,6 +44,9 @@
 #ifndef LFS_BWD_REORTH
 #define LFS_BWD_REORTH 1
 #endif
+#if LFS_SEL_E64 && !LFS_REC_LOG2
+#error "LFS_SEL_E64 is written for the LFS_REC_LOG2 records"
+#endif
 #ifndef LFS_FINISH_LDS_ROWS
 #define LFS_FINISH_LDS_ROWS 1 // (round 3, same box: finish_adam 0.106 / 0.102 -> 0.102 / 0.097 ms; 0 = four 16-byte loads per lane at a 64-byte stride)
 #endif
@@ -348,6 +351,29 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
         RayEval re;
         ray_eval<MODE>(rec, ro, rd, re);
         const float alpha = fminf(0.999f, LFS_REC_LOG2 ? re.vis : rec.r3.x * re.vis);
+#if LFS_SEL_E64
+        // lane-mask form (lfs_raster_common.cuh): the same compares and selects, no VCC / EXEC round trips. A lane that does not composite adds fma(c, 0, pix) = pix.
+        const lmask_t pass = mask_nlt_f32(alpha, thr); // live pixel and alpha >= 1/255 (a NaN alpha passes, as in the reference's `if (alpha < 1/255) continue`)
+        LFS_EMUL_COUNT(0);
+        if (pass == 0ull) return;
+        LFS_EMUL_COUNT(1);
+        const float next_T = T * (1.f - alpha);
+        const lmask_t fin = pass & mask_le_f32(next_T, 1e-4f); // the terminating Gaussian is not composited
+        const lmask_t contrib = pass & ~fin;
+        const float vis = sel_mask(contrib, alpha * T, 0.f);
+        if (CDIM <= 3) {
+            pix[0] = __builtin_fmaf(rec.r3.y, vis, pix[0]);
+            if (CDIM > 1) pix[1] = __builtin_fmaf(rec.r3.z, vis, pix[1]);
+            if (CDIM > 2) pix[2] = __builtin_fmaf(rec.r3.w, vis, pix[2]);
+        } else {
+            const float* cp = colors + size_t(e.x) * CDIM;
+#pragma unroll
+            for (int k = 0; k < CDIM; ++k) pix[k] = __builtin_fmaf(cp[k], vis, pix[k]);
+        }
+        cur_idx = sel_mask_i32(contrib, e.y, cur_idx);
+        T = sel_mask(contrib, next_T, T);
+        thr = sel_mask(fin, INF, thr);
+#else
         const bool pass = !(alpha < thr); // live pixel and alpha >= 1/255 (a NaN alpha passes, as in the reference's `if (alpha < 1/255) continue`)
         LFS_EMUL_COUNT(0);
         if (__ballot(pass) == 0ull) return;
@@ -370,6 +396,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
             T = next_T;
         }
         thr = fin ? INF : thr;
+#endif
     };
     walk_cell_list<1>(cl, recs, 0, cnt, eval, [&]() { return __ballot(thr < INF) != 0ull; });
 
@@ -510,18 +537,32 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         const float araw = opac * vis;
 #endif
         const float alpha = fminf(0.999f, araw);
-        const bool valid = e.y <= bin_final && !(alpha < (1.f / 255.f)); // (inactive lanes carry bin_final = -1; vis > 1 cannot happen)
         LFS_EMUL_COUNT(2);
+#if LFS_SEL_E64
+        const lmask_t vmask = mask_le_i32_uniform(e.y, bin_final) & mask_nlt_f32(alpha, 1.f / 255.f); // (lane-mask form: lfs_raster_common.cuh)
+        if (vmask == 0ull) return;
+#else
+        const bool valid = e.y <= bin_final && !(alpha < (1.f / 255.f)); // (inactive lanes carry bin_final = -1; vis > 1 cannot happen)
         if (__ballot(valid) == 0ull) return;
+#endif
         LFS_EMUL_COUNT(3);
+#if LFS_SEL_E64
+        LFS_EMUL_LANES(vmask);
+#else
         LFS_EMUL_LANES(__ballot(valid));
+#endif
 
         // Invalid lanes are masked by zeroing three scalars (fac, v_op, and through it s): every reduced value below is
         // a product with one of them. (All factors are finite for an inactive lane: its direction is 0, so w = gro, t = 0.)
         const float ra = fast_rcp(1.f - alpha);
         const float Tn = T * ra;
+#if LFS_SEL_E64
+        T = sel_mask(vmask, Tn, T);
+        const float fac = sel_mask(vmask, alpha * Tn, 0.f);
+#else
         T = valid ? Tn : T;
         const float fac = valid ? alpha * Tn : 0.f;
+#endif
         float v[16], v_extra = 0.f, cv;
         if (CDIM <= 3) {
             cv = rec.r3.y * vc[0];
@@ -545,7 +586,11 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         for (int k = CDIM; k < 3; ++k) v[13 + k] = 0.f;
         // through alpha = min(0.999, opac * vis): no gradient on the clamped side
 #if LFS_REC_LOG2
+#if LFS_SEL_E64
+        const float sgeo = sel_mask(vmask & mask_le_f32(araw, 0.999f), araw * v_alpha, 0.f);
+#else
         const float sgeo = (valid && araw <= 0.999f) ? araw * v_alpha : 0.f; // s = alpha_raw * dL/dalpha = opac * dL/dopacity = vis * dL/dvis
+#endif
         const float v_op = sgeo;                                            // (slot 12 holds opac * dL/dopacity: the finish kernels divide)
         v[12] = v_op;
 #else
