@@ -248,6 +248,7 @@ def main() -> None:
                          "rasterizer.cpp:224-344 makes through the reference-signature C++ wrappers of _lfs_torch_ops.so, op by op under torch autograd, then six "
                          "adam_step_wrapper launches (fused_adam.cpp:22-95) - what a reference build linking csrc/torch_ops.cpp gets without touching its trainer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ops-route", action="store_true", help="skip the 16 extra steps of the drop-in route (the `ops_route` block of the line)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -399,6 +400,46 @@ def main() -> None:
             except Exception as e:   # (memory on a small box, ...): reported, not fatal
                 config4_line = {"parallelism": f"dp{world}-replicated", "value": None, "failed": str(e).splitlines()[0][:200]}
 
+    # The drop-in route next to the headline (round-5 review, "What's missing" 3): the SAME workload through the call sequence a reference build makes when only
+    # gsplat_backend / fastgs_backend are swapped for this library - rasterizer.cpp:224-344 op by op under torch autograd through the compiled reference-signature
+    # wrappers (csrc/torch_ops.cpp), then six adam_step_wrapper launches (fused_adam.cpp:22-95) - 10 steps after 3 warm-up steps, in this process, AFTER the timed
+    # region of the headline. backend_kernel_ms = this library's kernels (event-bracketed scopes of three further steps), libtorch_glue_ms = the rest of the step.
+    ops_route = None
+    if (world == 1 and args.path == "step" and args.rasterizer == "gut" and args.strategy == "none" and not args.bilateral_grid and args.loss == "mse"
+            and args.views_per_rank == 1 and not args.no_ops_route):
+        try:
+            from lichtfeld_studio_amd import torch_ops_route
+            torch_ops_route.install()
+            tr_ops = GutTrainer(scene, device, iterations=7000, world=1, rank=0, views_per_rank=1, loss=args.loss, rasterizer="gut", fused_l2=False, fused_adam=False)
+            tr_ops.iteration = args.start_iteration
+            for _ in range(3):
+                tr_ops.train_step(targets)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                tr_ops.train_step(targets)
+            torch.cuda.synchronize()
+            ops_ms = (time.perf_counter() - t1) / 10 * 1e3
+            capi.profile_collect(); capi.profile_filter(None); capi.profile_enable(True)
+            for _ in range(3):
+                tr_ops.train_step(targets)
+            capi.profile_enable(False)
+            tab = capi.profile_collect()
+            backend_ms = sum(ms for ms, _cnt in tab.values()) / 3
+            ops_route = {"ms_per_step": round(ops_ms, 4), "value": round(1e3 / ops_ms, 3), "steps": 10, "warmup": 3,
+                         "backend_kernel_ms": round(backend_ms, 4), "libtorch_glue_ms": round(max(ops_ms - backend_ms, 0.0), 4),
+                         "backend_kernels": {k: round(ms / 3, 4) for k, (ms, _cnt) in sorted(tab.items(), key=lambda kv: -kv[1][0])},
+                         "what": "rasterizer.cpp:224-344 + fused_adam.cpp:22-95 through the reference-signature wrappers of csrc/torch_ops.cpp (Python autograd glue in place of the reference's C++ autograd: "
+                                 "tests/test_gpu_reference_links.py times the reference's own C++ on the same library)"}
+            del tr_ops
+        except Exception as e:   # reported, never fatal for the headline
+            ops_route = {"ms_per_step": None, "failed": str(e).splitlines()[0][:200]}
+        finally:
+            try:
+                torch_ops_route.uninstall()
+            except Exception:
+                pass
+
     refine_ms = None
     if args.strategy == "mcmc" and world == 1:   # one refinement step on its own (relocation of the dead Gaussians + the step around it)
         trainer.iteration = (trainer.iteration // 100 + 1) * 100 - 1
@@ -515,7 +556,13 @@ def main() -> None:
                       "inter_gpu_collectives_before_this_run": "none: rounds 1 - 5 were developed on single-GPU boxes (gloo ranks on CPU / sharing one GPU, RCCL at world size 1)",
                       "expected_speedup_at_8_gpus": {"factored_1_view_per_rank": 5.7, "flat_1_view_per_rank": 4.2, "configs3_8_views_per_rank": 7.0, "estimate": True,
                                                      "source": "DESIGN.md 7 (per-rank compute measured at world size 1 + assumed xGMI bus bandwidth)"}},
-        "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel, "library": capi.load_library().lfs_version().decode(),
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
+        "kernels_source": (f"{table_steps} event-bracketed warm-up steps BEFORE the timed region (every kernel scope between two hipEventRecord: the events stretch a step by a few per cent, "
+                           "so the rows sum to more than ms_per_step; the dominant kernel's live figure from inside the timed region is roofline.avg_launch_ms)") if per_kernel else None,
+        "ops_route": ops_route,
+        # hand-written stream kernels on this box class (tools/hbm_stream.hip -> profiles/r06/hbm_stream_ceiling.json): what an HBM-bound kernel is priced against besides the 8 TB/s spec
+        "hbm_practical_ceiling_TBps": {"read": 7.2, "write": 5.6, "copy": 5.8, "triad": 5.9, "adam_7_streams": 5.3, "rmw_32_streams": 5.1, "source": "profiles/r06/hbm_stream_ceiling.json"},
+        "library": capi.load_library().lfs_version().decode(),
         **({"sh_sharded": sharded_line} if sharded_line is not None else {}),
         **({"replicated_other_exchange": factored_line} if factored_line is not None else {}),
         **({"config4": config4_line} if config4_line is not None else {}),

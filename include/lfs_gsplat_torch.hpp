@@ -74,6 +74,18 @@ void adam_step_wrapper(torch::Tensor& param, torch::Tensor& exp_avg, torch::Tens
                        const float bias_correction2_sqrt_rcp);
 } // namespace fast_gs::optimizer
 
+// The forward -> backward staging slot of the rasterizer wrappers (csrc/torch_ops.cpp; Ops.h has no argument through which a forward could hand its records and
+// per-cell lists to its backward, so the last forward's workspace is parked, keyed on the identity of its operands). Control surface (extension, not in Ops.h):
+//   torch_raster_staging_clear()     drop the parked workspace NOW - a viewer at the end of a render, a module before it is unloaded;
+//   torch_keep_raster_staging(true)  park after EVERY forward (default: only when one of means / quats / scales / colors / opacities requires_grad(), i.e. a backward can follow);
+//   torch_raster_staging_stats()     counters for tests and tuning.
+namespace lfs {
+struct RasterStagingStats { uint64_t stores, hits, misses, skipped_forwards, parked_bytes; };
+void torch_raster_staging_clear();
+void torch_keep_raster_staging(bool always);
+RasterStagingStats torch_raster_staging_stats();
+} // namespace lfs
+
 #include "lfs_gut_train_step.hpp" // lfs::GutTrainStep, lfs::AdamGroupState: the --gut training step as ONE call (extension; does not depend on the declarations above)
 
 // ---- fastgs/rasterization/include/rasterization_api.h:27-75, include/kernels/ssim.cuh:11-30 ----

@@ -26,11 +26,7 @@ struct m3 { float m[3][3]; };
 #define LFS_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(emu::dyn_lds())
 #define LFS_WAVE_LOCKSTEP() ((void)emu::ballot(true))
 #define LFS_SYSTEM_FENCE() ((void)0)
-#define LFS_WAVES_PER_SIMD(n)
 #else
-// register budget of a streaming kernel: ask the allocator for `n` resident wavefronts per SIMD (512 / n VGPRs each); every use is checked for zero scratch by
-// tests/test_kernel_resources.py - a kernel that would have to spill for it does not get the attribute
-#define LFS_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #define LFS_SYSTEM_FENCE() __threadfence_system()
 #define LFS_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 #define LFS_WAVE_LOCKSTEP() ((void)0)

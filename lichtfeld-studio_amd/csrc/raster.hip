@@ -750,15 +750,95 @@ struct FinishAdam { float* m[4]; float* v[4]; AdamScalars s[4]; float scale_reg,
 // `accumulate`) to g_* instead of being consumed - raster_finish_kernel + activations_bwd_kernel + the copy of dL/dmeans in one launch; dL/dcolour goes
 // to v_colors for the SH backward, which adds dL/d(dirs) onto g_means afterwards. *loss += the fused MSE (as raster_finish_kernel).
 struct FinishGrads { float* g_means; float* g_scales; float* g_quats; float* g_opac; float* v_colors; int accumulate; };
+#ifndef LFS_FINISH_ONE_TRIP
+#define LFS_FINISH_ONE_TRIP 1   // (round 6) every load of raster_finish_adam_kernel in one round trip; 0 = the round-5 form (four dependent trips), kept for the A/B
+#endif
+#if LFS_FINISH_ONE_TRIP && (!LFS_REC_LOG2 || !LFS_FINISH_LDS_ROWS)
+#error "LFS_FINISH_ONE_TRIP is written for the LFS_REC_LOG2 records and the LDS row hand-over"
+#endif
 #ifndef LFS_FINISH_BLOCK
 #define LFS_FINISH_BLOCK 256   // threads per workgroup of raster_finish_adam_kernel (A/B hook: 512 / 1024 = a larger contiguous chunk per stream and CU for the 29-stream pass)
 #endif
+// the fused-loss fold reads LOSS_SLOTS = 256 partial sums with the first four wavefronts of workgroup 0 and adds wave_sum[0..3]: smaller workgroups would drop slots
+static_assert(LFS_FINISH_BLOCK >= 256 && LFS_FINISH_BLOCK % 64 == 0 && LFS_FINISH_BLOCK <= 1024, "LFS_FINISH_BLOCK: 256, 320, ..., 1024");
 template <bool ADAM>
 __global__ void __launch_bounds__(LFS_FINISH_BLOCK) raster_finish_adam_kernel(
     const uint32_t N, float* __restrict__ means, float* __restrict__ raw_scales, float* __restrict__ raw_quats, float* __restrict__ raw_opacities,
     const float* __restrict__ quats, const float* __restrict__ scales, const float* __restrict__ opacities,
     const CamDev* __restrict__ cams, const float* __restrict__ acc, const float* __restrict__ v_dirs, const FinishAdam ad, const FinishGrads gr,
     const float* __restrict__ loss_slots, float* __restrict__ loss, const int32_t* __restrict__ abort_flag = nullptr) {
+#if LFS_FINISH_ONE_TRIP && !defined(LFS_EMULATE)   // (the emulator has no wave-private LDS hand-over: it runs the round-5 form below)
+    // Round 6: ONE memory round trip per wavefront. The round-5 form had four in series - abort-flag pointer -> flag -> the accumulator rows (their LDS hand-over
+    // sits behind a scheduling barrier no load may cross) -> the other 21 loads (two of them issued late, behind the first arithmetic) - in a kernel whose 29 streams
+    // reach 5.1 TB/s in a trivial pass (tools/hbm_stream.hip: multi_rmw_32_streams) and that ran at 3.1 - 3.7. Here every load of the pass is issued before the first
+    // wait, through (SGPR base, 32-bit byte offset) addresses - three offset registers instead of a 64-bit address pair per stream - and the abort flag is looked at
+    // where it matters: in front of the stores.
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = gid < N;
+    const uint32_t g = live ? gid : (N - 1u);              // (tail lanes read the last row: no branch around the loads)
+    const uint32_t o4 = g << 2, o12 = g * 12u, o16 = g << 4;
+    auto at = [](const void* base, uint32_t byte_off) { return reinterpret_cast<const char*>(base) + byte_off; };
+    auto ld3o = [&](const float* base, float (&dst)[3]) { const V3f t = *reinterpret_cast<const V3f*>(at(base, o12)); dst[0] = t.a[0]; dst[1] = t.a[1]; dst[2] = t.a[2]; };
+    auto ld4o = [&](const float* base) { return *reinterpret_cast<const float4*>(at(base, o16)); };
+    auto ld1o = [&](const float* base) { return *reinterpret_cast<const float*>(at(base, o4)); };
+    int32_t aborted = 0;
+    if (ADAM && abort_flag != nullptr) aborted = *abort_flag; // (scalar load: in flight with everything else)
+    // the 64 accumulator rows of a wavefront (4 KB contiguous) as four fully coalesced 1-KB loads, handed to their lanes through a wave-private LDS block below
+    __shared__ float4 s_rows[LFS_FINISH_BLOCK / 64][64 * 5];
+    float4* const rows = s_rows[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63, g0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane;
+    float4 t_rows[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { // (rows past the end: the last row again - an address clamp instead of a branch around the load)
+        const uint32_t idx = i * 64 + lane, row = min(g0 + (idx >> 2), N - 1u);
+        t_rows[i] = *reinterpret_cast<const float4*>(at(acc, (row << 6) + ((idx & 3u) << 4)));
+    }
+    float mu_a[3], sc[3], vd[3] = {0.f, 0.f, 0.f};
+    ld3o(means, mu_a); ld3o(scales, sc);
+    if (ADAM || v_dirs != nullptr) ld3o(v_dirs, vd);   // (gradient-tensor form: nullable - the SH backward then adds dL/d(dirs) onto g_means afterwards)
+    const float4 q = ld4o(quats), rq = ld4o(raw_quats);
+    const float o = ld1o(opacities);
+    float m0[3] = {0.f, 0.f, 0.f}, v0[3] = {0.f, 0.f, 0.f}, p1[3] = {0.f, 0.f, 0.f}, m1[3] = {0.f, 0.f, 0.f}, v1[3] = {0.f, 0.f, 0.f};
+    float4 mq = make_float4(0.f, 0.f, 0.f, 0.f), vq4 = mq;
+    float po = 0.f, mo = 0.f, vo = 0.f;
+    if (ADAM) {
+        ld3o(ad.m[0], m0); ld3o(ad.v[0], v0); ld3o(raw_scales, p1); ld3o(ad.m[1], m1); ld3o(ad.v[1], v1);
+        mq = ld4o(ad.m[2]); vq4 = ld4o(ad.v[2]);
+        po = ld1o(raw_opacities); mo = ld1o(ad.m[3]); vo = ld1o(ad.v[3]);
+    }
+    float loss_v = 0.f;
+    if (loss_slots != nullptr && blockIdx.x == 0) loss_v = threadIdx.x < LOSS_SLOTS ? loss_slots[threadIdx.x] : 0.f;   // (LOSS_SLOTS = 256: the first four wavefronts carry the slots)
+    // ---- everything is in flight; from here on the pass only consumes (the accumulator rows were requested first and are the first to be waited for) ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const uint32_t idx = i * 64 + lane; rows[(idx >> 2) * 5 + (idx & 3)] = t_rows[i]; }
+    __builtin_amdgcn_wave_barrier();
+    if (loss_slots != nullptr && blockIdx.x == 0) { // *loss = the fused MSE (a store in a fixed order: the step needs no zeroed accumulator)
+        __shared__ float wave_sum[LFS_FINISH_BLOCK / 64];
+        float v = loss_v;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0 && aborted == 0) {
+            const float total = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+            if (ADAM) *loss = total; else if (total != 0.f) unsafeAtomicAdd(loss, total);
+        }
+    }
+    if (!live || aborted != 0) return; // (aborted: uniform) speculative step that did not fit its buffers: no update, the host runs it again
+    float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+    const float4* a4 = rows + lane * 5;
+    const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
+    const float A[9] = {a0.x * REC_UNSCALE, a0.y * REC_UNSCALE, a0.z * REC_UNSCALE, a0.w * REC_UNSCALE, a1.x * REC_UNSCALE, a1.y * REC_UNSCALE, a1.z * REC_UNSCALE,
+                        a1.w * REC_UNSCALE, a2.x * REC_UNSCALE};
+    const f3 G{-a2.y * REC_UNSCALE, -a2.z * REC_UNSCALE, -a2.w * REC_UNSCALE};
+    bool any = G.x != 0.f || G.y != 0.f || G.z != 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) any |= A[k] != 0.f;
+    const f3 mu{mu_a[0], mu_a[1], mu_a[2]};
+    auto st3a = [&](float* base, const float (&src)[3]) { V3f t; t.a[0] = src[0]; t.a[1] = src[1]; t.a[2] = src[2]; *reinterpret_cast<V3f*>(const_cast<char*>(at(base, o12))) = t; };
+    auto ld3a = [&](const float* base, float (&dst)[3]) { ld3o(base, dst); };
+    const float v_opac = a3.x != 0.f ? a3.x / o : 0.f;
+#else
     if (ADAM && abort_flag != nullptr && *abort_flag != 0) return; // (uniform) speculative step that did not fit its buffers: no update, the host runs it again
     if (loss_slots != nullptr && blockIdx.x == 0) { // *loss = the fused MSE (a store in a fixed order: the step needs no zeroed accumulator)
         __shared__ float wave_sum[LFS_FINISH_BLOCK / 64];
@@ -832,6 +912,7 @@ __global__ void __launch_bounds__(LFS_FINISH_BLOCK) raster_finish_adam_kernel(
         mq = reinterpret_cast<const float4*>(ad.m[2])[gid]; vq4 = reinterpret_cast<const float4*>(ad.v[2])[gid];
         po = raw_opacities[gid]; mo = ad.m[3][gid]; vo = ad.v[3][gid];
     }
+#endif // LFS_FINISH_ONE_TRIP
     { // exactly raster_finish_kernel<true> for C == 1 (selected by `any` at the end)
         const m3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
         const float is[3] = {1.f / sc[0], 1.f / sc[1], 1.f / sc[2]};

@@ -160,11 +160,15 @@ template <bool MODEL, class T> LFS_DI T* sh_coef(T* coeffs, T* sh0, T* shN, uint
 //   3. (bwd) lane = Gaussian : dL/d(dir) = sum_k s_k grad b_k, evaluated once per Gaussian.
 // The previous layout evaluated the polynomial in every one of the LPG lanes of a Gaussian and was VALU-bound
 // (rocprof: 8.1e7 VALU instructions = 0.13 ms of the 0.20 ms backward at 1M Gaussians, K = 16).
+// LFS_SH_FWD_UNCOND (round 6): the coefficient rows are requested for EVERY Gaussian of the wavefront, together with the visibility word and the direction - one
+// memory round trip per wavefront instead of two in series (visibility -> ballot -> rows); the rows of an invisible Gaussian are read and dropped. Pays when most
+// Gaussians are visible (SYN-B: 95 %); a view that sees a small part of a scene reads (1 - visible fraction) x 180 B per Gaussian more than it needs.
+#ifndef LFS_SH_FWD_UNCOND
+#define LFS_SH_FWD_UNCOND 0
+#endif
 #ifndef LFS_SH_FWD_SPLIT
 #define LFS_SH_FWD_SPLIT 1
 #endif
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wpass-failed"   // (LPG = 32 - SH degree 4 - does not fit 64 registers: the request is a hint there, nothing spills - tests/test_kernel_resources.py)
 template <int LPG, bool MODEL>
 __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors) {
     __shared__ float lds[64 * (LPG + 1)];
@@ -203,7 +207,7 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
     auto fetch = [&](const int it) {
         const uint32_t gl = it * GPI + lane / LPG;
         c0[it] = c1[it] = c2[it] = 0.f;
-        if (k < Kd && (!MODEL || k >= 1) && ((vis >> gl) & 1ull)) {
+        if (k < Kd && (!MODEL || k >= 1) && (LFS_SH_FWD_UNCOND || ((vis >> gl) & 1ull))) {
             const float* row = walk + size_t(g0 + uint32_t(it) * GPI) * KK * 3u;   // (uniform)
             const V3f t3 = *reinterpret_cast<const V3f*>(row + lane_el);   // ONE 12-byte load (global_load_dwordx3): written element by element the compiler emits three
             c0[it] = t3.a[0]; c1[it] = t3.a[1]; c2[it] = t3.a[2];          // dword loads at a 12-byte lane stride - 48 instead of 16 trips through the address unit per wavefront
@@ -237,6 +241,7 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
         float r0 = bk * c0[it], r1 = bk * c1[it], r2 = bk * c2[it];
         r0 = group_sum<LPG>(r0); r1 = group_sum<LPG>(r1); r2 = group_sum<LPG>(r2);
         if (k == 0 && g < a.n) {
+            if (LFS_SH_FWD_UNCOND && !((vis >> gl) & 1ull)) { r0 = 0.f; r1 = 0.f; r2 = 0.f; } // (0 x an un-masked non-finite coefficient would be NaN)
             if (MODEL) { r0 = fmaxf(r0 + 0.5f, 0.f); r1 = fmaxf(r1 + 0.5f, 0.f); r2 = fmaxf(r2 + 0.5f, 0.f); }
             const size_t cs = (MODEL && a.cs) ? a.cs : 3;
             colors[cs * g] = r0; colors[cs * g + 1] = r1; colors[cs * g + 2] = r2;
@@ -244,7 +249,6 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
     }
 }
 
-#pragma clang diagnostic pop
 
 // op   : v_coeffs [n,K,3] fully written, v_dirs [n,3] (or NULL) fully written.
 // model: v_colors = dL/d(clamped colors), the clamp passes where the stored colour is > 0; v_sh0 / v_shN written
@@ -480,8 +484,7 @@ __global__ void __launch_bounds__(64) sh_views_bwd_kernel(const ShViews a, const
     const bool want_dirs = degree >= 1;
     constexpr int GPI = 64 / LPG;
     const int k = lane % LPG;
-    // gradient accumulators over the views; the coefficient rows needed for dL/d(dirs) are re-read per view (L2 hits after the
-    // first view) rather than cached: with them the kernel needs > 256 VGPRs next to the 100 of the derivative basis in phase 3
+    // gradient accumulators over the views (the coefficient rows the dL/d(dirs) term needs sit in LDS: below)
     float a0[LPG], a1[LPG], a2[LPG];
 #pragma unroll
     for (int it = 0; it < LPG; ++it) a0[it] = a1[it] = a2[it] = 0.f;

@@ -11,6 +11,7 @@
 #include <c10/hip/HIPStream.h>
 #include <c10/hip/HIPCachingAllocator.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -54,8 +55,8 @@ at::Tensor scratch(size_t bytes, const at::Tensor& like) {
 // the identity of every tensor it was built from - storage address AND autograd version counter (an in-place update bumps it; the Adam / add_noise wrappers below
 // bump it for their raw-pointer writes) - and a backward called with exactly those tensors, on the same stream, takes the "prepared" entry point. Anything else:
 // the self-contained path, as before. One slot per process (a backward matches the forward that directly preceded it: the training step).
-// Round 5 (review of round 4): (a) the slot HOLDS the keyed tensors (`held`), so none of their storages can be freed and handed out again at the same address with the
-// same version and size between the forward and the backward (the ABA hit a caller with short-lived same-sized temporaries could otherwise produce); (b) the slot is
+// Round 5 (review of round 4): (a) a storage freed and handed out again at the same address with the same version and size between the forward and the backward (the
+// ABA hit a caller with short-lived same-sized temporaries could otherwise produce) must miss - round 5 held the keyed tensors, round 6 watches their storages (below); (b) the slot is
 // guarded by a mutex, and a backward MOVES the workspace out under the lock: the reference's viewer thread may render through these wrappers
 // (rendering_pipeline.cpp:79) while the training thread is between its forward and its backward (render_mutex_ only covers post_backward / step, trainer.cpp:741), and
 // libtorch runs a C++ autograd Function's backward on the engine's device thread, not on the thread that ran the forward - which is also why the slot cannot be
@@ -67,41 +68,70 @@ struct TensorId {
 TensorId tid(const at::Tensor& t) { return t.defined() ? TensorId{t.data_ptr(), (uint32_t)t._version(), t.numel()} : TensorId{}; }
 TensorId tid(const gsplat::OptT& t) { return (t.has_value() && t->defined()) ? tid(*t) : TensorId{}; }
 struct RasterKey {
-    TensorId t[14]; uint32_t W = 0, H = 0, tile = 0; int cam = 0, shutter = 0; lfs_stream_t stream = nullptr;
+    TensorId t[15]; uint32_t W = 0, H = 0, tile = 0; int cam = 0, shutter = 0; lfs_stream_t stream = nullptr;
     bool operator==(const RasterKey& o) const {
-        for (int i = 0; i < 14; ++i) if (!(t[i] == o.t[i])) return false;
+        for (int i = 0; i < 15; ++i) if (!(t[i] == o.t[i])) return false;
         return W == o.W && H == o.H && tile == o.tile && cam == o.cam && shutter == o.shutter && stream == o.stream;
     }
 };
+// Round 6 (review of round 5 / ADVICE): the slot no longer HOLDS its keyed tensors - it watches their storages through weak references. A storage that died between the
+// forward and the backward (whose address the allocator may have handed out again: the ABA case of round 4) makes the key stale: miss. Nothing a forward-only caller
+// passed in - a model's activated copies, an autograd graph hanging off `colors` - outlives the caller's own references any more; the slot owns the workspace only.
+typedef c10::weak_intrusive_ptr<c10::StorageImpl> WeakStorage;
 struct RasterCache {
-    std::mutex mu; bool valid = false; RasterKey key; at::Tensor ws; std::vector<at::Tensor> held;
-    void store(RasterKey k, at::Tensor w, std::vector<at::Tensor> h, bool ok) {
-        std::vector<at::Tensor> old_held; at::Tensor old_ws;   // (released outside the lock)
-        { std::lock_guard<std::mutex> g(mu); old_held.swap(held); old_ws = std::move(ws); valid = ok; key = k; ws = std::move(w); held = std::move(h); }
+    std::mutex mu; bool valid = false; RasterKey key; at::Tensor ws; std::vector<WeakStorage> watched;
+    uint64_t n_store = 0, n_hit = 0, n_miss = 0, n_skipped = 0;
+    void store(RasterKey k, at::Tensor w, std::vector<WeakStorage> h) {
+        at::Tensor old_ws;   // (released outside the lock)
+        { std::lock_guard<std::mutex> g(mu); old_ws = std::move(ws); valid = true; key = k; ws = std::move(w); watched = std::move(h); ++n_store; }
     }
-    // -> the forward's workspace if `k` is the stored key (the slot is emptied either way: one backward per forward)
-    at::Tensor take(const RasterKey& k) {
-        std::vector<at::Tensor> old_held; at::Tensor out, old_ws;
-        { std::lock_guard<std::mutex> g(mu); const bool hit = valid && key == k; if (hit) out = std::move(ws); else old_ws = std::move(ws); ws = at::Tensor(); valid = false; old_held.swap(held); }
+    // -> the forward's workspace if `k` is the stored key and every watched storage is still alive (the slot is emptied either way: one backward per forward)
+    at::Tensor take(const RasterKey& k, bool count = true) {
+        at::Tensor out, old_ws;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            bool hit = valid && key == k;
+            for (const WeakStorage& w : watched) hit = hit && !w.expired();
+            if (hit) out = std::move(ws); else old_ws = std::move(ws);
+            ws = at::Tensor(); valid = false; watched.clear();
+            if (count) { if (hit) ++n_hit; else ++n_miss; }
+        }
         return out;
     }
-} g_raster_cache;
-std::vector<at::Tensor> raster_held(const at::Tensor& means, const at::Tensor& quats, const at::Tensor& scales, const at::Tensor& colors, const at::Tensor& opacities,
-                                    const gsplat::OptT& backgrounds, const gsplat::OptT& masks, const at::Tensor& viewmats0, const gsplat::OptT& viewmats1, const at::Tensor& Ks,
-                                    const gsplat::OptT& radial, const gsplat::OptT& tangential, const at::Tensor& tile_offsets, const at::Tensor& flatten_ids) {
-    std::vector<at::Tensor> h{means, quats, scales, colors, opacities, viewmats0, Ks, tile_offsets, flatten_ids};
-    for (const gsplat::OptT* o : {&backgrounds, &masks, &viewmats1, &radial, &tangential}) if (o->has_value() && (*o)->defined()) h.push_back(**o);
+    void clear() { (void)take(RasterKey{}, false); }   // (an all-default key never matches a stored one: the workspace is released outside the lock)
+};
+// never destroyed: a static destructor would release device memory after the HIP runtime may already be gone (process exit reclaims it)
+RasterCache& raster_cache() { static RasterCache* c = new RasterCache; return *c; }
+// Callers whose tensors do not carry requires_grad although a backward follows (raw-pointer style bindings: the pybind test module's explicit forward + backward
+// pairs) switch the requires_grad test of the forward wrapper off: lfs::torch_keep_raster_staging(true).
+std::atomic<bool> g_keep_staging_always{false};
+std::vector<WeakStorage> raster_watched(const at::Tensor& means, const at::Tensor& quats, const at::Tensor& scales, const at::Tensor& colors, const at::Tensor& opacities,
+                                        const gsplat::OptT& backgrounds, const gsplat::OptT& masks, const at::Tensor& viewmats0, const gsplat::OptT& viewmats1, const at::Tensor& Ks,
+                                        const gsplat::OptT& radial, const gsplat::OptT& tangential, const gsplat::OptT& thin, const at::Tensor& tile_offsets, const at::Tensor& flatten_ids) {
+    std::vector<WeakStorage> h;
+    auto watch = [&](const at::Tensor& t) { if (t.defined() && t.has_storage()) h.push_back(t.storage().getWeakStorageImpl()); };
+    for (const at::Tensor* t : {&means, &quats, &scales, &colors, &opacities, &viewmats0, &Ks, &tile_offsets, &flatten_ids}) watch(*t);
+    for (const gsplat::OptT* o : {&backgrounds, &masks, &viewmats1, &radial, &tangential, &thin}) if (o->has_value()) watch(**o);
     return h;
+}
+// Can a backward follow this forward at all? Not in inference mode, and not when none of the five differentiable operands requires a gradient (an evaluation or viewer
+// render of detached tensors): such a forward parks nothing and releases what an earlier one parked. The reference's rasterizer_autograd.cpp calls the wrapper from
+// inside its autograd Function's forward(), where grad mode is switched off but the operands are the caller's variables and still say requires_grad(): the training
+// step is recognised by that, not by the grad mode. (A caller that renders parameter tensors under NoGradGuard cannot be told apart from the training step from in
+// here; its workspace is replaced by the next forward and can be dropped at once with lfs::torch_raster_staging_clear().)
+bool backward_may_follow(const at::Tensor& means, const at::Tensor& quats, const at::Tensor& scales, const at::Tensor& colors, const at::Tensor& opacities) {
+    if (c10::InferenceMode::is_enabled()) return false;
+    return means.requires_grad() || quats.requires_grad() || scales.requires_grad() || colors.requires_grad() || opacities.requires_grad();
 }
 RasterKey raster_key(const at::Tensor& means, const at::Tensor& quats, const at::Tensor& scales, const at::Tensor& colors, const at::Tensor& opacities,
                      const gsplat::OptT& backgrounds, const gsplat::OptT& masks, uint32_t W, uint32_t H, uint32_t tile, const at::Tensor& viewmats0,
                      const gsplat::OptT& viewmats1, const at::Tensor& Ks, int cam, int shutter, const gsplat::OptT& radial, const gsplat::OptT& tangential,
                      const gsplat::OptT& thin, const at::Tensor& tile_offsets, const at::Tensor& flatten_ids) {
     RasterKey k;
-    const TensorId ids[14] = {tid(means), tid(quats), tid(scales), tid(colors), tid(opacities), tid(backgrounds), tid(masks), tid(viewmats0), tid(viewmats1), tid(Ks),
-                              tid(radial), tid(tangential), tid(tile_offsets), tid(flatten_ids)};
-    for (int i = 0; i < 14; ++i) k.t[i] = ids[i];
-    (void)thin; // (thin-prism coefficients ride with the radial ones in every caller; not part of the key's 14 slots)
+    // round 6 (review of round 5): the thin-prism coefficients are part of the key like every other operand - two forwards that differ only in them are two keys
+    const TensorId ids[15] = {tid(means), tid(quats), tid(scales), tid(colors), tid(opacities), tid(backgrounds), tid(masks), tid(viewmats0), tid(viewmats1), tid(Ks),
+                              tid(radial), tid(tangential), tid(thin), tid(tile_offsets), tid(flatten_ids)};
+    for (int i = 0; i < 15; ++i) k.t[i] = ids[i];
     k.W = W; k.H = H; k.tile = tile; k.cam = cam; k.shutter = shutter; k.stream = cur_stream();
     return k;
 }
@@ -269,10 +299,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rasterize_to_pixels_from_world_3d
     TORCH_CHECK(rc != LFS_E_UNSUPPORTED, "Unsupported number of channels: ", channels); // Rasterization.cpp:127
     check_rc(rc, "rasterize_to_pixels_from_world_3dgs_fwd");
     // what the backward of THIS forward may reuse (see RasterCache)
-    g_raster_cache.store(raster_key(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1, Ks,
-                                    (int)camera_model, (int)rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids),
-                         ws, raster_held(means, quats, scales, colors, opacities, backgrounds, masks, viewmats0, viewmats1, Ks, radial_coeffs, tangential_coeffs, tile_offsets, flatten_ids),
-                         !present(thin_prism_coeffs));
+    if (g_keep_staging_always.load() || backward_may_follow(means, quats, scales, colors, opacities))
+        raster_cache().store(raster_key(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1, Ks,
+                                        (int)camera_model, (int)rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids),
+                             ws, raster_watched(means, quats, scales, colors, opacities, backgrounds, masks, viewmats0, viewmats1, Ks, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids));
+    else {
+        raster_cache().clear();   // a forward no backward can follow: nothing is parked, and what an earlier forward parked is released
+        std::lock_guard<std::mutex> g(raster_cache().mu); ++raster_cache().n_skipped;
+    }
     return std::make_tuple(renders, alphas, last_ids);
 }
 
@@ -294,9 +328,9 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> rasterize
     at::Tensor v_colors = at::empty_like(colors), v_opacities = at::empty_like(opacities);
     const lfs_cameras cams = make_cams(viewmats0, viewmats1, Ks, image_width, image_height, camera_model, rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs);
     const lfs_ut_params ut = make_ut(ut_params);
-    at::Tensor ws = g_raster_cache.take(raster_key(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1,
+    at::Tensor ws = raster_cache().take(raster_key(means, quats, scales, colors, opacities, backgrounds, masks, image_width, image_height, tile_size, viewmats0, viewmats1,
                                                    Ks, (int)camera_model, (int)rs_type, radial_coeffs, tangential_coeffs, thin_prism_coeffs, tile_offsets, flatten_ids));
-    const bool hit = ws.defined() && !present(thin_prism_coeffs);   // (the slot is empty now: one backward per forward; the staging is released with this call)
+    const bool hit = ws.defined();   // (the slot is empty now - workspace moved out, the held operands released: one backward per forward)
     if (!hit) ws = scratch(lfs_rasterize_workspace_bytes((uint32_t)C, (uint32_t)N, (uint32_t)channels, (uint32_t)image_width, (uint32_t)image_height, (uint32_t)tile_size, flatten_ids.numel()), means);
     const int rc = (hit ? lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared : lfs_rasterize_to_pixels_from_world_3dgs_bwd)(
         (uint32_t)N, (uint32_t)channels, means.data_ptr<float>(), quats.data_ptr<float>(), scales.data_ptr<float>(), colors.data_ptr<float>(),
@@ -331,6 +365,13 @@ void adam_step_wrapper(torch::Tensor& param, torch::Tensor& exp_avg, torch::Tens
 // lfs::GutTrainStep: the C++ training step (csrc/gut_step.hip) for a libtorch caller
 // ---------------------------------------------------------------------------------------------------------
 namespace lfs {
+void torch_raster_staging_clear() { raster_cache().clear(); }
+void torch_keep_raster_staging(bool always) { g_keep_staging_always.store(always); }
+RasterStagingStats torch_raster_staging_stats() {
+    RasterCache& c = raster_cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    return RasterStagingStats{c.n_store, c.n_hit, c.n_miss, c.n_skipped, c.ws.defined() ? (uint64_t)c.ws.numel() : 0u};
+}
 GutTrainStep::GutTrainStep(uint32_t tile_size, int64_t initial_capacity) : tile_(tile_size), capacity_(initial_capacity) {}
 
 void GutTrainStep::ensure(uint32_t N, uint32_t W, uint32_t H, const torch::Tensor& like) {

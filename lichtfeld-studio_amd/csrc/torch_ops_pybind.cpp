@@ -45,6 +45,10 @@ PYBIND11_MODULE(_lfs_torch_ops, m) {
                                                                      (ShutterType)rs_type, radial, tangential, thin, tile_offsets, flatten_ids,
                                                                      render_alphas, last_ids, v_render_colors, v_render_alphas);
           });
+    m.def("raster_staging_clear", &lfs::torch_raster_staging_clear);
+    m.def("keep_raster_staging", &lfs::torch_keep_raster_staging);
+    m.def("raster_staging_stats", []() { const auto s = lfs::torch_raster_staging_stats();
+                                          py::dict d; d["stores"] = s.stores; d["hits"] = s.hits; d["misses"] = s.misses; d["skipped_forwards"] = s.skipped_forwards; d["parked_bytes"] = s.parked_bytes; return d; });
     m.def("adam_step_wrapper", [](at::Tensor param, at::Tensor exp_avg, at::Tensor exp_avg_sq, at::Tensor grad, float lr, float b1, float b2,
                                   float eps, float bc1, float bc2) { fast_gs::optimizer::adam_step_wrapper(param, exp_avg, exp_avg_sq, grad, lr, b1, b2, eps, bc1, bc2); });
     m.def("fastgs_forward_wrapper",

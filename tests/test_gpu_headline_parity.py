@@ -28,6 +28,9 @@ NAMES = ["means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opacities"]
 
 
 MAX_FLIP_ROWS = 4
+# Gaussians per scene whose integer radius differs from the oracle's by 1 (GPU logf / sqrtf vs the host's within an ulp of an integer): measured 0 / 0 / 0 / 1 in
+# round 5 on the MI355X, pinned as upper bounds (+1 of slack for another box's libm-equivalent rounding on the flat scene only)
+MAX_RADIUS_OFF = {"syn_b": 0, "syn_c": 0, "syn_d": 0, "syn_b_flat": 2}
 
 
 SCENES = {
@@ -67,6 +70,8 @@ def test_projection_and_integer_stage_bit_exact(lfs, case):
     off = (r_gpu != r_ref).any(-1)
     print(f"[{case['name']}] projection: {int(off.sum())} of {r_ref.shape[1]} Gaussians with a radius that differs (by at most {int(np.abs(r_gpu - r_ref).max())})")
     assert int(off.sum()) <= 3 and int(np.abs(r_gpu - r_ref).max()) <= 1, (int(off.sum()), int(np.abs(r_gpu - r_ref).max()))
+    #  the measured counts per scene are pinned as upper bounds: a regression that produces "only" three wrong radii per scene does not slip through
+    assert int(off.sum()) <= MAX_RADIUS_OFF[case["name"]], (case["name"], int(off.sum()), MAX_RADIUS_OFF[case["name"]])
     assert np.array_equal((r_gpu > 0).all(-1), (r_ref > 0).all(-1))     # the visibility set itself is identical
     vis = o["visible"]
     assert np.array_equal(n(m2)[0][vis], o["means2d"][0][vis]) and np.array_equal(n(d)[0][vis], o["depths"][0][vis])
@@ -78,6 +83,17 @@ def test_projection_and_integer_stage_bit_exact(lfs, case):
     assert np.array_equal(n(tpg), o["tiles_per_gauss"])
     assert ids.shape[0] == len(o["isect_ids"]) and np.array_equal(n(ids), o["isect_ids"]) and np.array_equal(n(flat), o["flatten_ids"])
     assert np.array_equal(n(offs), o["offsets"]) and np.array_equal(n(ops.intersect_offset(ids, 1, tw, th)), o["offsets"])
+    if off.any():
+        #  and the integer stage on the GPU's OWN radii: tiles_per_gauss may differ from the oracle's only for the flagged Gaussians, and only by what
+        # one more / one fewer pixel of radius explains - at most one more tile row and one more tile column: (w + 1)(h + 1) - w h = w + h + 1 tiles
+        tpg_own = n(ops.intersect_tile(m2, radii, d, None, None, 1, 16, tw, th, True)[0])[0]
+        ref_t = o["tiles_per_gauss"][0]
+        changed = tpg_own != ref_t
+        assert not (changed & ~off[0]).any(), "tiles_per_gauss differs for a Gaussian whose radii agree"
+        r_max = np.maximum(r_gpu, r_ref)[0]
+        span = (np.ceil((2.0 * r_max[:, 0] + 1) / 16) + 1) + (np.ceil((2.0 * r_max[:, 1] + 1) / 16) + 1) + 1
+        assert (np.abs(tpg_own.astype(np.int64) - ref_t)[changed] <= span[changed]).all(), (tpg_own[changed], ref_t[changed], span[changed])
+        print(f"[{case['name']}] integer stage on the GPU's own radii: {int(changed.sum())} of the {int(off.sum())} flagged Gaussians cover a different number of tiles")
 
 
 def test_forward_and_backward_against_oracle(lfs, case):

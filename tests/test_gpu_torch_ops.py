@@ -258,6 +258,7 @@ def test_raster_staging_cache_survives_freed_and_reallocated_inputs(lfs):
     m = _mod()
     from lichtfeld_studio_amd import ops
     a = _raster_inputs(lfs, m, 3)
+    a[0] = a[0].clone().requires_grad_(True)   # (the slot parks a forward only when a backward can follow: one differentiable operand requires a gradient)
     f = m.rasterize_to_pixels_from_world_3dgs_fwd(*a)
     vr, va = torch.randn_like(f[0]), torch.randn_like(f[1])
     ptrs = (a[3].data_ptr(), a[4].data_ptr())
@@ -267,7 +268,8 @@ def test_raster_staging_cache_survives_freed_and_reallocated_inputs(lfs):
     c2 = torch.rand(shape_c, device="cuda:0") * 0.5 + 0.25     # ... and same-sized ones with other contents are allocated
     o2 = torch.rand(shape_o, device="cuda:0") * 0.5 + 0.1
     a[3], a[4] = c2, o2
-    print("addresses reused by the allocator:", (c2.data_ptr(), o2.data_ptr()) == ptrs, "(held by the cache slot: they must NOT be)")
+    print("addresses reused by the allocator:", (c2.data_ptr(), o2.data_ptr()) == ptrs, "(round 6: the slot only WATCHES the storages - they may be; the dead storage makes the key stale)")
+    a = [x.detach() if isinstance(x, torch.Tensor) else x for x in a]
     f2 = ops.rasterize_to_pixels_from_world_3dgs_fwd(*a[:13], lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, a[19], a[20])   # (ctypes path: does not touch the slot)
     got = m.rasterize_to_pixels_from_world_3dgs_bwd(*a, f2[1], f2[2], vr, va)
     want = [ops.rasterize_to_pixels_from_world_3dgs_bwd(*a[:13], lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, a[19], a[20], f2[1], f2[2], vr, va)
@@ -285,6 +287,7 @@ def test_raster_staging_cache_two_threads(lfs):
     m = _mod()
     from lichtfeld_studio_amd import ops
     a, b = _raster_inputs(lfs, m, 5), _raster_inputs(lfs, m, 6, n=2500)
+    m.keep_raster_staging(True)   # plain tensors on both threads: park after every forward, so that the two threads really fight over the slot
     fa = m.rasterize_to_pixels_from_world_3dgs_fwd(*a)
     vr, va = torch.randn_like(fa[0]), torch.randn_like(fa[1])
     want = [ops.rasterize_to_pixels_from_world_3dgs_bwd(*a[:13], lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None, a[19], a[20], fa[1], fa[2], vr, va)
@@ -315,6 +318,76 @@ def test_raster_staging_cache_two_threads(lfs):
     finally:
         stop.set()
         th.join()
+        m.keep_raster_staging(False)
+    st = m.raster_staging_stats()
+    print("staging slot under two threads:", st)
+    assert st["hits"] + st["misses"] >= 60
     assert not errors, errors
     for i in range(5):
         noise_check(f"two-thread fwd/bwd [{i}]", worst[i], bars[i])
+
+
+@pytest.mark.gpu
+def test_raster_staging_slot_round6(lfs):
+    """Round-5 review item 6 / ADVICE: (1) the thin-prism coefficients are part of the slot's key - two forwards that differ only in them, then the backward of the FIRST: a
+    miss (and a forward + its own backward with thin-prism coefficients: a hit, which round 5 never allowed); (2) a forward no backward can follow (no differentiable
+    operand requires a gradient) parks nothing and releases what an earlier forward parked; (3) the slot watches storages through weak references: an operand the caller
+    freed after the forward makes the key stale (miss), and nothing of the caller's stays alive in the slot; (4) the explicit clear."""
+    m = _mod()
+    from lichtfeld_studio_amd import ops
+    m.raster_staging_clear()
+    a = _raster_inputs(lfs, m, 11)
+    a[0] = a[0].clone().requires_grad_(True)          # means requires a gradient: the training step as the wrapper sees it from inside an autograd Function's forward
+    dev = a[0].device
+    thin1 = torch.tensor([[1e-3, -2e-3, 5e-4, 1e-3]], device=dev)
+    thin2 = torch.tensor([[2e-3, 1e-3, -5e-4, 2e-3]], device=dev)
+    radial = torch.tensor([[1e-2, -1e-3, 0.0, 0.0, 0.0, 0.0]], device=dev)
+    def with_thin(t):
+        b = list(a); b[16], b[18] = radial, t; return b
+    s0 = m.raster_staging_stats()
+    # (1a) forward + its own backward, thin-prism present: a hit
+    f = m.rasterize_to_pixels_from_world_3dgs_fwd(*with_thin(thin1))
+    vr, va = torch.randn_like(f[0]), torch.randn_like(f[1])
+    assert m.raster_staging_stats()["parked_bytes"] > 0
+    g_hit = m.rasterize_to_pixels_from_world_3dgs_bwd(*with_thin(thin1), f[1], f[2], vr, va)
+    s1 = m.raster_staging_stats()
+    assert s1["hits"] == s0["hits"] + 1 and s1["parked_bytes"] == 0, (s0, s1)
+    # the prepared backward equals the self-contained one (ctypes path, which never touches the slot)
+    b1 = with_thin(thin1)
+    want = [ops.rasterize_to_pixels_from_world_3dgs_bwd(*[x.detach() if isinstance(x, torch.Tensor) else x for x in b1[:13]], lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL,
+                                                        radial, None, thin1, b1[19], b1[20], f[1], f[2], vr, va) for _ in range(3)]
+    for i, x in enumerate(g_hit):
+        noise_check(f"prepared backward with thin-prism coefficients [{i}]", rel_l2(n(x), n(want[0][i])), atomic_noise_bar(want[0][i], want[1][i], want[2][i]))
+    # (1b) two forwards that differ only in the thin-prism coefficients, then the backward of the first: a miss
+    m.rasterize_to_pixels_from_world_3dgs_fwd(*with_thin(thin1))
+    m.rasterize_to_pixels_from_world_3dgs_fwd(*with_thin(thin2))
+    g_miss = m.rasterize_to_pixels_from_world_3dgs_bwd(*with_thin(thin1), f[1], f[2], vr, va)
+    s2 = m.raster_staging_stats()
+    assert s2["misses"] == s1["misses"] + 1 and s2["hits"] == s1["hits"], (s1, s2)
+    for i, x in enumerate(g_miss):
+        noise_check(f"backward after a forward with OTHER thin-prism coefficients [{i}]", rel_l2(n(x), n(want[0][i])), atomic_noise_bar(want[0][i], want[1][i], want[2][i]))
+    # (2) a forward of plain tensors (nothing requires a gradient): nothing parked, and what the previous forward parked is gone
+    m.rasterize_to_pixels_from_world_3dgs_fwd(*a)
+    assert m.raster_staging_stats()["parked_bytes"] > 0
+    plain = list(a); plain[0] = a[0].detach()
+    with torch.no_grad():
+        m.rasterize_to_pixels_from_world_3dgs_fwd(*plain)
+    s3 = m.raster_staging_stats()
+    assert s3["parked_bytes"] == 0 and s3["skipped_forwards"] == s2["skipped_forwards"] + 1, (s2, s3)
+    # (3) weak references: the caller frees an operand after the forward - the slot must not have kept it alive, and the backward with a same-sized replacement misses
+    import gc, weakref
+    c = a[3].clone()
+    probe = weakref.ref(c)
+    b = list(a); b[3] = c
+    f3 = m.rasterize_to_pixels_from_world_3dgs_fwd(*b)
+    del c; b[3] = None; gc.collect()
+    assert probe() is None, "the staging slot kept the caller's colours alive"
+    b[3] = a[3].clone()
+    m.rasterize_to_pixels_from_world_3dgs_bwd(*b, f3[1], f3[2], torch.randn_like(f3[0]), torch.randn_like(f3[1]))
+    s4 = m.raster_staging_stats()
+    assert s4["misses"] == s3["misses"] + 1, (s3, s4)
+    # (4) explicit clear
+    m.rasterize_to_pixels_from_world_3dgs_fwd(*a)
+    assert m.raster_staging_stats()["parked_bytes"] > 0
+    m.raster_staging_clear()
+    assert m.raster_staging_stats()["parked_bytes"] == 0

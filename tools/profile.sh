@@ -17,5 +17,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_sq" -o pmc -- $BENCH --no-profile > "$OUT/bench_sq.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD --output-format csv -d "$OUT/pmc_sq2" -o pmc -- $BENCH --no-profile > "$OUT/bench_sq2.log" 2>&1
 find "$OUT" -name "*.csv" | head -50
-python $REPO/tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+python $REPO/tools/summarize_prof.py "$OUT" --json "$OUT/summary.json" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt" | head -80
