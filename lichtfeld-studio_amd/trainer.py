@@ -427,8 +427,8 @@ class GutTrainer:
 
     def _step_cxx_factored(self, plan, targets, views, total_views) -> None:
         """Replicated layout, factored SH exchange. Per view of this rank: speculative forward, loss, rasterizer backward + finish (means / scales / quaternions /
-        opacities gradients into the bucket, dL/dcolour rows - clamp-masked - into the send buffer). Then: the all-reduce of the 11 remaining floats per Gaussian
-        starts (asynchronously, on RCCL's stream), the rows of all ranks are all-gathered, and the multi-view SH backward runs over the views of ALL ranks in
+        opacities gradients into the bucket, dL/dcolour rows - clamp-masked - into the send buffer). Then: the rows of all ranks are all-gathered, the all-reduce of
+        the 11 remaining floats per Gaussian starts behind them (asynchronously, on RCCL's stream), and the multi-view SH backward runs over the views of ALL ranks in
         rank-major order: sh0's gradient -> bucket, shN's Adam update inside (or its gradient -> bucket on refining iterations, or nothing while iteration <= 1000),
         the direction term of the means gradient -> added after the all-reduce has landed. Every rank executes the same sums in the same order."""
         from . import fused
@@ -458,8 +458,11 @@ class GutTrainer:
                                   loss_acc=self.loss_acc, v_render=v_render, scale_reg=self.scale_reg / self.world if k == 0 else 0.0,
                                   opacity_reg=self.opacity_reg / self.world if k == 0 else 0.0)
         self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
-        self.bucket.all_reduce_early([0, 3, 4, 5], chunks=1)          # 11 floats per Gaussian, on RCCL's stream while the rows travel and the SH backward runs
+        # Round 6: the all-gather goes FIRST. Collectives of one communicator execute in issue order on RCCL's stream; the multi-view SH backward below waits for the
+        # gathered rows and for nothing else, the 11-float all-reduce is only needed by the optimizer afterwards - issued second it travels UNDER the SH backward
+        # (rounds 4 - 5 issued it first: the rows, and with them the SH backward, started one all-reduce later).
         rows = ex.gather()                                            # [world * views, N, 3], rank-major
+        self.bucket.all_reduce_early([0, 3, 4, 5], chunks=1)          # 11 floats per Gaussian, on RCCL's stream while the SH backward runs
         every = self._views_all or [lfs_dist.views_for_step(self.iteration - 1, j, self.world, sc.viewmats.shape[0], len(views)) for j in range(self.world)]
         if rows.shape[0] != len(every) * len(views):                  # (one GPU forced through the collectives: the gathered rows are this rank's own)
             every = [list(views)]

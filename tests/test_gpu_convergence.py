@@ -80,3 +80,48 @@ def test_psnr_after_7k_iterations_mean_gap_to_the_oracle_within_0p05_db(lfs, tas
     print(f"PSNR after 7000 iterations, task {task}, {len(gaps)} seeds: mean gap {mean:+.4f} dB (95 % interval +- {ci:.3f}), single seeds {min(gaps):+.3f} .. {max(gaps):+.3f}")
     assert min(gaps) > -1.0 and all(np.isfinite(gaps))
     assert abs(mean) <= 0.05, (mean, ci, gaps)
+
+
+@pytest.mark.parametrize("task", ["flat50", "flat30_100k"])
+def test_psnr_after_7k_iterations_in_the_benchmarked_mode_float_atomics(lfs, task):
+    """Round-5 review ("What's weak" 6): the test above holds the criterion in the DETERMINISTIC accumulation mode; the library that is benchmarked accumulates with
+    float atomics, whose summation order differs from run to run - every run is another trajectory. Here: the default mode, 3 runs per seed. flat50 (8 of the 16
+    stored oracle seeds): |mean gap over all runs| <= 0.05 dB. flat30_100k (the 4 stored seeds, 100 000 Gaussians / 960 x 540 / SH 3, where the runs of one seed
+    scatter by +- 0.02 dB only): EVERY run within 0.05 dB of its oracle run, as measured in round 5 (12 of 12, profiles/r05/psnr_100k_summary.json)."""
+    import json
+    import os
+    import convergence_check as cc
+    from lichtfeld_studio_amd import scenes
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    here = os.path.dirname(os.path.abspath(__file__))
+    golden, task_kw = TASKS[task]
+    if not os.path.exists(os.path.join(here, "golden", golden)):
+        pytest.skip(f"tests/golden/{golden}: the oracle's trajectories for this task are not stored")
+    ores = json.load(open(os.path.join(here, "golden", golden)))["seeds"]
+    seeds = sorted(int(k) for k in ores)[:int(os.environ.get("LFS_PSNR_ATOMIC_SEEDS", "8"))]
+    runs_per_seed = 3
+    dev = torch.device("cuda:0")
+    assert lfs.load_library().lfs_get_debug_flags() == 0, "this test measures the default (float-atomic) accumulation"
+    gaps = []
+    for seed in seeds:
+        gt, init = cc.make_task(seed=100 + seed, **task_kw)
+        targets = cc.render_views_hip(gt, dev)
+        V = init.viewmats.shape[0]
+        for run in range(runs_per_seed):
+            tr = GutTrainer(init, dev, iterations=7000)
+            for it in range(7000):
+                tr.train_step([targets[it % V]], views=[it % V])
+            assert tr._gut_step is not None, "the run did not go through the C++ step"
+            m = tr.model
+            fin = scenes.Scene("fin", init.width, init.height, init.sh_degree, m.means.detach(), m.raw_quats.detach(), m.raw_scales.detach(), m.raw_opacities.detach(),
+                               m.sh0.detach(), m.shN.detach(), tr.scene.viewmats, tr.scene.Ks)
+            p = float(np.mean([cc.psnr(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(cc.render_views_hip(fin, dev), targets)]))
+            gaps.append(p - ores[str(seed)]["oracle_psnr_oracle_renderer"])
+            print(f"seed {seed} run {run}: HIP (float atomics) {p:.4f} dB, oracle {ores[str(seed)]['oracle_psnr_oracle_renderer']:.4f} dB, gap {gaps[-1]:+.4f}")
+    mean = float(np.mean(gaps))
+    within = sum(abs(g) <= 0.05 for g in gaps)
+    print(f"PSNR after 7000 iterations, float atomics, task {task}: {len(gaps)} runs over {len(seeds)} seeds, mean gap {mean:+.4f} dB, {within} of {len(gaps)} runs within 0.05 dB, "
+          f"single runs {min(gaps):+.3f} .. {max(gaps):+.3f}")
+    assert all(np.isfinite(gaps)) and abs(mean) <= 0.05, (mean, gaps)
+    if task == "flat30_100k":
+        assert within == len(gaps), gaps
