@@ -432,6 +432,16 @@ LFS_API int lfs_gut_view_backward_finish(const lfs_gut_step_args* args, int64_t 
 LFS_API int lfs_gut_view_backward_rows(const lfs_gut_step_args* args, int64_t capacity, const float* v_render, float* const* grads /* [6] host */, int accumulate,
                                        float* v_colors_out, void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 LFS_API int lfs_gut_step_wait(const int64_t* host_counts, int64_t stamp, double timeout_s, int64_t* n_isects, int64_t* longest);
+/*   lfs_gut_train_step_pipelined (round 6): lfs_gut_train_step - same arguments, same results - with the step's HBM-bound SH kernels on a side stream of the library,
+ *      UNDER the latency- / VALU-bound front end of the NEXT step: projection(k+1) (records without colours) | tile lists | culling run on `stream` while SH Adam(k)
+ *      (1.1 GB of read-modify-write at 1 M Gaussians) and the SH colours(k+1) run beside them; `stream` waits for the colours in front of the forward kernel. The SH
+ *      backward is split for it: a direction pass on `stream` (dL/d(dirs) + a 32-byte hand-over row per Gaussian) and the Adam pass on the side stream.
+ *      CONTRACT: between two pipelined calls sh0, shN and their Adam moments belong to the side stream - lfs_gut_pipeline_join(stream) makes `stream` wait (device-side,
+ *      no host wait) for the last update before anything else touches them (every other lfs_gut_* entry point joins by itself). All other tensors stay ordered on `stream`.
+ *   lfs_gut_pipeline_join: 1 = there was a pending update and `stream` now waits for it, 0 = nothing pending, < 0 = error. */
+LFS_API int lfs_gut_train_step_pipelined(const lfs_gut_step_args* args, int64_t capacity, int64_t assumed_longest, void* workspace, size_t workspace_bytes,
+                                         int64_t* host_counts, int64_t stamp, lfs_stream_t stream);
+LFS_API int lfs_gut_pipeline_join(lfs_stream_t stream);
 
 /* Extension: the all-inline training step of the fused 3DGUT path (one camera, global shutter, 3 channels, ONE view per step on one rank - the
  * reference's training configuration). No parameter gradient is materialised:

@@ -17,6 +17,7 @@
 #include "lfs_step_internal.h"
 #include "lfs_prof.h"
 #include <chrono>
+#include <cstdlib>
 #include <thread>
 
 namespace lfs {
@@ -26,7 +27,8 @@ inline size_t a256(size_t v) { return (v + 255) & ~size_t(255); }
 
 struct StepWs {
     float *quats, *scales, *opacities, *means2d, *depths, *colors, *v_dirs, *render, *alpha;
-    int32_t *radii, *tiles_per_gauss, *flatten_ids, *last_ids, *abort_flag;
+    int32_t *radii, *tiles_per_gauss, *flatten_ids, *last_ids, *abort_flag, *abort_snapshot;
+    void* handover;   // pipelined step: 32 bytes per Gaussian from the SH direction kernel (main stream) to the SH Adam kernel (side stream)
     int64_t *isect_ids, *binned, *dev_counts;
     void *isect_ws, *raster_ws;
     size_t isect_ws_bytes, raster_ws_bytes, bytes;
@@ -48,7 +50,9 @@ bool step_ws(void* base, uint32_t N, uint32_t W, uint32_t H, uint32_t tile, int6
     if (w.raster_ws_bytes == 0) return false;
     const size_t o_rws = take(w.raster_ws_bytes);
     const size_t o_render = take(12 * P), o_alpha = take(4 * P), o_last = take(4 * P), o_flag = take(4), o_counts = take(32);
+    const size_t o_hand = take(32 * n), o_snap = take(4);   // (appended in round 6: every earlier offset is where it was)
     w.bytes = o;
+    w.handover = p + o_hand; w.abort_snapshot = (int32_t*)(p + o_snap);
     w.quats = (float*)(p + o_quats); w.scales = (float*)(p + o_scales); w.opacities = (float*)(p + o_opac); w.radii = (int32_t*)(p + o_radii);
     w.means2d = (float*)(p + o_m2d); w.depths = (float*)(p + o_depths); w.tiles_per_gauss = (int32_t*)(p + o_tpg); w.colors = (float*)(p + o_colors);
     w.v_dirs = (float*)(p + o_vdirs); w.isect_ws = p + o_iws; w.isect_ids = (int64_t*)(p + o_ids); w.flatten_ids = (int32_t*)(p + o_flat);
@@ -65,8 +69,54 @@ bool step_ws(void* base, uint32_t N, uint32_t W, uint32_t H, uint32_t tile, int6
 
 struct Front { lfs_cameras cams; const int32_t* offsets; };
 
+// ---- the pipelined step's side stream -------------------------------------------------------------------------------------------------------------------
+// One per process (one process per GPU). The SH colour kernel of step k + 1 and the SH Adam kernel of step k live on it; three events tie it to the caller's
+// stream (see lfs_gut_train_step_pipelined below). `done` is what lfs_gut_pipeline_join makes a stream wait for.
+struct Pipeline {
+    hipStream_t side = nullptr;
+    hipEvent_t projected = nullptr, colours = nullptr, dirs = nullptr, done = nullptr;
+    bool pending = false;   // a side-stream update has been enqueued since the last join
+    bool start_after_finish = false;
+    int init() {
+        if (side != nullptr) return LFS_OK;
+        hipError_t e = hipSuccess;
+#ifndef LFS_EMULATE
+        // measurement knobs (tools/r6_lease10.sh): LFS_PIPE_PRIO = low | high (side stream priority), LFS_PIPE_CUMASK = n (side stream confined to every n-th CU),
+        // LFS_PIPE_START = finish (the SH Adam pass starts behind the finish pass instead of beside it)
+        const char* prio = getenv("LFS_PIPE_PRIO"); const char* cum = getenv("LFS_PIPE_CUMASK"); const char* st = getenv("LFS_PIPE_START");
+        start_after_finish = st != nullptr && st[0] == 'f';
+        if (cum != nullptr && atoi(cum) > 1) {
+            const int every = atoi(cum);
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int cu = 0; cu < 256; ++cu) if (cu % every == 0) mask[cu >> 5] |= 1u << (cu & 31);
+            e = hipExtStreamCreateWithCUMask(&side, 8, mask);
+        } else if (prio != nullptr) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // (numerically: lo = least urgent, hi = most urgent)
+            e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio[0] == 'l' ? lo : hi);
+        } else
+#endif
+        e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);   // (non-blocking: no implicit ordering against the legacy default stream torch may hand in)
+        if (e != hipSuccess) { side = nullptr; return (int)e; }
+        for (hipEvent_t* ev : {&projected, &colours, &dirs, &done}) {
+            e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+            if (e != hipSuccess) return (int)e;
+        }
+        return LFS_OK;
+    }
+};
+Pipeline g_pipe;
+// the other step forms read / write sh0 and shN on the caller's stream: they wait for a pending side-stream update first
+int auto_join(hipStream_t s) {
+    if (!g_pipe.pending || g_pipe.side == nullptr) return LFS_OK;
+    if (hipStreamWaitEvent(s, g_pipe.done, 0) != hipSuccess) return LFS_E_INVALID;
+    g_pipe.pending = false;
+    return LFS_OK;
+}
+
 // everything up to and including the rasterizer forward; shared by the Adam-inline step and the gradient-tensor step
-int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacity, int64_t assumed_longest, int64_t* host_counts, int64_t stamp, hipStream_t s, Front& f) {
+int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacity, int64_t assumed_longest, int64_t* host_counts, int64_t stamp, hipStream_t s, Front& f,
+                    Pipeline* pipe = nullptr) {
     const uint32_t N = a->N, W = a->image_width, H = a->image_height, tile = a->tile_size;
     const uint32_t tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile;
     lfs_cameras& cams = f.cams;
@@ -80,10 +130,36 @@ int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacit
     // Round 4: the SH colours are evaluated FIRST (for every Gaussian - visibility is not known yet, 6 % more coefficient rows on SYN-B) so that the projection
     // kernel, which has the activated quaternion / scale / opacity in registers, can write the rasterizer's 64-byte record and the 32-byte culling record of every
     // visible Gaussian itself: raster_pack_kernel's second pass over the Gaussians (0.040 ms, 152 MB re-read) is gone. Debug bit 6: the round-3 order (A/B, tests).
-    const bool pack_here = !(lfs_get_debug_flags() & 64u);
+    const bool pack_here = pipe != nullptr || !(lfs_get_debug_flags() & 64u);
     void *recs = nullptr, *cull = nullptr;
     raster_workspace_parts(w.raster_ws, N, nullptr, &recs, &cull);
     int rc = LFS_OK;
+    if (pipe != nullptr) {
+        // Pipelined: the projection goes FIRST and packs the records without colours; the SH colours (visible Gaussians only - the radii exist now) follow on the side
+        // stream, behind the previous step's SH Adam kernel, into `colors` and into the rgb slots of the records; the main stream carries on with the tile lists and
+        // waits for them in front of the forward kernel.
+        rc = activations_project_ut_impl(N, a->means, a->raw_quats, a->raw_scales, a->raw_opacities, &cams, 0.3f, 0.01f, 10000.f, 0.f, &ut, w.quats, w.scales,
+                                         w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th, w.raster_ws, s, recs, cull, nullptr);
+        if (rc) return rc;
+        hipError_t e = hipEventRecord(pipe->projected, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pipe->side, pipe->projected, 0);
+        if (e != hipSuccess) return (int)e;
+        rc = sh_model_fwd_records_impl(N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, static_cast<float*>(recs) + 13, 16, pipe->side);
+        if (rc) return rc;
+        e = hipEventRecord(pipe->colours, pipe->side);
+        if (e != hipSuccess) return (int)e;
+        const IsectGuard guard{capacity, assumed_longest, w.abort_flag};
+        int64_t* counts = host_counts ? host_counts : w.dev_counts;
+        rc = isect_count_impl(1, N, w.means2d, w.radii, tile, tw, th, w.tiles_per_gauss, counts, counts + 1, nullptr, LFS_ISECT_COUNTERS_ZERO, counts + 2, stamp, w.isect_ws,
+                              w.isect_ws_bytes, s, &guard);
+        if (rc) return rc;
+        rc = isect_emit_impl(1, N, w.means2d, w.radii, w.depths, tile, tw, th, 1, -1, w.tiles_per_gauss, w.isect_ids, w.flatten_ids, nullptr, w.binned, -1, w.isect_ws,
+                             w.isect_ws_bytes, s, &guard);
+        if (rc) return rc;
+        f.offsets = isect_workspace_offsets(w.isect_ws, 1, N, tw, th);
+        return raster_fwd_guarded(N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, tile, f.offsets, w.flatten_ids, capacity, w.render, w.alpha,
+                                  w.last_ids, w.raster_ws, w.raster_ws_bytes, s, /*cams_ready=*/true, /*records_ready=*/true, /*wait_before_fwd=*/pipe->colours);
+    }
     if (pack_here) {
         rc = sh_model_fwd_impl(N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, nullptr, w.colors, s);
         if (rc) return rc;
@@ -153,6 +229,8 @@ extern "C" int lfs_gut_train_step(const lfs_gut_step_args* a, int64_t capacity, 
     if (!step_ws(workspace, a->N, a->image_width, a->image_height, a->tile_size, capacity, w, nullptr)) return LFS_E_INVALID;
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    rc = auto_join(s);
+    if (rc) return rc;
     Front f;
     rc = enqueue_forward(a, w, capacity, assumed_longest, host_counts, stamp, s, f);
     if (rc) return rc;
@@ -171,6 +249,76 @@ extern "C" int lfs_gut_train_step(const lfs_gut_step_args* a, int64_t capacity, 
     for (int k = 0; k < 4; ++k) for (int j = 0; j < 6; ++j) sc[6 * k + j] = a->adam[grp[k]][j];
     return gut_finish_adam_impl(a->N, a->means, a->raw_scales, a->raw_quats, a->raw_opacities, w.quats, w.scales, w.opacities, w.v_dirs, m, v, sc, a->scale_reg,
                                 a->opacity_reg, a->loss, w.raster_ws, w.raster_ws_bytes, s, w.abort_flag);
+}
+
+// lfs_gut_train_step with the step's HBM-bound SH kernels moved UNDER its latency- and VALU-bound front end (round 6). Same arguments, same results (bit for bit in
+// the deterministic accumulation mode); what changes is the ORDER across two streams:
+//
+//   stream (caller's)                                                         side stream (the library's)
+//   projection(k) -> records without colours ----- event `projected` ------>  SH colours(k): visible Gaussians, -> colors [N,3] + the rgb slots of the records
+//   tile count + scan, row / tile binning, sort, culling                      (behind SH Adam(k - 1): the coefficients it reads are the updated ones)
+//   <------------------------------------------------ event `colours` ------
+//   forward, backward (MSE folded in)
+//   SH direction pass(k): dL/d(dirs) + 32-byte hand-over rows --- `dirs` -->  SH Adam(k): sh0 / shN read-modify-write, 1.1 GB at 1 M Gaussians
+//   finish + Adam(means, scales, quaternions, opacities)                      |  runs under finish(k), projection(k + 1), binning(k + 1), sort, culling:
+//   [next call] projection(k + 1) ...                                         v  kernels that leave the HBM idle
+//
+// In lfs_gut_train_step everything is one chain, and 0.33 ms of it (SH backward + Adam, SH colours) is pure HBM time during which no other kernel can run, while the
+// front end (0.25 ms) is latency / LDS / VALU bound and moves < 1 TB/s. Contract: between two pipelined calls sh0, shN and their moments belong to the side stream -
+// call lfs_gut_pipeline_join(stream) before anything else reads or writes them on `stream` (another step form, a strategy, evaluation, a checkpoint). Every other
+// tensor is ordered on `stream` as before. The price: the direction pass re-reads the coefficient rows of the Gaussians that received a gradient (<= 180 MB).
+extern "C" int lfs_gut_train_step_pipelined(const lfs_gut_step_args* a, int64_t capacity, int64_t assumed_longest, void* workspace, size_t workspace_bytes,
+                                            int64_t* host_counts, int64_t stamp, lfs_stream_t stream) {
+    int rc = check_args(a, true);
+    if (rc) return rc;
+    if (!workspace) return LFS_E_INVALID;
+    StepWs w;
+    if (!step_ws(workspace, a->N, a->image_width, a->image_height, a->tile_size, capacity, w, nullptr)) return LFS_E_INVALID;
+    if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
+    rc = g_pipe.init();
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    Front f;
+    rc = enqueue_forward(a, w, capacity, assumed_longest, host_counts, stamp, s, f, &g_pipe);
+    if (rc) return rc;
+    rc = raster_bwd_mse_acc_guarded(a->N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &f.cams, a->tile_size, f.offsets, w.flatten_ids, capacity,
+                                    w.render, w.alpha, w.last_ids, a->target_chw, a->loss_weight, w.raster_ws, w.raster_ws_bytes, s);
+    if (rc) return rc;
+    const float* acc_rows = reinterpret_cast<const float*>(static_cast<const char*>(w.raster_ws) + lfs_rasterize_workspace_acc_offset(1, a->N));
+    rc = sh_pipe_dirs_impl(a->N, a->K, a->sh_degree, a->means, a->viewmat, a->shN, w.radii, w.colors, acc_rows, w.v_dirs, w.handover, w.abort_flag, w.abort_snapshot, s);
+    if (rc) return rc;
+    float* const m[4] = {a->exp_avg[0], a->exp_avg[3], a->exp_avg[4], a->exp_avg[5]};
+    float* const v[4] = {a->exp_avg_sq[0], a->exp_avg_sq[3], a->exp_avg_sq[4], a->exp_avg_sq[5]};
+    float sc[24];
+    const int grp[4] = {0, 3, 4, 5};
+    for (int k = 0; k < 4; ++k) for (int j = 0; j < 6; ++j) sc[6 * k + j] = a->adam[grp[k]][j];
+    if (g_pipe.start_after_finish) {
+        rc = gut_finish_adam_impl(a->N, a->means, a->raw_scales, a->raw_quats, a->raw_opacities, w.quats, w.scales, w.opacities, w.v_dirs, m, v, sc, a->scale_reg,
+                                  a->opacity_reg, a->loss, w.raster_ws, w.raster_ws_bytes, s, w.abort_flag);
+        if (rc) return rc;
+    }
+    hipError_t e = hipEventRecord(g_pipe.dirs, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(g_pipe.side, g_pipe.dirs, 0);
+    if (e != hipSuccess) return (int)e;
+    rc = sh_pipe_adam_impl(a->N, a->K, a->sh_degree, a->sh0, a->shN, w.handover, a->exp_avg[1], a->exp_avg_sq[1], a->adam[1], a->exp_avg[2], a->exp_avg_sq[2], a->adam[2],
+                           w.abort_snapshot, g_pipe.side);
+    if (rc) return rc;
+    e = hipEventRecord(g_pipe.done, g_pipe.side);
+    if (e != hipSuccess) return (int)e;
+    g_pipe.pending = true;
+    if (g_pipe.start_after_finish) return LFS_OK;
+    return gut_finish_adam_impl(a->N, a->means, a->raw_scales, a->raw_quats, a->raw_opacities, w.quats, w.scales, w.opacities, w.v_dirs, m, v, sc, a->scale_reg,
+                                a->opacity_reg, a->loss, w.raster_ws, w.raster_ws_bytes, s, w.abort_flag);
+}
+
+// `stream` waits for the side stream's last SH update (no host wait). Cheap and idempotent: call it whenever sh0 / shN / their moments are about to be used outside
+// lfs_gut_train_step_pipelined. Returns 1 when there was something to wait for, 0 when not, < 0 on error.
+extern "C" int lfs_gut_pipeline_join(lfs_stream_t stream) {
+    if (!g_pipe.pending || g_pipe.side == nullptr) return 0;
+    const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, g_pipe.done, 0);
+    if (e != hipSuccess) return LFS_E_INVALID;
+    g_pipe.pending = false;
+    return 1;
 }
 
 // Backward of the view lfs_gut_view_forward left in the workspace, into GRADIENT TENSORS (data-parallel ranks, several views per step, iterations <= 1000):
@@ -205,6 +353,8 @@ extern "C" int lfs_gut_view_backward_sh(const lfs_gut_step_args* a, int64_t capa
     if (inline_shN && (accumulate || !a->exp_avg_sq[2])) return LFS_E_INVALID;
     if (!grads || !grads[1] || (a->K > 1 && !grads[2] && !inline_shN) || (!a->target_chw && !v_render)) return LFS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    rc = auto_join(s);
+    if (rc) return rc;
     if (a->target_chw)
         rc = raster_bwd_mse_acc_guarded(a->N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, a->tile_size, offsets, w.flatten_ids, capacity,
                                         w.render, w.alpha, w.last_ids, a->target_chw, a->loss_weight, w.raster_ws, w.raster_ws_bytes, s);
@@ -263,6 +413,8 @@ extern "C" int lfs_gut_view_forward(const lfs_gut_step_args* a, int64_t capacity
     StepWs w;
     if (!step_ws(workspace, a->N, a->image_width, a->image_height, a->tile_size, capacity, w, nullptr)) return LFS_E_INVALID;
     if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
+    rc = auto_join((hipStream_t)stream);
+    if (rc) return rc;
     Front f;
     return enqueue_forward(a, w, capacity, assumed_longest, host_counts, stamp, (hipStream_t)stream, f);
 }

@@ -33,7 +33,8 @@ const int32_t* isect_workspace_offsets(void* workspace, uint32_t C, uint32_t N, 
 int raster_fwd_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
                        const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
                        int64_t capacity, float* render_colors, float* render_alphas, int32_t* last_ids, void* workspace, size_t workspace_bytes, hipStream_t s,
-                       bool cams_ready = false, bool records_ready = false); // records_ready: the projection kernel wrote the records + culling records (no raster_pack launch)
+                       bool cams_ready = false, bool records_ready = false, // records_ready: the projection kernel wrote the records + culling records (no raster_pack launch)
+                       hipEvent_t wait_before_fwd = nullptr);               // the stream waits for this event between the culling kernel and the forward kernel (pipelined step)
 void raster_workspace_parts(void* workspace, uint32_t N, void** cams_dev, void** recs, void** cull);
 int sh_model_fwd_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
                       const int32_t* radii /* NULL: every Gaussian */, float* colors, hipStream_t s);
@@ -69,5 +70,14 @@ int sh_model_bwd_rows_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, cons
 int gut_finish_grads_impl(uint32_t N, const float* means, const float* raw_quats, const float* quats, const float* scales, const float* opacities, float scale_reg,
                           float opacity_reg, int accumulate, float* g_means, float* g_raw_scales, float* g_raw_quats, float* g_raw_opacities, float* v_colors,
                           const float* v_dirs, float* loss, void* workspace, size_t workspace_bytes, hipStream_t s);
+
+// pipelined training step (gut_step.hip): the SH backward in two kernels on two streams (sh.hip), and the SH colours written into the rasterizer's records
+int sh_pipe_dirs_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* shN, const int32_t* radii,
+                      const float* colors, const float* acc_rows, float* v_dirs, void* handover /* 32 B per Gaussian */, const int32_t* abort_flag, int32_t* abort_snapshot,
+                      hipStream_t s);
+int sh_pipe_adam_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, float* sh0, float* shN, const void* handover, float* sh0_exp_avg, float* sh0_exp_avg_sq,
+                      const float* sh0_scalars, float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, const int32_t* abort_snapshot, hipStream_t s);
+int sh_model_fwd_records_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+                              const int32_t* radii, float* colors, float* rec_rgb, uint32_t rec_stride, hipStream_t s);
 
 } // namespace lfs

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) projection_ut_kernel(
     if (compensations != nullptr) compensations[idx] = o_comp;
     if (PACK && out_rx > 0 && out_ry > 0) {
         GaussRec rec; CullRec cr;
-        const f3 col = ld3(pack_colors, gid);
+        const f3 col = pack_colors != nullptr ? ld3(pack_colors, gid) : f3{0.f, 0.f, 0.f}; // (uniform) NULL, the pipelined step: the SH colour kernel writes the rgb slots of the finished record afterwards
         pack_gaussian<true>(cam, p_mean, p_q, p_sc, p_op, col.x, col.y, col.z, rec, cr);
         recs[idx] = rec;
         cull[idx] = cr;
@@ -212,7 +212,7 @@ int lfs::activations_project_ut_impl(
     dim3 grid((N + 255) / 256, cams->C);
     lfs::ProfScope prof("activations_projection_ut", (hipStream_t)stream);
     if (recs_out != nullptr) { // the training step: records + culling records from the same pass (one camera, undistorted pinhole, global shutter)
-        if (!simple_camera(cams) || cams->C != 1 || !cull_out || !pack_colors) return LFS_E_INVALID;
+        if (!simple_camera(cams) || cams->C != 1 || !cull_out) return LFS_E_INVALID;
         hipLaunchKernelGGL((lfs::projection_ut_kernel<true, true, true>), grid, dim3(256), 0, (hipStream_t)stream,
                            N, means, raw_quats, raw_scales, raw_opacities, *cams, eps2d, near_plane, far_plane, radius_clip, ut,
                            radii, means2d, depths, nullptr, nullptr, quats, scales, opacities, zero_words, zero_n, static_cast<lfs::CamDev*>(cams_out),

@@ -1126,7 +1126,7 @@ static int raster_fwd_impl(
     const lfs_cameras* cams, uint32_t tile_size,
     const int32_t* tile_offsets, const int32_t* flatten_ids, const IsectCount ic,
     float* render_colors, float* render_alphas, int32_t* last_ids,
-    void* workspace, size_t workspace_bytes, hipStream_t s, bool cams_ready = false, bool records_ready = false) {
+    void* workspace, size_t workspace_bytes, hipStream_t s, bool cams_ready = false, bool records_ready = false, hipEvent_t wait_before_fwd = nullptr) {
     RasterGeom g;
     int rc = raster_check(N, channels, cams, tile_size, g);
     if (rc) return rc;
@@ -1140,6 +1140,8 @@ static int raster_fwd_impl(
     if (N > 0 && (!means || !quats || !scales || !colors || !opacities)) return LFS_E_INVALID;
     if (n_sized > 0 && !flatten_ids) return LFS_E_INVALID;
     raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s, cams_ready, records_ready);
+    // pipelined step: the culling above needs geometry only; the colours of the records arrive from the side stream (gut_step.hip)
+    if (wait_before_fwd != nullptr) { const hipError_t e = hipStreamWaitEvent(s, wait_before_fwd, 0); if (e != hipSuccess) return (int)e; }
     lfs::ProfScope prof("raster_fwd", s);
     const RasterGeom gw = wave_geom(cams, g);
 #define LFS_FWD(CD, MODE)                                                                                        \
@@ -1173,10 +1175,10 @@ extern "C" int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
 int lfs::raster_fwd_guarded(uint32_t N, const float* means, const float* quats, const float* scales, const float* colors, const float* opacities,
                             const float* backgrounds, const lfs_cameras* cams, uint32_t tile_size, const int32_t* tile_offsets, const int32_t* flatten_ids,
                             int64_t capacity, float* render_colors, float* render_alphas, int32_t* last_ids, void* workspace, size_t workspace_bytes, hipStream_t s,
-                            bool cams_ready, bool records_ready) {
+                            bool cams_ready, bool records_ready, hipEvent_t wait_before_fwd) {
     if (capacity < 0) return LFS_E_INVALID;
     return raster_fwd_impl(N, 3, means, quats, scales, colors, opacities, backgrounds, nullptr, cams, tile_size, tile_offsets, flatten_ids, IsectCount{-1, capacity},
-                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, s, cams_ready, records_ready);
+                           render_colors, render_alphas, last_ids, workspace, workspace_bytes, s, cams_ready, records_ready, wait_before_fwd);
 }
 
 // where the camera state / records / culling records of a (one-camera) rasterizer workspace live: the training step's projection kernel writes them there

@@ -10,6 +10,8 @@
 // measured 2.5x slower: partial-line stores), and the basis polynomial is evaluated once
 // per Gaussian in a lane-per-Gaussian phase and handed over through LDS (see the kernels).
 #include "lfs_math.cuh"
+#include <algorithm>
+#include <cstdlib>
 #include "lfs_prof.h"
 #include "lfs_adam.cuh"
 #include "lfs_step_internal.h"
@@ -137,6 +139,7 @@ struct ShArgs {
     uint32_t ds;              // model bwd: element stride of the v_dirs rows (0 = 3)
     bool dirs_store;          // model bwd: v_dirs rows are WRITTEN (0 for invisible Gaussians) instead of added to
     const int32_t* abort_flag; // (nullable) speculative training step: != 0 on the device -> the kernel must not touch the parameters (lfs_step_internal.h)
+    float* rec_rgb; uint32_t rec_stride; // model fwd (pipelined training step): the colour is ALSO written to rec_rgb + rec_stride * g (the rgb slots of the rasterizer's 64-byte records)
 };
 template <bool MODEL> LFS_DI bool sh_on(const ShArgs& a, uint32_t g) {
     if (MODEL) return a.mask_u32 ? a.mask_u32[g] != 0u : a.radii == nullptr ? true : (a.radii[2 * g] > 0 && a.radii[2 * g + 1] > 0); // (no visibility given: every Gaussian)
@@ -170,11 +173,10 @@ template <bool MODEL, class T> LFS_DI T* sh_coef(T* coeffs, T* sh0, T* shN, uint
 #define LFS_SH_FWD_SPLIT 1
 #endif
 template <int LPG, bool MODEL>
-__global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors) {
+LFS_DI void sh_fwd_block(const ShArgs& a, float* __restrict__ colors, const uint32_t g0 /* first of the workgroup's 64 Gaussians */) {
     __shared__ float lds[64 * (LPG + 1)];
     __shared__ float lds_dc[MODEL ? 64 * 3 : 1];
     const uint32_t lane = threadIdx.x;
-    const uint32_t g0 = blockIdx.x * 64u;
     const int degree = a.degree;
     const int Kd = (degree + 1) * (degree + 1);
     // Memory round trips of a wavefront, in series: (1) the visibility word and the direction of its 64 Gaussians, issued together; (2) the coefficient rows of
@@ -245,7 +247,24 @@ __global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __res
             if (MODEL) { r0 = fmaxf(r0 + 0.5f, 0.f); r1 = fmaxf(r1 + 0.5f, 0.f); r2 = fmaxf(r2 + 0.5f, 0.f); }
             const size_t cs = (MODEL && a.cs) ? a.cs : 3;
             colors[cs * g] = r0; colors[cs * g + 1] = r1; colors[cs * g + 2] = r2;
+            if (MODEL && a.rec_rgb != nullptr && ((vis >> gl) & 1ull)) { // (uniform pointer test) pipelined step: the projection kernel has written the record of every visible Gaussian already
+                float* rr = a.rec_rgb + size_t(a.rec_stride) * g;
+                rr[0] = r0; rr[1] = r1; rr[2] = r2;
+            }
         }
+    }
+}
+template <int LPG, bool MODEL>
+__global__ void __launch_bounds__(64) sh_fwd_kernel(const ShArgs a, float* __restrict__ colors) { sh_fwd_block<LPG, MODEL>(a, colors, blockIdx.x * 64u); }
+// The same blocks walked by a FIXED number of wavefronts (the pipelined step's side stream, gut_step.hip): a grid of one-wavefront workgroups as large as the problem
+// fills every wave slot of the chip for its whole run time, and a kernel of the main stream whose workgroups need four free slots on one CU at once then starts when this
+// one ENDS (rocprofv3 trace, profiles/r06/pipeline_slot_starvation.txt: the 56-us projection kernel took 308 us beside a 300-us single-wave grid). A few wavefronts per
+// CU, each with a whole block's coefficient rows in flight, leave the other slots free and still move several TB/s.
+template <int LPG>
+__global__ void __launch_bounds__(64) sh_fwd_persistent_kernel(const ShArgs a, float* __restrict__ colors) {
+    for (uint32_t g0 = blockIdx.x * 64u; g0 < a.n; g0 += gridDim.x * 64u) {
+        sh_fwd_block<LPG, true>(a, colors, g0);
+        __syncthreads();   // (the next block's basis overwrites the LDS rows)
     }
 }
 
@@ -374,12 +393,206 @@ __global__ void __launch_bounds__(64) sh_bwd_kernel(const ShArgs a, const float*
     }
 }
 
+// ---- the SH backward of the PIPELINED training step (csrc/gut_step.hip), in two kernels on two streams ----
+// sh_bwd_kernel<.., ADAM> does three things per Gaussian: dL/d(dirs) (needs every coefficient row as it was BEFORE the update), and the Adam updates of sh0 and shN - 1.1 GB
+// of read-modify-write at 1 M Gaussians, a quarter of a millisecond on the HBM, while the next thing the step needs is dL/d(dirs) alone (the means update, then the next
+// projection). The pipelined step splits it:
+//   sh_pipe_dirs_kernel (main stream) : phases 1 - 3 of sh_bwd_kernel without any coefficient write: reads the rows (only those of Gaussians with a non-zero dL/dcolour),
+//                                       writes dL/d(dirs) [n,3] and, per Gaussian, the 32-byte hand-over row {unit direction (3), visible, masked dL/dcolour (3), 0} -
+//                                       everything the update kernel needs from buffers the main stream is about to overwrite (means, radii, colours, accumulator rows)
+//   sh_pipe_adam_kernel (side stream) : phase 1 from the hand-over row, phase 2 = the ADAM branch of sh_bwd_kernel. Runs UNDER the finish pass, the next step's projection,
+//                                       tile binning, sort and culling - kernels that leave the HBM idle.
+// Same arithmetic in the same order as sh_bwd_kernel<LPG, true, false, true> (the direction is handed over AFTER its normalisation, the colour gradient after the clamp
+// mask): bit-identical parameters, moments and dL/d(dirs).
+template <int LPG>
+__global__ void __launch_bounds__(64) sh_pipe_dirs_kernel(const ShArgs a, const float* __restrict__ v_colors /* accumulator rows + 13, stride 16 */,
+                                                          float* __restrict__ v_dirs, float4* __restrict__ handover /* [n][2] */,
+                                                          const int32_t* __restrict__ abort_flag, int32_t* __restrict__ abort_snapshot) {
+    __shared__ float lds[64 * (LPG + 1)];
+    __shared__ float ldv[64 * 3];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g0 = blockIdx.x * 64u;
+    if (blockIdx.x == 0 && lane == 0) *abort_snapshot = *abort_flag; // the side stream must not look at the live flag: the next step's scan rewrites it
+    const int degree = a.degree;
+    const int Kd = (degree + 1) * (degree + 1);
+    const uint32_t gmine = g0 + lane;
+    bool on = false;
+    f3 d{0.f, 0.f, 0.f};
+    float inorm = 1.f;
+    {
+        float b[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) b[k] = 0.f;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (gmine < a.n) {
+            const f3 dr = sh_dir<true>(a, gmine);
+            const float4 r = *reinterpret_cast<const float4*>(v_colors + 16 * size_t(gmine) - 1); // slots 12..15 of the row: one aligned 16-byte load
+            const float k0 = a.colors[3 * size_t(gmine)], k1 = a.colors[3 * size_t(gmine) + 1], k2 = a.colors[3 * size_t(gmine) + 2];
+            const int2 rr = *reinterpret_cast<const int2*>(a.radii + 2 * size_t(gmine));
+            on = rr.x > 0 && rr.y > 0;
+            if (on) {
+                d = dr;
+                if (degree >= 1) { inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = d * inorm; }
+                sh_basis<false, (LPG > 16 ? 4 : 3)>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
+                v0 = (k0 > 0.f) ? r.y : 0.f; v1 = (k1 > 0.f) ? r.z : 0.f; v2 = (k2 > 0.f) ? r.w : 0.f;
+            }
+            handover[2 * size_t(gmine)] = make_float4(d.x, d.y, d.z, on ? 1.f : 0.f);
+            handover[2 * size_t(gmine) + 1] = make_float4(v0, v1, v2, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < LPG; ++k) lds[lane * (LPG + 1) + k] = (k < 25) ? b[k] : 0.f;
+        ldv[lane * 3] = v0; ldv[lane * 3 + 1] = v1; ldv[lane * 3 + 2] = v2;
+    }
+    __syncthreads();
+    constexpr int GPI = 64 / LPG;
+    const int k = lane % LPG;
+#pragma unroll 4
+    for (int it = 0; it < LPG; ++it) {
+        const uint32_t gl = it * GPI + lane / LPG;
+        const uint32_t g = g0 + gl;
+        const float v0 = ldv[gl * 3], v1 = ldv[gl * 3 + 1], v2 = ldv[gl * 3 + 2];
+        float sk = 0.f;
+        // s_k = coeff_k . dL/dcolour; a zero gradient gives 0 x (finite) = 0 whatever the row holds: its 12 bytes are not fetched
+        if (g < a.n && k >= 1 && k < Kd && uint32_t(k) < a.K && (v0 != 0.f || v1 != 0.f || v2 != 0.f)) {
+            const V3f p = *reinterpret_cast<const V3f*>(a.shN + (size_t(g) * (a.K - 1) + (k - 1)) * 3);
+            sk = p.a[0] * v0 + p.a[1] * v1 + p.a[2] * v2;
+        }
+        lds[gl * (LPG + 1) + k] = sk;
+    }
+    __syncthreads();
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+    if (on && degree >= 1) {
+        float b[25], bx[25], by[25], bz[25];
+        sh_basis<true, (LPG > 16 ? 4 : 3)>(degree, d.x, d.y, d.z, b, bx, by, bz);
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int kk = 1; kk < LPG && kk < 25; ++kk) {
+            const float sk = lds[lane * (LPG + 1) + kk];
+            gx += bx[kk] * sk; gy += by[kk] * sk; gz += bz[kk] * sk;
+        }
+        const float dd = gx * d.x + gy * d.y + gz * d.z;
+        ox = (gx - dd * d.x) * inorm; oy = (gy - dd * d.y) * inorm; oz = (gz - dd * d.z) * inorm;
+    }
+    if (gmine < a.n) st3(v_dirs, gmine, f3{ox, oy, oz});
+}
+
+// A FIXED grid of one-wavefront workgroups walks the blocks of 64 Gaussians (see sh_fwd_persistent_kernel: a problem-sized single-wave grid would take every wave slot of
+// the chip and starve the main stream's kernels). With only a few wavefronts per CU the bandwidth has to come from each wavefront: the rows of a block are updated in
+// batches of SH_PIPE_U, and the loads of the NEXT batch (parameter, two moments: 3 x 12 bytes per lane and row) are in flight while one batch goes through Adam and is stored.
+// SH_PIPE_DEPTH rows (parameter + two moments: 3 x 12 bytes per lane and row) are in flight per lane: row `it + SH_PIPE_DEPTH` is requested into the registers row `it`
+// has just left. The sh0 rows are updated in the lane = Gaussian phase (one coalesced 768-byte block per tensor and wavefront; basis 0 is the constant), so that the
+// lane = (Gaussian, basis) phase walks ONE tensor triple: wave-uniform row bases in SGPRs + one 32-bit per-lane offset. 57 VGPRs: two of these wavefronts per SIMD leave
+// the main stream's kernels three quarters of the register file (the first form, double-buffered batches behind 64-bit per-lane addresses, took 131 each, and the
+// projection kernel - 94 VGPRs - ran at 2 instead of 5 wavefronts per SIMD beside it: 150 instead of 56 us, profiles/r06/pipeline_timelines.txt).
+#ifndef LFS_SH_PIPE_DEPTH
+#define LFS_SH_PIPE_DEPTH 4
+#endif
+constexpr int SH_PIPE_DEPTH = LFS_SH_PIPE_DEPTH;
+#if defined(LFS_PIPE_ADAM_WAVES) && !defined(LFS_EMULATE)
+#define LFS_PIPE_ADAM_ATTR __attribute__((amdgpu_waves_per_eu(LFS_PIPE_ADAM_WAVES)))   // (A/B hook: a register budget for the kernel - 8 = 64 VGPRs, with spills)
+#else
+#define LFS_PIPE_ADAM_ATTR
+#endif
+template <int LPG>
+__global__ void __launch_bounds__(64) LFS_PIPE_ADAM_ATTR sh_pipe_adam_kernel(const uint32_t n, const uint32_t K, const int degree, float* __restrict__ sh0, float* __restrict__ shN,
+                                                          const float4* __restrict__ handover, const ShAdam adam, const int32_t* __restrict__ abort_snapshot) {
+    __shared__ float lds[64 * (LPG + 1)];
+    __shared__ float ldv[64 * 3];
+    if (*abort_snapshot != 0) return; // (uniform) the attempt did not fit its buffers: no update, the host runs the step again
+    const uint32_t lane = threadIdx.x;
+    constexpr int GPI = 64 / LPG;
+    constexpr int D = (LPG < SH_PIPE_DEPTH) ? LPG : SH_PIPE_DEPTH;
+    const int k = lane % LPG;
+    const uint32_t KK = K - 1;
+    const bool row_k = k >= 1 && uint32_t(k) < K;
+    const uint32_t lane_el = ((lane / LPG) * KK + uint32_t(k - 1)) * 3u;   // (k == 0 lanes: never used)
+    float* const mN = adam.m; float* const vN = adam.v;
+    for (uint32_t g0 = blockIdx.x * 64u; g0 < n; g0 += gridDim.x * 64u) {
+        const uint32_t gmine = g0 + lane;
+        auto row_ok = [&](const int it) { return row_k && (g0 + uint32_t(it) * GPI + lane / LPG) < n; };
+        V3f P[D], M[D], Q[D];
+        auto load = [&](const int it, const int slot) {
+            if (row_ok(it)) {
+                const size_t base = size_t(g0 + uint32_t(it) * GPI) * KK * 3u;   // (uniform)
+                P[slot] = *reinterpret_cast<const V3f*>(shN + base + lane_el); M[slot] = *reinterpret_cast<const V3f*>(mN + base + lane_el);
+                Q[slot] = *reinterpret_cast<const V3f*>(vN + base + lane_el);
+            }
+        };
+        {
+            float b[25];
+#pragma unroll
+            for (int kk = 0; kk < 25; ++kk) b[kk] = 0.f;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            bool on = false;
+            if (gmine < n) {
+                const float4 h0 = handover[2 * size_t(gmine)], h1 = handover[2 * size_t(gmine) + 1];
+                on = h0.w != 0.f;
+                if (on) sh_basis<false, (LPG > 16 ? 4 : 3)>(degree, h0.x, h0.y, h0.z, b, nullptr, nullptr, nullptr);
+                v0 = h1.x; v1 = h1.y; v2 = h1.z;
+            }
+#pragma unroll
+            for (int kk = 0; kk < LPG; ++kk) lds[lane * (LPG + 1) + kk] = (kk < 25) ? b[kk] : 0.f;
+            ldv[lane * 3] = v0; ldv[lane * 3 + 1] = v1; ldv[lane * 3 + 2] = v2;
+            if (gmine < n) {   // the sh0 row (sh_bwd_kernel's k == 0 lane): gradient = basis 0 (the constant) x dL/dcolour - after the polynomial's registers are free
+                const float b0 = on ? 0.2820947917738781f : 0.f;
+                V3f p = *reinterpret_cast<const V3f*>(sh0 + 3 * size_t(gmine)), m = *reinterpret_cast<const V3f*>(adam.m0 + 3 * size_t(gmine)),
+                    q = *reinterpret_cast<const V3f*>(adam.v0 + 3 * size_t(gmine));
+                adam_elem(p.a[0], m.a[0], q.a[0], b0 * v0, adam.s0); adam_elem(p.a[1], m.a[1], q.a[1], b0 * v1, adam.s0); adam_elem(p.a[2], m.a[2], q.a[2], b0 * v2, adam.s0);
+                *reinterpret_cast<V3f*>(sh0 + 3 * size_t(gmine)) = p; *reinterpret_cast<V3f*>(adam.m0 + 3 * size_t(gmine)) = m; *reinterpret_cast<V3f*>(adam.v0 + 3 * size_t(gmine)) = q;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < D; ++it) load(it, it);   // (requested once the polynomial's temporaries are dead: see the register note above)
+        __syncthreads();
+#pragma unroll 1
+        for (int it0 = 0; it0 < LPG; it0 += D) {   // (a real loop: fully unrolled the compiler hoists the loads of every later row and the allocation doubles)
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int it = it0 + u;
+                if (row_ok(it)) {
+                    const uint32_t gl = it * GPI + lane / LPG;
+                    const float bk = lds[gl * (LPG + 1) + k];
+                    const float o0 = bk * ldv[gl * 3], o1 = bk * ldv[gl * 3 + 1], o2 = bk * ldv[gl * 3 + 2];
+                    V3f p = P[u], m = M[u], q = Q[u];
+                    adam_elem(p.a[0], m.a[0], q.a[0], o0, adam.s); adam_elem(p.a[1], m.a[1], q.a[1], o1, adam.s); adam_elem(p.a[2], m.a[2], q.a[2], o2, adam.s);
+                    const size_t base = size_t(g0 + uint32_t(it) * GPI) * KK * 3u;
+                    *reinterpret_cast<V3f*>(shN + base + lane_el) = p; *reinterpret_cast<V3f*>(mN + base + lane_el) = m; *reinterpret_cast<V3f*>(vN + base + lane_el) = q;
+                }
+                if (it + D < LPG) load(it + D, u);
+            }
+        }
+        __syncthreads();   // (the next block's lane = Gaussian phase overwrites the LDS rows)
+    }
+}
+
+// wavefronts the side-stream kernels of the pipelined step run with: LFS_PIPE_WAVES per CU (default 8 = two of a SIMD's eight slots) x 256 CUs
+static inline uint32_t sh_pipe_side_grid() {
+    static uint32_t g = 0;
+    if (g == 0) {
+        uint32_t per_cu = 8;
+#ifndef LFS_EMULATE
+        if (const char* e = getenv("LFS_PIPE_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 32) per_cu = uint32_t(v); }
+#endif
+        g = 256u * per_cu;
+    }
+    return g;
+}
 static inline int lanes_for(uint32_t k) { return k <= 1 ? 1 : k <= 4 ? 4 : k <= 16 ? 16 : 32; }
 
 template <bool MODEL>
-static int sh_launch_fwd(const ShArgs& a, uint32_t Kcover, float* colors, hipStream_t s) {
+static int sh_launch_fwd(const ShArgs& a, uint32_t Kcover, float* colors, hipStream_t s, uint32_t fixed_grid = 0) {
     const dim3 grid((a.n + 63) / 64), block(64);
     lfs::ProfScope prof("sh_fwd", s);
+    if (MODEL && fixed_grid != 0 && fixed_grid < grid.x) { // the side stream of the pipelined step: a fixed number of wavefronts walk the blocks
+        const dim3 pg(fixed_grid);
+        switch (lanes_for(Kcover)) {
+        case 1: hipLaunchKernelGGL((sh_fwd_persistent_kernel<1>), pg, block, 0, s, a, colors); break;
+        case 4: hipLaunchKernelGGL((sh_fwd_persistent_kernel<4>), pg, block, 0, s, a, colors); break;
+        case 16: hipLaunchKernelGGL((sh_fwd_persistent_kernel<16>), pg, block, 0, s, a, colors); break;
+        default: hipLaunchKernelGGL((sh_fwd_persistent_kernel<32>), pg, block, 0, s, a, colors); break;
+        }
+        return (int)hipGetLastError();
+    }
     switch (lanes_for(Kcover)) {
     case 1: hipLaunchKernelGGL((sh_fwd_kernel<1, MODEL>), grid, block, 0, s, a, colors); break;
     case 4: hipLaunchKernelGGL((sh_fwd_kernel<4, MODEL>), grid, block, 0, s, a, colors); break;
@@ -749,6 +962,60 @@ extern "C" int lfs_sh_model_bwd_adam_all(
     float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, lfs_stream_t stream) {
     return lfs::sh_model_bwd_adam_all_impl(n, K, degrees_to_use, means, viewmat, sh0, shN, radii, colors, acc_rows, v_dirs, sh0_exp_avg, sh0_exp_avg_sq, sh0_scalars,
                                            shN_exp_avg, shN_exp_avg_sq, shN_scalars, (hipStream_t)stream, nullptr);
+}
+
+// The two halves of lfs_sh_model_bwd_adam_all for the pipelined training step (kernels above). pipe_dirs: main stream, before the finish pass; pipe_adam: side stream.
+int lfs::sh_pipe_dirs_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* shN, const int32_t* radii,
+                           const float* colors, const float* acc_rows, float* v_dirs, void* handover, const int32_t* abort_flag, int32_t* abort_snapshot, hipStream_t s) {
+    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
+    if (degrees_to_use > 4 || Kd > K || K > 32 || K < 2) return LFS_E_INVALID;
+    if (n == 0) return LFS_OK;
+    if (!means || !viewmat || !shN || !radii || !colors || !acc_rows || !v_dirs || !handover || !abort_flag || !abort_snapshot) return LFS_E_INVALID;
+    lfs::ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.shN = shN; a.radii = radii; a.colors = colors;
+    const dim3 grid((n + 63) / 64), block(64);
+    lfs::ProfScope prof("sh_bwd_dirs", s);
+    float4* h = static_cast<float4*>(handover);
+    switch (lfs::lanes_for(K)) {
+    case 4: hipLaunchKernelGGL((lfs::sh_pipe_dirs_kernel<4>), grid, block, 0, s, a, acc_rows + 13, v_dirs, h, abort_flag, abort_snapshot); break;
+    case 16: hipLaunchKernelGGL((lfs::sh_pipe_dirs_kernel<16>), grid, block, 0, s, a, acc_rows + 13, v_dirs, h, abort_flag, abort_snapshot); break;
+    default: hipLaunchKernelGGL((lfs::sh_pipe_dirs_kernel<32>), grid, block, 0, s, a, acc_rows + 13, v_dirs, h, abort_flag, abort_snapshot); break;
+    }
+    return (int)hipGetLastError();
+}
+
+int lfs::sh_pipe_adam_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, float* sh0, float* shN, const void* handover, float* sh0_exp_avg, float* sh0_exp_avg_sq,
+                           const float* sh0_scalars, float* shN_exp_avg, float* shN_exp_avg_sq, const float* shN_scalars, const int32_t* abort_snapshot, hipStream_t s) {
+    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
+    if (degrees_to_use > 4 || Kd > K || K > 32 || K < 2) return LFS_E_INVALID;
+    if (n == 0) return LFS_OK;
+    if (!sh0 || !shN || !handover || !sh0_exp_avg || !sh0_exp_avg_sq || !sh0_scalars || !shN_exp_avg || !shN_exp_avg_sq || !shN_scalars || !abort_snapshot) return LFS_E_INVALID;
+    lfs::ShAdam adam{shN_exp_avg, shN_exp_avg_sq, lfs::AdamScalars{shN_scalars[0], shN_scalars[1], shN_scalars[2], shN_scalars[3], shN_scalars[4], shN_scalars[5]}};
+    adam.m0 = sh0_exp_avg; adam.v0 = sh0_exp_avg_sq;
+    adam.s0 = lfs::AdamScalars{sh0_scalars[0], sh0_scalars[1], sh0_scalars[2], sh0_scalars[3], sh0_scalars[4], sh0_scalars[5]};
+    // a fixed number of wavefronts (lfs::sh_pipe_side_waves() per CU x 256 CUs), not one per block: see sh_fwd_persistent_kernel
+    const dim3 grid(std::min<uint32_t>((n + 63) / 64, lfs::sh_pipe_side_grid())), block(64);
+    lfs::ProfScope prof("sh_bwd_adam", s);
+    const float4* h = static_cast<const float4*>(handover);
+    switch (lfs::lanes_for(K)) {
+    case 4: hipLaunchKernelGGL((lfs::sh_pipe_adam_kernel<4>), grid, block, 0, s, n, K, int(degrees_to_use), sh0, shN, h, adam, abort_snapshot); break;
+    case 16: hipLaunchKernelGGL((lfs::sh_pipe_adam_kernel<16>), grid, block, 0, s, n, K, int(degrees_to_use), sh0, shN, h, adam, abort_snapshot); break;
+    default: hipLaunchKernelGGL((lfs::sh_pipe_adam_kernel<32>), grid, block, 0, s, n, K, int(degrees_to_use), sh0, shN, h, adam, abort_snapshot); break;
+    }
+    return (int)hipGetLastError();
+}
+
+// lfs_sh_model_fwd for the pipelined step: visible Gaussians only (radii), colours to `colors` [n,3] AND into the rgb slots of the rasterizer's records
+int lfs::sh_model_fwd_records_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* sh0, const float* shN,
+                                   const int32_t* radii, float* colors, float* rec_rgb, uint32_t rec_stride, hipStream_t stream) {
+    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
+    if (degrees_to_use > 4 || Kd > K || K > 32) return LFS_E_INVALID;
+    if (n == 0) return LFS_OK;
+    if (!means || !viewmat || !sh0 || (K > 1 && !shN) || !colors || !radii || !rec_rgb) return LFS_E_INVALID;
+    lfs::ShArgs a{};
+    a.n = n; a.K = K; a.degree = int(degrees_to_use); a.means = means; a.viewmat = viewmat; a.sh0 = sh0; a.shN = shN; a.radii = radii;
+    a.rec_rgb = rec_rgb; a.rec_stride = rec_stride;
+    return lfs::sh_launch_fwd<true>(a, Kd, colors, stream, lfs::sh_pipe_side_grid());
 }
 
 static bool sh_views_ok(uint32_t n, uint32_t K, uint32_t degree, uint32_t V, uint32_t stride) {

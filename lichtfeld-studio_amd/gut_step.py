@@ -136,23 +136,34 @@ class GutStep:
     # ---- the step -------------------------------------------------------------------------------------------------------------------------------
     def train_step(self, params: Sequence[torch.Tensor], adam: Dict[str, dict], sh_degree: int, W: int, H: int, viewmat: torch.Tensor, Kmat: torch.Tensor,
                    bg: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float, loss_acc: torch.Tensor, scale_reg: float = 0.0,
-                   opacity_reg: float = 0.0) -> int:
+                   opacity_reg: float = 0.0, pipelined: bool = False) -> int:
         """Forward + backward + Adam on all six parameter tensors, in place; *loss_acc = weight * mse. `adam[name]` = FusedAdam.prepare_inline(param) for
-        the six names of GROUPS. Returns n_isects."""
+        the six names of GROUPS. Returns n_isects.
+        pipelined: lfs_gut_train_step_pipelined - the SH Adam pass of this step and the SH colours of the next run on the library's side stream, under the next step's
+        front end. Same results; sh0 / shN and their moments then belong to that stream until join() (every other method of this class joins by itself)."""
         lib = load_library()
         N = params[0].shape[0]
+        fn, what = (lib.lfs_gut_train_step_pipelined, "gut_train_step_pipelined") if pipelined else (lib.lfs_gut_train_step, "gut_train_step")
         for attempt in range(4):
             self._ensure(N, W, H)
             a = self._args(params, sh_degree, W, H, viewmat, Kmat, bg, target_chw, weight, scale_reg, opacity_reg, loss_acc, adam)
             self._stamp += 1
-            check(lib.lfs_gut_train_step(C.byref(a), C.c_int64(self.capacity), C.c_int64(self.assumed_longest), C.c_void_p(self.ws.data_ptr()),
-                                         C.c_size_t(self.ws.numel()), C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), stream()), "gut_train_step")
+            check(fn(C.byref(a), C.c_int64(self.capacity), C.c_int64(self.assumed_longest), C.c_void_p(self.ws.data_ptr()),
+                     C.c_size_t(self.ws.numel()), C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), stream()), what)
             if self._wait():
                 self._after_fit()
                 return self.n_isects
             self.retries += 1
             self._grow(self.n_isects, self.longest)
         raise LfsError("gut_step: the step did not fit its workspace after 4 attempts")
+
+    @staticmethod
+    def join() -> bool:
+        """The current stream waits (on the device) for the side stream's last SH update of a pipelined step. -> was there one?"""
+        rc = load_library().lfs_gut_pipeline_join(stream())
+        if rc < 0:
+            raise LfsError("gut_pipeline_join failed")
+        return rc == 1
 
     def view_forward(self, params: Sequence[torch.Tensor], sh_degree: int, W: int, H: int, viewmat, Kmat, bg) -> int:
         """Forward of one view into the workspace (render / alpha / radii via .view()); re-run on overflow. Returns n_isects."""

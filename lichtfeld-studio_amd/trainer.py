@@ -151,6 +151,7 @@ class GutTrainer:
         self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=self._deferred()) if (world > 1 or fused_l2) else None  # 2 = shN
         self.loss_acc = torch.zeros(1, device=device)
         self.inline_all_adam = True   # one view / one rank / MSE: all six parameters are updated inside the backward kernels (fused.backward_adam_all)
+        self.pipelined = False        # True: with its SH Adam pass / SH colours on the library's side stream, under the next step's front end (lfs_gut_train_step_pipelined)
         self.cxx_step = True          # ... and that step is ONE C++ call without a host read on the critical path (gut_step.GutStep -> csrc/gut_step.hip);
         self._gut_step = None         #     False: the same kernels enqueued call by call from Python (fused.py; tests compare the two)
         self.inline_shN_adam = True   # see train_step; False keeps the SH backward and the optimizer separate (tests compare the two)
@@ -298,10 +299,12 @@ class GutTrainer:
 
     def full_shN(self) -> torch.Tensor:
         """[N,K-1,3] on every rank (all-gathers the owners' rows when SH-sharded): export, evaluation."""
+        self.join_pipeline()
         return self.model.shN.detach() if self.sh_exchange is None else self.sh_exchange.gather_rows(self.model.shN.detach())
 
     def export_model(self) -> SplatModel:
         """The complete model on this rank (SH-sharded: shN all-gathered; every rank must call it): what loader.save_ply / evaluate.evaluate take."""
+        self.join_pipeline()
         m = self.model
         out = SplatModel(m.means.detach(), m.sh0.detach(), self.full_shN(), m.raw_scales.detach(), m.raw_quats.detach(), m.raw_opacities.detach(), m.max_sh_degree,
                          active_sh_degree=m.active_sh_degree)
@@ -339,6 +342,8 @@ class GutTrainer:
         self._views_all = views_all
         total_views = self.world * len(views)
         plan = self.last_plan = self._plan(len(views))   # (kept for tests and tools: which form the step took)
+        if plan.path != "cxx_all":
+            self.join_pipeline()
         if plan.path == "fastgs":
             return self._train_step_fastgs(targets, views, total_views)
         if plan.path == "autograd":
@@ -386,8 +391,15 @@ class GutTrainer:
         gs, sc, v = self._gut(), self.scene, views[0]
         N = self.model.means.shape[0]
         self.last_n_isects = gs.train_step([p.detach() for p in self.model.parameters()], inline_all, self.model.get_active_sh_degree(), sc.width, sc.height,
-                                           sc.viewmats[v], sc.Ks[v], self.bg, targets[0], 1.0 / total_views, self.loss_acc, self.scale_reg, self.opacity_reg)
+                                           sc.viewmats[v], sc.Ks[v], self.bg, targets[0], 1.0 / total_views, self.loss_acc, self.scale_reg, self.opacity_reg,
+                                           pipelined=self.pipelined)
         self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
+
+    def join_pipeline(self) -> None:
+        """After pipelined steps sh0 / shN and their moments belong to the library's side stream: the current stream waits for its last update (device-side, no host
+        wait). Called before everything that touches them outside the pipelined step - other step forms, strategies, export, evaluation."""
+        if self._gut_step is not None:
+            self._gut_step.join()
 
     def _step_cxx_views(self, plan, targets, views, total_views) -> None:
         """Gradient-tensor form of the C++ step (data-parallel ranks with the north-star layout - replicated Gaussians, one all-reduce of the flat bucket -,

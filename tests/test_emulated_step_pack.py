@@ -119,3 +119,83 @@ def test_guarded_attempt_that_does_not_fit_reports_counts_and_renders_nothing(em
     small = _forward(emu, sc, W, H, tile, max(int(ok["counts"][0]) // 3, 1), flags=0)
     assert small["abort"] == 1 and np.array_equal(small["counts"][:2], ok["counts"][:2])
     assert small["offsets"].max() == 0 and float(small["alpha"].max()) == 0.0
+
+
+# ---- round 6: the pipelined step (lfs_gut_train_step_pipelined) against lfs_gut_train_step on the emulator -----------------------------------------------------------
+# Streams are synchronous here, so this pins the DATA FLOW of the two-stream form - records packed without colours + the colour kernel writing their rgb slots, the SH
+# backward split into a direction pass and an Adam pass fed by 32-byte hand-over rows, the abort-flag snapshot - not its ordering (tests/test_gpu_gut_step.py does that
+# on the GPU, in the deterministic accumulation mode).
+def _train(lib, sc, W, H, tile, capacity, steps, pipelined, assumed_longest=1 << 20, shrink_on_step=None):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lfs_gut_step_defs", os.path.join(ROOT, "lichtfeld-studio_amd", "gut_step.py"))
+    src = open(spec.origin).read()
+    ns = {}
+    exec("import ctypes as C\n" + src[src.index("class StepArgs"):src.index("class GutStep")], ns)
+    StepArgs, StepLayout = ns["StepArgs"], ns["StepLayout"]
+    N = sc["means"].shape[0]
+    lay = StepLayout()
+    assert lib.lfs_gut_step_layout_for(C.c_uint32(N), C.c_uint32(W), C.c_uint32(H), C.c_uint32(tile), C.c_int64(capacity), C.byref(lay)) == 0
+    ws = np.full(int(lay.bytes) + 64, 0xA5, np.uint8)
+    names = ("means", "sh0", "shN", "raw_scales", "raw_quats", "raw_opac")
+    params = [np.ascontiguousarray(sc[k], np.float32).copy() for k in names]
+    m = [np.zeros_like(p) for p in params]
+    v = [np.zeros_like(p) for p in params]
+    rng = np.random.default_rng(11)
+    target = rng.random((3, H, W)).astype(np.float32)
+    vm, Km, bg = [np.ascontiguousarray(sc[k], np.float32) for k in ("vm", "K", "bg")]
+    loss = np.zeros(1, np.float32)
+    losses, fitted = [], []
+    fn = lib.lfs_gut_train_step_pipelined if pipelined else lib.lfs_gut_train_step
+    for it in range(steps):
+        a = StepArgs()
+        a.N, a.K, a.sh_degree, a.image_width, a.image_height, a.tile_size = N, sc["Kn"], sc["degree"], W, H, tile
+        a.means, a.sh0, a.shN, a.raw_scales, a.raw_quats, a.raw_opacities = [p.ctypes.data for p in params]
+        for k in range(6):
+            a.exp_avg[k], a.exp_avg_sq[k] = m[k].ctypes.data, v[k].ctypes.data
+            t = it + 1
+            for j, val in enumerate((1e-2 if k else 1e-3, 0.9, 0.999, 1e-15, 1.0 / (1.0 - 0.9 ** t), 1.0 / np.sqrt(1.0 - 0.999 ** t))):
+                a.adam[k][j] = val
+        a.viewmat, a.Kmat, a.background, a.target_chw = vm.ctypes.data, Km.ctypes.data, bg.ctypes.data, target.ctypes.data
+        a.loss_weight, a.scale_reg, a.opacity_reg, a.loss = 1.0, 0.01, 0.01, loss.ctypes.data
+        counts = np.zeros(3, np.int64)
+        cap = capacity if shrink_on_step != it else 8          # an attempt that cannot fit: nothing may be updated by it
+        rc = fn(C.byref(a), C.c_int64(cap), C.c_int64(assumed_longest), C.c_void_p(ws.ctypes.data), C.c_size_t(int(lay.bytes)), C.c_void_p(counts.ctypes.data),
+                C.c_int64(it + 1), None)
+        assert rc == 0, rc
+        fitted.append(bool(lib.lfs_gut_step_fits(C.c_int64(int(counts[0])), C.c_int64(int(counts[1])), C.c_int64(cap), C.c_int64(assumed_longest))))
+        losses.append(float(loss[0]))
+    assert lib.lfs_gut_pipeline_join(None) in (0, 1)
+    return dict(params=params, m=m, v=v, losses=losses, fitted=fitted)
+
+
+@pytest.mark.parametrize("case", ["syn_a_like", "large_gaussians"])
+def test_pipelined_step_matches_the_serial_step_bit_for_bit(emu, case):
+    N, W, H, tile, smin, smax, spread = CASES[case]
+    N = min(N, 600)
+    sc = _scene(3 + sum(map(ord, case)), N, W, H, smin, smax, spread, K=16, degree=3)
+    ref = _train(emu, sc, W, H, tile, 64 * N, 3, pipelined=False)
+    new = _train(emu, sc, W, H, tile, 64 * N, 3, pipelined=True)
+    assert all(ref["fitted"]) and all(new["fitted"]) and ref["losses"][0] > 0
+    assert ref["losses"] == new["losses"]
+    moved = 0
+    for k in range(6):
+        assert np.array_equal(ref["params"][k], new["params"][k]), k
+        assert np.array_equal(ref["m"][k], new["m"][k]) and np.array_equal(ref["v"][k], new["v"][k]), k
+        moved += int((ref["m"][k] != 0).sum())
+    assert moved > 100, "no gradient reached the parameters"
+
+
+def test_pipelined_attempt_that_does_not_fit_updates_nothing(emu):
+    N, W, H, tile, smin, smax, spread = CASES["syn_a_like"]
+    N = 500
+    sc = _scene(21, N, W, H, smin, smax, spread, K=16, degree=3)
+    ref = _train(emu, sc, W, H, tile, 64 * N, 2, pipelined=True)
+    # the same two steps with a hopeless attempt in between (step index 1 of 3 runs with capacity 8): its kernels must leave parameters and moments alone
+    new = _train(emu, sc, W, H, tile, 64 * N, 3, pipelined=True, shrink_on_step=1)
+    assert new["fitted"] == [True, False, True]
+    # (Adam's bias corrections follow the call index in _train, so only the FIRST step and the untouched state after the aborted attempt are compared)
+    one = _train(emu, sc, W, H, tile, 64 * N, 1, pipelined=True)
+    two = _train(emu, sc, W, H, tile, 64 * N, 2, pipelined=True, shrink_on_step=1)
+    for k in range(6):
+        assert np.array_equal(one["params"][k], two["params"][k]) and np.array_equal(one["m"][k], two["m"][k]) and np.array_equal(one["v"][k], two["v"][k]), k
+    assert ref["fitted"] == [True, True]

@@ -214,3 +214,77 @@ def test_view_forward_backward_gradients_match_render_and_backward(lfs):
         lib.lfs_set_debug_flags(0)
     assert all(torch.isfinite(x).all() for x in g)
     assert float((g[0] - g_ref[0]).abs().max()) > 0
+
+
+# ---- round 6: lfs_gut_train_step_pipelined (two streams) against lfs_gut_train_step (one) ---------------------------------------------------------------------------
+def _pipe_pair(sc):
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    a, b = GutTrainer(sc, DEV, iterations=7000), GutTrainer(sc, DEV, iterations=7000)
+    a.pipelined, b.pipelined = True, False
+    a.iteration = b.iteration = 1500
+    return a, b
+
+
+@pytest.mark.parametrize("n_gauss,degree", [(7000, 2), (200000, 3), (65, 3)])
+def test_pipelined_step_is_bit_identical_to_the_one_stream_step(lfs, n_gauss, degree):
+    """The SH Adam pass of step k and the SH colours of step k + 1 run on the library's side stream, beside finish(k) / projection(k + 1) / tile lists / culling on the
+    caller's: every buffer one of them writes while the other reads would show up here as a difference (200 000 Gaussians: kernels long enough to overlap for real).
+    Several views in turn, deterministic rasterizer sums: parameters and moments bit for bit after 6 steps."""
+    from lichtfeld_studio_amd import scenes
+    sc = scenes.syn_a(n=n_gauss, sh_degree=degree)
+    g = torch.Generator().manual_seed(5)
+    targets = [torch.rand(3, sc.height, sc.width, generator=g).to(DEV) * 0.7 for _ in range(3)]
+    n_views = sc.viewmats.shape[0]
+    lib = lfs.load_library()
+    try:
+        lib.lfs_set_debug_flags(16)
+        a, b = _pipe_pair(sc)
+        for it in range(6):
+            la, lb = a.train_step([targets[it % 3]], views=[it % n_views]), b.train_step([targets[it % 3]], views=[it % n_views])
+        a.join_pipeline()
+        torch.cuda.synchronize()
+    finally:
+        lib.lfs_set_debug_flags(0)
+    assert a.last_plan.path == b.last_plan.path == "cxx_all"
+    noise_check("pipelined vs one-stream loss value", abs(float(la) - float(lb)), 1e-5 * float(lb))
+    assert a.last_n_isects == b.last_n_isects > 0
+    _same_state(a, b, 6)
+    assert float(a.optimizer.state[id(a.model.shN)]["exp_avg"].abs().sum()) > 0, "no gradient reached shN"
+
+
+def test_pipelined_step_with_an_overflowing_attempt_and_a_change_of_step_form(lfs):
+    """First attempt of a pipelined step overflows its workspace (nothing may be updated, on either stream), then the run switches to the gradient-tensor form
+    (L1 + D-SSIM loss for one step: it reads sh0 / shN on the caller's stream and must wait for the side stream by itself) and back."""
+    from lichtfeld_studio_amd import scenes
+    from lichtfeld_studio_amd.gut_step import GutStep
+    sc = scenes.syn_a(n=4000, sh_degree=1)
+    target = torch.rand(3, sc.height, sc.width, generator=torch.Generator().manual_seed(4)).to(DEV) * 0.7
+    lib = lfs.load_library()
+    try:
+        lib.lfs_set_debug_flags(16)
+        a, b = _pipe_pair(sc)
+        a._gut_step = GutStep(DEV, initial_capacity=1500)
+        for it in range(5):
+            kind = "l1_ssim" if it == 2 else "mse"
+            a.loss_kind = b.loss_kind = kind
+            la, lb = a.train_step([target], views=[0]), b.train_step([target], views=[0])
+        a.join_pipeline()
+        torch.cuda.synchronize()
+    finally:
+        lib.lfs_set_debug_flags(0)
+    assert a._gut_step.retries >= 1, "the first attempt was meant to overflow"
+    _same_state(a, b, 5)
+
+
+def test_pipelined_step_float_atomics_stays_within_accumulation_noise(lfs):
+    """The benchmarked mode (float atomics, no debug flag): pipelined and one-stream steps differ only by the order of the rasterizer's atomic sums."""
+    from lichtfeld_studio_amd import scenes
+    sc = scenes.syn_a(n=20000, sh_degree=3)
+    target = torch.rand(3, sc.height, sc.width, generator=torch.Generator().manual_seed(6)).to(DEV) * 0.7
+    a, b = _pipe_pair(sc)
+    for it in range(4):
+        la, lb = a.train_step([target], views=[it % sc.viewmats.shape[0]]), b.train_step([target], views=[it % sc.viewmats.shape[0]])
+    a.join_pipeline()
+    torch.cuda.synchronize()
+    for name, pa, pb in zip(NAMES, a.model.parameters(), b.model.parameters()):
+        assert rel_l2(n(pa), n(pb)) < 2e-4, (name, rel_l2(n(pa), n(pb)))
