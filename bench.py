@@ -247,8 +247,10 @@ def main() -> None:
                     help="step (default) = the C++ training step (csrc/gut_step.hip, one host call per step); ops = the DROP-IN route: the sequence "
                          "rasterizer.cpp:224-344 makes through the reference-signature C++ wrappers of _lfs_torch_ops.so, op by op under torch autograd, then six "
                          "adam_step_wrapper launches (fused_adam.cpp:22-95) - what a reference build linking csrc/torch_ops.cpp gets without touching its trainer")
-    ap.add_argument("--no-pipeline", action="store_true", help="single-GPU MSE step: lfs_gut_train_step (one stream) instead of lfs_gut_train_step_pipelined (round 6: the SH Adam "
-                                                               "pass and the SH colours on the library's side stream, under the next step's projection / tile lists / culling)")
+    ap.add_argument("--no-fused-tail", action="store_true", help="single-GPU MSE step: lfs_gut_train_step (SH backward + Adam, finish + Adam, SH colours as three launches) instead of "
+                                                                 "lfs_gut_train_step_ex (round 6: one launch for all three, the next view's colours from the rows in registers)")
+    ap.add_argument("--pipeline", action="store_true", help="single-GPU MSE step: lfs_gut_train_step_pipelined (round 6: the SH Adam pass and the SH colours on the library's side stream, "
+                                                            "under the next step's projection / tile lists / culling; measured -4.5 % at best, profiles/r06/pipeline/README.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops-route", action="store_true", help="skip the 16 extra steps of the drop-in route (the `ops_route` block of the line)")
     ap.add_argument("--no-profile", action="store_true")
@@ -306,7 +308,8 @@ def main() -> None:
     headline_factored = (not args.replicated and not headline_sharded and args.rasterizer == "gut" and args.path == "step"
                          and ((bool(args.factored) and (world > 1 or forced)) or (not args.factored and auto_factored(args.views_per_rank))))
     trainer = make_trainer(headline_sharded, headline_factored)
-    trainer.pipelined = not args.no_pipeline   # (only the one-call step form, plan "cxx_all", has a pipelined variant; every other form joins the side stream by itself)
+    trainer.pipelined = bool(args.pipeline)        # (only the one-call step form, plan "cxx_all", has these variants; every other form joins the side stream by itself)
+    trainer.fused_tail = not args.no_fused_tail
     if headline_factored and not args.factored:
         # the factored exchange has never run between two GPUs (no multi-GPU box was ever available to this repository): one guarded trial step, on EVERY rank, before
         # anything is timed; if any rank's collective library refuses it the headline falls back to the flat all-reduce and says so
@@ -547,7 +550,7 @@ def main() -> None:
                                f"16x16 tiles, {n_views} orbit cameras, {'MSE' if args.loss == 'mse' else 'L1 + 0.2 D-SSIM'} loss, default_optimization_params lrs",
                    "global_batch": world * args.views_per_rank, "views_per_rank": args.views_per_rank,
                    "parallelism": f"dp{world}" + ("-sh-sharded" if trainer.sh_exchange is not None else ("-replicated-factored-sh" if trainer.factored_sh and (world > 1 or os.environ.get("LFS_DIST_FORCE_COLLECTIVES")) else ("-replicated-flat-all-reduce" if world > 1 else ""))),
-                   "path": args.path, "step_form": (None if args.path != "step" or trainer.last_plan is None else trainer.last_plan.path + ("_pipelined" if trainer.last_plan.path == "cxx_all" and trainer.pipelined else "")),
+                   "path": args.path, "step_form": (None if args.path != "step" or trainer.last_plan is None else trainer.last_plan.path + (("_pipelined" if trainer.pipelined else "_fused_tail" if trainer.fused_tail else "") if trainer.last_plan.path == "cxx_all" else "")),
                    "start_iteration": args.start_iteration,
                    "strategy": args.strategy, "bilateral_grid": bool(args.bilateral_grid), "refine_step_ms": None if refine_ms is None else round(refine_ms, 3),
                    "visible_gaussians": V, **({"visible_gaussians_source": v_source} if v_source else {}), "n_isects": I},

@@ -165,7 +165,9 @@ LFS_API size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t ch
  *      tests/test_gpu_raster.py); bits 1 - 3: unused (the experimental kernels they selected were measured and removed);
  *      bit 4 = deterministic backward accumulation (two passes, 64-bit fixed point: run-to-run bit-identical gradients; lfs_rasterize_workspace_bytes grows while it is set);
  *      bit 5 = the one-pass intersection scatter even when a scratch array is given; bit 6 = the training step packs the rasterizer's records with the separate
- *      raster_pack pass of rounds 1 - 3 instead of inside the projection kernel (A/B, tests/test_emulated_step_pack.py). */
+ *      raster_pack pass of rounds 1 - 3 instead of inside the projection kernel (A/B, tests/test_emulated_step_pack.py); bit 7: unused (round 6: the projection kernel clearing the
+ *      backward's accumulator rows instead of the memset - measured slower, removed); bit 8 = lfs_intersect_tile_count* runs its count and scan as two launches
+ *      (rounds 1 - 5) instead of the scan in the count kernel's last workgroup (A/B, tests/test_gpu_intersect.py). */
 LFS_API void lfs_set_debug_flags(uint32_t flags);
 LFS_API uint32_t lfs_get_debug_flags(void);
 LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_fwd(
@@ -432,6 +434,13 @@ LFS_API int lfs_gut_view_backward_finish(const lfs_gut_step_args* args, int64_t 
 LFS_API int lfs_gut_view_backward_rows(const lfs_gut_step_args* args, int64_t capacity, const float* v_render, float* const* grads /* [6] host */, int accumulate,
                                        float* v_colors_out, void* workspace, size_t workspace_bytes, lfs_stream_t stream);
 LFS_API int lfs_gut_step_wait(const int64_t* host_counts, int64_t stamp, double timeout_s, int64_t* n_isects, int64_t* longest);
+/*   lfs_gut_train_step_ex (round 6): lfs_gut_train_step with its three per-Gaussian tail passes (SH backward + Adam on sh0 / shN, finish + Adam on the other four tensors,
+ *      and the NEXT step's SH colours) as ONE launch. next_viewmat (device [4,4], nullable): the view the next step will render - its SH colours are then written to the
+ *      workspace's colours for every Gaussian, from the coefficient rows as they leave their Adam update. colors_ready != 0: the caller's statement that the previous call on
+ *      this workspace was this entry point with next_viewmat naming the matrix args->viewmat holds now, same N / K / sh_degree, that it fitted its buffers, and that nothing
+ *      has written means / sh0 / shN since - the SH colour kernel is then not launched. Same results as lfs_gut_train_step. */
+LFS_API int lfs_gut_train_step_ex(const lfs_gut_step_args* args, const float* next_viewmat, int colors_ready, int64_t capacity, int64_t assumed_longest, void* workspace,
+                                  size_t workspace_bytes, int64_t* host_counts, int64_t stamp, lfs_stream_t stream);
 /*   lfs_gut_train_step_pipelined (round 6): lfs_gut_train_step - same arguments, same results - with the step's HBM-bound SH kernels on a side stream of the library,
  *      UNDER the latency- / VALU-bound front end of the NEXT step: projection(k+1) (records without colours) | tile lists | culling run on `stream` while SH Adam(k)
  *      (1.1 GB of read-modify-write at 1 M Gaussians) and the SH colours(k+1) run beside them; `stream` waits for the colours in front of the forward kernel. The SH

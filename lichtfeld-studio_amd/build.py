@@ -42,11 +42,11 @@ SOURCES = {
     "prof.hip": [],
     # no SLP packing: v_pk_* operand pairing forces SGPR shuffles right after the scalar record
     # load and defeats the software prefetch (measured on the ISA); plain v_fma with SGPR operands
-    "raster.hip": ["-fno-slp-vectorize"],
+    "raster.hip": ["-fno-slp-vectorize", "-DLFS_SH_DPP_SUM"],   # (LFS_SH_DPP_SUM: the SH lane-group sums of gut_tail_kernel as in sh.hip)
     "gut_step.hip": [],   # host code only: the C++ training-step driver
     "version.hip": [],    # lfs_version(): carries the hash of the sources (recompiled whenever any of them changed)
 }
-HEADERS = ["lfs_math.cuh", "lfs_adam.cuh", "lfs_camera.cuh", "lfs_prof.h", "lfs_raster_common.cuh", "lfs_cull_conic.cuh", "lfs_raster_pack.cuh", "lfs_tilelists.cuh", "lfs_fastgs.cuh", "lfs_step_internal.h", os.path.join("..", "..", "include", "lfs_gsplat.h")]
+HEADERS = ["lfs_math.cuh", "lfs_sh.cuh", "lfs_adam.cuh", "lfs_camera.cuh", "lfs_prof.h", "lfs_raster_common.cuh", "lfs_cull_conic.cuh", "lfs_raster_pack.cuh", "lfs_tilelists.cuh", "lfs_fastgs.cuh", "lfs_step_internal.h", os.path.join("..", "..", "include", "lfs_gsplat.h")]
 
 
 def source_hash() -> str:

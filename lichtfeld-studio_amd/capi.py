@@ -87,7 +87,7 @@ EXPORTS = [
     "lfs_fastgs_set_debug_flags", "lfs_fused_ssim_fwd", "lfs_fused_ssim_bwd", "lfs_photometric_loss_workspace_bytes", "lfs_photometric_loss_fwd_bwd", "lfs_photometric_loss_chw_fwd_bwd", "lfs_photometric_loss_ex_fwd_bwd", "lfs_mse_loss_ex_fwd_bwd",
     "lfs_bilateral_slice_fwd", "lfs_bilateral_slice_bwd", "lfs_bilateral_tv_loss_fwd", "lfs_bilateral_tv_loss_bwd", "lfs_image_u8_to_chw_f32", "lfs_mean_neighbor_distances", "lfs_mean_neighbor_distances_exact",
     "lfs_quats_to_rotmats", "lfs_relocation", "lfs_add_noise", "lfs_mcmc_relocate_workspace_bytes", "lfs_mcmc_relocate",
-    "lfs_activations_project_ut", "lfs_gut_step_layout_for", "lfs_gut_step_fits", "lfs_gut_train_step", "lfs_gut_view_forward", "lfs_gut_view_backward", "lfs_gut_view_backward_sh", "lfs_gut_view_backward_finish", "lfs_gut_view_backward_rows", "lfs_gut_step_wait", "lfs_gut_step_supported", "lfs_gut_train_step_pipelined", "lfs_gut_pipeline_join",
+    "lfs_activations_project_ut", "lfs_gut_step_layout_for", "lfs_gut_step_fits", "lfs_gut_train_step", "lfs_gut_view_forward", "lfs_gut_view_backward", "lfs_gut_view_backward_sh", "lfs_gut_view_backward_finish", "lfs_gut_view_backward_rows", "lfs_gut_step_wait", "lfs_gut_step_supported", "lfs_gut_train_step_pipelined", "lfs_gut_pipeline_join", "lfs_gut_train_step_ex",
     "lfs_rasterize_workspace_acc_offset", "lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_mse_acc", "lfs_sh_model_bwd_adam_all", "lfs_gut_finish_adam", "lfs_gut_finish_grads", "lfs_rasterize_to_pixels_from_world_3dgs_bwd_prepared_acc", "lfs_adam_step", "lfs_adam_step_multi", "lfs_version", "lfs_profile_enable", "lfs_profile_filter", "lfs_profile_collect",
 ]
 

@@ -116,7 +116,7 @@ int auto_join(hipStream_t s) {
 
 // everything up to and including the rasterizer forward; shared by the Adam-inline step and the gradient-tensor step
 int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacity, int64_t assumed_longest, int64_t* host_counts, int64_t stamp, hipStream_t s, Front& f,
-                    Pipeline* pipe = nullptr) {
+                    Pipeline* pipe = nullptr, bool colors_ready = false) {   // colors_ready: w.colors holds this view's SH colours already (the previous step's fused tail wrote them)
     const uint32_t N = a->N, W = a->image_width, H = a->image_height, tile = a->tile_size;
     const uint32_t tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile;
     lfs_cameras& cams = f.cams;
@@ -139,7 +139,7 @@ int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacit
         // stream, behind the previous step's SH Adam kernel, into `colors` and into the rgb slots of the records; the main stream carries on with the tile lists and
         // waits for them in front of the forward kernel.
         rc = activations_project_ut_impl(N, a->means, a->raw_quats, a->raw_scales, a->raw_opacities, &cams, 0.3f, 0.01f, 10000.f, 0.f, &ut, w.quats, w.scales,
-                                         w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th, w.raster_ws, s, recs, cull, nullptr);
+                                         w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th + 1u /* + the count kernel's ticket counter */, w.raster_ws, s, recs, cull, nullptr);
         if (rc) return rc;
         hipError_t e = hipEventRecord(pipe->projected, s);
         if (e == hipSuccess) e = hipStreamWaitEvent(pipe->side, pipe->projected, 0);
@@ -160,12 +160,12 @@ int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacit
         return raster_fwd_guarded(N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &cams, tile, f.offsets, w.flatten_ids, capacity, w.render, w.alpha,
                                   w.last_ids, w.raster_ws, w.raster_ws_bytes, s, /*cams_ready=*/true, /*records_ready=*/true, /*wait_before_fwd=*/pipe->colours);
     }
-    if (pack_here) {
+    if (pack_here && !colors_ready) {
         rc = sh_model_fwd_impl(N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, nullptr, w.colors, s);
         if (rc) return rc;
     }
     rc = activations_project_ut_impl(N, a->means, a->raw_quats, a->raw_scales, a->raw_opacities, &cams, 0.3f, 0.01f, 10000.f, 0.f, &ut, w.quats, w.scales,
-                                     w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th, w.raster_ws, s,
+                                     w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th + 1u /* + the count kernel's ticket counter */, w.raster_ws, s,
                                      pack_here ? recs : nullptr, pack_here ? cull : nullptr, pack_here ? w.colors : nullptr);
     if (rc) return rc;
     const IsectGuard guard{capacity, assumed_longest, w.abort_flag};
@@ -173,7 +173,7 @@ int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacit
     rc = isect_count_impl(1, N, w.means2d, w.radii, tile, tw, th, w.tiles_per_gauss, counts, counts + 1, nullptr, LFS_ISECT_COUNTERS_ZERO, counts + 2, stamp, w.isect_ws,
                           w.isect_ws_bytes, s, &guard);
     if (rc) return rc;
-    if (!pack_here) { // the SH colours need the projection's radii only: enqueued between the count and the binning passes, as the Python step did with its `overlap` hook
+    if (!pack_here && !colors_ready) { // the SH colours need the projection's radii only: enqueued between the count and the binning passes, as the Python step did with its `overlap` hook
         rc = lfs_sh_model_fwd(N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, s);
         if (rc) return rc;
     }
@@ -242,6 +242,48 @@ extern "C" int lfs_gut_train_step(const lfs_gut_step_args* a, int64_t capacity, 
                                     a->adam[1], a->exp_avg[2], a->exp_avg_sq[2], a->adam[2], s, w.abort_flag);
     if (rc) return rc;
     // lfs_gut_finish_adam's order: means, raw_scales, raw_quats, raw_opacities = FusedAdam groups 0, 3, 4, 5
+    float* const m[4] = {a->exp_avg[0], a->exp_avg[3], a->exp_avg[4], a->exp_avg[5]};
+    float* const v[4] = {a->exp_avg_sq[0], a->exp_avg_sq[3], a->exp_avg_sq[4], a->exp_avg_sq[5]};
+    float sc[24];
+    const int grp[4] = {0, 3, 4, 5};
+    for (int k = 0; k < 4; ++k) for (int j = 0; j < 6; ++j) sc[6 * k + j] = a->adam[grp[k]][j];
+    return gut_finish_adam_impl(a->N, a->means, a->raw_scales, a->raw_quats, a->raw_opacities, w.quats, w.scales, w.opacities, w.v_dirs, m, v, sc, a->scale_reg,
+                                a->opacity_reg, a->loss, w.raster_ws, w.raster_ws_bytes, s, w.abort_flag);
+}
+
+// lfs_gut_train_step with its three per-Gaussian tail passes as ONE (round 6; raster.hip: gut_tail_kernel): SH backward + Adam(sh0, shN) + finish + Adam(means, scales,
+// quaternions, opacities) in one launch, dL/d(dirs) handed over in registers - and, when the caller names the NEXT step's view (next_viewmat, device [4,4]), that view's SH
+// colours for every Gaussian from the coefficient rows as they leave their Adam update: the next call then passes colors_ready = 1 and its SH colour kernel is not launched.
+//   one-call step :  ... backward | SH backward + Adam (0.26 ms) | finish + Adam (0.10) | [next step] SH colours (0.07) | projection ...
+//   this form     :  ... backward | tail (SH backward + six Adam updates + next colours) | [next step] projection ...
+// colors_ready = 1 is the caller's statement that (a) the previous call on this workspace was this entry point with next_viewmat pointing at the matrix args->viewmat holds
+// now, (b) with the same N, K and sh_degree, (c) it fitted its buffers (lfs_gut_step_fits), and (d) nothing has written means / sh0 / shN since. gut_step.GutStep keeps that
+// book. Same results as lfs_gut_train_step, bit for bit in the deterministic accumulation mode. K > 16 (SH degree 4): the three separate passes run, as there.
+extern "C" int lfs_gut_train_step_ex(const lfs_gut_step_args* a, const float* next_viewmat, int colors_ready, int64_t capacity, int64_t assumed_longest, void* workspace,
+                                     size_t workspace_bytes, int64_t* host_counts, int64_t stamp, lfs_stream_t stream) {
+    int rc = check_args(a, true);
+    if (rc) return rc;
+    if (!workspace) return LFS_E_INVALID;
+    StepWs w;
+    if (!step_ws(workspace, a->N, a->image_width, a->image_height, a->tile_size, capacity, w, nullptr)) return LFS_E_INVALID;
+    if (workspace_bytes < w.bytes) return LFS_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    rc = auto_join(s);
+    if (rc) return rc;
+    Front f;
+    rc = enqueue_forward(a, w, capacity, assumed_longest, host_counts, stamp, s, f, nullptr, colors_ready != 0);
+    if (rc) return rc;
+    rc = raster_bwd_mse_acc_guarded(a->N, a->means, w.quats, w.scales, w.colors, w.opacities, a->background, &f.cams, a->tile_size, f.offsets, w.flatten_ids, capacity,
+                                    w.render, w.alpha, w.last_ids, a->target_chw, a->loss_weight, w.raster_ws, w.raster_ws_bytes, s);
+    if (rc) return rc;
+    rc = gut_tail_impl(a->N, a->K, a->sh_degree, a->means, a->sh0, a->shN, a->raw_scales, a->raw_quats, a->raw_opacities, w.quats, w.scales, w.opacities, a->viewmat,
+                       next_viewmat, w.radii, w.colors, a->exp_avg, a->exp_avg_sq, a->adam, a->scale_reg, a->opacity_reg, a->loss, w.raster_ws, w.raster_ws_bytes, s, w.abort_flag);
+    if (rc != LFS_E_UNSUPPORTED) return rc;
+    // K > 16: the separate passes of lfs_gut_train_step (no colours for the next step: the caller's next call must pass colors_ready = 0 - GutStep checks K)
+    const float* acc_rows = reinterpret_cast<const float*>(static_cast<const char*>(w.raster_ws) + lfs_rasterize_workspace_acc_offset(1, a->N));
+    rc = sh_model_bwd_adam_all_impl(a->N, a->K, a->sh_degree, a->means, a->viewmat, a->sh0, a->shN, w.radii, w.colors, acc_rows, w.v_dirs, a->exp_avg[1], a->exp_avg_sq[1],
+                                    a->adam[1], a->exp_avg[2], a->exp_avg_sq[2], a->adam[2], s, w.abort_flag);
+    if (rc) return rc;
     float* const m[4] = {a->exp_avg[0], a->exp_avg[3], a->exp_avg[4], a->exp_avg[5]};
     float* const v[4] = {a->exp_avg_sq[0], a->exp_avg_sq[3], a->exp_avg_sq[4], a->exp_avg_sq[5]};
     float sc[24];

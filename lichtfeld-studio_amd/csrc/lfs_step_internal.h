@@ -71,6 +71,13 @@ int gut_finish_grads_impl(uint32_t N, const float* means, const float* raw_quats
                           float opacity_reg, int accumulate, float* g_means, float* g_raw_scales, float* g_raw_quats, float* g_raw_opacities, float* v_colors,
                           const float* v_dirs, float* loss, void* workspace, size_t workspace_bytes, hipStream_t s);
 
+// the fused tail of the all-inline step (raster.hip: gut_tail_kernel): SH backward + the six Adam updates in one pass; next_viewmat (nullable): also the NEXT view's SH
+// colours -> colors [N,3], every Gaussian. exp_avg / exp_avg_sq / scalars in FusedAdam's group order (lfs_gut_step_args). LFS_E_UNSUPPORTED for K > 16.
+int gut_tail_impl(uint32_t N, uint32_t K, uint32_t degrees_to_use, float* means, float* sh0, float* shN, float* raw_scales, float* raw_quats, float* raw_opacities,
+                  const float* quats, const float* scales, const float* opacities, const float* viewmat, const float* next_viewmat, const int32_t* radii, float* colors,
+                  float* const* exp_avg, float* const* exp_avg_sq, const float (*scalars)[6], float scale_reg, float opacity_reg, float* loss, void* workspace,
+                  size_t workspace_bytes, hipStream_t s, const int32_t* abort_flag);
+
 // pipelined training step (gut_step.hip): the SH backward in two kernels on two streams (sh.hip), and the SH colours written into the rasterizer's records
 int sh_pipe_dirs_impl(uint32_t n, uint32_t K, uint32_t degrees_to_use, const float* means, const float* viewmat, const float* shN, const int32_t* radii,
                       const float* colors, const float* acc_rows, float* v_dirs, void* handover /* 32 B per Gaussian */, const int32_t* abort_flag, int32_t* abort_snapshot,

@@ -27,7 +27,8 @@
 //             mean vjp (done per (pixel, Gaussian) in the reference).
 // Measured and removed in round 5 (commit f684d4b, profiles/r05/lease4/ab_fwdzero_off.txt): the forward kernel clearing the backward's accumulator rows on the side (two or three
 // 16-byte stores per lane at kernel start, instead of the 64 MB hipMemsetAsync in front of the backward: 9 - 10 us): raster_fwd 0.234 -> 0.247 ms, step +0.015 - 0.025 ms - stores
-// issued by a VALU-bound kernel are not free.
+// issued by a VALU-bound kernel are not free. Round 6 (profiles/r06/lease15_ab_tail_acc_clear.txt): the same 64 MB cleared by the step's PROJECTION kernel (four 16-byte stores per lane at its
+// top): projection 0.064 -> 0.081 ms, step +0.007 ms against the memset's 0.0115 ms + launch gap - that kernel moves 204 MB in 64 us and has no memory slack either: removed.
 // Measured and removed in round 3 (kernels in git history up to e34272a, numbers under profiles/): 16x8 "wide" cells with two pixels per lane
 // (profiles/r01/raster_wide_cells_ab.json: bwd 0.84 vs 0.69 ms), quadrant-row kernels with DPP-broadcast records (profiles/r02/raster_rows_vs_default_pmc.txt:
 // 1.17x the VALU instructions), SH colours + record packing in one kernel (profiles/r02/fuse_front_ab.txt: no gain).
@@ -37,6 +38,7 @@
 #include "lfs_cull_conic.cuh"
 #include "lfs_raster_pack.cuh"
 #include "lfs_adam.cuh"
+#include "lfs_sh.cuh"
 #include "lfs_step_internal.h"
 
 // LFS_BWD_REORTH (default 1 since round 5; -DLFS_BWD_REORTH=0 = the rounds 1 - 4 backward, kept for A/B: tools/build_variant.py noreorth raster.hip -DLFS_BWD_REORTH=0): the backward
@@ -644,6 +646,70 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     walk_cell_list<-1>(cl, recs, n_walk - 1, n_walk, eval, []() { return true; });
 }
 
+// dL/d(mean, quaternion, scale) of ONE Gaussian under ONE camera from its accumulator sums A = dL/d(record matrix), G = dL/dg - the vjp tail of Bwd.cu:318-333 through
+// M = S^-1 R^T (global shutter: record matrix M Rinv, g = M (o - mu)). Shared by raster_finish_kernel, raster_finish_adam_kernel and gut_tail_kernel, which are held to
+// each other bit for bit (tests/test_gpu_gut_step.py): the arithmetic is pinned contraction-free here, helpers included (lfs_math.cuh's take the including file's default and
+// this file allows contraction - round 6: a third inlined copy of the fused form came out one ulp off in dL/dmeans, the compiler fuses a*b + c*d differently per context).
+// ADDS to vm / vq / vs (the operator form sums over cameras).
+template <bool UNIFORM_ORIGIN>
+LFS_DI void finish_geometry(const float4 q, const float (&is)[3], const float (&A)[9], const f3 G, const f3 mu, const CamDev& cam, float (&vm)[3], float (&vq)[4], float (&vs)[3]) {
+#pragma clang fp contract(off)
+    m3 R;
+    float qw = q.x, qx = q.y, qy = q.z, qz = q.w;
+    const float qinv = 1.f / sqrtf(qx * qx + qy * qy + qz * qz + qw * qw);
+    qx *= qinv; qy *= qinv; qz *= qinv; qw *= qinv;
+    {   // quat_to_rotmat
+        const float x2 = qx * qx, y2 = qy * qy, z2 = qz * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
+        R.m[0][0] = 1.f - 2.f * (y2 + z2); R.m[1][0] = 2.f * (xy + wz); R.m[2][0] = 2.f * (xz - wy);
+        R.m[0][1] = 2.f * (xy - wz); R.m[1][1] = 1.f - 2.f * (x2 + z2); R.m[2][1] = 2.f * (yz + wx);
+        R.m[0][2] = 2.f * (xz + wy); R.m[1][2] = 2.f * (yz - wx); R.m[2][2] = 1.f - 2.f * (x2 + y2);
+    }
+    m3 M;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
+    // dL/dM (math rows r, cols c). Global shutter: the record matrix was M Rinv, so dL/dM = dL/d(M Rinv) Rinv^T
+    m3 vM;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (UNIFORM_ORIGIN) {
+                const m3& Ri = cam.Rinv;
+                vM.m[r][c] = A[3 * r] * Ri.m[c][0] + A[3 * r + 1] * Ri.m[c][1] + A[3 * r + 2] * Ri.m[c][2];
+            } else vM.m[r][c] = A[3 * r + c];
+        }
+    if (UNIFORM_ORIGIN) {
+        const float gv[3] = {G.x, G.y, G.z}, ov[3] = {cam.origin.x - mu.x, cam.origin.y - mu.y, cam.origin.z - mu.z};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vM.m[r][c] += gv[r] * ov[c];
+    }
+    // mean: gro = M (o - mu)  ->  dL/dmu = -M^T G
+    vm[0] -= M.m[0][0] * G.x + M.m[1][0] * G.y + M.m[2][0] * G.z;
+    vm[1] -= M.m[0][1] * G.x + M.m[1][1] * G.y + M.m[2][1] * G.z;
+    vm[2] -= M.m[0][2] * G.x + M.m[1][2] * G.y + M.m[2][2] * G.z;
+    // M = S^-1 R^T, i.e. P = M^T = R S^-1 with dL/dP = (dL/dM)^T:  dL/dR[r][c] = dL/dP[r][c] / s_c ;  dL/ds_c = -(1/s_c^2) sum_r R[r][c] dL/dP[r][c]
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[r][c] = vM.m[c][r] * is[c];
+    {   // quat_to_rotmat_vjp on the normalised quaternion
+        const float vw = 2.f * (qx * (g[2][1] - g[1][2]) + qy * (g[0][2] - g[2][0]) + qz * (g[1][0] - g[0][1]));
+        const float vx = 2.f * (-2.f * qx * (g[1][1] + g[2][2]) + qy * (g[1][0] + g[0][1]) + qz * (g[2][0] + g[0][2]) + qw * (g[2][1] - g[1][2]));
+        const float vy = 2.f * (qx * (g[1][0] + g[0][1]) - 2.f * qy * (g[0][0] + g[2][2]) + qz * (g[2][1] + g[1][2]) + qw * (g[0][2] - g[2][0]));
+        const float vz = 2.f * (qx * (g[2][0] + g[0][2]) + qy * (g[2][1] + g[1][2]) - 2.f * qz * (g[0][0] + g[1][1]) + qw * (g[1][0] - g[0][1]));
+        const float dq = vw * qw + vx * qx + vy * qy + vz * qz;
+        vq[0] += (vw - dq * qw) * qinv; vq[1] += (vx - dq * qx) * qinv; vq[2] += (vy - dq * qy) * qinv; vq[3] += (vz - dq * qz) * qinv;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        vs[c] += -is[c] * is[c] * (R.m[0][c] * vM.m[c][0] + R.m[1][c] * vM.m[c][1] + R.m[2][c] * vM.m[c][2]);
+}
+
 // ---------------------------------------------------------------------------
 // finish: accumulator -> dL/d(means, quats, scales, colors, opacities)
 // ---------------------------------------------------------------------------
@@ -665,7 +731,7 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
     if (gid >= N) return;
     float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
     bool geom_loaded = false;
-    f3 mu{0.f, 0.f, 0.f}; float4 q = make_float4(1.f, 0.f, 0.f, 0.f); float is[3] = {0.f, 0.f, 0.f}; m3 R, M;
+    f3 mu{0.f, 0.f, 0.f}; float4 q = make_float4(1.f, 0.f, 0.f, 0.f); float is[3] = {0.f, 0.f, 0.f};
     for (uint32_t cid = 0; cid < C; ++cid) {
         const size_t idx = size_t(cid) * N + gid;
         const float4* a4 = reinterpret_cast<const float4*>(acc + idx * ACC_STRIDE);
@@ -693,47 +759,10 @@ __global__ void __launch_bounds__(256) raster_finish_kernel(
         if (!geom_loaded) {
             mu = {means[3 * gid], means[3 * gid + 1], means[3 * gid + 2]};
             q = reinterpret_cast<const float4*>(quats)[gid];
-            R = quat_to_rotmat(q.x, q.y, q.z, q.w);
             is[0] = 1.f / scales[3 * gid]; is[1] = 1.f / scales[3 * gid + 1]; is[2] = 1.f / scales[3 * gid + 2];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
             geom_loaded = true;
         }
-        // dL/dM (math rows r, cols c). Global shutter: the record matrix was M Rinv, so dL/dM = dL/d(M Rinv) Rinv^T
-        m3 vM;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (UNIFORM_ORIGIN) {
-                    const m3& Ri = cams[cid].Rinv;
-                    vM.m[r][c] = A[3 * r] * Ri.m[c][0] + A[3 * r + 1] * Ri.m[c][1] + A[3 * r + 2] * Ri.m[c][2];
-                } else vM.m[r][c] = A[3 * r + c];
-            }
-        if (UNIFORM_ORIGIN) {
-            const f3 om = cams[cid].origin - mu;
-            const float gv[3] = {G.x, G.y, G.z}, ov[3] = {om.x, om.y, om.z};
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) vM.m[r][c] += gv[r] * ov[c];
-        }
-        // mean: gro = M (o - mu)  ->  dL/dmu = -M^T G
-        const f3 vom = mul_t(M, G);
-        vm[0] -= vom.x; vm[1] -= vom.y; vm[2] -= vom.z;
-        // M = S^-1 R^T, i.e. P = M^T = R S^-1 with dL/dP = (dL/dM)^T:
-        //   dL/dR[r][c] = dL/dP[r][c] / s_c ;  dL/ds_c = -(1/s_c^2) sum_r R[r][c] dL/dP[r][c]
-        m3 GR;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) GR.m[r][c] = vM.m[c][r] * is[c];
-        quat_to_rotmat_vjp(q.x, q.y, q.z, q.w, GR, vq);
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            vs[c] += -is[c] * is[c] * (R.m[0][c] * vM.m[c][0] + R.m[1][c] * vM.m[c][1] + R.m[2][c] * vM.m[c][2]);
+        finish_geometry<UNIFORM_ORIGIN>(q, is, A, G, mu, cams[cid], vm, vq, vs);
     }
     v_means[3 * gid] = vm[0]; v_means[3 * gid + 1] = vm[1]; v_means[3 * gid + 2] = vm[2];
     reinterpret_cast<float4*>(v_quats)[gid] = make_float4(vq[0], vq[1], vq[2], vq[3]);
@@ -914,36 +943,8 @@ __global__ void __launch_bounds__(LFS_FINISH_BLOCK) raster_finish_adam_kernel(
     }
 #endif // LFS_FINISH_ONE_TRIP
     { // exactly raster_finish_kernel<true> for C == 1 (selected by `any` at the end)
-        const m3 R = quat_to_rotmat(q.x, q.y, q.z, q.w);
         const float is[3] = {1.f / sc[0], 1.f / sc[1], 1.f / sc[2]};
-        m3 M;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
-        m3 vM;
-        const m3& Ri = cams[0].Rinv;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) vM.m[r][c] = A[3 * r] * Ri.m[c][0] + A[3 * r + 1] * Ri.m[c][1] + A[3 * r + 2] * Ri.m[c][2];
-        const f3 om = cams[0].origin - mu;
-        const float gv[3] = {G.x, G.y, G.z}, ov[3] = {om.x, om.y, om.z};
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) vM.m[r][c] += gv[r] * ov[c];
-        const f3 vom = mul_t(M, G);
-        vm[0] -= vom.x; vm[1] -= vom.y; vm[2] -= vom.z;
-        m3 GR;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) GR.m[r][c] = vM.m[c][r] * is[c];
-        quat_to_rotmat_vjp(q.x, q.y, q.z, q.w, GR, vq);
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            vs[c] += -is[c] * is[c] * (R.m[0][c] * vM.m[c][0] + R.m[1][c] * vM.m[c][1] + R.m[2][c] * vM.m[c][2]);
+        finish_geometry<true>(q, is, A, G, mu, cams[0], vm, vq, vs);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { vm[k] = any ? vm[k] : 0.f; vs[k] = any ? vs[k] : 0.f; }
 #pragma unroll
@@ -1009,6 +1010,321 @@ __global__ void __launch_bounds__(LFS_FINISH_BLOCK) raster_finish_adam_kernel(
         reinterpret_cast<float4*>(raw_quats)[gid] = make_float4(pq[0], pq[1], pq[2], pq[3]);
         reinterpret_cast<float4*>(ad.m[2])[gid] = mq; reinterpret_cast<float4*>(ad.v[2])[gid] = vq4;
         raw_opacities[gid] = po; ad.m[3][gid] = mo; ad.v[3][gid] = vo;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The TAIL of the all-inline training step in ONE pass over the Gaussians (round 6): SH backward + Adam(sh0, shN) + finish + activation backward +
+// Adam(means, scales, quaternions, opacities) + - when the caller names the NEXT view - the SH colours of the next step. Replaces three launches of the one-call step
+// (sh_bwd_kernel<.., ADAM>, raster_finish_adam_kernel<true>, next step's sh_fwd_kernel):
+//   * dL/d(dirs) goes from the SH backward to the means update in registers (was: 12 B written + read per Gaussian);
+//   * the next view's colours are evaluated from the coefficient rows while they sit in registers for their Adam update (was: sh_fwd re-reads 192 B per Gaussian, 65 us);
+//   * the pass that follows the 1.1 GB read-modify-write of the SH Adam update no longer exists (finish_adam ran at 3.2 - 3.5 TB/s behind it, 5.9 alone: the dirty lines
+//     of the update were still draining - profiles/r06/stream_kernels_alone_1M.json).
+// One wavefront per 64 Gaussians, five phases (__syncthreads between them; LDS: basis rows, a second row block, the masked colour gradient):
+//   1  lane = Gaussian          : direction of THIS view, visibility, basis -> lds_b; dL/dcolour (accumulator slots 13..15) under the clamp mask -> ldv; the finish pass's
+//                                 operands are requested here and land under phase 2
+//   2  lane = (Gaussian, basis) : s_k = coefficient row . dL/dcolour -> lds_s (rows of Gaussians without a colour gradient are not fetched)
+//   3  lane = Gaussian          : dL/d(dirs) = sum_k s_k grad b_k; then exactly raster_finish_adam_kernel<true>'s arithmetic with it; the updated mean stays in registers
+//   4  lane = Gaussian          : direction of the NEXT view from the updated mean, its basis -> lds_s
+//   5  lane = (Gaussian, basis) : coefficient row + moments -> Adam -> stored; next colour = sum_k (new basis)_k x (updated row) -> colors (clamped as sh_fwd_kernel)
+// The SH arithmetic is pinned contraction-free (lfs_sh.cuh and the blocks below) as in sh.hip; the finish arithmetic is raster_finish_adam_kernel's, statement by statement:
+// parameters and moments come out bit-identical to the three kernels (tests/test_gpu_gut_step.py, tests/test_emulated_step_pack.py).
+struct GutTail {
+    uint32_t N, K; int degree;
+    float *means, *sh0, *shN, *raw_scales, *raw_quats, *raw_opacities;
+    const float *quats, *scales, *opacities;       // activated values (the projection kernel wrote them)
+    const float* viewmat; const float* next_viewmat;   // next_viewmat: NULL = no colours for the next step
+    const int32_t* radii; float* colors;             // in: this step's colours (clamp mask); out (next_viewmat given): the next step's, for EVERY Gaussian
+    const float* acc;
+    float *m0, *v0, *mN, *vN; AdamScalars s0, sN;    // sh0 / shN moments
+    FinishAdam fin;
+    const float* loss_slots; float* loss; const int32_t* abort_flag;
+};
+#ifndef LFS_TAIL_DEPTH
+#define LFS_TAIL_DEPTH 4   // coefficient rows (parameter + two moments) in flight per lane in phase 5
+#endif
+#ifndef LFS_TAIL_KEEP
+#define LFS_TAIL_KEEP 0    // 1: the coefficient rows phase 2 fetches stay in registers for phase 5 (same lane, same rows: 3 x LPG VGPRs; every row is then fetched in phase 2)
+#endif
+#ifndef LFS_TAIL_EARLY
+#define LFS_TAIL_EARLY 0   // 1: the first LFS_TAIL_DEPTH moment rows of phase 5 are requested in front of phase 3 (they land under the finish arithmetic)
+#endif
+#ifndef LFS_TAIL_NT
+#define LFS_TAIL_NT 0      // 1: the moments leave with non-temporal stores (nothing reads them for a whole step: they need not sit in the Infinity Cache)
+#endif
+template <int LPG, bool NEXT>
+__global__ void __launch_bounds__(64) gut_tail_kernel(const GutTail t, const CamDev* __restrict__ cams) {
+    __shared__ float lds_b[64 * (LPG + 1)];
+    __shared__ float lds_s[64 * (LPG + 1)];
+    __shared__ float ldv[64 * 3];
+    const uint32_t lane = threadIdx.x;
+    if (t.abort_flag != nullptr && *t.abort_flag != 0) return; // (uniform) speculative step that did not fit its buffers: no update, no loss - the host runs it again
+    if (t.loss_slots != nullptr && blockIdx.x == 0) { // *loss = the fused MSE: raster_finish_adam_kernel's fold (four wavefront sums of 64 slots, then (w0 + w1) + (w2 + w3))
+        float w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = t.loss_slots[64 * j + lane];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            w[j] = v;
+        }
+        if (lane == 0) *t.loss = (w[0] + w[1]) + (w[2] + w[3]);
+    }
+    const uint32_t N = t.N, K = t.K, KK = K - 1;
+    const int degree = t.degree, Kd = (degree + 1) * (degree + 1);
+    const uint32_t g0 = blockIdx.x * 64u, gmine = g0 + lane;
+    const bool live = gmine < N;
+    const uint32_t g = live ? gmine : (N - 1u);   // (tail lanes read the last row: no branch around the loads; they store nothing)
+    constexpr int GPI = 64 / LPG;
+    const int k = lane % LPG;
+    // ---- phase 1 ------------------------------------------------------------------------------------------------------------------------------------------
+    bool on = false;
+    f3 d{0.f, 0.f, 0.f};
+    float inorm = 1.f;
+    const float4* a4 = reinterpret_cast<const float4*>(t.acc + size_t(g) * ACC_STRIDE);
+    const float4 a3 = a4[3];
+    const f3 mu = ld3(t.means, g);
+    {
+#pragma clang fp contract(off)
+        const int2 rr = *reinterpret_cast<const int2*>(t.radii + 2 * size_t(g));
+        const f3 kc = ld3(t.colors, g);
+        const f3 cp = campos_of(t.viewmat);
+        float b[25];
+#pragma unroll
+        for (int kk = 0; kk < 25; ++kk) b[kk] = 0.f;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        on = live && rr.x > 0 && rr.y > 0;
+        if (on) {
+            d = {mu.x - cp.x, mu.y - cp.y, mu.z - cp.z};
+            if (degree >= 1) { inorm = 1.f / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z); d = {d.x * inorm, d.y * inorm, d.z * inorm}; }
+            sh_basis<false, (LPG > 16 ? 4 : 3)>(degree, d.x, d.y, d.z, b, nullptr, nullptr, nullptr);
+            v0 = (kc.x > 0.f) ? a3.y : 0.f; v1 = (kc.y > 0.f) ? a3.z : 0.f; v2 = (kc.z > 0.f) ? a3.w : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < LPG; ++kk) lds_b[lane * (LPG + 1) + kk] = (kk < 25) ? b[kk] : 0.f;
+        ldv[lane * 3] = v0; ldv[lane * 3 + 1] = v1; ldv[lane * 3 + 2] = v2;
+    }
+    // the finish pass's operands (raster_finish_adam_kernel, one round trip): in flight under phase 2
+    const uint32_t o4 = g << 2, o12 = g * 12u, o16 = g << 4;
+    auto at = [](const void* base, uint32_t byte_off) { return reinterpret_cast<const char*>(base) + byte_off; };
+    auto ld3o = [&](const float* base, float (&dst)[3]) { const V3f x = *reinterpret_cast<const V3f*>(at(base, o12)); dst[0] = x.a[0]; dst[1] = x.a[1]; dst[2] = x.a[2]; };
+    auto ld4o = [&](const float* base) { return *reinterpret_cast<const float4*>(at(base, o16)); };
+    auto ld1o = [&](const float* base) { return *reinterpret_cast<const float*>(at(base, o4)); };
+    const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2];
+    float sc[3], m0[3], v0m[3], p1[3], m1[3], v1[3];
+    ld3o(t.scales, sc);
+    const float4 q = ld4o(t.quats), rq = ld4o(t.raw_quats);
+    const float o = ld1o(t.opacities);
+    const FinishAdam& ad = t.fin;
+    ld3o(ad.m[0], m0); ld3o(ad.v[0], v0m); ld3o(t.raw_scales, p1); ld3o(ad.m[1], m1); ld3o(ad.v[1], v1);
+    float4 mq = ld4o(ad.m[2]), vq4 = ld4o(ad.v[2]);
+    float po = ld1o(t.raw_opacities), mo = ld1o(ad.m[3]), vo = ld1o(ad.v[3]);
+    __syncthreads();
+    // ---- phase 2: s_k ------------------------------------------------------------------------------------------------------------------------------------
+    const uint32_t lane_el = ((lane / LPG) * KK + uint32_t(k - 1)) * 3u;   // (k == 0 lanes never use it)
+    // phase 5's row addressing (the same lane meets the same rows in phase 2: LFS_TAIL_KEEP)
+    const bool row_k = uint32_t(k) < K;
+    float* const pbase = (k == 0) ? t.sh0 : t.shN;
+    float* const mbase = (k == 0) ? t.m0 : t.mN;
+    float* const vbase = (k == 0) ? t.v0 : t.vN;
+    auto row_el = [&](const int it) -> size_t {
+        const size_t gg = size_t(g0) + uint32_t(it) * GPI + lane / LPG;
+        return (k == 0) ? gg * 3 : (gg * KK + uint32_t(k - 1)) * 3;
+    };
+    auto row_ok = [&](const int it) { return row_k && (g0 + uint32_t(it) * GPI + lane / LPG) < N; };
+#if LFS_TAIL_KEEP
+    V3f PK[LPG];
+#pragma unroll
+    for (int it = 0; it < LPG; ++it) {
+        PK[it].a[0] = PK[it].a[1] = PK[it].a[2] = 0.f;
+        if (row_ok(it)) PK[it] = *reinterpret_cast<const V3f*>(pbase + row_el(it));
+    }
+#endif
+    {
+#pragma clang fp contract(off)
+#if LFS_TAIL_KEEP
+#pragma unroll
+#else
+#pragma unroll 4
+#endif
+        for (int it = 0; it < LPG; ++it) {
+            const uint32_t gl = it * GPI + lane / LPG;
+            const float w0 = ldv[gl * 3], w1 = ldv[gl * 3 + 1], w2 = ldv[gl * 3 + 2];
+            float sk = 0.f;
+            // a zero gradient gives 0 x (finite) = 0 whatever the row holds: its 12 bytes are not fetched (sh_pipe_dirs_kernel, sh.hip)
+            if (g0 + gl < N && k >= 1 && k < Kd && uint32_t(k) < K && (w0 != 0.f || w1 != 0.f || w2 != 0.f)) {
+#if LFS_TAIL_KEEP
+                const V3f p = PK[it];
+#else
+                const V3f p = *reinterpret_cast<const V3f*>(t.shN + size_t(g0 + uint32_t(it) * GPI) * KK * 3u + lane_el);
+#endif
+                sk = p.a[0] * w0 + p.a[1] * w1 + p.a[2] * w2;
+            }
+            lds_s[gl * (LPG + 1) + k] = sk;
+        }
+    }
+    // phase 5's moment rows: LFS_TAIL_DEPTH of them per lane in flight
+    constexpr int D = (LPG < LFS_TAIL_DEPTH) ? LPG : LFS_TAIL_DEPTH;
+#if !LFS_TAIL_KEEP
+    V3f P[D];
+#endif
+    V3f M[D], Q[D];
+    auto load = [&](const int it, const int slot) {
+#if !LFS_TAIL_KEEP
+        P[slot].a[0] = P[slot].a[1] = P[slot].a[2] = 0.f;
+#endif
+        if (row_ok(it)) {
+            const size_t e = row_el(it);
+#if !LFS_TAIL_KEEP
+            P[slot] = *reinterpret_cast<const V3f*>(pbase + e);
+#endif
+            M[slot] = *reinterpret_cast<const V3f*>(mbase + e); Q[slot] = *reinterpret_cast<const V3f*>(vbase + e);
+        }
+    };
+#if LFS_TAIL_EARLY
+#pragma unroll
+    for (int it = 0; it < D; ++it) load(it, it);
+#endif
+    __syncthreads();
+    // ---- phase 3: dL/d(dirs), then the finish pass ------------------------------------------------------------------------------------------------------------
+    float vd[3] = {0.f, 0.f, 0.f};
+    if (on && degree >= 1) {
+#pragma clang fp contract(off)
+        float b[25], bx[25], by[25], bz[25];
+        sh_basis<true, (LPG > 16 ? 4 : 3)>(degree, d.x, d.y, d.z, b, bx, by, bz);
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int kk = 1; kk < LPG && kk < 25; ++kk) {
+            const float sk = lds_s[lane * (LPG + 1) + kk];
+            gx += bx[kk] * sk; gy += by[kk] * sk; gz += bz[kk] * sk;
+        }
+        const float dd = gx * d.x + gy * d.y + gz * d.z;
+        vd[0] = (gx - dd * d.x) * inorm; vd[1] = (gy - dd * d.y) * inorm; vd[2] = (gz - dd * d.z) * inorm;
+    }
+    float pm[3] = {mu.x, mu.y, mu.z};   // the mean: updated below, read again by phase 4
+    {   // raster_finish_adam_kernel<true> from its "everything is in flight" line on, statement by statement
+        const float A[9] = {a0.x * REC_UNSCALE, a0.y * REC_UNSCALE, a0.z * REC_UNSCALE, a0.w * REC_UNSCALE, a1.x * REC_UNSCALE, a1.y * REC_UNSCALE, a1.z * REC_UNSCALE,
+                            a1.w * REC_UNSCALE, a2.x * REC_UNSCALE};
+        const f3 G{-a2.y * REC_UNSCALE, -a2.z * REC_UNSCALE, -a2.w * REC_UNSCALE};
+        bool any = G.x != 0.f || G.y != 0.f || G.z != 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) any |= A[kk] != 0.f;
+        const float v_opac = a3.x != 0.f ? a3.x / o : 0.f;
+        float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+        {
+            const float is[3] = {1.f / sc[0], 1.f / sc[1], 1.f / sc[2]};
+            finish_geometry<true>(q, is, A, G, mu, cams[0], vm, vq, vs);
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) { vm[kk] = any ? vm[kk] : 0.f; vs[kk] = any ? vs[kk] : 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) vq[kk] = any ? vq[kk] : 0.f;
+        }
+        {
+#pragma clang fp contract(off)
+            float gm[3] = {vm[0] + vd[0], vm[1] + vd[1], vm[2] + vd[2]};
+            const float nrm = sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
+            float gq[4];
+            if (nrm > 1e-12f) {
+                const float inv = 1.f / nrm;
+                const float y[4] = {rq.x * inv, rq.y * inv, rq.z * inv, rq.w * inv};
+                const float dq = vq[0] * y[0] + vq[1] * y[1] + vq[2] * y[2] + vq[3] * y[3];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) gq[kk] = (vq[kk] - dq * y[kk]) * inv;
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) gq[kk] = vq[kk] * 1e12f;
+            }
+            float gs[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) gs[kk] = (vs[kk] + ad.scale_reg) * sc[kk];
+            const float go = (v_opac + ad.opacity_reg) * o * (1.f - o);
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                adam_elem(pm[kk], m0[kk], v0m[kk], gm[kk], ad.s[0]);
+                adam_elem(p1[kk], m1[kk], v1[kk], gs[kk], ad.s[1]);
+            }
+            float pq[4] = {rq.x, rq.y, rq.z, rq.w};
+            adam_elem(pq[0], mq.x, vq4.x, gq[0], ad.s[2]); adam_elem(pq[1], mq.y, vq4.y, gq[1], ad.s[2]);
+            adam_elem(pq[2], mq.z, vq4.z, gq[2], ad.s[2]); adam_elem(pq[3], mq.w, vq4.w, gq[3], ad.s[2]);
+            adam_elem(po, mo, vo, go, ad.s[3]);
+            if (live) {
+                auto st3a = [&](float* base, const float (&src)[3]) { V3f x; x.a[0] = src[0]; x.a[1] = src[1]; x.a[2] = src[2]; *reinterpret_cast<V3f*>(const_cast<char*>(at(base, o12))) = x; };
+                st3a(t.means, pm); st3a(ad.m[0], m0); st3a(ad.v[0], v0m);
+                st3a(t.raw_scales, p1); st3a(ad.m[1], m1); st3a(ad.v[1], v1);
+                reinterpret_cast<float4*>(t.raw_quats)[gmine] = make_float4(pq[0], pq[1], pq[2], pq[3]);
+                reinterpret_cast<float4*>(ad.m[2])[gmine] = mq; reinterpret_cast<float4*>(ad.v[2])[gmine] = vq4;
+                t.raw_opacities[gmine] = po; ad.m[3][gmine] = mo; ad.v[3][gmine] = vo;
+            }
+        }
+    }
+    // ---- phase 4: the next view's basis (every Gaussian: its visibility there is not known yet) -> lds_s (this lane's own row: phase 3 has consumed it) -----------------
+    if (NEXT) {
+#pragma clang fp contract(off)
+        const f3 cp = campos_of(t.next_viewmat);
+        float b[25];
+#pragma unroll
+        for (int kk = 0; kk < 25; ++kk) b[kk] = 0.f;
+        if (live) {   // sh_fwd_kernel<LPG, true> with radii == NULL
+            f3 dn{pm[0] - cp.x, pm[1] - cp.y, pm[2] - cp.z};
+            if (degree >= 1) { const float inn = 1.f / sqrtf(dn.x * dn.x + dn.y * dn.y + dn.z * dn.z); dn = {dn.x * inn, dn.y * inn, dn.z * inn}; }
+            sh_basis<false, (LPG > 16 ? 4 : 3)>(degree, dn.x, dn.y, dn.z, b, nullptr, nullptr, nullptr);
+        }
+#pragma unroll
+        for (int kk = 0; kk < LPG; ++kk) lds_s[lane * (LPG + 1) + kk] = (kk < 25) ? b[kk] : 0.f;
+    }
+    __syncthreads();
+    // ---- phase 5: Adam on the coefficient rows (+ the next colours) ------------------------------------------------------------------------------------------------
+    {
+#pragma clang fp contract(off)
+        const AdamScalars as = (k == 0) ? t.s0 : t.sN;
+        auto st_mom = [&](float* q, const V3f& x) {
+#if LFS_TAIL_NT
+            __builtin_nontemporal_store(x.a[0], q); __builtin_nontemporal_store(x.a[1], q + 1); __builtin_nontemporal_store(x.a[2], q + 2);
+#else
+            *reinterpret_cast<V3f*>(q) = x;
+#endif
+        };
+#if !LFS_TAIL_EARLY
+#pragma unroll
+        for (int it = 0; it < D; ++it) load(it, it);
+#endif
+#if LFS_TAIL_KEEP
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+        for (int it0 = 0; it0 < LPG; it0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int it = it0 + u;
+                const uint32_t gl = it * GPI + lane / LPG;
+#if LFS_TAIL_KEEP
+                V3f p = PK[it];
+#else
+                V3f p = P[u];
+#endif
+                if (row_ok(it)) {
+                    const float bk = lds_b[gl * (LPG + 1) + k];
+                    const float o0 = bk * ldv[gl * 3], o1 = bk * ldv[gl * 3 + 1], o2 = bk * ldv[gl * 3 + 2];
+                    V3f m = M[u], qq = Q[u];
+                    adam_elem(p.a[0], m.a[0], qq.a[0], o0, as); adam_elem(p.a[1], m.a[1], qq.a[1], o1, as); adam_elem(p.a[2], m.a[2], qq.a[2], o2, as);
+                    const size_t e = row_el(it);
+                    *reinterpret_cast<V3f*>(pbase + e) = p; st_mom(mbase + e, m); st_mom(vbase + e, qq);
+                }
+                if (NEXT) {   // sh_fwd_kernel's phase 2 on the updated row (rows k >= Kd meet a zero basis value; lanes without a row contribute c = 0)
+                    const float bn = lds_s[gl * (LPG + 1) + k];
+                    const bool use = row_ok(it) && k < Kd;
+                    float r0 = bn * (use ? p.a[0] : 0.f), r1 = bn * (use ? p.a[1] : 0.f), r2 = bn * (use ? p.a[2] : 0.f);
+                    r0 = group_sum<LPG>(r0); r1 = group_sum<LPG>(r1); r2 = group_sum<LPG>(r2);
+                    if (k == 0 && g0 + gl < N) {
+                        float* co = t.colors + 3 * size_t(g0 + gl);
+                        co[0] = fmaxf(r0 + 0.5f, 0.f); co[1] = fmaxf(r1 + 0.5f, 0.f); co[2] = fmaxf(r2 + 0.5f, 0.f);
+                    }
+                }
+                if (it + D < LPG) load(it + D, u);
+            }
+        }
     }
 }
 
@@ -1423,6 +1739,44 @@ int lfs::gut_finish_adam_impl(
     lfs::ProfScope prof("finish_adam", s);
     hipLaunchKernelGGL(raster_finish_adam_kernel<true>, dim3((N + LFS_FINISH_BLOCK - 1) / LFS_FINISH_BLOCK), dim3(LFS_FINISH_BLOCK), 0, s, N, means, raw_scales, raw_quats, raw_opacities, quats, scales, opacities,
                        w.cams, w.acc, v_dirs, ad, FinishGrads{}, loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr, loss, abort_flag);
+    return (int)hipGetLastError();
+}
+
+// The fused tail of the all-inline step (gut_tail_kernel): SH backward + all six Adam updates (+ the next view's SH colours -> colors [N,3] when next_viewmat is given).
+// LFS_E_UNSUPPORTED for K > 16 (degree 4): the caller enqueues lfs_sh_model_bwd_adam_all + lfs_gut_finish_adam instead.
+int lfs::gut_tail_impl(
+    uint32_t N, uint32_t K, uint32_t degrees_to_use, float* means, float* sh0, float* shN, float* raw_scales, float* raw_quats, float* raw_opacities,
+    const float* quats, const float* scales, const float* opacities, const float* viewmat, const float* next_viewmat, const int32_t* radii, float* colors,
+    float* const* exp_avg /* [6] host, FusedAdam group order */, float* const* exp_avg_sq, const float (*scalars)[6], float scale_reg, float opacity_reg, float* loss,
+    void* workspace, size_t workspace_bytes, hipStream_t s, const int32_t* abort_flag) {
+    if (N == 0) return LFS_OK;
+    const uint32_t Kd = (degrees_to_use + 1) * (degrees_to_use + 1);
+    if (degrees_to_use > 3 || Kd > K || K < 2) return LFS_E_INVALID;
+    if (K > 16) return LFS_E_UNSUPPORTED;
+    if (!means || !sh0 || !shN || !raw_scales || !raw_quats || !raw_opacities || !quats || !scales || !opacities || !viewmat || !radii || !colors || !exp_avg || !exp_avg_sq ||
+        !scalars || !workspace) return LFS_E_INVALID;
+    for (int k = 0; k < 6; ++k) if (!exp_avg[k] || !exp_avg_sq[k]) return LFS_E_INVALID;
+    const RasterWs w = raster_ws(workspace, 1, N, 0, 0);
+    if (workspace_bytes < size_t(reinterpret_cast<const char*>(w.cull) - static_cast<const char*>(workspace))) return LFS_E_WORKSPACE;
+    GutTail t{};
+    t.N = N; t.K = K; t.degree = int(degrees_to_use);
+    t.means = means; t.sh0 = sh0; t.shN = shN; t.raw_scales = raw_scales; t.raw_quats = raw_quats; t.raw_opacities = raw_opacities;
+    t.quats = quats; t.scales = scales; t.opacities = opacities; t.viewmat = viewmat; t.next_viewmat = next_viewmat; t.radii = radii; t.colors = colors; t.acc = w.acc;
+    auto sc = [&](int k) { return AdamScalars{scalars[k][0], scalars[k][1], scalars[k][2], scalars[k][3], scalars[k][4], scalars[k][5]}; };
+    t.m0 = exp_avg[1]; t.v0 = exp_avg_sq[1]; t.s0 = sc(1);
+    t.mN = exp_avg[2]; t.vN = exp_avg_sq[2]; t.sN = sc(2);
+    const int grp[4] = {0, 3, 4, 5};   // raster_finish_adam_kernel's order: means, raw_scales, raw_quats, raw_opacities
+    for (int j = 0; j < 4; ++j) { t.fin.m[j] = exp_avg[grp[j]]; t.fin.v[j] = exp_avg_sq[grp[j]]; t.fin.s[j] = sc(grp[j]); }
+    t.fin.scale_reg = scale_reg / (3.f * float(N)); t.fin.opacity_reg = opacity_reg / float(N);   // (as gut_finish_adam_impl)
+    t.loss_slots = loss ? w.acc + ACC_STRIDE * size_t(N) : nullptr; t.loss = loss; t.abort_flag = abort_flag;
+    const dim3 grid((N + 63) / 64), block(64);
+    lfs::ProfScope prof("tail_sh_finish_adam", s);
+    const bool next = next_viewmat != nullptr;
+    if (K <= 4) {
+        if (next) hipLaunchKernelGGL((gut_tail_kernel<4, true>), grid, block, 0, s, t, w.cams); else hipLaunchKernelGGL((gut_tail_kernel<4, false>), grid, block, 0, s, t, w.cams);
+    } else {
+        if (next) hipLaunchKernelGGL((gut_tail_kernel<16, true>), grid, block, 0, s, t, w.cams); else hipLaunchKernelGGL((gut_tail_kernel<16, false>), grid, block, 0, s, t, w.cams);
+    }
     return (int)hipGetLastError();
 }
 

@@ -50,6 +50,9 @@ class GutStep:
         self.longest = 0
         self.wait_poll_s = 5.0    # how long _wait spins on the pinned counts before it falls back to a stream synchronisation
         self.retries = 0          # attempts that did not fit (each one is re-run): a few right after start-up or a densification, none in steady state
+        self.colors_for = None    # fused tail (lfs_gut_train_step_ex): what the workspace's SH colours were evaluated for by the previous step - (viewmat pointer, N, K,
+                                  # degree, workspace pointer) - or None; a step for exactly that skips its SH colour kernel
+        self.colour_launches_saved = 0
 
     # ---- workspace --------------------------------------------------------------------------------------------------------------------------
     def _ensure(self, N: int, W: int, H: int) -> None:
@@ -136,18 +139,42 @@ class GutStep:
     # ---- the step -------------------------------------------------------------------------------------------------------------------------------
     def train_step(self, params: Sequence[torch.Tensor], adam: Dict[str, dict], sh_degree: int, W: int, H: int, viewmat: torch.Tensor, Kmat: torch.Tensor,
                    bg: Optional[torch.Tensor], target_chw: torch.Tensor, weight: float, loss_acc: torch.Tensor, scale_reg: float = 0.0,
-                   opacity_reg: float = 0.0, pipelined: bool = False) -> int:
+                   opacity_reg: float = 0.0, pipelined: bool = False, fused_tail: bool = False, next_viewmat: Optional[torch.Tensor] = None) -> int:
         """Forward + backward + Adam on all six parameter tensors, in place; *loss_acc = weight * mse. `adam[name]` = FusedAdam.prepare_inline(param) for
         the six names of GROUPS. Returns n_isects.
         pipelined: lfs_gut_train_step_pipelined - the SH Adam pass of this step and the SH colours of the next run on the library's side stream, under the next step's
-        front end. Same results; sh0 / shN and their moments then belong to that stream until join() (every other method of this class joins by itself)."""
+        front end. Same results; sh0 / shN and their moments then belong to that stream until join() (every other method of this class joins by itself).
+        fused_tail: lfs_gut_train_step_ex - SH backward, the six Adam updates and (next_viewmat: the view the NEXT step renders, a tensor that stays untouched until then)
+        the next step's SH colours in one launch; a following step for exactly that view (same tensor, same N / K / degree / workspace) skips its SH colour kernel."""
         lib = load_library()
         N = params[0].shape[0]
+        K = 1 + params[2].shape[1]
         fn, what = (lib.lfs_gut_train_step_pipelined, "gut_train_step_pipelined") if pipelined else (lib.lfs_gut_train_step, "gut_train_step")
         for attempt in range(4):
             self._ensure(N, W, H)
             a = self._args(params, sh_degree, W, H, viewmat, Kmat, bg, target_chw, weight, scale_reg, opacity_reg, loss_acc, adam)
             self._stamp += 1
+            if fused_tail and not pipelined:
+                key = lambda vm: (vm.data_ptr(), N, K, sh_degree, self.ws.data_ptr(), params[0].data_ptr(), params[1].data_ptr(), params[2].data_ptr())   # (replaced parameter tensors void the colours too)
+                ready = self.colors_for is not None and self.colors_for == key(viewmat)
+                nxt = next_viewmat if (next_viewmat is not None and K <= 16) else None
+                self.colors_for = None   # (whatever happens below, the colours of THIS view are consumed / overwritten)
+                check(lib.lfs_gut_train_step_ex(C.byref(a), C.c_void_p(nxt.data_ptr()) if nxt is not None else None, C.c_int(int(ready)), C.c_int64(self.capacity),
+                                                C.c_int64(self.assumed_longest), C.c_void_p(self.ws.data_ptr()), C.c_size_t(self.ws.numel()),
+                                                C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), stream()), "gut_train_step_ex")
+                if self._wait():
+                    if nxt is not None:
+                        self.colors_for = key(nxt)
+                    self.colour_launches_saved += int(ready)
+                    self._after_fit()
+                    return self.n_isects
+                # the attempt did not fit: its tail returned without writing anything, so colours that were ready still are - unless _grow replaces the workspace below
+                if ready:
+                    self.colors_for = key(viewmat)
+                self.retries += 1
+                self._grow(self.n_isects, self.longest)
+                continue
+            self.colors_for = None
             check(fn(C.byref(a), C.c_int64(self.capacity), C.c_int64(self.assumed_longest), C.c_void_p(self.ws.data_ptr()),
                      C.c_size_t(self.ws.numel()), C.c_void_p(self.counts.data_ptr()), C.c_int64(self._stamp), stream()), what)
             if self._wait():
@@ -169,6 +196,7 @@ class GutStep:
         """Forward of one view into the workspace (render / alpha / radii via .view()); re-run on overflow. Returns n_isects."""
         lib = load_library()
         N = params[0].shape[0]
+        self.colors_for = None   # (this forward evaluates its own colours into the workspace)
         for attempt in range(4):
             self._ensure(N, W, H)
             a = self._args(params, sh_degree, W, H, viewmat, Kmat, bg, None, 0.0, 0.0, 0.0, None, None)

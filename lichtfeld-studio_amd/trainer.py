@@ -151,6 +151,8 @@ class GutTrainer:
         self.bucket = lfs_dist.GradBucket(self.model.parameters(), deferred=self._deferred()) if (world > 1 or fused_l2) else None  # 2 = shN
         self.loss_acc = torch.zeros(1, device=device)
         self.inline_all_adam = True   # one view / one rank / MSE: all six parameters are updated inside the backward kernels (fused.backward_adam_all)
+        self.fused_tail = True        # ... whose three per-Gaussian tail passes (SH backward + Adam, finish + Adam, next step's SH colours) are ONE launch (lfs_gut_train_step_ex)
+        self._next_view = None        #     the view the NEXT step renders, when the trainer knows it (round-robin schedule, or train_step(next_views=...))
         self.pipelined = False        # True: with its SH Adam pass / SH colours on the library's side stream, under the next step's front end (lfs_gut_train_step_pipelined)
         self.cxx_step = True          # ... and that step is ONE C++ call without a host read on the critical path (gut_step.GutStep -> csrc/gut_step.hip);
         self._gut_step = None         #     False: the same kernels enqueued call by call from Python (fused.py; tests compare the two)
@@ -314,7 +316,16 @@ class GutTrainer:
         sc = self.scene
         return Camera(sc.viewmats[view:view + 1].contiguous(), sc.Ks[view:view + 1].contiguous(), sc.width, sc.height)
 
-    def train_step(self, targets: List[torch.Tensor], views: Optional[List[int]] = None, views_all: Optional[List[List[int]]] = None) -> float:
+    def train_step(self, targets: List[torch.Tensor], views: Optional[List[int]] = None, views_all: Optional[List[List[int]]] = None,
+                   next_views: Optional[List[int]] = None) -> float:
+        """next_views: with an explicit `views`, the views the NEXT call will pass (a data loader knows them: src/training/dataloader.cpp prefetches) - the one-call step's
+        fused tail then evaluates their SH colours on the side. Without `views` the round-robin schedule names them."""
+        self._next_view = None
+        if self.world == 1 and self.views_per_rank == 1:
+            if views is None and views_all is None:
+                self._next_view = lfs_dist.views_for_step(self.iteration + 1, self.rank, self.world, self.scene.viewmats.shape[0], self.views_per_rank)[0]
+            elif next_views:
+                self._next_view = int(next_views[0])
         out = self._train_step(targets, views, views_all)
         # the SH schedule, AFTER the backward / optimizer step of the iteration, where the strategies keep it (post_backward: mcmc.cpp:366-368,
         # default_strategy.cpp) - iteration 1000, 2000, ... still renders with the old degree, as the reference does; without a strategy the trainer does it
@@ -344,6 +355,8 @@ class GutTrainer:
         plan = self.last_plan = self._plan(len(views))   # (kept for tests and tools: which form the step took)
         if plan.path != "cxx_all":
             self.join_pipeline()
+            if self._gut_step is not None:
+                self._gut_step.colors_for = None   # (another step form is about to change the parameters: colours a fused tail left for this step are void)
         if plan.path == "fastgs":
             return self._train_step_fastgs(targets, views, total_views)
         if plan.path == "autograd":
@@ -392,7 +405,8 @@ class GutTrainer:
         N = self.model.means.shape[0]
         self.last_n_isects = gs.train_step([p.detach() for p in self.model.parameters()], inline_all, self.model.get_active_sh_degree(), sc.width, sc.height,
                                            sc.viewmats[v], sc.Ks[v], self.bg, targets[0], 1.0 / total_views, self.loss_acc, self.scale_reg, self.opacity_reg,
-                                           pipelined=self.pipelined)
+                                           pipelined=self.pipelined, fused_tail=self.fused_tail,
+                                           next_viewmat=None if self._next_view is None else sc.viewmats[self._next_view])
         self._last_radii = gs.view("radii", torch.int32, (1, N, 2))
 
     def join_pipeline(self) -> None:

@@ -35,7 +35,11 @@ SELECTION = {
     # the benchmarked path: the whole training step as ONE C++ call (csrc/gut_step.hip: lfs_gut_train_step, speculative workspace, pinned counts) against the
     # Python-enqueued op sequence, bit for bit; its split forms against render_and_backward
     "test_gpu_gut_step": {"test_cxx_split_step_is_bit_identical_for_the_other_losses_and_mcmc": "40 s per variant (trainer steps with SSIM / bilateral grid / MCMC around the C++ calls)",
-                          "test_overflowing_attempt_updates_nothing_and_is_run_again": "20 - 130 s (the guarded attempt is covered by tests/test_emulated_step_pack.py)"},
+                          "test_overflowing_attempt_updates_nothing_and_is_run_again": "20 - 130 s (the guarded attempt is covered by tests/test_emulated_step_pack.py)",
+                          "test_fused_tail_step_is_bit_identical_to_the_three_pass_step[200000-3]": "twelve training steps on 200 000 Gaussians: minutes under emulation (three smaller cases are taken)",
+                          "test_pipelined_step_is_bit_identical_to_the_one_stream_step[200000-3]": "as above",
+                          "test_pipelined_step_is_bit_identical_to_the_one_stream_step[7000-2]": "a minute (the optional two-stream form: [65-3] and [3000-1] are taken; tests/test_emulated_step_pack.py holds it bit for bit on its own scenes)",
+                          "test_pipelined_step_float_atomics_stays_within_accumulation_noise": "two minutes (the optional two-stream form, float atomics: a GPU property)"},
     # one whole training image through the Python mirror (projection -> SH -> intersection -> rasterize -> loss -> backward) against the oracle's pipeline
     "test_gpu_pipeline": ["test_train_step_gradients_match_oracle", "test_render_modes_and_background_gradient"],
     # the fused front half / backward / finish / inline-Adam entry points against the op-by-op path, torch autograd and the oracle
@@ -72,8 +76,9 @@ def _without_cases(fn, dropped):
     new.__dict__.update(fn.__dict__)
     marks = []
     for m in getattr(fn, "pytestmark", []):
-        if m.name == "parametrize" and isinstance(m.args[0], str) and "," not in m.args[0]:
-            m = pytest.mark.parametrize(m.args[0], [v for v in m.args[1] if str(v) not in dropped], **m.kwargs).mark
+        if m.name == "parametrize" and isinstance(m.args[0], str):   # (several arguments: the case id is their values joined with "-", as pytest writes it)
+            case = (lambda v: "-".join(str(x) for x in v)) if "," in m.args[0] else str
+            m = pytest.mark.parametrize(m.args[0], [v for v in m.args[1] if case(v) not in dropped], **m.kwargs).mark
         marks.append(m)
     new.pytestmark = marks
     return new

@@ -125,7 +125,7 @@ def test_guarded_attempt_that_does_not_fit_reports_counts_and_renders_nothing(em
 # Streams are synchronous here, so this pins the DATA FLOW of the two-stream form - records packed without colours + the colour kernel writing their rgb slots, the SH
 # backward split into a direction pass and an Adam pass fed by 32-byte hand-over rows, the abort-flag snapshot - not its ordering (tests/test_gpu_gut_step.py does that
 # on the GPU, in the deterministic accumulation mode).
-def _train(lib, sc, W, H, tile, capacity, steps, pipelined, assumed_longest=1 << 20, shrink_on_step=None):
+def _train(lib, sc, W, H, tile, capacity, steps, pipelined, assumed_longest=1 << 20, shrink_on_step=None, tail=False):
     import importlib.util
     spec = importlib.util.spec_from_file_location("lfs_gut_step_defs", os.path.join(ROOT, "lichtfeld-studio_amd", "gut_step.py"))
     src = open(spec.origin).read()
@@ -143,10 +143,14 @@ def _train(lib, sc, W, H, tile, capacity, steps, pipelined, assumed_longest=1 <<
     rng = np.random.default_rng(11)
     target = rng.random((3, H, W)).astype(np.float32)
     vm, Km, bg = [np.ascontiguousarray(sc[k], np.float32) for k in ("vm", "K", "bg")]
+    from gpu_util import small_rotation_viewmat
+    vms = [vm, np.ascontiguousarray(small_rotation_viewmat(np.random.default_rng(77), 0.2, 0.3), np.float32), vm]   # the views take turns: 0, 1, 2 (= 0 again), 0, ...
     loss = np.zeros(1, np.float32)
     losses, fitted = [], []
     fn = lib.lfs_gut_train_step_pipelined if pipelined else lib.lfs_gut_train_step
+    colours_ready = False
     for it in range(steps):
+        vm = vms[it % 3]
         a = StepArgs()
         a.N, a.K, a.sh_degree, a.image_width, a.image_height, a.tile_size = N, sc["Kn"], sc["degree"], W, H, tile
         a.means, a.sh0, a.shN, a.raw_scales, a.raw_quats, a.raw_opacities = [p.ctypes.data for p in params]
@@ -159,10 +163,17 @@ def _train(lib, sc, W, H, tile, capacity, steps, pipelined, assumed_longest=1 <<
         a.loss_weight, a.scale_reg, a.opacity_reg, a.loss = 1.0, 0.01, 0.01, loss.ctypes.data
         counts = np.zeros(3, np.int64)
         cap = capacity if shrink_on_step != it else 8          # an attempt that cannot fit: nothing may be updated by it
-        rc = fn(C.byref(a), C.c_int64(cap), C.c_int64(assumed_longest), C.c_void_p(ws.ctypes.data), C.c_size_t(int(lay.bytes)), C.c_void_p(counts.ctypes.data),
-                C.c_int64(it + 1), None)
+        if tail:   # lfs_gut_train_step_ex: the fused tail, with the next view named on every step but the last
+            nxt = vms[(it + 1) % 3] if it + 1 < steps else None
+            rc = lib.lfs_gut_train_step_ex(C.byref(a), C.c_void_p(nxt.ctypes.data) if nxt is not None else None, C.c_int(int(colours_ready)), C.c_int64(cap),
+                                           C.c_int64(assumed_longest), C.c_void_p(ws.ctypes.data), C.c_size_t(int(lay.bytes)), C.c_void_p(counts.ctypes.data), C.c_int64(it + 1), None)
+        else:
+            rc = fn(C.byref(a), C.c_int64(cap), C.c_int64(assumed_longest), C.c_void_p(ws.ctypes.data), C.c_size_t(int(lay.bytes)), C.c_void_p(counts.ctypes.data),
+                    C.c_int64(it + 1), None)
         assert rc == 0, rc
         fitted.append(bool(lib.lfs_gut_step_fits(C.c_int64(int(counts[0])), C.c_int64(int(counts[1])), C.c_int64(cap), C.c_int64(assumed_longest))))
+        if tail:   # (an attempt that did not fit wrote no colours; what was ready before it still is - the NEXT call in this helper renders another view, though)
+            colours_ready = fitted[-1] and it + 1 < steps
         losses.append(float(loss[0]))
     assert lib.lfs_gut_pipeline_join(None) in (0, 1)
     return dict(params=params, m=m, v=v, losses=losses, fitted=fitted)
@@ -199,3 +210,34 @@ def test_pipelined_attempt_that_does_not_fit_updates_nothing(emu):
     for k in range(6):
         assert np.array_equal(one["params"][k], two["params"][k]) and np.array_equal(one["m"][k], two["m"][k]) and np.array_equal(one["v"][k], two["v"][k]), k
     assert ref["fitted"] == [True, True]
+
+
+# ---- round 6: the fused tail (lfs_gut_train_step_ex: SH backward + six Adam updates + the next view's SH colours in one launch) ----------------------------------------
+@pytest.mark.parametrize("case,K,degree", [("syn_a_like", 16, 3), ("large_gaussians", 16, 2), ("tile_8_ragged", 4, 1)])
+def test_fused_tail_step_matches_the_three_pass_step_bit_for_bit(emu, case, K, degree):
+    """Three views in turn, 4 steps: every step after the first renders with the colours the previous step's tail evaluated for it (colors_ready), from the coefficient
+    rows in registers and the mean it had just updated - parameters, moments and losses must be those of lfs_gut_train_step."""
+    N, W, H, tile, smin, smax, spread = CASES[case]
+    N = min(N, 600)
+    sc = _scene(9 + sum(map(ord, case)), N, W, H, smin, smax, spread, K=K, degree=degree)
+    ref = _train(emu, sc, W, H, tile, 64 * N, 4, pipelined=False)
+    new = _train(emu, sc, W, H, tile, 64 * N, 4, pipelined=False, tail=True)
+    assert all(ref["fitted"]) and all(new["fitted"]) and ref["losses"][0] > 0
+    assert ref["losses"] == new["losses"]
+    moved = 0
+    for k in range(6):
+        assert np.array_equal(ref["params"][k], new["params"][k]), k
+        assert np.array_equal(ref["m"][k], new["m"][k]) and np.array_equal(ref["v"][k], new["v"][k]), k
+        moved += int((ref["m"][k] != 0).sum())
+    assert moved > 100, "no gradient reached the parameters"
+
+
+def test_fused_tail_attempt_that_does_not_fit_updates_nothing(emu):
+    N, W, H, tile, smin, smax, spread = CASES["syn_a_like"]
+    N = 500
+    sc = _scene(21, N, W, H, smin, smax, spread, K=16, degree=3)
+    one = _train(emu, sc, W, H, tile, 64 * N, 1, pipelined=False, tail=True)
+    two = _train(emu, sc, W, H, tile, 64 * N, 2, pipelined=False, tail=True, shrink_on_step=1)
+    assert two["fitted"] == [True, False]
+    for k in range(6):
+        assert np.array_equal(one["params"][k], two["params"][k]) and np.array_equal(one["m"][k], two["m"][k]) and np.array_equal(one["v"][k], two["v"][k]), k

@@ -288,3 +288,64 @@ def test_pipelined_step_float_atomics_stays_within_accumulation_noise(lfs):
     torch.cuda.synchronize()
     for name, pa, pb in zip(NAMES, a.model.parameters(), b.model.parameters()):
         assert rel_l2(n(pa), n(pb)) < 2e-4, (name, rel_l2(n(pa), n(pb)))
+
+
+# ---- round 6: lfs_gut_train_step_ex (fused tail: SH backward + six Adam updates + the next view's SH colours in one launch) against lfs_gut_train_step -----------------
+@pytest.mark.parametrize("n_gauss,degree", [(7000, 2), (200000, 3), (65, 3), (3000, 1)])
+def test_fused_tail_step_is_bit_identical_to_the_three_pass_step(lfs, n_gauss, degree):
+    """Round-robin view schedule (the trainer then knows the next view and the tail evaluates its colours: every step but the first skips its SH colour kernel), six steps,
+    deterministic rasterizer sums: parameters and moments bit for bit."""
+    from lichtfeld_studio_amd import scenes
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    sc = scenes._syn_box("SYN-T", 7, n_gauss, 320, 192, 260.0, 5, sh_degree=degree)   # five orbit cameras: consecutive steps render different views
+    g = torch.Generator().manual_seed(5)
+    targets = [torch.rand(3, sc.height, sc.width, generator=g).to(DEV) * 0.7]
+    lib = lfs.load_library()
+    try:
+        lib.lfs_set_debug_flags(16)
+        a, b = GutTrainer(sc, DEV, iterations=7000), GutTrainer(sc, DEV, iterations=7000)
+        a.fused_tail, b.fused_tail = True, False
+        a.iteration = b.iteration = 1500
+        for it in range(6):
+            la, lb = a.train_step(targets), b.train_step(targets)
+        torch.cuda.synchronize()
+    finally:
+        lib.lfs_set_debug_flags(0)
+    assert a.last_plan.path == b.last_plan.path == "cxx_all"
+    assert a._gut_step.colour_launches_saved == 5 and b._gut_step.colour_launches_saved == 0
+    noise_check("fused tail vs three passes loss value", abs(float(la) - float(lb)), 1e-5 * float(lb))
+    assert a.last_n_isects == b.last_n_isects > 0
+    _same_state(a, b, 6)
+
+
+def test_fused_tail_colours_are_dropped_when_the_next_step_is_another_one(lfs):
+    """The tail evaluated colours for the scheduled view; the caller then renders a DIFFERENT view, raises the SH degree, or runs another step form in between: the
+    workspace's colours must not be used (GutStep's book), and the results stay those of the three-pass step."""
+    from lichtfeld_studio_amd import scenes
+    from lichtfeld_studio_amd.trainer import GutTrainer
+    sc = scenes._syn_box("SYN-T", 8, 5000, 320, 192, 260.0, 5, sh_degree=3)
+    target = torch.rand(3, sc.height, sc.width, generator=torch.Generator().manual_seed(8)).to(DEV) * 0.7
+    nv = sc.viewmats.shape[0]
+    lib = lfs.load_library()
+    try:
+        lib.lfs_set_debug_flags(16)
+        a, b = GutTrainer(sc, DEV, iterations=7000), GutTrainer(sc, DEV, iterations=7000)
+        a.fused_tail, b.fused_tail = True, False
+        a.iteration = b.iteration = 1997   # the SH degree rises after iteration 2000 (sh_degree_interval 1000): colours evaluated at the old degree are void
+        a.model.active_sh_degree = b.model.active_sh_degree = 2
+        for it in range(7):
+            if it == 4:      # an explicit view that is not the scheduled one, announced by nobody
+                kw = dict(views=[(it + 3) % nv])
+            elif it == 5:    # explicit view + announcement of the next
+                kw = dict(views=[1 % nv], next_views=[2 % nv])
+            elif it == 6:
+                kw = dict(views=[2 % nv])
+            else:
+                kw = {}
+            la, lb = a.train_step([target], **kw), b.train_step([target], **kw)
+        torch.cuda.synchronize()
+    finally:
+        lib.lfs_set_debug_flags(0)
+    assert a.model.active_sh_degree == 3
+    assert 1 <= a._gut_step.colour_launches_saved <= 4
+    _same_state(a, b, 7)
