@@ -166,8 +166,7 @@ LFS_API size_t lfs_rasterize_workspace_bytes(uint32_t C, uint32_t N, uint32_t ch
  *      bit 4 = deterministic backward accumulation (two passes, 64-bit fixed point: run-to-run bit-identical gradients; lfs_rasterize_workspace_bytes grows while it is set);
  *      bit 5 = the one-pass intersection scatter even when a scratch array is given; bit 6 = the training step packs the rasterizer's records with the separate
  *      raster_pack pass of rounds 1 - 3 instead of inside the projection kernel (A/B, tests/test_emulated_step_pack.py); bit 7: unused (round 6: the projection kernel clearing the
- *      backward's accumulator rows instead of the memset - measured slower, removed); bit 8 = lfs_intersect_tile_count* runs its count and scan as two launches
- *      (rounds 1 - 5) instead of the scan in the count kernel's last workgroup (A/B, tests/test_gpu_intersect.py). */
+ *      backward's accumulator rows instead of the memset - measured slower, removed). */
 LFS_API void lfs_set_debug_flags(uint32_t flags);
 LFS_API uint32_t lfs_get_debug_flags(void);
 LFS_API int lfs_rasterize_to_pixels_from_world_3dgs_fwd(

@@ -139,7 +139,7 @@ int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacit
         // stream, behind the previous step's SH Adam kernel, into `colors` and into the rgb slots of the records; the main stream carries on with the tile lists and
         // waits for them in front of the forward kernel.
         rc = activations_project_ut_impl(N, a->means, a->raw_quats, a->raw_scales, a->raw_opacities, &cams, 0.3f, 0.01f, 10000.f, 0.f, &ut, w.quats, w.scales,
-                                         w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th + 1u /* + the count kernel's ticket counter */, w.raster_ws, s, recs, cull, nullptr);
+                                         w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th, w.raster_ws, s, recs, cull, nullptr);
         if (rc) return rc;
         hipError_t e = hipEventRecord(pipe->projected, s);
         if (e == hipSuccess) e = hipStreamWaitEvent(pipe->side, pipe->projected, 0);
@@ -165,7 +165,7 @@ int enqueue_forward(const lfs_gut_step_args* a, const StepWs& w, int64_t capacit
         if (rc) return rc;
     }
     rc = activations_project_ut_impl(N, a->means, a->raw_quats, a->raw_scales, a->raw_opacities, &cams, 0.3f, 0.01f, 10000.f, 0.f, &ut, w.quats, w.scales,
-                                     w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th + 1u /* + the count kernel's ticket counter */, w.raster_ws, s,
+                                     w.opacities, w.radii, w.means2d, w.depths, isect_workspace_totals(w.isect_ws, 1, N, tw, th), tw * th, w.raster_ws, s,
                                      pack_here ? recs : nullptr, pack_here ? cull : nullptr, pack_here ? w.colors : nullptr);
     if (rc) return rc;
     const IsectGuard guard{capacity, assumed_longest, w.abort_flag};

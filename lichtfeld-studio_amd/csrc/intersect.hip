@@ -62,8 +62,7 @@ __global__ void __launch_bounds__(1024) isect_count_kernel(
     const uint32_t C, const uint32_t N, const uint32_t per_block,
     const float* __restrict__ means2d, const int32_t* __restrict__ radii,
     const float tile_size_f, const uint32_t tw, const uint32_t th,
-    int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ totals,
-    uint32_t* __restrict__ done = nullptr, const TileScanArgs scan = TileScanArgs{}) {
+    int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ totals) {
     LFS_DYN_LDS(uint32_t, hist);
     const uint32_t T = C * tw * th, n_tiles = tw * th;
     if (LDS_HIST) {
@@ -94,19 +93,6 @@ __global__ void __launch_bounds__(1024) isect_count_kernel(
             if (c) atomicAdd(&totals[t], c);
         }
     }
-    // Round 6: the exclusive scan of the totals as the tail of the workgroup that finishes LAST (was: tile_scan_kernel, a launch of one workgroup: 8 us plus the gap
-    // in front of it). Every workgroup releases its atomics and takes a ticket; the holder of the last ticket sees all of them (device-scope fences either side of the
-    // ticket) and reads the totals past its vector cache (tile_scan_body<true>). *done is zero on entry (it sits behind totals[T] and is cleared with them) and is left zero.
-    if (done == nullptr) return;
-    __shared__ uint32_t s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(done, 1u) == gridDim.x - 1u) ? 1u : 0u;
-    __syncthreads();
-    if (s_last == 0u) return;
-    __threadfence();
-    if (threadIdx.x == 0) *done = 0u;
-    tile_scan_body<true>(scan);
 }
 
 // ---------------------------------------------------------------------------
@@ -438,7 +424,7 @@ static IsectWs isect_ws(void* base, uint32_t C, uint32_t N, uint32_t tw, uint32_
     const size_t T = size_t(C) * tw * th;
     const size_t nb = (size_t(C) * N + SCAN_ITEMS - 1) / SCAN_ITEMS + 1;
     IsectWs w; char* p = (char*)base; size_t o = 0;
-    w.totals = (uint32_t*)(p + o); o += align256((T + 1) * 4);   // [T] + the count kernel's ticket counter (zeroed and left zero together with the totals)
+    w.totals = (uint32_t*)(p + o); o += align256(T * 4);
     w.cursor = (uint32_t*)(p + o); o += align256(T * 4);
     w.row_cursor = (uint32_t*)(p + o); o += align256(size_t(C) * th * 4);
     w.offsets = (int32_t*)(p + o); o += align256((T + 1) * 4);
@@ -475,31 +461,33 @@ int lfs::isect_count_impl(
     // the scan kernel leaves totals[] zero again and zeroes both cursors itself: a caller that OWNS the workspace and passes the one of its previous call
     // (same C, N, tile grid) may set LFS_ISECT_COUNTERS_ZERO and save the memset (nothing in this repository does any more: 32 KB, ~2 us)
     if (!(flags & LFS_ISECT_COUNTERS_ZERO)) {
-        hipError_t e = hipMemsetAsync(w.totals, 0, (size_t(T) + 1) * 4, s);   // (+ the ticket counter behind the totals)
+        hipError_t e = hipMemsetAsync(w.totals, 0, size_t(T) * 4, s);
         if (e != hipSuccess) return (int)e;
     }
     const size_t total = size_t(C) * N;
+    // Round 6, measured and removed (profiles/r06/lease16_count_scan_tail_ab.txt): the scan as the tail of the count kernel's LAST workgroup (ticket counter behind a
+    // device-scope fence, totals read with device-scope atomic loads) - count + scan 0.031 -> 0.140 ms. A device-scope release on this part writes the L2 of the XCD
+    // back (the eight L2s are not coherent with each other), and every one of the 512 workgroups paid for it behind the projection kernel's 200 MB of dirty lines:
+    // "last workgroup finishes the job" is not a pattern for an eight-XCD device; the second launch (8 us + gap) stays.
     lfs::ProfScope prof("isect_count_scan", s);
-    if (guard != nullptr && (guard->capacity < 0 || !guard->abort_flag)) return LFS_E_INVALID;
-    const TileScanArgs scan{T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets, max_tile_isects, stamp_out, stamp,
-                            guard ? guard->capacity : -1, guard ? sort_class_limit(guard->assumed_longest) : 0xFFFFFFFFu, guard ? guard->abort_flag : nullptr};
-    // debug bit 8: count and scan as two launches, as before round 6 (A/B, tests)
-    const bool fused = total > 0 && !(lfs_get_debug_flags() & 256u);
     if (total > 0) {
         if (!means2d || !radii || !tiles_per_gauss) return LFS_E_INVALID;
         const uint32_t pb = isect_per_block(total);
         const uint32_t blocks = uint32_t((total + pb - 1) / pb);
-        uint32_t* const done = fused ? w.totals + T : nullptr;
         if (size_t(T) * 8 <= LDS_HIST_LIMIT)
             hipLaunchKernelGGL(isect_count_kernel<true>, dim3(blocks), dim3(1024), T * 4, s, C, N, pb, means2d, radii,
-                               float(tile_size), tile_width, tile_height, tiles_per_gauss, w.totals, done, scan);
+                               float(tile_size), tile_width, tile_height, tiles_per_gauss, w.totals);
         else
             hipLaunchKernelGGL(isect_count_kernel<false>, dim3(blocks), dim3(1024), 0, s, C, N, pb, means2d, radii,
-                               float(tile_size), tile_width, tile_height, tiles_per_gauss, w.totals, done, scan);
+                               float(tile_size), tile_width, tile_height, tiles_per_gauss, w.totals);
     }
-    if (!fused)
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, scan.T, scan.totals, scan.offsets, scan.n_isects, scan.zero_totals, scan.cursor, scan.aux, scan.n_aux,
-                           scan.offsets_out, scan.max_total, scan.stamp_out, scan.stamp, scan.capacity, scan.max_list, scan.abort_flag);
+    if (guard != nullptr) {
+        if (guard->capacity < 0 || !guard->abort_flag) return LFS_E_INVALID;
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets,
+                           max_tile_isects, stamp_out, stamp, guard->capacity, sort_class_limit(guard->assumed_longest), guard->abort_flag);
+    } else
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, w.totals, w.offsets, n_isects, true, w.cursor, w.row_cursor, C * tile_height, tile_offsets,
+                           max_tile_isects, stamp_out, stamp);
     return (int)hipGetLastError();
 }
 

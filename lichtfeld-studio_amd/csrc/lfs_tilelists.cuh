@@ -13,14 +13,11 @@ namespace lfs {
 // zero_totals: totals[] is left zero for the next call (zero-on-consume: the caller may then skip its memset); cursor / aux (nullable) are zeroed for
 // the scatter kernels of THIS call; offsets_out (nullable, [T]) receives a second copy of the offsets (the caller's tile_offsets tensor); max_total
 // (nullable) the longest tile list (the caller skips the sort launches of the size classes no tile falls into)
-// COHERENT (round 6: the scan as the tail of the count kernel's LAST workgroup, intersect.hip): totals[] has just been written by device-scope atomics of other
-// workgroups of the SAME launch - read with device-scope atomic loads (no line of it may come from this CU's vector cache).
-template <bool COHERENT>
-LFS_DI void tile_scan_body(
+static __global__ void __launch_bounds__(1024) tile_scan_kernel(
     const uint32_t T, uint32_t* __restrict__ totals, int32_t* __restrict__ offsets, int64_t* __restrict__ n_isects,
-    const bool zero_totals, uint32_t* __restrict__ cursor, uint32_t* __restrict__ aux, const uint32_t n_aux,
-    int32_t* __restrict__ offsets_out, int64_t* __restrict__ max_total, int64_t* __restrict__ stamp_out, const int64_t stamp,
-    const int64_t capacity, const uint32_t max_list, int32_t* __restrict__ abort_flag) {
+    const bool zero_totals = false, uint32_t* __restrict__ cursor = nullptr, uint32_t* __restrict__ aux = nullptr, const uint32_t n_aux = 0,
+    int32_t* __restrict__ offsets_out = nullptr, int64_t* __restrict__ max_total = nullptr, int64_t* __restrict__ stamp_out = nullptr, const int64_t stamp = 0,
+    const int64_t capacity = -1, const uint32_t max_list = 0xFFFFFFFFu, int32_t* __restrict__ abort_flag = nullptr) {
     // capacity >= 0 (the speculative training step, csrc/gut_step.hip): the caller sized its list buffers for `capacity` intersections and launched the
     // per-tile sort classes up to `max_list` entries BEFORE these counts existed. When either assumption fails, *abort_flag = 1, every offset is
     // rewritten to 0 (all lists empty: nothing downstream indexes past its buffers) and the true counts are still reported - the host sees them after
@@ -38,10 +35,7 @@ LFS_DI void tile_scan_body(
     for (uint32_t base = 0; base < T; base += SLICE) {
         const uint32_t n = min(SLICE, T - base);
 #pragma unroll
-        for (uint32_t k = 0; k < PER; ++k) {
-            const uint32_t i = threadIdx.x + k * 1024;
-            vals[i] = i < n ? (COHERENT ? __hip_atomic_load(totals + base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : totals[base + i]) : 0u;
-        }
+        for (uint32_t k = 0; k < PER; ++k) { const uint32_t i = threadIdx.x + k * 1024; vals[i] = i < n ? totals[base + i] : 0u; }
         __syncthreads();
         uint32_t v[PER]; uint32_t local = 0;
 #pragma unroll
@@ -92,25 +86,6 @@ LFS_DI void tile_scan_body(
             *reinterpret_cast<volatile int64_t*>(stamp_out) = stamp;
         }
     }
-}
-
-// what the scan needs, as one kernel argument (the count kernel of intersect.hip carries it for its last workgroup)
-struct TileScanArgs {
-    uint32_t T; uint32_t* totals; int32_t* offsets; int64_t* n_isects; bool zero_totals; uint32_t* cursor; uint32_t* aux; uint32_t n_aux;
-    int32_t* offsets_out; int64_t* max_total; int64_t* stamp_out; int64_t stamp; int64_t capacity; uint32_t max_list; int32_t* abort_flag;
-};
-template <bool COHERENT>
-LFS_DI void tile_scan_body(const TileScanArgs& a) {
-    tile_scan_body<COHERENT>(a.T, a.totals, a.offsets, a.n_isects, a.zero_totals, a.cursor, a.aux, a.n_aux, a.offsets_out, a.max_total, a.stamp_out, a.stamp, a.capacity,
-                             a.max_list, a.abort_flag);
-}
-
-static __global__ void __launch_bounds__(1024) tile_scan_kernel(
-    const uint32_t T, uint32_t* __restrict__ totals, int32_t* __restrict__ offsets, int64_t* __restrict__ n_isects,
-    const bool zero_totals = false, uint32_t* __restrict__ cursor = nullptr, uint32_t* __restrict__ aux = nullptr, const uint32_t n_aux = 0,
-    int32_t* __restrict__ offsets_out = nullptr, int64_t* __restrict__ max_total = nullptr, int64_t* __restrict__ stamp_out = nullptr, const int64_t stamp = 0,
-    const int64_t capacity = -1, const uint32_t max_list = 0xFFFFFFFFu, int32_t* __restrict__ abort_flag = nullptr) {
-    tile_scan_body<false>(T, totals, offsets, n_isects, zero_totals, cursor, aux, n_aux, offsets_out, max_total, stamp_out, stamp, capacity, max_list, abort_flag);
 }
 
 // Ascending bitonic network over n_pad (power of two) 64-bit keys in LDS; all THREADS threads of the workgroup call it.

@@ -49,6 +49,9 @@
 #if LFS_SEL_E64 && !LFS_REC_LOG2
 #error "LFS_SEL_E64 is written for the LFS_REC_LOG2 records"
 #endif
+#ifndef LFS_FWD_MARK
+#define LFS_FWD_MARK 0   // 1: the forward marks the cell-list entries nothing composited and the backward skips them. Measured (round 6, profiles/r06/lease18_fwd_marks_projfast_ab.txt,
+#endif                   // same box, 4 x 200 steps): raster_fwd 0.233 -> 0.256 ms, raster_bwd 0.4856 -> 0.4845 ms, 734 -> 722 img/s: off.
 #ifndef LFS_FINISH_LDS_ROWS
 #define LFS_FINISH_LDS_ROWS 1 // (round 3, same box: finish_adam 0.106 / 0.102 -> 0.102 / 0.097 ms; 0 = four 16-byte loads per lane at a 64-byte stride)
 #endif
@@ -308,7 +311,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     const CamDev* __restrict__ cams, const GaussRec* __restrict__ recs, const float* __restrict__ colors,
     const float* __restrict__ backgrounds, const uint8_t* __restrict__ masks,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ cell_count, const int2* __restrict__ cell_list, const int32_t n_isects,
-    float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids) {
+    float* __restrict__ render_colors, float* __restrict__ render_alphas, int32_t* __restrict__ last_ids, int32_t* __restrict__ cell_marks) {
     const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
     if (!cc.in_grid) return;
@@ -341,6 +344,20 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     const int32_t end = (cc.tile_global == total_tiles - 1 && n_isects >= 0) ? n_isects : offsets[cc.tile_global + 1]; // n_isects < 0: offsets has T + 1 entries (guarded step)
     const int2* __restrict__ cl = cell_list + (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
     const int32_t cnt = cell_count[size_t(cc.tile_global) * wpt + cc.wl];
+#if LFS_FWD_MARK
+    // Round 6: an entry whose alpha stays below 1/255 on every live ray of this cell (the culling in front is conservative) cannot pass the backward's test either (a lane valid there composited here: e.y <= its last contributor and alpha >= 1/255, the same
+    // bits). The forward says so in the list itself - the sign bit of the entry's Gaussian index, one 4-byte store by one lane - and the backward skips the entry before
+    // it evaluates anything (14 % of its evaluations on the dense SYN-B window of profiles/r05/quarter_histogram.txt: 31 VALU instructions each). The record address of
+    // a marked entry is unchanged: the walker forms it as uint32(index) << 6 and the bit falls off the top. Entries the forward never reaches lie behind the last
+    // contributor, where the backward does not walk.
+    // cell_marks IS the cell list (host: the same pointer), handed over as a second __restrict__ argument: a store through cell_list itself makes the list "written in
+    // this kernel" for the compiler, and the walker's entry loads stop being scalar loads (measured: raster_fwd 0.238 -> 0.399 ms). A position is never read again
+    // once it is marked (the walker runs ahead of the evaluation), so the two views of the memory never meet.
+    int32_t* const cl_mark = cell_marks + 2 * (size_t(wpt) * size_t(start) + size_t(cc.wl) * size_t(end - start));
+    const bool marker = (threadIdx.x & 63u) == 0u;
+    int32_t pos = 0;   // (uniform) the evaluations run over positions 0, 1, 2, ... of the list
+    auto mark = [&](const int32_t p, const int32_t g) { if (marker) cl_mark[2 * p] = g | int32_t(0x80000000u); };
+#endif
 
     float T = 1.f;
     float pix[CDIM];
@@ -357,7 +374,12 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
         // lane-mask form (lfs_raster_common.cuh): the same compares and selects, no VCC / EXEC round trips. A lane that does not composite adds fma(c, 0, pix) = pix.
         const lmask_t pass = mask_nlt_f32(alpha, thr); // live pixel and alpha >= 1/255 (a NaN alpha passes, as in the reference's `if (alpha < 1/255) continue`)
         LFS_EMUL_COUNT(0);
+#if LFS_FWD_MARK
+        const int32_t my_pos = pos; pos += 1;
+        if (pass == 0ull) { mark(my_pos, e.x); return; }
+#else
         if (pass == 0ull) return;
+#endif
         LFS_EMUL_COUNT(1);
         const float next_T = T * (1.f - alpha);
         const lmask_t fin = pass & mask_le_f32(next_T, 1e-4f); // the terminating Gaussian is not composited
@@ -378,7 +400,12 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 #else
         const bool pass = !(alpha < thr); // live pixel and alpha >= 1/255 (a NaN alpha passes, as in the reference's `if (alpha < 1/255) continue`)
         LFS_EMUL_COUNT(0);
+#if LFS_FWD_MARK
+        const int32_t my_pos = pos; pos += 1;
+        if (__ballot(pass) == 0ull) { mark(my_pos, e.x); return; }
+#else
         if (__ballot(pass) == 0ull) return;
+#endif
         LFS_EMUL_COUNT(1);
         const float next_T = T * (1.f - alpha);
         const bool fin = pass && next_T <= 1e-4f; // the terminating Gaussian is not composited
@@ -521,6 +548,9 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     if (n_walk <= 0) return;
 
     auto eval = [&](const GaussRec& rec, const int2 e) {
+#if LFS_FWD_MARK
+        if (e.x < 0) return;   // (uniform) marked by the forward: no pixel of this cell composited the entry - nothing to accumulate (see raster_fwd_kernel)
+#endif
         RayEval re;
         ray_eval<MODE>(rec, ro, rd, re);
 #if LFS_BWD_REORTH
@@ -1044,14 +1074,20 @@ struct GutTail {
 #ifndef LFS_TAIL_DEPTH
 #define LFS_TAIL_DEPTH 4   // coefficient rows (parameter + two moments) in flight per lane in phase 5
 #endif
+// Same-box A/B with the order rotated, 4 rounds of 200 steps, SYN-B (profiles/r06/lease16_count_scan_tail_ab.txt; lease 15 before it: the same ranking on another box):
+//   KEEP EARLY DEPTH   img/s (median)            KEEP EARLY DEPTH   img/s
+//    0     0     4      670.3                     1     1     4      687.3   <- default
+//    0     1     4      681.7                     1     1     8      687.9
+//    0     0     8      686.2                     1     1     4 NT   686.8
+//    0     1     8      682.7                     1     0     4      lease 15: below 0 / 0
 #ifndef LFS_TAIL_KEEP
-#define LFS_TAIL_KEEP 0    // 1: the coefficient rows phase 2 fetches stay in registers for phase 5 (same lane, same rows: 3 x LPG VGPRs; every row is then fetched in phase 2)
-#endif
+#define LFS_TAIL_KEEP 1    // 1: the coefficient rows phase 2 fetches stay in registers for phase 5 (same lane, same rows: 3 x LPG VGPRs; every row is then fetched in phase 2;
+#endif                     //    196 - 224 VGPRs: two wavefronts per SIMD, each with 16 rows x 12 B per lane in flight in phase 2)
 #ifndef LFS_TAIL_EARLY
-#define LFS_TAIL_EARLY 0   // 1: the first LFS_TAIL_DEPTH moment rows of phase 5 are requested in front of phase 3 (they land under the finish arithmetic)
+#define LFS_TAIL_EARLY 1   // 1: the first LFS_TAIL_DEPTH moment rows of phase 5 are requested in front of phase 3 (they land under the finish arithmetic)
 #endif
 #ifndef LFS_TAIL_NT
-#define LFS_TAIL_NT 0      // 1: the moments leave with non-temporal stores (nothing reads them for a whole step: they need not sit in the Infinity Cache)
+#define LFS_TAIL_NT 0      // 1: the moments leave with non-temporal stores (nothing reads them for a whole step) - no difference measured
 #endif
 template <int LPG, bool NEXT>
 __global__ void __launch_bounds__(64) gut_tail_kernel(const GutTail t, const CamDev* __restrict__ cams) {
@@ -1464,7 +1500,7 @@ static int raster_fwd_impl(
     hipLaunchKernelGGL((raster_fwd_kernel<CD, MODE>), dim3(gw.grid), dim3(gw.threads), 0, s, C, N, g.tw, g.th,     \
                        cams->image_width, cams->image_height, tile_size, gw.blocks_per_tile, gw.waves_per_block, \
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, ic.arg(), \
-                       render_colors, render_alphas, last_ids)
+                       render_colors, render_alphas, last_ids, reinterpret_cast<int32_t*>(w.cell_list))
     switch (channels * 2 + raster_mode(cams)) {
     case 2: LFS_FWD(1, 0); break; case 3: LFS_FWD(1, 1); break;
     case 4: LFS_FWD(2, 0); break; case 5: LFS_FWD(2, 1); break;

@@ -244,10 +244,6 @@ static inline unsigned long long __shfl_xor(unsigned long long v, int m, int = 6
 // at cross-lane operations: the barrier is one here (every live lane arrives before any continues). It must sit in wave-converged code - as on the GPU.
 #define __builtin_amdgcn_wave_barrier() ((void)emu::ballot(true))
 #define __builtin_amdgcn_fence(...) do { } while (0)
-// one host thread runs the workgroups of a launch one after the other: device-scope fences and coherent loads have nothing to order
-static inline void __threadfence() { }
-#define __HIP_MEMORY_SCOPE_AGENT 0
-#define __hip_atomic_load(p, order, scope) (*(p))
 // __shfl_up: lane i reads lane i - d; lanes below d keep their own value
 static inline uint64_t emu_shfl_up64(uint64_t v, int d) { uint64_t o[2][64]; emu::wave_exchange(v, 0, o); const int l = int(emu::lane_id()); return l >= d ? o[0][l - d] : v; }
 static inline uint64_t __shfl_up(uint64_t v, int d, int = 64) { return emu_shfl_up64(v, d); }

@@ -113,7 +113,7 @@ def test_intersect_full_size_properties(lfs):
 def test_two_pass_scatter_equals_one_pass_over_random_shapes(lfs):
     """The binned two-pass scatter (default) against the one-pass kernel (debug bit 5) over random problem shapes - cameras, image sizes down to one
     tile and up to thousands of tiles per row, tile sizes, dense and sparse lists, a reused workspace (LFS_ISECT_COUNTERS_ZERO) and the overlap form
-    (counts written to pinned host memory), the scan inside the count kernel's last workgroup (round 6, default) and as its own launch (debug bit 8): every output identical. (Each path against the oracle: the tests above and tests/test_emulated_intersect.py.)"""
+    (counts written to pinned host memory): every output identical. (Each path against the oracle: the tests above and tests/test_emulated_intersect.py.)"""
     from lichtfeld_studio_amd import ops
     lib = lfs.load_library()
     g = np.random.default_rng(7)
@@ -131,7 +131,7 @@ def test_two_pass_scatter_equals_one_pass_over_random_shapes(lfs):
         d = (np.round(g.uniform(0.2, 30.0, (C, N)) * 8) / 8).astype(np.float32)
         tm, tr, td = t(m), t(r, torch.int32), t(d)
         outs = []
-        for flags, overlap in ((0, None), (0, lambda: 1), (32, None), (256, None), (256 | 32, lambda: 1)):   # (bit 8: count and scan as two launches, the rounds 1 - 5 form)
+        for flags, overlap in ((0, None), (0, lambda: 1), (32, None)):
             lib.lfs_set_debug_flags(flags)
             try:
                 res = ops.intersect_tile(tm, tr, td, None, None, C, ts, tw, th, True, return_offsets=True, overlap=overlap)

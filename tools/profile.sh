@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ops-route"   # the driver's command without its two side legs (oracle check, Ops.h route): the headline path only
 # 1) kernel trace + stats (same command as the bench line, events enabled)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/bench_trace.log" 2>&1
 # 2) PMC passes, each on its own (TCC slots: FETCH_SIZE costs 3, WRITE_SIZE 2)
