@@ -318,10 +318,12 @@ def main() -> None:
         # asynchronous all_reduce), the ranks agree on the outcome with one MIN all-reduce - the one collective every torch.distributed backend has - and only a
         # layout that every rank accepted runs its full trial step (whose remaining failure modes - an unsupported problem shape, a kernel error - are functions of
         # replicated state and hit all ranks alike, outside the collectives).
+        # Round 6 (ADVICE): the agreement itself runs over a gloo side group on CPU tensors (dist.agree_all) - not over the communicator under test, which a caught
+        # RCCL error may have left aborted - and every group carries a bounded timeout (LFS_DIST_TIMEOUT_S, 300 s): a rank that dies inside the probe ends the run
+        # within minutes instead of leaving its peers blocked.
         def agree(ok_here: int) -> bool:
-            f = torch.tensor([float(ok_here)], device=device)
-            torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MIN)
-            return float(f) == 1.0
+            return lfs_dist.agree_all(bool(ok_here))
+        agree(1)   # (creates the side group on every rank BEFORE anything can fail one-sidedly)
         ok = 1
         try:
             from lichtfeld_studio_amd import dist as lfs_dist   # (the layout's own collective wrappers: gloo ranks stage through the host, RCCL goes direct)
@@ -344,10 +346,8 @@ def main() -> None:
                 ok = 0
         else:
             ok = 0
-        flag = torch.tensor([float(ok)], device=device)
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        trainer = make_trainer(False, float(flag) == 1.0)   # (a fresh model either way: the trial step updated the parameters)
-        headline_factored = float(flag) == 1.0
+        headline_factored = agree(ok)
+        trainer = make_trainer(False, headline_factored)   # (a fresh model either way: the trial step updated the parameters)
     if args.strategy == "mcmc" and args.start_iteration == 3000:
         # the warm-up must contain one refinement step (iteration 3000: relocation + its torch index kernels, whose first use loads ~20 code
         # objects at 20 - 200 ms each); the timed window then holds warm steps only, one of them (every 100th) a refinement step

@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(64) sh_pipe_dirs_kernel(const ShArgs a, const 
 // has just left. The sh0 rows are updated in the lane = Gaussian phase (one coalesced 768-byte block per tensor and wavefront; basis 0 is the constant), so that the
 // lane = (Gaussian, basis) phase walks ONE tensor triple: wave-uniform row bases in SGPRs + one 32-bit per-lane offset. 57 VGPRs: two of these wavefronts per SIMD leave
 // the main stream's kernels three quarters of the register file (the first form, double-buffered batches behind 64-bit per-lane addresses, took 131 each, and the
-// projection kernel - 94 VGPRs - ran at 2 instead of 5 wavefronts per SIMD beside it: 150 instead of 56 us, profiles/r06/pipeline_timelines.txt).
+// projection kernel - 94 VGPRs - ran at 2 instead of 5 wavefronts per SIMD beside it: 150 instead of 56 us, profiles/r06/pipeline/lease11_timelines.txt).
 #ifndef LFS_SH_PIPE_DEPTH
 #define LFS_SH_PIPE_DEPTH 4
 #endif

@@ -194,20 +194,28 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> intersect_tile(const at::Tensor m
     (void)camera_ids; (void)gaussian_ids;
     const uint32_t N = (uint32_t)means2d.size(1);
     at::Tensor tiles_per_gauss = at::empty_like(depths, depths.options().dtype(at::kInt));
-    at::Tensor n_dev = at::empty({1}, depths.options().dtype(at::kLong));
     const size_t ws_bytes = lfs_intersect_tile_workspace_bytes(C, N, tile_width, tile_height);
     at::Tensor ws = scratch(ws_bytes, depths);
-    check_rc(lfs_intersect_tile_count(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), tile_size, tile_width, tile_height,
-                                      tiles_per_gauss.data_ptr<int32_t>(), n_dev.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+    // The one host sync of the path, at the place the reference has it (Intersect.cpp:75-76: it allocates to the count). Round 6: the scan kernel writes
+    // {n_isects, longest tile list, stamp} straight into pinned host memory and the host spins on its own stamp - no device-to-host copy, no stream
+    // synchronisation behind it (was n_dev.item<int64_t>(): a copy kernel + hipStreamSynchronize in the bubble the GPU idles through). The longest list also tells
+    // the per-tile sort which size classes occur. One slot per host thread, never freed (a static tensor's destructor would run after the HIP runtime's).
+    static thread_local at::Tensor* const counts = new at::Tensor(at::zeros({3}, at::TensorOptions().dtype(at::kLong).pinned_memory(true)));
+    static thread_local int64_t stamp = 0;
+    stamp += 1;
+    int64_t* const host = counts->data_ptr<int64_t>();
+    check_rc(lfs_intersect_tile_count_ex(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), tile_size, tile_width, tile_height,
+                                         tiles_per_gauss.data_ptr<int32_t>(), host, host + 1, nullptr, 0u, host + 2, stamp, ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
              "intersect_tile(count)");
-    const int64_t n_isects = n_dev.item<int64_t>(); // the one host sync, as Intersect.cpp:76
+    int64_t n_isects = 0, longest = -1;
+    check_rc(lfs_gut_step_wait(host, stamp, 30.0, &n_isects, &longest), "intersect_tile(count read-back)");
     at::Tensor isect_ids = at::empty({n_isects}, depths.options().dtype(at::kLong));
     at::Tensor flatten_ids = at::empty({n_isects}, depths.options().dtype(at::kInt));
     at::Tensor binned = at::empty({sort ? n_isects : 0}, depths.options().dtype(at::kLong)); // the two-pass scatter's intermediate (row-binned) array
     check_rc(lfs_intersect_tile_emit_ex(C, N, means2d.data_ptr<float>(), radii.data_ptr<int32_t>(), depths.data_ptr<float>(), tile_size, tile_width,
                                         tile_height, sort ? 1 : 0, n_isects, tiles_per_gauss.data_ptr<int32_t>(),
                                         n_isects ? isect_ids.data_ptr<int64_t>() : nullptr, n_isects ? flatten_ids.data_ptr<int32_t>() : nullptr, nullptr,
-                                        (sort && n_isects) ? binned.data_ptr<int64_t>() : nullptr, (int64_t)-1, ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+                                        (sort && n_isects) ? binned.data_ptr<int64_t>() : nullptr, longest, ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
              "intersect_tile(emit)");
     return std::make_tuple(tiles_per_gauss, isect_ids, flatten_ids);
 }
@@ -378,6 +386,7 @@ void GutTrainStep::ensure(uint32_t N, uint32_t W, uint32_t H, const torch::Tenso
     if (capacity_ <= 0) capacity_ = std::max<int64_t>(4 * int64_t(N), 1 << 16);   // first guess; the first step corrects it
     const uint32_t flags = lfs_get_debug_flags();
     if (ws_.defined() && N == N_ && W == W_ && H == H_ && cap_built_ == capacity_ && flags == flags_) return;
+    colours_for_.valid = false;   // a new layout (or block): whatever colours the last tail prepared are not where the next step would look for them
     lfs_gut_step_layout lay{};
     check_rc(lfs_gut_step_layout_for(N, W, H, tile_, capacity_, &lay), "gut_step_layout_for");
     if (!ws_.defined() || (size_t)ws_.numel() < lay.bytes || ws_.device() != like.device()) {
@@ -392,7 +401,8 @@ void GutTrainStep::ensure(uint32_t N, uint32_t W, uint32_t H, const torch::Tenso
 int64_t GutTrainStep::step(torch::Tensor& means, torch::Tensor& sh0, torch::Tensor& shN, torch::Tensor& raw_scales, torch::Tensor& raw_quats,
                            torch::Tensor& raw_opacities, const std::array<AdamGroupState, 6>& adam, uint32_t sh_degree, const torch::Tensor& viewmat,
                            const torch::Tensor& K, uint32_t image_width, uint32_t image_height, const at::optional<torch::Tensor>& background,
-                           const torch::Tensor& target_chw, float loss_weight, torch::Tensor& loss, float scale_reg, float opacity_reg) {
+                           const torch::Tensor& target_chw, float loss_weight, torch::Tensor& loss, float scale_reg, float opacity_reg,
+                           const at::optional<torch::Tensor>& next_viewmat) {
     LFS_DEVICE_GUARD(means);
     LFS_CHECK_INPUT(means); LFS_CHECK_INPUT(sh0); LFS_CHECK_INPUT(shN); LFS_CHECK_INPUT(raw_scales); LFS_CHECK_INPUT(raw_quats); LFS_CHECK_INPUT(raw_opacities);
     LFS_CHECK_INPUT(viewmat); LFS_CHECK_INPUT(K); LFS_CHECK_INPUT(target_chw); LFS_CHECK_INPUT(loss);
@@ -412,19 +422,46 @@ int64_t GutTrainStep::step(torch::Tensor& means, torch::Tensor& sh0, torch::Tens
     a.viewmat = viewmat.data_ptr<float>(); a.Kmat = K.data_ptr<float>();
     a.background = opt_ptr<float>(background); a.target_chw = target_chw.data_ptr<float>();
     a.loss_weight = loss_weight; a.scale_reg = scale_reg; a.opacity_reg = opacity_reg; a.loss = loss.data_ptr<float>();
+    // Round 6: the fused tail (lfs_gut_train_step_ex). The colours in the workspace are "ready" for this call when the previous call's tail evaluated them for exactly
+    // this view tensor from exactly these parameter tensors and nothing has written to either since (storage address + autograd version: every in-place torch op and the
+    // raw-pointer wrappers of this file bump the version; this step's own writes are recorded AFTER the call, below).
+    const float* next_vm = nullptr;
+    if (next_viewmat.has_value() && next_viewmat->defined() && a.K <= 16) {   // (K > 16: the tail falls back to the separate passes and prepares nothing)
+        LFS_CHECK_INPUT(next_viewmat.value());
+        TORCH_CHECK(next_viewmat->numel() == 16, "next_viewmat must be [4,4]");
+        next_vm = next_viewmat->data_ptr<float>();
+    }
+    const torch::Tensor* const watched[3] = {&means, &sh0, &shN};
+    auto describes = [&](const ColoursFor& c, const torch::Tensor& vm) {
+        bool same = c.valid && c.viewmat == vm.data_ptr() && c.viewmat_version == (uint32_t)vm._version() && c.ws == ws_.data_ptr() && c.N == N && c.K == a.K && c.degree == sh_degree;
+        for (int k = 0; k < 3; ++k) same = same && c.param[k] == watched[k]->data_ptr() && c.param_version[k] == (uint32_t)watched[k]->_version();
+        return same;
+    };
     for (int attempt = 0; attempt < 4; ++attempt) {
         ensure(N, image_width, image_height, means);
         ++stamp_;
         int64_t* counts = counts_.data_ptr<int64_t>();
-        check_rc(lfs_gut_train_step(&a, capacity_, assumed_longest_, ws_.data_ptr(), (size_t)ws_.numel(), counts, stamp_, cur_stream()), "gut_train_step");
+        const bool ready = describes(colours_for_, viewmat);
+        colours_for_.valid = false;   // whatever happens below, the colours of THIS view are consumed / overwritten
+        check_rc(lfs_gut_train_step_ex(&a, next_vm, ready ? 1 : 0, capacity_, assumed_longest_, ws_.data_ptr(), (size_t)ws_.numel(), counts, stamp_, cur_stream()), "gut_train_step_ex");
         // the counts were written by the scan kernel early in the step: by now they have long arrived (no GPU idle time behind this wait)
         check_rc(lfs_gut_step_wait(counts, stamp_, 30.0, &n_isects_, &longest_), "gut_step_wait");
         if (lfs_gut_step_fits(n_isects_, longest_, capacity_, assumed_longest_)) {
+            colours_saved_ += ready ? 1 : 0;
+            for (torch::Tensor* t : {&means, &sh0, &shN, &raw_scales, &raw_quats, &raw_opacities}) bump(*t);   // in-place updates through raw pointers: visible to autograd / the staging slot
+            if (next_vm != nullptr) {
+                ColoursFor& c = colours_for_;
+                c.valid = true; c.viewmat = next_viewmat->data_ptr(); c.viewmat_version = (uint32_t)next_viewmat->_version(); c.ws = ws_.data_ptr();
+                c.N = N; c.K = a.K; c.degree = sh_degree;
+                for (int k = 0; k < 3; ++k) { c.param[k] = watched[k]->data_ptr(); c.param_version[k] = (uint32_t)watched[k]->_version(); }
+            }
             if (double(n_isects_) > 0.92 * double(capacity_)) capacity_ = int64_t(double(n_isects_) * 1.25) + 1024;   // stay ahead of a growing scene
             const int64_t limit = assumed_longest_ <= 1024 ? 1024 : assumed_longest_ <= 4096 ? 4096 : assumed_longest_ <= 16384 ? 16384 : (int64_t(1) << 62);
             if (double(longest_) > 0.92 * double(limit)) assumed_longest_ = std::max<int64_t>(assumed_longest_, int64_t(double(longest_) * 1.25));
             return n_isects_;
         }
+        // the attempt did not fit: its tail returned without writing anything, so colours that were ready still are - unless ensure() replaces the workspace (the key holds its address)
+        if (ready) { colours_for_.valid = true; }
         ++retries_;
         capacity_ = std::max<int64_t>(capacity_, int64_t(double(n_isects_) * 1.25) + 1024);
         assumed_longest_ = std::max<int64_t>(assumed_longest_, int64_t(double(longest_) * 1.25));

@@ -25,8 +25,27 @@ def init_distributed(backend: Optional[str] = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:  # LFS_DIST_BACKEND=gloo: several ranks on one GPU (tests / smoke runs; collectives staged through the host)
             backend = os.environ.get("LFS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # a bounded timeout: a rank that dies before it enters a collective must not leave its peers blocked for the backend's default 10 - 30 minutes
+        import datetime
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("LFS_DIST_TIMEOUT_S", "300"))))
     return rank, world, local_rank
+
+
+_AGREE_GROUP = None
+
+
+def agree_all(ok_here: bool) -> bool:
+    """True when EVERY rank passes True. Runs over a gloo side group on CPU tensors (created on first use, by all ranks together): the agreement does not travel over
+    the communicator whose collectives are being tried - after a caught RCCL error that communicator may be aborted or poisoned."""
+    global _AGREE_GROUP
+    if not _active():
+        return bool(ok_here)
+    if _AGREE_GROUP is None:
+        import datetime
+        _AGREE_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=int(os.environ.get("LFS_DIST_TIMEOUT_S", "300"))))
+    f = torch.tensor([1.0 if ok_here else 0.0])
+    dist.all_reduce(f, op=dist.ReduceOp.MIN, group=_AGREE_GROUP)
+    return float(f) == 1.0
 
 
 # LFS_DIST_FORCE_COLLECTIVES=1: issue every collective even at world size 1 (tests/test_gpu_rccl_world1.py: the RCCL code path - device

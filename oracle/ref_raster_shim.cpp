@@ -348,7 +348,9 @@ REF_API int reflink_fused_adam_steps(const int64_t* sizes, float* const* params,
 //           the loss of SURVEY.md §8d), every operator through the linked backend one by one;
 //   mode 1: the patch - the optimizer state is taken from FusedAdam with the members it really has (torch::optim::Optimizer::param_groups() / state(), the group's
 //           FusedAdam::Options, FusedAdam::AdamParamState; lazy initialisation and ++step_count as fused_adam.cpp:44-66 do them) and the whole step is ONE call of
-//           lfs::GutTrainStep::step (include/lfs_gut_train_step.hpp).
+//           lfs::GutTrainStep::step (include/lfs_gut_train_step.hpp);
+//   mode 2: the patch with the NEXT view named (round 6: next_viewmat - here the same camera, as a trainer whose dataloader has the next camera queued would pass it): the
+//           step's tail then prepares the next call's SH colours and that call skips its colour kernel.
 // Both leave parameters and moments in the same FusedAdam / SplatData objects, which are read back: tests/test_gpu_reference_links.py holds mode 1 to mode 0.
 #include "lfs_gut_train_step.hpp"
 #include <chrono>
@@ -379,6 +381,7 @@ REF_API int reflink_mse_train_steps(int mode, int64_t N, int64_t K1, int sh_degr
         FusedAdam optimizer(std::move(groups), std::move(global_options));
         lfs::GutTrainStep gut_step;
         torch::Tensor loss_scalar = torch::zeros({1}, gt.options());
+        const torch::Tensor viewmat = cam.world_view_transform().contiguous(), Kmat = cam.K().contiguous();   // (modes 1 / 2: one tensor per camera, alive across the steps)
         std::chrono::steady_clock::time_point t0;
         const bool timing = ms_per_step != nullptr && timed_from >= 0 && timed_from < n_steps;
         for (int k = 0; k < n_steps; ++k) {
@@ -412,13 +415,14 @@ REF_API int reflink_mse_train_steps(int mode, int64_t N, int64_t K1, int sh_degr
                                (float)(1.0 / std::sqrt(1.0 - std::pow(b2, st.step_count)))}; // :78-79
                 }
                 loss_scalar.zero_();
-                auto viewmat = cam.world_view_transform().contiguous(), Kmat = cam.K().contiguous();
                 *n_isects_out = gut_step.step(model.means(), model.sh0(), model.shN(), model.scaling_raw(), model.rotation_raw(), model.opacity_raw(), adam,
                                               (uint32_t)model.get_active_sh_degree(), viewmat, Kmat, (uint32_t)width, (uint32_t)height,
-                                              bgc.defined() ? at::optional<torch::Tensor>(bgc) : at::nullopt, gt, 1.f, loss_scalar);
+                                              bgc.defined() ? at::optional<torch::Tensor>(bgc) : at::nullopt, gt, 1.f, loss_scalar, 0.f, 0.f,
+                                              mode == 2 ? at::optional<torch::Tensor>(viewmat) : at::nullopt);
                 if (!timing) losses[k] = loss_scalar.item<float>();
             }
         }
+        if (mode == 2) TORCH_CHECK(gut_step.colour_launches_saved() >= n_steps - 1 - 2 * gut_step.retries(), "the prepared colours were not used: ", gut_step.colour_launches_saved(), " of ", n_steps);
         if (timing) {
             torch::cuda::synchronize();
             *ms_per_step = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / double(n_steps - timed_from);

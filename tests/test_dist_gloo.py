@@ -387,3 +387,34 @@ def test_factored_color_gradient_exchange_matches_replicated_computation(world, 
         for a, b in zip(results[0][1], results[rank][1]):
             assert np.array_equal(a, b), "replicas must stay bit-identical"
     assert float(np.abs(ref_shN.numpy()).max()) > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dist.agree_all: the bench's layout agreement travels over its own gloo side group
+# ---------------------------------------------------------------------------------------------------------------------
+def _worker_agree(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LFS_DIST_TIMEOUT_S="120")
+    import lichtfeld_studio_amd  # noqa: F401
+    from lichtfeld_studio_amd import dist as ld
+    ld.init_distributed(backend="gloo")
+    out = [ld.agree_all(True), ld.agree_all(rank != 1), ld.agree_all(rank == 1), ld.agree_all(True)]
+    q.put((rank, out, ld._AGREE_GROUP is not None and ld._AGREE_GROUP is not dist.group.WORLD))
+    dist.destroy_process_group()
+
+
+def test_layout_agreement_runs_over_its_own_group_and_is_the_minimum_over_ranks():
+    """One rank saying no is everybody's no; the answer is the same on every rank; the side group exists after the first call and is not the default group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker_agree, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(3)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, own_group in results:
+        assert out == [True, False, False, True], (rank, out)
+        assert own_group

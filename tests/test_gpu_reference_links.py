@@ -168,8 +168,12 @@ def test_integration_patch_with_fused_adams_real_members_equals_the_references_o
         lib.lfs_set_debug_flags(16)
         a = oracle_mod.ref_links_mse_train_steps(0, *args)
         b = oracle_mod.ref_links_mse_train_steps(1, *args)
+        b2 = oracle_mod.ref_links_mse_train_steps(2, *args)   # round 6: the patch with next_viewmat - the tail prepares the next call's SH colours (the shim checks they were used)
     finally:
         lib.lfs_set_debug_flags(0)
+    for key, p1, p2 in zip(("means", "sh0", "shN", "scaling", "rotation", "opacity"), b["params"], b2["params"]):
+        assert np.array_equal(p1, p2), f"{key}: the step that found its colours prepared differs from the step that evaluated them itself"
+    assert np.array_equal(np.asarray(b["losses"]), np.asarray(b2["losses"]))
     print("reference sequence losses", a["losses"], "patched step losses", b["losses"], "n_isects", b["n_isects"])
     assert b["n_isects"] > 0 and a["losses"][0] > 0
     assert abs(a["losses"][0] - b["losses"][0]) <= 2e-6 * a["losses"][0]
@@ -204,10 +208,11 @@ def test_reference_trainer_sequence_at_the_benchmark_size_timed(lfs, oracle_mod)
     first = [oracle_mod.ref_links_mse_train_steps(mode, *args, 1)["losses"][0] for mode in (0, 1)]
     assert first[0] > 0 and abs(first[0] - first[1]) <= 2e-6 * first[0], first
     out = {"workload": "SYN-B view 0: 1000000 Gaussians, 1920x1080, SH degree 3, MSE, iteration 3000 (all six groups in Adam)", "steps_timed": 20, "warmup": 5, "repeats": "best of 3"}
-    for mode, name in ((0, "reference_sequence_ms_per_step"), (1, "one_call_patch_ms_per_step")):
+    for mode, name in ((0, "reference_sequence_ms_per_step"), (1, "one_call_patch_ms_per_step"), (2, "one_call_patch_next_view_named_ms_per_step")):
         out[name] = round(min(oracle_mod.ref_links_mse_train_steps(mode, *args, 25, timed_from=5)["ms_per_step"] for _ in range(3)), 4)   # best of three (a timing, reported - not asserted)
     out["reference_sequence_img_per_s"] = round(1e3 / out["reference_sequence_ms_per_step"], 1)
     out["one_call_patch_img_per_s"] = round(1e3 / out["one_call_patch_ms_per_step"], 1)
+    out["one_call_patch_next_view_named_img_per_s"] = round(1e3 / out["one_call_patch_next_view_named_ms_per_step"], 1)
     print("linked reference on SYN-B:", out)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "reference_links_synb_timing.json"), "w") as f:
