@@ -18,6 +18,19 @@ constexpr int ACC_STRIDE = 16; // A(9) | G(3) | opacity | rgb(3)
 #ifndef LFS_REC_LOG2
 #define LFS_REC_LOG2 1
 #endif
+// LFS_REC_ROT (round 6, global shutter only): the record is stored in a ROTATED Gaussian frame U (rot_frame below) in which g = M (o - mu) points along the third axis,
+// g'' = U g = (0, 0, G). Rotations leave the distance of the ray q = M d to the origin untouched, and with two components of g'' gone it collapses:
+//   t = G q''.z / |q''|^2,   w'' = g'' - t q'' = (-t q''.x, -t q''.y, G m / l),   |w''|^2 = G^2 m / l,   m = q''.x^2 + q''.y^2,  l = m + q''.z^2
+// (|g| sin(angle between the ray and the direction to the centre)). The forward needs neither t nor w: 9 + 3 + rcp + 3 + exp2 instructions instead of 9 + 3 + rcp + 3 + 1 + 3 + 3
+// + exp2; the backward gets a foot vector with NO difference of large numbers in it - the Gram-Schmidt step of LFS_BWD_REORTH (7 instructions) has nothing left to remove -
+// and accumulates dL/dA'' = U dL/dA, dL/dg'' = U dL/dg exactly as before; finish_geometry (raster.hip) multiplies the two sums by U^T once per Gaussian.
+// Record: rows of U M' (M' = c M Rinv) in r0..r2.xyz, r0.w = G^2, r1.w = 0, r2.w = G (G = c |g|). 0 = the round-3 .. 6 records (g in the .w fields).
+#ifndef LFS_REC_ROT
+#define LFS_REC_ROT 1
+#endif
+#if LFS_REC_ROT && !LFS_REC_LOG2
+#error "LFS_REC_ROT is written for the LFS_REC_LOG2 records"
+#endif
 constexpr float REC_SCALE = 0.84932180028801904f;   // sqrt(0.5 * log2(e))
 constexpr float REC_UNSCALE = 1.17741002251547469f; // 1 / REC_SCALE = sqrt(2 ln 2)
 
@@ -71,6 +84,20 @@ LFS_DI CellCtx cell_ctx(uint32_t n_tiles, uint32_t total_tiles, uint32_t tw, uin
 
 LFS_DI float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 LFS_DI float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// a * b with 0 * anything (inf, NaN) = 0 (v_mul_legacy_f32): the reciprocal of a zero length needs no clamp before it meets the zero numerator. Through the LLVM
+// intrinsic, NOT through inline asm: the compiler has to see the instruction to keep the wait state gfx950 needs between a transcendental (v_rcp_f32) and a VALU
+// instruction that reads its result - the first form of this (asm) was scheduled right behind the v_rcp_f32 in raster_fwd_kernel and read the stale register: images
+// off by 5e-2, on the hardware only (profiles/r06/lease21_rot_frame_ab.txt).
+#ifndef LFS_EMULATE
+extern "C" __device__ float lfs_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+#endif
+LFS_DI float mul_zero(float a, float b) {
+#ifdef LFS_EMULATE
+    return (a == 0.f || b == 0.f) ? 0.f : a * b;
+#else
+    return lfs_fmul_legacy(a, b);
+#endif
+}
 
 // LFS_SEL_E64 (round 6): the per-lane conditions of the inner loops as LANE MASKS in SGPR pairs - v_cmp_*_e64 writes the mask, plain SALU combines masks, the
 // wave-level "nobody" test is s_cmp on the mask, and every select is v_cndmask_b32_e64 on a mask - instead of the compiler's VCC / EXEC forms. tools/valu_rate.hip on
@@ -151,6 +178,59 @@ LFS_DI float fma3(float ax, float bx, float ay, float by, float az, float bz) {
 LFS_DI f3 cross_fma(const f3& a, const f3& b) {
     return {__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)), __builtin_fmaf(a.x, b.y, -(b.x * a.y))};
 }
+// The frame of LFS_REC_ROT: an orthonormal U (rows) whose third axis is g / |g|, U g = (0, 0, |g|); g = 0 or not finite: some frame, nothing depends on which. Duff et al.
+// 2017 ("Building an orthonormal basis, revisited"): branch-free, no cancellation for any direction. In DOUBLE precision, with the two products it is used in, and rebuilt
+// bit for bit by the finish pass from the same fp32 g. Every cheaper form was measured (tools/aniso_probe.py; profiles/r06/lease21 .. 23):
+//   - the frame in single precision: U g is (0, 0, |g|) only to 6e-8 |g|, and for a flat Gaussian |g| is 1e4 where the foot vector is 1 - an offset of 6e-4 in w that the
+//     evaluation knows nothing about: dL/dmeans 5e-3 off at aspect 80, the forward 2.6e-4;
+//   - double in the record, single in the finish pass: two frames 1e-7 apart put 1e-7 of the large rows of dL/dA into the thin one, which the scale gradient multiplies by
+//     1 / s_min^2: dL/dscales 1.5e-4 -> 3.0e-4 off at aspect 10;
+//   - one single-precision frame on both sides with its residual (U g).xy sheared away: the frame is then orthonormal to 1e-7 only, t carries that strain against the
+//     |g| = 1e4 it is multiplied with, and dL/dscale of the thin axis - a difference of two sums that cancel to 1e-6 - is 2e-3 off at aspect 80 (double frame: 5e-4).
+// Cost: the fused tail kernel sits at 224 of the 256 VGPRs its two wavefronts per SIMD allow, and a double-precision frame written naively took it to 258 and ONE wavefront
+// (0.29 -> 0.40 ms). Hence the form below: single-precision v_rsq / v_rcp seeds with two Newton steps in double instead of IEEE sqrt / division, eight coefficients
+// instead of a matrix, and rot_apply_t one vector at a time between scheduling barriers - the compiler otherwise converts and multiplies all twelve at once.
+struct RotFrame { double nx, ny, nz, b, c00, c11, sgb, sgnx, len; };
+LFS_DI void rot_frame(const f3 g, RotFrame& F) {
+#pragma clang fp contract(off)
+    const double gx = g.x, gy = g.y, gz = g.z;
+    const double len2 = gx * gx + gy * gy + gz * gz;
+    double nx = 0.0, ny = 0.0, nz = 1.0;
+    F.len = 0.0;
+    if (len2 > 1e-36 && len2 < 1e36) {   // (|g| within 1e-18 .. 1e18: inside the range of the single-precision seed)
+        double inv = double(fast_rsq(float(len2)));
+        inv = inv * (1.5 - 0.5 * len2 * inv * inv);
+        inv = inv * (1.5 - 0.5 * len2 * inv * inv);
+        F.len = len2 * inv; nx = gx * inv; ny = gy * inv; nz = gz * inv;
+    }
+    const double sg = nz >= 0.0 ? 1.0 : -1.0;
+    const double den = sg + nz;            // |den| in [1, 2]
+    double r = double(fast_rcp(float(den)));
+    r = r * (2.0 - den * r);
+    r = r * (2.0 - den * r);
+    const double a = -r;
+    F.nx = nx; F.ny = ny; F.nz = nz;
+    F.b = nx * ny * a; F.c00 = 1.0 + sg * nx * nx * a; F.c11 = sg + ny * ny * a; F.sgb = sg * F.b; F.sgnx = sg * nx;
+}
+// rows of U: (c00, sgb, -sgnx), (b, c11, -ny), (nx, ny, nz)
+LFS_DI void rot_apply(const RotFrame& F, const float v0, const float v1, const float v2, float& o0, float& o1, float& o2) {   // U v
+#pragma clang fp contract(off)
+    const double x = v0, y = v1, z = v2;
+    o0 = float(F.c00 * x + F.sgb * y - F.sgnx * z);
+    o1 = float(F.b * x + F.c11 * y - F.ny * z);
+    o2 = float(F.nx * x + F.ny * y + F.nz * z);
+}
+LFS_DI void rot_apply_t(const RotFrame& F, const float v0, const float v1, const float v2, float& o0, float& o1, float& o2) { // U^T v
+#pragma clang fp contract(off)
+    const double x = v0, y = v1, z = v2;
+    o0 = float(F.c00 * x + F.b * y + F.nx * z);
+    o1 = float(F.sgb * x + F.c11 * y + F.ny * z);
+    o2 = float(F.nz * z - F.sgnx * x - F.ny * y);
+#ifndef LFS_EMULATE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // Walk a cell list with the records arriving through the SCALAR unit: two groups of two record
 // buffers in SGPRs. Scalar loads return out of order, so every wait is s_waitcnt lgkmcnt(0): the loop
 // waits for group B right BEFORE refilling group A (and vice versa), which gives each record load two full
@@ -411,6 +491,66 @@ LFS_DI void wave_sum16_atomic_lds(const v2f (&V)[8], float* __restrict__ dst, co
 #endif
     }
 }
+
+// LFS_RED_QUAD (round 6): the same value-major block, read so that the four partial sums of a slot land in ONE QUAD: lane L (k = L >> 2, q = L & 3) reads the pieces
+// {16 j + 4 q .. + 3}, j = 0..3, of row k, and the cross-lane part of the reduction is two quad-permute DPP adds instead of mov + v_permlane16_swap + add + mov +
+// v_permlane32_swap + add (6 VALU and their wait states). Row stride 80 floats: the 8 lanes of a ds_read_b128 service group (two rows x four quarters) hit 8 disjoint 4-bank
+// ranges ((16 k + 4 q) mod 64). The atomic goes out with the accumulator row's address in an SGPR pair (the Gaussian is wave-uniform) and a constant per-lane offset: no
+// 64-bit VALU add per evaluation. lds_base = the block's LDS byte address, read once per kernel (the compiler re-issued v_readfirstlane per evaluation).
+#ifndef LFS_RED_QUAD
+#define LFS_RED_QUAD 1
+#endif
+constexpr int RED_QROW = 80;
+constexpr int RED_QUAD_SCRATCH_FLOATS = 16 * RED_QROW;
+#if LFS_RED_QUAD && LFS_RED_ADDTID && !defined(LFS_EMULATE)   // (-DLFS_RED_ADDTID=0, the test suite's second build: compiler-generated stores in the round-3 layout)
+#define LFS_RED_QUAD_ASM 1
+#else
+#define LFS_RED_QUAD_ASM 0
+#endif
+#if LFS_RED_QUAD_ASM
+template <int ACC = 0>
+LFS_DI void wave_sum16_atomic_quad(const v2f (&V)[8], float* __restrict__ dst /* wave-uniform */, const uint32_t lane, const uint32_t lds_base, const float4* __restrict__ rd /* this lane's read pointer */,
+                                   unsigned long long* __restrict__ det64 = nullptr) {
+    float c[16];
+    {
+        uint32_t m0_saved; // (M0 saved and put back inside the block: see wave_sum16_atomic_lds)
+        asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[base]\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %[a0] offset:0\n\tds_write_addtid_b32 %[a1] offset:320\n\tds_write_addtid_b32 %[a2] offset:640\n\tds_write_addtid_b32 %[a3] offset:960\n\t"
+                     "ds_write_addtid_b32 %[a4] offset:1280\n\tds_write_addtid_b32 %[a5] offset:1600\n\tds_write_addtid_b32 %[a6] offset:1920\n\tds_write_addtid_b32 %[a7] offset:2240\n\t"
+                     "ds_write_addtid_b32 %[a8] offset:2560\n\tds_write_addtid_b32 %[a9] offset:2880\n\tds_write_addtid_b32 %[a10] offset:3200\n\tds_write_addtid_b32 %[a11] offset:3520\n\t"
+                     "ds_write_addtid_b32 %[a12] offset:3840\n\tds_write_addtid_b32 %[a13] offset:4160\n\tds_write_addtid_b32 %[a14] offset:4480\n\tds_write_addtid_b32 %[a15] offset:4800\n\t"
+                     "s_mov_b32 m0, %[sv]"
+                     : [sv] "=&s"(m0_saved)
+                     : [a0] "v"(V[0].x), [a1] "v"(V[0].y), [a2] "v"(V[1].x), [a3] "v"(V[1].y), [a4] "v"(V[2].x), [a5] "v"(V[2].y), [a6] "v"(V[3].x), [a7] "v"(V[3].y),
+                       [a8] "v"(V[4].x), [a9] "v"(V[4].y), [a10] "v"(V[5].x), [a11] "v"(V[5].y), [a12] "v"(V[6].x), [a13] "v"(V[6].y), [a14] "v"(V[7].x), [a15] "v"(V[7].y),
+                       [base] "s"(lds_base) : "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float4 r = rd[4 * j]; c[4 * j] = r.x; c[4 * j + 1] = r.y; c[4 * j + 2] = r.z; c[4 * j + 3] = r.w; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    v2f p0 = v2f{c[0], c[1]} + v2f{c[2], c[3]}, p1 = v2f{c[4], c[5]} + v2f{c[6], c[7]}, p2 = v2f{c[8], c[9]} + v2f{c[10], c[11]}, p3 = v2f{c[12], c[13]} + v2f{c[14], c[15]};
+    p0 += p1; p2 += p3; p0 += p2;
+    float t = p0.x + p0.y;
+    t += dpp_mov<0xB1>(t);   // lane ^ 1
+    t += dpp_mov<0x4E>(t);   // lane ^ 2: every lane of quad k holds the total of slot k
+    asm volatile("" : "+v"(t)); // (no instruction: keeps the second add in front of the one-lane-in-four branch, where it folds into a v_add_f32_dpp; sunk into the branch it is mov + mov_dpp + add)
+    if ((lane & 3u) == 0u) {
+        const uint32_t slot = lane >> 2;
+        if (ACC == 0) {
+            const uint32_t voff = lane;   // = 4 bytes x slot
+            asm volatile("global_atomic_add_f32 %0, %1, %2" ::"v"(voff), "v"(t), "s"(dst) : "memory");
+        } else if (ACC == 1) atomicMax(reinterpret_cast<uint32_t*>(dst) + slot, __float_as_uint(t) & 0x7fffffffu);
+        else {
+            const uint32_t mbits = reinterpret_cast<const uint32_t*>(dst)[slot];
+            if (mbits != 0u && t != 0.f) {
+                const int e = max(int((mbits >> 23) & 0xffu), 1) - 127;
+                atomicAdd(det64 + slot, (unsigned long long)__float2ll_rn(ldexpf(t, 40 - e)));
+            }
+        }
+    }
+}
+#endif
 
 // The EWA blend backward's NINE sums the same way (a [64][9] block: the odd stride is conflict-free for the row writes and for the column reads alike);
 // lanes 9..15 of every quarter read a duplicate column and are dropped at the atomic. Replaces wave_sum8_atomic + wave_sum1 + two atomics.

@@ -11,8 +11,8 @@ namespace lfs {
 // Per-Gaussian culling record (the silhouette conic of the alpha >= 1/255 ellipsoid in normalised camera coordinates)
 struct __attribute__((aligned(16))) CullRec { float4 a, b; };
 
-// UNIFORM_ORIGIN (global shutter): the record matrix is S^-1 R^T Rinv (camera-space ray directions -> Gaussian frame) and g = S^-1 R^T (o - mu);
-// rolling shutters keep S^-1 R^T and g = mu (per-pixel origins) and are never culled.
+// UNIFORM_ORIGIN (global shutter): the record matrix is S^-1 R^T Rinv (camera-space ray directions -> Gaussian frame) and g = S^-1 R^T (o - mu) - since round 6 both in
+// the rotated frame of LFS_REC_ROT (lfs_raster_common.cuh): U S^-1 R^T Rinv, |g|^2, |g|; rolling shutters keep S^-1 R^T and g = mu (per-pixel origins) and are never culled.
 template <bool UNIFORM_ORIGIN>
 LFS_DI void pack_gaussian(const CamDev& cam, const f3 mu, const float4 q, const float sc[3], const float opac, const float c0, const float c1, const float c2,
                           GaussRec& rec, CullRec& cr) {
@@ -36,11 +36,12 @@ LFS_DI void pack_gaussian(const CamDev& cam, const f3 mu, const float4 q, const 
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
-    f3 g = mu;
+    f3 g = mu, g_unscaled = mu;
     m3 Mr = M;
     if (UNIFORM_ORIGIN) {
         const float omx = cam.origin.x - mu.x, omy = cam.origin.y - mu.y, omz = cam.origin.z - mu.z;
         g = {M.m[0][0] * omx + M.m[0][1] * omy + M.m[0][2] * omz, M.m[1][0] * omx + M.m[1][1] * omy + M.m[1][2] * omz, M.m[2][0] * omx + M.m[2][1] * omy + M.m[2][2] * omz};
+        g_unscaled = g;
         const m3& Ri = cam.Rinv; // camera -> world: the kernels then work on CAMERA-space ray directions
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -58,6 +59,18 @@ LFS_DI void pack_gaussian(const CamDev& cam, const f3 mu, const float4 q, const 
     const float opac_field = __builtin_amdgcn_logf(opac);   // v_log_f32 = log2
 #else
     const float opac_field = opac;
+#endif
+#if LFS_REC_ROT
+    if (UNIFORM_ORIGIN) { // the record in the frame in which g lies on the third axis (lfs_raster_common.cuh, LFS_REC_ROT): rows of U M' (one rounding, from double), G^2, G
+        RotFrame F;
+        rot_frame(g_unscaled, F);
+        m3 Mu;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rot_apply(F, Mr.m[0][c], Mr.m[1][c], Mr.m[2][c], Mu.m[0][c], Mu.m[1][c], Mu.m[2][c]);
+        Mr = Mu;
+        const float G = float(F.len * double(REC_SCALE));
+        g = {G * G, 0.f, G};
+    }
 #endif
     rec.r0 = make_float4(Mr.m[0][0], Mr.m[0][1], Mr.m[0][2], g.x);
     rec.r1 = make_float4(Mr.m[1][0], Mr.m[1][1], Mr.m[1][2], g.y);

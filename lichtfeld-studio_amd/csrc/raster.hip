@@ -260,6 +260,25 @@ struct RayEval { f3 om, w, q; float t, vis, rl; }; // LFS_REC_LOG2: w = c w_true
 template <int MODE>
 LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& d, RayEval& e) {
     e.om = {0.f, 0.f, 0.f};
+#if LFS_REC_ROT
+    if (MODE == RAY_GLOBAL) { // the record lives in the frame in which g = (0, 0, G) (lfs_raster_common.cuh, LFS_REC_ROT): |w|^2 = G^2 m / l, no difference of large numbers anywhere
+        const f3 q{fma3(rec.r0.x, d.x, rec.r0.y, d.y, rec.r0.z, d.z),
+                   fma3(rec.r1.x, d.x, rec.r1.y, d.y, rec.r1.z, d.z),
+                   fma3(rec.r2.x, d.x, rec.r2.y, d.y, rec.r2.z, d.z)};
+        const float m = __builtin_fmaf(q.y, q.y, q.x * q.x);
+        const float l = __builtin_fmaf(q.z, q.z, m);
+        const float rl = fast_rcp(l);      // l == 0 (inactive lane: d = 0; degenerate record): inf, and m = q.z = 0 - the two products below are v_mul_legacy_f32 (0 * inf = 0): u = 0, t = 0, w = 0
+        const float u = mul_zero(m, rl);   // sin^2 of the angle between the ray and the direction to the centre
+        e.vis = __builtin_amdgcn_exp2f(__builtin_fmaf(-rec.r0.w, u, rec.r3.x));
+        e.t = rec.r2.w * mul_zero(q.z, rl);
+#ifndef LFS_EMULATE
+        asm volatile("" ::"s"(rec.r1.w), "s"(rec.r2.w)); // (no instruction: the unused fields of the record - r1.w, and G in the forward - stay "used", so the record still arrives as ONE s_load_dwordx16; without it the compiler splits the load into two to four)
+#endif
+        e.q = q; e.rl = rl;
+        e.w = {-e.t * q.x, -e.t * q.y, rec.r2.w * u};
+        return;
+    }
+#endif
     f3 gro;
     if (MODE != RAY_ROLLING) gro = {rec.r0.w, rec.r1.w, rec.r2.w};
     else {
@@ -453,6 +472,12 @@ struct MseFuse { const float* render; const float* target; float scale; float* l
 #ifndef LFS_BWD_LDS_REDUCE
 #define LFS_BWD_LDS_REDUCE 1   // the 16-value wave reduction through an LDS transpose instead of register swaps (lfs_raster_common.cuh). Measured on SYN-B, same box,
 #endif                         // 3 pairs (profiles/r03/raster_bwd_lds_reduce_ab.txt): raster_bwd 0.621 - 0.624 -> 0.534 - 0.541 ms; 0 = the register transpose of rounds 1 - 2
+#ifndef LFS_BWD_ALPHA0
+#define LFS_BWD_ALPHA0 1   // (round 6) invalid lanes of a backward evaluation carry alpha = 0 instead of selects on T and fac, and the running tail - B is ONE variable: -2 VALU per evaluation
+#endif
+#if LFS_BWD_ALPHA0 && LFS_SEL_E64
+#error "LFS_BWD_ALPHA0 is written for the bool form of the conditions"
+#endif
 #ifndef LFS_BWD_PK
 #define LFS_BWD_PK 1   // the backward's gradient products and the first two levels of its 16-value reduction on register pairs (v_pk_mul_f32 / v_pk_add_f32): 47 fewer
 #endif                 // VALU instructions in the kernel (-12 per evaluation), bit-identical sums; measured 0.621 - 0.631 -> 0.611 - 0.617 ms (same box, 3 pairs)
@@ -468,8 +493,13 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     float* __restrict__ acc, float* __restrict__ v_colors_extra, const MseFuse mse = MseFuse{}) {
     const uint32_t n_tiles = tw * th, total_tiles = C * n_tiles;
 #if LFS_BWD_LDS_REDUCE
-    __shared__ __attribute__((aligned(16))) float s_red[(LFS_RASTER_WAVE_BLOCKS ? 1 : 4) * RED_SCRATCH_FLOATS]; // one transpose block per wavefront (wave_sum16_atomic_lds)
-    float* const red_scratch = s_red + (threadIdx.x >> 6) * RED_SCRATCH_FLOATS;
+    constexpr int RED_BLOCK = (LFS_RED_QUAD_ASM && RED_QUAD_SCRATCH_FLOATS > RED_SCRATCH_FLOATS) ? RED_QUAD_SCRATCH_FLOATS : RED_SCRATCH_FLOATS;
+    __shared__ __attribute__((aligned(16))) float s_red[(LFS_RASTER_WAVE_BLOCKS ? 1 : 4) * RED_BLOCK]; // one transpose block per wavefront (wave_sum16_atomic_lds / _quad)
+    float* const red_scratch = s_red + (threadIdx.x >> 6) * RED_BLOCK;
+#if LFS_RED_QUAD_ASM
+    const uint32_t red_base = __builtin_amdgcn_readfirstlane(uint32_t(reinterpret_cast<uintptr_t>(red_scratch)));   // LDS byte address of the block (low half of the flat address)
+    const float4* const red_rd = reinterpret_cast<const float4*>(red_scratch + ((threadIdx.x & 63u) >> 2) * RED_QROW + 4u * (threadIdx.x & 3u));
+#endif
 #endif
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
     if (!cc.in_grid) return;
@@ -554,6 +584,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         RayEval re;
         ray_eval<MODE>(rec, ro, rd, re);
 #if LFS_BWD_REORTH
+        if (!(LFS_REC_ROT && MODE == RAY_GLOBAL)) // (the rotated records of LFS_REC_ROT form w without a difference: nothing to take out)
         {   // w = gro - t q is the difference of two vectors of length |o - mu| / s_min: for a FLAT Gaussian (one scale 20 - 100 x below the others, 5 units away: 1e4) its
             // component ALONG q carries an absolute rounding error of ulp(1e4) ~ 1e-3 - harmless in |w|^2 (alpha above is computed from the un-corrected w, bit-identical
             // to the forward), but dL/dgro = -s w is multiplied by 1 / s_min again in the finish pass. w is orthogonal to q by construction: one Gram-Schmidt step takes
@@ -586,6 +617,15 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 
         // Invalid lanes are masked by zeroing three scalars (fac, v_op, and through it s): every reduced value below is
         // a product with one of them. (All factors are finite for an inactive lane: its direction is 0, so w = gro, t = 0.)
+#if LFS_BWD_ALPHA0
+        // an invalid lane takes part with alpha = 0: 1 / (1 - 0) = 1 exactly (v_rcp_f32 is exact at 1: tests/test_gpu_raster.py), so its T is multiplied by 1 and its
+        // fac is 0 * T - one select instead of the two on T and fac
+        const float alpha_v = valid ? alpha : 0.f;
+        const float ra = fast_rcp(1.f - alpha_v);
+        const float Tn = T * ra;
+        T = Tn;
+        const float fac = alpha_v * Tn;
+#else
         const float ra = fast_rcp(1.f - alpha);
         const float Tn = T * ra;
 #if LFS_SEL_E64
@@ -594,6 +634,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 #else
         T = valid ? Tn : T;
         const float fac = valid ? alpha * Tn : 0.f;
+#endif
 #endif
         float v[16], v_extra = 0.f, cv;
         if (CDIM <= 3) {
@@ -607,8 +648,13 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
             for (int k = 1; k < CDIM; ++k) cv = __builtin_fmaf(cp[k], vc[k], cv);
         }
         // dL/dalpha = (tail - B) / (1 - alpha) + T (c . v_c), B = sum over the entries behind of fac_j (c_j . v_c)
+#if LFS_BWD_ALPHA0
+        const float v_alpha = __builtin_fmaf(ra, tail, Tn * cv);   // `tail` carries tail - B: one fma per entry instead of a subtraction and an fma
+        tail = __builtin_fmaf(-fac, cv, tail);
+#else
         const float v_alpha = __builtin_fmaf(ra, tail - Bsum, Tn * cv);
         Bsum = __builtin_fmaf(fac, cv, Bsum);
+#endif
 #pragma unroll
         for (int k = 0; k < CDIM; ++k) {
             const float vrgb = fac * vc[k];
@@ -633,6 +679,21 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 #if LFS_BWD_PK
         if (CDIM == 3 && MODE == RAY_GLOBAL) { // the 18 products and the first two reduction levels on register PAIRS (v_pk_mul_f32 / v_pk_add_f32)
             v2f V[8];
+#if LFS_REC_ROT
+            // w = (-t q.x, -t q.y, G u): a = s w straight from q (one packed product for the two components that are multiples of q)
+            // Slots 9 .. 11 of the row hold (a.z, a.x, a.y) in this form - the pair (a.x, a.y) is used as it comes out of the packed product; finish_geometry puts them back.
+            const float nst = -(sgeo * re.t);
+            const v2f axy = v2f{re.q.x, re.q.y} * nst;
+            const float az = re.w.z * sgeo;
+            const v2f vgxy = axy * re.t;
+            const float vgz = az * re.t;
+            V[0] = v2f{rd.x, rd.y} * vgxy.x;
+            V[1] = v2f{vgxy.x * rd.z, vgxy.y * rd.x};
+            V[2] = v2f{rd.y, rd.z} * vgxy.y;
+            V[3] = v2f{rd.x, rd.y} * vgz;
+            V[4] = v2f{vgz * rd.z, az};
+            V[5] = axy;
+#else
             const float ax = re.w.x * sgeo;
             const v2f ayz = v2f{re.w.y, re.w.z} * sgeo;
             const float vgx = ax * re.t;
@@ -643,9 +704,12 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
             V[3] = v2f{rd.x, rd.y} * vgyz.y;
             V[4] = v2f{vgyz.y * rd.z, ax};
             V[5] = ayz;
+#endif
             V[6] = v2f{v_op, fac * vc[0]};
             V[7] = v2f{vc[1], vc[2]} * fac;
-#if LFS_BWD_LDS_REDUCE
+#if LFS_BWD_LDS_REDUCE && LFS_RED_QUAD_ASM
+            wave_sum16_atomic_quad<ACC>(V, acc + size_t(uint32_t(e.x)) * ACC_STRIDE, lane, red_base, red_rd, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
+#elif LFS_BWD_LDS_REDUCE
             wave_sum16_atomic_lds<ACC>(V, acc + size_t(e.x) * ACC_STRIDE, lane, red_scratch, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
 #else
             wave_sum16_atomic_pk<ACC>(V, acc + size_t(e.x) * ACC_STRIDE, lane, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
@@ -665,7 +729,8 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
             v[3] -= a.y * om.x; v[4] -= a.y * om.y; v[5] -= a.y * om.z;
             v[6] -= a.z * om.x; v[7] -= a.z * om.y; v[8] -= a.z * om.z;
         }
-        v[9] = a.x; v[10] = a.y; v[11] = a.z;
+        if (LFS_REC_ROT && MODE == RAY_GLOBAL) { v[9] = a.z; v[10] = a.x; v[11] = a.y; } // (the slot order of the rotated records: see the packed form above)
+        else { v[9] = a.x; v[10] = a.y; v[11] = a.z; }
         wave_sum16_atomic<ACC>(v, acc + size_t(e.x) * ACC_STRIDE, lane, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
         if (CDIM > 3) {
 #pragma unroll
@@ -682,7 +747,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 // this file allows contraction - round 6: a third inlined copy of the fused form came out one ulp off in dL/dmeans, the compiler fuses a*b + c*d differently per context).
 // ADDS to vm / vq / vs (the operator form sums over cameras).
 template <bool UNIFORM_ORIGIN>
-LFS_DI void finish_geometry(const float4 q, const float (&is)[3], const float (&A)[9], const f3 G, const f3 mu, const CamDev& cam, float (&vm)[3], float (&vq)[4], float (&vs)[3]) {
+LFS_DI void finish_geometry(const float4 q, const float (&is)[3], const float (&A_in)[9], const f3 G_in, const f3 mu, const CamDev& cam, float (&vm)[3], float (&vq)[4], float (&vs)[3]) {
 #pragma clang fp contract(off)
     m3 R;
     float qw = q.x, qx = q.y, qy = q.z, qz = q.w;
@@ -699,6 +764,23 @@ LFS_DI void finish_geometry(const float4 q, const float (&is)[3], const float (&
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
+#if LFS_REC_ROT
+    float Au[9]; f3 Gu = G_in;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Au[k] = A_in[k];
+    if (UNIFORM_ORIGIN) { // the sums were accumulated in the record's rotated frame (lfs_raster_common.cuh, LFS_REC_ROT): dL/dA = U^T dL/dA'', dL/dg = U^T dL/dg''
+        const float omx = cam.origin.x - mu.x, omy = cam.origin.y - mu.y, omz = cam.origin.z - mu.z;
+        const f3 g{M.m[0][0] * omx + M.m[0][1] * omy + M.m[0][2] * omz, M.m[1][0] * omx + M.m[1][1] * omy + M.m[1][2] * omz, M.m[2][0] * omx + M.m[2][1] * omy + M.m[2][2] * omz};
+        RotFrame F;
+        rot_frame(g, F);   // (the record's frame, bit for bit: lfs_raster_common.cuh)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rot_apply_t(F, A_in[c], A_in[3 + c], A_in[6 + c], Au[c], Au[3 + c], Au[6 + c]);
+        rot_apply_t(F, G_in.y, G_in.z, G_in.x, Gu.x, Gu.y, Gu.z);   // slots 9 .. 11 arrive as (z, x, y) (raster_bwd_kernel)
+    }
+    const float (&A)[9] = Au; const f3 G = Gu;
+#else
+    const float (&A)[9] = A_in; const f3 G = G_in;
+#endif
     // dL/dM (math rows r, cols c). Global shutter: the record matrix was M Rinv, so dL/dM = dL/d(M Rinv) Rinv^T
     m3 vM;
 #pragma unroll

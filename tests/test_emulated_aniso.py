@@ -4,7 +4,9 @@ have. Found by the differential fuzzer (tools/fuzz_emulated.py --oracle, seed 12
 dL/dgro by 1 / s_min again - without a correction dL/dmeans is off by 0.3 % at aspect 10 and by tens of percent at aspect 80, dL/dquats by 2 - 4 % at aspect 40 - 80, where the
 reference's cross-product form evaluated in fp32 (the oracle's float instantiation) stays at 1e-4. The forward image is not affected (|w|^2 is insensitive to the error).
 LFS_BWD_REORTH (one Gram-Schmidt step on w, seven FMA-class instructions per evaluation, alpha untouched) removes it: the DEFAULT since round 5 (timed and re-verified on
-the MI355X: DESIGN.md 6). Both builds are run here: the default must hold the oracle's own fp32 accuracy at every aspect ratio; the -DLFS_BWD_REORTH=0 build documents
+the MI355X: DESIGN.md 6). Round 6: the global-shutter kernels evaluate in a per-Gaussian ROTATED frame in which g lies on one axis (LFS_REC_ROT, lfs_raster_common.cuh): the
+foot vector is formed without a difference, the step has nothing left to remove there (the frame is built in double precision - in single precision its own rounding
+puts the offset back: v_means 5e-3 at aspect 80); -DLFS_REC_ROT=0 is the round-5 form, which the rolling-shutter kernels keep. All three builds are run here: the default must hold the oracle's own fp32 accuracy at every aspect ratio; the -DLFS_BWD_REORTH=0 build documents
 what the step is there for (so that nobody removes it as dead arithmetic). The same probe runs on the hardware in tests/test_gpu_aniso.py."""
 import json
 import os
@@ -43,8 +45,13 @@ def test_flat_gaussians_default_build_holds_fp32_accuracy(tmp_path):
     _holds_the_oracles_fp32_accuracy(_probe(str(tmp_path), ""))
 
 
+def test_round5_records_with_the_gram_schmidt_step_hold_fp32_accuracy(tmp_path):
+    """-DLFS_REC_ROT=0: the round-5 form (g in the record, w = g - t q, one Gram-Schmidt step in the backward) - what the rolling-shutter kernels still run."""
+    _holds_the_oracles_fp32_accuracy(_probe(str(tmp_path), "-DLFS_REC_ROT=0"))
+
+
 def test_without_the_reorthogonalisation_flat_gaussians_lose_their_position_gradient(tmp_path):
-    rows = _probe(str(tmp_path), "-DLFS_BWD_REORTH=0")
+    rows = _probe(str(tmp_path), "-DLFS_REC_ROT=0 -DLFS_BWD_REORTH=0")
     for r in rows:
         if 2 <= r["aspect"] <= 4:
             assert r["v_quats_hip"] < 5e-4 and r["v_means_hip"] < 5e-4 and r["v_scales_hip"] < 5e-4, r

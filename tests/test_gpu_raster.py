@@ -356,6 +356,26 @@ def test_deterministic_backward_mode_is_bit_reproducible(lfs, oracle_mod):
         assert torch.equal(a, b) and float(a.abs().max()) > 0
 
 
+def test_instruction_properties_the_backward_relies_on(tmp_path):
+    """tests/hw_probe.hip, compiled and run here: v_rcp_f32 is exact at 1.0 (and on every power of two), v_mul_legacy_f32 gives 0 * inf = 0 * NaN = 0 - what
+    LFS_BWD_ALPHA0 and mul_zero (raster.hip / lfs_raster_common.cuh, round 6) assume and what no parity bar would notice."""
+    import json
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "hw_probe")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hw_probe.hip")
+    r = subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", src, "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    print(d)
+    assert d["rcp_of_one_bits"] == "0x3f800000" and d["rcp_exact_on_powers_of_two"] == 1 and d["mul_legacy_zero_times_anything_is_zero"] == 1, d
+
+
 def test_lds_reduction_asm_block_agrees_with_the_compiler_generated_stores(lfs, tmp_path):
     """The backward's 16-value (3DGUT) / 9-value (EWA) wave reduction stores its values with ds_write_addtid_b32 from an inline-asm block that sets M0 (saved and
     restored inside the block, lfs_raster_common.cuh). The second library of the build (build.build_variants: -DLFS_RED_ADDTID=0, plain ds_write2_b32 stores the

@@ -29,6 +29,8 @@ def main():
         import lichtfeld_studio_amd as lfs
         from lichtfeld_studio_amd import ops
         cm, st = lfs.CameraModelType(0), lfs.ShutterType(4)
+        if on_gpu and "--deterministic" in sys.argv:   # order-independent accumulation (debug bit 4): the table is then the same on every run - with float atomics dL/dscales moves by 1e-4 .. 1e-3 between runs
+            lfs.load_library().lfs_set_debug_flags(16)
         print("image  thin scale  aspect | v_quats: HIP / oracle-fp32 (rel. to fp64) | v_scales: HIP / oracle-fp32 | v_means: HIP / oracle-fp32 | forward: max |colour - fp64 oracle|")
         for size in (48,):
             for thin in (0.04, 0.01, 0.004, 0.002, 0.001, 0.0005):
