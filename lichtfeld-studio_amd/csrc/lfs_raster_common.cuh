@@ -31,6 +31,20 @@ constexpr int ACC_STRIDE = 16; // A(9) | G(3) | opacity | rgb(3)
 #if LFS_REC_ROT && !LFS_REC_LOG2
 #error "LFS_REC_ROT is written for the LFS_REC_LOG2 records"
 #endif
+// LFS_ACC_SYM (round 6, with LFS_REC_ROT): what the backward accumulates per Gaussian. With a = s w (s = alpha_raw dL/dalpha_raw) the gradients of the record are
+// dL/dq = t a and dL/dg = -a, so dL/dM = sum (t a (x) d - a (x) (o - mu)) = -sum a (x) (o - mu - t d) - and o - mu - t d is M^-1 w, the closest point of the ray in
+// world space. Hence dL/dM = -B M^-T with the SYMMETRIC B = sum s w w^T: six sums instead of the nine of dL/dA plus three of them again in dL/dg, no ray direction and
+// no second use of t in the products (10 VALU instead of 15 per evaluation, 13 LDS rows instead of 16), and dL/dscale_c = B_cc / s_c comes out of the finish pass WITHOUT
+// the difference it used to be: for a flat Gaussian the thin axis' dL/dA . M and dL/dg . g are 1e6 times their sum, which is why dL/dscales of the thin axis was
+// "fp32-limited for every implementation" (the reference's per-pixel form included: tools/aniso_probe.py, 3e-4 .. 2e-3 at aspect 80). The finish pass rotates B'' and
+// sum a'' back with a single-precision frame: a frame 1e-7 away from the record's now mixes 1e-7 of B's large entries into small ones that nothing amplifies.
+// Row: B''xx, B''yy, B''xz, B''yz, B''xy, B''zz | a''x, a''y, a''z | - - - | opac dL/dopac | dL/drgb. 0 = dL/dA (9) | -dL/dg (3) | ... (rounds 1 - 6; the rolling-shutter kernels keep it).
+#ifndef LFS_ACC_SYM
+#define LFS_ACC_SYM LFS_REC_ROT
+#endif
+#if LFS_ACC_SYM && !LFS_REC_ROT
+#error "LFS_ACC_SYM needs the rotated records (LFS_REC_ROT)"
+#endif
 constexpr float REC_SCALE = 0.84932180028801904f;   // sqrt(0.5 * log2(e))
 constexpr float REC_UNSCALE = 1.17741002251547469f; // 1 / REC_SCALE = sqrt(2 ln 2)
 
@@ -179,17 +193,13 @@ LFS_DI f3 cross_fma(const f3& a, const f3& b) {
     return {__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)), __builtin_fmaf(a.x, b.y, -(b.x * a.y))};
 }
 // The frame of LFS_REC_ROT: an orthonormal U (rows) whose third axis is g / |g|, U g = (0, 0, |g|); g = 0 or not finite: some frame, nothing depends on which. Duff et al.
-// 2017 ("Building an orthonormal basis, revisited"): branch-free, no cancellation for any direction. In DOUBLE precision, with the two products it is used in, and rebuilt
-// bit for bit by the finish pass from the same fp32 g. Every cheaper form was measured (tools/aniso_probe.py; profiles/r06/lease21 .. 23):
-//   - the frame in single precision: U g is (0, 0, |g|) only to 6e-8 |g|, and for a flat Gaussian |g| is 1e4 where the foot vector is 1 - an offset of 6e-4 in w that the
-//     evaluation knows nothing about: dL/dmeans 5e-3 off at aspect 80, the forward 2.6e-4;
-//   - double in the record, single in the finish pass: two frames 1e-7 apart put 1e-7 of the large rows of dL/dA into the thin one, which the scale gradient multiplies by
-//     1 / s_min^2: dL/dscales 1.5e-4 -> 3.0e-4 off at aspect 10;
-//   - one single-precision frame on both sides with its residual (U g).xy sheared away: the frame is then orthonormal to 1e-7 only, t carries that strain against the
-//     |g| = 1e4 it is multiplied with, and dL/dscale of the thin axis - a difference of two sums that cancel to 1e-6 - is 2e-3 off at aspect 80 (double frame: 5e-4).
-// Cost: the fused tail kernel sits at 224 of the 256 VGPRs its two wavefronts per SIMD allow, and a double-precision frame written naively took it to 258 and ONE wavefront
-// (0.29 -> 0.40 ms). Hence the form below: single-precision v_rsq / v_rcp seeds with two Newton steps in double instead of IEEE sqrt / division, eight coefficients
-// instead of a matrix, and rot_apply_t one vector at a time between scheduling barriers - the compiler otherwise converts and multiplies all twelve at once.
+// 2017 ("Building an orthonormal basis, revisited"): branch-free, no cancellation for any direction. The RECORD's frame is built in DOUBLE precision, with the product
+// U M' it is used in: in single precision U g is (0, 0, |g|) only to 6e-8 |g|, and for a flat Gaussian |g| is 1e4 where the foot vector is 1 - an offset of 6e-4 in w
+// that the evaluation knows nothing about (measured: tools/aniso_probe.py, dL/dmeans 5e-3 off at aspect 80, the forward 2.6e-4; profiles/r06/lease21). Single-precision
+// v_rsq / v_rcp seeds with two Newton steps in double instead of IEEE sqrt / division. What else was measured on the way (lease 21 - 23, with the dL/dA accumulators of
+// LFS_ACC_SYM = 0, whose finish pass needs the record's frame bit for bit): the double frame rebuilt in the fused tail kernel took it from 224 to 258 VGPRs and ONE wavefront
+// per SIMD (0.29 -> 0.40 ms); a single-precision frame there doubled the error of dL/dscales (1e-7 of dL/dA's large rows lands in the thin one); one single-precision frame
+// on both sides with its residual sheared away strains t against the |g| = 1e4 it multiplies (dL/dscales 2e-3 off at aspect 80).
 struct RotFrame { double nx, ny, nz, b, c00, c11, sgb, sgnx, len; };
 LFS_DI void rot_frame(const f3 g, RotFrame& F) {
 #pragma clang fp contract(off)
@@ -220,7 +230,7 @@ LFS_DI void rot_apply(const RotFrame& F, const float v0, const float v1, const f
     o1 = float(F.b * x + F.c11 * y - F.ny * z);
     o2 = float(F.nx * x + F.ny * y + F.nz * z);
 }
-LFS_DI void rot_apply_t(const RotFrame& F, const float v0, const float v1, const float v2, float& o0, float& o1, float& o2) { // U^T v
+LFS_DI void rot_apply_t(const RotFrame& F, const float v0, const float v1, const float v2, float& o0, float& o1, float& o2) { // U^T v (the finish pass of LFS_ACC_SYM = 0: one vector at a time between scheduling barriers, for the tail kernel's register budget)
 #pragma clang fp contract(off)
     const double x = v0, y = v1, z = v2;
     o0 = float(F.c00 * x + F.b * y + F.nx * z);
@@ -229,6 +239,18 @@ LFS_DI void rot_apply_t(const RotFrame& F, const float v0, const float v1, const
 #ifndef LFS_EMULATE
     __builtin_amdgcn_sched_barrier(0);
 #endif
+}
+// The same frame in single precision: the finish pass of LFS_ACC_SYM (see there for why 1e-7 of disagreement with the record's frame is harmless on that side)
+LFS_DI void rot_frame_f32(const f3 g, m3& U) {
+#pragma clang fp contract(off)
+    const float len2 = g.x * g.x + g.y * g.y + g.z * g.z;
+    float nx = 0.f, ny = 0.f, nz = 1.f;
+    if (len2 > 1e-36f && len2 < 1e36f) { const float inv = fast_rsq(len2); nx = g.x * inv; ny = g.y * inv; nz = g.z * inv; }
+    const float sg = nz >= 0.f ? 1.f : -1.f;
+    const float a = -fast_rcp(sg + nz), b = nx * ny * a;
+    U.m[0][0] = 1.f + sg * nx * nx * a; U.m[0][1] = sg * b; U.m[0][2] = -sg * nx;
+    U.m[1][0] = b; U.m[1][1] = sg + ny * ny * a; U.m[1][2] = -ny;
+    U.m[2][0] = nx; U.m[2][1] = ny; U.m[2][2] = nz;
 }
 
 // Walk a cell list with the records arriving through the SCALAR unit: two groups of two record
@@ -508,12 +530,26 @@ constexpr int RED_QUAD_SCRATCH_FLOATS = 16 * RED_QROW;
 #define LFS_RED_QUAD_ASM 0
 #endif
 #if LFS_RED_QUAD_ASM
-template <int ACC = 0>
+// SKIP_9_11 (LFS_ACC_SYM rows: slots 9 .. 11 carry nothing): their three stores are left out, their quads read whatever the block held and must not reach the atomic -
+// the caller's `atomic_lane` ((lane & 3) == 0 and slot not in 9 .. 11) says which lanes do.
+template <int ACC = 0, bool SKIP_9_11 = false>
 LFS_DI void wave_sum16_atomic_quad(const v2f (&V)[8], float* __restrict__ dst /* wave-uniform */, const uint32_t lane, const uint32_t lds_base, const float4* __restrict__ rd /* this lane's read pointer */,
-                                   unsigned long long* __restrict__ det64 = nullptr) {
+                                   const bool atomic_lane, unsigned long long* __restrict__ det64 = nullptr) {
     float c[16];
     {
         uint32_t m0_saved; // (M0 saved and put back inside the block: see wave_sum16_atomic_lds)
+        if (SKIP_9_11)
+        asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[base]\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %[a0] offset:0\n\tds_write_addtid_b32 %[a1] offset:320\n\tds_write_addtid_b32 %[a2] offset:640\n\tds_write_addtid_b32 %[a3] offset:960\n\t"
+                     "ds_write_addtid_b32 %[a4] offset:1280\n\tds_write_addtid_b32 %[a5] offset:1600\n\tds_write_addtid_b32 %[a6] offset:1920\n\tds_write_addtid_b32 %[a7] offset:2240\n\t"
+                     "ds_write_addtid_b32 %[a8] offset:2560\n\t"
+                     "ds_write_addtid_b32 %[a12] offset:3840\n\tds_write_addtid_b32 %[a13] offset:4160\n\tds_write_addtid_b32 %[a14] offset:4480\n\tds_write_addtid_b32 %[a15] offset:4800\n\t"
+                     "s_mov_b32 m0, %[sv]"
+                     : [sv] "=&s"(m0_saved)
+                     : [a0] "v"(V[0].x), [a1] "v"(V[0].y), [a2] "v"(V[1].x), [a3] "v"(V[1].y), [a4] "v"(V[2].x), [a5] "v"(V[2].y), [a6] "v"(V[3].x), [a7] "v"(V[3].y),
+                       [a8] "v"(V[4].x), [a12] "v"(V[6].x), [a13] "v"(V[6].y), [a14] "v"(V[7].x), [a15] "v"(V[7].y),
+                       [base] "s"(lds_base) : "memory");
+        else
         asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[base]\n\ts_nop 0\n\t"
                      "ds_write_addtid_b32 %[a0] offset:0\n\tds_write_addtid_b32 %[a1] offset:320\n\tds_write_addtid_b32 %[a2] offset:640\n\tds_write_addtid_b32 %[a3] offset:960\n\t"
                      "ds_write_addtid_b32 %[a4] offset:1280\n\tds_write_addtid_b32 %[a5] offset:1600\n\tds_write_addtid_b32 %[a6] offset:1920\n\tds_write_addtid_b32 %[a7] offset:2240\n\t"
@@ -535,7 +571,7 @@ LFS_DI void wave_sum16_atomic_quad(const v2f (&V)[8], float* __restrict__ dst /*
     t += dpp_mov<0xB1>(t);   // lane ^ 1
     t += dpp_mov<0x4E>(t);   // lane ^ 2: every lane of quad k holds the total of slot k
     asm volatile("" : "+v"(t)); // (no instruction: keeps the second add in front of the one-lane-in-four branch, where it folds into a v_add_f32_dpp; sunk into the branch it is mov + mov_dpp + add)
-    if ((lane & 3u) == 0u) {
+    if (atomic_lane) {
         const uint32_t slot = lane >> 2;
         if (ACC == 0) {
             const uint32_t voff = lane;   // = 4 bytes x slot

@@ -499,6 +499,8 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 #if LFS_RED_QUAD_ASM
     const uint32_t red_base = __builtin_amdgcn_readfirstlane(uint32_t(reinterpret_cast<uintptr_t>(red_scratch)));   // LDS byte address of the block (low half of the flat address)
     const float4* const red_rd = reinterpret_cast<const float4*>(red_scratch + ((threadIdx.x & 63u) >> 2) * RED_QROW + 4u * (threadIdx.x & 3u));
+    constexpr bool RED_SKIP = LFS_ACC_SYM && MODE == RAY_GLOBAL && CDIM == 3;   // (slots 9 .. 11 of the LFS_ACC_SYM row are empty)
+    const bool red_atomic_lane = (threadIdx.x & 3u) == 0u && !(RED_SKIP && ((threadIdx.x & 63u) >> 2) >= 9u && ((threadIdx.x & 63u) >> 2) <= 11u);
 #endif
 #endif
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
@@ -679,7 +681,18 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 #if LFS_BWD_PK
         if (CDIM == 3 && MODE == RAY_GLOBAL) { // the 18 products and the first two reduction levels on register PAIRS (v_pk_mul_f32 / v_pk_add_f32)
             v2f V[8];
-#if LFS_REC_ROT
+#if LFS_ACC_SYM
+            // B'' = a (x) w (symmetric: six products) and a = s w - lfs_raster_common.cuh, LFS_ACC_SYM. Slots: xx, yy | xz, yz | xy, zz | ax, ay | az
+            const v2f wxy = v2f{re.w.x, re.w.y};
+            const v2f axy = wxy * sgeo;
+            const float az = re.w.z * sgeo;
+            V[0] = axy * wxy;
+            V[1] = axy * re.w.z;
+            V[2] = v2f{axy.x * wxy.y, az * re.w.z};
+            V[3] = axy;
+            V[4] = v2f{az, 0.f};
+            V[5] = v2f{0.f, 0.f};
+#elif LFS_REC_ROT
             // w = (-t q.x, -t q.y, G u): a = s w straight from q (one packed product for the two components that are multiples of q)
             // Slots 9 .. 11 of the row hold (a.z, a.x, a.y) in this form - the pair (a.x, a.y) is used as it comes out of the packed product; finish_geometry puts them back.
             const float nst = -(sgeo * re.t);
@@ -708,7 +721,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
             V[6] = v2f{v_op, fac * vc[0]};
             V[7] = v2f{vc[1], vc[2]} * fac;
 #if LFS_BWD_LDS_REDUCE && LFS_RED_QUAD_ASM
-            wave_sum16_atomic_quad<ACC>(V, acc + size_t(uint32_t(e.x)) * ACC_STRIDE, lane, red_base, red_rd, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
+            wave_sum16_atomic_quad<ACC, RED_SKIP>(V, acc + size_t(uint32_t(e.x)) * ACC_STRIDE, lane, red_base, red_rd, red_atomic_lane, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
 #elif LFS_BWD_LDS_REDUCE
             wave_sum16_atomic_lds<ACC>(V, acc + size_t(e.x) * ACC_STRIDE, lane, red_scratch, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
 #else
@@ -718,6 +731,17 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         }
 #endif
         const f3 a = re.w * sgeo;                                           // = -dL/dgro (the sign is undone in raster_finish_kernel)
+        if (LFS_ACC_SYM && MODE == RAY_GLOBAL) { // the symmetric row (see the packed form above): B'' xx, yy, xz, yz, xy, zz | a | - - -
+            v[0] = a.x * re.w.x; v[1] = a.y * re.w.y; v[2] = a.x * re.w.z; v[3] = a.y * re.w.z; v[4] = a.x * re.w.y; v[5] = a.z * re.w.z;
+            v[6] = a.x; v[7] = a.y; v[8] = a.z; v[9] = 0.f; v[10] = 0.f; v[11] = 0.f;
+            wave_sum16_atomic<ACC>(v, acc + size_t(e.x) * ACC_STRIDE, lane, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
+            if (CDIM > 3) {
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) v_extra += __shfl_xor(v_extra, m, 64);
+                if (lane == 0) unsafeAtomicAdd(v_colors_extra + size_t(e.x) * CDIM + 3, v_extra);
+            }
+            return;
+        }
         const f3 vg = a * re.t;                                             // dL/dq, q = (record matrix) d
         // dL/d(record matrix) = vg (x) d  [- a (x) (o - mu) per pixel only when the origin varies]
         v[0] = vg.x * rd.x; v[1] = vg.x * rd.y; v[2] = vg.x * rd.z;
@@ -764,7 +788,52 @@ LFS_DI void finish_geometry(const float4 q, const float (&is)[3], const float (&
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) M.m[r][c] = is[r] * R.m[c][r];
-#if LFS_REC_ROT
+#if LFS_ACC_SYM
+    if (UNIFORM_ORIGIN) { // the symmetric row (lfs_raster_common.cuh, LFS_ACC_SYM): A_in = B'' (xx, yy, xz, yz, xy, zz) | sum a'', every slot times REC_UNSCALE by the caller; G_in: empty slots
+        const float omx = cam.origin.x - mu.x, omy = cam.origin.y - mu.y, omz = cam.origin.z - mu.z;
+        const f3 gv{M.m[0][0] * omx + M.m[0][1] * omy + M.m[0][2] * omz, M.m[1][0] * omx + M.m[1][1] * omy + M.m[1][2] * omz, M.m[2][0] * omx + M.m[2][1] * omy + M.m[2][2] * omz};
+        m3 U;
+        rot_frame_f32(gv, U);
+        float Bp[3][3];   // B'' = sum a'' (x) w'', two factors of c in it: the second REC_UNSCALE here
+        Bp[0][0] = A_in[0] * REC_UNSCALE; Bp[1][1] = A_in[1] * REC_UNSCALE; Bp[2][2] = A_in[5] * REC_UNSCALE;
+        Bp[0][2] = Bp[2][0] = A_in[2] * REC_UNSCALE; Bp[1][2] = Bp[2][1] = A_in[3] * REC_UNSCALE; Bp[0][1] = Bp[1][0] = A_in[4] * REC_UNSCALE;
+        float T[3][3], B[3][3];   // B = U^T B'' U: the sums in the Gaussian's own frame
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) T[k][c] = Bp[k][0] * U.m[0][c] + Bp[k][1] * U.m[1][c] + Bp[k][2] * U.m[2][c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) B[r][c] = U.m[0][r] * T[0][c] + U.m[1][r] * T[1][c] + U.m[2][r] * T[2][c];
+        const float as[3] = {U.m[0][0] * A_in[6] + U.m[1][0] * A_in[7] + U.m[2][0] * A_in[8], U.m[0][1] * A_in[6] + U.m[1][1] * A_in[7] + U.m[2][1] * A_in[8],
+                             U.m[0][2] * A_in[6] + U.m[1][2] * A_in[7] + U.m[2][2] * A_in[8]};   // sum a = -dL/dg
+        // mean: g = M (o - mu)  ->  dL/dmu = -M^T dL/dg = M^T sum a
+        vm[0] += M.m[0][0] * as[0] + M.m[1][0] * as[1] + M.m[2][0] * as[2];
+        vm[1] += M.m[0][1] * as[0] + M.m[1][1] * as[1] + M.m[2][1] * as[2];
+        vm[2] += M.m[0][2] * as[0] + M.m[1][2] * as[1] + M.m[2][2] * as[2];
+        // dL/dM = -B M^-T = -B S R^T. Scales: dL/ds_c = -(1 / s_c^2) (dL/dM R)_cc = B_cc / s_c - a sum of like-signed terms, where dL/dA . M + dL/dg . g cancelled to 1e-6.
+        // Rotation: dL/dR[r][c] = dL/dM[c][r] / s_c = -(1 / s_c) sum_k B[c][k] s_k R[r][k]
+        const float sk[3] = {1.f / is[0], 1.f / is[1], 1.f / is[2]};
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[r][c] = -is[c] * (B[c][0] * sk[0] * R.m[r][0] + B[c][1] * sk[1] * R.m[r][1] + B[c][2] * sk[2] * R.m[r][2]);
+        {   // quat_to_rotmat_vjp on the normalised quaternion
+            const float vw = 2.f * (qx * (g[2][1] - g[1][2]) + qy * (g[0][2] - g[2][0]) + qz * (g[1][0] - g[0][1]));
+            const float vx = 2.f * (-2.f * qx * (g[1][1] + g[2][2]) + qy * (g[1][0] + g[0][1]) + qz * (g[2][0] + g[0][2]) + qw * (g[2][1] - g[1][2]));
+            const float vy = 2.f * (qx * (g[1][0] + g[0][1]) - 2.f * qy * (g[0][0] + g[2][2]) + qz * (g[2][1] + g[1][2]) + qw * (g[0][2] - g[2][0]));
+            const float vz = 2.f * (qx * (g[2][0] + g[0][2]) + qy * (g[2][1] + g[1][2]) - 2.f * qz * (g[0][0] + g[1][1]) + qw * (g[1][0] - g[0][1]));
+            const float dq = vw * qw + vx * qx + vy * qy + vz * qz;
+            vq[0] += (vw - dq * qw) * qinv; vq[1] += (vx - dq * qx) * qinv; vq[2] += (vy - dq * qy) * qinv; vq[3] += (vz - dq * qz) * qinv;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vs[c] += B[c][c] * is[c];
+        return;
+    }
+    const float (&A)[9] = A_in; const f3 G = G_in;
+#elif LFS_REC_ROT
     float Au[9]; f3 Gu = G_in;
 #pragma unroll
     for (int k = 0; k < 9; ++k) Au[k] = A_in[k];

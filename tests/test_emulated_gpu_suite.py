@@ -51,6 +51,7 @@ SELECTION = {
     "test_gpu_raster": {"test_cell_culling_full_size_bit_identical": "1 M Gaussians at 1080p", "test_raster_bwd_is_linear_in_output_gradients_full_size": "1 M Gaussians at 1080p",
                         "test_deterministic_backward_mode_is_bit_reproducible": "the integer-atomic accumulation mode is compiled out of the emulated build (no 64-bit atomics to model)",
                         "test_lds_reduction_asm_block_agrees_with_the_compiler_generated_stores": "compares two GPU builds in a subprocess (ISA-level by definition)",
+                        "test_instruction_properties_the_backward_relies_on": "runs a hipcc-built probe on the device (v_rcp_f32 at 1.0, v_mul_legacy_f32): hardware by definition",
                         "test_cell_culling_is_conservative[huge_and_near]": "half a minute (culling-off walks of every tile list); [small] and [low_opacity] are taken",
                         "test_cell_culling_is_conservative[needles]": "as above", "test_cell_culling_is_conservative[flat_disks]": "as above (tools/fuzz_emulated.py --flat checks culling on / off on flat disks)"},
     "test_gpu_strategies": {"test_default_strategy_fused_refinement_one_host_read_same_result": "counts host synchronisations of a HIP stream",

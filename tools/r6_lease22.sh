@@ -16,7 +16,7 @@ import sys, json
 d = json.loads(sys.stdin.read()); print('[$v]', d['value'], d['ms_per_step'], d['roofline']['frac'], {k: v['avg_ms'] for k, v in d['kernels'].items()})"
   done; done; unset LFS_GSPLAT_LIB
 }
-ab ${AB_ROUNDS:-3} default ${AB_VARIANTS:-r6base} 2>&1 | tee $OUT/ab.txt
+ab ${AB_ROUNDS:-3} default ${AB_VARIANTS:-r6base r6nosym} 2>&1 | tee $OUT/ab.txt
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_default.json
 python -c "
 import json; d = json.load(open('$OUT/bench_default.json')); print('driver command:', d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('ops_route', {}).get('ms_per_step'))"

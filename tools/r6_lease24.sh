@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round 6, lease 24: the library with the rotated records + symmetric accumulators (LFS_REC_ROT / LFS_ACC_SYM / LFS_RED_QUAD / LFS_BWD_ALPHA0): whole GPU suite, the driver's
+# command x3, the round's rocprofv3 evidence (trace + 4 PMC passes of the driver's command, headline path only), configs[3] / configs[4] side lines
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; cd $REPO
+OUT=gpurun_out/r6_lease24; mkdir -p $OUT
+python -c "import lichtfeld_studio_amd as l; print(l.load_library().lfs_version().decode())" 2>&1 | tail -1 | tee $OUT/library.txt
+timeout 1800 python -m pytest tests/ -q -m gpu -p no:cacheprovider > $OUT/tests.log 2>&1; echo "tests rc $?: $(tail -1 $OUT/tests.log)"
+grep -n "^FAILED\|^ERROR" $OUT/tests.log | head -20
+for r in 1 2 3; do
+  timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_default_$r.json
+  python -c "
+import json; d = json.load(open('$OUT/bench_default_$r.json')); print('driver command:', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['config'].get('step_form'), d.get('ops_route', {}).get('ms_per_step'))"
+done 2>&1 | tee $OUT/driver_command.txt
+bash tools/profile.sh r06_lease24 > $OUT/profile.log 2>&1; head -40 gpurun_out/prof_r06_lease24/summary.txt | cut -c1-200
