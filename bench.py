@@ -561,7 +561,7 @@ def main() -> None:
         # DESIGN.md 7 is arithmetic (estimate: true), and which exchange is the headline (factored up to 16 views per step, flat beyond) was chosen from that arithmetic
         "multi_gpu": {"layout_choice": {"rule": "factored SH exchange while world x views_per_rank <= 16, flat all-reduce beyond", "basis": "arithmetic, not a measurement", "estimate": True},
                       "inter_gpu_collectives_before_this_run": "none: rounds 1 - 5 were developed on single-GPU boxes (gloo ranks on CPU / sharing one GPU, RCCL at world size 1)",
-                      "expected_speedup_at_8_gpus": {"factored_1_view_per_rank": 5.7, "flat_1_view_per_rank": 4.2, "configs3_8_views_per_rank": 7.0, "estimate": True,
+                      "expected_speedup_at_8_gpus": {"factored_1_view_per_rank": 5.2, "factored_chunked_gather": 5.9, "sh_sharded_1_view_per_rank": 6.0, "flat_1_view_per_rank": 4.1, "configs3_8_views_per_rank": 7.0, "estimate": True,
                                                      "source": "DESIGN.md 7 (per-rank compute measured at world size 1 + assumed xGMI bus bandwidth)"}},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
         "kernels_source": (f"{table_steps} event-bracketed warm-up steps BEFORE the timed region (every kernel scope between two hipEventRecord: the events stretch a step by a few per cent, "

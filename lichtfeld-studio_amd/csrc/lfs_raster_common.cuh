@@ -8,7 +8,7 @@ namespace lfs {
 
 struct __attribute__((aligned(16))) GaussRec { float4 r0, r1, r2, r3; };
 
-constexpr int ACC_STRIDE = 16; // A(9) | G(3) | opacity | rgb(3)
+constexpr int ACC_STRIDE = 16; // LFS_ACC_SYM (global shutter): B'' (6) | a'' (3) | - - - | opacity | rgb(3); otherwise A(9) | G(3) | opacity | rgb(3)
 
 // LFS_REC_LOG2 (round 3, the 3DGUT rasterizer): records carry M' = c M, g' = c g with c = sqrt(0.5 log2 e), and log2(opacity) in place of the opacity, so that
 //   alpha_raw = opac * exp(-0.5 |w|^2) = exp2(log2(opac) - |w'|^2),   w' = g' - t q' = c w  (t is scale-free)

@@ -4,27 +4,36 @@
 // host gsplat/Rasterization.cpp:20-261, helpers gsplat/Utils.cuh:80-194).
 //
 // CDNA4 design (not the reference's block-cooperative shared-memory batches):
-//  * pack   : one pass turns every Gaussian into a 64-byte record
-//             { M = S^-1 R^T (9), M(o-mu) or mu (3), opacity, rgb } — all the
+//  * pack   : one pass turns every Gaussian into a 64-byte record - all the
 //             per-Gaussian work the reference redoes per tile batch (rotmat,
 //             1/scale, matrix product) happens once per Gaussian, coalesced.
+//             Global shutter (round 6, LFS_REC_ROT): { U M (9), G^2, G, log2
+//             opacity, rgb } with M = c S^-1 R^T Rinv and U the rotation that
+//             puts g = M (o - mu) on the third axis: the distance of a ray to
+//             the centre is then |g| sin(angle) = G^2 m / l from the three
+//             components of q = U M d alone - no foot vector in the forward,
+//             no difference of large numbers anywhere (lfs_raster_common.cuh).
+//             Rolling shutters: { M (9), mu (3), ... }, per-pixel origins.
 //  * raster : a wavefront owns an 8x8 pixel cell of a tile and walks the tile's
 //             depth-sorted list ALONE: the list position is wave-uniform, so the
 //             record arrives through the scalar unit (s_load_dwordx16 into
-//             SGPRs, served by the scalar cache / L2) and feeds v_pk_fma_f32
+//             SGPRs, served by the scalar cache / L2) and feeds v_fma_f32
 //             directly. No LDS staging, no __syncthreads, no 64-lane broadcast
 //             reads; early-out, the alpha < 1/255 skip and the backward's
 //             "behind the last contributor" skip are per 8x8 cell (ballot),
 //             4x finer than the reference's 16x16 block.
-//  * bwd    : the chain rule through M is linear, so a lane only accumulates
-//             dL/dM (9), dL/d(gro) (3), dL/dopacity, dL/drgb = 16 floats; a
-//             permlane32/16-swap "transpose" reduction leaves the 16 wave sums
-//             in 16 lanes and ONE 64-byte-contiguous global_atomic_add_f32
-//             instruction per (wave, Gaussian) adds them to a [C*N][16]
-//             accumulator (the reference: 14 shuffle reductions x 5 steps + 14
-//             scalar atomics per (warp, Gaussian)).
+//  * bwd    : with a = s w (s = alpha dL/dalpha, w the foot vector) the record's
+//             gradient is dL/dM = -B M^-T, B = sum s w w^T, and dL/dg = -sum a
+//             (LFS_ACC_SYM): a lane accumulates B (6), a (3), dL/dopacity,
+//             dL/drgb = 13 floats; an LDS transpose (ds_write_addtid_b32 rows,
+//             ds_read_b128 columns, two quad-permute DPP adds) leaves the wave
+//             sums one per quad and ONE global_atomic_add_f32 instruction per
+//             (wave, Gaussian) adds them to a [C*N][16] accumulator (the
+//             reference: 14 shuffle reductions x 5 steps + 14 scalar atomics per
+//             (warp, Gaussian)). Rolling shutters: dL/dM (9) + dL/dg (3).
 //  * finish : one pass maps the accumulator through the quaternion / scale /
-//             mean vjp (done per (pixel, Gaussian) in the reference).
+//             mean vjp (done per (pixel, Gaussian) in the reference);
+//             dL/dscale_c = B_cc / s_c has no cancellation left in it.
 // Measured and removed in round 5 (commit f684d4b, profiles/r05/lease4/ab_fwdzero_off.txt): the forward kernel clearing the backward's accumulator rows on the side (two or three
 // 16-byte stores per lane at kernel start, instead of the 64 MB hipMemsetAsync in front of the backward: 9 - 10 us): raster_fwd 0.234 -> 0.247 ms, step +0.015 - 0.025 ms - stores
 // issued by a VALU-bound kernel are not free. Round 6 (profiles/r06/lease15_ab_tail_acc_clear.txt): the same 64 MB cleared by the step's PROJECTION kernel (four 16-byte stores per lane at its
