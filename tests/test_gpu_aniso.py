@@ -26,3 +26,6 @@ def test_flat_gaussians_hold_the_oracles_fp32_accuracy_on_the_gpu(lfs, tmp_path)
             continue
         for k in ("v_quats", "v_means", "v_scales"):
             assert x[k + "_hip"] <= max(4 * x[k + "_o32"], 3e-4), (k, x)
+        # round 6 (LFS_ACC_SYM): the scale and rotation gradients are sums of like-signed second moments - 8e-6 .. 3e-5 on the MI355X at every aspect ratio, float atomics
+        # included (the dL/dA form moved by 1e-4 .. 4e-3 between runs at aspect 80: profiles/r06/lease23_aniso_probe_noise.txt)
+        assert x["v_scales_hip"] < 1e-4 and x["v_quats_hip"] < 1e-4, x
