@@ -532,30 +532,68 @@ constexpr int RED_QUAD_SCRATCH_FLOATS = 16 * RED_QROW;
 #if LFS_RED_QUAD_ASM
 // SKIP_9_11 (LFS_ACC_SYM rows: slots 9 .. 11 carry nothing): their three stores are left out, their quads read whatever the block held and must not reach the atomic -
 // the caller's `atomic_lane` ((lane & 3) == 0 and slot not in 9 .. 11) says which lanes do.
+// LFS_RED_M0_ONCE: M0 (the base of the add-TID stores) is written ONCE by the kernel (raster_bwd_kernel's prologue) instead of saved / set / restored around every block of
+// stores (3 SALU + a wait state per evaluation). Nothing else in that kernel touches M0 on gfx950 (DS instructions do not need it since GFX9) - the compiler does not know
+// about the asm's use of it, so tests/test_kernel_resources.py holds that statement against the disassembly of the shipped kernels (exactly one write of m0).
+#ifndef LFS_RED_M0_ONCE
+#define LFS_RED_M0_ONCE 1
+#endif
+#if LFS_RED_M0_ONCE
+#define LFS_RED_M0_PROLOGUE "; m0 = %[base] (set in the kernel prologue), scratch %[sv]\n\t"
+#define LFS_RED_M0_EPILOGUE ""
+#else
+#define LFS_RED_M0_PROLOGUE "s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[base]\n\ts_nop 0\n\t"
+#define LFS_RED_M0_EPILOGUE "s_mov_b32 m0, %[sv]"
+#endif
+// LFS_RED_BUF_ATOMIC (ACC == 0): the 13 / 16 totals leave through ONE buffer atomic with no EXEC round trip and no 64-bit address arithmetic. The accumulator is
+// addressed as a raw buffer (descriptor built once per kernel: base = acc, num_records = its size in bytes); the row of the Gaussian is the instruction's SGPR offset
+// (the SAME e.x << 6 the record load uses: rows and records are both 64 B), the lane's slot its VGPR offset - and a lane that carries no total (three of every quad,
+// slots 9 .. 11 of an LFS_ACC_SYM row) holds RED_BUF_DEAD there, which the hardware's range check drops: 0x80000000 is beyond every accumulator this library accepts
+// (C * N < 2^25 rows on this path, raster_check) whether the check adds the SGPR offset or not, and the sum does not wrap. Against `if (atomic_lane) global_atomic`:
+// s_and_saveexec + s_cbranch_execz + s_lshl_b64 + s_add_u32 + s_addc_u32 + s_or exec -> nothing (tools/valu_rate.hip: an EXEC save / restore pair costs the SIMD as
+// much as four v_fma_f32, and scalar instructions share one issue port per CU). The deterministic passes (ACC 1 / 2) keep the branch.
+#ifndef LFS_RED_BUF_ATOMIC
+#define LFS_RED_BUF_ATOMIC 1
+#endif
+constexpr uint32_t RED_BUF_DEAD = 0x80000000u;
+static_assert(ACC_STRIDE * sizeof(float) == 64, "the buffer atomic's row offset is the record walker's e.x << 6");
+#if LFS_RED_BUF_ATOMIC
+struct RedBuf { __amdgpu_buffer_rsrc_t rsrc; uint32_t voff; };   // voff: 4 x slot on the lanes that add, RED_BUF_DEAD on the others
+LFS_DI RedBuf red_buf_make(float* acc, const uint64_t rows, const uint32_t lane, const bool atomic_lane) {
+    RedBuf b;
+    b.rsrc = __builtin_amdgcn_make_buffer_rsrc(acc, 0, uint32_t(rows * uint64_t(ACC_STRIDE * sizeof(float))), 0x00020000);   // raw buffer, 32-bit data format (the gfx9 word 3 of every untyped buffer)
+    b.voff = atomic_lane ? lane : RED_BUF_DEAD;   // lane = 4 x slot on the first lane of a quad
+    return b;
+}
+#endif
 template <int ACC = 0, bool SKIP_9_11 = false>
 LFS_DI void wave_sum16_atomic_quad(const v2f (&V)[8], float* __restrict__ dst /* wave-uniform */, const uint32_t lane, const uint32_t lds_base, const float4* __restrict__ rd /* this lane's read pointer */,
-                                   const bool atomic_lane, unsigned long long* __restrict__ det64 = nullptr) {
+                                   const bool atomic_lane, unsigned long long* __restrict__ det64 = nullptr
+#if LFS_RED_BUF_ATOMIC
+                                   , const RedBuf* __restrict__ rb = nullptr, const uint32_t row_bytes = 0u /* wave-uniform: 64 x the Gaussian's row */
+#endif
+                                   ) {
     float c[16];
     {
         uint32_t m0_saved; // (M0 saved and put back inside the block: see wave_sum16_atomic_lds)
         if (SKIP_9_11)
-        asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[base]\n\ts_nop 0\n\t"
+        asm volatile(LFS_RED_M0_PROLOGUE
                      "ds_write_addtid_b32 %[a0] offset:0\n\tds_write_addtid_b32 %[a1] offset:320\n\tds_write_addtid_b32 %[a2] offset:640\n\tds_write_addtid_b32 %[a3] offset:960\n\t"
                      "ds_write_addtid_b32 %[a4] offset:1280\n\tds_write_addtid_b32 %[a5] offset:1600\n\tds_write_addtid_b32 %[a6] offset:1920\n\tds_write_addtid_b32 %[a7] offset:2240\n\t"
                      "ds_write_addtid_b32 %[a8] offset:2560\n\t"
                      "ds_write_addtid_b32 %[a12] offset:3840\n\tds_write_addtid_b32 %[a13] offset:4160\n\tds_write_addtid_b32 %[a14] offset:4480\n\tds_write_addtid_b32 %[a15] offset:4800\n\t"
-                     "s_mov_b32 m0, %[sv]"
+                     LFS_RED_M0_EPILOGUE
                      : [sv] "=&s"(m0_saved)
                      : [a0] "v"(V[0].x), [a1] "v"(V[0].y), [a2] "v"(V[1].x), [a3] "v"(V[1].y), [a4] "v"(V[2].x), [a5] "v"(V[2].y), [a6] "v"(V[3].x), [a7] "v"(V[3].y),
                        [a8] "v"(V[4].x), [a12] "v"(V[6].x), [a13] "v"(V[6].y), [a14] "v"(V[7].x), [a15] "v"(V[7].y),
                        [base] "s"(lds_base) : "memory");
         else
-        asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[base]\n\ts_nop 0\n\t"
+        asm volatile(LFS_RED_M0_PROLOGUE
                      "ds_write_addtid_b32 %[a0] offset:0\n\tds_write_addtid_b32 %[a1] offset:320\n\tds_write_addtid_b32 %[a2] offset:640\n\tds_write_addtid_b32 %[a3] offset:960\n\t"
                      "ds_write_addtid_b32 %[a4] offset:1280\n\tds_write_addtid_b32 %[a5] offset:1600\n\tds_write_addtid_b32 %[a6] offset:1920\n\tds_write_addtid_b32 %[a7] offset:2240\n\t"
                      "ds_write_addtid_b32 %[a8] offset:2560\n\tds_write_addtid_b32 %[a9] offset:2880\n\tds_write_addtid_b32 %[a10] offset:3200\n\tds_write_addtid_b32 %[a11] offset:3520\n\t"
                      "ds_write_addtid_b32 %[a12] offset:3840\n\tds_write_addtid_b32 %[a13] offset:4160\n\tds_write_addtid_b32 %[a14] offset:4480\n\tds_write_addtid_b32 %[a15] offset:4800\n\t"
-                     "s_mov_b32 m0, %[sv]"
+                     LFS_RED_M0_EPILOGUE
                      : [sv] "=&s"(m0_saved)
                      : [a0] "v"(V[0].x), [a1] "v"(V[0].y), [a2] "v"(V[1].x), [a3] "v"(V[1].y), [a4] "v"(V[2].x), [a5] "v"(V[2].y), [a6] "v"(V[3].x), [a7] "v"(V[3].y),
                        [a8] "v"(V[4].x), [a9] "v"(V[4].y), [a10] "v"(V[5].x), [a11] "v"(V[5].y), [a12] "v"(V[6].x), [a13] "v"(V[6].y), [a14] "v"(V[7].x), [a15] "v"(V[7].y),
@@ -570,6 +608,12 @@ LFS_DI void wave_sum16_atomic_quad(const v2f (&V)[8], float* __restrict__ dst /*
     float t = p0.x + p0.y;
     t += dpp_mov<0xB1>(t);   // lane ^ 1
     t += dpp_mov<0x4E>(t);   // lane ^ 2: every lane of quad k holds the total of slot k
+#if LFS_RED_BUF_ATOMIC
+    if (ACC == 0) {
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(t, rb->rsrc, int(rb->voff), int(row_bytes), 0);   // buffer_atomic_add_f32 v, v, s[4], s offen - every lane issues, the dead ones are out of range
+        return;
+    }
+#endif
     asm volatile("" : "+v"(t)); // (no instruction: keeps the second add in front of the one-lane-in-four branch, where it folds into a v_add_f32_dpp; sunk into the branch it is mov + mov_dpp + add)
     if (atomic_lane) {
         const uint32_t slot = lane >> 2;

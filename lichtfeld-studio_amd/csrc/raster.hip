@@ -507,9 +507,15 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     float* const red_scratch = s_red + (threadIdx.x >> 6) * RED_BLOCK;
 #if LFS_RED_QUAD_ASM
     const uint32_t red_base = __builtin_amdgcn_readfirstlane(uint32_t(reinterpret_cast<uintptr_t>(red_scratch)));   // LDS byte address of the block (low half of the flat address)
+#if LFS_RED_M0_ONCE
+    asm volatile("s_mov_b32 m0, %0" ::"s"(red_base));   // the one write of M0 in this kernel (lfs_raster_common.cuh, LFS_RED_M0_ONCE)
+#endif
     const float4* const red_rd = reinterpret_cast<const float4*>(red_scratch + ((threadIdx.x & 63u) >> 2) * RED_QROW + 4u * (threadIdx.x & 3u));
     constexpr bool RED_SKIP = LFS_ACC_SYM && MODE == RAY_GLOBAL && CDIM == 3;   // (slots 9 .. 11 of the LFS_ACC_SYM row are empty)
     const bool red_atomic_lane = (threadIdx.x & 3u) == 0u && !(RED_SKIP && ((threadIdx.x & 63u) >> 2) >= 9u && ((threadIdx.x & 63u) >> 2) <= 11u);
+#if LFS_RED_BUF_ATOMIC
+    const RedBuf red_buf = red_buf_make(acc, uint64_t(C) * N, threadIdx.x & 63u, red_atomic_lane);   // (ACC == 0: the totals leave through a buffer atomic, lfs_raster_common.cuh)
+#endif
 #endif
 #endif
     const CellCtx cc = cell_ctx(n_tiles, total_tiles, tw, tile_size, blocks_per_tile, waves_per_block);
@@ -730,7 +736,12 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
             V[6] = v2f{v_op, fac * vc[0]};
             V[7] = v2f{vc[1], vc[2]} * fac;
 #if LFS_BWD_LDS_REDUCE && LFS_RED_QUAD_ASM
+#if LFS_RED_BUF_ATOMIC
+            wave_sum16_atomic_quad<ACC, RED_SKIP>(V, acc + size_t(uint32_t(e.x)) * ACC_STRIDE, lane, red_base, red_rd, red_atomic_lane, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr,
+                                                  &red_buf, uint32_t(e.x) << 6);
+#else
             wave_sum16_atomic_quad<ACC, RED_SKIP>(V, acc + size_t(uint32_t(e.x)) * ACC_STRIDE, lane, red_base, red_rd, red_atomic_lane, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
+#endif
 #elif LFS_BWD_LDS_REDUCE
             wave_sum16_atomic_lds<ACC>(V, acc + size_t(e.x) * ACC_STRIDE, lane, red_scratch, ACC == 2 ? mse.det64 + size_t(e.x) * ACC_STRIDE : nullptr);
 #else
@@ -1599,6 +1610,9 @@ static int raster_check(uint32_t N, uint32_t channels, const lfs_cameras* cams, 
     if (channels < 1 || channels > 4) return LFS_E_UNSUPPORTED; // Rasterization.cpp:65 asserts 3; depth modes need 1 and 4
     if (!raster_geom(cams, tile_size, g)) return LFS_E_UNSUPPORTED;
     if (uint64_t(cams->C) * N >= (1ull << 26)) return LFS_E_UNSUPPORTED; // 32-bit byte offsets of the record walker (4 GB of 64-B records)
+#if LFS_RED_BUF_ATOMIC
+    if (uint64_t(cams->C) * N >= (1ull << 25)) return LFS_E_UNSUPPORTED; // the backward's buffer atomic: accumulator rows below RED_BUF_DEAD = 2 GB (lfs_raster_common.cuh)
+#endif
     return LFS_OK;
 }
 

@@ -56,3 +56,29 @@ def test_streaming_kernels_register_budgets(table):
         assert table[k]["waves_per_simd"] == 8, (k, table[k])
     for k in ("sh_fwd_kernel<16, true>", "projection_ut_kernel<true, true, true>", "raster_finish_adam_kernel<true>"):
         assert table[k]["vgprs"] <= 104 and table[k]["waves_per_simd"] >= 4, (k, table[k])
+
+
+def test_backward_rasterizer_writes_m0_exactly_once():
+    """LFS_RED_M0_ONCE (lfs_raster_common.cuh): the add-TID stores of the LDS reduction take their base from M0, which raster_bwd_kernel's prologue sets once. The
+    compiler is not told that the inline asm reads M0, so the statement "nothing else in the kernel touches it" is held here, against the disassembly of every
+    shipped instantiation: one instruction mentions m0 (the prologue's s_mov_b32), and none of the forms that use it implicitly (LDS-direct loads, s_movrel /
+    v_movrel, s_sendmsg with a payload, GDS) occurs."""
+    if not os.path.exists(LIB) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("library not built / no llvm-objdump")
+    spec = importlib.util.spec_from_file_location("isa", os.path.join(ROOT, "tools", "isa.py"))
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    isa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(isa)
+    kernels = {k: v for k, v in isa.disassemble(LIB).items() if k.startswith("raster_bwd_kernel<")}
+    assert len(kernels) >= 16, sorted(kernels)
+    for k, lines in kernels.items():
+        ops = [l.split("//")[0].strip() for l in lines]
+        m0 = [o for o in ops if "m0" in o.replace(",", " ").split()]
+        addtid = [o for o in ops if o.startswith("ds_write_addtid_b32")]
+        if not addtid:      # (a build with the asm stores switched off has nothing to hold)
+            continue
+        assert len(m0) == 1 and m0[0].startswith("s_mov_b32 m0,"), (k, m0)
+        assert ops.index(m0[0]) < ops.index(addtid[0]), k
+        implicit = [o for o in ops if o.split()[0].startswith(("s_movrel", "v_movrel", "s_sendmsg", "ds_gws", "ds_ordered")) or " lds" in o or " gds" in o]
+        assert not implicit, (k, implicit[:4])
