@@ -28,6 +28,14 @@ constexpr int ACC_STRIDE = 16; // LFS_ACC_SYM (global shutter): B'' (6) | a'' (3
 #ifndef LFS_REC_ROT
 #define LFS_REC_ROT 1
 #endif
+// LFS_REC_PKQ (with LFS_REC_ROT, global shutter): rows 0 / 1 of the record's matrix interleaved by column, q.x and q.y as ONE chain of v_pk_mul_f32 + 2 v_pk_fma_f32 with
+// the column pairs as SGPR-pair operands - the same products and roundings per component (bit-identical images and gradients), 3 instructions instead of 6.
+#ifndef LFS_REC_PKQ
+#define LFS_REC_PKQ 0
+#endif
+#if LFS_REC_PKQ && !LFS_REC_ROT
+#error "LFS_REC_PKQ is a layout of the rotated records"
+#endif
 #if LFS_REC_ROT && !LFS_REC_LOG2
 #error "LFS_REC_ROT is written for the LFS_REC_LOG2 records"
 #endif

@@ -72,8 +72,16 @@ LFS_DI void pack_gaussian(const CamDev& cam, const f3 mu, const float4 q, const 
         g = {G * G, 0.f, G};
     }
 #endif
+#if LFS_REC_PKQ
+    if (UNIFORM_ORIGIN) { // rows 0 and 1 of U M' interleaved by column: (q.x, q.y) is then a chain of three packed operations on aligned SGPR pairs (raster.hip, ray_eval)
+        rec.r0 = make_float4(Mr.m[0][0], Mr.m[1][0], Mr.m[0][1], Mr.m[1][1]);
+        rec.r1 = make_float4(Mr.m[0][2], Mr.m[1][2], g.x, g.y);
+    } else
+#endif
+    {
     rec.r0 = make_float4(Mr.m[0][0], Mr.m[0][1], Mr.m[0][2], g.x);
     rec.r1 = make_float4(Mr.m[1][0], Mr.m[1][1], Mr.m[1][2], g.y);
+    }
     rec.r2 = make_float4(Mr.m[2][0], Mr.m[2][1], Mr.m[2][2], g.z);
     rec.r3 = make_float4(opac_field, c0, c1, c2);
     ConicRec k = conic_never();

@@ -271,14 +271,23 @@ LFS_DI void ray_eval(const GaussRec& rec, const f3& ro, const f3& d, RayEval& e)
     e.om = {0.f, 0.f, 0.f};
 #if LFS_REC_ROT
     if (MODE == RAY_GLOBAL) { // the record lives in the frame in which g = (0, 0, G) (lfs_raster_common.cuh, LFS_REC_ROT): |w|^2 = G^2 m / l, no difference of large numbers anywhere
+#if LFS_REC_PKQ
+        v2f qxy = v2f{rec.r0.x, rec.r0.y} * v2f{d.x, d.x};
+        qxy = __builtin_elementwise_fma(v2f{rec.r0.z, rec.r0.w}, v2f{d.y, d.y}, qxy);
+        qxy = __builtin_elementwise_fma(v2f{rec.r1.x, rec.r1.y}, v2f{d.z, d.z}, qxy);
+        const f3 q{qxy.x, qxy.y, fma3(rec.r2.x, d.x, rec.r2.y, d.y, rec.r2.z, d.z)};
+        const float rec_k = rec.r1.z;
+#else
         const f3 q{fma3(rec.r0.x, d.x, rec.r0.y, d.y, rec.r0.z, d.z),
                    fma3(rec.r1.x, d.x, rec.r1.y, d.y, rec.r1.z, d.z),
                    fma3(rec.r2.x, d.x, rec.r2.y, d.y, rec.r2.z, d.z)};
+        const float rec_k = rec.r0.w;
+#endif
         const float m = __builtin_fmaf(q.y, q.y, q.x * q.x);
         const float l = __builtin_fmaf(q.z, q.z, m);
         const float rl = fast_rcp(l);      // l == 0 (inactive lane: d = 0; degenerate record): inf, and m = q.z = 0 - the two products below are v_mul_legacy_f32 (0 * inf = 0): u = 0, t = 0, w = 0
         const float u = mul_zero(m, rl);   // sin^2 of the angle between the ray and the direction to the centre
-        e.vis = __builtin_amdgcn_exp2f(__builtin_fmaf(-rec.r0.w, u, rec.r3.x));
+        e.vis = __builtin_amdgcn_exp2f(__builtin_fmaf(-rec_k, u, rec.r3.x));
         e.t = rec.r2.w * mul_zero(q.z, rl);
 #ifndef LFS_EMULATE
         asm volatile("" ::"s"(rec.r1.w), "s"(rec.r2.w)); // (no instruction: the unused fields of the record - r1.w, and G in the forward - stay "used", so the record still arrives as ONE s_load_dwordx16; without it the compiler splits the load into two to four)
