@@ -72,6 +72,8 @@ CASES = {
     "tile_masks_ts32": dict(masks=True, ts=32, W=72, H=40),
     "dense_early_termination": dict(spread=0.4, smin=0.05, smax=0.3),
     "rolling_shutter": dict(shutter=3),
+    "global_shutter": dict(shutter=4),              # (the cases above run the ROLLING-shutter kernels on one pose, shutter 0; these two the global-shutter kernels: the rotated records, the symmetric accumulators)
+    "global_shutter_dense": dict(shutter=4, spread=0.4, smin=0.05, smax=0.3),
 }
 
 
@@ -87,7 +89,7 @@ def test_emulated_kernels_agree_with_the_oracle_and_with_each_other(emu, case):
     N, W, H, ts, Cn, cdim = kw["N"], kw["W"], kw["H"], kw["ts"], kw["C"], kw["cdim"]
     means, quats, scales, opac = make_gaussians(rng, N, spread=kw["spread"], smin=kw["smin"], smax=kw["smax"])
     vm0 = np.stack([small_rotation_viewmat(rng, 0.05 + 0.1 * c, 0.1) for c in range(Cn)])
-    vm1 = small_rotation_viewmat(rng, 0.12, 0.2)[None] if kw["shutter"] else None
+    vm1 = small_rotation_viewmat(rng, 0.12, 0.2)[None] if kw["shutter"] in (1, 2, 3) else None
     K = pinhole_K(0.8 * W, W, H, Cn)
     colors = rng.random((Cn, N, cdim)).astype(np.float32)
     opacs = np.tile(opac[None], (Cn, 1)).astype(np.float32)
