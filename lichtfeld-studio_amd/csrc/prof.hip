@@ -24,13 +24,23 @@ hipEvent_t get_event() {
 
 int prof_begin(const char* name, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_on) return -1;
+    if (!g_on || !name || !*name) return -1;   // ("" = a scope whose one kernel is timed through prof_kernel_events)
     if (!g_filter.empty() && g_filter != name) return -1;
     Pending p{name, get_event(), get_event(), false};
     if (!p.e0 || !p.e1) return -1;
     (void)hipEventRecord(p.e0, s);
     g_pending.push_back(p);
     return int(g_pending.size()) - 1;
+}
+bool prof_kernel_events(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_on) return false;
+    if (!g_filter.empty() && g_filter != name) return false;
+    Pending p{name, get_event(), get_event(), true};   // (closed: the launch itself records both)
+    if (!p.e0 || !p.e1) return false;
+    g_pending.push_back(p);
+    *start = p.e0; *stop = p.e1;
+    return true;
 }
 void prof_end(int token, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);

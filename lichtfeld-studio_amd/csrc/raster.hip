@@ -43,6 +43,12 @@
 // 1.17x the VALU instructions), SH colours + record packing in one kernel (profiles/r02/fuse_front_ab.txt: no gain).
 #include "lfs_camera.cuh"
 #include "lfs_prof.h"
+#ifndef LFS_EMULATE
+#include <hip/hip_ext.h>
+#endif
+#ifndef LFS_PROF_EXT_LAUNCH
+#define LFS_PROF_EXT_LAUNCH 1   // 0: two hipEventRecord around the backward's launch (rounds 1 - 6)
+#endif
 #include "lfs_raster_common.cuh"
 #include "lfs_cull_conic.cuh"
 #include "lfs_raster_pack.cuh"
@@ -1762,10 +1768,24 @@ static int raster_bwd_impl(
     // the workspace still holds what the forward call with the same inputs left there
     if (!prepared) raster_prepare(w, g, N, channels, means, quats, scales, colors, opacities, masks, cams, tile_size, tile_offsets, flatten_ids, ic, s);
     if (n_sized > 0) {
-        lfs::ProfScope prof("raster_bwd", s);
+        // One launch (every mode but the deterministic one): timed, when asked for, through the dispatch packet's own signal (lfs_prof.h, prof_kernel_events) - no
+        // event-record packets around the dominant kernel inside bench.py's timed region. The deterministic mode's two passes + resolve keep the event scope.
+        hipEvent_t pe0 = nullptr, pe1 = nullptr;
+#ifndef LFS_EMULATE
+        const bool ext_timed = !det && LFS_PROF_EXT_LAUNCH && lfs::prof_kernel_events("raster_bwd", &pe0, &pe1);
+#else
+        const bool ext_timed = false;
+#endif
+        lfs::ProfScope prof(ext_timed ? "" : "raster_bwd", s);
         const RasterGeom gw = wave_geom(cams, g);
+#ifndef LFS_EMULATE
+#define LFS_BWD_LAUNCH(KERNEL, ...) do { if (ext_timed) hipExtLaunchKernelGGL(KERNEL, dim3(gw.grid), dim3(gw.threads), 0, s, pe0, pe1, 0, __VA_ARGS__); \
+                                         else hipLaunchKernelGGL(KERNEL, dim3(gw.grid), dim3(gw.threads), 0, s, __VA_ARGS__); } while (0)
+#else
+#define LFS_BWD_LAUNCH(KERNEL, ...) hipLaunchKernelGGL(KERNEL, dim3(gw.grid), dim3(gw.threads), 0, s, __VA_ARGS__)
+#endif
 #define LFS_BWD_K(CD, MODE, ...)                                                                                 \
-    hipLaunchKernelGGL((raster_bwd_kernel<CD, MODE, ##__VA_ARGS__>), dim3(gw.grid), dim3(gw.threads), 0, s, C, N, g.tw, g.th, \
+    LFS_BWD_LAUNCH((raster_bwd_kernel<CD, MODE, ##__VA_ARGS__>), C, N, g.tw, g.th, \
                        cams->image_width, cams->image_height, tile_size, gw.blocks_per_tile, gw.waves_per_block, \
                        w.cams, w.recs, colors, backgrounds, masks, tile_offsets, w.cell_count, w.cell_list, ic.arg(), \
                        render_alphas, last_ids, v_render_colors, v_render_alphas, w.acc, v_colors, mse_dev)
@@ -1786,6 +1806,7 @@ static int raster_bwd_impl(
         case 8: LFS_BWD_K(4, 0); break; default: LFS_BWD_K(4, 1); break;
         }
 #undef LFS_BWD_K
+#undef LFS_BWD_LAUNCH
     }
     if (!finish) return (int)hipGetLastError();
     const dim3 fg((N + 255) / 256);
