@@ -171,6 +171,24 @@ def test_raster_unsupported_channels_raises(lfs):
                                                     torch.zeros((1, 2, 2), dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev))
 
 
+def test_raster_refuses_more_rows_than_the_backward_can_address(lfs):
+    """cameras x Gaussians >= 2^25: the backward's buffer atomic addresses 2 GB of accumulator rows and relies on 0x80000000 being out of range (lfs_raster_common.cuh,
+    LFS_RED_BUF_ATOMIC) - the entry points refuse such a call up front (raster_check: LFS_E_UNSUPPORTED -> RuntimeError) instead of running it; one row fewer is accepted."""
+    from lichtfeld_studio_amd import ops
+    dev = "cuda:0"
+    z = lambda *s: torch.zeros(*s, device=dev)
+    def call(N):
+        return ops.rasterize_to_pixels_from_world_3dgs_fwd(z(N, 3), z(N, 4), z(N, 3), z(1, N, 3), z(1, N), None, None, 32, 32, 16,
+                                                           torch.eye(4, device=dev)[None].contiguous(), None, torch.eye(3, device=dev)[None].contiguous(),
+                                                           lfs.CameraModelType.PINHOLE, None, lfs.ShutterType.GLOBAL, None, None, None,
+                                                           torch.zeros((1, 2, 2), dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev))
+    with pytest.raises(RuntimeError):
+        call(1 << 25)
+    rc, ra, li = call((1 << 25) - 1)   # (no intersections: the image is empty, the call is valid)
+    assert float(ra.abs().max()) == 0.0
+    torch.cuda.empty_cache()
+
+
 def test_raster_bwd_is_linear_in_output_gradients_full_size(lfs):
     """BASELINE config-2 sized property test (no oracle needed): the backward is linear in
     (v_render_colors, v_render_alphas), fwd is deterministic, alpha in [0, 1], gradients finite."""
