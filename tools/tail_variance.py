@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Is the spread of the HBM-bound tail kernel (0.285 - 0.338 ms between runs of bench.py on one box, profiles/r06/lease36c_...) a property of the PROCESS - where its
+"""(Superseded reading: profiles/r06/tail_kernel_levels.txt item 4 - the level follows the clock, not the allocation.) Is the spread of the HBM-bound tail kernel (0.285 - 0.338 ms between runs of bench.py on one box, profiles/r06/lease36c_...) a property of the PROCESS - where its
 allocations landed - or of the moment? One process, the headline step of SYN-B, W windows of S steps each with the tail kernel and raster_bwd timed (events), then the
 whole thing again in a fresh trainer of the same process (new allocations). GPU.   python tools/tail_variance.py [windows] [steps]"""
 import os
@@ -21,7 +21,7 @@ def main():
     dev = torch.device("cuda:0")
     scene = scenes.syn_b()
     target = [scenes.target_image(scene.height, scene.width, seed=43).to(dev)]
-    for trainer_no in range(3):
+    for trainer_no in range(int(os.environ.get("LFS_TAILVAR_TRAINERS", "3"))):
         tr = GutTrainer(scene, dev, iterations=7000, world=1, rank=0, views_per_rank=1)
         tr.iteration = 3000
         for _ in range(10):
